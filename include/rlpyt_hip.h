@@ -1,0 +1,209 @@
+/*
+ * rlpyt_hip.h -- C ABI of librlpyt_hip.so: the MI355X (gfx950 / CDNA4) hot path of
+ * astooke/rlpyt (rollout -> advantage/return -> minibatch loss; prioritized replay).
+ *
+ * The reference is pure Python: it has no FFI.  Each entry point below replaces the
+ * body of one reference routine (cited as file:line under /root/reference); the
+ * reference-side binding a maintainer would add is the ctypes stub shown in
+ * INTEGRATION.md (rlpyt_amd/_lib.py is that stub, in tree).
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer (HBM) unless the name ends in
+ *     "_host"; arrays are dense row-major with the leading dims stated per call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call is
+ *     asynchronous with respect to the host unless stated otherwise;
+ *   - no torch types, no allocation inside a call except the opaque handles
+ *     (`rlpyt_sumtree`) which own their HBM;
+ *   - return value: 0 = ok, <0 = RLPYT_E*; `rlpyt_hip_last_error()` gives the text
+ *     (thread-local);
+ *   - `done`/`valid` masks: `done` is uint8 0/1 (torch.bool storage), `valid` is f32 0/1
+ *     exactly as the reference materialises them.
+ */
+#ifndef RLPYT_HIP_H
+#define RLPYT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLPYT_OK 0
+#define RLPYT_EINVAL (-1) /* bad argument (null pointer, negative size, unsupported option) */
+#define RLPYT_ESHAPE (-2) /* shape / alignment not supported by the requested variant */
+#define RLPYT_EHIP (-3)   /* a HIP runtime call failed; see rlpyt_hip_last_error() */
+#define RLPYT_ESTATE (-4) /* handle used out of protocol (e.g. update before sample) */
+
+typedef void* rlpyt_stream_t; /* hipStream_t */
+
+const char* rlpyt_hip_last_error(void);
+/* ABI version of this header; bumped when a signature changes. */
+int rlpyt_hip_abi_version(void);
+/* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
+int rlpyt_hip_device_info(char* name, int cap);
+
+/* ------------------------------------------------------------------------------------
+ * Return / advantage scans over [T, N] trajectories (N = B * any trailing dims).
+ * Coalesced along N, sequential along T.
+ * ---------------------------------------------------------------------------------- */
+
+/* Scan variants. */
+#define RLPYT_SCAN_EXACT 0     /* one lane per column, reference association, no FMA
+                                  contraction: bit-identical to the reference fp32 path */
+#define RLPYT_SCAN_SEGMENTED 1 /* time axis split in LDS-staged segments, affine-map
+                                  composition across segments (wave shuffles): lower
+                                  latency at small N, fp32 tolerance (re-associated) */
+
+/* generalized_advantage_estimation -- rlpyt/algos/utils.py:24-40.
+ *   A[T-1] = r + g*bv*nd - V ; A[t] = (r + g*V[t+1]*nd - V) + (g*l)*nd*A[t+1] ; R = A + V
+ * `valid` (nullable) additionally receives valid_from_done(done) (utils.py:104-112),
+ * fusing rlpyt/algos/pg/base.py:57-63 into one launch. */
+int rlpyt_gae_f32(const float* reward, const float* value, const uint8_t* done,
+                  const float* bootstrap /*[N]*/, float* advantage, float* return_,
+                  float* valid /*nullable [T,N]*/, int T, int64_t N, double discount,
+                  double gae_lambda, int variant, rlpyt_stream_t stream);
+
+/* discount_return -- rlpyt/algos/utils.py:8-21.  R[t] = r + R[t+1]*g*nd.
+ * If `value` and `advantage` are non-null also writes advantage = R - V
+ * (rlpyt/algos/pg/base.py:53-55).  `valid` nullable as above. */
+int rlpyt_discount_return_f32(const float* reward, const uint8_t* done,
+                              const float* bootstrap /*[N]*/, float* return_,
+                              const float* value /*nullable*/, float* advantage /*nullable*/,
+                              float* valid /*nullable*/, int T, int64_t N, double discount,
+                              int variant, rlpyt_stream_t stream);
+
+/* valid_from_done -- rlpyt/algos/utils.py:104-112. valid[0]=1, valid[t]=1-min(1,sum done[:t]) */
+int rlpyt_valid_from_done(const uint8_t* done, float* valid, int T, int64_t N,
+                          rlpyt_stream_t stream);
+
+/* discount_return_n_step -- rlpyt/algos/utils.py:67-101.
+ * in: reward f32 [T_in,N], done u8 [T_in,N]; out: return_ f32 [T_out,N], done_n u8 [T_out,N]
+ * with T_out = do_truncated ? T_in : T_in-(n_step-1). */
+int rlpyt_nstep_return_f32(const float* reward, const uint8_t* done, float* return_,
+                           uint8_t* done_n, int T_in, int64_t N, int n_step, double discount,
+                           int do_truncated, rlpyt_stream_t stream);
+
+/* Advantage normalisation -- rlpyt/algos/pg/base.py:65-73:
+ *   A <- (A - mean(A[valid>0])) / max(std_unbiased(A[valid>0]), eps), in place.
+ * `workspace`: >= rlpyt_adv_normalize_workspace_bytes(n) bytes of device scratch.
+ * `stats_out` (nullable, device, 3 floats): mean, std, count. */
+int64_t rlpyt_adv_normalize_workspace_bytes(int64_t n);
+int rlpyt_adv_normalize_f32(float* advantage, const float* valid /*nullable*/, int64_t n,
+                            float eps, void* workspace, float* stats_out,
+                            rlpyt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Policy-gradient losses, forward + backward in one pass over the minibatch.
+ * out_scalars (device, 5 floats): loss, pi_loss, value_loss, entropy, perplexity.
+ * grad_prob [M,A], grad_value [M] receive dLoss/dprob_new and dLoss/dvalue.
+ * `workspace`: >= rlpyt_pg_loss_workspace_bytes(M) bytes of device scratch.
+ * ---------------------------------------------------------------------------------- */
+int64_t rlpyt_pg_loss_workspace_bytes(int64_t M);
+
+/* PPO.loss -- rlpyt/algos/pg/ppo.py:117-154 with Categorical
+ * (rlpyt/distributions/categorical.py:32-43, EPS=1e-8) and valid_mean
+ * (rlpyt/utils/tensor.py:39-46). */
+int rlpyt_ppo_loss_fwd_bwd_f32(const float* prob_new /*[M,A]*/, const float* value /*[M]*/,
+                               const float* prob_old /*[M,A]*/, const int64_t* action /*[M]*/,
+                               const float* advantage, const float* return_,
+                               const float* valid /*nullable [M]*/, int64_t M, int A,
+                               float ratio_clip, float value_loss_coeff,
+                               float entropy_loss_coeff, float* out_scalars,
+                               float* grad_prob, float* grad_value, void* workspace,
+                               rlpyt_stream_t stream);
+
+/* A2C.loss -- rlpyt/algos/pg/a2c.py:63-103: pi_loss = -valid_mean(log(p[a]+eps) * A). */
+int rlpyt_a2c_loss_fwd_bwd_f32(const float* prob /*[M,A]*/, const float* value /*[M]*/,
+                               const int64_t* action, const float* advantage,
+                               const float* return_, const float* valid /*nullable*/,
+                               int64_t M, int A, float value_loss_coeff,
+                               float entropy_loss_coeff, float* out_scalars, float* grad_prob,
+                               float* grad_value, void* workspace, rlpyt_stream_t stream);
+
+/* DQN.loss -- rlpyt/algos/dqn/dqn.py:231-263 (Huber TD with IS weights).
+ *   q = qs[i,a_i]; tq = double ? target_qs[i, argmax next_qs[i]] : max target_qs[i]
+ *   y = return_ + (1-done_n) * disc_n * tq ; delta = y - q
+ *   losses = huber(delta, delta_clip) (delta_clip<=0: 0.5*delta^2) * is_weights ; loss = mean
+ * out_scalars (2 floats): loss, mean |delta|.  td_abs [M] = clamp(|delta|, 0, delta_clip).
+ * grad_qs [M,A] = dLoss/dqs (zero except the taken action). */
+int rlpyt_dqn_loss_fwd_bwd_f32(const float* qs /*[M,A]*/, const float* target_qs /*[M,A]*/,
+                               const float* next_qs /*nullable [M,A]: double-DQN*/,
+                               const int64_t* action, const float* return_,
+                               const uint8_t* done_n, const float* is_weights /*nullable*/,
+                               int64_t M, int A, float disc_n, float delta_clip,
+                               float* out_scalars, float* td_abs, float* grad_qs,
+                               void* workspace, rlpyt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Gathers.
+ * ---------------------------------------------------------------------------------- */
+
+/* Minibatch row gather out of a [T,B,E] batch: dst[m,:] = src[idx%T, idx/T, :] with
+ * idx = flat_idx[m] -- the index map of rlpyt/algos/pg/ppo.py:94-95 applied by
+ * namedarraytuple slicing (ppo.py:99-100).  elem_bytes = bytes per [t,b] row. */
+int rlpyt_gather_tb(const void* src, const int64_t* flat_idx, void* dst, int T, int64_t B,
+                    int64_t elem_bytes, int64_t M, rlpyt_stream_t stream);
+
+/* Generic 2-index gather: dst[m,:] = src[t_idx[m], b_idx[m], :] (negative t wraps once,
+ * as numpy negative indexing does in rlpyt/replays/non_sequence/n_step.py:27-28). */
+int rlpyt_gather_rows(const void* src, const int64_t* t_idx, const int64_t* b_idx, void* dst,
+                      int T, int64_t B, int64_t elem_bytes, int64_t M, rlpyt_stream_t stream);
+
+/* NStepFrameBuffer.extract_observation -- rlpyt/replays/non_sequence/frame.py:14-30.
+ * frames u8 [T+C-1, B, H*W]; done u8 [T,B]; obs[i,c,:] = frames[t_i+c, b_i, :], then for
+ * f=1..C-1: if done[(t_i-f) mod T, b_i]: obs[i, :C-f] = 0. */
+int rlpyt_frames_gather(const uint8_t* frames, const uint8_t* done, const int64_t* t_idx,
+                        const int64_t* b_idx, uint8_t* obs /*[n,C,HW]*/, int64_t n, int T,
+                        int64_t B, int C, int64_t HW, rlpyt_stream_t stream);
+
+/* SequenceNStepFrameBuffer.extract_observation -- rlpyt/replays/sequence/frame.py:17-50.
+ * obs [seq_T, n, C, HW]; wrap at T (head rows duplicated), post-reset blanking. */
+int rlpyt_frames_gather_seq(const uint8_t* frames, const uint8_t* done, const int64_t* t_idx,
+                            const int64_t* b_idx, uint8_t* obs, int64_t n, int seq_T, int T,
+                            int64_t B, int C, int64_t HW, rlpyt_stream_t stream);
+
+/* extract_sequences -- rlpyt/utils/misc.py:38-56: dst[s,i,:] = src[(t_i+s) mod T, b_i, :]. */
+int rlpyt_gather_sequences(const void* src, const int64_t* t_idx, const int64_t* b_idx,
+                           void* dst, int64_t n, int seq_T, int T, int64_t B,
+                           int64_t elem_bytes, rlpyt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Sum tree (f64, HBM resident) -- rlpyt/replays/sum_tree.py:8-222.
+ * Cursor / wrap-guard logic (sum_tree.py:60-99) runs on the host inside advance();
+ * the tree itself never leaves HBM.
+ * ---------------------------------------------------------------------------------- */
+typedef struct rlpyt_sumtree rlpyt_sumtree;
+
+int rlpyt_sumtree_create(rlpyt_sumtree** out, int T, int B, int off_backward, int off_forward,
+                         double default_value, int enable_input_priorities,
+                         int input_priority_shift);
+void rlpyt_sumtree_destroy(rlpyt_sumtree* t);
+int rlpyt_sumtree_reset(rlpyt_sumtree* t, rlpyt_stream_t stream);
+/* geometry queries (host): */
+int rlpyt_sumtree_levels(const rlpyt_sumtree* t);
+int64_t rlpyt_sumtree_low_idx(const rlpyt_sumtree* t);
+int rlpyt_sumtree_cursor(const rlpyt_sumtree* t);
+/* device pointer to the f64 tree (2^levels - 1 nodes), for inspection / parity tests. */
+double* rlpyt_sumtree_data(rlpyt_sumtree* t);
+/* async device-to-device copy of the whole tree into dst (2^levels - 1 doubles). */
+int rlpyt_sumtree_copy_tree(rlpyt_sumtree* t, double* dst, rlpyt_stream_t stream);
+
+/* advance -- sum_tree.py:60-99,155-204.  `priorities` (device f64, nullable): kind
+ * 0 = none (default value), 1 = scalar [1], 2 = [B], 3 = [T_new,B]. */
+int rlpyt_sumtree_advance(rlpyt_sumtree* t, int T_new, const double* priorities, int kind,
+                          rlpyt_stream_t stream);
+/* sample/find -- sum_tree.py:101-128,211-222.  uniforms: device f64 [n] in [0,1).
+ * Outputs (device): T_idxs, B_idxs i64 [n]; priorities f64 [n] (nullable);
+ * The sampled tree indices are remembered inside the handle (device) for update(). */
+int rlpyt_sumtree_sample(rlpyt_sumtree* t, const double* uniforms, int n, int64_t* T_idxs,
+                         int64_t* B_idxs, double* priorities, rlpyt_stream_t stream);
+/* update_batch_priorities -- sum_tree.py:130-153,206-209.  new_priorities device f64 [n]
+ * (already ** alpha); duplicates among the last sampled indices are removed keeping the
+ * FIRST occurrence in batch order (np.unique(return_index=True) semantics). */
+int rlpyt_sumtree_update(rlpyt_sumtree* t, const double* new_priorities, int n,
+                         rlpyt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLPYT_HIP_H */

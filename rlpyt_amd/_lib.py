@@ -1,0 +1,131 @@
+"""ctypes binding of ``librlpyt_hip.so`` (C ABI declared in ``include/rlpyt_hip.h``).
+
+This is the stub a maintainer of the reference would add: the
+reference is pure Python (no FFI of its own), so each entry point here replaces the body
+of one reference routine.  There is NO CPU fallback: if the shared library is missing the
+import fails loudly, and every wrapper raises on CPU-only torch builds when asked to run.
+
+``torch`` is imported first on purpose: it loads its bundled ``libamdhip64.so`` (soname
+``libamdhip64.so.7``) so that the kernels here share torch's HIP runtime, streams and
+device allocations instead of instantiating a second runtime.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p)
+
+import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librlpyt_hip.so")
+ABI_VERSION = 1
+
+
+class HipExtensionMissing(ImportError):
+    pass
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found: the MI355X HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+            "rlpyt_amd/csrc`). There is deliberately no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    return lib
+
+
+lib = _load()
+
+_p = c_void_p
+_SIGNATURES = {
+    # name: (restype, [argtypes])
+    "rlpyt_hip_last_error": (c_char_p, []),
+    "rlpyt_hip_abi_version": (c_int, []),
+    "rlpyt_hip_device_info": (c_int, [c_char_p, c_int]),
+    "rlpyt_gae_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int, c_int64, c_double, c_double,
+                              c_int, _p]),
+    "rlpyt_discount_return_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int, c_int64, c_double,
+                                          c_int, _p]),
+    "rlpyt_valid_from_done": (c_int, [_p, _p, c_int, c_int64, _p]),
+    "rlpyt_nstep_return_f32": (c_int, [_p, _p, _p, _p, c_int, c_int64, c_int, c_double, c_int,
+                                       _p]),
+    "rlpyt_adv_normalize_workspace_bytes": (c_int64, [c_int64]),
+    "rlpyt_adv_normalize_f32": (c_int, [_p, _p, c_int64, c_float, _p, _p, _p]),
+    "rlpyt_pg_loss_workspace_bytes": (c_int64, [c_int64]),
+    "rlpyt_ppo_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,
+                                           c_float, c_float, _p, _p, _p, _p, _p]),
+    "rlpyt_a2c_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,
+                                           c_float, _p, _p, _p, _p, _p]),
+    "rlpyt_dqn_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,
+                                           c_float, _p, _p, _p, _p, _p]),
+    "rlpyt_gather_tb": (c_int, [_p, _p, _p, c_int, c_int64, c_int64, c_int64, _p]),
+    "rlpyt_gather_rows": (c_int, [_p, _p, _p, _p, c_int, c_int64, c_int64, c_int64, _p]),
+    "rlpyt_frames_gather": (c_int, [_p, _p, _p, _p, _p, c_int64, c_int, c_int64, c_int, c_int64,
+                                    _p]),
+    "rlpyt_frames_gather_seq": (c_int, [_p, _p, _p, _p, _p, c_int64, c_int, c_int, c_int64,
+                                        c_int, c_int64, _p]),
+    "rlpyt_gather_sequences": (c_int, [_p, _p, _p, _p, c_int64, c_int, c_int, c_int64, c_int64,
+                                       _p]),
+    "rlpyt_sumtree_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_double,
+                                     c_int, c_int]),
+    "rlpyt_sumtree_destroy": (None, [_p]),
+    "rlpyt_sumtree_reset": (c_int, [_p, _p]),
+    "rlpyt_sumtree_levels": (c_int, [_p]),
+    "rlpyt_sumtree_low_idx": (c_int64, [_p]),
+    "rlpyt_sumtree_cursor": (c_int, [_p]),
+    "rlpyt_sumtree_data": (c_void_p, [_p]),
+    "rlpyt_sumtree_copy_tree": (c_int, [_p, _p, _p]),
+    "rlpyt_sumtree_advance": (c_int, [_p, c_int, _p, c_int, _p]),
+    "rlpyt_sumtree_sample": (c_int, [_p, _p, c_int, _p, _p, _p, _p]),
+    "rlpyt_sumtree_update": (c_int, [_p, _p, c_int, _p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+for _name, (_res, _args) in _SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header/library mismatch: fail loudly.
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.rlpyt_hip_abi_version() != ABI_VERSION:
+    raise HipExtensionMissing(
+        f"{LIB_PATH} has ABI {lib.rlpyt_hip_abi_version()}, binding expects {ABI_VERSION}: rebuild.")
+
+
+def last_error():
+    return lib.rlpyt_hip_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise HipError(f"{what or 'librlpyt_hip'} failed (rc={rc}): {last_error()}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise HipError("rlpyt_amd hot path needs an MI355X (torch.cuda.is_available() is "
+                       "False); there is no CPU fallback.")
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda, "rlpyt_amd kernels take device tensors"
+    assert t.is_contiguous(), "rlpyt_amd kernels take contiguous tensors"
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_info():
+    buf = ctypes.create_string_buffer(128)
+    n = lib.rlpyt_hip_device_info(buf, 128)
+    check(min(n, 0), "rlpyt_hip_device_info")
+    return buf.value.decode(), n

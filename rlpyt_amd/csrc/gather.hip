@@ -1,0 +1,275 @@
+// Row / frame gathers for gfx950: minibatch extraction out of [T,B,...] rollout batches
+// and observation re-assembly out of the unique-frame replay ring, all HBM -> HBM.
+//
+// Reference routines replaced (Python fancy indexing / list comprehensions on the host):
+//   rlpyt/algos/pg/ppo.py:94-100            minibatch slicing  idx -> (idx % T, idx // T)
+//   rlpyt/replays/non_sequence/n_step.py:16-43   extract_batch
+//   rlpyt/replays/non_sequence/frame.py:14-30    4-frame stack + post-reset blanking
+//   rlpyt/replays/sequence/frame.py:17-50        sequence frame stack (wrap + blanking)
+//   rlpyt/utils/misc.py:38-56                    extract_sequences
+//
+// All kernels are pure byte movers (HBM-bound): 16 B per lane where alignment allows,
+// one workgroup per destination row for wide rows so a row is one contiguous burst.
+#include "common.h"
+
+namespace rlpyt {
+namespace {
+
+struct alignas(16) B16 { uint32_t x, y, z, w; };
+
+// ---- index maps -------------------------------------------------------------------------
+struct MapTB {            // ppo.py:94-95
+  const int64_t* flat; int T; int64_t B;
+  __device__ __forceinline__ int64_t row(int64_t m) const {
+    const int64_t idx = flat[m];
+    return (idx % T) * B + (idx / T);
+  }
+};
+struct MapPair {          // numpy [t_idx, b_idx]; negative t wraps once
+  const int64_t* t; const int64_t* b; int T; int64_t B;
+  __device__ __forceinline__ int64_t row(int64_t m) const {
+    int64_t tt = t[m];
+    if (tt < 0) tt += T;
+    return tt * B + b[m];
+  }
+};
+
+// One workgroup per destination row (gridDim.y strides rows), VT = bytes per lane access.
+template <typename V, typename Map>
+__global__ __launch_bounds__(256) void gather_wide_kernel(const V* __restrict__ src,
+                                                          V* __restrict__ dst, Map map,
+                                                          int64_t M, int64_t nvec) {
+  for (int64_t m = blockIdx.y; m < M; m += gridDim.y) {
+    const V* __restrict__ s = src + map.row(m) * nvec;
+    V* __restrict__ d = dst + m * nvec;
+    for (int64_t v0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; v0 < nvec;
+         v0 += (int64_t)gridDim.x * 1024) {
+      V tmp[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (v0 + k * 256 < nvec) tmp[k] = s[v0 + k * 256];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (v0 + k * 256 < nvec) d[v0 + k * 256] = tmp[k];
+    }
+  }
+}
+
+// Narrow rows: one lane per vector element of the flattened [M, nvec] destination.
+template <typename V, typename Map>
+__global__ __launch_bounds__(256) void gather_flat_kernel(const V* __restrict__ src,
+                                                          V* __restrict__ dst, Map map,
+                                                          int64_t M, int64_t nvec) {
+  const int64_t total = M * nvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / nvec, e = i - m * nvec;
+    dst[i] = src[map.row(m) * nvec + e];
+  }
+}
+
+template <typename V, typename Map>
+int launch_gather_v(const void* src, void* dst, Map map, int64_t M, int64_t elem_bytes,
+                    hipStream_t s) {
+  const int64_t nvec = elem_bytes / (int64_t)sizeof(V);
+  if (nvec >= 256) {
+    const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(nvec, 1024), 64);
+    const unsigned gy = (unsigned)std::min<int64_t>(M, 65535);
+    hipLaunchKernelGGL((gather_wide_kernel<V, Map>), dim3(gx, gy), dim3(256), 0, s,
+                       (const V*)src, (V*)dst, map, M, nvec);
+  } else {
+    const int64_t total = M * nvec;
+    const unsigned g = (unsigned)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
+    hipLaunchKernelGGL((gather_flat_kernel<V, Map>), dim3(g), dim3(256), 0, s, (const V*)src,
+                       (V*)dst, map, M, nvec);
+  }
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+template <typename Map>
+int launch_gather(const void* src, void* dst, Map map, int64_t M, int64_t elem_bytes,
+                  hipStream_t s) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) |
+                      (uintptr_t)elem_bytes;
+  if ((a & 15) == 0) return launch_gather_v<B16, Map>(src, dst, map, M, elem_bytes, s);
+  if ((a & 7) == 0) return launch_gather_v<uint64_t, Map>(src, dst, map, M, elem_bytes, s);
+  if ((a & 3) == 0) return launch_gather_v<uint32_t, Map>(src, dst, map, M, elem_bytes, s);
+  return launch_gather_v<uint8_t, Map>(src, dst, map, M, elem_bytes, s);
+}
+
+// ---- frame re-assembly ------------------------------------------------------------------
+// Channel c of the observation at ring time tt is blank iff done was set at any of the
+// C-c-1 steps before tt (frame.py:27-29 / sequence/frame.py:41-48).
+__device__ __forceinline__ bool channel_blank(const uint8_t* __restrict__ done, int64_t tt,
+                                              int64_t b, int c, int C, int T, int64_t B) {
+  bool blank = false;
+  for (int f = 1; f <= C - c - 1; ++f) {
+    int64_t td = (tt - f) % T;
+    if (td < 0) td += T;
+    blank = blank || (done[td * B + b] != 0);
+  }
+  return blank;
+}
+
+// grid = (chunks of the frame, C, n);  V = 16 B vectors of one frame (nvec per frame).
+template <typename V>
+__global__ __launch_bounds__(256) void frames_gather_kernel(
+    const V* __restrict__ frames, const uint8_t* __restrict__ done,
+    const int64_t* __restrict__ t_idx, const int64_t* __restrict__ b_idx, V* __restrict__ obs,
+    int64_t n, int seq_T, int T, int64_t B, int C, int64_t nvec) {
+  const int c = blockIdx.y;
+  const int64_t items = n * (int64_t)seq_T;
+  for (int64_t item = blockIdx.z; item < items; item += gridDim.z) {
+    // obs layout [seq_T, n, C, HW]: item = s * n + i
+    const int64_t s = item / n, i = item - s * n;
+    const int64_t b = b_idx[i];
+    int64_t tt = (t_idx[i] + s) % T;
+    if (tt < 0) tt += T;
+    const bool blank = channel_blank(done, tt, b, c, C, T, B);  // workgroup-uniform
+    const V* __restrict__ src = frames + ((tt + c) * B + b) * nvec;
+    V* __restrict__ dst = obs + (item * C + c) * nvec;
+    V zero;
+    memset(&zero, 0, sizeof(V));
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
+         v += (int64_t)gridDim.x * blockDim.x)
+      dst[v] = blank ? zero : src[v];
+  }
+}
+
+template <typename V>
+int launch_frames_v(const uint8_t* frames, const uint8_t* done, const int64_t* t_idx,
+                    const int64_t* b_idx, uint8_t* obs, int64_t n, int seq_T, int T, int64_t B,
+                    int C, int64_t HW, hipStream_t s) {
+  const int64_t nvec = HW / (int64_t)sizeof(V);
+  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(nvec, 256), 16);
+  const unsigned gz = (unsigned)std::min<int64_t>(n * seq_T, 65535);
+  hipLaunchKernelGGL((frames_gather_kernel<V>), dim3(gx, C, gz), dim3(256), 0, s,
+                     (const V*)frames, done, t_idx, b_idx, (V*)obs, n, seq_T, T, B, C, nvec);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+int launch_frames(const uint8_t* frames, const uint8_t* done, const int64_t* t_idx,
+                  const int64_t* b_idx, uint8_t* obs, int64_t n, int seq_T, int T, int64_t B,
+                  int C, int64_t HW, hipStream_t s) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(frames) | reinterpret_cast<uintptr_t>(obs) |
+                      (uintptr_t)HW;
+  if ((a & 15) == 0)
+    return launch_frames_v<B16>(frames, done, t_idx, b_idx, obs, n, seq_T, T, B, C, HW, s);
+  if ((a & 3) == 0)
+    return launch_frames_v<uint32_t>(frames, done, t_idx, b_idx, obs, n, seq_T, T, B, C, HW, s);
+  return launch_frames_v<uint8_t>(frames, done, t_idx, b_idx, obs, n, seq_T, T, B, C, HW, s);
+}
+
+// ---- extract_sequences (utils/misc.py:38-56) --------------------------------------------
+// Non-negative start: dst[s,i] = src[(t+s) mod T, b].  Negative start t<0 ("wrap
+// beginning", misc.py:49-51) is reproduced literally: the reference writes
+//   sequences[t:, i] = array[t:, b]   (the LAST |t| output rows get the LAST |t| ring rows)
+//   sequences[:t, i] = array[:t+T, b] (the first seq_T-|t| output rows get ring rows 0..)
+template <typename V>
+__global__ __launch_bounds__(256) void gather_seq_kernel(
+    const V* __restrict__ src, const int64_t* __restrict__ t_idx,
+    const int64_t* __restrict__ b_idx, V* __restrict__ dst, int64_t n, int seq_T, int T,
+    int64_t B, int64_t nvec) {
+  const int64_t total = (int64_t)seq_T * n * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx % nvec;
+    const int64_t si = idx / nvec;
+    const int64_t s = si / n, i = si - s * n;
+    const int64_t t = t_idx[i], b = b_idx[i];
+    int64_t row;
+    if (t < 0) {
+      const int64_t head = seq_T + t;            // rows taken from the ring start
+      row = (s < head) ? s : (T + (s - seq_T));  // tail rows: array[t:] = ring rows T+t..T-1
+    } else {
+      row = (t + s) % T;
+    }
+    dst[idx] = src[(row * B + b) * nvec + e];
+  }
+}
+
+}  // namespace
+}  // namespace rlpyt
+
+using namespace rlpyt;
+
+extern "C" int rlpyt_gather_tb(const void* src, const int64_t* flat_idx, void* dst, int T,
+                               int64_t B, int64_t elem_bytes, int64_t M,
+                               rlpyt_stream_t stream) {
+  RL_CHECK_ARG(src && flat_idx && dst, RLPYT_EINVAL, "rlpyt_gather_tb: null pointer");
+  RL_CHECK_ARG(T > 0 && B > 0 && elem_bytes > 0 && M >= 0, RLPYT_EINVAL,
+               "rlpyt_gather_tb: bad sizes T=%d B=%ld E=%ld M=%ld", T, (long)B, (long)elem_bytes,
+               (long)M);
+  if (M == 0) return RLPYT_OK;
+  MapTB map{flat_idx, T, B};
+  return launch_gather(src, dst, map, M, elem_bytes, (hipStream_t)stream);
+}
+
+extern "C" int rlpyt_gather_rows(const void* src, const int64_t* t_idx, const int64_t* b_idx,
+                                 void* dst, int T, int64_t B, int64_t elem_bytes, int64_t M,
+                                 rlpyt_stream_t stream) {
+  RL_CHECK_ARG(src && t_idx && b_idx && dst, RLPYT_EINVAL, "rlpyt_gather_rows: null pointer");
+  RL_CHECK_ARG(T > 0 && B > 0 && elem_bytes > 0 && M >= 0, RLPYT_EINVAL,
+               "rlpyt_gather_rows: bad sizes");
+  if (M == 0) return RLPYT_OK;
+  MapPair map{t_idx, b_idx, T, B};
+  return launch_gather(src, dst, map, M, elem_bytes, (hipStream_t)stream);
+}
+
+extern "C" int rlpyt_frames_gather(const uint8_t* frames, const uint8_t* done,
+                                   const int64_t* t_idx, const int64_t* b_idx, uint8_t* obs,
+                                   int64_t n, int T, int64_t B, int C, int64_t HW,
+                                   rlpyt_stream_t stream) {
+  RL_CHECK_ARG(frames && done && t_idx && b_idx && obs, RLPYT_EINVAL,
+               "rlpyt_frames_gather: null pointer");
+  RL_CHECK_ARG(n >= 0 && T > 0 && B > 0 && C > 0 && C <= 65535 && HW > 0, RLPYT_EINVAL,
+               "rlpyt_frames_gather: bad sizes");
+  if (n == 0) return RLPYT_OK;
+  return launch_frames(frames, done, t_idx, b_idx, obs, n, 1, T, B, C, HW, (hipStream_t)stream);
+}
+
+extern "C" int rlpyt_frames_gather_seq(const uint8_t* frames, const uint8_t* done,
+                                       const int64_t* t_idx, const int64_t* b_idx,
+                                       uint8_t* obs, int64_t n, int seq_T, int T, int64_t B,
+                                       int C, int64_t HW, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(frames && done && t_idx && b_idx && obs, RLPYT_EINVAL,
+               "rlpyt_frames_gather_seq: null pointer");
+  RL_CHECK_ARG(n >= 0 && seq_T > 0 && T > 0 && B > 0 && C > 0 && C <= 65535 && HW > 0,
+               RLPYT_EINVAL, "rlpyt_frames_gather_seq: bad sizes");
+  RL_CHECK_ARG(seq_T <= T, RLPYT_ESHAPE, "rlpyt_frames_gather_seq: seq_T=%d > ring T=%d", seq_T,
+               T);
+  if (n == 0) return RLPYT_OK;
+  return launch_frames(frames, done, t_idx, b_idx, obs, n, seq_T, T, B, C, HW,
+                       (hipStream_t)stream);
+}
+
+extern "C" int rlpyt_gather_sequences(const void* src, const int64_t* t_idx,
+                                      const int64_t* b_idx, void* dst, int64_t n, int seq_T,
+                                      int T, int64_t B, int64_t elem_bytes,
+                                      rlpyt_stream_t stream) {
+  RL_CHECK_ARG(src && t_idx && b_idx && dst, RLPYT_EINVAL,
+               "rlpyt_gather_sequences: null pointer");
+  RL_CHECK_ARG(n >= 0 && seq_T > 0 && T > 0 && B > 0 && elem_bytes > 0, RLPYT_EINVAL,
+               "rlpyt_gather_sequences: bad sizes");
+  if (n == 0) return RLPYT_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) |
+                      (uintptr_t)elem_bytes;
+  const int64_t total_bytes = (int64_t)seq_T * n * elem_bytes;
+#define RL_SEQ(V)                                                                          \
+  do {                                                                                     \
+    const int64_t nvec = elem_bytes / (int64_t)sizeof(V);                                  \
+    const unsigned g =                                                                     \
+        (unsigned)std::min<int64_t>(ceil_div(total_bytes / (int64_t)sizeof(V), 256), 4096); \
+    hipLaunchKernelGGL((gather_seq_kernel<V>), dim3(g), dim3(256), 0, s, (const V*)src, t_idx, \
+                       b_idx, (V*)dst, n, seq_T, T, B, nvec);                              \
+  } while (0)
+  if ((a & 15) == 0) RL_SEQ(B16);
+  else if ((a & 3) == 0) RL_SEQ(uint32_t);
+  else RL_SEQ(uint8_t);
+#undef RL_SEQ
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}

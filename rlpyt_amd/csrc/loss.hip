@@ -1,0 +1,425 @@
+// Fused forward+backward loss kernels (PPO / A2C / DQN) and advantage normalisation
+// for gfx950.  Replaces ~15 elementwise/reduction torch ops per minibatch that the
+// reference runs on CPU tensors (rlpyt/algos/pg/ppo.py:133-153, a2c.py:85-101,
+// dqn/dqn.py:231-263, pg/base.py:65-73).
+//
+// Data movement: the [M,A] probability tile of a workgroup is staged through LDS with
+// flat coalesced loads (a lane-per-sample read of A consecutive floats would issue A
+// strided dword loads per wave); gradients leave through the same tile.  Reductions are
+// deterministic: per-workgroup partials in f64 -> a one-workgroup finalize kernel.
+#include "common.h"
+
+namespace rlpyt {
+namespace {
+
+constexpr int kLossBlock = 256;
+constexpr int kMaxLossGrid = 1024;
+constexpr float kEpsCat = 1e-8f;  // rlpyt/distributions/categorical.py:9
+
+struct LossWs {            // layout of the caller's workspace
+  double valid_part[kMaxLossGrid];
+  double part[kMaxLossGrid][6];
+};
+
+__global__ __launch_bounds__(kLossBlock) void valid_partial_kernel(
+    const float* __restrict__ valid, int64_t M, double* __restrict__ part) {
+  __shared__ double scratch[16];
+  double acc[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
+       i += (int64_t)gridDim.x * blockDim.x)
+    acc[0] += (double)valid[i];
+  block_sum<1>(acc, scratch);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
+}
+
+// Sum `n` partials (n <= kMaxLossGrid) redundantly inside a workgroup.
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int n,
+                                               double* scratch) {
+  double acc[1] = {0.0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc[0] += part[i];
+  block_sum<1>(acc, scratch);
+  __shared__ double bcast;
+  if (threadIdx.x == 0) bcast = acc[0];
+  __syncthreads();
+  return bcast;
+}
+
+// MODE 0: PPO clipped surrogate; MODE 1: A2C log-likelihood.
+template <int MODE>
+__global__ __launch_bounds__(kLossBlock) void pg_loss_kernel(
+    const float* __restrict__ prob_new, const float* __restrict__ value,
+    const float* __restrict__ prob_old, const int64_t* __restrict__ action,
+    const float* __restrict__ advantage, const float* __restrict__ return_,
+    const float* __restrict__ valid, int64_t M, int A, float ratio_clip, float c_v, float c_e,
+    float* __restrict__ grad_prob, float* __restrict__ grad_value, LossWs* __restrict__ ws,
+    int n_valid_part) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [kLossBlock * A]
+  __shared__ double scratch[6 * 16];
+  // Normaliser of valid_mean (utils/tensor.py:39-46): sum(valid) or M.
+  double denom = (double)M;
+  if (valid != nullptr) denom = sum_partials(ws->valid_part, n_valid_part, scratch);
+  const float inv = (float)(1.0 / denom);
+
+  double acc[6] = {0, 0, 0, 0, 0, 0};  // surr|logliA, verr, H, exp(H), count, unused
+  const int64_t n_tiles = ceil_div(M, kLossBlock);
+  for (int64_t tile_i = blockIdx.x; tile_i < n_tiles; tile_i += gridDim.x) {
+    const int64_t m0 = tile_i * kLossBlock;
+    const int rows = (int)min((int64_t)kLossBlock, M - m0);
+    const int n_el = rows * A;
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_el; e += kLossBlock) tile[e] = prob_new[m0 * A + e];
+    __syncthreads();
+    const int row = threadIdx.x;
+    float g_sel = 0.f;   // extra gradient on the selected action's probability
+    int a_sel = -1;
+    float w = 0.f;
+    if (row < rows) {
+      const int64_t m = m0 + row;
+      const float vmask = valid ? valid[m] : 1.0f;
+      w = vmask * inv;
+      a_sel = (int)action[m];
+      const float adv = advantage[m];
+      const float p_sel = tile[row * A + a_sel];
+      float pi_term;
+      if (MODE == 0) {
+        // categorical.py:40-43 ; ppo.py:136-143
+        const float den = prob_old[m * A + a_sel] + kEpsCat;
+        const float ratio = (p_sel + kEpsCat) / den;
+        const float lo = 1.0f - ratio_clip, hi = 1.0f + ratio_clip;
+        const float clipped = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = ratio * adv, s2 = clipped * adv;
+        pi_term = fminf(s1, s2);
+        // d min(s1,s2)/d ratio with torch's tie rule (ties split the gradient) and
+        // clamp's inclusive pass-through.
+        const bool inside = (ratio >= lo) && (ratio <= hi);
+        float dr;
+        if (s1 < s2) dr = adv;
+        else if (s1 > s2) dr = inside ? adv : 0.f;
+        else dr = 0.5f * adv + (inside ? 0.5f * adv : 0.f);
+        g_sel = -w * dr / den;
+      } else {
+        // categorical.py:36-38 ; a2c.py:87-88
+        const float logli = logf(p_sel + kEpsCat);
+        pi_term = logli * adv;
+        g_sel = -w * adv / (p_sel + kEpsCat);
+      }
+      // value loss 0.5*(V-R)^2 (ppo.py:145-146)
+      const float verr_d = value[m] - return_[m];
+      const float verr = 0.5f * verr_d * verr_d;
+      grad_value[m] = c_v * w * verr_d;
+      // entropy -sum p log(p+eps) (categorical.py:32-34) and its gradient.
+      float H = 0.f;
+      for (int j = 0; j < A; ++j) {
+        const float p = tile[row * A + j];
+        const float lp = logf(p + kEpsCat);
+        H -= p * lp;
+        // d(-c_e * w * H)/dp_j = c_e * w * (log(p+eps) + p/(p+eps))
+        float gj = c_e * w * (lp + p / (p + kEpsCat));
+        if (j == a_sel) gj += g_sel;
+        tile[row * A + j] = gj;
+      }
+      acc[0] += (double)(vmask * pi_term);
+      acc[1] += (double)(vmask * verr);
+      acc[2] += (double)(vmask * H);
+      acc[3] += (double)(vmask * expf(H));
+      acc[4] += (double)vmask;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_el; e += kLossBlock) grad_prob[m0 * A + e] = tile[e];
+  }
+  block_sum<6>(acc, scratch);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ws->part[blockIdx.x][k] = acc[k];
+  }
+}
+
+__global__ __launch_bounds__(kLossBlock) void pg_loss_finalize_kernel(
+    const LossWs* __restrict__ ws, int n_part, int64_t M, int has_valid, int mode, float c_v,
+    float c_e, float* __restrict__ out) {
+  __shared__ double scratch[6 * 16];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] += ws->part[i][k];
+  }
+  block_sum<6>(acc, scratch);
+  if (threadIdx.x == 0) {
+    const double denom = has_valid ? acc[4] : (double)M;
+    const float pi_loss = -(float)(acc[0] / denom);
+    const float value_loss = c_v * (float)(acc[1] / denom);
+    const float entropy = (float)(acc[2] / denom);
+    const float perplexity = (float)(acc[3] / denom);
+    const float entropy_loss = -c_e * entropy;
+    out[0] = pi_loss + value_loss + entropy_loss;  // ppo.py:151
+    out[1] = pi_loss;
+    out[2] = value_loss;
+    out[3] = entropy;
+    out[4] = perplexity;
+    (void)mode;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// DQN TD / Huber loss (dqn.py:231-263).  One lane per sample; A <= a few dozen.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLossBlock) void dqn_loss_kernel(
+    const float* __restrict__ qs, const float* __restrict__ target_qs,
+    const float* __restrict__ next_qs, const int64_t* __restrict__ action,
+    const float* __restrict__ return_, const uint8_t* __restrict__ done_n,
+    const float* __restrict__ is_weights, int64_t M, int A, float disc_n, float delta_clip,
+    float* __restrict__ td_abs, float* __restrict__ grad_qs, LossWs* __restrict__ ws) {
+  __shared__ double scratch[2 * 16];
+  double acc[2] = {0, 0};
+  const float invM = 1.0f / (float)M;
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M;
+       m += (int64_t)gridDim.x * blockDim.x) {
+    const int a = (int)action[m];
+    const float q = qs[m * A + a];
+    float tq;
+    if (next_qs != nullptr) {  // double DQN: argmax of the online net (first max wins)
+      int best = 0;
+      float bv = next_qs[m * A];
+      for (int j = 1; j < A; ++j) {
+        const float x = next_qs[m * A + j];
+        if (x > bv) { bv = x; best = j; }
+      }
+      tq = target_qs[m * A + best];
+    } else {
+      tq = target_qs[m * A];
+      for (int j = 1; j < A; ++j) tq = fmaxf(tq, target_qs[m * A + j]);
+    }
+    const float y = return_[m] + (1.0f - (float)(done_n[m] ? 1 : 0)) * (disc_n * tq);
+    const float delta = y - q;
+    const float ad = fabsf(delta);
+    float loss = 0.5f * delta * delta;
+    float dl_ddelta = delta;
+    if (delta_clip > 0.f && !(ad <= delta_clip)) {
+      loss = delta_clip * (ad - delta_clip / 2);
+      dl_ddelta = delta_clip * (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f));
+    }
+    const float isw = is_weights ? is_weights[m] : 1.0f;
+    loss *= isw;
+    td_abs[m] = delta_clip > 0.f ? fminf(fmaxf(ad, 0.f), delta_clip) : ad;
+    for (int j = 0; j < A; ++j) grad_qs[m * A + j] = (j == a) ? (-invM * isw * dl_ddelta) : 0.f;
+    acc[0] += (double)loss;
+    acc[1] += (double)ad;
+  }
+  block_sum<2>(acc, scratch);
+  if (threadIdx.x == 0) {
+    ws->part[blockIdx.x][0] = acc[0];
+    ws->part[blockIdx.x][1] = acc[1];
+  }
+}
+
+__global__ __launch_bounds__(kLossBlock) void dqn_loss_finalize_kernel(
+    const LossWs* __restrict__ ws, int n_part, int64_t M, float* __restrict__ out) {
+  __shared__ double scratch[2 * 16];
+  double acc[2] = {0, 0};
+  for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
+    acc[0] += ws->part[i][0];
+    acc[1] += ws->part[i][1];
+  }
+  block_sum<2>(acc, scratch);
+  if (threadIdx.x == 0) {
+    out[0] = (float)(acc[0] / (double)M);
+    out[1] = (float)(acc[1] / (double)M);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Advantage normalisation (pg/base.py:65-73): masked mean, UNBIASED std, in place.
+// Three deterministic passes; partials in f64.
+// ---------------------------------------------------------------------------------------
+constexpr int kNormMaxGrid = 1024;
+struct NormWs {
+  double sum[kNormMaxGrid];
+  double cnt[kNormMaxGrid];
+  double ssq[kNormMaxGrid];
+};
+
+__global__ __launch_bounds__(256) void norm_pass1_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ valid,
+                                                         int64_t n, NormWs* __restrict__ ws) {
+  __shared__ double scratch[2 * 16];
+  double acc[2] = {0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const bool ok = valid ? (valid[i] > 0.f) : true;
+    if (ok) { acc[0] += (double)x[i]; acc[1] += 1.0; }
+  }
+  block_sum<2>(acc, scratch);
+  if (threadIdx.x == 0) { ws->sum[blockIdx.x] = acc[0]; ws->cnt[blockIdx.x] = acc[1]; }
+}
+
+__global__ __launch_bounds__(256) void norm_pass2_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ valid,
+                                                         int64_t n, NormWs* __restrict__ ws,
+                                                         int n_part) {
+  __shared__ double scratch[2 * 16];
+  __shared__ double s_mean;
+  double acc[2] = {0, 0};
+  for (int i = threadIdx.x; i < n_part; i += blockDim.x) { acc[0] += ws->sum[i]; acc[1] += ws->cnt[i]; }
+  block_sum<2>(acc, scratch);
+  if (threadIdx.x == 0) s_mean = acc[0] / acc[1];
+  __syncthreads();
+  // torch computes mean in fp32 and the deviations against that fp32 mean.
+  const float mean = (float)s_mean;
+  double ss[1] = {0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const bool ok = valid ? (valid[i] > 0.f) : true;
+    if (ok) { const double dlt = (double)x[i] - (double)mean; ss[0] += dlt * dlt; }
+  }
+  block_sum<1>(ss, scratch);
+  if (threadIdx.x == 0) ws->ssq[blockIdx.x] = ss[0];
+}
+
+__global__ __launch_bounds__(256) void norm_pass3_kernel(float* __restrict__ x, int64_t n,
+                                                         const NormWs* __restrict__ ws,
+                                                         int n_part, float eps,
+                                                         float* __restrict__ stats_out) {
+  __shared__ double scratch[3 * 16];
+  __shared__ float s_mean, s_den;
+  double acc[3] = {0, 0, 0};
+  for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
+    acc[0] += ws->sum[i]; acc[1] += ws->cnt[i]; acc[2] += ws->ssq[i];
+  }
+  block_sum<3>(acc, scratch);
+  if (threadIdx.x == 0) {
+    const float mean = (float)(acc[0] / acc[1]);
+    const float stdv = (float)sqrt(acc[2] / (acc[1] - 1.0));  // unbiased (torch .std())
+    // Python max(adv_std, 1e-6): NaN std stays NaN.
+    const float den = (eps > stdv) ? eps : stdv;
+    s_mean = mean; s_den = den;
+    if (stats_out != nullptr && blockIdx.x == 0) {
+      stats_out[0] = mean; stats_out[1] = stdv; stats_out[2] = (float)acc[1];
+    }
+  }
+  __syncthreads();
+  const float mean = s_mean, den = s_den;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = (x[i] - mean) / den;
+}
+
+}  // namespace
+}  // namespace rlpyt
+
+using namespace rlpyt;
+
+extern "C" int64_t rlpyt_pg_loss_workspace_bytes(int64_t M) {
+  (void)M;
+  return (int64_t)sizeof(LossWs);
+}
+extern "C" int64_t rlpyt_adv_normalize_workspace_bytes(int64_t n) {
+  (void)n;
+  return (int64_t)sizeof(NormWs);
+}
+
+namespace {
+template <int MODE>
+int launch_pg_loss(const float* prob_new, const float* value, const float* prob_old,
+                   const int64_t* action, const float* advantage, const float* return_,
+                   const float* valid, int64_t M, int A, float ratio_clip, float c_v, float c_e,
+                   float* out_scalars, float* grad_prob, float* grad_value, void* workspace,
+                   hipStream_t s) {
+  LossWs* ws = reinterpret_cast<LossWs*>(workspace);
+  const int grid = (int)std::min<int64_t>(ceil_div(M, kLossBlock), kMaxLossGrid);
+  int n_valid_part = 0;
+  if (valid != nullptr) {
+    n_valid_part = grid;
+    hipLaunchKernelGGL(valid_partial_kernel, dim3(grid), dim3(kLossBlock), 0, s, valid, M,
+                       ws->valid_part);
+    RL_LAUNCH_CHECK();
+  }
+  const size_t lds = (size_t)kLossBlock * A * sizeof(float);
+  hipLaunchKernelGGL((pg_loss_kernel<MODE>), dim3(grid), dim3(kLossBlock), lds, s, prob_new,
+                     value, prob_old, action, advantage, return_, valid, M, A, ratio_clip, c_v,
+                     c_e, grad_prob, grad_value, ws, n_valid_part);
+  RL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pg_loss_finalize_kernel, dim3(1), dim3(kLossBlock), 0, s, ws, grid, M,
+                     valid != nullptr ? 1 : 0, MODE, c_v, c_e, out_scalars);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+}  // namespace
+
+extern "C" int rlpyt_ppo_loss_fwd_bwd_f32(const float* prob_new, const float* value,
+                                          const float* prob_old, const int64_t* action,
+                                          const float* advantage, const float* return_,
+                                          const float* valid, int64_t M, int A,
+                                          float ratio_clip, float value_loss_coeff,
+                                          float entropy_loss_coeff, float* out_scalars,
+                                          float* grad_prob, float* grad_value, void* workspace,
+                                          rlpyt_stream_t stream) {
+  RL_CHECK_ARG(prob_new && value && prob_old && action && advantage && return_ && out_scalars &&
+                   grad_prob && grad_value && workspace,
+               RLPYT_EINVAL, "rlpyt_ppo_loss_fwd_bwd_f32: null pointer");
+  RL_CHECK_ARG(M > 0 && A > 0 && A <= 160, RLPYT_ESHAPE,
+               "rlpyt_ppo_loss_fwd_bwd_f32: need M>0, 0<A<=160 (M=%ld A=%d)", (long)M, A);
+  return launch_pg_loss<0>(prob_new, value, prob_old, action, advantage, return_, valid, M, A,
+                           ratio_clip, value_loss_coeff, entropy_loss_coeff, out_scalars,
+                           grad_prob, grad_value, workspace, (hipStream_t)stream);
+}
+
+extern "C" int rlpyt_a2c_loss_fwd_bwd_f32(const float* prob, const float* value,
+                                          const int64_t* action, const float* advantage,
+                                          const float* return_, const float* valid, int64_t M,
+                                          int A, float value_loss_coeff,
+                                          float entropy_loss_coeff, float* out_scalars,
+                                          float* grad_prob, float* grad_value, void* workspace,
+                                          rlpyt_stream_t stream) {
+  RL_CHECK_ARG(prob && value && action && advantage && return_ && out_scalars && grad_prob &&
+                   grad_value && workspace,
+               RLPYT_EINVAL, "rlpyt_a2c_loss_fwd_bwd_f32: null pointer");
+  RL_CHECK_ARG(M > 0 && A > 0 && A <= 160, RLPYT_ESHAPE,
+               "rlpyt_a2c_loss_fwd_bwd_f32: need M>0, 0<A<=160 (M=%ld A=%d)", (long)M, A);
+  return launch_pg_loss<1>(prob, value, nullptr, action, advantage, return_, valid, M, A, 0.f,
+                           value_loss_coeff, entropy_loss_coeff, out_scalars, grad_prob,
+                           grad_value, workspace, (hipStream_t)stream);
+}
+
+extern "C" int rlpyt_dqn_loss_fwd_bwd_f32(const float* qs, const float* target_qs,
+                                          const float* next_qs, const int64_t* action,
+                                          const float* return_, const uint8_t* done_n,
+                                          const float* is_weights, int64_t M, int A,
+                                          float disc_n, float delta_clip, float* out_scalars,
+                                          float* td_abs, float* grad_qs, void* workspace,
+                                          rlpyt_stream_t stream) {
+  RL_CHECK_ARG(qs && target_qs && action && return_ && done_n && out_scalars && td_abs &&
+                   grad_qs && workspace,
+               RLPYT_EINVAL, "rlpyt_dqn_loss_fwd_bwd_f32: null pointer");
+  RL_CHECK_ARG(M > 0 && A > 0, RLPYT_ESHAPE, "rlpyt_dqn_loss_fwd_bwd_f32: need M>0, A>0");
+  LossWs* ws = reinterpret_cast<LossWs*>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = (int)std::min<int64_t>(ceil_div(M, kLossBlock), kMaxLossGrid);
+  hipLaunchKernelGGL(dqn_loss_kernel, dim3(grid), dim3(kLossBlock), 0, s, qs, target_qs, next_qs,
+                     action, return_, done_n, is_weights, M, A, disc_n, delta_clip, td_abs,
+                     grad_qs, ws);
+  RL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dqn_loss_finalize_kernel, dim3(1), dim3(kLossBlock), 0, s, ws, grid, M,
+                     out_scalars);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_adv_normalize_f32(float* advantage, const float* valid, int64_t n,
+                                       float eps, void* workspace, float* stats_out,
+                                       rlpyt_stream_t stream) {
+  RL_CHECK_ARG(advantage && workspace, RLPYT_EINVAL, "rlpyt_adv_normalize_f32: null pointer");
+  RL_CHECK_ARG(n >= 0, RLPYT_EINVAL, "rlpyt_adv_normalize_f32: negative n");
+  if (n == 0) return RLPYT_OK;
+  NormWs* ws = reinterpret_cast<NormWs*>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = (int)std::min<int64_t>(ceil_div(n, 256 * 4), kNormMaxGrid);
+  hipLaunchKernelGGL(norm_pass1_kernel, dim3(grid), dim3(256), 0, s, advantage, valid, n, ws);
+  RL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(norm_pass2_kernel, dim3(grid), dim3(256), 0, s, advantage, valid, n, ws,
+                     grid);
+  RL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(norm_pass3_kernel, dim3(grid), dim3(256), 0, s, advantage, n, ws, grid, eps,
+                     stats_out);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}

@@ -1,0 +1,455 @@
+"""Device-tensor wrappers over the C ABI (``include/rlpyt_hip.h``).
+
+Every function here takes/returns ``torch`` tensors living on the MI355X and launches on
+torch's current HIP stream.  Shapes follow the reference's ``[Time, Batch, ...]`` layout.
+No function in this module computes anything itself: arithmetic lives in the HIP kernels.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream
+
+SCAN_EXACT = 0
+SCAN_SEGMENTED = 1
+
+
+def _tn(x):
+    """[T, ...] -> (T, N) with N = prod(trailing dims)."""
+    T = x.shape[0]
+    N = 1
+    for s in x.shape[1:]:
+        N *= s
+    return T, N
+
+
+def _as_done_u8(done):
+    """torch.bool / uint8 / float done mask -> contiguous uint8 0/1 view or copy."""
+    if done.dtype == torch.bool:
+        return done.contiguous().view(torch.uint8)
+    if done.dtype == torch.uint8:
+        return done.contiguous()
+    return (done != 0).contiguous().view(torch.uint8)
+
+
+def _f32(x):
+    return x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# scans
+# --------------------------------------------------------------------------------------
+def gae(reward, value, done, bootstrap_value, discount, gae_lambda, advantage_dest=None,
+        return_dest=None, with_valid=False, variant=SCAN_EXACT):
+    """rlpyt/algos/utils.py:24-40 on device.  Returns (advantage, return_[, valid])."""
+    _lib.require_gpu()
+    reward, value = _f32(reward), _f32(value)
+    done8 = _as_done_u8(done)
+    T, N = _tn(reward)
+    bv = _f32(bootstrap_value).reshape(-1)
+    if bv.numel() != N:
+        bv = _f32(bootstrap_value.expand(reward.shape[1:])).reshape(-1)
+    adv = advantage_dest if advantage_dest is not None else torch.empty_like(reward)
+    ret = return_dest if return_dest is not None else torch.empty_like(reward)
+    valid = torch.empty_like(reward) if with_valid else None
+    check(lib.rlpyt_gae_f32(ptr(reward), ptr(value), ptr(done8), ptr(bv), ptr(adv), ptr(ret),
+                            ptr(valid), T, N, float(discount), float(gae_lambda), variant,
+                            stream()), "rlpyt_gae_f32")
+    return (adv, ret, valid) if with_valid else (adv, ret)
+
+
+def discount_return(reward, done, bootstrap_value, discount, return_dest=None, value=None,
+                    with_valid=False, variant=SCAN_EXACT):
+    """rlpyt/algos/utils.py:8-21 on device.  With ``value`` also returns advantage=R-V."""
+    _lib.require_gpu()
+    reward = _f32(reward)
+    done8 = _as_done_u8(done)
+    T, N = _tn(reward)
+    bv = _f32(bootstrap_value).reshape(-1)
+    if bv.numel() != N:
+        bv = _f32(bootstrap_value.expand(reward.shape[1:])).reshape(-1)
+    ret = return_dest if return_dest is not None else torch.empty_like(reward)
+    adv = None
+    if value is not None:
+        value = _f32(value)
+        adv = torch.empty_like(reward)
+    valid = torch.empty_like(reward) if with_valid else None
+    check(lib.rlpyt_discount_return_f32(ptr(reward), ptr(done8), ptr(bv), ptr(ret), ptr(value),
+                                        ptr(adv), ptr(valid), T, N, float(discount), variant,
+                                        stream()), "rlpyt_discount_return_f32")
+    out = (ret,)
+    if value is not None:
+        out += (adv,)
+    if with_valid:
+        out += (valid,)
+    return out[0] if len(out) == 1 else out
+
+
+def valid_from_done(done):
+    """rlpyt/algos/utils.py:104-112 on device -> float32 mask."""
+    _lib.require_gpu()
+    done8 = _as_done_u8(done)
+    T, N = _tn(done8)
+    valid = torch.empty(done8.shape, dtype=torch.float32, device=done8.device)
+    check(lib.rlpyt_valid_from_done(ptr(done8), ptr(valid), T, N, stream()),
+          "rlpyt_valid_from_done")
+    return valid
+
+
+def discount_return_n_step(reward, done, n_step, discount, return_dest=None, done_n_dest=None,
+                           do_truncated=False):
+    """rlpyt/algos/utils.py:67-101 on device -> (return_, done_n[bool])."""
+    _lib.require_gpu()
+    reward = _f32(reward)
+    done8 = _as_done_u8(done)
+    T_in, N = _tn(reward)
+    rlen = T_in if do_truncated else T_in - (n_step - 1)
+    shape = (max(rlen, 0),) + tuple(reward.shape[1:])
+    ret = return_dest if return_dest is not None else torch.empty(
+        shape, dtype=torch.float32, device=reward.device)
+    dn = done_n_dest if done_n_dest is not None else torch.empty(
+        shape, dtype=torch.bool, device=reward.device)
+    assert ret.is_contiguous() and dn.is_contiguous()
+    dn8 = dn.view(torch.uint8) if dn.dtype == torch.bool else dn
+    check(lib.rlpyt_nstep_return_f32(ptr(reward), ptr(done8), ptr(ret), ptr(dn8), T_in, N,
+                                     int(n_step), float(discount), int(bool(do_truncated)),
+                                     stream()), "rlpyt_nstep_return_f32")
+    return ret, dn
+
+
+_ws_cache = {}
+
+
+def _workspace(kind, nbytes, device):
+    key = (kind, device, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def normalize_advantage_(advantage, valid=None, eps=1e-6, return_stats=False):
+    """In-place ``(A - mean) / max(std, eps)`` over valid entries (pg/base.py:65-73)."""
+    _lib.require_gpu()
+    assert advantage.dtype == torch.float32 and advantage.is_contiguous()
+    n = advantage.numel()
+    if valid is not None:
+        valid = _f32(valid)
+        assert valid.numel() == n
+    ws = _workspace("norm", lib.rlpyt_adv_normalize_workspace_bytes(n), advantage.device)
+    stats = torch.empty(3, dtype=torch.float32, device=advantage.device) if return_stats else None
+    check(lib.rlpyt_adv_normalize_f32(ptr(advantage), ptr(valid), n, float(eps), ptr(ws),
+                                      ptr(stats), stream()), "rlpyt_adv_normalize_f32")
+    return (advantage, stats) if return_stats else advantage
+
+
+# --------------------------------------------------------------------------------------
+# losses (autograd Functions: forward runs the fused fwd+bwd kernel, backward hands the
+# saved gradients to autograd scaled by the incoming grad)
+# --------------------------------------------------------------------------------------
+class _PpoLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prob_new, value, prob_old, action, advantage, return_, valid, ratio_clip,
+                value_loss_coeff, entropy_loss_coeff):
+        _lib.require_gpu()
+        A = prob_new.shape[-1]
+        pn = _f32(prob_new).reshape(-1, A)
+        M = pn.shape[0]
+        v = _f32(value).reshape(-1)
+        po = _f32(prob_old).reshape(-1, A)
+        act = action.reshape(-1).long().contiguous()
+        adv = _f32(advantage).reshape(-1)
+        ret = _f32(return_).reshape(-1)
+        val = None if valid is None else _f32(valid).reshape(-1)
+        out = torch.empty(5, dtype=torch.float32, device=pn.device)
+        gp = torch.empty_like(pn)
+        gv = torch.empty_like(v)
+        ws = _workspace("loss", lib.rlpyt_pg_loss_workspace_bytes(M), pn.device)
+        check(lib.rlpyt_ppo_loss_fwd_bwd_f32(ptr(pn), ptr(v), ptr(po), ptr(act), ptr(adv),
+                                             ptr(ret), ptr(val), M, A, float(ratio_clip),
+                                             float(value_loss_coeff), float(entropy_loss_coeff),
+                                             ptr(out), ptr(gp), ptr(gv), ptr(ws), stream()),
+              "rlpyt_ppo_loss_fwd_bwd_f32")
+        ctx.save_for_backward(gp, gv)
+        ctx.shapes = (prob_new.shape, value.shape)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        gp, gv = ctx.saved_tensors
+        ps, vs = ctx.shapes
+        return ((gp * g_loss).reshape(ps), (gv * g_loss).reshape(vs), None, None, None, None,
+                None, None, None, None)
+
+
+def ppo_loss(prob_new, value, prob_old, action, advantage, return_, valid, ratio_clip,
+             value_loss_coeff, entropy_loss_coeff):
+    """PPO.loss (rlpyt/algos/pg/ppo.py:117-154) as one fused kernel.
+
+    Returns ``(loss, scalars)`` where ``loss`` is differentiable w.r.t. ``prob_new`` and
+    ``value`` and ``scalars = [loss, pi_loss, value_loss, entropy, perplexity]`` (detached).
+    """
+    return _PpoLoss.apply(prob_new, value, prob_old, action, advantage, return_, valid,
+                          ratio_clip, value_loss_coeff, entropy_loss_coeff)
+
+
+class _A2cLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prob, value, action, advantage, return_, valid, value_loss_coeff,
+                entropy_loss_coeff):
+        _lib.require_gpu()
+        A = prob.shape[-1]
+        pn = _f32(prob).reshape(-1, A)
+        M = pn.shape[0]
+        v = _f32(value).reshape(-1)
+        act = action.reshape(-1).long().contiguous()
+        adv = _f32(advantage).reshape(-1)
+        ret = _f32(return_).reshape(-1)
+        val = None if valid is None else _f32(valid).reshape(-1)
+        out = torch.empty(5, dtype=torch.float32, device=pn.device)
+        gp = torch.empty_like(pn)
+        gv = torch.empty_like(v)
+        ws = _workspace("loss", lib.rlpyt_pg_loss_workspace_bytes(M), pn.device)
+        check(lib.rlpyt_a2c_loss_fwd_bwd_f32(ptr(pn), ptr(v), ptr(act), ptr(adv), ptr(ret),
+                                             ptr(val), M, A, float(value_loss_coeff),
+                                             float(entropy_loss_coeff), ptr(out), ptr(gp),
+                                             ptr(gv), ptr(ws), stream()),
+              "rlpyt_a2c_loss_fwd_bwd_f32")
+        ctx.save_for_backward(gp, gv)
+        ctx.shapes = (prob.shape, value.shape)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        gp, gv = ctx.saved_tensors
+        ps, vs = ctx.shapes
+        return ((gp * g_loss).reshape(ps), (gv * g_loss).reshape(vs), None, None, None, None,
+                None, None)
+
+
+def a2c_loss(prob, value, action, advantage, return_, valid, value_loss_coeff,
+             entropy_loss_coeff):
+    """A2C.loss (rlpyt/algos/pg/a2c.py:63-103) as one fused kernel; see ``ppo_loss``."""
+    return _A2cLoss.apply(prob, value, action, advantage, return_, valid, value_loss_coeff,
+                          entropy_loss_coeff)
+
+
+class _DqnLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qs, target_qs, next_qs, action, return_, done_n, is_weights, disc_n,
+                delta_clip):
+        _lib.require_gpu()
+        A = qs.shape[-1]
+        q = _f32(qs).reshape(-1, A)
+        M = q.shape[0]
+        tq = _f32(target_qs).reshape(-1, A)
+        nq = None if next_qs is None else _f32(next_qs).reshape(-1, A)
+        act = action.reshape(-1).long().contiguous()
+        ret = _f32(return_).reshape(-1)
+        dn = _as_done_u8(done_n).reshape(-1)
+        isw = None if is_weights is None else _f32(is_weights).reshape(-1)
+        out = torch.empty(2, dtype=torch.float32, device=q.device)
+        td = torch.empty(M, dtype=torch.float32, device=q.device)
+        gq = torch.empty_like(q)
+        ws = _workspace("loss", lib.rlpyt_pg_loss_workspace_bytes(M), q.device)
+        check(lib.rlpyt_dqn_loss_fwd_bwd_f32(ptr(q), ptr(tq), ptr(nq), ptr(act), ptr(ret),
+                                             ptr(dn), ptr(isw), M, A, float(disc_n),
+                                             float(delta_clip if delta_clip is not None else 0.),
+                                             ptr(out), ptr(td), ptr(gq), ptr(ws), stream()),
+              "rlpyt_dqn_loss_fwd_bwd_f32")
+        ctx.save_for_backward(gq)
+        ctx.shape = qs.shape
+        ctx.mark_non_differentiable(td)
+        return out[0], td
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_td):
+        (gq,) = ctx.saved_tensors
+        return ((gq * g_loss).reshape(ctx.shape), None, None, None, None, None, None, None, None)
+
+
+def dqn_loss(qs, target_qs, next_qs, action, return_, done_n, is_weights, disc_n, delta_clip):
+    """DQN.loss (rlpyt/algos/dqn/dqn.py:231-263): returns (loss, td_abs_errors)."""
+    return _DqnLoss.apply(qs, target_qs, next_qs, action, return_, done_n, is_weights, disc_n,
+                          delta_clip)
+
+
+# --------------------------------------------------------------------------------------
+# gathers
+# --------------------------------------------------------------------------------------
+def _row_bytes(x, lead):
+    n = x.element_size()
+    for s in x.shape[lead:]:
+        n *= s
+    return n
+
+
+def gather_tb(src, flat_idx, out=None):
+    """``src[idx % T, idx // T]`` for a [T,B,...] tensor (ppo.py:94-100)."""
+    _lib.require_gpu()
+    assert src.is_contiguous() and src.dim() >= 2
+    T, B = src.shape[:2]
+    flat_idx = flat_idx.long().contiguous()
+    M = flat_idx.numel()
+    if out is None:
+        out = torch.empty((M,) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+    check(lib.rlpyt_gather_tb(ptr(src), ptr(flat_idx), ptr(out), T, B, _row_bytes(src, 2), M,
+                              stream()), "rlpyt_gather_tb")
+    return out
+
+
+def gather_rows(src, t_idx, b_idx, out=None):
+    """``src[t_idx, b_idx]`` for a [T,B,...] tensor; negative t wraps once (numpy rule)."""
+    _lib.require_gpu()
+    assert src.is_contiguous() and src.dim() >= 2
+    T, B = src.shape[:2]
+    t_idx, b_idx = t_idx.long().contiguous(), b_idx.long().contiguous()
+    M = t_idx.numel()
+    if out is None:
+        out = torch.empty((M,) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+    check(lib.rlpyt_gather_rows(ptr(src), ptr(t_idx), ptr(b_idx), ptr(out), T, B,
+                                _row_bytes(src, 2), M, stream()), "rlpyt_gather_rows")
+    return out
+
+
+def frames_gather(frames, done, t_idx, b_idx, n_frames, out=None):
+    """NStepFrameBuffer.extract_observation (replays/non_sequence/frame.py:14-30).
+
+    frames: uint8 [T+C-1, B, *img]; done: bool [T, B] -> uint8 [n, C, *img]."""
+    _lib.require_gpu()
+    assert frames.dtype == torch.uint8 and frames.is_contiguous()
+    C = int(n_frames)
+    T = frames.shape[0] - (C - 1)
+    B = frames.shape[1]
+    img = tuple(frames.shape[2:])
+    HW = 1
+    for s in img:
+        HW *= s
+    done8 = _as_done_u8(done)
+    assert done8.shape[0] == T and done8.shape[1] == B
+    t_idx, b_idx = t_idx.long().contiguous(), b_idx.long().contiguous()
+    n = t_idx.numel()
+    if out is None:
+        out = torch.empty((n, C) + img, dtype=torch.uint8, device=frames.device)
+    check(lib.rlpyt_frames_gather(ptr(frames), ptr(done8), ptr(t_idx), ptr(b_idx), ptr(out), n,
+                                  T, B, C, HW, stream()), "rlpyt_frames_gather")
+    return out
+
+
+def frames_gather_seq(frames, done, t_idx, b_idx, n_frames, seq_T, out=None):
+    """SequenceNStepFrameBuffer.extract_observation (replays/sequence/frame.py:17-50)
+    -> uint8 [seq_T, n, C, *img]."""
+    _lib.require_gpu()
+    assert frames.dtype == torch.uint8 and frames.is_contiguous()
+    C = int(n_frames)
+    T = frames.shape[0] - (C - 1)
+    B = frames.shape[1]
+    img = tuple(frames.shape[2:])
+    HW = 1
+    for s in img:
+        HW *= s
+    done8 = _as_done_u8(done)
+    t_idx, b_idx = t_idx.long().contiguous(), b_idx.long().contiguous()
+    n = t_idx.numel()
+    if out is None:
+        out = torch.empty((seq_T, n, C) + img, dtype=torch.uint8, device=frames.device)
+    check(lib.rlpyt_frames_gather_seq(ptr(frames), ptr(done8), ptr(t_idx), ptr(b_idx), ptr(out),
+                                      n, int(seq_T), T, B, C, HW, stream()),
+          "rlpyt_frames_gather_seq")
+    return out
+
+
+def extract_sequences(src, t_idx, b_idx, seq_T, out=None):
+    """rlpyt/utils/misc.py:38-56 on device -> [seq_T, n, ...]."""
+    _lib.require_gpu()
+    assert src.is_contiguous() and src.dim() >= 2
+    T, B = src.shape[:2]
+    t_idx, b_idx = t_idx.long().contiguous(), b_idx.long().contiguous()
+    n = t_idx.numel()
+    view = src.view(torch.uint8) if src.dtype == torch.bool else src
+    if out is None:
+        out = torch.empty((seq_T, n) + tuple(src.shape[2:]), dtype=view.dtype, device=src.device)
+    check(lib.rlpyt_gather_sequences(ptr(view), ptr(t_idx), ptr(b_idx), ptr(out), n, int(seq_T),
+                                     T, B, _row_bytes(view, 2), stream()),
+          "rlpyt_gather_sequences")
+    return out.view(torch.bool) if src.dtype == torch.bool else out
+
+
+# --------------------------------------------------------------------------------------
+# sum tree
+# --------------------------------------------------------------------------------------
+class DeviceSumTree:
+    """Opaque handle over ``rlpyt_sumtree`` (f64 tree in HBM)."""
+
+    def __init__(self, T, B, off_backward, off_forward, default_value=1.,
+                 enable_input_priorities=False, input_priority_shift=0, device=None):
+        _lib.require_gpu()
+        self.device = torch.device(device if device is not None else
+                                   f"cuda:{torch.cuda.current_device()}")
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.rlpyt_sumtree_create(ctypes.byref(h), int(T), int(B), int(off_backward),
+                                           int(off_forward), float(default_value),
+                                           int(bool(enable_input_priorities)),
+                                           int(input_priority_shift)), "rlpyt_sumtree_create")
+        self._h = h
+        self.T, self.B = int(T), int(B)
+        self.tree_levels = lib.rlpyt_sumtree_levels(h)
+        self.low_idx = lib.rlpyt_sumtree_low_idx(h)
+        self.n_nodes = 2 ** self.tree_levels - 1
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.rlpyt_sumtree_destroy(h)
+            self._h = None
+
+    @property
+    def t(self):
+        return lib.rlpyt_sumtree_cursor(self._h)
+
+    def reset(self):
+        check(lib.rlpyt_sumtree_reset(self._h, stream()), "rlpyt_sumtree_reset")
+
+    def advance(self, T, priorities=None):
+        if priorities is None:
+            check(lib.rlpyt_sumtree_advance(self._h, int(T), None, 0, stream()),
+                  "rlpyt_sumtree_advance")
+            return
+        p = torch.as_tensor(priorities, dtype=torch.float64, device=self.device).contiguous()
+        if p.numel() == 1:
+            kind = 1
+        elif p.numel() == self.B:
+            kind = 2
+        else:
+            assert p.numel() == T * self.B, "priorities must be scalar, [B] or [T,B]"
+            kind = 3
+        check(lib.rlpyt_sumtree_advance(self._h, int(T), ptr(p), kind, stream()),
+              "rlpyt_sumtree_advance")
+
+    def sample(self, uniforms):
+        """uniforms: f64 device tensor [n] in [0,1) -> (T_idxs, B_idxs, priorities)."""
+        u = uniforms.to(device=self.device, dtype=torch.float64).contiguous()
+        n = u.numel()
+        T_idxs = torch.empty(n, dtype=torch.int64, device=self.device)
+        B_idxs = torch.empty(n, dtype=torch.int64, device=self.device)
+        pri = torch.empty(n, dtype=torch.float64, device=self.device)
+        check(lib.rlpyt_sumtree_sample(self._h, ptr(u), n, ptr(T_idxs), ptr(B_idxs), ptr(pri),
+                                       stream()), "rlpyt_sumtree_sample")
+        return T_idxs, B_idxs, pri
+
+    def update_batch_priorities(self, priorities):
+        p = priorities.to(device=self.device, dtype=torch.float64).contiguous()
+        check(lib.rlpyt_sumtree_update(self._h, ptr(p), p.numel(), stream()),
+              "rlpyt_sumtree_update")
+
+    def tree_tensor(self):
+        """Copy of the whole f64 tree (for parity tests / inspection)."""
+        out = torch.empty(self.n_nodes, dtype=torch.float64, device=self.device)
+        check(lib.rlpyt_sumtree_copy_tree(self._h, ptr(out), stream()),
+              "rlpyt_sumtree_copy_tree")
+        return out

@@ -1,0 +1,373 @@
+"""Generate golden vectors from the REAL reference (astooke/rlpyt at /root/reference).
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own functions/classes for the hot path,
+feeds them seeded synthetic inputs and stores inputs + outputs as small ``.npz`` files
+next to this script.  The oracle (``oracle/``) and the HIP path are both tested against
+these files, which is what pins parity (the reference's own tests hold no numeric vectors
+for this path -- SURVEY.md section 4).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get("RLPYT_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from rlpyt.algos.utils import (discount_return, discount_return_n_step,  # noqa: E402
+                               generalized_advantage_estimation, valid_from_done)
+from rlpyt.distributions.categorical import Categorical, DistInfo  # noqa: E402
+from rlpyt.replays.sum_tree import SumTree  # noqa: E402
+from rlpyt.utils.misc import extract_sequences  # noqa: E402
+from rlpyt.utils.tensor import select_at_indexes, valid_mean  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def scan_inputs(T, B, p_done, seed):
+    g = torch.Generator().manual_seed(seed)
+    reward = 0.5 * torch.randn(T, B, generator=g)
+    value = torch.randn(T, B, generator=g)
+    done = torch.rand(T, B, generator=g) < p_done
+    bv = torch.randn(1, B, generator=g)
+    return reward, value, done, bv
+
+
+def gen_scans():
+    out = {}
+    cases = [("cfg", 128, 256, 0.01, 0.99, 0.98, 0), ("nodone", 16, 8, 0.0, 0.99, 0.95, 1),
+             ("dense", 33, 7, 0.2, 0.9, 0.8, 2), ("t1", 1, 5, 0.3, 0.99, 0.97, 3),
+             ("t2", 2, 3, 0.5, 0.95, 0.5, 4)]
+    for name, T, B, p, gamma, lam, seed in cases:
+        reward, value, done, bv = scan_inputs(T, B, p, seed)
+        done_f = done.type(reward.dtype)  # as rlpyt/algos/pg/base.py:51
+        adv, ret = generalized_advantage_estimation(reward, value, done_f, bv, gamma, lam)
+        disc = discount_return(reward, done_f, bv, gamma)
+        valid = valid_from_done(done_f)
+        out.update({f"{name}_reward": reward.numpy(), f"{name}_value": value.numpy(),
+                    f"{name}_done": done.numpy(), f"{name}_bv": bv.numpy(),
+                    f"{name}_gamma": np.float64(gamma), f"{name}_lambda": np.float64(lam),
+                    f"{name}_adv": adv.numpy(), f"{name}_ret": ret.numpy(),
+                    f"{name}_disc": disc.numpy(), f"{name}_valid": valid.numpy()})
+    # the survey's hand-checkable known-answer mini
+    reward = torch.tensor([[1, 0], [0, 1], [2, -1], [.5, 0]])
+    value = torch.tensor([[.5, .1], [.2, -.3], [1, .4], [0, .7]])
+    done = torch.tensor([[0, 0], [1, 0], [0, 0], [0, 1]], dtype=torch.float)
+    bv = torch.tensor([[2., 3.]])
+    adv, ret = generalized_advantage_estimation(reward, value, done, bv, 0.9, 0.8)
+    out.update(kat_reward=reward.numpy(), kat_value=value.numpy(), kat_done=done.numpy() > 0,
+               kat_bv=bv.numpy(), kat_gamma=np.float64(0.9), kat_lambda=np.float64(0.8),
+               kat_adv=adv.numpy(), kat_ret=ret.numpy(),
+               kat_disc=discount_return(reward, done, bv, 0.9).numpy(),
+               kat_valid=valid_from_done(done).numpy())
+    # 1-D [T] input (no batch dim), as the reference allows
+    r1, v1, d1, b1 = scan_inputs(9, 1, 0.2, 7)
+    a1, rt1 = generalized_advantage_estimation(r1[:, 0], v1[:, 0], d1[:, 0].float(), b1[0, 0],
+                                               0.99, 0.9)
+    out.update(oned_reward=r1[:, 0].numpy(), oned_value=v1[:, 0].numpy(),
+               oned_done=d1[:, 0].numpy(), oned_bv=b1[0, 0].numpy(), oned_adv=a1.numpy(),
+               oned_ret=rt1.numpy())
+    save("scans", **out)
+
+
+def gen_nstep():
+    out = {}
+    for name, T, B, n, gamma, p, seed in [("r2d1", 44, 32, 5, 0.997, 0.05, 10),
+                                          ("n3", 12, 4, 3, 0.99, 0.2, 11),
+                                          ("n1", 6, 3, 1, 0.99, 0.2, 12),
+                                          ("n2", 4, 2, 2, 0.9, 0.3, 13)]:
+        reward, _, done, _ = scan_inputs(T, B, p, seed)
+        # torch path
+        rt, dn = discount_return_n_step(reward, done, n, gamma)
+        rt_tr, dn_tr = discount_return_n_step(reward, done, n, gamma, do_truncated=True)
+        # numpy path, as rlpyt/replays/n_step.py:81-108 calls it
+        rn, dnn = discount_return_n_step(reward.numpy(), done.numpy(), n, gamma)
+        assert np.array_equal(rn, rt.numpy()) and np.array_equal(dnn, dn.numpy())
+        out.update({f"{name}_reward": reward.numpy(), f"{name}_done": done.numpy(),
+                    f"{name}_n": np.int64(n), f"{name}_gamma": np.float64(gamma),
+                    f"{name}_ret": rt.numpy(), f"{name}_done_n": dn.numpy(),
+                    f"{name}_ret_trunc": rt_tr.numpy(), f"{name}_done_n_trunc": dn_tr.numpy()})
+    save("nstep", **out)
+
+
+def gen_normalize():
+    out = {}
+    for name, T, B, p, seed in [("cfg", 128, 256, 0.01, 20), ("small", 16, 8, 0.2, 21)]:
+        reward, value, done, bv = scan_inputs(T, B, p, seed)
+        done_f = done.float()
+        adv, _ = generalized_advantage_estimation(reward, value, done_f, bv, 0.99, 0.98)
+        valid = valid_from_done(done_f)
+        # rlpyt/algos/pg/base.py:65-73, both branches
+        a_all = adv.clone()
+        a_all[:] = (a_all - a_all.mean()) / max(a_all.std(), 1e-6)
+        a_val = adv.clone()
+        mask = valid > 0
+        a_val[:] = (a_val - a_val[mask].mean()) / max(a_val[mask].std(), 1e-6)
+        out.update({f"{name}_adv": adv.numpy(), f"{name}_valid": valid.numpy(),
+                    f"{name}_norm_all": a_all.numpy(), f"{name}_norm_valid": a_val.numpy()})
+    save("normalize", **out)
+
+
+def ppo_reference_loss(prob_new, value, prob_old, action, advantage, return_, valid, ratio_clip,
+                       c_v, c_e):
+    """The arithmetic of rlpyt/algos/pg/ppo.py:136-153 driven through the reference's own
+    Categorical / valid_mean objects."""
+    dist = Categorical(dim=prob_new.shape[-1])
+    new_info, old_info = DistInfo(prob=prob_new), DistInfo(prob=prob_old)
+    ratio = dist.likelihood_ratio(action, old_dist_info=old_info, new_dist_info=new_info)
+    surr_1 = ratio * advantage
+    surr_2 = torch.clamp(ratio, 1. - ratio_clip, 1. + ratio_clip) * advantage
+    pi_loss = -valid_mean(torch.min(surr_1, surr_2), valid)
+    value_loss = c_v * valid_mean(0.5 * (value - return_) ** 2, valid)
+    entropy = dist.mean_entropy(new_info, valid)
+    loss = pi_loss + value_loss - c_e * entropy
+    perplexity = dist.mean_perplexity(new_info, valid)
+    return loss, pi_loss, value_loss, entropy, perplexity
+
+
+def a2c_reference_loss(prob, value, action, advantage, return_, valid, c_v, c_e):
+    """rlpyt/algos/pg/a2c.py:85-101 through the reference's Categorical / valid_mean."""
+    dist = Categorical(dim=prob.shape[-1])
+    info = DistInfo(prob=prob)
+    logli = dist.log_likelihood(action, info)
+    pi_loss = -valid_mean(logli * advantage, valid)
+    value_loss = c_v * valid_mean(0.5 * (value - return_) ** 2, valid)
+    entropy = dist.mean_entropy(info, valid)
+    loss = pi_loss + value_loss - c_e * entropy
+    perplexity = dist.mean_perplexity(info, valid)
+    return loss, pi_loss, value_loss, entropy, perplexity
+
+
+def loss_inputs(M, A, seed, with_valid):
+    g = torch.Generator().manual_seed(seed)
+    prob_new = torch.softmax(torch.randn(M, A, generator=g), dim=-1)
+    prob_old = torch.softmax(torch.randn(M, A, generator=g) * 0.3 +
+                             torch.log(prob_new), dim=-1)
+    action = torch.randint(0, A, (M,), generator=g)
+    advantage = torch.randn(M, generator=g)
+    return_ = torch.randn(M, generator=g)
+    value = torch.randn(M, generator=g)
+    valid = (torch.rand(M, generator=g) > 0.2).float() if with_valid else None
+    return prob_new, value, prob_old, action, advantage, return_, valid
+
+
+def gen_losses():
+    out = {}
+    for name, M, A, seed, with_valid, clip in [("ppo_cfg", 2048, 6, 30, False, 0.1),
+                                               ("ppo_valid", 777, 6, 31, True, 0.2),
+                                               ("ppo_a18", 300, 18, 32, True, 0.1)]:
+        pn, v, po, a, adv, ret, valid = loss_inputs(M, A, seed, with_valid)
+        pn.requires_grad_(True)
+        v.requires_grad_(True)
+        res = ppo_reference_loss(pn, v, po, a, adv, ret, valid, clip, 1.0, 0.01)
+        res[0].backward()
+        out.update({f"{name}_prob_new": pn.detach().numpy(), f"{name}_value": v.detach().numpy(),
+                    f"{name}_prob_old": po.numpy(), f"{name}_action": a.numpy(),
+                    f"{name}_adv": adv.numpy(), f"{name}_ret": ret.numpy(),
+                    f"{name}_clip": np.float64(clip),
+                    f"{name}_scalars": np.array([x.item() for x in res], dtype=np.float32),
+                    f"{name}_grad_prob": pn.grad.numpy(), f"{name}_grad_value": v.grad.numpy()})
+        if valid is not None:
+            out[f"{name}_valid"] = valid.numpy()
+    for name, M, A, seed, with_valid in [("a2c_cfg", 5 * 32, 6, 40, False),
+                                         ("a2c_valid", 640, 4, 41, True)]:
+        pn, v, _, a, adv, ret, valid = loss_inputs(M, A, seed, with_valid)
+        pn.requires_grad_(True)
+        v.requires_grad_(True)
+        res = a2c_reference_loss(pn, v, a, adv, ret, valid, 0.5, 0.01)
+        res[0].backward()
+        out.update({f"{name}_prob": pn.detach().numpy(), f"{name}_value": v.detach().numpy(),
+                    f"{name}_action": a.numpy(), f"{name}_adv": adv.numpy(),
+                    f"{name}_ret": ret.numpy(),
+                    f"{name}_scalars": np.array([x.item() for x in res], dtype=np.float32),
+                    f"{name}_grad_prob": pn.grad.numpy(), f"{name}_grad_value": v.grad.numpy()})
+        if valid is not None:
+            out[f"{name}_valid"] = valid.numpy()
+    # DQN.loss arithmetic (rlpyt/algos/dqn/dqn.py:231-263) -- the method needs an agent, so
+    # its statements are replayed here on the reference's select_at_indexes.
+    for name, M, A, seed, double, clip, pri in [("dqn", 128, 6, 50, False, 1.0, True),
+                                                ("ddqn", 32, 18, 51, True, 1.0, True),
+                                                ("dqn_mse", 64, 4, 52, False, None, False)]:
+        g = torch.Generator().manual_seed(seed)
+        qs = (2 * torch.randn(M, A, generator=g)).requires_grad_(True)
+        target_qs = 2 * torch.randn(M, A, generator=g)
+        next_qs = 2 * torch.randn(M, A, generator=g)
+        action = torch.randint(0, A, (M,), generator=g)
+        return_ = torch.randn(M, generator=g)
+        done_n = torch.rand(M, generator=g) < 0.1
+        isw = torch.rand(M, generator=g) if pri else None
+        discount, n_step = 0.99, 3
+        q = select_at_indexes(action, qs)
+        with torch.no_grad():
+            if double:
+                target_q = select_at_indexes(torch.argmax(next_qs, dim=-1), target_qs)
+            else:
+                target_q = torch.max(target_qs, dim=-1).values
+        disc_target_q = (discount ** n_step) * target_q
+        y = return_ + (1 - done_n.float()) * disc_target_q
+        delta = y - q
+        losses = 0.5 * delta ** 2
+        abs_delta = abs(delta)
+        if clip is not None:
+            b = clip * (abs_delta - clip / 2)
+            losses = torch.where(abs_delta <= clip, losses, b)
+        if pri:
+            losses *= isw
+        td = abs_delta.detach()
+        if clip is not None:
+            td = torch.clamp(td, 0, clip)
+        loss = torch.mean(losses)
+        loss.backward()
+        out.update({f"{name}_qs": qs.detach().numpy(), f"{name}_target_qs": target_qs.numpy(),
+                    f"{name}_next_qs": next_qs.numpy(), f"{name}_action": action.numpy(),
+                    f"{name}_ret": return_.numpy(), f"{name}_done_n": done_n.numpy(),
+                    f"{name}_double": np.bool_(double),
+                    f"{name}_clip": np.float64(-1.0 if clip is None else clip),
+                    f"{name}_disc_n": np.float64(discount ** n_step),
+                    f"{name}_loss": np.float32(loss.item()), f"{name}_td": td.numpy(),
+                    f"{name}_grad_qs": qs.grad.numpy()})
+        if pri:
+            out[f"{name}_isw"] = isw.numpy()
+    save("losses", **out)
+
+
+def sumtree_stream(T, B, ob, of, n_ops, n_sample, adv_T, seed, input_pri=False, shift=0,
+                   record_tree=False):
+    """Drive the reference SumTree with interleaved advance / sample / update and record the
+    uniforms fed, the indices and priorities returned, and root sums (or whole trees)."""
+    rng = np.random.RandomState(seed)
+    tree = SumTree(T, B, ob, of, default_value=1.0 ** 0.6, enable_input_priorities=input_pri,
+                   input_priority_shift=shift)
+    rec = dict(uniforms=[], T_idxs=[], B_idxs=[], pri=[], new_pri=[], root=[], adv_pri=[],
+               trees=[])
+    for op in range(n_ops):
+        if input_pri:
+            kind = op % 3
+            p = (np.abs(rng.randn(adv_T, B)) ** 0.6 if kind == 0 else
+                 np.abs(rng.randn(B)) ** 0.6 if kind == 1 else
+                 np.abs(rng.randn(1)) ** 0.6)
+            rec["adv_pri"].append(np.broadcast_to(p, (adv_T, B)).copy())
+            tree.advance(adv_T, priorities=p if kind != 2 else float(p[0]))
+        else:
+            tree.advance(adv_T)
+        if tree.tree[0] <= 0:
+            rec["root"].append(tree.tree[0])
+            if record_tree:
+                rec["trees"].append(tree.tree.copy())
+            continue
+        u = rng.rand(n_sample)
+        # inject the uniforms: np.random.rand is what sample() calls (sum_tree.py:107)
+        orig = np.random.rand
+        np.random.rand = lambda n, _u=u: _u.copy()
+        try:
+            (Ti, Bi), pri = tree.sample(n_sample)
+        finally:
+            np.random.rand = orig
+        new_p = np.abs(rng.randn(n_sample)) ** 0.6
+        tree.update_batch_priorities(new_p)
+        rec["uniforms"].append(u)
+        rec["T_idxs"].append(Ti.astype(np.int32))
+        rec["B_idxs"].append(Bi.astype(np.int32))
+        rec["pri"].append(pri.copy())
+        rec["new_pri"].append(new_p)
+        rec["root"].append(tree.tree[0])
+        if record_tree:
+            rec["trees"].append(tree.tree.copy())
+    res = {k: np.array(v) for k, v in rec.items() if len(v)}
+    res.update(T=np.int64(T), B=np.int64(B), ob=np.int64(ob), of=np.int64(of),
+               n_sample=np.int64(n_sample), adv_T=np.int64(adv_T), shift=np.int64(shift),
+               input_pri=np.bool_(input_pri), final_tree_root=np.float64(tree.tree[0]),
+               final_leaves_head=tree.tree[tree.low_idx:tree.low_idx + min(T * B, 4096)].copy(),
+               levels=np.int64(tree.tree_levels), low_idx=np.int64(tree.low_idx))
+    return res
+
+
+def gen_sumtree():
+    out = {}
+    # survey known-answer mini: SumTree(8,2,1,1), advance(4), seed-0 samples (section 8c)
+    t = SumTree(8, 2, 1, 1, default_value=1)
+    t.advance(4)
+    np.random.seed(0)
+    (Ti, Bi), p = t.sample(5)
+    t.update_batch_priorities(np.array([0.5, 2, 3, 0.1, 4]))
+    root_after = t.tree[0]
+    (Ti2, Bi2), p2 = t.sample(5)
+    np.random.seed(0)
+    u_first = np.random.rand(5)
+    u_second = np.random.rand(5)
+    out.update(kat_T1=Ti, kat_B1=Bi, kat_p1=p, kat_root=np.float64(root_after), kat_T2=Ti2,
+               kat_B2=Bi2, kat_p2=p2, kat_u1=u_first, kat_u2=u_second, kat_tree=t.tree.copy())
+    for name, kw in [
+        ("small", dict(T=16, B=3, ob=2, of=3, n_ops=60, n_sample=9, adv_T=3, seed=1,
+                       record_tree=True)),
+        ("wrap", dict(T=10, B=2, ob=1, of=1, n_ops=40, n_sample=6, adv_T=4, seed=2,
+                      record_tree=True)),
+        ("inpri", dict(T=12, B=4, ob=3, of=1, n_ops=50, n_sample=8, adv_T=2, seed=3,
+                       input_pri=True, shift=1, record_tree=True)),
+        ("dqn1m", dict(T=62500, B=16, ob=1, of=3, n_ops=150, n_sample=128, adv_T=2, seed=4)),
+    ]:
+        res = sumtree_stream(**kw)
+        out.update({f"{name}_{k}": v for k, v in res.items()})
+    save("sumtree", **out)
+
+
+def gen_frames():
+    from rlpyt.replays.non_sequence.frame import NStepFrameBuffer
+    from rlpyt.replays.sequence.frame import SequenceNStepFrameBuffer
+    out = {}
+    rng = np.random.RandomState(5)
+    # non-sequence frame gather: call the reference method on a bare object carrying only
+    # the attributes it reads (samples_frames, samples.done, n_frames).
+    for name, T, B, C, H, W, n, p in [("small", 20, 3, 4, 5, 4, 17, 0.15),
+                                      ("c2", 9, 2, 2, 3, 3, 8, 0.3)]:
+        frames = rng.randint(0, 256, size=(T + C - 1, B, H, W)).astype(np.uint8)
+        frames[:C - 1] = frames[-(C - 1):]  # wrapped state: head rows mirror the tail
+        done = rng.rand(T, B) < p
+        T_idxs = rng.randint(0, T, size=n)
+        T_idxs[:3] = [0, 1, T - 1]  # exercise the negative-index wrap of done[T_idxs - f]
+        B_idxs = rng.randint(0, B, size=n)
+
+        class Bare:
+            pass
+        obj = Bare()
+        obj.samples_frames, obj.n_frames = frames, C
+        obj.samples = Bare()
+        obj.samples.done = done
+        obs = NStepFrameBuffer.extract_observation(obj, T_idxs, B_idxs)
+        out.update({f"{name}_frames": frames, f"{name}_done": done, f"{name}_T_idxs": T_idxs,
+                    f"{name}_B_idxs": B_idxs, f"{name}_C": np.int64(C), f"{name}_obs": obs})
+        seq_T = 7 if T > 10 else 4
+        obj.T = T
+        sT = rng.randint(0, T, size=n)
+        sT[:3] = [0, T - 2, T - seq_T]
+        seq = SequenceNStepFrameBuffer.extract_observation(obj, sT, B_idxs, seq_T)
+        out.update({f"{name}_seq_T_idxs": sT, f"{name}_seq_T": np.int64(seq_T),
+                    f"{name}_seq_obs": seq})
+    # extract_sequences incl. wrap-at-end and the negative-start branch
+    arr = rng.randn(11, 3, 2).astype(np.float32)
+    Ti = np.array([0, 5, 9, -1, 10, -2])
+    Bi = np.array([0, 1, 2, 0, 1, 2])
+    out.update(es_arr=arr, es_T_idxs=Ti, es_B_idxs=Bi, es_seq_T=np.int64(4),
+               es_out=extract_sequences(arr, Ti, Bi, 4))
+    save("frames", **out)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    np.random.seed(0)
+    gen_scans()
+    gen_nstep()
+    gen_normalize()
+    gen_losses()
+    gen_sumtree()
+    gen_frames()

@@ -1,0 +1,405 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors generated from
+the real reference, against the CPU oracle on seeded inputs, and -- at BASELINE.json's full
+sizes -- through size-independent properties.
+
+Bars: bit-exact for the EXACT scans, n-step returns, valid masks, sum-tree indices /
+priorities / whole tree, frame and sequence gathers; fp32 tolerance (written per test) for
+the segmented scan, advantage normalisation and the losses (their reductions have no
+defined summation order on either side -- SURVEY.md App. B.1)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from rlpyt_amd import ops as _ops
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return _ops
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def host(x):
+    return x.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------ scans
+@pytest.mark.parametrize("name", ["cfg", "nodone", "dense", "t1", "t2", "kat"])
+def test_scans_golden_bit_exact(ops, name):
+    g = load_golden("scans")
+    r, v, d, bv = (dev(g[f"{name}_{k}"]) for k in ("reward", "value", "done", "bv"))
+    gamma, lam = float(g[f"{name}_gamma"]), float(g[f"{name}_lambda"])
+    adv, ret, valid = ops.gae(r, v, d, bv, gamma, lam, with_valid=True)
+    assert np.array_equal(host(adv), g[f"{name}_adv"])
+    assert np.array_equal(host(ret), g[f"{name}_ret"])
+    assert np.array_equal(host(valid), g[f"{name}_valid"])
+    adv2, ret2 = ops.gae(r, v, d, bv, gamma, lam)
+    assert torch.equal(adv, adv2) and torch.equal(ret, ret2)
+    disc, dadv, dvalid = ops.discount_return(r, d, bv, gamma, value=v, with_valid=True)
+    assert np.array_equal(host(disc), g[f"{name}_disc"])
+    assert np.array_equal(host(dadv), g[f"{name}_disc"] - g[f"{name}_value"])
+    assert np.array_equal(host(dvalid), g[f"{name}_valid"])
+    assert np.array_equal(host(ops.discount_return(r, d, bv, gamma)), g[f"{name}_disc"])
+    assert np.array_equal(host(ops.valid_from_done(d)), g[f"{name}_valid"])
+
+
+def test_scan_1d_and_trailing_dims(ops):
+    g = load_golden("scans")
+    adv, ret = ops.gae(dev(g["oned_reward"]), dev(g["oned_value"]), dev(g["oned_done"]),
+                       dev(g["oned_bv"]), 0.99, 0.9)
+    assert np.array_equal(host(adv), g["oned_adv"]) and np.array_equal(host(ret), g["oned_ret"])
+    # [T,B,K] trailing dims: flattened columns
+    rng = np.random.RandomState(0)
+    r = rng.randn(12, 5, 3).astype(np.float32)
+    v = rng.randn(12, 5, 3).astype(np.float32)
+    d = rng.rand(12, 5, 3) < 0.2
+    bv = rng.randn(1, 5, 3).astype(np.float32)
+    adv, ret = ops.gae(dev(r), dev(v), dev(d), dev(bv), 0.99, 0.95)
+    ea, er = O.generalized_advantage_estimation(r, v, d, bv, 0.99, 0.95)
+    assert np.array_equal(host(adv), ea) and np.array_equal(host(ret), er)
+
+
+@pytest.mark.parametrize("T,N,p", [(128, 256, 0.01), (128, 4096, 0.01), (7, 65536 + 4, 0.3),
+                                   (40, 70001, 0.05), (128, 1 << 20, 0.01), (1, 1, 1.0),
+                                   (3, 63, 0.0), (300, 130, 0.02)])
+def test_scans_vs_oracle_bit_exact(ops, T, N, p):
+    """All launch geometries (1 and 4 columns per lane, ragged N) against the oracle."""
+    rng = np.random.RandomState(T * 7 + N % 1000)
+    r = (0.5 * rng.randn(T, N)).astype(np.float32)
+    v = rng.randn(T, N).astype(np.float32)
+    d = rng.rand(T, N) < p
+    bv = rng.randn(1, N).astype(np.float32)
+    adv, ret, valid = ops.gae(dev(r), dev(v), dev(d), dev(bv), 0.99, 0.98, with_valid=True)
+    ea, er = O.generalized_advantage_estimation(r, v, d, bv, 0.99, 0.98)
+    assert np.array_equal(host(adv), ea)
+    assert np.array_equal(host(ret), er)
+    assert np.array_equal(host(valid), O.valid_from_done(d))
+    disc = ops.discount_return(dev(r), dev(d), dev(bv), 0.99)
+    assert np.array_equal(host(disc), O.discount_return(r, d, bv, 0.99))
+    assert np.array_equal(host(ops.valid_from_done(dev(d))), O.valid_from_done(d))
+
+
+def test_scan_empty(ops):
+    z = torch.zeros(0, 4, device="cuda")
+    adv, ret = ops.gae(z, z, z.bool(), torch.zeros(1, 4, device="cuda"), 0.99, 0.9)
+    assert adv.shape == (0, 4)
+    z = torch.zeros(5, 0, device="cuda")
+    adv, ret = ops.gae(z, z, z.bool(), torch.zeros(1, 0, device="cuda"), 0.99, 0.9)
+    assert ret.shape == (5, 0)
+
+
+@pytest.mark.parametrize("T,N", [(128, 256), (64, 32), (5, 16), (250, 100), (2, 1)])
+def test_segmented_scan_tolerance(ops, T, N):
+    """Re-associated latency variant: rtol 1e-5 / atol 2e-6 against the exact oracle."""
+    rng = np.random.RandomState(T + N)
+    r = (0.5 * rng.randn(T, N)).astype(np.float32)
+    v = rng.randn(T, N).astype(np.float32)
+    d = rng.rand(T, N) < 0.02
+    bv = rng.randn(1, N).astype(np.float32)
+    adv, ret, valid = ops.gae(dev(r), dev(v), dev(d), dev(bv), 0.99, 0.98, with_valid=True,
+                              variant=ops.SCAN_SEGMENTED)
+    ea, er = O.generalized_advantage_estimation(r, v, d, bv, 0.99, 0.98)
+    np.testing.assert_allclose(host(adv), ea, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(host(ret), er, rtol=1e-5, atol=2e-6)
+    assert np.array_equal(host(valid), O.valid_from_done(d))
+    disc, dadv = ops.discount_return(dev(r), dev(d), dev(bv), 0.99, value=dev(v),
+                                     variant=ops.SCAN_SEGMENTED)
+    np.testing.assert_allclose(host(disc), O.discount_return(r, d, bv, 0.99), rtol=1e-5,
+                               atol=2e-6)
+
+
+def test_scan_properties_full_size(ops):
+    """Size-independent properties at a scaled shape (T=128, N=2^20):
+    lambda=1 GAE return == discounted return (up to fp32 re-association);
+    all-done => advantage = reward - value exactly; linearity in reward for done=0."""
+    T, N = 128, 1 << 20
+    g = torch.Generator(device="cuda").manual_seed(0)
+    r = 0.5 * torch.randn(T, N, device="cuda", generator=g)
+    v = torch.randn(T, N, device="cuda", generator=g)
+    d = torch.rand(T, N, device="cuda", generator=g) < 0.01
+    bv = torch.randn(1, N, device="cuda", generator=g)
+    adv, ret = ops.gae(r, v, d, bv, 0.99, 1.0)
+    disc = ops.discount_return(r, d, bv, 0.99)
+    torch.testing.assert_close(ret, disc, rtol=1e-4, atol=1e-4)
+    ones = torch.ones_like(d)
+    adv, ret = ops.gae(r, v, ones, bv, 0.99, 0.98)
+    assert torch.equal(adv, r - v) and torch.equal(ret, (r - v) + v)
+    zeros = torch.zeros_like(d)
+    a1, _ = ops.gae(r, torch.zeros_like(v), zeros, torch.zeros_like(bv), 0.99, 0.98)
+    a2, _ = ops.gae(2 * r, torch.zeros_like(v), zeros, torch.zeros_like(bv), 0.99, 0.98)
+    assert torch.equal(a2, 2 * a1)  # scaling by 2 is exact in fp32
+
+
+# ----------------------------------------------------------------------------------- n-step
+@pytest.mark.parametrize("name", ["r2d1", "n3", "n1", "n2"])
+def test_nstep_golden_bit_exact(ops, name):
+    g = load_golden("nstep")
+    r, d = dev(g[f"{name}_reward"]), dev(g[f"{name}_done"])
+    n, gamma = int(g[f"{name}_n"]), float(g[f"{name}_gamma"])
+    ret, dn = ops.discount_return_n_step(r, d, n, gamma)
+    assert np.array_equal(host(ret), g[f"{name}_ret"])
+    assert np.array_equal(host(dn), g[f"{name}_done_n"])
+    ret, dn = ops.discount_return_n_step(r, d, n, gamma, do_truncated=True)
+    assert np.array_equal(host(ret), g[f"{name}_ret_trunc"])
+    assert np.array_equal(host(dn), g[f"{name}_done_n_trunc"])
+
+
+@pytest.mark.parametrize("T,N,n", [(130, 4096, 5), (9, 33, 3), (50, 1 << 16, 2)])
+def test_nstep_vs_oracle(ops, T, N, n):
+    rng = np.random.RandomState(n)
+    r = rng.randn(T, N).astype(np.float32)
+    d = rng.rand(T, N) < 0.05
+    for trunc in (False, True):
+        ret, dn = ops.discount_return_n_step(dev(r), dev(d), n, 0.997, do_truncated=trunc)
+        er, edn = O.discount_return_n_step(r, d, n, 0.997, do_truncated=trunc)
+        assert np.array_equal(host(ret), er) and np.array_equal(host(dn), edn)
+
+
+# -------------------------------------------------------------------------------- normalise
+@pytest.mark.parametrize("name", ["cfg", "small"])
+def test_normalize_golden(ops, name):
+    """Reductions re-associate: rtol 2e-5 / atol 2e-6 (statistics accumulate in f64 here)."""
+    g = load_golden("normalize")
+    a = dev(g[f"{name}_adv"]).clone()
+    ops.normalize_advantage_(a)
+    np.testing.assert_allclose(host(a), g[f"{name}_norm_all"], rtol=2e-5, atol=2e-6)
+    a = dev(g[f"{name}_adv"]).clone()
+    _, stats = ops.normalize_advantage_(a, dev(g[f"{name}_valid"]), return_stats=True)
+    np.testing.assert_allclose(host(a), g[f"{name}_norm_valid"], rtol=2e-5, atol=2e-6)
+    sel = g[f"{name}_adv"][g[f"{name}_valid"] > 0]
+    np.testing.assert_allclose(host(stats), [sel.mean(), sel.std(ddof=1), sel.size], rtol=1e-5)
+
+
+def test_normalize_large(ops):
+    x = torch.randn(128 * (1 << 16), device="cuda") * 3 + 1
+    y = x.clone()
+    ops.normalize_advantage_(y)
+    ref = (x - x.mean()) / x.std()
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------- losses
+def _check_pg(ops, g, name, kind):
+    t = lambda k: dev(g[f"{name}_{k}"])  # noqa: E731
+    valid = t("valid") if f"{name}_valid" in g else None
+    if kind == "ppo":
+        pn, v = t("prob_new").requires_grad_(True), t("value").requires_grad_(True)
+        loss, sc = ops.ppo_loss(pn, v, t("prob_old"), t("action"), t("adv"), t("ret"), valid,
+                                float(g[f"{name}_clip"]), 1.0, 0.01)
+    else:
+        pn, v = t("prob").requires_grad_(True), t("value").requires_grad_(True)
+        loss, sc = ops.a2c_loss(pn, v, t("action"), t("adv"), t("ret"), valid, 0.5, 0.01)
+    loss.backward()
+    # fp32 tolerance: rtol 1e-5 on the scalars (reduction order), 1e-5 / 1e-8 on gradients
+    np.testing.assert_allclose(host(sc), g[f"{name}_scalars"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(pn.grad), g[f"{name}_grad_prob"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(host(v.grad), g[f"{name}_grad_value"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["ppo_cfg", "ppo_valid", "ppo_a18"])
+def test_ppo_loss_golden(ops, name):
+    _check_pg(ops, load_golden("losses"), name, "ppo")
+
+
+@pytest.mark.parametrize("name", ["a2c_cfg", "a2c_valid"])
+def test_a2c_loss_golden(ops, name):
+    _check_pg(ops, load_golden("losses"), name, "a2c")
+
+
+@pytest.mark.parametrize("M,A,with_valid", [(8192, 6, False), (8192, 6, True), (1, 2, False),
+                                            (300000, 4, True), (255, 18, False)])
+def test_ppo_loss_vs_oracle(ops, M, A, with_valid):
+    g = torch.Generator().manual_seed(M + A)
+    pn = torch.softmax(torch.randn(M, A, generator=g), -1)
+    po = torch.softmax(torch.randn(M, A, generator=g) * 0.3 + torch.log(pn), -1)
+    a = torch.randint(0, A, (M,), generator=g)
+    adv, ret, v = (torch.randn(M, generator=g) for _ in range(3))
+    valid = (torch.rand(M, generator=g) > 0.3).float() if with_valid else None
+    pn_c, v_c = pn.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    ref = O.ppo_loss_torch(pn_c, v_c, po, a, adv, ret, valid, 0.1, 1.0, 0.01)
+    ref[0].backward()
+    pn_d, v_d = pn.cuda().requires_grad_(True), v.cuda().requires_grad_(True)
+    loss, sc = ops.ppo_loss(pn_d, v_d, po.cuda(), a.cuda(), adv.cuda(), ret.cuda(),
+                            None if valid is None else valid.cuda(), 0.1, 1.0, 0.01)
+    (2.0 * loss).backward()  # also checks the incoming-gradient scaling
+    np.testing.assert_allclose(host(sc), [x.item() for x in ref], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(host(pn_d.grad), 2 * pn_c.grad.numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(host(v_d.grad), 2 * v_c.grad.numpy(), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["dqn", "ddqn", "dqn_mse"])
+def test_dqn_loss_golden(ops, name):
+    g = load_golden("losses")
+    t = lambda k: dev(g[f"{name}_{k}"])  # noqa: E731
+    qs = t("qs").requires_grad_(True)
+    clip = float(g[f"{name}_clip"])
+    loss, td = ops.dqn_loss(qs, t("target_qs"), t("next_qs") if bool(g[f"{name}_double"])
+                            else None, t("action"), t("ret"), t("done_n"),
+                            t("isw") if f"{name}_isw" in g else None,
+                            float(g[f"{name}_disc_n"]), None if clip < 0 else clip)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[f"{name}_loss"], rtol=1e-5)
+    np.testing.assert_allclose(host(td), g[f"{name}_td"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(host(qs.grad), g[f"{name}_grad_qs"], rtol=1e-5, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------- gathers
+def test_gather_tb_exact(ops):
+    rng = np.random.RandomState(0)
+    T, B = 16, 8
+    idx = rng.permutation(T * B)[:50]
+    for shape, dt in [((4, 13, 10), np.uint8), ((6,), np.float32), ((), np.int64),
+                      ((3,), np.uint8), ((4, 104, 80), np.uint8)]:
+        src = rng.randint(0, 255, size=(T, B) + shape).astype(dt)
+        out = ops.gather_tb(dev(src), dev(idx))
+        assert np.array_equal(host(out), src[idx % T, idx // T])
+    t_idx = rng.randint(-1, T, size=40)
+    b_idx = rng.randint(0, B, size=40)
+    src = rng.randn(T, B, 5).astype(np.float32)
+    assert np.array_equal(host(ops.gather_rows(dev(src), dev(t_idx), dev(b_idx))),
+                          src[t_idx, b_idx])
+
+
+def test_gather_tb_full_size_permutation_roundtrip(ops):
+    """PPO config shape: gathering all 4 minibatches of a permutation moves every row once."""
+    T, B = 128, 256
+    obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, device="cuda")
+    perm = torch.randperm(T * B, device="cuda")
+    mb = T * B // 4
+    total = torch.zeros((), dtype=torch.int64, device="cuda")
+    for k in range(4):
+        idx = perm[k * mb:(k + 1) * mb]
+        out = ops.gather_tb(obs, idx)
+        ref = obs[idx % T, idx // T]
+        assert torch.equal(out, ref)
+        total += out.sum(dtype=torch.int64)
+    assert total.item() == obs.sum(dtype=torch.int64).item()
+
+
+@pytest.mark.parametrize("name", ["small", "c2"])
+def test_frames_golden_bit_exact(ops, name):
+    g = load_golden("frames")
+    C = int(g[f"{name}_C"])
+    obs = ops.frames_gather(dev(g[f"{name}_frames"]), dev(g[f"{name}_done"]),
+                            dev(g[f"{name}_T_idxs"]), dev(g[f"{name}_B_idxs"]), C)
+    assert np.array_equal(host(obs), g[f"{name}_obs"])
+    seq = ops.frames_gather_seq(dev(g[f"{name}_frames"]), dev(g[f"{name}_done"]),
+                                dev(g[f"{name}_seq_T_idxs"]), dev(g[f"{name}_B_idxs"]), C,
+                                int(g[f"{name}_seq_T"]))
+    assert np.array_equal(host(seq), g[f"{name}_seq_obs"])
+
+
+def test_frames_atari_shape_vs_oracle(ops):
+    """Atari frame shape (104x80), ring with wrap duplicates, dones near the samples."""
+    rng = np.random.RandomState(3)
+    T, B, C, H, W, n = 500, 16, 4, 104, 80, 128
+    frames = rng.randint(0, 256, size=(T + C - 1, B, H, W)).astype(np.uint8)
+    frames[:C - 1] = frames[-(C - 1):]
+    done = rng.rand(T, B) < 0.05
+    T_idxs, B_idxs = rng.randint(0, T, size=n), rng.randint(0, B, size=n)
+    obs = ops.frames_gather(dev(frames), dev(done), dev(T_idxs), dev(B_idxs), C)
+    assert np.array_equal(host(obs), O.frames_gather(frames, done, T_idxs, B_idxs, C))
+    sT = rng.randint(0, T, size=8)
+    sT[0] = T - 5
+    seq = ops.frames_gather_seq(dev(frames), dev(done), dev(sT), dev(B_idxs[:8]), C, 25)
+    assert np.array_equal(host(seq), O.frames_gather_seq(frames, done, sT, B_idxs[:8], C, 25))
+
+
+def test_extract_sequences_golden(ops):
+    g = load_golden("frames")
+    out = ops.extract_sequences(dev(g["es_arr"]), dev(g["es_T_idxs"]), dev(g["es_B_idxs"]),
+                                int(g["es_seq_T"]))
+    assert np.array_equal(host(out), g["es_out"])
+
+
+# --------------------------------------------------------------------------------- sum tree
+def _device_tree_api(ops):
+    def make(T, B, ob, of, input_pri, shift):
+        return ops.DeviceSumTree(T, B, ob, of, default_value=1.0,
+                                 enable_input_priorities=input_pri, input_priority_shift=shift)
+
+    def sample(tree, u):
+        Ti, Bi, pri = tree.sample(dev(u))
+        return host(Ti), host(Bi), host(pri)
+
+    def root(tree):
+        return tree.tree_tensor()[0].item()
+    return dict(make_tree=make, sample=sample,
+                update=lambda tree, p: tree.update_batch_priorities(dev(p)),
+                advance=lambda tree, T, p: tree.advance(T, None if p is None else dev(p)),
+                root=root, tree_of=lambda tree: host(tree.tree_tensor()))
+
+
+@pytest.mark.parametrize("name", ["small", "wrap", "inpri", "dqn1m"])
+def test_sumtree_streams_bit_exact(ops, name):
+    """Indices, priorities, root sums (and whole trees for the small streams) recorded from
+    the reference SumTree, replayed on the HBM tree with the same uniforms."""
+    from test_oracle_golden import replay_sumtree_stream
+    g = load_golden("sumtree")
+    tree = replay_sumtree_stream(g, name, **_device_tree_api(ops))
+    full = host(tree.tree_tensor())
+    assert full[0] == float(g[f"{name}_final_tree_root"])
+    n = len(g[f"{name}_final_leaves_head"])
+    assert np.array_equal(full[tree.low_idx:tree.low_idx + n], g[f"{name}_final_leaves_head"])
+    assert tree.tree_levels == int(g[f"{name}_levels"]) and tree.low_idx == int(g[f"{name}_low_idx"])
+
+
+def test_sumtree_known_answer(ops):
+    g = load_golden("sumtree")
+    t = ops.DeviceSumTree(8, 2, 1, 1, default_value=1)
+    t.advance(4)
+    assert t.tree_tensor()[0].item() == 4.0 and t.tree_levels == 6 and t.low_idx == 31
+    Ti, Bi, p = t.sample(dev(g["kat_u1"]))
+    assert host(Ti).tolist() == [2, 2, 2, 2, 1] and host(Bi).tolist() == [0, 0, 0, 0, 1]
+    t.update_batch_priorities(dev(np.array([0.5, 2, 3, 0.1, 4])))
+    assert t.tree_tensor()[0].item() == 6.5
+    Ti, Bi, p = t.sample(dev(g["kat_u2"]))
+    assert np.array_equal(host(Ti), g["kat_T2"]) and np.array_equal(host(Bi), g["kat_B2"])
+    assert np.array_equal(host(p), g["kat_p2"])
+    assert np.array_equal(host(t.tree_tensor()), g["kat_tree"])
+
+
+def test_sumtree_vs_oracle_random_stream(ops):
+    """A longer random stream against the oracle incl. whole-tree equality every op."""
+    rng = np.random.RandomState(11)
+    T, B = 200, 8
+    dt = ops.DeviceSumTree(T, B, 3, 3, default_value=1.0)
+    ot = O.SumTree(T, B, 3, 3, default_value=1.0)
+    for op in range(300):
+        k = int(rng.randint(1, 6))
+        dt.advance(k)
+        ot.advance(k)
+        if ot.tree[0] > 0:
+            u = rng.rand(64)
+            (oT, oB), op_ = ot.sample_with(u)
+            Ti, Bi, p = dt.sample(dev(u))
+            assert np.array_equal(host(Ti), oT) and np.array_equal(host(Bi), oB)
+            assert np.array_equal(host(p), op_)
+            newp = np.abs(rng.randn(64)) ** 0.6
+            ot.update_batch_priorities(newp)
+            dt.update_batch_priorities(dev(newp))
+        assert np.array_equal(host(dt.tree_tensor()), ot.tree), op
+        assert dt.t == ot.t
+
+
+def test_sumtree_sampling_distribution(ops):
+    """Property at the 1M-leaf size: sampled frequencies follow the priorities."""
+    T, B = 62500, 16
+    t = ops.DeviceSumTree(T, B, 1, 3, default_value=1.0)
+    for _ in range(50):
+        t.advance(1000)
+    u = torch.rand(200000, dtype=torch.float64, device="cuda")
+    Ti, Bi, p = t.sample(u)
+    assert (p > 0).all()
+    # valid zone only: rows [3, 50000-1)
+    assert int(Ti.min()) >= 3 and int(Ti.max()) < 50000 - 1
+    frac = (Ti < 25000).double().mean().item()
+    assert abs(frac - (25000 - 3) / (49999 - 3)) < 0.01
