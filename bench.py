@@ -1,0 +1,214 @@
+"""bench.py -- BASELINE.json's metric on the MI355X: env-steps/sec (SPS), PPO Atari
+[T=128, B=256] per GPU, 1/2/4/8 GPUs (weak scaling, one process per GPU over RCCL).
+
+A "step" = one full PPO iteration of the hot path on one synthetic batch:
+  rollout of T x B env steps (host envs, batched action selection on the device, sample
+  batch resident in HBM) -> fused GAE scan -> epochs x minibatches of {device gather,
+  AtariFfModel forward, fused PPO loss fwd+bwd kernel, backward, grad-clip, Adam}
+  (under N>1: DistributedDataParallel all-reduces the 7.14 MB of gradients per minibatch).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      -- the dominant own kernel of the timed region (the HBM->HBM minibatch
+                   observation gather), HIP-event timed live inside the timed steps;
+  kernels       -- the same live measurement for the other path kernels (GAE scan, PPO loss);
+  roofline_gae_scaled -- the GAE scan at T=128, N=2^20 columns (the shape at which the
+                   HBM criterion of BASELINE.md section 3 is meaningful), timed in this run;
+  cpu_baseline  -- the oracle's CPU port of the reference iteration (oracle/ppo_cpu_port.py)
+                   timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+Data: synthetic Atari-shaped env (no ALE in the image), random-init weights.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-T", type=int, default=128)
+    ap.add_argument("--batch-B", type=int, default=256)
+    ap.add_argument("--workers", type=int, default=-1, help="env worker processes per rank "
+                    "(-1: host cores / ranks, capped at B/4)")
+    ap.add_argument("--env-cost-us", type=float, default=0., help="declared extra host cost "
+                    "per env step (busy wait) to emulate an ALE-like emulator")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-B", type=int, default=32)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    import torch.distributed as dist
+
+    from rlpyt_amd.agents.pg.atari import AtariFfAgent
+    from rlpyt_amd.algos.pg.ppo import PPO
+    from rlpyt_amd.envs.synthetic import SyntheticPong
+    from rlpyt_amd.samplers.collections import AtariTrajInfo
+    from rlpyt_amd.samplers.gpu import GpuSampler
+    from rlpyt_amd.utils import ktimer, logger
+    from rlpyt_amd.utils.seed import set_seed
+    logger.set_quiet(True)
+
+    T, B = args.batch_T, args.batch_B
+    ncpu = os.cpu_count() or 8
+    workers = args.workers
+    if workers < 0:
+        workers = max(min((ncpu - 2 * world) // world, B // 4), 0)
+    env_kwargs = dict(step_cost_us=args.env_cost_us)
+    n_itr_total = args.warmup + args.steps
+
+    # --- build the stack in the reference's order: sampler (forks workers) BEFORE any HIP
+    #     call, then device placement, then DDP, then the algorithm ------------------------
+    seed = 0 + 100 * rank
+    set_seed(seed)
+    sampler = GpuSampler(SyntheticPong, env_kwargs, batch_T=T, batch_B=B, n_workers=workers,
+                         TrajInfoCls=AtariTrajInfo, max_decorrelation_steps=100)
+    agent = AtariFfAgent()
+    algo = PPO(discount=0.99, learning_rate=1e-3, value_loss_coeff=1., entropy_loss_coeff=0.01,
+               clip_grad_norm=1., gae_lambda=0.98, minibatches=4, epochs=4, ratio_clip=0.1,
+               linear_lr_schedule=True, normalize_advantage=False)
+    examples = sampler.initialize(agent, seed=seed + 1, bootstrap_value=True, rank=rank,
+                                  world_size=world)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    agent.to_device(local_rank)
+    if world > 1:
+        agent.data_parallel()
+    algo.initialize(agent=agent, n_itr=max(n_itr_total, 1), batch_spec=sampler.batch_spec,
+                    mid_batch_reset=sampler.mid_batch_reset, examples=examples,
+                    world_size=world, rank=rank)
+
+    def one_step(itr):
+        agent.sample_mode(itr)
+        samples, _infos = sampler.obtain_samples(itr)
+        agent.train_mode(itr)
+        return algo.optimize_agent(itr, samples)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for itr in range(args.warmup):
+        one_step(itr)
+    if not args.no_kernel_timing:
+        ktimer.reset()
+        ktimer.enable(True)
+    sync()
+    t0 = time.perf_counter()
+    t_sample = 0.
+    for k in range(args.steps):
+        itr = args.warmup + k
+        ts = time.perf_counter()
+        agent.sample_mode(itr)
+        samples, _infos = sampler.obtain_samples(itr)
+        t_sample += time.perf_counter() - ts
+        agent.train_mode(itr)
+        opt_info = algo.optimize_agent(itr, samples)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ktimer.enable(False)
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = el.item()
+    ksum = ktimer.summary() if not args.no_kernel_timing else {}
+    sampler.shutdown()
+
+    if rank == 0:
+        steps_total = T * B * world * args.steps
+        out = {
+            "metric": "env-steps/sec (SPS) whole node, PPO Atari [T=128,B=256]",
+            "value": steps_total / elapsed, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (Atari-shaped SyntheticPong env on host cores, random-init "
+                    "AtariFfModel)",
+            "config": {"workload": f"PPO AtariFfAgent, GpuSampler T={T} B={B} per GPU, "
+                                   "4 epochs x 4 minibatches, gae_lambda=0.98, Adam lr=1e-3",
+                       "T": T, "B": B, "env_workers_per_gpu": workers,
+                       "env_step_cost_us": args.env_cost_us, "host_cores": ncpu,
+                       "parallelism": f"dp{world}"},
+            "sampling_frac_of_step": t_sample / (elapsed if elapsed > 0 else 1.),
+            "last_loss": opt_info.loss[-1] if opt_info.loss else None,
+        }
+        if ksum:
+            g = ksum.get("gather_tb")
+            if g:
+                out["roofline"] = {"kernel": "gather_wide_kernel (minibatch observation gather)",
+                                   "bound": "hbm", "achieved": g["GBps"],
+                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": g["GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                                   "avg_us": g["avg_us"], "launches": g["launches"],
+                                   "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
+            out["kernels"] = {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv)
+                                  for kk, vv in v.items()} for k, v in ksum.items()}
+        out["roofline_gae_scaled"] = gae_scaled_roofline()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(T, args.cpu_baseline_B, env_kwargs)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def gae_scaled_roofline(T=128, log2n=20, iters=20):
+    """GAE scan at a shape where HBM is the bound: [128, 2^20] (17 B/element)."""
+    from rlpyt_amd import ops
+    N = 1 << log2n
+    r = torch.randn(T, N, device="cuda") * 0.5
+    v = torch.randn(T, N, device="cuda")
+    d = torch.rand(T, N, device="cuda") < 0.01
+    bv = torch.randn(1, N, device="cuda")
+    adv, ret = torch.empty_like(r), torch.empty_like(r)
+    for _ in range(3):
+        ops.gae(r, v, d, bv, 0.99, 0.98, advantage_dest=adv, return_dest=ret)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        ops.gae(r, v, d, bv, 0.99, 0.98, advantage_dest=adv, return_dest=ret)
+    e.record()
+    torch.cuda.synchronize()
+    secs = s.elapsed_time(e) * 1e-3 / iters
+    nbytes = T * N * 17 + 4 * N
+    return {"kernel": "scan_exact_kernel<GAE> [128, 2^20]", "bound": "hbm",
+            "achieved": nbytes / secs / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": nbytes / secs / 1e9 / HBM_PEAK_GBPS, "avg_us": secs * 1e6,
+            "alg_bytes_per_launch": nbytes}
+
+
+def cpu_baseline(T, B_cpu, env_kwargs):
+    """Oracle CPU port of the reference iteration on this box's host cores (bounded sample)."""
+    from oracle.ppo_cpu_port import time_cpu_baseline
+    from rlpyt_amd.envs.synthetic import SyntheticPong
+    threads = os.cpu_count() or 8
+    res = time_cpu_baseline(SyntheticPong, env_kwargs, T=T, B=B_cpu, iters=1, threads=threads)
+    return {"value": res["value"], "unit": "env-steps/s", "cores": res["cores"], "kind": "port",
+            "sample": f"1 PPO iteration at [T={T}, B={B_cpu}] ({T * B_cpu} env steps, 16 "
+                      f"minibatch updates), torch CPU with {res['cores']} threads, "
+                      f"{res['seconds']:.1f} s",
+            "seconds": res["seconds"]}
+
+
+if __name__ == "__main__":
+    main()

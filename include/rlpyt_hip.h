@@ -42,6 +42,12 @@ int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
 
+/* Page-lock (pin) an existing host range so the sampler's fork-shared step buffer
+ * (rlpyt/samplers/parallel/gpu/sampler.py:134-139) can be the source / destination of
+ * asynchronous H2D / D2H copies.  Host pointers; synchronous. */
+int rlpyt_host_register(void* host_ptr, int64_t bytes);
+int rlpyt_host_unregister(void* host_ptr);
+
 /* ------------------------------------------------------------------------------------
  * Return / advantage scans over [T, N] trajectories (N = B * any trailing dims).
  * Coalesced along N, sequential along T.

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "rlpyt_hip_last_error": (c_char_p, []),
     "rlpyt_hip_abi_version": (c_int, []),
     "rlpyt_hip_device_info": (c_int, [c_char_p, c_int]),
+    "rlpyt_host_register": (c_int, [_p, c_int64]),
+    "rlpyt_host_unregister": (c_int, [_p]),
     "rlpyt_gae_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int, c_int64, c_double, c_double,
                               c_int, _p]),
     "rlpyt_discount_return_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int, c_int64, c_double,

@@ -1,0 +1,124 @@
+"""Agent protocol (rlpyt/agents/base.py:17-245): the object the sampler steps and the
+algorithm differentiates through.
+
+MI355X-first difference from the reference: outputs stay in HBM.  The reference's
+``__call__``/``step`` copy model outputs back to the host every call
+(agents/pg/categorical.py:25,42) because its losses and collectors run on CPU tensors;
+here the loss kernels and the rollout buffers live on the device, so outputs are returned
+where the model computed them unless ``host_outputs=True`` (drop-in mode under the
+reference's own CPU samplers/algos).
+"""
+import torch
+
+from ..models.utils import strip_ddp_state_dict
+from ..utils import logger
+from ..utils.collections import namedarraytuple
+from ..utils.quick_args import save__init__args
+
+AgentInputs = namedarraytuple("AgentInputs", ["observation", "prev_action", "prev_reward"])
+AgentStep = namedarraytuple("AgentStep", ["action", "agent_info"])
+AgentInputsRnn = namedarraytuple("AgentInputsRnn",
+                                 ["observation", "prev_action", "prev_reward", "init_rnn_state"])
+
+
+class BaseAgent:
+    recurrent = False
+    alternating = False
+
+    def __init__(self, ModelCls=None, model_kwargs=None, initial_model_state_dict=None,
+                 host_outputs=False):
+        save__init__args(locals())
+        self.model = None
+        self.shared_model = None
+        self.distribution = None
+        self.device = torch.device("cpu")
+        self._mode = None
+        if self.model_kwargs is None:
+            self.model_kwargs = dict()
+
+    def __call__(self, observation, prev_action, prev_reward):
+        raise NotImplementedError
+
+    def initialize(self, env_spaces, share_memory=False, **kwargs):
+        self.env_model_kwargs = self.make_env_to_model_kwargs(env_spaces)
+        self.model = self.ModelCls(**self.env_model_kwargs, **self.model_kwargs)
+        if share_memory:
+            self.model.share_memory()
+            self.shared_model = self.model
+        if self.initial_model_state_dict is not None:
+            self.model.load_state_dict(self.initial_model_state_dict)
+        self.env_spaces = env_spaces
+        self.share_memory = share_memory
+
+    def make_env_to_model_kwargs(self, env_spaces):
+        return {}
+
+    def to_device(self, cuda_idx=None):
+        if cuda_idx is None:
+            return
+        if self.shared_model is not None:
+            self.model = self.ModelCls(**self.env_model_kwargs, **self.model_kwargs)
+            self.model.load_state_dict(self.shared_model.state_dict())
+        self.device = torch.device("cuda", index=cuda_idx)
+        self.model.to(self.device)
+        logger.log(f"Initialized agent model on device: {self.device}.")
+
+    def data_parallel(self):
+        """Wrap the model in DistributedDataParallel: gradient all-reduce rides RCCL over
+        xGMI when the process group backend is "nccl" (gloo on CPU)."""
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        device_id = self.device.index
+        self.model = DDP(self.model, device_ids=None if device_id is None else [device_id],
+                         output_device=device_id)
+        logger.log(f"Initialized DistributedDataParallel agent model on device {self.device}.")
+        return device_id
+
+    def collector_initialize(self, global_B=1, env_ranks=None):
+        pass
+
+    def step(self, observation, prev_action, prev_reward):
+        raise NotImplementedError
+
+    def reset(self):
+        pass
+
+    def reset_one(self, idx):
+        pass
+
+    def parameters(self):
+        return self.model.parameters()
+
+    def state_dict(self):
+        return self.model.state_dict()
+
+    def load_state_dict(self, state_dict):
+        self.model.load_state_dict(state_dict)
+
+    def train_mode(self, itr):
+        self.model.train()
+        self._mode = "train"
+
+    def sample_mode(self, itr):
+        self.model.eval()
+        self._mode = "sample"
+
+    def eval_mode(self, itr):
+        self.model.eval()
+        self._mode = "eval"
+
+    def sync_shared_memory(self):
+        if self.shared_model is not None and self.shared_model is not self.model:
+            self.shared_model.load_state_dict(strip_ddp_state_dict(self.model.state_dict()))
+
+    def toggle_alt(self):
+        pass
+
+    # -- helpers ------------------------------------------------------------------------
+    def _to_model_device(self, *xs):
+        return tuple(x if (x is None or x.device == self.device)
+                     else x.to(self.device, non_blocking=True) for x in xs)
+
+    def _out(self, x):
+        """Leave outputs in HBM unless running in reference drop-in mode."""
+        from ..utils.buffer import buffer_to
+        return buffer_to(x, device="cpu") if self.host_outputs else x

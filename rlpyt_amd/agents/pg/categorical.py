@@ -1,0 +1,39 @@
+"""Categorical policy-gradient agent (rlpyt/agents/pg/categorical.py:11-51)."""
+import torch
+
+from ...distributions.categorical import Categorical, DistInfo
+from ...utils.collections import namedarraytuple
+from ..base import AgentStep, BaseAgent
+
+AgentInfo = namedarraytuple("AgentInfo", ["dist_info", "value"])
+
+
+class CategoricalPgAgent(BaseAgent):
+    def __call__(self, observation, prev_action, prev_reward):
+        """Training forward: (DistInfo(prob), value), differentiable, in HBM."""
+        prev_action = self.distribution.to_onehot(prev_action)
+        obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
+        pi, value = self.model(obs, pa, pr)
+        return self._out((DistInfo(prob=pi), value))
+
+    def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
+        super().initialize(env_spaces, share_memory, global_B=global_B, env_ranks=env_ranks)
+        self.distribution = Categorical(dim=env_spaces.action.n)
+
+    @torch.no_grad()
+    def step(self, observation, prev_action, prev_reward):
+        """Sampling forward: one batched model call + on-device multinomial."""
+        prev_action = self.distribution.to_onehot(prev_action)
+        obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
+        pi, value = self.model(obs, pa, pr)
+        dist_info = DistInfo(prob=pi)
+        action = self.distribution.sample(dist_info)
+        agent_info = AgentInfo(dist_info=dist_info, value=value)
+        return self._out(AgentStep(action=action, agent_info=agent_info))
+
+    @torch.no_grad()
+    def value(self, observation, prev_action, prev_reward):
+        prev_action = self.distribution.to_onehot(prev_action)
+        obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
+        _pi, value = self.model(obs, pa, pr)
+        return self._out(value)

@@ -1,0 +1,49 @@
+"""A2C on the MI355X (API of rlpyt/algos/pg/a2c.py:12-103): one gradient step per batch,
+returns from the fused scan, loss + gradients from the fused A2C kernel."""
+import torch
+
+from ... import ops
+from ...agents.base import AgentInputs
+from ...utils.quick_args import save__init__args
+from .base import OptInfo, PolicyGradientAlgo
+
+
+class A2C(PolicyGradientAlgo):
+    def __init__(self, discount=0.99, learning_rate=0.001, value_loss_coeff=0.5,
+                 entropy_loss_coeff=0.01, OptimCls=torch.optim.Adam, optim_kwargs=None,
+                 clip_grad_norm=1., initial_optim_state_dict=None, gae_lambda=1,
+                 normalize_advantage=False):
+        if optim_kwargs is None:
+            optim_kwargs = dict()
+        save__init__args(locals())
+
+    def initialize(self, *args, **kwargs):
+        super().initialize(*args, **kwargs)
+        self._batch_size = self.batch_spec.size
+
+    def optimize_agent(self, itr, samples):
+        if hasattr(self.agent, "update_obs_rms"):
+            self.agent.update_obs_rms(samples.env.observation)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss, scalars = self.loss(samples)
+        loss.backward()
+        grad_norm = torch.nn.utils.clip_grad_norm_(self.agent.parameters(),
+                                                   self.clip_grad_norm)
+        self.optimizer.step()
+        host = torch.stack([scalars[0], grad_norm.to(scalars.dtype), scalars[3],
+                            scalars[4]]).cpu().tolist()
+        self.update_counter += 1
+        return OptInfo(loss=host[0], gradNorm=host[1], entropy=host[2], perplexity=host[3])
+
+    def loss(self, samples):
+        dev = self.agent.device
+        mv = lambda x: x if x.device == dev else x.to(dev, non_blocking=True)  # noqa: E731
+        agent_inputs = AgentInputs(observation=mv(samples.env.observation),
+                                   prev_action=mv(samples.agent.prev_action),
+                                   prev_reward=mv(samples.env.prev_reward))
+        if self.agent.recurrent:
+            raise NotImplementedError("recurrent A2C is outside the hot-path scope")
+        dist_info, value = self.agent(*agent_inputs)
+        return_, advantage, valid = self.process_returns(samples)
+        return ops.a2c_loss(dist_info.prob, value, mv(samples.agent.action), advantage, return_,
+                            valid, self.value_loss_coeff, self.entropy_loss_coeff)

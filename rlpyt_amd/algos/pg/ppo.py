@@ -1,0 +1,107 @@
+"""PPO on the MI355X (API and hyper-parameters of rlpyt/algos/pg/ppo.py:16-154).
+
+What changed underneath, relative to the reference's ``optimize_agent``:
+* the sample batch is already in HBM (GpuSampler) -- no bulk H2D (ppo.py:72);
+* ``process_returns`` is one fused HIP scan (+ an in-place normalise);
+* each minibatch is gathered on the device with ``rlpyt_gather_tb`` honouring the
+  reference's index map ``idx -> (idx % T, idx // T)`` (ppo.py:94-95);
+* ratio / clip / min-surrogate / value MSE / entropy / perplexity and all their gradients
+  are ONE fused forward+backward kernel (ppo.py:136-153) feeding autograd;
+* per-minibatch diagnostics stay on the device; a single D2H per iteration replaces the
+  reference's 4 ``.item()`` syncs per minibatch (ppo.py:106-109).
+"""
+import numpy as np
+import torch
+
+from ... import ops
+from ...agents.base import AgentInputs
+from ...utils.buffer import buffer_method
+from ...utils.collections import namedarraytuple
+from ...utils.misc import iterate_mb_idxs
+from ...utils.quick_args import save__init__args
+from .base import OptInfo, PolicyGradientAlgo
+
+LossInputs = namedarraytuple("LossInputs", ["agent_inputs", "action", "return_", "advantage",
+                                            "valid", "old_dist_info"])
+
+
+class PPO(PolicyGradientAlgo):
+    def __init__(self, discount=0.99, learning_rate=0.001, value_loss_coeff=1.,
+                 entropy_loss_coeff=0.01, OptimCls=torch.optim.Adam, optim_kwargs=None,
+                 clip_grad_norm=1., initial_optim_state_dict=None, gae_lambda=1,
+                 minibatches=4, epochs=4, ratio_clip=0.1, linear_lr_schedule=True,
+                 normalize_advantage=False):
+        if optim_kwargs is None:
+            optim_kwargs = dict()
+        save__init__args(locals())
+
+    def initialize(self, *args, **kwargs):
+        super().initialize(*args, **kwargs)
+        self._batch_size = self.batch_spec.size // self.minibatches
+        if self.linear_lr_schedule:
+            self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(
+                optimizer=self.optimizer, lr_lambda=lambda itr: (self.n_itr - itr) / self.n_itr)
+            self._ratio_clip = self.ratio_clip
+
+    def optimize_agent(self, itr, samples):
+        recurrent = self.agent.recurrent
+        dev = self.agent.device
+        mv = lambda x: x if x.device == dev else x.to(dev, non_blocking=True)  # noqa: E731
+        agent_inputs = AgentInputs(observation=mv(samples.env.observation),
+                                   prev_action=mv(samples.agent.prev_action),
+                                   prev_reward=mv(samples.env.prev_reward))
+        if hasattr(self.agent, "update_obs_rms"):
+            self.agent.update_obs_rms(agent_inputs.observation)
+        return_, advantage, valid = self.process_returns(samples)
+        action = mv(samples.agent.action)
+        old_prob = mv(samples.agent.agent_info.dist_info.prob)
+        if recurrent:
+            init_rnn_state = samples.agent.agent_info.prev_rnn_state[0]
+        T, B = samples.env.reward.shape[:2]
+        batch_size = B if recurrent else T * B
+        mb_size = batch_size // self.minibatches
+        stats = []
+        # [T,B] fields the gather kernel can slice need contiguous storage; prev_action /
+        # prev_reward are [:-1] views of [T+1,B] arrays (contiguous as [T,B] blocks).
+        for _ in range(self.epochs):
+            for idxs in iterate_mb_idxs(batch_size, mb_size, shuffle=True):
+                self.optimizer.zero_grad(set_to_none=True)
+                if recurrent:
+                    raise NotImplementedError("recurrent PPO is outside the hot-path scope")
+                idx_dev = torch.from_numpy(np.ascontiguousarray(idxs)).to(dev, non_blocking=True)
+                mb_inputs = AgentInputs(*(ops.gather_tb(f.contiguous(), idx_dev)
+                                          for f in agent_inputs))
+                mb_action = ops.gather_tb(action.contiguous(), idx_dev)
+                mb_return = ops.gather_tb(return_, idx_dev)
+                mb_adv = ops.gather_tb(advantage, idx_dev)
+                mb_valid = None if valid is None else ops.gather_tb(valid, idx_dev)
+                mb_old_prob = ops.gather_tb(old_prob.contiguous(), idx_dev)
+                loss, scalars = self.loss(mb_inputs, mb_action, mb_return, mb_adv, mb_valid,
+                                          mb_old_prob)
+                loss.backward()
+                grad_norm = torch.nn.utils.clip_grad_norm_(self.agent.parameters(),
+                                                           self.clip_grad_norm)
+                self.optimizer.step()
+                # loss, gradNorm, entropy, perplexity -- kept on the device until the end
+                stats.append(torch.stack([scalars[0], grad_norm.to(scalars.dtype), scalars[3],
+                                          scalars[4]]))
+                self.update_counter += 1
+        if self.linear_lr_schedule:
+            self.lr_scheduler.step()
+            self.ratio_clip = self._ratio_clip * (self.n_itr - itr) / self.n_itr
+        host = self._opt_info_to_host(stats)
+        opt_info = OptInfo(*([row[k] for row in host] for k in range(4)))
+        return opt_info
+
+    def loss(self, agent_inputs, action, return_, advantage, valid, old_prob,
+             init_rnn_state=None):
+        """Fused PPO loss on a minibatch (already gathered, all in HBM).  Returns
+        ``(loss, scalars)`` with scalars = [loss, pi_loss, value_loss, entropy, perplexity]."""
+        if init_rnn_state is not None:
+            init_rnn_state = buffer_method(init_rnn_state, "transpose", 0, 1)
+            init_rnn_state = buffer_method(init_rnn_state, "contiguous")
+            dist_info, value, _ = self.agent(*agent_inputs, init_rnn_state)
+        else:
+            dist_info, value = self.agent(*agent_inputs)
+        return ops.ppo_loss(dist_info.prob, value, old_prob, action, advantage, return_, valid,
+                            self.ratio_clip, self.value_loss_coeff, self.entropy_loss_coeff)

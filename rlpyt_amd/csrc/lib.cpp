@@ -33,3 +33,15 @@ extern "C" int rlpyt_hip_device_info(char* name, int cap) {
   }
   return prop.multiProcessorCount;
 }
+
+extern "C" int rlpyt_host_register(void* host_ptr, int64_t bytes) {
+  RL_CHECK_ARG(host_ptr != nullptr && bytes > 0, RLPYT_EINVAL, "rlpyt_host_register: bad range");
+  RL_HIP(hipHostRegister(host_ptr, (size_t)bytes, hipHostRegisterDefault));
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_host_unregister(void* host_ptr) {
+  RL_CHECK_ARG(host_ptr != nullptr, RLPYT_EINVAL, "rlpyt_host_unregister: null pointer");
+  RL_HIP(hipHostUnregister(host_ptr));
+  return RLPYT_OK;
+}

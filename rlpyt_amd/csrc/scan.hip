@@ -385,10 +385,11 @@ extern "C" int rlpyt_gae_f32(const float* reward, const float* value, const uint
                              const float* bootstrap, float* advantage, float* return_,
                              float* valid, int T, int64_t N, double discount,
                              double gae_lambda, int variant, rlpyt_stream_t stream) {
-  RL_CHECK_ARG(reward && value && done && bootstrap && advantage && return_, RLPYT_EINVAL,
-               "rlpyt_gae_f32: null pointer");
   RL_CHECK_ARG(T >= 0 && N >= 0, RLPYT_EINVAL, "rlpyt_gae_f32: negative size T=%d N=%ld", T,
                (long)N);
+  if (T == 0 || N == 0) return RLPYT_OK;  // empty batch: nothing to do (pointers may be null)
+  RL_CHECK_ARG(reward && value && done && bootstrap && advantage && return_, RLPYT_EINVAL,
+               "rlpyt_gae_f32: null pointer");
   RL_CHECK_ARG(variant == RLPYT_SCAN_EXACT || variant == RLPYT_SCAN_SEGMENTED, RLPYT_EINVAL,
                "rlpyt_gae_f32: unknown variant %d", variant);
   if (T == 0 || N == 0) return RLPYT_OK;
@@ -407,11 +408,12 @@ extern "C" int rlpyt_discount_return_f32(const float* reward, const uint8_t* don
                                          const float* value, float* advantage, float* valid,
                                          int T, int64_t N, double discount, int variant,
                                          rlpyt_stream_t stream) {
+  RL_CHECK_ARG(T >= 0 && N >= 0, RLPYT_EINVAL, "rlpyt_discount_return_f32: negative size");
+  if (T == 0 || N == 0) return RLPYT_OK;
   RL_CHECK_ARG(reward && done && bootstrap && return_, RLPYT_EINVAL,
                "rlpyt_discount_return_f32: null pointer");
   RL_CHECK_ARG((value == nullptr) == (advantage == nullptr), RLPYT_EINVAL,
                "rlpyt_discount_return_f32: value and advantage must be given together");
-  RL_CHECK_ARG(T >= 0 && N >= 0, RLPYT_EINVAL, "rlpyt_discount_return_f32: negative size");
   RL_CHECK_ARG(variant == RLPYT_SCAN_EXACT || variant == RLPYT_SCAN_SEGMENTED, RLPYT_EINVAL,
                "rlpyt_discount_return_f32: unknown variant %d", variant);
   if (T == 0 || N == 0) return RLPYT_OK;
@@ -426,8 +428,9 @@ extern "C" int rlpyt_discount_return_f32(const float* reward, const uint8_t* don
 
 extern "C" int rlpyt_valid_from_done(const uint8_t* done, float* valid, int T, int64_t N,
                                      rlpyt_stream_t stream) {
-  RL_CHECK_ARG(done && valid, RLPYT_EINVAL, "rlpyt_valid_from_done: null pointer");
   RL_CHECK_ARG(T >= 0 && N >= 0, RLPYT_EINVAL, "rlpyt_valid_from_done: negative size");
+  if (T == 0 || N == 0) return RLPYT_OK;
+  RL_CHECK_ARG(done && valid, RLPYT_EINVAL, "rlpyt_valid_from_done: null pointer");
   if (T == 0 || N == 0) return RLPYT_OK;
   hipStream_t s = (hipStream_t)stream;
   if (N % 4 == 0 && aligned4(done) && aligned16(valid) && N >= 4 * 256 * 256) {
@@ -446,13 +449,13 @@ extern "C" int rlpyt_nstep_return_f32(const float* reward, const uint8_t* done, 
                                       uint8_t* done_n, int T_in, int64_t N, int n_step,
                                       double discount, int do_truncated,
                                       rlpyt_stream_t stream) {
-  RL_CHECK_ARG(reward && done && return_ && done_n, RLPYT_EINVAL,
-               "rlpyt_nstep_return_f32: null pointer");
   RL_CHECK_ARG(n_step >= 1 && n_step <= 32, RLPYT_EINVAL,
                "rlpyt_nstep_return_f32: n_step=%d outside [1,32]", n_step);
   RL_CHECK_ARG(T_in >= 0 && N >= 0, RLPYT_EINVAL, "rlpyt_nstep_return_f32: negative size");
   const int T_out = do_truncated ? T_in : T_in - (n_step - 1);
   if (T_out <= 0 || N == 0) return RLPYT_OK;
+  RL_CHECK_ARG(reward && done && return_ && done_n, RLPYT_EINVAL,
+               "rlpyt_nstep_return_f32: null pointer");
   NStepCoef coef;
   // Python's float ** int for small ints is repeated multiplication in double (pow());
   // use pow() to match libm exactly as CPython's float_pow does.

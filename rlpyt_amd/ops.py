@@ -10,6 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import check, lib, ptr, stream
+from .utils import ktimer
 
 SCAN_EXACT = 0
 SCAN_SEGMENTED = 1
@@ -53,9 +54,10 @@ def gae(reward, value, done, bootstrap_value, discount, gae_lambda, advantage_de
     adv = advantage_dest if advantage_dest is not None else torch.empty_like(reward)
     ret = return_dest if return_dest is not None else torch.empty_like(reward)
     valid = torch.empty_like(reward) if with_valid else None
-    check(lib.rlpyt_gae_f32(ptr(reward), ptr(value), ptr(done8), ptr(bv), ptr(adv), ptr(ret),
-                            ptr(valid), T, N, float(discount), float(gae_lambda), variant,
-                            stream()), "rlpyt_gae_f32")
+    with ktimer.region("gae", T * N * (21 if with_valid else 17) + 4 * N):
+        check(lib.rlpyt_gae_f32(ptr(reward), ptr(value), ptr(done8), ptr(bv), ptr(adv),
+                                ptr(ret), ptr(valid), T, N, float(discount),
+                                float(gae_lambda), variant, stream()), "rlpyt_gae_f32")
     return (adv, ret, valid) if with_valid else (adv, ret)
 
 
@@ -167,11 +169,11 @@ class _PpoLoss(torch.autograd.Function):
         gp = torch.empty_like(pn)
         gv = torch.empty_like(v)
         ws = _workspace("loss", lib.rlpyt_pg_loss_workspace_bytes(M), pn.device)
-        check(lib.rlpyt_ppo_loss_fwd_bwd_f32(ptr(pn), ptr(v), ptr(po), ptr(act), ptr(adv),
-                                             ptr(ret), ptr(val), M, A, float(ratio_clip),
-                                             float(value_loss_coeff), float(entropy_loss_coeff),
-                                             ptr(out), ptr(gp), ptr(gv), ptr(ws), stream()),
-              "rlpyt_ppo_loss_fwd_bwd_f32")
+        with ktimer.region("ppo_loss", M * (12 * A + 28 + (4 if val is not None else 0))):
+            check(lib.rlpyt_ppo_loss_fwd_bwd_f32(
+                ptr(pn), ptr(v), ptr(po), ptr(act), ptr(adv), ptr(ret), ptr(val), M, A,
+                float(ratio_clip), float(value_loss_coeff), float(entropy_loss_coeff), ptr(out),
+                ptr(gp), ptr(gv), ptr(ws), stream()), "rlpyt_ppo_loss_fwd_bwd_f32")
         ctx.save_for_backward(gp, gv)
         ctx.shapes = (prob_new.shape, value.shape)
         ctx.mark_non_differentiable(out)
@@ -297,8 +299,10 @@ def gather_tb(src, flat_idx, out=None):
     M = flat_idx.numel()
     if out is None:
         out = torch.empty((M,) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
-    check(lib.rlpyt_gather_tb(ptr(src), ptr(flat_idx), ptr(out), T, B, _row_bytes(src, 2), M,
-                              stream()), "rlpyt_gather_tb")
+    rb = _row_bytes(src, 2)
+    with ktimer.region("gather_tb" if rb >= 4096 else "gather_tb_small", 2 * M * rb + 8 * M):
+        check(lib.rlpyt_gather_tb(ptr(src), ptr(flat_idx), ptr(out), T, B, rb, M, stream()),
+              "rlpyt_gather_tb")
     return out
 
 

@@ -1,0 +1,57 @@
+"""Optional HIP-event timing of individual kernel launches on torch's current stream.
+
+``bench.py`` enables it over the timed region to obtain the average launch duration of
+the path's kernels (BASELINE metric's ``roofline`` object); disabled it costs one branch.
+The events are recorded on the SAME stream the C-ABI kernels are launched on
+(``torch.cuda.current_stream()``), so the pair brackets exactly that launch.
+"""
+import torch
+
+_enabled = False
+_records = {}
+
+
+def enable(flag=True):
+    global _enabled
+    _enabled = flag
+
+
+def reset():
+    _records.clear()
+
+
+class _Region:
+    __slots__ = ("name", "nbytes", "s", "e")
+
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        if _enabled:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _enabled:
+            self.e.record()
+            _records.setdefault(self.name, []).append((self.s, self.e, self.nbytes))
+        return False
+
+
+def region(name, nbytes=0):
+    return _Region(name, nbytes)
+
+
+def summary():
+    """{name: dict(launches, avg_us, alg_bytes_per_launch, GBps)} (synchronises)."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, recs in _records.items():
+        ms = [s.elapsed_time(e) for s, e, _ in recs]
+        nb = sum(b for _, _, b in recs) / max(len(recs), 1)
+        avg = sum(ms) / len(ms) * 1e-3
+        out[name] = dict(launches=len(recs), avg_us=avg * 1e6, alg_bytes_per_launch=nb,
+                         GBps=(nb / avg / 1e9) if avg > 0 else 0.)
+    return out
