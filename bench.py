@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--env-cost-us", type=float, default=0., help="declared extra host cost "
                     "per env step (busy wait) to emulate an ALE-like emulator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-B", type=int, default=32)
+    ap.add_argument("--cpu-baseline-B", type=int, default=0,
+                    help="B of the bounded CPU sample (0: sized for ~15 s of CPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
@@ -201,11 +202,13 @@ def cpu_baseline(T, B_cpu, env_kwargs):
     """Oracle CPU port of the reference iteration on this box's host cores (bounded sample)."""
     from oracle.ppo_cpu_port import time_cpu_baseline
     from rlpyt_amd.envs.synthetic import SyntheticPong
-    threads = os.cpu_count() or 8
-    res = time_cpu_baseline(SyntheticPong, env_kwargs, T=T, B=B_cpu, iters=1, threads=threads)
+    res = time_cpu_baseline(SyntheticPong, env_kwargs, T=T, B=B_cpu if B_cpu > 0 else None,
+                            iters=1, threads=None)
+    B_cpu = res["B"]
     return {"value": res["value"], "unit": "env-steps/s", "cores": res["cores"], "kind": "port",
             "sample": f"1 PPO iteration at [T={T}, B={B_cpu}] ({T * B_cpu} env steps, 16 "
-                      f"minibatch updates), torch CPU with {res['cores']} threads, "
+                      f"minibatch updates), torch CPU with {res['cores']} threads (best of a thread-count "
+                      f"calibration on {os.cpu_count()} host cores), "
                       f"{res['seconds']:.1f} s",
             "seconds": res["seconds"]}
 

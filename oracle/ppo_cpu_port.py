@@ -140,9 +140,42 @@ class PpoCpuPort:
         return self.optimize(bv)
 
 
-def time_cpu_baseline(EnvCls, env_kwargs, T=128, B=32, iters=1, threads=None, seed=0):
+def calibrate_threads(candidates=(8, 16, 32, 64, 128), n_obs=256):
+    """Pick the torch intra-op thread count with the best fwd+bwd rate of the model on this
+    box (more threads is NOT faster for these small convolutions) -> (threads, obs/s)."""
+    import os
+    ncpu = os.cpu_count() or 8
+    model = AtariFfModelCpu()
+    x = torch.randint(0, 256, (n_obs, 4, 104, 80), dtype=torch.uint8)
+    best = (None, 0.)
+    for th in candidates:
+        if th > ncpu:
+            continue
+        torch.set_num_threads(th)
+        rate = 0.
+        for rep in range(2):  # first pass warms the thread pool
+            t0 = time.perf_counter()
+            pi, v = model(x)
+            (pi.sum() + v.sum()).backward()
+            rate = n_obs / (time.perf_counter() - t0)
+        if rate > best[1]:
+            best = (th, rate)
+    return best
+
+
+def time_cpu_baseline(EnvCls, env_kwargs, T=128, B=None, iters=1, threads=None, seed=0,
+                      target_seconds=15.):
     """env-steps/sec of the CPU port on a bounded sample: ``iters`` PPO iterations at
-    [T, B] (same hyper-parameters as the GPU run)."""
+    [T, B] (same hyper-parameters as the GPU run).  ``threads=None`` calibrates the thread
+    count; ``B=None`` sizes the sample for about ``target_seconds`` of CPU work."""
+    rate = None
+    if threads is None:
+        threads, rate = calibrate_threads()
+    if B is None:
+        if rate is None:
+            _, rate = calibrate_threads((threads,))
+        B = int(target_seconds * rate / (T * 4.4))  # 4 epochs fwd+bwd + sampling forward
+        B = max(8, min(64, 1 << max(B, 1).bit_length() - 1))
     port = PpoCpuPort(EnvCls, env_kwargs, T, B, seed=seed, threads=threads)
     t0 = time.perf_counter()
     for _ in range(iters):
