@@ -140,6 +140,40 @@ int rlpyt_dqn_loss_fwd_bwd_f32(const float* qs /*[M,A]*/, const float* target_qs
                                float* out_scalars, float* td_abs, float* grad_qs,
                                void* workspace, rlpyt_stream_t stream);
 
+/* R2D1.loss -- rlpyt/algos/dqn/r2d1.py:298-345 (after the network forward passes).
+ *   tq = double ? target_qs[argmax next_qs] : max target_qs       (all [T,B,A])
+ *   y = h(return_ + (1-done_n) * disc_n * h^-1(tq)); delta = y - qs[action]
+ *   losses = (delta_clip<=0 ? 0.5 delta^2 : huber) * is_weights[b]; loss = valid_mean
+ *   td = clamp(|delta|) * valid ; priorities[b] = eta*max_t td + (1-eta)*valid_mean_t |delta|
+ * out_scalars (2 floats): loss, 1/sum(valid).  grad_qs [T,B,A] = dLoss/dqs. */
+int64_t rlpyt_r2d1_loss_workspace_bytes(void);
+int rlpyt_r2d1_loss_fwd_bwd_f32(const float* qs, const float* target_qs,
+                                const float* next_qs /*nullable*/, const int64_t* action,
+                                const float* return_, const uint8_t* done_n,
+                                const float* valid /*[T,B]*/,
+                                const float* is_weights /*nullable [B]*/, int T, int B, int A,
+                                float disc_n, float delta_clip, float value_scale_eps,
+                                float pri_eta, float* out_scalars, float* td_abs_valid,
+                                float* priorities /*[B]*/, float* grad_qs, void* workspace,
+                                rlpyt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Observation running mean / std -- rlpyt/models/running_mean_std.py:21-45 and the
+ * normalise+clip of rlpyt/models/pg/mujoco_ff_model.py:68-73.  x is [n, D] row-major.
+ * ---------------------------------------------------------------------------------- */
+int64_t rlpyt_obs_rms_workspace_bytes(int64_t n, int64_t D);
+/* per-dimension mean and BIASED variance over the n rows. */
+int rlpyt_obs_batch_stats_f32(const float* x, int64_t n, int64_t D, float* mean, float* var,
+                              void* workspace, rlpyt_stream_t stream);
+/* Chan merge of (batch_mean, batch_var, batch_count) into running (mean, var, count[1]). */
+int rlpyt_obs_rms_merge_f32(float* mean, float* var, float* count, const float* batch_mean,
+                            const float* batch_var, float batch_count, int64_t D,
+                            rlpyt_stream_t stream);
+/* out = clamp((x - mean) / sqrt(max(var, var_clip)), -obs_clip, obs_clip); var_clip<=0: none */
+int rlpyt_obs_normalize_f32(const float* x, const float* mean, const float* var, float* out,
+                            int64_t n, int64_t D, float var_clip, float obs_clip,
+                            rlpyt_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Gathers.
  * ---------------------------------------------------------------------------------- */

@@ -280,6 +280,88 @@ def dqn_loss(qs, target_qs, next_qs, action, return_, done_n, is_weights, disc_n
                           delta_clip)
 
 
+class _R2d1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qs, target_qs, next_qs, action, return_, done_n, valid, is_weights,
+                disc_n, delta_clip, value_scale_eps, pri_eta):
+        _lib.require_gpu()
+        T, B, A = qs.shape
+        q = _f32(qs)
+        tq = _f32(target_qs)
+        nq = None if next_qs is None else _f32(next_qs)
+        act = action.long().contiguous()
+        ret = _f32(return_)
+        dn = _as_done_u8(done_n)
+        val = _f32(valid)
+        isw = None if is_weights is None else _f32(is_weights)
+        out = torch.empty(2, dtype=torch.float32, device=q.device)
+        td = torch.empty((T, B), dtype=torch.float32, device=q.device)
+        pri = torch.empty(B, dtype=torch.float32, device=q.device)
+        gq = torch.empty_like(q)
+        ws = _workspace("r2d1", lib.rlpyt_r2d1_loss_workspace_bytes(), q.device)
+        check(lib.rlpyt_r2d1_loss_fwd_bwd_f32(
+            ptr(q), ptr(tq), ptr(nq), ptr(act), ptr(ret), ptr(dn), ptr(val), ptr(isw), T, B, A,
+            float(disc_n), float(delta_clip if delta_clip is not None else 0.),
+            float(value_scale_eps), float(pri_eta), ptr(out), ptr(td), ptr(pri), ptr(gq),
+            ptr(ws), stream()), "rlpyt_r2d1_loss_fwd_bwd_f32")
+        ctx.save_for_backward(gq)
+        ctx.mark_non_differentiable(td, pri)
+        return out[0], td, pri
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_td, _g_pri):
+        (gq,) = ctx.saved_tensors
+        return (gq * g_loss,) + (None,) * 11
+
+
+def r2d1_loss(qs, target_qs, next_qs, action, return_, done_n, valid, is_weights, disc_n,
+              delta_clip, value_scale_eps, pri_eta):
+    """R2D1.loss after the network passes (rlpyt/algos/dqn/r2d1.py:298-345):
+    returns (loss, valid_td_abs_errors [T,B], priorities [B])."""
+    return _R2d1Loss.apply(qs, target_qs, next_qs, action, return_, done_n, valid, is_weights,
+                           disc_n, delta_clip, value_scale_eps, pri_eta)
+
+
+# --------------------------------------------------------------------------------------
+# observation running mean / std (rlpyt/models/running_mean_std.py)
+# --------------------------------------------------------------------------------------
+def obs_batch_stats(x, n_feature_dims):
+    """Per-dimension mean and biased variance over all leading dims of ``x``."""
+    _lib.require_gpu()
+    x = _f32(x)
+    shape = tuple(x.shape[x.dim() - n_feature_dims:]) if n_feature_dims else ()
+    D = 1
+    for s in shape:
+        D *= s
+    n = x.numel() // D
+    mean = torch.empty(shape, dtype=torch.float32, device=x.device)
+    var = torch.empty(shape, dtype=torch.float32, device=x.device)
+    ws = _workspace("rms", lib.rlpyt_obs_rms_workspace_bytes(n, D), x.device)
+    check(lib.rlpyt_obs_batch_stats_f32(ptr(x), n, D, ptr(mean), ptr(var), ptr(ws), stream()),
+          "rlpyt_obs_batch_stats_f32")
+    return mean, var, n
+
+
+def obs_rms_merge_(mean, var, count, batch_mean, batch_var, batch_count):
+    """In-place Chan merge into the running (mean, var, count) buffers."""
+    _lib.require_gpu()
+    check(lib.rlpyt_obs_rms_merge_f32(ptr(mean), ptr(var), ptr(count), ptr(_f32(batch_mean)),
+                                      ptr(_f32(batch_var)), float(batch_count), mean.numel(),
+                                      stream()), "rlpyt_obs_rms_merge_f32")
+
+
+def obs_normalize(x, mean, var, var_clip=1e-6, obs_clip=10.):
+    """clamp((x - mean) / sqrt(max(var, var_clip)), +-obs_clip) (mujoco_ff_model.py:68-73)."""
+    _lib.require_gpu()
+    x = _f32(x)
+    D = mean.numel()
+    out = torch.empty_like(x)
+    check(lib.rlpyt_obs_normalize_f32(ptr(x), ptr(mean), ptr(var), ptr(out), x.numel() // D, D,
+                                      float(var_clip if var_clip is not None else 0.),
+                                      float(obs_clip), stream()), "rlpyt_obs_normalize_f32")
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # gathers
 # --------------------------------------------------------------------------------------

@@ -362,6 +362,222 @@ def gen_frames():
     save("frames", **out)
 
 
+def gen_replay():
+    """End-to-end stream through the reference's PrioritizedReplayFrameBuffer and
+    UniformReplayFrameBuffer (append with wraps, n-step returns, sample, priority update)."""
+    from rlpyt.replays.non_sequence.frame import (PrioritizedReplayFrameBuffer,
+                                                  UniformReplayFrameBuffer)
+    from rlpyt.utils.collections import namedarraytuple
+    from rlpyt.utils.logging import logger as ref_logger
+    ref_logger.log = lambda *a, **k: None
+    SamplesToBuffer = namedarraytuple("SamplesToBuffer",
+                                      ["observation", "action", "reward", "done"])
+    out = {}
+    for name, pri, n_step, alpha in [("pri_n3", True, 3, 1.0), ("pri_n1", True, 1, 0.6),
+                                     ("uni_n2", False, 2, None)]:
+        rng = np.random.RandomState(77)
+        B, C, H, W, Tring, Tapp, n_app, nb = 4, 4, 6, 5, 40, 5, 26, 12
+        example = SamplesToBuffer(observation=np.zeros((C, H, W), np.uint8),
+                                  action=np.int64(0), reward=np.float32(0), done=False)
+        kw = dict(example=example, size=Tring * B, B=B, discount=0.99, n_step_return=n_step)
+        if pri:
+            buf = PrioritizedReplayFrameBuffer(alpha=alpha, beta=0.5, default_priority=1.,
+                                               **kw)
+        else:
+            buf = UniformReplayFrameBuffer(**kw)
+        # a consistent frame-stacked observation stream per env
+        frames = rng.randint(0, 256, size=(n_app * Tapp + C, B, H, W)).astype(np.uint8)
+        rec = dict(obs=[], action=[], reward=[], done=[])
+        samp = dict(app_idx=[], agent_obs=[], target_obs=[], prev_action=[], prev_reward=[],
+                    action=[], return_=[], done=[], done_n=[], tgt_prev_action=[],
+                    is_weights=[], new_pri=[], seeds=[])
+        t_abs = 0
+        for k in range(n_app):
+            obs = np.stack([np.stack([frames[t_abs + i + c] for c in range(C)], axis=1)
+                            for i in range(Tapp)])  # [Tapp, B, C, H, W]
+            action = rng.randint(0, 6, size=(Tapp, B)).astype(np.int64)
+            reward = rng.randn(Tapp, B).astype(np.float32)
+            done = rng.rand(Tapp, B) < 0.1
+            t_abs += Tapp
+            buf.append_samples(SamplesToBuffer(obs, action, reward, done))
+            for key, v in zip(("obs", "action", "reward", "done"), (obs, action, reward, done)):
+                rec[key].append(v)
+            if k >= 2:
+                seed = 1000 + k
+                np.random.seed(seed)
+                batch = buf.sample_batch(nb)
+                samp["seeds"].append(seed)
+                samp["app_idx"].append(k)
+                samp["agent_obs"].append(batch.agent_inputs.observation.numpy().copy())
+                samp["target_obs"].append(batch.target_inputs.observation.numpy().copy())
+                samp["prev_action"].append(batch.agent_inputs.prev_action.numpy().copy())
+                samp["prev_reward"].append(batch.agent_inputs.prev_reward.numpy().copy())
+                samp["tgt_prev_action"].append(batch.target_inputs.prev_action.numpy().copy())
+                samp["action"].append(batch.action.numpy().copy())
+                samp["return_"].append(batch.return_.numpy().copy())
+                samp["done"].append(batch.done.numpy().copy())
+                samp["done_n"].append(batch.done_n.numpy().copy())
+                if pri:
+                    samp["is_weights"].append(batch.is_weights.numpy().copy())
+                    new_p = torch.from_numpy(np.abs(rng.randn(nb)).astype(np.float32))
+                    buf.update_batch_priorities(new_p)
+                    samp["new_pri"].append(new_p.numpy())
+        out.update({f"{name}_{k}": np.array(v) for k, v in rec.items()})
+        out.update({f"{name}_s_{k}": np.array(v) for k, v in samp.items() if len(v)})
+        out.update({f"{name}_meta": np.array([B, C, H, W, Tring, Tapp, n_app, nb, n_step]),
+                    f"{name}_alpha": np.float64(alpha if alpha else 0.)})
+        if pri:
+            out[f"{name}_final_root"] = np.float64(buf.priority_tree.tree[0])
+    save("replay", **out)
+
+
+def gen_seq_replay():
+    """Stream through the reference's PrioritizedSequenceReplayFrameBuffer (R2D1 geometry in
+    miniature: periodic RNN-state storage, n-step returns, input priorities with shift)."""
+    from rlpyt.replays.sequence.frame import (PrioritizedSequenceReplayFrameBuffer,
+                                              UniformSequenceReplayFrameBuffer)
+    from rlpyt.utils.collections import namedarraytuple
+    from rlpyt.utils.logging import logger as ref_logger
+    ref_logger.log = lambda *a, **k: None
+    RnnState = namedarraytuple("RnnState", ["h", "c"])
+    S2B = namedarraytuple("SamplesToBufferRnn",
+                          ["observation", "action", "reward", "done", "prev_rnn_state"])
+    Pri = namedarraytuple("PrioritiesSamplesToBuffer", ["priorities", "samples"])
+    out = {}
+    for name, pri in [("pseq", True), ("useq", False)]:
+        rng = np.random.RandomState(91)
+        B, C, H, W, Tring, Tapp, n_app, nb, n_step, rsi, bT = 3, 4, 5, 4, 48, 4, 40, 5, 2, 4, 8
+        example = S2B(observation=np.zeros((C, H, W), np.uint8), action=np.int64(0),
+                      reward=np.float32(0), done=False,
+                      prev_rnn_state=RnnState(np.zeros((1, 3), np.float32),
+                                              np.zeros((1, 3), np.float32)))
+        kw = dict(example=example, size=Tring * B, B=B, discount=0.99, n_step_return=n_step,
+                  rnn_state_interval=rsi, batch_T=bT)
+        if pri:
+            buf = PrioritizedSequenceReplayFrameBuffer(alpha=1.0, beta=0.5, default_priority=1.,
+                                                       input_priorities=True,
+                                                       input_priority_shift=1, **kw)
+        else:
+            buf = UniformSequenceReplayFrameBuffer(**kw)
+        frames = rng.randint(0, 256, size=(n_app * Tapp + C, B, H, W)).astype(np.uint8)
+        rec = dict(obs=[], action=[], reward=[], done=[], h=[], c=[], in_pri=[])
+        samp = dict(seeds=[], all_obs=[], all_action=[], all_reward=[], return_=[], done=[],
+                    done_n=[], h=[], c=[], is_weights=[], new_pri=[])
+        t_abs = 0
+        for k in range(n_app):
+            obs = np.stack([np.stack([frames[t_abs + i + c] for c in range(C)], axis=1)
+                            for i in range(Tapp)])
+            action = rng.randint(0, 6, size=(Tapp, B)).astype(np.int64)
+            reward = rng.randn(Tapp, B).astype(np.float32)
+            done = rng.rand(Tapp, B) < 0.06
+            h = rng.randn(Tapp, B, 1, 3).astype(np.float32)
+            c = rng.randn(Tapp, B, 1, 3).astype(np.float32)
+            t_abs += Tapp
+            smp = S2B(obs, action, reward, done, RnnState(h, c))
+            in_pri = np.abs(rng.randn(B)) + 0.1
+            buf.append_samples(Pri(priorities=in_pri, samples=smp) if pri else smp)
+            for key, v in zip(("obs", "action", "reward", "done", "h", "c", "in_pri"),
+                              (obs, action, reward, done, h, c, in_pri)):
+                rec[key].append(v)
+            if k >= 5:
+                seed = 2000 + k
+                np.random.seed(seed)
+                batch = buf.sample_batch(nb)
+                samp["seeds"].append(seed)
+                samp["all_obs"].append(batch.all_observation.numpy().copy())
+                samp["all_action"].append(batch.all_action.numpy().copy())
+                samp["all_reward"].append(batch.all_reward.numpy().copy())
+                samp["return_"].append(batch.return_.numpy().copy())
+                samp["done"].append(batch.done.numpy().copy())
+                samp["done_n"].append(batch.done_n.numpy().copy())
+                samp["h"].append(batch.init_rnn_state.h.numpy().copy())
+                samp["c"].append(batch.init_rnn_state.c.numpy().copy())
+                if pri:
+                    samp["is_weights"].append(batch.is_weights.numpy().copy())
+                    new_p = torch.from_numpy((np.abs(rng.randn(nb)) + 0.05).astype(np.float32))
+                    buf.update_batch_priorities(new_p)
+                    samp["new_pri"].append(new_p.numpy())
+        out.update({f"{name}_{k}": np.array(v) for k, v in rec.items()})
+        out.update({f"{name}_s_{k}": np.array(v) for k, v in samp.items() if len(v)})
+        out[f"{name}_meta"] = np.array([B, C, H, W, Tring, Tapp, n_app, nb, n_step, rsi, bT])
+        if pri:
+            out[f"{name}_final_root"] = np.float64(buf.priority_tree.tree[0])
+            out[f"{name}_tree_geom"] = np.array([buf.priority_tree.T,
+                                                 buf.priority_tree.off_backward,
+                                                 buf.priority_tree.off_forward])
+    save("seq_replay", **out)
+
+
+def gen_r2d1_rms():
+    """R2D1 post-network loss arithmetic (rlpyt/algos/dqn/r2d1.py:298-345) driven through
+    the reference R2D1 object's own value_scale / inv_value_scale, and the reference
+    RunningMeanStdModel over three updates."""
+    from rlpyt.algos.dqn.r2d1 import R2D1
+    from rlpyt.models.running_mean_std import RunningMeanStdModel
+    out = {}
+    for name, T, B, A, double, clip, pri in [("r2d1", 80, 64, 6, True, None, True),
+                                             ("r2d1_huber", 20, 5, 4, False, 1.0, False)]:
+        algo = R2D1(delta_clip=clip, double_dqn=double, prioritized_replay=pri)
+        g = torch.Generator().manual_seed(60 + T)
+        qs = (3 * torch.randn(T, B, A, generator=g)).requires_grad_(True)
+        target_qs = 3 * torch.randn(T, B, A, generator=g)
+        next_qs = 3 * torch.randn(T, B, A, generator=g)
+        action = torch.randint(0, A, (T, B), generator=g)
+        return_ = torch.randn(T, B, generator=g)
+        done_n = torch.rand(T, B, generator=g) < 0.05
+        done = torch.rand(T, B, generator=g) < 0.02
+        isw = torch.rand(B, generator=g) + 0.1
+        q = select_at_indexes(action, qs)
+        with torch.no_grad():
+            if double:
+                target_q = select_at_indexes(torch.argmax(next_qs, dim=-1), target_qs)
+            else:
+                target_q = torch.max(target_qs, dim=-1).values
+        disc = algo.discount ** algo.n_step_return
+        y = algo.value_scale(return_ + (1 - done_n.float()) * disc *
+                             algo.inv_value_scale(target_q))
+        delta = y - q
+        losses = 0.5 * delta ** 2
+        abs_delta = abs(delta)
+        if clip is not None:
+            b = clip * (abs_delta - clip / 2)
+            losses = torch.where(abs_delta <= clip, losses, b)
+        if pri:
+            losses *= isw.unsqueeze(0)
+        valid = valid_from_done(done)
+        loss = valid_mean(losses, valid)
+        td = abs_delta.detach()
+        if clip is not None:
+            td = torch.clamp(td, 0, clip)
+        vtd = td * valid
+        max_d = torch.max(vtd, dim=0).values
+        mean_d = valid_mean(td, valid, dim=0)
+        priorities = algo.pri_eta * max_d + (1 - algo.pri_eta) * mean_d
+        loss.backward()
+        out.update({f"{name}_qs": qs.detach().numpy(), f"{name}_target_qs": target_qs.numpy(),
+                    f"{name}_next_qs": next_qs.numpy(), f"{name}_action": action.numpy(),
+                    f"{name}_ret": return_.numpy(), f"{name}_done_n": done_n.numpy(),
+                    f"{name}_valid": valid.numpy(), f"{name}_isw": isw.numpy(),
+                    f"{name}_double": np.bool_(double), f"{name}_pri": np.bool_(pri),
+                    f"{name}_clip": np.float64(-1. if clip is None else clip),
+                    f"{name}_disc_n": np.float64(disc), f"{name}_eps": np.float64(
+                        algo.value_scale_eps), f"{name}_eta": np.float64(algo.pri_eta),
+                    f"{name}_loss": np.float32(loss.item()), f"{name}_vtd": vtd.numpy(),
+                    f"{name}_priorities": priorities.numpy(),
+                    f"{name}_grad_qs": qs.grad.numpy()})
+    g = torch.Generator().manual_seed(70)
+    rms = RunningMeanStdModel((17,))
+    xs = [torch.randn(16, 8, 17, generator=g) * (1 + k) + k for k in range(3)]
+    for k, x in enumerate(xs):
+        rms.update(x)
+        out.update({f"rms_x{k}": x.numpy(), f"rms_mean{k}": rms.mean.numpy().copy(),
+                    f"rms_var{k}": rms.var.numpy().copy(),
+                    f"rms_count{k}": np.float32(rms.count.item())})
+    obs_var = torch.clamp(rms.var, min=1e-6)
+    out["rms_norm"] = torch.clamp((xs[0] - rms.mean) / obs_var.sqrt(), -10, 10).numpy()
+    save("r2d1_rms", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
@@ -371,3 +587,6 @@ if __name__ == "__main__":
     gen_losses()
     gen_sumtree()
     gen_frames()
+    gen_replay()
+    gen_seq_replay()
+    gen_r2d1_rms()

@@ -404,3 +404,146 @@ def test_sumtree_sampling_distribution(ops):
     assert int(Ti.min()) >= 3 and int(Ti.max()) < 50000 - 1
     frac = (Ti < 25000).double().mean().item()
     assert abs(frac - (25000 - 3) / (49999 - 3)) < 0.01
+
+
+# ---------------------------------------------------------------------------- replay buffers
+@pytest.mark.parametrize("name", ["pri_n3", "pri_n1", "uni_n2"])
+def test_replay_buffer_stream_vs_reference(ops, name):
+    """Whole-buffer stream recorded from the reference's PrioritizedReplayFrameBuffer /
+    UniformReplayFrameBuffer (appends with ring wraps, n-step returns, frame store
+    duplication, sampling with the same np.random seed, priority updates): every sampled
+    field must be identical; importance weights within fp32 tolerance (device pow)."""
+    from rlpyt_amd.replays.non_sequence import (PrioritizedReplayFrameBuffer,
+                                                UniformReplayFrameBuffer)
+    from rlpyt_amd.utils.collections import namedarraytuple
+    g = load_golden("replay")
+    B, C, H, W, Tring, Tapp, n_app, nb, n_step = (int(x) for x in g[f"{name}_meta"])
+    S2B = namedarraytuple("SamplesToBuffer", ["observation", "action", "reward", "done"])
+    example = S2B(observation=np.zeros((C, H, W), np.uint8), action=np.int64(0),
+                  reward=np.float32(0), done=False)
+    kw = dict(example=example, size=Tring * B, B=B, discount=0.99, n_step_return=n_step,
+              device="cuda")
+    pri = name.startswith("pri")
+    alpha = float(g[f"{name}_alpha"])
+    buf = (PrioritizedReplayFrameBuffer(alpha=alpha, beta=0.5, default_priority=1., **kw)
+           if pri else UniformReplayFrameBuffer(**kw))
+    exact_pow = alpha == 1.0
+    k_s = 0
+    for k in range(n_app):
+        buf.append_samples(S2B(*(dev(g[f"{name}_{f}"][k]) for f in
+                                 ("obs", "action", "reward", "done"))))
+        if k < 2:
+            continue
+        np.random.seed(int(g[f"{name}_s_seeds"][k_s]))
+        batch = buf.sample_batch(nb)
+        chk = lambda field, val: np.array_equal(host(val), g[f"{name}_s_{field}"][k_s])  # noqa
+        same = (chk("agent_obs", batch.agent_inputs.observation) and
+                chk("target_obs", batch.target_inputs.observation) and
+                chk("prev_action", batch.agent_inputs.prev_action) and
+                chk("prev_reward", batch.agent_inputs.prev_reward) and
+                chk("tgt_prev_action", batch.target_inputs.prev_action) and
+                chk("action", batch.action) and chk("return_", batch.return_) and
+                chk("done", batch.done) and chk("done_n", batch.done_n))
+        if exact_pow or not pri or k_s == 0:
+            assert same, (name, k)
+        elif not same:
+            # alpha=0.6: device powf may differ from numpy's by an ulp, after which the
+            # streams may legitimately part ways; require agreement up to here.
+            assert k_s >= 1
+            break
+        if pri:
+            np.testing.assert_allclose(host(batch.is_weights), g[f"{name}_s_is_weights"][k_s],
+                                       rtol=2e-6)
+            buf.update_batch_priorities(dev(g[f"{name}_s_new_pri"][k_s]))
+        k_s += 1
+    if pri and exact_pow:
+        assert buf.priority_tree.tree_tensor()[0].item() == float(g[f"{name}_final_root"])
+
+
+@pytest.mark.parametrize("name", ["pseq", "useq"])
+def test_sequence_replay_stream_vs_reference(ops, name):
+    """Stream recorded from the reference's (Prioritized|Uniform)SequenceReplayFrameBuffer
+    (R2D1 geometry in miniature: rnn_state_interval=4, batch_T=8, n_step=2, input
+    priorities with shift 1, alpha=1 so the tree stream is exact): every field identical."""
+    from rlpyt_amd.replays.sequence import (PrioritizedSequenceReplayFrameBuffer,
+                                            UniformSequenceReplayFrameBuffer)
+    from rlpyt_amd.utils.collections import namedarraytuple
+    g = load_golden("seq_replay")
+    B, C, H, W, Tring, Tapp, n_app, nb, n_step, rsi, bT = (int(x) for x in g[f"{name}_meta"])
+    RnnState = namedarraytuple("RnnState", ["h", "c"])
+    S2B = namedarraytuple("SamplesToBufferRnn",
+                          ["observation", "action", "reward", "done", "prev_rnn_state"])
+    Pri = namedarraytuple("PrioritiesSamplesToBuffer", ["priorities", "samples"])
+    example = S2B(observation=np.zeros((C, H, W), np.uint8), action=np.int64(0),
+                  reward=np.float32(0), done=False,
+                  prev_rnn_state=RnnState(np.zeros((1, 3), np.float32),
+                                          np.zeros((1, 3), np.float32)))
+    kw = dict(example=example, size=Tring * B, B=B, discount=0.99, n_step_return=n_step,
+              rnn_state_interval=rsi, batch_T=bT, device="cuda")
+    pri = name == "pseq"
+    if pri:
+        buf = PrioritizedSequenceReplayFrameBuffer(alpha=1.0, beta=0.5, default_priority=1.,
+                                                   input_priorities=True,
+                                                   input_priority_shift=1, **kw)
+        geom = g[f"{name}_tree_geom"]
+        assert (buf.priority_tree.T, ) == (int(geom[0]),)
+    else:
+        buf = UniformSequenceReplayFrameBuffer(**kw)
+    k_s = 0
+    for k in range(n_app):
+        smp = S2B(dev(g[f"{name}_obs"][k]), dev(g[f"{name}_action"][k]),
+                  dev(g[f"{name}_reward"][k]), dev(g[f"{name}_done"][k]),
+                  RnnState(dev(g[f"{name}_h"][k]), dev(g[f"{name}_c"][k])))
+        buf.append_samples(Pri(priorities=g[f"{name}_in_pri"][k], samples=smp) if pri else smp)
+        if k < 5:
+            continue
+        np.random.seed(int(g[f"{name}_s_seeds"][k_s]))
+        batch = buf.sample_batch(nb)
+        for field, val in [("all_obs", batch.all_observation), ("all_action", batch.all_action),
+                           ("all_reward", batch.all_reward), ("return_", batch.return_),
+                           ("done", batch.done), ("done_n", batch.done_n),
+                           ("h", batch.init_rnn_state.h), ("c", batch.init_rnn_state.c)]:
+            assert np.array_equal(host(val), g[f"{name}_s_{field}"][k_s]), (name, k, field)
+        if pri:
+            np.testing.assert_allclose(host(batch.is_weights), g[f"{name}_s_is_weights"][k_s],
+                                       rtol=2e-6)
+            buf.update_batch_priorities(dev(g[f"{name}_s_new_pri"][k_s]))
+        k_s += 1
+    if pri:
+        assert buf.priority_tree.tree_tensor()[0].item() == float(g[f"{name}_final_root"])
+
+
+# ------------------------------------------------------------------------- R2D1 loss, obs RMS
+@pytest.mark.parametrize("name", ["r2d1", "r2d1_huber"])
+def test_r2d1_loss_golden(ops, name):
+    """fp32 tolerance: rtol 2e-5 on loss / priorities (sqrt + reductions), 1e-5 on td and
+    gradients."""
+    g = load_golden("r2d1_rms")
+    t = lambda k: dev(g[f"{name}_{k}"])  # noqa: E731
+    qs = t("qs").requires_grad_(True)
+    clip = float(g[f"{name}_clip"])
+    loss, vtd, pri = ops.r2d1_loss(
+        qs, t("target_qs"), t("next_qs") if bool(g[f"{name}_double"]) else None, t("action"),
+        t("ret"), t("done_n"), t("valid"), t("isw") if bool(g[f"{name}_pri"]) else None,
+        float(g[f"{name}_disc_n"]), None if clip < 0 else clip, float(g[f"{name}_eps"]),
+        float(g[f"{name}_eta"]))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[f"{name}_loss"], rtol=2e-5)
+    np.testing.assert_allclose(host(vtd), g[f"{name}_vtd"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(pri), g[f"{name}_priorities"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(host(qs.grad), g[f"{name}_grad_qs"], rtol=2e-5, atol=1e-9)
+
+
+def test_running_mean_std_golden(ops):
+    """Three successive updates of the reference RunningMeanStdModel; tolerance rtol 1e-5 /
+    atol 1e-6 (batch statistics accumulate in f64 here, Welford in f32 there)."""
+    from rlpyt_amd.models.running_mean_std import RunningMeanStdModel
+    g = load_golden("r2d1_rms")
+    rms = RunningMeanStdModel((17,)).cuda()
+    for k in range(3):
+        rms.update(dev(g[f"rms_x{k}"]))
+        np.testing.assert_allclose(host(rms.mean), g[f"rms_mean{k}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(host(rms.var), g[f"rms_var{k}"], rtol=1e-5, atol=1e-6)
+        assert rms.count.item() == float(g[f"rms_count{k}"])
+    out = rms.normalize(dev(g["rms_x0"]))
+    np.testing.assert_allclose(host(out), g["rms_norm"], rtol=1e-5, atol=1e-5)
