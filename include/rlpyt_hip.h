@@ -184,6 +184,14 @@ int rlpyt_obs_normalize_f32(const float* x, const float* mean, const float* var,
 int rlpyt_gather_tb(const void* src, const int64_t* flat_idx, void* dst, int T, int64_t B,
                     int64_t elem_bytes, int64_t M, rlpyt_stream_t stream);
 
+/* Conv-stack input preparation in ONE pass: minibatch gather (flat_idx as above; NULL =
+ * identity over M rows) + uint8 -> float32 * scale (rlpyt/models/pg/atari_ff_model.py:50-51)
+ * + CHW -> HWC so the result is the channels-last storage of a logical [M,C,H,W] tensor.
+ * src u8 [T*B, C, HW]; dst f32 [M, HW, C]. */
+int rlpyt_obs_to_nhwc_f32(const uint8_t* src, const int64_t* flat_idx /*nullable*/, float* dst,
+                          int T, int64_t B, int C, int64_t HW, int64_t M, float scale,
+                          rlpyt_stream_t stream);
+
 /* Generic 2-index gather: dst[m,:] = src[t_idx[m], b_idx[m], :] (negative t wraps once,
  * as numpy negative indexing does in rlpyt/replays/non_sequence/n_step.py:27-28). */
 int rlpyt_gather_rows(const void* src, const int64_t* t_idx, const int64_t* b_idx, void* dst,

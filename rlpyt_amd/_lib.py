@@ -74,6 +74,8 @@ _SIGNATURES = {
     "rlpyt_obs_normalize_f32": (c_int, [_p, _p, _p, _p, c_int64, c_int64, c_float, c_float,
                                         _p]),
     "rlpyt_gather_tb": (c_int, [_p, _p, _p, c_int, c_int64, c_int64, c_int64, _p]),
+    "rlpyt_obs_to_nhwc_f32": (c_int, [_p, _p, _p, c_int, c_int64, c_int, c_int64, c_int64,
+                                      c_float, _p]),
     "rlpyt_gather_rows": (c_int, [_p, _p, _p, _p, c_int, c_int64, c_int64, c_int64, _p]),
     "rlpyt_frames_gather": (c_int, [_p, _p, _p, _p, _p, c_int64, c_int, c_int64, c_int, c_int64,
                                     _p]),

@@ -113,6 +113,13 @@ class BaseAgent:
     def toggle_alt(self):
         pass
 
+    def gather_observation(self, observation, flat_idx):
+        """Minibatch rows ``idx -> (idx % T, idx // T)`` of a [T,B,...] observation batch
+        (rlpyt/algos/pg/ppo.py:94-100); image agents override this to deliver the rows
+        already converted for their conv stack."""
+        from .. import ops
+        return ops.gather_tb(observation.contiguous(), flat_idx)
+
     # -- helpers ------------------------------------------------------------------------
     def _to_model_device(self, *xs):
         return tuple(x if (x is None or x.device == self.device)

@@ -1,4 +1,6 @@
 """Atari policy-gradient agents (rlpyt/agents/pg/atari.py:21-37)."""
+import torch
+
 from ...models.pg.atari_ff_model import AtariFfModel
 from ...models.pg.mlp_pg_model import MlpPgModel
 from .categorical import CategoricalPgAgent
@@ -8,6 +10,22 @@ class AtariMixin:
     def make_env_to_model_kwargs(self, env_spaces):
         return dict(image_shape=env_spaces.observation.shape,
                     output_size=env_spaces.action.n)
+
+    def to_device(self, cuda_idx=None):
+        super().to_device(cuda_idx)
+        if cuda_idx is not None:
+            # weights in channels-last so MIOpen's NHWC fp32 kernels run without transposes
+            self.model.to(memory_format=torch.channels_last)
+            if hasattr(self, "target_model"):
+                self.target_model.to(memory_format=torch.channels_last)
+
+    def gather_observation(self, observation, flat_idx):
+        """Minibatch rows of a [T,B,C,H,W] uint8 batch, delivered as the conv stack's input:
+        gather + uint8->float32/255 + NHWC in one kernel."""
+        if observation.is_cuda and observation.dtype == torch.uint8 and observation.dim() == 5:
+            from ... import ops
+            return ops.obs_to_nhwc_f32(observation, flat_idx)
+        return super().gather_observation(observation, flat_idx)
 
 
 class AtariFfAgent(AtariMixin, CategoricalPgAgent):

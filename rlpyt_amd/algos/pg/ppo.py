@@ -69,8 +69,11 @@ class PPO(PolicyGradientAlgo):
                 if recurrent:
                     raise NotImplementedError("recurrent PPO is outside the hot-path scope")
                 idx_dev = torch.from_numpy(np.ascontiguousarray(idxs)).to(dev, non_blocking=True)
-                mb_inputs = AgentInputs(*(ops.gather_tb(f.contiguous(), idx_dev)
-                                          for f in agent_inputs))
+                mb_inputs = AgentInputs(
+                    observation=self.agent.gather_observation(agent_inputs.observation,
+                                                              idx_dev),
+                    prev_action=ops.gather_tb(agent_inputs.prev_action.contiguous(), idx_dev),
+                    prev_reward=ops.gather_tb(agent_inputs.prev_reward.contiguous(), idx_dev))
                 mb_action = ops.gather_tb(action.contiguous(), idx_dev)
                 mb_return = ops.gather_tb(return_, idx_dev)
                 mb_adv = ops.gather_tb(advantage, idx_dev)

@@ -273,3 +273,98 @@ extern "C" int rlpyt_gather_sequences(const void* src, const int64_t* t_idx,
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Fused minibatch gather + uint8 -> float32 (x scale) + CHW -> HWC for the conv stack input
+// (replaces: fancy-index gather, .type(float), .mul_(1/255) of
+// rlpyt/models/pg/atari_ff_model.py:50-51 and the NCHW->NHWC transpose MIOpen's fp32
+// implicit-GEMM kernels need).  src u8 [R, C, HW]; dst f32 [M, HW, C] (channels-last
+// storage of a logical [M, C, H, W] tensor).  One workgroup per destination image; a lane
+// converts 4 consecutive pixels: C 4-byte plane reads -> 4*C contiguous floats.
+// ---------------------------------------------------------------------------------------
+namespace rlpyt {
+namespace {
+
+template <int C>
+__global__ __launch_bounds__(256) void obs_to_nhwc_f32_kernel(
+    const uint8_t* __restrict__ src, const int64_t* __restrict__ flat_idx, float* __restrict__ dst,
+    int T, int64_t B, int64_t HW, int64_t M, float scale) {
+  const int64_t quads = HW / 4;
+  for (int64_t m = blockIdx.y; m < M; m += gridDim.y) {
+    int64_t row = m;
+    if (flat_idx != nullptr) {
+      const int64_t idx = flat_idx[m];
+      row = (idx % T) * B + (idx / T);
+    }
+    const uint8_t* __restrict__ s = src + row * C * HW;
+    float* __restrict__ d = dst + m * HW * C;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads;
+         q += (int64_t)gridDim.x * blockDim.x) {
+      uint32_t px[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) px[c] = *reinterpret_cast<const uint32_t*>(s + c * HW + q * 4);
+      float o[4][C];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[p][c] = (float)((px[c] >> (8 * p)) & 0xffu) * scale;
+      float* dp = d + q * 4 * C;
+      if constexpr (C == 4) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          *reinterpret_cast<float4*>(dp + p * 4) = make_float4(o[p][0], o[p][1], o[p][2], o[p][3]);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int c = 0; c < C; ++c) dp[p * C + c] = o[p][c];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void obs_to_nhwc_f32_generic_kernel(
+    const uint8_t* __restrict__ src, const int64_t* __restrict__ flat_idx, float* __restrict__ dst,
+    int T, int64_t B, int C, int64_t HW, int64_t M, float scale) {
+  const int64_t per = HW * C;
+  for (int64_t m = blockIdx.y; m < M; m += gridDim.y) {
+    int64_t row = m;
+    if (flat_idx != nullptr) {
+      const int64_t idx = flat_idx[m];
+      row = (idx % T) * B + (idx / T);
+    }
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < per;
+         e += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t hw = e / C, c = e - hw * C;
+      dst[m * per + e] = (float)src[row * per + c * HW + hw] * scale;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace rlpyt
+
+extern "C" int rlpyt_obs_to_nhwc_f32(const uint8_t* src, const int64_t* flat_idx, float* dst,
+                                     int T, int64_t B, int C, int64_t HW, int64_t M, float scale,
+                                     rlpyt_stream_t stream) {
+  RL_CHECK_ARG(T > 0 && B > 0 && C > 0 && HW > 0 && M >= 0, RLPYT_EINVAL,
+               "rlpyt_obs_to_nhwc_f32: bad sizes");
+  if (M == 0) return RLPYT_OK;
+  RL_CHECK_ARG(src && dst, RLPYT_EINVAL, "rlpyt_obs_to_nhwc_f32: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned gy = (unsigned)std::min<int64_t>(M, 65535);
+  const bool fast = (C == 4) && (HW % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(src) & 3) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+  if (fast) {
+    const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(HW / 4, 256), 16);
+    hipLaunchKernelGGL((obs_to_nhwc_f32_kernel<4>), dim3(gx, gy), dim3(256), 0, s, src, flat_idx,
+                       dst, T, B, HW, M, scale);
+  } else {
+    const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(HW * C, 256), 64);
+    hipLaunchKernelGGL(obs_to_nhwc_f32_generic_kernel, dim3(gx, gy), dim3(256), 0, s, src,
+                       flat_idx, dst, T, B, C, HW, M, scale);
+  }
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}

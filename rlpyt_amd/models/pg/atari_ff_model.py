@@ -2,15 +2,29 @@
 softmax, value: FC 1} (architecture and parameter names of
 rlpyt/models/pg/atari_ff_model.py:9-63; 1 785 911 parameters at A=6).
 
-uint8 observations are scaled by 1/255 inside forward, as the reference does.  The
-contraction itself runs on the MI355X through PyTorch-ROCm (MIOpen/hipBLASLt fp32);
-everything around it on the training path is the fused HIP kernels of this package.
+Input handling on the MI355X: uint8 observations are converted by ONE HIP kernel
+(``rlpyt_obs_to_nhwc_f32``: uint8 -> float32 * 1/255, CHW -> HWC) into channels-last
+storage, which is the layout MIOpen's fp32 implicit-GEMM convolutions run in natively --
+this replaces the reference's ``.type(float)`` + ``.mul_(1/255)`` (atari_ff_model.py:50-51)
+and the NCHW<->NHWC transposes around every convolution.  A float input is taken as already
+prepared (the PPO minibatch path fuses the gather into the same kernel).  On CPU tensors the
+plain torch ops run (used by host-logic tests and example generation only).
 """
 import torch
 import torch.nn.functional as F
 
 from ...utils.tensor import infer_leading_dims, restore_leading_dims
 from ..conv2d import Conv2dHeadModel
+
+
+def prepare_image(image, T_B, img_shape):
+    """uint8 [..., C, H, W] -> float32 [T*B, C, H, W] scaled to [0,1] (channels-last on GPU)."""
+    if image.dtype != torch.uint8:
+        return image.reshape(T_B, *img_shape)
+    if image.is_cuda:
+        from ... import ops
+        return ops.obs_to_nhwc_f32(image.contiguous().reshape(T_B, *img_shape))
+    return image.reshape(T_B, *img_shape).float().mul_(1. / 255)
 
 
 class AtariFfModel(torch.nn.Module):
@@ -25,9 +39,9 @@ class AtariFfModel(torch.nn.Module):
         self.value = torch.nn.Linear(self.conv.output_size, 1)
 
     def forward(self, image, prev_action, prev_reward):
-        """[T,B,C,H,W] / [B,C,H,W] / [C,H,W] uint8 -> (pi, value) with the same lead dims."""
+        """[T,B,C,H,W] / [B,C,H,W] / [C,H,W] -> (pi, value) with the same lead dims."""
         lead_dim, T, B, img_shape = infer_leading_dims(image, 3)
-        img = image.reshape(T * B, *img_shape).float().mul_(1. / 255)
+        img = prepare_image(image, T * B, img_shape)
         fc_out = self.conv(img)
         pi = F.softmax(self.pi(fc_out), dim=-1)
         v = self.value(fc_out).squeeze(-1)

@@ -388,6 +388,32 @@ def gather_tb(src, flat_idx, out=None):
     return out
 
 
+def obs_to_nhwc_f32(obs, flat_idx=None, scale=1. / 255, out=None):
+    """uint8 image batch -> float32 * scale in channels-last storage, optionally gathering
+    minibatch rows ``idx -> (idx % T, idx // T)`` of a [T,B,C,H,W] batch in the same pass.
+
+    Returns a logical ``[M, C, H, W]`` tensor whose memory is NHWC (torch.channels_last)."""
+    _lib.require_gpu()
+    assert obs.dtype == torch.uint8 and obs.is_contiguous() and obs.dim() >= 3
+    C, H, W = obs.shape[-3:]
+    if flat_idx is not None:
+        assert obs.dim() == 5
+        T, B = obs.shape[:2]
+        flat_idx = flat_idx.long().contiguous()
+        M = flat_idx.numel()
+    else:
+        M = obs.numel() // (C * H * W)
+        T, B = 1, M
+    if out is None:
+        out = torch.empty((M, C, H, W), dtype=torch.float32, device=obs.device,
+                          memory_format=torch.channels_last)
+    with ktimer.region("obs_to_nhwc", M * C * H * W * 5 + (8 * M if flat_idx is not None else 0)):
+        check(lib.rlpyt_obs_to_nhwc_f32(ptr(obs), ptr(flat_idx), ctypes.c_void_p(out.data_ptr()),
+                                        T, B, C, H * W, M, float(scale), stream()),
+              "rlpyt_obs_to_nhwc_f32")
+    return out
+
+
 def gather_rows(src, t_idx, b_idx, out=None):
     """``src[t_idx, b_idx]`` for a [T,B,...] tensor; negative t wraps once (numpy rule)."""
     _lib.require_gpu()

@@ -547,3 +547,36 @@ def test_running_mean_std_golden(ops):
         assert rms.count.item() == float(g[f"rms_count{k}"])
     out = rms.normalize(dev(g["rms_x0"]))
     np.testing.assert_allclose(host(out), g["rms_norm"], rtol=1e-5, atol=1e-5)
+
+
+def test_obs_to_nhwc_fused_exact(ops):
+    """gather + uint8->f32*(1/255) + NHWC in one kernel == torch's ops on the gathered rows
+    (bit-exact: one correctly-rounded fp32 multiply per element)."""
+    T, B = 6, 5
+    obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, device="cuda")
+    idx = torch.randperm(T * B, device="cuda")[:17]
+    out = ops.obs_to_nhwc_f32(obs, idx)
+    ref = obs[idx % T, idx // T].float().mul_(1. / 255)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out, ref)
+    out2 = ops.obs_to_nhwc_f32(obs[2])            # identity map, [B,C,H,W]
+    assert torch.equal(out2, obs[2].float().mul_(1. / 255))
+    odd = torch.randint(0, 256, (3, 2, 3, 5, 7), dtype=torch.uint8, device="cuda")  # generic path
+    i2 = torch.tensor([5, 0, 3], device="cuda")
+    assert torch.equal(ops.obs_to_nhwc_f32(odd, i2), odd[i2 % 3, i2 // 3].float().mul_(1. / 255))
+
+
+def test_model_matches_cpu_port_weights(ops):
+    """AtariFfModel on the device (fused NHWC input path) vs the same weights on CPU torch:
+    fp32 tolerance rtol 1e-4 / atol 1e-5 (different conv algorithms)."""
+    from rlpyt_amd.models.pg.atari_ff_model import AtariFfModel
+    torch.manual_seed(0)
+    cpu = AtariFfModel((4, 104, 80), 6)
+    gpu = AtariFfModel((4, 104, 80), 6)
+    gpu.load_state_dict(cpu.state_dict())
+    gpu = gpu.cuda().to(memory_format=torch.channels_last)
+    x = torch.randint(0, 256, (3, 7, 4, 104, 80), dtype=torch.uint8)
+    pc, vc = cpu(x, None, None)
+    pg, vg = gpu(x.cuda(), None, None)
+    np.testing.assert_allclose(host(pg), pc.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(vg), vc.detach().numpy(), rtol=1e-4, atol=1e-5)
