@@ -28,7 +28,10 @@ def main():
     obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, device="cuda")
     idx = torch.randperm(T * B, device="cuda")[:M]
     res = {}
-    for name, cl in [("nchw", False), ("nhwc", True)]:
+    variants = [("nchw", False), ("nhwc", True)]
+    if len(sys.argv) > 1:
+        variants = [v for v in variants if v[0] == sys.argv[1]]
+    for name, cl in variants:
         model = AtariFfModel((4, 104, 80), 6).cuda()
         if cl:
             model = model.to(memory_format=torch.channels_last)

@@ -516,8 +516,11 @@ def test_sequence_replay_stream_vs_reference(ops, name):
 # ------------------------------------------------------------------------- R2D1 loss, obs RMS
 @pytest.mark.parametrize("name", ["r2d1", "r2d1_huber"])
 def test_r2d1_loss_golden(ops, name):
-    """fp32 tolerance: rtol 2e-5 on loss / priorities (sqrt + reductions), 1e-5 on td and
-    gradients."""
+    """fp32 tolerance.  The inverse value rescaling h^-1(z) = sign(z)(((sqrt(1+4e(|z|+1+e))-1)
+    /(2e))^2 - 1) with e=1e-3 is ill-conditioned: the cancellation in sqrt(.)-1 followed by
+    the division by 2e = 0.002 amplifies a single fp32 ulp (6e-8) to ~3e-5 absolute before
+    squaring, so device and host results may differ by ~1e-4 absolute on targets of O(10).
+    Hence rtol 2e-4 / atol 1e-4 on |TD| and priorities, rtol 2e-4 on loss and gradients."""
     g = load_golden("r2d1_rms")
     t = lambda k: dev(g[f"{name}_{k}"])  # noqa: E731
     qs = t("qs").requires_grad_(True)
@@ -528,10 +531,10 @@ def test_r2d1_loss_golden(ops, name):
         float(g[f"{name}_disc_n"]), None if clip < 0 else clip, float(g[f"{name}_eps"]),
         float(g[f"{name}_eta"]))
     loss.backward()
-    np.testing.assert_allclose(loss.item(), g[f"{name}_loss"], rtol=2e-5)
-    np.testing.assert_allclose(host(vtd), g[f"{name}_vtd"], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(host(pri), g[f"{name}_priorities"], rtol=2e-5, atol=1e-6)
-    np.testing.assert_allclose(host(qs.grad), g[f"{name}_grad_qs"], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(loss.item(), g[f"{name}_loss"], rtol=2e-4)
+    np.testing.assert_allclose(host(vtd), g[f"{name}_vtd"], rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(host(pri), g[f"{name}_priorities"], rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(host(qs.grad), g[f"{name}_grad_qs"], rtol=2e-4, atol=1e-7)
 
 
 def test_running_mean_std_golden(ops):
@@ -578,5 +581,5 @@ def test_model_matches_cpu_port_weights(ops):
     x = torch.randint(0, 256, (3, 7, 4, 104, 80), dtype=torch.uint8)
     pc, vc = cpu(x, None, None)
     pg, vg = gpu(x.cuda(), None, None)
-    np.testing.assert_allclose(host(pg), pc.detach().numpy(), rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(host(vg), vc.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(pg.detach()), pc.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(vg.detach()), vc.detach().numpy(), rtol=1e-4, atol=1e-5)
