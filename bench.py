@@ -48,6 +48,8 @@ def parse():
                     "(-1: host cores / ranks, capped at B/4)")
     ap.add_argument("--env-cost-us", type=float, default=0., help="declared extra host cost "
                     "per env step (busy wait) to emulate an ALE-like emulator")
+    ap.add_argument("--groups", type=int, default=-1, help="sampler pipeline groups (-1: auto)")
+    ap.add_argument("--no-graph", action="store_true", help="no hipGraph for the sampling step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-B", type=int, default=0,
                     help="B of the bounded CPU sample (0: sized for ~15 s of CPU work)")
@@ -85,7 +87,9 @@ def main():
     seed = 0 + 100 * rank
     set_seed(seed)
     sampler = GpuSampler(SyntheticPong, env_kwargs, batch_T=T, batch_B=B, n_workers=workers,
-                         TrajInfoCls=AtariTrajInfo, max_decorrelation_steps=100)
+                         TrajInfoCls=AtariTrajInfo, max_decorrelation_steps=100,
+                         n_groups=None if args.groups < 0 else args.groups,
+                         use_graph=not args.no_graph)
     agent = AtariFfAgent()
     algo = PPO(discount=0.99, learning_rate=1e-3, value_loss_coeff=1., entropy_loss_coeff=0.01,
                clip_grad_norm=1., gae_lambda=0.98, minibatches=4, epochs=4, ratio_clip=0.1,
@@ -118,6 +122,8 @@ def main():
     if not args.no_kernel_timing:
         ktimer.reset()
         ktimer.enable(True)
+    for k in sampler.timing:
+        sampler.timing[k] = 0.
     sync()
     t0 = time.perf_counter()
     t_sample = 0.
@@ -152,9 +158,16 @@ def main():
             "config": {"workload": f"PPO AtariFfAgent, GpuSampler T={T} B={B} per GPU, "
                                    "4 epochs x 4 minibatches, gae_lambda=0.98, Adam lr=1e-3",
                        "T": T, "B": B, "env_workers_per_gpu": workers,
+                       "sampler_pipeline_groups": sampler.n_groups,
                        "env_step_cost_us": args.env_cost_us, "host_cores": ncpu,
                        "parallelism": f"dp{world}"},
             "sampling_frac_of_step": t_sample / (elapsed if elapsed > 0 else 1.),
+            "sampler": {"pipeline_groups": sampler.n_groups, "hip_graph": not args.no_graph,
+                        "ms_per_time_step": t_sample / args.steps / T * 1e3,
+                        "master_wait_env_ms": sampler.timing["wait_env_s"] / args.steps / T * 1e3,
+                        "master_issue_ms": sampler.timing["device_issue_s"] / args.steps / T * 1e3,
+                        "master_wait_device_ms":
+                            sampler.timing["device_wait_s"] / args.steps / T * 1e3},
             "last_loss": opt_info.loss[-1] if opt_info.loss else None,
         }
         if ksum:

@@ -73,6 +73,12 @@ class BaseAgent:
         logger.log(f"Initialized DistributedDataParallel agent model on device {self.device}.")
         return device_id
 
+    @property
+    def sampling_model(self):
+        """The bare module for no-grad sampling forwards: skips the DistributedDataParallel
+        wrapper's per-call bookkeeping (and keeps the step hipGraph-capturable)."""
+        return getattr(self.model, "module", self.model)
+
     def collector_initialize(self, global_B=1, env_ranks=None):
         pass
 

@@ -25,7 +25,7 @@ class CategoricalPgAgent(BaseAgent):
         """Sampling forward: one batched model call + on-device multinomial."""
         prev_action = self.distribution.to_onehot(prev_action)
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
-        pi, value = self.model(obs, pa, pr)
+        pi, value = self.sampling_model(obs, pa, pr)
         dist_info = DistInfo(prob=pi)
         action = self.distribution.sample(dist_info)
         agent_info = AgentInfo(dist_info=dist_info, value=value)
@@ -35,5 +35,5 @@ class CategoricalPgAgent(BaseAgent):
     def value(self, observation, prev_action, prev_reward):
         prev_action = self.distribution.to_onehot(prev_action)
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
-        _pi, value = self.model(obs, pa, pr)
+        _pi, value = self.sampling_model(obs, pa, pr)
         return self._out(value)

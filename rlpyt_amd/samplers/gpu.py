@@ -6,10 +6,20 @@ rlpyt/samplers/parallel/{base,worker}.py), re-designed for a 288 GB device:
 
 * environments step on host cores, in forked worker processes (or inline when
   ``n_workers=0``), exactly as in the reference;
-* workers write each step's observations into ONE fork-shared, page-locked step buffer;
-  the master issues an asynchronous H2D of that step straight into row ``t`` of the
-  HBM-resident observation batch, runs the batched action-selection forward on the
-  device, samples the actions there, and copies only ``action[B]`` back;
+* workers write each step's observations / reward / done into a fork-shared, page-locked
+  step buffer; the master issues asynchronous H2D copies of that step into small device
+  staging buffers and replays ONE captured hipGraph per step which (i) commits the staged
+  observation / reward / done into row ``t`` of the HBM-resident batch (``t`` is a device
+  counter, so the same graph serves every time step), (ii) runs the batched
+  action-selection forward, (iii) samples the actions on the device and (iv) writes
+  action / agent_info rows; only ``action[B]`` travels back to the host;
+* the environments are split into ``n_groups`` pipeline groups (default 2 with workers):
+  while the device serves group g, the host cores step the environments of the other
+  group, so per time step the wall time is max(device, host) instead of their sum.
+  Groups are column ranges of the same ``[T, B]`` batch -- every column is still one
+  environment's contiguous trajectory under one fixed policy, so the batch has exactly the
+  reference's semantics (this is not the alternating sampler: one agent, one model call
+  per group, same parameters);
 * every other field of the batch (action, reward, done, dist_info, value, bootstrap) is
   written on the device, so ``algo.optimize_agent(samples)`` starts from HBM: the
   reference's 1.09 GB re-upload of the whole batch (rlpyt/algos/pg/ppo.py:72) and its
@@ -30,7 +40,8 @@ import torch
 
 from ..agents.base import AgentInputs
 from ..utils import logger
-from ..utils.buffer import buffer_from_example, torchify_buffer
+from ..utils.buffer import (_map, buffer_from_example, buffer_leaves, np_mp_array,
+                            torchify_buffer)
 from ..utils.collections import AttrDict, namedarraytuple
 from ..utils.seed import set_seed
 from .base import BaseSampler
@@ -51,7 +62,9 @@ class EnvRunner:
         self.mid_batch_reset = mid_batch_reset
         self.traj_infos = [TrajInfoCls() for _ in envs]
         self.need_reset = np.zeros(len(envs), dtype=bool)
-        self.done_this_batch = np.zeros(len(envs), dtype=bool)
+        # wait-reset: the observation returned with done is held back until the next
+        # batch starts (collectors.py:65-68,103-104)
+        self.temp_observation = None if mid_batch_reset else [None] * len(envs)
 
     def start(self, max_decorrelation_steps=0):
         """Reset (and optionally decorrelate with random actions,
@@ -78,25 +91,30 @@ class EnvRunner:
             step.done[b] = False
 
     def begin_batch(self):
-        """Between batches: reset envs that finished under wait-reset mode
-        (collectors.py:117-126)."""
-        if not self.mid_batch_reset:
-            for b in np.where(self.need_reset)[0]:
-                self.step.observation[b] = self.envs[b].reset()
-                self.step.action[b] = 0
-                self.step.reward[b] = 0
-                self.step.done[b] = False
-            self.need_reset[:] = False
+        """Between batches under wait-reset: reinstate held observations, reset finished
+        envs, clear ``done`` (collectors.py:73-76,117-126)."""
+        if self.mid_batch_reset:
+            return
+        step = self.step
+        for b in np.where(step.done)[0]:
+            if self.need_reset[b]:
+                step.observation[b] = self.envs[b].reset()
+                step.action[b] = 0
+                step.reward[b] = 0
+            elif self.temp_observation[b] is not None:
+                step.observation[b] = self.temp_observation[b]
+        self.need_reset[:] = False
+        step.done[:] = False
 
     def step_all(self, t, completed):
         """Apply ``step.action`` to every env; write obs/reward/done for the next step."""
         step = self.step
+        mbr = self.mid_batch_reset
         for b, env in enumerate(self.envs):
-            if self.need_reset[b]:
-                # wait-reset: a finished env idles with done=True, zero obs/reward
-                # (collectors.py:85-93); the master zeroes its action row.
+            if not mbr and step.done[b]:
+                # wait-reset: a finished env idles with done=True and blank reward
+                # (collectors.py:85-91); the master blanks its action / agent_info rows.
                 step.reward[b] = 0
-                step.done[b] = True
                 continue
             a = step.action[b]
             o, r, d, info = env.step(a)
@@ -104,12 +122,13 @@ class EnvRunner:
             if getattr(info, "traj_done", d):
                 completed.append(self.traj_infos[b].terminate(o))
                 self.traj_infos[b] = self.TrajInfoCls()
-                if self.mid_batch_reset:
+                if mbr:
                     o = env.reset()
                 else:
                     self.need_reset[b] = True
-            if d and not self.mid_batch_reset:
-                o = 0 * o if not isinstance(o, tuple) else o
+            if d and not mbr:
+                self.temp_observation[b] = o
+                o = 0
             step.observation[b] = o
             step.reward[b] = r
             step.done[b] = d
@@ -117,8 +136,9 @@ class EnvRunner:
                 self.env_info[t, b] = info
 
 
-def _worker_loop(rank, runner, ctrl, batch_T, seed, cpus):
-    """Forked sampler worker (rlpyt/samplers/parallel/worker.py:37-101)."""
+def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus):
+    """Forked sampler worker (rlpyt/samplers/parallel/worker.py:37-101).  ``runners`` holds
+    this worker's environments of every pipeline group, served in group order."""
     try:
         if cpus is not None:
             import psutil
@@ -127,36 +147,65 @@ def _worker_loop(rank, runner, ctrl, batch_T, seed, cpus):
         pass
     torch.set_num_threads(1)
     set_seed(seed)
-    runner.start(ctrl.max_decorrelation_steps)
+    for rn in runners:
+        rn.start(ctrl.max_decorrelation_steps)
     ctrl.barrier_out.wait()
+    obs_ready = [sems[rank] for sems in ctrl.obs_ready]
+    act_ready = [sems[rank] for sems in ctrl.act_ready]
     while True:
         ctrl.barrier_in.wait()
         if ctrl.quit.value:
             break
         completed = []
-        runner.begin_batch()
-        ctrl.obs_ready[rank].release()
+        for g, rn in enumerate(runners):
+            rn.begin_batch()
+            obs_ready[g].release()
         for t in range(batch_T):
-            ctrl.act_ready[rank].acquire()
-            runner.step_all(t, completed)
-            ctrl.obs_ready[rank].release()
+            for g, rn in enumerate(runners):
+                act_ready[g].acquire()
+                rn.step_all(t, completed)
+                obs_ready[g].release()
         for info in completed:
             ctrl.traj_infos_queue.put(dict(info))
         ctrl.barrier_out.wait()
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _copy_leaves(dst, src, non_blocking=False):
+    for d, s in zip(buffer_leaves(dst), buffer_leaves(src)):
+        d.copy_(s, non_blocking=non_blocking)
+
+
 class GpuSampler(BaseSampler):
     """See module docstring.  ``mid_batch_reset=True`` behaves like GpuResetCollector,
-    ``False`` like GpuWaitResetCollector."""
+    ``False`` like GpuWaitResetCollector.
+
+    ``n_groups``: pipeline groups (None: 2 when worker processes are used and B allows it,
+    else 1).  ``use_graph``: capture the per-step device work in a hipGraph (GPU only)."""
+
+    GRAPH_WARMUP_CALLS = 3   # eager calls per group before capture (MIOpen/hipBLASLt find)
 
     def __init__(self, *args, n_workers=0, mid_batch_reset=True, pin_step_buffer=True,
-                 **kwargs):
+                 n_groups=None, use_graph=True, **kwargs):
         super().__init__(*args, **kwargs)
         self.n_workers = int(n_workers)
         self.mid_batch_reset = bool(mid_batch_reset)
         self.pin_step_buffer = pin_step_buffer
+        self.use_graph = bool(use_graph)
+        B = self.batch_spec.B
+        if n_groups is None:
+            n_groups = 2 if (self.n_workers > 0 and B >= 2 * max(self.n_workers, 1)) else 1
+        self.n_groups = max(1, min(int(n_groups), B))
         self._pinned_ptrs = []
         self.workers = []
+        self.timing = dict(wait_env_s=0., device_issue_s=0., device_wait_s=0., batches=0)
 
     # ------------------------------------------------------------------------ initialize
     def initialize(self, agent, affinity=None, seed=None, bootstrap_value=False,
@@ -187,35 +236,48 @@ class GpuSampler(BaseSampler):
         examples = dict(observation=o, reward=r, done=np.asarray(d, dtype=bool),
                         env_info=env_info, action=a_t, agent_info=agent_info)
         self.examples = examples
-        # ---- fork-shared host step buffer + host env_info batch ------------------------
+        # ---- fork-shared host step buffers (one per pipeline group) + host env_info ----
         shared = self.n_workers > 0
-        self.step_np = StepBuffer(
-            observation=buffer_from_example(o, (B,), share_memory=shared),
-            action=buffer_from_example(a_t, (B,), share_memory=shared),
-            reward=buffer_from_example(r, (B,), share_memory=shared),
-            done=buffer_from_example(np.asarray(d, dtype=bool), (B,), share_memory=shared))
         self.env_info_np = (buffer_from_example(env_info, (T, B), share_memory=shared)
                             if env_info else None)
         self._bootstrap = bootstrap_value
-        # ---- runners / workers ------------------------------------------------------------
+        gb = np.linspace(0, B, self.n_groups + 1).astype(int)
         n_w = max(self.n_workers, 1)
-        bounds = np.linspace(0, B, n_w + 1).astype(int)
-        self.runners = []
-        for w in range(n_w):
-            lo, hi = int(bounds[w]), int(bounds[w + 1])
-            self.runners.append(EnvRunner(
-                envs[lo:hi], self.step_np[lo:hi],
-                None if self.env_info_np is None else self.env_info_np[:, lo:hi],
-                self.TrajInfoCls, self.mid_batch_reset))
+        self.groups = []
+        runners = [[] for _ in range(n_w)]       # [worker][group]
+        for g in range(self.n_groups):
+            lo, hi = int(gb[g]), int(gb[g + 1])
+            Bg = hi - lo
+            # reward f32[Bg] and done bool[Bg] share ONE block so they travel in one H2D
+            nbytes = 4 * Bg + ((Bg + 15) // 16) * 16
+            misc = (np_mp_array(nbytes, np.uint8) if shared else np.zeros(nbytes, np.uint8))
+            misc[:] = 0
+            step_np = StepBuffer(
+                observation=buffer_from_example(o, (Bg,), share_memory=shared),
+                action=buffer_from_example(a_t, (Bg,), share_memory=shared),
+                reward=misc[:4 * Bg].view(np.float32),
+                done=misc[4 * Bg:5 * Bg].view(np.bool_))
+            G = AttrDict(idx=g, lo=lo, hi=hi, Bg=Bg, step_np=step_np, misc_np=misc, calls=0,
+                         graph=None)
+            self.groups.append(G)
+            wb = np.linspace(0, Bg, n_w + 1).astype(int)
+            for w in range(n_w):
+                l, h = int(wb[w]), int(wb[w + 1])
+                runners[w].append(EnvRunner(
+                    envs[lo + l:lo + h], step_np[l:h],
+                    None if self.env_info_np is None else self.env_info_np[:, lo + l:lo + h],
+                    self.TrajInfoCls, self.mid_batch_reset))
+        self.runners = runners
         if self.n_workers > 0:
             self._launch_workers(affinity)
         else:
             set_state = np.random.get_state()
-            for rn in self.runners:
+            for rn in runners[0]:
                 rn.start(self.max_decorrelation_steps)
             np.random.set_state(set_state)
         self._device_ready = False
-        logger.log(f"GpuSampler initialized: B={B}, T={T}, workers={self.n_workers}.")
+        logger.log(f"GpuSampler initialized: B={B}, T={T}, workers={self.n_workers}, "
+                   f"pipeline groups={self.n_groups}.")
         return AttrDict(examples)
 
     def _launch_workers(self, affinity):
@@ -224,8 +286,8 @@ class GpuSampler(BaseSampler):
         self.ctrl = AttrDict(
             quit=ctx.RawValue(ctypes.c_bool, False),
             barrier_in=ctx.Barrier(n + 1), barrier_out=ctx.Barrier(n + 1),
-            obs_ready=[ctx.Semaphore(0) for _ in range(n)],
-            act_ready=[ctx.Semaphore(0) for _ in range(n)],
+            obs_ready=[[ctx.Semaphore(0) for _ in range(n)] for _ in self.groups],
+            act_ready=[[ctx.Semaphore(0) for _ in range(n)] for _ in self.groups],
             traj_infos_queue=ctx.Queue(),
             max_decorrelation_steps=self.max_decorrelation_steps)
         cpus = affinity.get("workers_cpus", None)
@@ -238,7 +300,7 @@ class GpuSampler(BaseSampler):
                 self.seed + 1000 * (self.rank + 1) + w, wc), daemon=True)
             p.start()
             self.workers.append(p)
-        self.ctrl.barrier_out.wait()  # decorrelation done, step buffer filled
+        self.ctrl.barrier_out.wait()  # decorrelation done, step buffers filled
 
     # ------------------------------------------------------------- device-side allocation
     def _ensure_device(self):
@@ -252,98 +314,229 @@ class GpuSampler(BaseSampler):
         self.device = dev
         all_action = buffer_from_example(ex["action"], (T + 1, B), device=dev)
         all_reward = buffer_from_example(ex["reward"], (T + 1, B), device=dev)
+        all_done = buffer_from_example(ex["done"], (T + 1, B), device=dev)
         agent_info = buffer_from_example(ex["agent_info"], (T, B), device=dev)
         observation = buffer_from_example(ex["observation"], (T, B), device=dev)
-        done = buffer_from_example(ex["done"], (T, B), device=dev)
         agent_buf = AgentSamples(action=all_action[1:], prev_action=all_action[:-1],
                                  agent_info=agent_info)
         if self._bootstrap:
             bv = buffer_from_example(ex["agent_info"].value, (1, B), device=dev)
             agent_buf = AgentSamplesBsv(*agent_buf, bootstrap_value=bv)
+        # done[t] lives in row t+1 of a [T+1,B] array whose row 0 carries the previous
+        # batch's last ``done`` (the reset flag the first step of a batch sees).
         env_buf = EnvSamples(observation=observation, reward=all_reward[1:],
-                             prev_reward=all_reward[:-1], done=done,
+                             prev_reward=all_reward[:-1], done=all_done[1:],
                              env_info=self.env_info_np)
         self.samples = Samples(agent=agent_buf, env=env_buf)
-        self._all_action, self._all_reward = all_action, all_reward
-        self.step_pyt = torchify_buffer(self.step_np)
-        self._next_obs_dev = torch.zeros((B,) + tuple(observation.shape[2:]),
-                                         dtype=observation.dtype, device=dev)
-        # pin the shared step buffer so the per-step copies are true async DMA
-        if dev.type == "cuda" and self.pin_step_buffer:
-            from .. import _lib
-            for arr in self.step_np:
-                rc = _lib.lib.rlpyt_host_register(ctypes.c_void_p(arr.ctypes.data),
-                                                  int(arr.nbytes))
-                if rc == 0:
-                    self._pinned_ptrs.append(arr.ctypes.data)
-                else:
-                    logger.log(f"hipHostRegister failed ({_lib.last_error()}); "
-                               "falling back to pageable copies.")
+        self._all_action, self._all_reward, self._all_done = all_action, all_reward, all_done
+        cuda = dev.type == "cuda"
+        for G in self.groups:
+            Bg = G.Bg
+            G.step_pyt = torchify_buffer(G.step_np)
+            G.misc_h = torch.from_numpy(G.misc_np)
+            G.obs_stage = buffer_from_example(ex["observation"], (Bg,), device=dev)
+            G.misc_stage = torch.zeros(G.misc_np.size, dtype=torch.uint8, device=dev)
+            G.reward_stage = G.misc_stage[:4 * Bg].view(torch.float32)
+            G.done_stage = G.misc_stage[4 * Bg:5 * Bg].view(torch.bool)
+            G.action_out = buffer_from_example(ex["action"], (Bg,), device=dev)
+            G.t_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            G.event = torch.cuda.Event() if cuda else None
+            # one HIP stream per pipeline group: the H2D of one group overlaps the forward of
+            # the other (a single group keeps torch's current stream)
+            G.stream = torch.cuda.Stream(device=dev) if (cuda and self.n_groups > 1) else None
+            # pin the shared step buffer so the per-step copies are true async DMA
+            if cuda and self.pin_step_buffer:
+                from .. import _lib
+                arrs = buffer_leaves(G.step_np.observation) + buffer_leaves(G.step_np.action)
+                for arr in arrs + [G.misc_np]:
+                    rc = _lib.lib.rlpyt_host_register(ctypes.c_void_p(arr.ctypes.data),
+                                                      int(arr.nbytes))
+                    if rc == 0:
+                        self._pinned_ptrs.append(arr.ctypes.data)
+                    else:
+                        logger.log(f"hipHostRegister failed ({_lib.last_error()}); "
+                                   "falling back to pageable copies.")
         self._device_ready = True
+
+    # ------------------------------------------------------------------ per-step device work
+    def _commit_rows(self, dst, src, G, t_idx):
+        """``dst[t, lo:hi] = src`` for every leaf, ``t`` being a device index tensor."""
+        lo, hi = G.lo, G.hi
+        _map(lambda d, s: d[:, lo:hi].index_copy_(0, t_idx, s.unsqueeze(0)), dst, src)
+
+    def _step_body(self, G):
+        """Device work of one time step of group ``G`` (graph-capturable: fixed addresses,
+        the time index is the device counter ``G.t_dev``).
+
+        Staging holds obs_t and the (reward, done) produced by env step t-1 (at t=0: the
+        carry from the previous batch).  Commits obs -> row t, reward -> all_reward[t]
+        (= reward[t-1] = prev_reward[t]), done -> all_done[t] (= done[t-1]); runs
+        ``agent.step``; writes action -> all_action[t+1] (= action[t]) and agent_info[t]."""
+        s, t = self.samples, G.t_dev
+        lo, hi = G.lo, G.hi
+        self._commit_rows(s.env.observation, G.obs_stage, G, t)
+        self._all_reward[:, lo:hi].index_copy_(0, t, G.reward_stage.unsqueeze(0))
+        self._all_done[:, lo:hi].index_copy_(0, t, G.done_stage.unsqueeze(0))
+        prev_action = _map(lambda x: x[:, lo:hi].index_select(0, t).squeeze(0),
+                           self._all_action)
+        prev_reward = G.reward_stage
+        if self.mid_batch_reset:
+            # after a reset the agent sees null prev action/reward
+            # (action_server.py:49-53); the stored rows stay untouched.
+            dn = G.done_stage
+            prev_action = _map(lambda x: torch.where(
+                dn.reshape((-1,) + (1,) * (x.dim() - 1)), torch.zeros_like(x), x), prev_action)
+            prev_reward = torch.where(dn, torch.zeros_like(prev_reward), prev_reward)
+        action, agent_info = self.agent.step(G.obs_stage, prev_action, prev_reward)
+        if not self.mid_batch_reset:
+            # wait-reset: finished envs record blank action / agent_info
+            # (collectors.py:85-91)
+            keep = ~G.done_stage
+
+            def blank(x):
+                return x * keep.reshape((-1,) + (1,) * (x.dim() - 1)).to(x.dtype)
+            action, agent_info = _map(blank, action), _map(blank, agent_info)
+        self._commit_rows(self._all_action, action, G, t + 1)
+        self._commit_rows(s.agent.agent_info, agent_info, G, t)
+        _copy_leaves(G.action_out, action)
+        t.add_(1)
+
+    def _tail_body(self, G):
+        """After the last env step of the batch: commit reward/done of step T-1 and compute
+        the bootstrap value on obs_T (action_server.py:60-62)."""
+        T = self.batch_spec.T
+        s = self.samples
+        lo, hi = G.lo, G.hi
+        self._all_reward[T, lo:hi] = G.reward_stage
+        self._all_done[T, lo:hi] = G.done_stage
+        if "bootstrap_value" in s.agent:
+            prev_action = _map(lambda x: x[T, lo:hi], self._all_action)
+            prev_reward = G.reward_stage
+            if self.mid_batch_reset:
+                dn = G.done_stage
+                prev_action = _map(lambda x: torch.where(
+                    dn.reshape((-1,) + (1,) * (x.dim() - 1)), torch.zeros_like(x), x),
+                    prev_action)
+                prev_reward = torch.where(dn, torch.zeros_like(prev_reward), prev_reward)
+            s.agent.bootstrap_value[0, lo:hi] = self.agent.value(G.obs_stage, prev_action,
+                                                                 prev_reward)
+
+    def _upload(self, G, nb):
+        _copy_leaves(G.obs_stage, G.step_pyt.observation, non_blocking=nb)
+        G.misc_stage.copy_(G.misc_h, non_blocking=nb)
+
+    def _on_stream(self, G):
+        return torch.cuda.stream(G.stream) if G.stream is not None else _NullCtx()
+
+    def _issue(self, G):
+        """Enqueue H2D staging -> (graph of) step body -> D2H action on the group's stream."""
+        cuda = self.device.type == "cuda"
+        t0 = time.perf_counter()
+        with self._on_stream(G):
+            self._upload(G, cuda)
+            if cuda and self.use_graph:
+                if G.graph is None and G.calls >= self.GRAPH_WARMUP_CALLS:
+                    G.graph = self._capture(G)
+                if G.graph is not None:
+                    G.graph.replay()
+                else:
+                    self._step_body(G)
+            else:
+                self._step_body(G)
+            G.calls += 1
+            _copy_leaves(G.step_pyt.action, G.action_out, non_blocking=cuda)
+            if cuda:
+                G.event.record()
+        self.timing["device_issue_s"] += time.perf_counter() - t0
+
+    def _finish(self, G):
+        """Block until the group's actions are visible to the host."""
+        if G.event is not None:
+            t0 = time.perf_counter()
+            G.event.synchronize()
+            self.timing["device_wait_s"] += time.perf_counter() - t0
+
+    def _capture(self, G):
+        """Capture ``_step_body`` of one group into a hipGraph (torch.cuda.CUDAGraph is the
+        HIP graph API on ROCm).  Warm-up calls ran eagerly before, so MIOpen / hipBLASLt
+        have picked their kernels and no allocation or search happens under capture."""
+        torch.cuda.synchronize()
+        t_keep = G.t_dev.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._step_body(G)
+        G.t_dev.copy_(t_keep)       # capture does not execute, keep the counter anyway
+        torch.cuda.synchronize()
+        logger.log(f"GpuSampler: captured the step graph of pipeline group {G.idx}.")
+        return graph
 
     # --------------------------------------------------------------------- obtain_samples
     def obtain_samples(self, itr):
         self._ensure_device()
         T, B = self.batch_spec
-        agent, dev = self.agent, self.device
-        s, step = self.samples, self.step_pyt
-        nb = dev.type == "cuda"
+        agent = self.agent
         agent.sample_mode(itr)
         completed = []
-        if self.n_workers > 0:
+        par = self.n_workers > 0
+        if par:
             self.ctrl.barrier_in.wait()
-            self._wait_obs()
         else:
-            for rn in self.runners:
+            for rn in self.runners[0]:
                 rn.begin_batch()
-        # leading prev_action / prev_reward rows (collectors.py:23-24)
-        self._all_action[0].copy_(step.action, non_blocking=nb)
-        self._all_reward[0].copy_(step.reward, non_blocking=nb)
-        done_prev = None
+        cuda = self.device.type == "cuda"
+        for G in self.groups:
+            if G.stream is not None:
+                G.stream.wait_stream(torch.cuda.current_stream())   # see the updated weights
+            with self._on_stream(G):
+                G.t_dev.zero_()
+                # leading prev_action row (collectors.py:23-24); prev_reward[0] and the
+                # done carry are committed from the staging block by the first step
+                _map(lambda d, s: d[0, G.lo:G.hi].copy_(s, non_blocking=True),
+                     self._all_action, G.step_pyt.action)
+        tm = self.timing
         for t in range(T):
-            s.env.observation[t].copy_(step.observation, non_blocking=nb)
-            prev_action, prev_reward = self._all_action[t], self._all_reward[t]
-            if done_prev is not None:
-                # after a reset the agent sees zero prev action/reward
-                # (action_server.py:49-53); the stored rows stay untouched.
-                prev_action = torch.where(done_prev, torch.zeros_like(prev_action), prev_action)
-                prev_reward = torch.where(done_prev, torch.zeros_like(prev_reward), prev_reward)
-            action, agent_info = agent.step(s.env.observation[t], prev_action, prev_reward)
-            self._all_action[t + 1].copy_(action)
-            s.agent.agent_info[t] = agent_info
-            step.action.copy_(action, non_blocking=nb)
-            if nb:
-                torch.cuda.current_stream().synchronize()
-            if self.n_workers > 0:
-                for sem in self.ctrl.act_ready:
-                    sem.release()
-                self._wait_obs()
-            else:
-                for rn in self.runners:
-                    rn.step_all(t, completed)
-            # reward / done produced by this env step -> rows t of the HBM batch
-            self._all_reward[t + 1].copy_(step.reward, non_blocking=nb)
-            s.env.done[t].copy_(step.done, non_blocking=nb)
-            done_prev = s.env.done[t] if self.mid_batch_reset else None
-            if not self.mid_batch_reset:
-                # finished envs record zero action for the rest of the batch
-                # (collectors.py:85-93): handled by zeroing their action rows below.
-                pass
-        if "bootstrap_value" in s.agent:
-            self._next_obs_dev.copy_(step.observation, non_blocking=nb)
-            prev_action, prev_reward = self._all_action[T], self._all_reward[T]
-            if done_prev is not None:
-                prev_action = torch.where(done_prev, torch.zeros_like(prev_action), prev_action)
-                prev_reward = torch.where(done_prev, torch.zeros_like(prev_reward), prev_reward)
-            s.agent.bootstrap_value[0] = agent.value(self._next_obs_dev, prev_action,
-                                                     prev_reward)
-        if self.n_workers > 0:
+            for G in self.groups:
+                if par:
+                    t0 = time.perf_counter()
+                    self._wait_obs(G)
+                    tm["wait_env_s"] += time.perf_counter() - t0
+                self._issue(G)
+                if not par:
+                    self._finish(G)
+                    t0 = time.perf_counter()
+                    self.runners[0][G.idx].step_all(t, completed)
+                    tm["wait_env_s"] += time.perf_counter() - t0
+            if par:
+                for G in self.groups:
+                    self._finish(G)
+                    for sem in self.ctrl.act_ready[G.idx]:
+                        sem.release()
+        for G in self.groups:
+            if par:
+                t0 = time.perf_counter()
+                self._wait_obs(G)
+                tm["wait_env_s"] += time.perf_counter() - t0
+            with self._on_stream(G):
+                self._upload(G, cuda)
+                self._tail_body(G)
+        if cuda:
+            for G in self.groups:
+                (G.stream or torch.cuda.current_stream()).synchronize()
+        # end of batch: null the prev action / reward the next batch starts from where the
+        # env finished (action_server.py:63-68); ``done`` stays set as the carry flag.
+        for G in self.groups:
+            dn = G.step_np.done
+            if np.any(dn):
+                _map(lambda x: x.__setitem__(dn, 0), G.step_np.action)
+                G.step_np.reward[dn] = 0
+        if par:
             self.ctrl.barrier_out.wait()
             completed = self._drain_traj_infos()
+        tm["batches"] += 1
         return self.samples, completed
 
-    def _wait_obs(self):
-        for sem in self.ctrl.obs_ready:
+    def _wait_obs(self, G):
+        for sem in self.ctrl.obs_ready[G.idx]:
             sem.acquire()
 
     def _drain_traj_infos(self):
@@ -374,10 +567,11 @@ class GpuSampler(BaseSampler):
                 if p.is_alive():
                     p.terminate()
             self.workers = []
+        for G in getattr(self, "groups", []):
+            G.graph = None
         if self._pinned_ptrs:
             from .. import _lib
             for p in self._pinned_ptrs:
                 _lib.lib.rlpyt_host_unregister(ctypes.c_void_p(p))
             self._pinned_ptrs = []
-        t0 = time.time()
-        logger.log(f"GpuSampler shut down ({time.time() - t0:.2f}s).")
+        logger.log("GpuSampler shut down.")

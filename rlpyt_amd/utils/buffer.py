@@ -19,7 +19,7 @@ def _map(fn, buf, *rest):
     if buf is None:
         return None
     if isinstance(buf, tuple):
-        vals = [_map(fn, b, *(r[i] if isinstance(r, tuple) else r for r in rest))
+        vals = [_map(fn, b, *(tuple.__getitem__(r, i) if isinstance(r, tuple) else r for r in rest))
                 for i, b in enumerate(buf)]
         return type(buf)(*vals) if is_namedtuple(buf) else type(buf)(vals)
     return fn(buf, *rest)

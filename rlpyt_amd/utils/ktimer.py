@@ -27,14 +27,15 @@ class _Region:
         self.name, self.nbytes = name, nbytes
 
     def __enter__(self):
-        if _enabled:
+        self.s = None
+        if _enabled and not torch.cuda.is_current_stream_capturing():
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
             self.s.record()
         return self
 
     def __exit__(self, *exc):
-        if _enabled:
+        if self.s is not None:
             self.e.record()
             _records.setdefault(self.name, []).append((self.s, self.e, self.nbytes))
         return False

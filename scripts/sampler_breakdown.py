@@ -1,4 +1,7 @@
-"""Host-side timing of the phases of one sampler time-step on the MI355X box."""
+"""Host-side timing of the rollout phase on the MI355X box: per-step wall time and where the
+master spends it (waiting for env workers / issuing device work / waiting for the device).
+
+usage: sampler_breakdown.py [workers=64] [groups=2] [graph=1] [env_cost_us=0]"""
 import json
 import os
 import sys
@@ -17,9 +20,10 @@ logger.set_quiet(True)
 
 def main():
     B, T = 256, 128
-    nw = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    s = GpuSampler(SyntheticPong, {}, batch_T=T, batch_B=B, n_workers=nw,
-                   max_decorrelation_steps=10)
+    arg = lambda i, d: type(d)(sys.argv[i]) if len(sys.argv) > i else d  # noqa: E731
+    nw, ng, graph, cost = arg(1, 64), arg(2, 2), arg(3, 1), arg(4, 0.)
+    s = GpuSampler(SyntheticPong, dict(step_cost_us=cost), batch_T=T, batch_B=B, n_workers=nw,
+                   n_groups=ng, use_graph=bool(graph), max_decorrelation_steps=10)
     a = AtariFfAgent()
     s.initialize(a, seed=0, bootstrap_value=True)
     torch.cuda.set_device(0)
@@ -27,41 +31,46 @@ def main():
     for itr in range(2):
         s.obtain_samples(itr)
     torch.cuda.synchronize()
+    for k in s.timing:
+        s.timing[k] = 0.
+    n = 4
     t0 = time.perf_counter()
-    for itr in range(3):
-        s.obtain_samples(itr)
+    for itr in range(n):
+        s.obtain_samples(2 + itr)
     torch.cuda.synchronize()
-    per_step = (time.perf_counter() - t0) / 3 / T
-    # isolated pieces
-    step = s.step_pyt
-    obs_dev = s.samples.env.observation[0]
-    sync = torch.cuda.synchronize
+    wall = time.perf_counter() - t0
+    res = dict(workers=nw, groups=s.n_groups, graph=bool(graph), env_cost_us=cost,
+               per_step_ms=wall / n / T * 1e3, sps=n * T * B / wall)
+    for k in ("wait_env_s", "device_issue_s", "device_wait_s"):
+        res[k.replace("_s", "_ms_per_step")] = s.timing[k] / n / T * 1e3
+    # isolated device pieces of one group-step (HIP events, 100 reps each)
+    G = s.groups[0]
 
-    def tm(fn, n=200):
-        fn(); sync()
-        t = time.perf_counter()
-        for _ in range(n):
+    def ev(fn, n=100):
+        st = G.stream or torch.cuda.current_stream()
+        with torch.cuda.stream(st):
             fn()
-        sync()
-        return (time.perf_counter() - t) / n * 1e3
-    res = dict(workers=nw, per_step_ms=per_step * 1e3)
-    res["h2d_obs_ms"] = tm(lambda: obs_dev.copy_(step.observation, non_blocking=True))
-    pa, pr = s._all_action[0], s._all_reward[0]
-    a.sample_mode(0)
-    res["agent_step_ms"] = tm(lambda: a.step(obs_dev, pa, pr))
-    act = a.step(obs_dev, pa, pr).action
-
-    def d2h():
-        step.action.copy_(act, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-    res["d2h_action_sync_ms"] = tm(d2h)
-    t = time.perf_counter()
-    for _ in range(50):
-        for sem in s.ctrl.act_ready:
-            sem.release()
-        s._wait_obs()
-    res["env_step_roundtrip_ms"] = (time.perf_counter() - t) / 50 * 1e3 if nw else None
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record()
+            for _ in range(n):
+                fn()
+            b_.record()
+        st.synchronize()
+        return a_.elapsed_time(b_) / n * 1e3
+    res["Bg"] = G.Bg
+    res["h2d_us"] = ev(lambda: s._upload(G, True))
+    if G.graph is not None:
+        def rep():
+            G.t_dev.zero_()
+            G.graph.replay()
+        res["graph_us"] = ev(rep)
+    else:
+        def body():
+            G.t_dev.zero_()
+            s._step_body(G)
+        res["eager_body_us"] = ev(body)
     print(json.dumps(res), flush=True)
+    s.shutdown()
     os._exit(0)
 
 

@@ -520,7 +520,9 @@ def test_r2d1_loss_golden(ops, name):
     /(2e))^2 - 1) with e=1e-3 is ill-conditioned: the cancellation in sqrt(.)-1 followed by
     the division by 2e = 0.002 amplifies a single fp32 ulp (6e-8) to ~3e-5 absolute before
     squaring, so device and host results may differ by ~1e-4 absolute on targets of O(10).
-    Hence rtol 2e-4 / atol 1e-4 on |TD| and priorities, rtol 2e-4 on loss and gradients."""
+    Hence rtol 2e-4 / atol 1e-4 on |TD| and priorities, rtol 2e-4 on the loss; the gradient
+    is dL/dq = w * clip(td) / (T*B) with 1/(T*B) = 1e-2 here, so the 1e-4 absolute slack on td
+    becomes atol 2e-6 on the gradient."""
     g = load_golden("r2d1_rms")
     t = lambda k: dev(g[f"{name}_{k}"])  # noqa: E731
     qs = t("qs").requires_grad_(True)
@@ -534,7 +536,7 @@ def test_r2d1_loss_golden(ops, name):
     np.testing.assert_allclose(loss.item(), g[f"{name}_loss"], rtol=2e-4)
     np.testing.assert_allclose(host(vtd), g[f"{name}_vtd"], rtol=2e-4, atol=1e-4)
     np.testing.assert_allclose(host(pri), g[f"{name}_priorities"], rtol=2e-4, atol=1e-4)
-    np.testing.assert_allclose(host(qs.grad), g[f"{name}_grad_qs"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(host(qs.grad), g[f"{name}_grad_qs"], rtol=2e-4, atol=2e-6)
 
 
 def test_running_mean_std_golden(ops):

@@ -120,6 +120,56 @@ def test_sampler_batches_are_contiguous_in_time():
     s.shutdown()
 
 
+@pytest.mark.parametrize("n_workers,n_groups", [(2, 2), (0, 2), (3, 1)])
+def test_sampler_pipeline_groups_keep_trajectories_contiguous(n_workers, n_groups):
+    """Pipeline groups are column ranges of the same [T,B] batch: every column stays one
+    env's contiguous trajectory, within a batch and across batches, and prev_* rows are the
+    shifted action / reward rows."""
+    s = GpuSampler(SyntheticPong, dict(points_to_end=100, max_steps=10 ** 6), batch_T=5,
+                   batch_B=6, n_workers=n_workers, n_groups=n_groups,
+                   max_decorrelation_steps=0)
+    a = AtariFfAgent()
+    s.initialize(a, seed=2, bootstrap_value=True)
+    assert s.n_groups == n_groups
+    smp, _ = s.obtain_samples(0)
+    obs = smp.env.observation.clone()
+    for t in range(4):     # frame stack shifts by exactly one frame per step, every column
+        assert torch.equal(obs[t + 1][:, :3], obs[t][:, 1:])
+    last_a, last_r = smp.agent.action[-1].clone(), smp.env.reward[-1].clone()
+    smp, _ = s.obtain_samples(1)
+    assert torch.equal(smp.env.observation[0][:, :3], obs[-1][:, 1:])
+    assert torch.equal(smp.agent.prev_action[0], last_a)
+    assert torch.equal(smp.env.prev_reward[0], last_r)
+    assert not smp.env.done.any()
+    s.shutdown()
+
+
+@pytest.mark.parametrize("n_workers", [0, 2])
+def test_sampler_wait_reset_blanks_rows_after_done(n_workers):
+    """GpuWaitResetCollector semantics (collectors.py:70-126): once an env is done it
+    records done=True and blank action / reward / agent_info / observation for the rest of
+    the batch, and starts the next batch from a fresh reset."""
+    s = GpuSampler(TinyDiscreteEnv, dict(size=5, horizon=3), batch_T=8, batch_B=4,
+                   n_workers=n_workers, mid_batch_reset=False, max_decorrelation_steps=0)
+    a = MlpCategoricalPgAgent()
+    s.initialize(a, seed=0, bootstrap_value=True)
+    for itr in range(2):
+        smp, infos = s.obtain_samples(itr)
+        done = smp.env.done.numpy()
+        assert done[-1].all()                       # horizon 3 < T: every env finishes
+        for b in range(4):
+            first = int(np.argmax(done[:, b]))
+            assert done[first:, b].all() and not done[:first, b].any()
+            assert (smp.agent.action[first + 1:, b] == 0).all()
+            assert (smp.env.reward[first + 1:, b] == 0).all()
+            assert (smp.agent.agent_info.value[first + 1:, b] == 0).all()
+            assert (smp.agent.agent_info.dist_info.prob[first + 1:, b] == 0).all()
+            assert (smp.env.observation[first + 1:, b] == 0).all()
+            assert smp.env.observation[0, b, 2] == 1.   # fresh reset obs (bias feature)
+        assert len(infos) == 4
+    s.shutdown()
+
+
 # --------------------------------------------------------------------------------- runner
 class OraclePPO(PPO):
     """TEST ONLY: PPO with the HIP touch points replaced by the CPU oracle, to exercise the
