@@ -33,6 +33,7 @@ extern "C" {
 #define RLPYT_ESHAPE (-2) /* shape / alignment not supported by the requested variant */
 #define RLPYT_EHIP (-3)   /* a HIP runtime call failed; see rlpyt_hip_last_error() */
 #define RLPYT_ESTATE (-4) /* handle used out of protocol (e.g. update before sample) */
+#define RLPYT_ETIMEOUT (-5) /* rlpyt_seq_wait gave up (peer process gone?) */
 
 typedef void* rlpyt_stream_t; /* hipStream_t */
 
@@ -47,6 +48,19 @@ int rlpyt_hip_device_info(char* name, int cap);
  * asynchronous H2D / D2H copies.  Host pointers; synchronous. */
 int rlpyt_host_register(void* host_ptr, int64_t bytes);
 int rlpyt_host_unregister(void* host_ptr);
+
+/* Step hand-off between the sampler master and its forked env workers: replaces the
+ * 2 x n_workers semaphores per time step of rlpyt/samplers/parallel/gpu/action_server.py:44-58
+ * / collectors.py:29-50 with 32-bit sequence words in fork-shared memory (futex; host only,
+ * no HIP call -- usable in forked children).
+ *   rlpyt_seq_post(word, v)       master: publish step number v, wake every waiter;
+ *   rlpyt_seq_wait(word, v, ...)  block until (int32)(*word - v) >= 0 (spin, then sleep);
+ *                                 timeout_ms <= 0 waits forever, else RLPYT_ETIMEOUT;
+ *   rlpyt_seq_arrive(word, n)     worker: atomically ++*word, wake the master once it
+ *                                 reaches n (= arrivals expected so far). */
+int rlpyt_seq_wait(uint32_t* word, uint32_t target, int spin_iters, int timeout_ms);
+int rlpyt_seq_post(uint32_t* word, uint32_t value);
+int rlpyt_seq_arrive(uint32_t* word, uint32_t wake_at);
 
 /* ------------------------------------------------------------------------------------
  * Return / advantage scans over [T, N] trajectories (N = B * any trailing dims).
@@ -191,6 +205,34 @@ int rlpyt_gather_tb(const void* src, const int64_t* flat_idx, void* dst, int T, 
 int rlpyt_obs_to_nhwc_f32(const uint8_t* src, const int64_t* flat_idx /*nullable*/, float* dst,
                           int T, int64_t B, int C, int64_t HW, int64_t M, float scale,
                           rlpyt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * AtariFfModel convolution stack on fp32 MFMA -- rlpyt/models/pg/atari_ff_model.py:40-63 with
+ * rlpyt/models/conv2d.py:8-117 at its default geometry: uint8 [4,104,80] -> conv(4->16, k8,
+ * s4, p0) + ReLU -> conv(16->32, k4, s2, p1) + ReLU -> 3456 features (NCHW flatten order, so
+ * the reference's nn.Linear(3456, 512) weight applies unchanged).  Fused in: the minibatch
+ * gather idx -> (idx % T, idx / T) (flat_idx nullable = identity over M images, T/B then
+ * only bound the row index), uint8 -> f32, the 1/255 scale, bias, ReLU and the backward
+ * ReLU masks.  Weight layouts are torch's: w1 [16,4,8,8], w2 [32,16,4,4], contiguous.
+ *   y1  f32 [M, 25*19, 16]  conv1 output after ReLU, channels-last (saved for backward)
+ *   y2  f32 [M, 32*12*9]    conv2 output after ReLU
+ *   g2  f32 [M, 3456]       dL/dy2;   dy1 f32 [M, 475, 16]  dL/d(conv1 pre-activation)
+ * Weight gradients OVERWRITE dw / db (no accumulation); `workspace` holds
+ * rlpyt_atari_conv_wgrad_workspace_bytes() bytes (per-workgroup partial sums, reduced in a
+ * fixed order: deterministic). */
+int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat_idx /*nullable*/, int T,
+                              int64_t B, int64_t M, const float* w1, const float* b1,
+                              float scale, float* y1, rlpyt_stream_t stream);
+int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float* w2, const float* b2,
+                              float* y2, rlpyt_stream_t stream);
+int rlpyt_atari_conv2_dgrad_f32(const float* g2, const float* y2, const float* y1, int64_t M,
+                                const float* w2, float* dy1, rlpyt_stream_t stream);
+int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void);
+int rlpyt_atari_conv2_wgrad_f32(const float* g2, const float* y2, const float* y1, int64_t M,
+                                float* workspace, float* dw2, float* db2, rlpyt_stream_t stream);
+int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* flat_idx /*nullable*/, int T,
+                                int64_t B, int64_t M, const float* dy1, float scale,
+                                float* workspace, float* dw1, float* db1, rlpyt_stream_t stream);
 
 /* Generic 2-index gather: dst[m,:] = src[t_idx[m], b_idx[m], :] (negative t wraps once,
  * as numpy negative indexing does in rlpyt/replays/non_sequence/n_step.py:27-28). */

@@ -11,7 +11,7 @@ device allocations instead of instantiating a second runtime.
 """
 import ctypes
 import os
-from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p)
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint32, c_void_p)
 
 import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 
@@ -48,6 +48,9 @@ _SIGNATURES = {
     "rlpyt_hip_device_info": (c_int, [c_char_p, c_int]),
     "rlpyt_host_register": (c_int, [_p, c_int64]),
     "rlpyt_host_unregister": (c_int, [_p]),
+    "rlpyt_seq_wait": (c_int, [_p, c_uint32, c_int, c_int]),
+    "rlpyt_seq_post": (c_int, [_p, c_uint32]),
+    "rlpyt_seq_arrive": (c_int, [_p, c_uint32]),
     "rlpyt_gae_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int, c_int64, c_double, c_double,
                               c_int, _p]),
     "rlpyt_discount_return_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int, c_int64, c_double,
@@ -76,6 +79,13 @@ _SIGNATURES = {
     "rlpyt_gather_tb": (c_int, [_p, _p, _p, c_int, c_int64, c_int64, c_int64, _p]),
     "rlpyt_obs_to_nhwc_f32": (c_int, [_p, _p, _p, c_int, c_int64, c_int, c_int64, c_int64,
                                       c_float, _p]),
+    "rlpyt_atari_conv1_fwd_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, _p, c_float, _p, _p]),
+    "rlpyt_atari_conv2_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p]),
+    "rlpyt_atari_conv2_dgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p]),
+    "rlpyt_atari_conv_wgrad_workspace_bytes": (c_int64, []),
+    "rlpyt_atari_conv2_wgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p, _p]),
+    "rlpyt_atari_conv1_wgrad_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, c_float, _p, _p,
+                                            _p, _p]),
     "rlpyt_gather_rows": (c_int, [_p, _p, _p, _p, c_int, c_int64, c_int64, c_int64, _p]),
     "rlpyt_frames_gather": (c_int, [_p, _p, _p, _p, _p, c_int64, c_int, c_int64, c_int, c_int64,
                                     _p]),

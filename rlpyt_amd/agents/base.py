@@ -128,7 +128,7 @@ class BaseAgent:
 
     # -- helpers ------------------------------------------------------------------------
     def _to_model_device(self, *xs):
-        return tuple(x if (x is None or x.device == self.device)
+        return tuple(x if (x is None or not isinstance(x, torch.Tensor) or x.device == self.device)
                      else x.to(self.device, non_blocking=True) for x in xs)
 
     def _out(self, x):

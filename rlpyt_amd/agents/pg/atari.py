@@ -13,16 +13,21 @@ class AtariMixin:
 
     def to_device(self, cuda_idx=None):
         super().to_device(cuda_idx)
-        if cuda_idx is not None:
-            # weights in channels-last so MIOpen's NHWC fp32 kernels run without transposes
+        if cuda_idx is not None and not getattr(self.model, "fused_conv", False):
+            # MIOpen path: weights in channels-last so its NHWC fp32 kernels run without
+            # transposes (the hand-written conv stack takes torch's plain [co,c,ky,kx])
             self.model.to(memory_format=torch.channels_last)
             if hasattr(self, "target_model"):
                 self.target_model.to(memory_format=torch.channels_last)
 
     def gather_observation(self, observation, flat_idx):
-        """Minibatch rows of a [T,B,C,H,W] uint8 batch, delivered as the conv stack's input:
-        gather + uint8->float32/255 + NHWC in one kernel."""
+        """Minibatch rows of a [T,B,C,H,W] uint8 batch, delivered as the conv stack's input.
+        Fused conv stack: just the (batch, indices) pair -- the kernels gather while staging.
+        MIOpen path: gather + uint8->float32/255 + NHWC in one kernel."""
         if observation.is_cuda and observation.dtype == torch.uint8 and observation.dim() == 5:
+            if getattr(self.sampling_model, "fused_conv", False):
+                from ...models.pg.atari_ff_model import ObsGather
+                return ObsGather(observation, flat_idx)
             from ... import ops
             return ops.obs_to_nhwc_f32(observation, flat_idx)
         return super().gather_observation(observation, flat_idx)

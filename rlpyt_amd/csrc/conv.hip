@@ -1,0 +1,544 @@
+// AtariFfModel convolution stack on gfx950 fp32 MFMA (rlpyt/models/pg/atari_ff_model.py:40-63,
+// rlpyt/models/conv2d.py:8-117): the only dense contraction on the PPO hot path.
+//
+//   obs u8[4,104,80] --(x 1/255)--> conv1 4->16 k8 s4 p0 + bias + ReLU -> y1 [25*19, 16] (NHWC)
+//                                   conv2 16->32 k4 s2 p1 + bias + ReLU -> y2 [32, 12*9]  (NCHW flat,
+//                                   i.e. exactly the 3456-feature order nn.Linear's weight expects)
+//
+// Forward and backward are implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact f32 FMA chains,
+// 64 FLOP/clk/SIMD = the chip's f32 peak).  One workgroup owns one image at a time: the
+// image (or its activations / gradients) is staged once in LDS, the *weights* of the
+// contraction live in VGPRs as MFMA operands for the whole kernel, and the patch matrix is
+// never materialised -- every MFMA operand element is read from LDS at the address the
+// convolution geometry dictates.  uint8 -> f32 conversion, the minibatch gather
+// idx -> (idx % T, idx / T), the 1/255 scale, bias, ReLU (forward) and the ReLU masks
+// (backward) are fused into those kernels, so the f32 image never exists in HBM.
+//
+// MFMA 16x16x4 f32 operand map (cdna_hip_programming.md section 3): lane l supplies
+// A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; it receives
+// D[row = 4 * (l >> 4) + r][col = l & 15], r = 0..3.  Everywhere below A = the small
+// "weights-like" operand (rows = output channels) and B = the streamed operand, so that a
+// lane ends up with 4 consecutive output channels of one position -> 16-byte stores.
+//
+// When a lane needs 4 consecutive K-elements that are contiguous in LDS it reads them with
+// one ds_read_b128 and feeds 4 successive MFMAs (the K order inside a group of 16 is
+// permuted identically for A and B: MFMA k-slot kq of sub-step s' <-> element 4*kq + s').
+#include <algorithm>
+#include "common.h"
+
+namespace rlpyt {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- geometry (AtariFfModel defaults) ------------------------------------------------
+constexpr int C0 = 4, H0 = 104, W0 = 80, HW0 = H0 * W0, IMG = C0 * HW0;  // 33280 B
+constexpr int C1 = 16, H1 = 25, W1 = 19, P1 = H1 * W1;                   // 475 positions
+constexpr int C2 = 32, H2 = 12, W2 = 9, P2 = H2 * W2;                    // 108 positions
+constexpr int F2 = C2 * P2;                                              // 3456 features
+constexpr int Y1 = P1 * C1;                                              // 7600 floats / image
+// padded conv2 input plane: rows -1..24, cols -1..18 (only the top row / left col are ever
+// out of range for k4 s2 p1 on 25x19)
+constexpr int PH = H1 + 1, PW = W1 + 1, PPIX = PH * PW;                  // 26 x 20 = 520
+
+__device__ __forceinline__ int64_t image_row(const int64_t* flat_idx, int64_t m, int T, int64_t B) {
+  if (flat_idx == nullptr) return m;
+  const int64_t idx = flat_idx[m];
+  return (idx % T) * B + (idx / T);   // rlpyt/algos/pg/ppo.py:94-95
+}
+
+// ======================================================================================
+// conv1 forward: y1[m, pos, co] = relu(scale * sum_k w1[co,k] * x[m, patch(pos,k)] + b1[co])
+//   A = w1 (rows co, 64 K-steps held in 64 VGPRs), B = raw bytes of the image in LDS.
+//   K index k = c*64 + ky*8 + kx = 4*s + kq  ->  step s = (c, ky, kx>>2), kq = kx & 3.
+// ======================================================================================
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(
+    const uint8_t* __restrict__ obs, const int64_t* __restrict__ flat_idx, int T, int64_t B,
+    const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ y1,
+    int64_t M, float scale) {
+  __shared__ __attribute__((aligned(16))) uint8_t img[IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  float wa[64];
+#pragma unroll
+  for (int s = 0; s < 64; ++s) wa[s] = w1[j * 256 + 4 * s + kq];
+  float bias[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = b1[4 * kq + r];
+
+  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+    const uint4* __restrict__ src =
+        reinterpret_cast<const uint4*>(obs + image_row(flat_idx, m, T, B) * IMG);
+    __syncthreads();  // the previous image's readers are done
+    for (int i = tid; i < IMG / 16; i += 256) reinterpret_cast<uint4*>(img)[i] = src[i];
+    __syncthreads();
+    for (int p = wave; p < 15; p += 4) {   // 30 tiles of 16 positions, two at a time
+      const int pos0 = p * 32 + j, pos1 = pos0 + 16;
+      const int q0 = min(pos0, P1 - 1), q1 = min(pos1, P1 - 1);
+      const int a0 = (q0 / W1) * (4 * W0) + (q0 % W1) * 4 + kq;
+      const int a1 = (q1 / W1) * (4 * W0) + (q1 % W1) * 4 + kq;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 64; ++s) {
+        const int off = (s >> 4) * HW0 + ((s >> 1) & 7) * W0 + (s & 1) * 4;
+        const float x0 = (float)img[a0 + off];
+        const float x1 = (float)img[a1 + off];
+        acc0 = mfma16(wa[s], x0, acc0);
+        acc1 = mfma16(wa[s], x1, acc1);
+      }
+      float* out = y1 + m * Y1 + 4 * kq;
+      if (pos0 < P1) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc0[r] * scale + bias[r], 0.f);
+        *reinterpret_cast<f32x4*>(out + pos0 * C1) = o;
+      }
+      if (pos1 < P1) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc1[r] * scale + bias[r], 0.f);
+        *reinterpret_cast<f32x4*>(out + pos1 * C1) = o;
+      }
+    }
+  }
+}
+
+// Stage one image's y1 [475,16] into the zero-bordered plane pad[(iy+1)*PW + ix+1][PS].
+template <int PS>
+__device__ __forceinline__ void stage_y1_padded(float* pad, const float* __restrict__ y1img, int tid,
+                                                int nthreads) {
+  const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(y1img);
+  for (int i = tid; i < Y1 / 4; i += nthreads) {
+    const int p = i >> 2, q = i & 3;
+    const int iy = p / W1, ix = p - iy * W1;
+    const f32x4 v = src[i];
+    float* d = pad + ((iy + 1) * PW + ix + 1) * PS + 4 * q;
+    if constexpr (PS % 4 == 0) {
+      *reinterpret_cast<f32x4*>(d) = v;
+    } else {
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+  }
+}
+
+// ======================================================================================
+// conv2 forward: y2[m, co, pos] = relu(sum_{ky,kx,c} w2[co,c,ky,kx] * y1pad[2oy+ky, 2ox+kx, c] + b2)
+//   A = w2 (one 16-row co tile per wave, 64 VGPRs), B = y1 in LDS read as float4 over c.
+//   K: kk = ky*4+kx (16 groups) x 16 channels; MFMA slot kq of sub-step s' <-> c = 4*kq + s'.
+//   Pixel stride 20 floats makes the 16-lane ds_read_b128 groups bank-conflict free.
+// ======================================================================================
+constexpr int PS_F = 20;
+
+__global__ __launch_bounds__(256) void conv2_fwd_kernel(
+    const float* __restrict__ y1, const float* __restrict__ w2, const float* __restrict__ b2,
+    float* __restrict__ y2, int64_t M) {
+  __shared__ __attribute__((aligned(16))) float pad[PPIX * PS_F];  // 41,600 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int ct = wave & 1, t0 = wave >> 1;  // co tile; position tiles t0, t0+2, t0+4, t0+6
+  float wa[64];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp)
+      wa[kk * 4 + sp] = w2[(ct * 16 + j) * 256 + (4 * kq + sp) * 16 + kk];
+  float bias[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = b2[ct * 16 + 4 * kq + r];
+  int base[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pos = min((t0 + 2 * i) * 16 + j, P2 - 1);
+    const int oy = pos / W2, ox = pos - oy * W2;
+    base[i] = ((2 * oy) * PW + 2 * ox) * PS_F + 4 * kq;
+  }
+  for (int i = tid; i < PPIX * PS_F; i += 256) pad[i] = 0.f;  // border stays zero
+
+  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+    __syncthreads();
+    stage_y1_padded<PS_F>(pad, y1 + m * Y1, tid, 256);
+    __syncthreads();
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int off = ((kk >> 2) * PW + (kk & 3)) * PS_F;
+      f32x4 bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(pad + base[i] + off);
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = mfma16(wa[kk * 4 + sp], bv[i][sp], acc[i]);
+    }
+    float* out = y2 + m * F2 + (ct * 16 + 4 * kq) * P2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pos = (t0 + 2 * i) * 16 + j;
+      if (pos < P2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[r * P2 + pos] = fmaxf(acc[i][r] + bias[r], 0.f);
+      }
+    }
+  }
+}
+
+// ======================================================================================
+// conv2 backward-data + ReLU mask of conv1:
+//   dy1[m, iy, ix, c] = (y1 > 0) * sum_{co, ky, kx} gm2[co, oy, ox] * w2[co, c, ky, kx],
+//   iy + 1 = 2 oy + ky, ix + 1 = 2 ox + kx, gm2 = g2 * (y2 > 0).
+// Stride 2 / kernel 4: an input pixel of parity (py,px) sees exactly 2x2 taps
+// ky = 1-py+2dy, kx = 1-px+2dx with oy = a+py-dy, ox = b+px-dx (iy = 2a+py, ix = 2b+px).
+// Wave w owns parity class w: its 32 K-steps of weights (co x 4 taps = 128) stay in VGPRs.
+//   A = w2 taps (rows c), B = gm2 transposed in LDS [pos][co] (stride 40 floats, row 108 = 0).
+// ======================================================================================
+constexpr int RS_D = 40;
+
+__global__ __launch_bounds__(256) void conv2_dgrad_kernel(
+    const float* __restrict__ g2, const float* __restrict__ y2, const float* __restrict__ y1,
+    const float* __restrict__ w2, float* __restrict__ dy1, int64_t M) {
+  __shared__ __attribute__((aligned(16))) float gT[(P2 + 1) * RS_D];  // 17,440 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int py = wave >> 1, px = wave & 1;
+  const int na = py ? 12 : 13, nb = px ? 9 : 10, npx = na * nb;
+  const int ntile = (npx + 15) >> 4;
+  float wa[32];
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const int co = sg * 16 + 4 * kq + sp;
+        const int ky = 1 - py + 2 * (dd >> 1), kx = 1 - px + 2 * (dd & 1);
+        wa[(dd * 2 + sg) * 4 + sp] = w2[co * 256 + j * 16 + ky * 4 + kx];
+      }
+  for (int i = tid; i < (P2 + 1) * RS_D; i += 256) gT[i] = 0.f;
+
+  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+    __syncthreads();
+    for (int i = tid; i < F2; i += 256) {
+      const int co = i / P2, pos = i - co * P2;
+      const float g = g2[m * F2 + i], y = y2[m * F2 + i];
+      gT[pos * RS_D + co] = y > 0.f ? g : 0.f;
+    }
+    __syncthreads();
+    for (int tile = 0; tile < ntile; tile += 2) {
+      int off[2][4];
+      int pix[2];
+      bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = (tile + u) * 16 + j;
+        ok[u] = p < npx;
+        const int pc = min(p, npx - 1);
+        const int a = pc / nb, b = pc - a * nb;
+        pix[u] = (2 * a + py) * W1 + 2 * b + px;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          const int oy = a + py - (dd >> 1), ox = b + px - (dd & 1);
+          const bool v = (oy >= 0) && (oy < H2) && (ox >= 0) && (ox < W2);
+          off[u][dd] = (v ? oy * W2 + ox : P2) * RS_D + 4 * kq;
+        }
+      }
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          f32x4 bv[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            bv[u] = *reinterpret_cast<const f32x4*>(gT + off[u][dd] + sg * 16);
+#pragma unroll
+          for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              acc[u] = mfma16(wa[(dd * 2 + sg) * 4 + sp], bv[u][sp], acc[u]);
+        }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (ok[u]) {
+          const int64_t e = m * Y1 + pix[u] * C1 + 4 * kq;
+          const f32x4 yv = *reinterpret_cast<const f32x4*>(y1 + e);
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = yv[r] > 0.f ? acc[u][r] : 0.f;
+          *reinterpret_cast<f32x4*>(dy1 + e) = o;
+        }
+      }
+    }
+  }
+}
+
+// ======================================================================================
+// conv2 backward-weights (+ bias): dW2[co,c,ky,kx] = sum_{m,pos} gm2[m,co,pos] * y1pad[m,2oy+ky,2ox+kx,c]
+// Persistent workgroups; the 32x256 accumulator tile lives in VGPRs across all images of the
+// workgroup (wave w <-> ky = w; 4 kx tiles x 2 co tiles), partial sums are written once per
+// workgroup and reduced by reduce_partials_kernel (deterministic, no atomics).
+//   A = gm2 [co][pos] in LDS (stride 120, float4 over pos), B = y1pad [pix][c] (stride 18).
+//   K = positions: 7 groups of 16; MFMA slot kq of sub-step s' <-> pos = 16*sg + 4*kq + s'.
+// ======================================================================================
+constexpr int GS_W = 120, PS_W = 18, NSG2 = 7;
+constexpr int DW2_N = C2 * 256, PART2 = DW2_N + C2;  // 8192 weights + 32 biases
+
+__global__ __launch_bounds__(256) void conv2_wgrad_kernel(
+    const float* __restrict__ g2, const float* __restrict__ y2, const float* __restrict__ y1,
+    float* __restrict__ partial, int64_t M) {
+  __shared__ __attribute__((aligned(16))) float gm[C2 * GS_W];        // 15,360 B
+  __shared__ __attribute__((aligned(16))) float pad[PPIX * PS_W];     // 37,440 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  int pbase[NSG2 * 4];  // LDS float offset of the patch origin of this lane's positions
+#pragma unroll
+  for (int s = 0; s < NSG2 * 4; ++s) {
+    const int pos = min(16 * (s >> 2) + 4 * kq + (s & 3), P2 - 1);
+    const int oy = pos / W2, ox = pos - oy * W2;
+    pbase[s] = ((2 * oy + wave) * PW + 2 * ox) * PS_W + j;
+  }
+  for (int i = tid; i < C2 * GS_W; i += 256) gm[i] = 0.f;   // pos 108..119 stay zero
+  for (int i = tid; i < PPIX * PS_W; i += 256) pad[i] = 0.f;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[kx][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+
+  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+    __syncthreads();
+    for (int i = tid; i < F2; i += 256) {
+      const int co = i / P2, pos = i - co * P2;
+      const float g = g2[m * F2 + i], y = y2[m * F2 + i];
+      gm[co * GS_W + pos] = y > 0.f ? g : 0.f;
+    }
+    stage_y1_padded<PS_W>(pad, y1 + m * Y1, tid, 256);
+    __syncthreads();
+#pragma unroll
+    for (int sg = 0; sg < NSG2; ++sg) {
+      f32x4 av[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        av[ct] = *reinterpret_cast<const f32x4*>(gm + (ct * 16 + j) * GS_W + 16 * sg + 4 * kq);
+      if (wave == 0) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) bsum[ct] += (av[ct][0] + av[ct][1]) + (av[ct][2] + av[ct][3]);
+      }
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const float* bp = pad + pbase[sg * 4 + sp];
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          const float bval = bp[kx * PS_W];
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) acc[kx][ct] = mfma16(av[ct][sp], bval, acc[kx][ct]);
+        }
+      }
+    }
+  }
+  // D[row = co_local = 4*kq + r][col = c = j] -> dW2[co][c][ky = wave][kx]
+  float* out = partial + (int64_t)blockIdx.x * PART2;
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(ct * 16 + 4 * kq + r) * 256 + j * 16 + wave * 4 + kx] = acc[kx][ct][r];
+  if (wave == 0) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      float v = bsum[ct];
+      v += __shfl_xor(v, 16, kWave);
+      v += __shfl_xor(v, 32, kWave);
+      if (kq == 0) out[DW2_N + ct * 16 + j] = v;
+    }
+  }
+}
+
+// ======================================================================================
+// conv1 backward-weights (+ bias): dW1[co,c,ky,kx] = scale * sum_{m,pos} dy1[m,pos,co] * x[m,c,4oy+ky,4ox+kx]
+// Persistent workgroups, wave w <-> input channel c = w; 4 tiles of 16 K-columns
+// (ky pair x 8 kx) per wave.  A = dy1 [pos][co] in LDS (stride 20), B = image bytes.
+//   K = positions: 30 groups of 16 (475 -> 480, rows 475..479 zero).
+// ======================================================================================
+constexpr int DS_1 = 20, NSG1 = 30;
+constexpr int DW1_N = C1 * 256, PART1 = DW1_N + C1;  // 4096 + 16
+
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(
+    const uint8_t* __restrict__ obs, const int64_t* __restrict__ flat_idx, int T, int64_t B,
+    const float* __restrict__ dy1, float* __restrict__ partial, int64_t M, float scale) {
+  __shared__ __attribute__((aligned(16))) uint8_t img[IMG];             // 33,280 B
+  __shared__ __attribute__((aligned(16))) float dl[NSG1 * 16 * DS_1];   // 38,400 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int xlane = wave * HW0 + (j >> 3) * W0 + (j & 7);
+  for (int i = tid; i < NSG1 * 16 * DS_1; i += 256) dl[i] = 0.f;  // rows 475..479 stay zero
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+    const uint4* __restrict__ src =
+        reinterpret_cast<const uint4*>(obs + image_row(flat_idx, m, T, B) * IMG);
+    const f32x4* __restrict__ dsrc = reinterpret_cast<const f32x4*>(dy1 + m * Y1);
+    __syncthreads();
+    for (int i = tid; i < IMG / 16; i += 256) reinterpret_cast<uint4*>(img)[i] = src[i];
+    for (int i = tid; i < Y1 / 4; i += 256)
+      *reinterpret_cast<f32x4*>(dl + (i >> 2) * DS_1 + 4 * (i & 3)) = dsrc[i];
+    __syncthreads();
+#pragma unroll 2
+    for (int sg = 0; sg < NSG1; ++sg) {
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const int posr = 16 * sg + 4 * kq + sp;
+        const float a = dl[posr * DS_1 + j];
+        if (wave == 0) bsum += a;
+        const int pos = min(posr, P1 - 1);
+        const int oy = pos / W1, ox = pos - oy * W1;
+        const uint8_t* xp = img + xlane + oy * (4 * W0) + ox * 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(a, (float)xp[t * 2 * W0], acc[t]);
+      }
+    }
+  }
+  // D[row = co = 4*kq + r][col = j] -> dW1[co][c = wave][ky = 2t + (j>>3)][kx = j&7]
+  float* out = partial + (int64_t)blockIdx.x * PART1;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      out[(4 * kq + r) * 256 + wave * 64 + t * 16 + j] = acc[t][r] * scale;
+  if (wave == 0) {
+    float v = bsum;
+    v += __shfl_xor(v, 16, kWave);
+    v += __shfl_xor(v, 32, kWave);
+    if (kq == 0) out[DW1_N + j] = v;
+  }
+}
+
+// out[e] = sum_g partial[g][e]; e < n.  Fixed order -> run-to-run deterministic.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
+                                                              int G, int n, float* __restrict__ out_w,
+                                                              int n_w, float* __restrict__ out_b) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int g = 0;
+  for (; g + 4 <= G; g += 4) {
+    s0 += partial[(int64_t)(g + 0) * n + e];
+    s1 += partial[(int64_t)(g + 1) * n + e];
+    s2 += partial[(int64_t)(g + 2) * n + e];
+    s3 += partial[(int64_t)(g + 3) * n + e];
+  }
+  for (; g < G; ++g) s0 += partial[(int64_t)g * n + e];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (e < n_w) out_w[e] = s; else out_b[e - n_w] = s;
+}
+
+int grid_for(int64_t M, int per_cu) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+  }
+  return (int)std::min<int64_t>(M, (int64_t)cus * per_cu);
+}
+
+constexpr int kWgradGrid = 512;  // persistent workgroups of the weight-gradient kernels
+
+}  // namespace
+}  // namespace rlpyt
+
+using namespace rlpyt;
+
+#define RL_ALIGNED16(p) ((reinterpret_cast<uintptr_t>(p) & 15) == 0)
+
+extern "C" int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat_idx, int T,
+                                         int64_t B, int64_t M, const float* w1, const float* b1,
+                                         float scale, float* y1, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(M >= 0 && T > 0 && B > 0, RLPYT_EINVAL, "rlpyt_atari_conv1_fwd_f32: bad sizes");
+  if (M == 0) return RLPYT_OK;
+  RL_CHECK_ARG(obs && w1 && b1 && y1, RLPYT_EINVAL, "rlpyt_atari_conv1_fwd_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(y1), RLPYT_ESHAPE,
+               "rlpyt_atari_conv1_fwd_f32: obs / y1 must be 16-byte aligned");
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for(M, 4)), dim3(256), 0, (hipStream_t)stream,
+                     obs, flat_idx, T, B, w1, b1, y1, M, scale);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float* w2,
+                                         const float* b2, float* y2, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(M >= 0, RLPYT_EINVAL, "rlpyt_atari_conv2_fwd_f32: bad sizes");
+  if (M == 0) return RLPYT_OK;
+  RL_CHECK_ARG(y1 && w2 && b2 && y2, RLPYT_EINVAL, "rlpyt_atari_conv2_fwd_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(y1), RLPYT_ESHAPE, "rlpyt_atari_conv2_fwd_f32: y1 must be 16-byte aligned");
+  hipLaunchKernelGGL(conv2_fwd_kernel, dim3(grid_for(M, 3)), dim3(256), 0, (hipStream_t)stream,
+                     y1, w2, b2, y2, M);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_atari_conv2_dgrad_f32(const float* g2, const float* y2, const float* y1,
+                                           int64_t M, const float* w2, float* dy1,
+                                           rlpyt_stream_t stream) {
+  RL_CHECK_ARG(M >= 0, RLPYT_EINVAL, "rlpyt_atari_conv2_dgrad_f32: bad sizes");
+  if (M == 0) return RLPYT_OK;
+  RL_CHECK_ARG(g2 && y2 && y1 && w2 && dy1, RLPYT_EINVAL, "rlpyt_atari_conv2_dgrad_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(dy1), RLPYT_ESHAPE,
+               "rlpyt_atari_conv2_dgrad_f32: y1 / dy1 must be 16-byte aligned");
+  hipLaunchKernelGGL(conv2_dgrad_kernel, dim3(grid_for(M, 6)), dim3(256), 0, (hipStream_t)stream,
+                     g2, y2, y1, w2, dy1, M);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void) {
+  return (int64_t)kWgradGrid * (PART1 > PART2 ? PART1 : PART2) * (int64_t)sizeof(float);
+}
+
+extern "C" int rlpyt_atari_conv2_wgrad_f32(const float* g2, const float* y2, const float* y1,
+                                           int64_t M, float* workspace, float* dw2, float* db2,
+                                           rlpyt_stream_t stream) {
+  RL_CHECK_ARG(M > 0, RLPYT_EINVAL, "rlpyt_atari_conv2_wgrad_f32: bad sizes");
+  RL_CHECK_ARG(g2 && y2 && y1 && workspace && dw2 && db2, RLPYT_EINVAL,
+               "rlpyt_atari_conv2_wgrad_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(y1), RLPYT_ESHAPE, "rlpyt_atari_conv2_wgrad_f32: y1 must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int g = (int)std::min<int64_t>(M, kWgradGrid);
+  hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(g), dim3(256), 0, s, g2, y2, y1, workspace, M);
+  RL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART2 + 255) / 256), dim3(256), 0, s, workspace,
+                     g, PART2, dw2, DW2_N, db2);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* flat_idx, int T,
+                                           int64_t B, int64_t M, const float* dy1, float scale,
+                                           float* workspace, float* dw1, float* db1,
+                                           rlpyt_stream_t stream) {
+  RL_CHECK_ARG(M > 0 && T > 0 && B > 0, RLPYT_EINVAL, "rlpyt_atari_conv1_wgrad_f32: bad sizes");
+  RL_CHECK_ARG(obs && dy1 && workspace && dw1 && db1, RLPYT_EINVAL,
+               "rlpyt_atari_conv1_wgrad_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(dy1), RLPYT_ESHAPE,
+               "rlpyt_atari_conv1_wgrad_f32: obs / dy1 must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int g = (int)std::min<int64_t>(M, kWgradGrid);
+  hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(g), dim3(256), 0, s, obs, flat_idx, T, B, dy1,
+                     workspace, M, scale);
+  RL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART1 + 255) / 256), dim3(256), 0, s, workspace,
+                     g, PART1, dw1, DW1_N, db1);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}

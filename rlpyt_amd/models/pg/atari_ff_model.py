@@ -2,19 +2,29 @@
 softmax, value: FC 1} (architecture and parameter names of
 rlpyt/models/pg/atari_ff_model.py:9-63; 1 785 911 parameters at A=6).
 
-Input handling on the MI355X: uint8 observations are converted by ONE HIP kernel
-(``rlpyt_obs_to_nhwc_f32``: uint8 -> float32 * 1/255, CHW -> HWC) into channels-last
-storage, which is the layout MIOpen's fp32 implicit-GEMM convolutions run in natively --
-this replaces the reference's ``.type(float)`` + ``.mul_(1/255)`` (atari_ff_model.py:50-51)
-and the NCHW<->NHWC transposes around every convolution.  A float input is taken as already
-prepared (the PPO minibatch path fuses the gather into the same kernel).  On CPU tensors the
+Input handling on the MI355X: with the default geometry (uint8 [4,104,80], conv 16-32,
+kernels 8-4, strides 4-2, paddings 0-1) and the parameters on the device, the whole
+convolution stack -- minibatch gather, uint8 -> float32 * 1/255, both convolutions, biases and
+ReLUs, forward and backward -- runs in the hand-written fp32-MFMA kernels of csrc/conv.hip
+(``ops.atari_conv_stack``); the f32 image is never materialised and the 3456 features come out
+in the NCHW-flatten order the reference's ``nn.Linear`` weight expects, so state dicts
+interchange with the reference.  Other geometries fall back to MIOpen: uint8 observations are
+then converted by ``rlpyt_obs_to_nhwc_f32`` into channels-last storage.  On CPU tensors the
 plain torch ops run (used by host-logic tests and example generation only).
 """
+from collections import namedtuple
+
 import torch
 import torch.nn.functional as F
 
 from ...utils.tensor import infer_leading_dims, restore_leading_dims
 from ..conv2d import Conv2dHeadModel
+
+
+# A minibatch of observations named by index instead of by value: rows ``idx -> (idx % T,
+# idx // T)`` of a [T,B,C,H,W] uint8 batch (rlpyt/algos/pg/ppo.py:94-100).  The fused conv
+# kernels resolve the indices while staging each image, so the gathered copy never exists.
+ObsGather = namedtuple("ObsGather", ["observation", "flat_idx"])
 
 
 def prepare_image(image, T_B, img_shape):
@@ -37,12 +47,40 @@ class AtariFfModel(torch.nn.Module):
             paddings=paddings or [0, 1], use_maxpool=use_maxpool, hidden_sizes=fc_sizes)
         self.pi = torch.nn.Linear(self.conv.output_size, output_size)
         self.value = torch.nn.Linear(self.conv.output_size, 1)
+        self._default_geometry = (
+            tuple(image_shape) == (4, 104, 80) and not use_maxpool
+            and list(channels or [16, 32]) == [16, 32] and list(kernel_sizes or [8, 4]) == [8, 4]
+            and list(strides or [4, 2]) == [4, 2] and list(paddings or [0, 1]) == [0, 1])
+        self.use_fused_conv = True   # set False to force the MIOpen path (A/B tests)
+
+    @property
+    def fused_conv(self):
+        """True when the hand-written MFMA conv stack applies (geometry + device)."""
+        w = self.conv.conv.conv[0].weight
+        return (self.use_fused_conv and self._default_geometry and w.is_cuda
+                and w.dtype == torch.float32)
+
+    def _conv_features(self, obs, flat_idx):
+        from ... import ops
+        c1, c2 = self.conv.conv.conv[0], self.conv.conv.conv[2]
+        return ops.atari_conv_stack(obs, flat_idx, c1.weight, c1.bias, c2.weight, c2.bias)
 
     def forward(self, image, prev_action, prev_reward):
         """[T,B,C,H,W] / [B,C,H,W] / [C,H,W] -> (pi, value) with the same lead dims."""
-        lead_dim, T, B, img_shape = infer_leading_dims(image, 3)
-        img = prepare_image(image, T * B, img_shape)
-        fc_out = self.conv(img)
+        if isinstance(image, ObsGather):
+            lead_dim, T, B = 1, 1, image.flat_idx.numel()
+            if self.fused_conv:
+                fc_out = self.conv.head(self._conv_features(*image))
+            else:
+                from ... import ops
+                fc_out = self.conv(ops.obs_to_nhwc_f32(*image))
+        else:
+            lead_dim, T, B, img_shape = infer_leading_dims(image, 3)
+            if image.dtype == torch.uint8 and image.is_cuda and self.fused_conv:
+                feat = self._conv_features(image.contiguous().reshape(T * B, *img_shape), None)
+                fc_out = self.conv.head(feat)
+            else:
+                fc_out = self.conv(prepare_image(image, T * B, img_shape))
         pi = F.softmax(self.pi(fc_out), dim=-1)
         v = self.value(fc_out).squeeze(-1)
         return restore_leading_dims((pi, v), lead_dim, T, B)

@@ -363,6 +363,85 @@ def obs_normalize(x, mean, var, var_clip=1e-6, obs_clip=10.):
 
 
 # --------------------------------------------------------------------------------------
+# AtariFfModel convolution stack (fp32 MFMA implicit GEMMs, csrc/conv.hip)
+# --------------------------------------------------------------------------------------
+ATARI_IMG = (4, 104, 80)
+ATARI_P1, ATARI_C1, ATARI_F2 = 25 * 19, 16, 32 * 12 * 9
+# algorithmic flops per image (2 * MACs): conv1 475x256x16, conv2 108x256x32
+_FL_C1, _FL_C2 = 2 * 475 * 256 * 16, 2 * 108 * 256 * 32
+_FL_C2D = 2 * 475 * 128 * 16      # transposed conv: 2x2 taps x 32 channels per input pixel
+
+
+def _conv_rows(obs, flat_idx):
+    assert obs.dtype == torch.uint8 and obs.is_contiguous()
+    assert tuple(obs.shape[-3:]) == ATARI_IMG, "fused conv stack is built for uint8 [4,104,80]"
+    if flat_idx is not None:
+        assert obs.dim() == 5
+        T, B = obs.shape[:2]
+        flat_idx = flat_idx.long().contiguous()
+        return T, B, flat_idx.numel(), flat_idx
+    M = obs.numel() // (4 * 104 * 80)
+    return 1, max(M, 1), M, None
+
+
+class _AtariConvStack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, obs, flat_idx, w1, b1, w2, b2, scale):
+        _lib.require_gpu()
+        T, B, M, idx = _conv_rows(obs, flat_idx)
+        w1c, b1c, w2c, b2c = (x.detach().contiguous() for x in (w1, b1, w2, b2))
+        assert w1c.shape == (16, 4, 8, 8) and w2c.shape == (32, 16, 4, 4)
+        y1 = torch.empty((M, ATARI_P1, ATARI_C1), dtype=torch.float32, device=obs.device)
+        y2 = torch.empty((M, ATARI_F2), dtype=torch.float32, device=obs.device)
+        with ktimer.region("conv1_fwd", M * (33280 + 4 * 7600), M * _FL_C1):
+            check(lib.rlpyt_atari_conv1_fwd_f32(ptr(obs), ptr(idx), T, B, M, ptr(w1c), ptr(b1c),
+                                                float(scale), ptr(y1), stream()),
+                  "rlpyt_atari_conv1_fwd_f32")
+        with ktimer.region("conv2_fwd", M * 4 * (7600 + 3456), M * _FL_C2):
+            check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1), M, ptr(w2c), ptr(b2c), ptr(y2),
+                                                stream()), "rlpyt_atari_conv2_fwd_f32")
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(obs, idx, w2c, y1, y2)
+            ctx.dims = (T, B, M, float(scale))
+        return y2
+
+    @staticmethod
+    def backward(ctx, g2):
+        obs, idx, w2c, y1, y2 = ctx.saved_tensors
+        T, B, M, scale = ctx.dims
+        g2 = _f32(g2)
+        dev = obs.device
+        dy1 = torch.empty_like(y1)
+        ws = _workspace("conv_wgrad", lib.rlpyt_atari_conv_wgrad_workspace_bytes(), dev)
+        dw1 = torch.empty((16, 4, 8, 8), dtype=torch.float32, device=dev)
+        db1 = torch.empty(16, dtype=torch.float32, device=dev)
+        dw2 = torch.empty((32, 16, 4, 4), dtype=torch.float32, device=dev)
+        db2 = torch.empty(32, dtype=torch.float32, device=dev)
+        with ktimer.region("conv2_dgrad", M * 4 * (2 * 3456 + 2 * 7600), M * _FL_C2D):
+            check(lib.rlpyt_atari_conv2_dgrad_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2c), ptr(dy1),
+                                                  stream()), "rlpyt_atari_conv2_dgrad_f32")
+        with ktimer.region("conv2_wgrad", M * 4 * (2 * 3456 + 7600), M * _FL_C2):
+            check(lib.rlpyt_atari_conv2_wgrad_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(ws), ptr(dw2),
+                                                  ptr(db2), stream()),
+                  "rlpyt_atari_conv2_wgrad_f32")
+        with ktimer.region("conv1_wgrad", M * (33280 + 4 * 7600), M * _FL_C1):
+            check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs), ptr(idx), T, B, M, ptr(dy1), scale,
+                                                  ptr(ws), ptr(dw1), ptr(db1), stream()),
+                  "rlpyt_atari_conv1_wgrad_f32")
+        return None, None, dw1, db1, dw2, db2, None
+
+
+def atari_conv_stack(obs, flat_idx, w1, b1, w2, b2, scale=1. / 255):
+    """uint8 observations -> the 3456 conv features of AtariFfModel (differentiable w.r.t.
+    the four conv parameters): ``relu(conv2(relu(conv1(obs * scale))))`` flattened in NCHW
+    order (rlpyt/models/pg/atari_ff_model.py:50-55, rlpyt/models/conv2d.py).
+
+    ``obs``: uint8 ``[M,4,104,80]``, or ``[T,B,4,104,80]`` together with ``flat_idx`` (int64
+    ``[M]``) selecting the minibatch rows ``idx -> (idx % T, idx // T)`` inside the kernel."""
+    return _AtariConvStack.apply(obs, flat_idx, w1, b1, w2, b2, scale)
+
+
+# --------------------------------------------------------------------------------------
 # gathers
 # --------------------------------------------------------------------------------------
 def _row_bytes(x, lead):

@@ -150,8 +150,7 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus):
     for rn in runners:
         rn.start(ctrl.max_decorrelation_steps)
     ctrl.barrier_out.wait()
-    obs_ready = [sems[rank] for sems in ctrl.obs_ready]
-    act_ready = [sems[rank] for sems in ctrl.act_ready]
+    seq = _StepSync(ctrl.sync_words, len(runners), ctrl.n_workers)
     while True:
         ctrl.barrier_in.wait()
         if ctrl.quit.value:
@@ -159,15 +158,59 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus):
         completed = []
         for g, rn in enumerate(runners):
             rn.begin_batch()
-            obs_ready[g].release()
+            seq.worker_arrive(g)
         for t in range(batch_T):
             for g, rn in enumerate(runners):
-                act_ready[g].acquire()
+                seq.worker_wait_act(g)
                 rn.step_all(t, completed)
-                obs_ready[g].release()
+                seq.worker_arrive(g)
         for info in completed:
             ctrl.traj_infos_queue.put(dict(info))
         ctrl.barrier_out.wait()
+
+
+class _StepSync:
+    """Per-group step hand-off on two fork-shared 32-bit words (``rlpyt_seq_*`` in the C
+    ABI): ``act`` = number of action sets the master has published, ``obs`` = running
+    count of worker arrivals.  Both sides keep private copies of the expected values, so
+    a hand-off is one atomic + at most one futex syscall instead of the reference's
+    per-worker semaphore pair."""
+
+    MASTER_SPIN = 4000     # ~40 us of polling before sleeping (hand-offs are ~100 us apart)
+    WORKER_SPIN = 300
+
+    def __init__(self, words, n_groups, n_workers):
+        from .. import _lib
+        self._lib = _lib.lib
+        base = words.ctypes.data
+        # words[2g] = act sequence, words[2g+1] = arrival counter; 64 B apart per group
+        self.act = [ctypes.c_void_p(base + 128 * g) for g in range(n_groups)]
+        self.obs = [ctypes.c_void_p(base + 128 * g + 64) for g in range(n_groups)]
+        self.n_workers = n_workers
+        self.acts = [0] * n_groups       # action sets published / consumed so far
+        self.rounds = [0] * n_groups     # arrival rounds completed so far
+
+    # -- worker side
+    def worker_arrive(self, g):
+        self.rounds[g] += 1
+        self._lib.rlpyt_seq_arrive(self.obs[g], (self.rounds[g] * self.n_workers) & 0xffffffff)
+
+    def worker_wait_act(self, g):
+        self.acts[g] += 1
+        self._lib.rlpyt_seq_wait(self.act[g], self.acts[g] & 0xffffffff, self.WORKER_SPIN, 0)
+
+    # -- master side
+    def master_wait_obs(self, g, timeout_ms=120000):
+        self.rounds[g] += 1
+        rc = self._lib.rlpyt_seq_wait(self.obs[g], (self.rounds[g] * self.n_workers) & 0xffffffff,
+                                      self.MASTER_SPIN, timeout_ms)
+        if rc != 0:
+            raise RuntimeError("GpuSampler: env workers did not report within "
+                               f"{timeout_ms / 1e3:.0f} s (rc={rc}); a worker process died?")
+
+    def master_post_act(self, g):
+        self.acts[g] += 1
+        self._lib.rlpyt_seq_post(self.act[g], self.acts[g] & 0xffffffff)
 
 
 class _NullCtx:
@@ -286,8 +329,7 @@ class GpuSampler(BaseSampler):
         self.ctrl = AttrDict(
             quit=ctx.RawValue(ctypes.c_bool, False),
             barrier_in=ctx.Barrier(n + 1), barrier_out=ctx.Barrier(n + 1),
-            obs_ready=[[ctx.Semaphore(0) for _ in range(n)] for _ in self.groups],
-            act_ready=[[ctx.Semaphore(0) for _ in range(n)] for _ in self.groups],
+            sync_words=np_mp_array(32 * len(self.groups), np.uint32), n_workers=n,
             traj_infos_queue=ctx.Queue(),
             max_decorrelation_steps=self.max_decorrelation_steps)
         cpus = affinity.get("workers_cpus", None)
@@ -300,6 +342,7 @@ class GpuSampler(BaseSampler):
                 self.seed + 1000 * (self.rank + 1) + w, wc), daemon=True)
             p.start()
             self.workers.append(p)
+        self.sync = _StepSync(self.ctrl.sync_words, len(self.groups), n)
         self.ctrl.barrier_out.wait()  # decorrelation done, step buffers filled
 
     # ------------------------------------------------------------- device-side allocation
@@ -509,8 +552,7 @@ class GpuSampler(BaseSampler):
             if par:
                 for G in self.groups:
                     self._finish(G)
-                    for sem in self.ctrl.act_ready[G.idx]:
-                        sem.release()
+                    self.sync.master_post_act(G.idx)
         for G in self.groups:
             if par:
                 t0 = time.perf_counter()
@@ -536,8 +578,7 @@ class GpuSampler(BaseSampler):
         return self.samples, completed
 
     def _wait_obs(self, G):
-        for sem in self.ctrl.obs_ready[G.idx]:
-            sem.acquire()
+        self.sync.master_wait_obs(G.idx)
 
     def _drain_traj_infos(self):
         out = []

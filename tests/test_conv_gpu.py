@@ -1,0 +1,191 @@
+"""GPU parity of the hand-written fp32-MFMA AtariFfModel conv stack (csrc/conv.hip) against a
+float64 torch reference of the same ops (rlpyt/models/pg/atari_ff_model.py:50-55 with
+rlpyt/models/conv2d.py geometry 4->16 k8 s4 p0, 16->32 k4 s2 p1).
+
+Tolerance (floating point, f32 FMA chains of length 256 in the forward, up to M*475 in the
+weight gradients, different summation order than the reference): max |err| <= 2e-5 * max |ref|
+(+1e-6), stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from rlpyt_amd import ops as _ops
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def _params(seed=0, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    w1 = (torch.rand(16, 4, 8, 8, generator=g, dtype=dtype) - 0.5) * 0.25   # asymmetric
+    b1 = (torch.rand(16, generator=g, dtype=dtype) - 0.5) * 0.2
+    w2 = (torch.rand(32, 16, 4, 4, generator=g, dtype=dtype) - 0.5) * 0.25
+    b2 = (torch.rand(32, generator=g, dtype=dtype) - 0.5) * 0.2
+    return w1, b1, w2, b2
+
+
+def _ref_stack(obs_u8, params):
+    """float64 reference; returns (y1 [M,475,16], y2 [M,3456]) with grad graph on params."""
+    w1, b1, w2, b2 = params
+    x = obs_u8.double() * (1. / 255)
+    a1 = F.relu(F.conv2d(x, w1, b1, stride=4))
+    a2 = F.relu(F.conv2d(a1, w2, b2, stride=2, padding=1))
+    return a1, a1.permute(0, 2, 3, 1).reshape(x.shape[0], 475, 16), a2.reshape(x.shape[0], -1)
+
+
+def _close(actual, desired, rel=2e-5, what=""):
+    a = actual.detach().double().cpu().numpy()
+    d = desired.detach().double().cpu().numpy()
+    assert a.shape == d.shape, (what, a.shape, d.shape)
+    err = np.abs(a - d).max() if a.size else 0.
+    tol = rel * max(np.abs(d).max() if d.size else 0., 1e-30) + 1e-6
+    assert err <= tol, f"{what}: max err {err:.3e} > tol {tol:.3e} (max ref {np.abs(d).max():.3e})"
+
+
+@pytest.mark.parametrize("M", [1, 7, 300])
+def test_conv_forward_kernels(ops, M):
+    from rlpyt_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(M)
+    obs = torch.randint(0, 256, (M, 4, 104, 80), dtype=torch.uint8, generator=g)
+    p64 = _params(1)
+    _a1, y1_ref, y2_ref = _ref_stack(obs, p64)
+    w1, b1, w2, b2 = (t.float().cuda().contiguous() for t in p64)
+    obs_d = obs.cuda()
+    y1 = torch.full((M, 475, 16), float("nan"), device="cuda")
+    y2 = torch.full((M, 3456), float("nan"), device="cuda")
+    check(lib.rlpyt_atari_conv1_fwd_f32(ptr(obs_d), None, 1, M, M, ptr(w1), ptr(b1), 1. / 255,
+                                        ptr(y1), stream()), "conv1")
+    _close(y1, y1_ref, what="conv1 fwd")
+    # conv2 on the float64 reference's y1 (isolates conv2 from conv1's rounding)
+    y1_in = y1_ref.float().cuda().contiguous()
+    check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1_in), M, ptr(w2), ptr(b2), ptr(y2), stream()), "conv2")
+    _close(y2, y2_ref, what="conv2 fwd")
+    assert not torch.isnan(y1).any() and not torch.isnan(y2).any()   # every element written
+
+
+def test_conv_identity_weights_asymmetric(ops):
+    """A=I-style check with asymmetric data: w1 picks exactly one input pixel per channel, so
+    the output must be that pixel / 255 -- catches transposed row/col or swapped ky/kx maps."""
+    M = 3
+    g = torch.Generator().manual_seed(5)
+    obs = torch.randint(0, 256, (M, 4, 104, 80), dtype=torch.uint8, generator=g)
+    w1 = torch.zeros(16, 4, 8, 8)
+    for co in range(16):
+        w1[co, co % 4, (3 * co) % 8, (5 * co + 1) % 8] = 1.
+    from rlpyt_amd._lib import check, lib, ptr, stream
+    y1 = torch.empty((M, 475, 16), device="cuda")
+    b1 = torch.zeros(16, device="cuda")
+    obs_d, w1_d = obs.cuda(), w1.cuda()      # keep the device copies alive across the launch
+    check(lib.rlpyt_atari_conv1_fwd_f32(ptr(obs_d), None, 1, M, M, ptr(w1_d), ptr(b1),
+                                        1. / 255, ptr(y1), stream()), "conv1")
+    y1 = y1.cpu().reshape(M, 25, 19, 16)
+    for co in range(16):
+        c, ky, kx = co % 4, (3 * co) % 8, (5 * co + 1) % 8
+        exp = obs[:, c, ky:ky + 97:4, kx:kx + 73:4].float() / 255
+        np.testing.assert_allclose(y1[..., co].numpy(), exp.numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("M", [1, 5, 700])
+def test_conv_backward_kernels(ops, M):
+    from rlpyt_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(100 + M)
+    obs = torch.randint(0, 256, (M, 4, 104, 80), dtype=torch.uint8, generator=g)
+    p64 = [t.requires_grad_(True) for t in _params(2)]
+    a1, y1_ref, y2_ref = _ref_stack(obs, p64)
+    a1.retain_grad()
+    g2 = torch.randn(M, 3456, generator=g, dtype=torch.float64)
+    (y2_ref * g2).sum().backward()
+    # reference dL/d(conv1 pre-activation) = grad wrt a1 masked by relu
+    dy1_ref = (a1.grad * (a1 > 0)).permute(0, 2, 3, 1).reshape(M, 475, 16)
+    w2 = p64[2].detach().float().cuda().contiguous()
+    y1 = y1_ref.detach().float().cuda().contiguous()
+    y2 = y2_ref.detach().float().cuda().contiguous()
+    g2d = g2.float().cuda().contiguous()
+    obs_d = obs.cuda()
+    dy1 = torch.full((M, 475, 16), float("nan"), device="cuda")
+    check(lib.rlpyt_atari_conv2_dgrad_f32(ptr(g2d), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1),
+                                          stream()), "dgrad")
+    _close(dy1, dy1_ref, what="conv2 dgrad")
+    assert not torch.isnan(dy1).any()
+    ws = torch.empty(lib.rlpyt_atari_conv_wgrad_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    dw2 = torch.full((32, 16, 4, 4), float("nan"), device="cuda")
+    db2 = torch.full((32,), float("nan"), device="cuda")
+    check(lib.rlpyt_atari_conv2_wgrad_f32(ptr(g2d), ptr(y2), ptr(y1), M, ptr(ws), ptr(dw2),
+                                          ptr(db2), stream()), "wgrad2")
+    _close(dw2, p64[2].grad, what="conv2 wgrad")
+    _close(db2, p64[3].grad, what="conv2 bias grad")
+    dw1 = torch.full((16, 4, 8, 8), float("nan"), device="cuda")
+    db1 = torch.full((16,), float("nan"), device="cuda")
+    dy1_in = dy1_ref.float().cuda().contiguous()
+    check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs_d), None, 1, M, M, ptr(dy1_in), 1. / 255,
+                                          ptr(ws), ptr(dw1), ptr(db1), stream()), "wgrad1")
+    _close(dw1, p64[0].grad, what="conv1 wgrad")
+    _close(db1, p64[1].grad, what="conv1 bias grad")
+
+
+def test_conv_stack_autograd_with_gather(ops):
+    """ops.atari_conv_stack on a [T,B] batch with the PPO minibatch index map
+    idx -> (idx % T, idx // T), forward + backward, against the float64 reference on the
+    explicitly gathered rows."""
+    T, B, M = 6, 5, 17
+    g = torch.Generator().manual_seed(9)
+    obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, generator=g)
+    idx = torch.randperm(T * B, generator=g)[:M]
+    rows = obs[idx % T, idx // T]
+    p64 = [t.requires_grad_(True) for t in _params(3)]
+    _a1, _y1, y2_ref = _ref_stack(rows, p64)
+    g2 = torch.randn(M, 3456, generator=g, dtype=torch.float64)
+    (y2_ref * g2).sum().backward()
+    p32 = [t.detach().float().cuda().requires_grad_(True) for t in p64]
+    y2 = ops.atari_conv_stack(obs.cuda(), idx.cuda(), *p32)
+    _close(y2, y2_ref, what="stack fwd")
+    (y2 * g2.float().cuda()).sum().backward()
+    for name, a, b in zip(["w1", "b1", "w2", "b2"], p32, p64):
+        _close(a.grad, b.grad, rel=3e-5, what=f"stack grad {name}")
+    # run-to-run deterministic (fixed-order partial reduction, no atomics)
+    p32b = [t.detach().clone().requires_grad_(True) for t in p32]
+    y2b = ops.atari_conv_stack(obs.cuda(), idx.cuda(), *p32b)
+    (y2b * g2.float().cuda()).sum().backward()
+    assert torch.equal(y2, y2b)
+    for a, b in zip(p32, p32b):
+        assert torch.equal(a.grad, b.grad)
+
+
+def test_model_fused_vs_miopen_path(ops):
+    """AtariFfModel: fused MFMA conv stack vs the MIOpen path of the same module (same
+    parameters): outputs and all parameter gradients agree to f32 tolerance; leading-dim
+    handling [T,B], [B], [] preserved."""
+    from rlpyt_amd.models.pg.atari_ff_model import AtariFfModel, ObsGather
+    torch.manual_seed(0)
+    model = AtariFfModel((4, 104, 80), 6).cuda()
+    assert model.fused_conv
+    obs = torch.randint(0, 256, (3, 4, 4, 104, 80), dtype=torch.uint8, device="cuda")
+
+    def run(fused, inp):
+        model.use_fused_conv = fused
+        model.zero_grad(set_to_none=True)
+        pi, v = model(inp, None, None)
+        ((pi * torch.arange(6, device="cuda")).sum() + (v * v).sum()).backward()
+        return pi.detach(), v.detach(), [p.grad.clone() for p in model.parameters()]
+    pf, vf, gf = run(True, obs)
+    pm, vm, gm = run(False, obs)
+    assert pf.shape == (3, 4, 6) and vf.shape == (3, 4)
+    np.testing.assert_allclose(pf.cpu().numpy(), pm.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(vf.cpu().numpy(), vm.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    for a, b in zip(gf, gm):
+        _close(a, b, rel=1e-4, what="param grad fused vs MIOpen")
+    idx = torch.tensor([11, 0, 7, 5], device="cuda")
+    pg, vg, _ = run(True, ObsGather(obs, idx))
+    pe, ve, _ = run(False, obs[idx % 3, idx // 3])
+    np.testing.assert_allclose(pg.cpu().numpy(), pe.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    with torch.no_grad():
+        model.use_fused_conv = True
+        p1, v1 = model(obs[0, 0], None, None)
+        assert p1.shape == (6,) and v1.shape == ()
+        p2, _ = model(obs[0], None, None)
+        np.testing.assert_allclose(p2[0].cpu().numpy(), p1.cpu().numpy(), rtol=1e-5, atol=1e-7)
