@@ -30,7 +30,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense f32 peak
 KERNEL_NAMES = {
+    "conv1_fwd": "conv1_fwd_kernel (gather + u8->f32 + conv 4->16 k8 s4 + bias + ReLU, fp32 MFMA)",
+    "conv2_fwd": "conv2_fwd_kernel (conv 16->32 k4 s2 p1 + bias + ReLU, fp32 MFMA)",
+    "conv2_dgrad": "conv2_dgrad_kernel (transposed conv + ReLU masks, fp32 MFMA)",
+    "conv2_wgrad": "conv2_wgrad_kernel (+ bias grad, fp32 MFMA)",
+    "conv1_wgrad": "conv1_wgrad_kernel (gather + u8->f32 + weight/bias grad, fp32 MFMA)",
     "obs_to_nhwc": "obs_to_nhwc_f32_kernel (minibatch gather + u8->f32 + CHW->HWC)",
     "gather_tb": "gather_wide_kernel (minibatch observation gather)",
     "gae": "scan_exact_kernel<GAE>", "ppo_loss": "pg_loss_kernel<PPO>",
@@ -173,12 +179,21 @@ def main():
         if ksum:
             # dominant own kernel of the timed region = largest total HIP-event time
             name, g = max(ksum.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])
-            out["roofline"] = {"kernel": KERNEL_NAMES.get(name, name),
-                               "bound": "hbm", "achieved": g["GBps"],
-                               "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": g["GBps"] / HBM_PEAK_GBPS, "traffic": None,
-                               "avg_us": g["avg_us"], "launches": g["launches"],
-                               "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
+            if "TFLOPs" in g:   # dense contraction: priced against the fp32 MFMA peak
+                out["roofline"] = {"kernel": KERNEL_NAMES.get(name, name), "bound": "mfma",
+                                   "achieved": g["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": g["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
+                                   "traffic": None, "avg_us": g["avg_us"],
+                                   "launches": g["launches"],
+                                   "alg_flops_per_launch": g["alg_flops_per_launch"],
+                                   "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
+            else:
+                out["roofline"] = {"kernel": KERNEL_NAMES.get(name, name),
+                                   "bound": "hbm", "achieved": g["GBps"],
+                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": g["GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                                   "avg_us": g["avg_us"], "launches": g["launches"],
+                                   "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
             out["kernels"] = {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv)
                                   for kk, vv in v.items()} for k, v in ksum.items()}
         out["roofline_gae_scaled"] = gae_scaled_roofline()

@@ -207,6 +207,39 @@ int rlpyt_obs_to_nhwc_f32(const uint8_t* src, const int64_t* flat_idx /*nullable
                           rlpyt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Per-time-step device work of the HBM-resident sampler.
+ *
+ * rlpyt_commit_rows: the row writes of rlpyt/samplers/parallel/gpu/collectors.py:30-47
+ * (`env_buf.observation[t] = step.observation`, `agent_buf.action[t] = ...`, ...) for up to
+ * 64 leaves in ONE launch.  Entry e copies nbytes from src to
+ *     dst + (t + dt) * row_stride_bytes + col_off_bytes,
+ * with t read from device memory (*t_dev, or 0 when t_dev is null) so a captured hipGraph
+ * serves every time step.  `table_dev` is an array of rlpyt_row_copy in DEVICE memory;
+ * max_entry_bytes sizes the grid.
+ *
+ * rlpyt_categorical_head_f32: policy/value heads + softmax + action sampling of
+ * rlpyt/models/pg/atari_ff_model.py:56-58 and rlpyt/distributions/categorical.py:28-31
+ * (sample_mode forward only): prob = softmax(h w_pi^T + b_pi) [n,A]; value = h w_v^T + b_v
+ * [n] (w_v/value nullable together); action[i] = min{a : sum_{a'<=a} prob[i,a'] >
+ * uniforms[i]} (inverse CDF; action nullable = no sampling).  A <= 32. */
+typedef struct rlpyt_row_copy {
+  void* dst;
+  const void* src;
+  int64_t row_stride_bytes;
+  int64_t col_off_bytes;
+  int64_t nbytes;
+  int32_t dt;
+  int32_t reserved;
+} rlpyt_row_copy;
+int rlpyt_commit_rows(const rlpyt_row_copy* table_dev, int n_entries, int64_t max_entry_bytes,
+                      const int64_t* t_dev /*nullable*/, rlpyt_stream_t stream);
+int rlpyt_categorical_head_f32(const float* h /*[n,K]*/, const float* w_pi /*[A,K]*/,
+                               const float* b_pi, const float* w_v /*[K], nullable*/,
+                               const float* b_v, const float* uniforms /*[n], nullable*/,
+                               int64_t n, int K, int A, float* prob, float* value,
+                               int64_t* action, rlpyt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * AtariFfModel convolution stack on fp32 MFMA -- rlpyt/models/pg/atari_ff_model.py:40-63 with
  * rlpyt/models/conv2d.py:8-117 at its default geometry: uint8 [4,104,80] -> conv(4->16, k8,
  * s4, p0) + ReLU -> conv(16->32, k4, s2, p1) + ReLU -> 3456 features (NCHW flatten order, so

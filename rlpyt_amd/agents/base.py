@@ -79,6 +79,12 @@ class BaseAgent:
         wrapper's per-call bookkeeping (and keeps the step hipGraph-capturable)."""
         return getattr(self.model, "module", self.model)
 
+    @property
+    def uses_prev_inputs(self):
+        """False when the model ignores prev_action / prev_reward (e.g. AtariFfModel): the
+        sampler then skips building them every step."""
+        return getattr(self.sampling_model, "uses_prev_inputs", True)
+
     def collector_initialize(self, global_B=1, env_ranks=None):
         pass
 

@@ -11,7 +11,10 @@ AgentInfo = namedarraytuple("AgentInfo", ["dist_info", "value"])
 class CategoricalPgAgent(BaseAgent):
     def __call__(self, observation, prev_action, prev_reward):
         """Training forward: (DistInfo(prob), value), differentiable, in HBM."""
-        prev_action = self.distribution.to_onehot(prev_action)
+        if self.uses_prev_inputs:
+            prev_action = self.distribution.to_onehot(prev_action)
+        else:
+            prev_action = prev_reward = None
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         pi, value = self.model(obs, pa, pr)
         return self._out((DistInfo(prob=pi), value))
@@ -22,18 +25,32 @@ class CategoricalPgAgent(BaseAgent):
 
     @torch.no_grad()
     def step(self, observation, prev_action, prev_reward):
-        """Sampling forward: one batched model call + on-device multinomial."""
-        prev_action = self.distribution.to_onehot(prev_action)
+        """Sampling forward: one batched model call + on-device categorical draw.  Models
+        that provide ``sample_step`` (AtariFfModel) fuse heads, softmax and the draw."""
+        m = self.sampling_model
+        fused = (hasattr(m, "sample_step") and isinstance(observation, torch.Tensor)
+                 and observation.is_cuda and observation.dim() == 4)
+        if self.uses_prev_inputs and prev_action is not None:
+            prev_action = self.distribution.to_onehot(prev_action)
+        else:
+            prev_action = prev_reward = None
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
-        pi, value = self.sampling_model(obs, pa, pr)
-        dist_info = DistInfo(prob=pi)
-        action = self.distribution.sample(dist_info)
+        if fused:
+            action, pi, value = m.sample_step(obs, pa, pr)
+            dist_info = DistInfo(prob=pi)
+        else:
+            pi, value = m(obs, pa, pr)
+            dist_info = DistInfo(prob=pi)
+            action = self.distribution.sample(dist_info)
         agent_info = AgentInfo(dist_info=dist_info, value=value)
         return self._out(AgentStep(action=action, agent_info=agent_info))
 
     @torch.no_grad()
     def value(self, observation, prev_action, prev_reward):
-        prev_action = self.distribution.to_onehot(prev_action)
+        if self.uses_prev_inputs and prev_action is not None:
+            prev_action = self.distribution.to_onehot(prev_action)
+        else:
+            prev_action = prev_reward = None
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         _pi, value = self.sampling_model(obs, pa, pr)
         return self._out(value)

@@ -425,22 +425,28 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(
 }
 
 // out[e] = sum_g partial[g][e]; e < n.  Fixed order -> run-to-run deterministic.
+// 64 elements per workgroup, the G partials split over the 4 waves (coalesced 256 B rows).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
                                                               int G, int n, float* __restrict__ out_w,
                                                               int n_w, float* __restrict__ out_b) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int g = 0;
-  for (; g + 4 <= G; g += 4) {
-    s0 += partial[(int64_t)(g + 0) * n + e];
-    s1 += partial[(int64_t)(g + 1) * n + e];
-    s2 += partial[(int64_t)(g + 2) * n + e];
-    s3 += partial[(int64_t)(g + 3) * n + e];
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < n) {
+    int g = wave;
+    for (; g + 4 < G; g += 8) {
+      s0 += partial[(int64_t)g * n + e];
+      s1 += partial[(int64_t)(g + 4) * n + e];
+    }
+    if (g < G) s0 += partial[(int64_t)g * n + e];
   }
-  for (; g < G; ++g) s0 += partial[(int64_t)g * n + e];
-  const float s = (s0 + s1) + (s2 + s3);
-  if (e < n_w) out_w[e] = s; else out_b[e - n_w] = s;
+  red[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && e < n) {
+    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (e < n_w) out_w[e] = s; else out_b[e - n_w] = s;
+  }
 }
 
 int grid_for(int64_t M, int per_cu) {
@@ -517,7 +523,7 @@ extern "C" int rlpyt_atari_conv2_wgrad_f32(const float* g2, const float* y2, con
   const int g = (int)std::min<int64_t>(M, kWgradGrid);
   hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(g), dim3(256), 0, s, g2, y2, y1, workspace, M);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART2 + 255) / 256), dim3(256), 0, s, workspace,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(256), 0, s, workspace,
                      g, PART2, dw2, DW2_N, db2);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -537,7 +543,7 @@ extern "C" int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* fl
   hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(g), dim3(256), 0, s, obs, flat_idx, T, B, dy1,
                      workspace, M, scale);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART1 + 255) / 256), dim3(256), 0, s, workspace,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART1 + 63) / 64), dim3(256), 0, s, workspace,
                      g, PART1, dw1, DW1_N, db1);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;

@@ -1,0 +1,132 @@
+// Per-time-step device work of the HBM-resident sampler that is not the model itself
+// (roles of rlpyt/samplers/parallel/gpu/collectors.py:30-47 -- writing row t of the sample
+// batch -- and of rlpyt/agents/pg/categorical.py:34-43 + distributions/categorical.py:28-31
+// -- policy head, softmax, action sampling).  Both kernels read the time index from device
+// memory so that ONE captured hipGraph serves every step of the batch.
+#include "common.h"
+
+namespace rlpyt {
+namespace {
+
+// Copy n_entries byte ranges: dst_e + (t + dt_e) * row_stride_e + col_off_e <- src_e[0:nbytes_e].
+// grid = (chunks, n_entries); 16-byte lanes when everything is 16-byte aligned.
+__global__ __launch_bounds__(256) void commit_rows_kernel(const rlpyt_row_copy* __restrict__ table,
+                                                          const int64_t* __restrict__ t_dev) {
+  const rlpyt_row_copy e = table[blockIdx.y];
+  const int64_t t = (t_dev != nullptr ? *t_dev : 0) + e.dt;
+  char* __restrict__ dst = static_cast<char*>(e.dst) + t * e.row_stride_bytes + e.col_off_bytes;
+  const char* __restrict__ src = static_cast<const char*>(e.src);
+  const int64_t n = e.nbytes;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+  const bool wide = (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0);
+  if (wide) {
+    const int64_t n16 = n >> 4;
+    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
+    uint4* __restrict__ d4 = reinterpret_cast<uint4*>(dst);
+    for (int64_t i = tid; i < n16; i += nthr) d4[i] = s4[i];
+    for (int64_t i = (n16 << 4) + tid; i < n; i += nthr) dst[i] = src[i];
+  } else {
+    for (int64_t i = tid; i < n; i += nthr) dst[i] = src[i];
+  }
+}
+
+// One wave per row: logits = h . w_pi^T + b_pi, prob = softmax(logits), value = h . w_v + b_v,
+// action = inverse-CDF sample of prob at the given uniform (first a with cumsum > u).
+template <int AMAX>
+__global__ __launch_bounds__(256) void categorical_head_kernel(
+    const float* __restrict__ h, const float* __restrict__ w_pi, const float* __restrict__ b_pi,
+    const float* __restrict__ w_v, const float* __restrict__ b_v,
+    const float* __restrict__ uniforms, int64_t n, int K, int A, float* __restrict__ prob,
+    float* __restrict__ value, int64_t* __restrict__ action) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* __restrict__ hr = h + row * K;
+  float acc[AMAX + 1];
+#pragma unroll
+  for (int a = 0; a <= AMAX; ++a) acc[a] = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float x = hr[k];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) acc[a] = fmaf(x, w_pi[a * K + k], acc[a]);
+    if (w_v != nullptr) acc[AMAX] = fmaf(x, w_v[k], acc[AMAX]);
+  }
+#pragma unroll
+  for (int a = 0; a <= AMAX; ++a) acc[a] = wave_sum(acc[a]);
+  if (lane == 0) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) {
+        acc[a] += b_pi[a];
+        mx = fmaxf(mx, acc[a]);
+      }
+    float den = 0.f;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) {
+        acc[a] = expf(acc[a] - mx);
+        den += acc[a];
+      }
+    const float inv = 1.f / den;
+    float cum = 0.f;
+    int pick = -1, last_pos = 0;
+    const float u = uniforms != nullptr ? uniforms[row] : 0.f;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) {
+        const float p = acc[a] * inv;
+        prob[row * A + a] = p;
+        cum += p;
+        if (p > 0.f) last_pos = a;
+        if (pick < 0 && cum > u) pick = a;
+      }
+    if (value != nullptr) value[row] = acc[AMAX] + (b_v != nullptr ? b_v[0] : 0.f);
+    if (action != nullptr) action[row] = pick >= 0 ? pick : last_pos;  // u ~ 1: rounding guard
+  }
+}
+
+}  // namespace
+}  // namespace rlpyt
+
+using namespace rlpyt;
+
+extern "C" int rlpyt_commit_rows(const rlpyt_row_copy* table_dev, int n_entries,
+                                 int64_t max_entry_bytes, const int64_t* t_dev,
+                                 rlpyt_stream_t stream) {
+  RL_CHECK_ARG(n_entries >= 0 && n_entries <= 64, RLPYT_EINVAL, "rlpyt_commit_rows: 0..64 entries");
+  if (n_entries == 0) return RLPYT_OK;
+  RL_CHECK_ARG(table_dev != nullptr, RLPYT_EINVAL, "rlpyt_commit_rows: null table");
+  const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(max_entry_bytes, 256 * 64), 1024));
+  hipLaunchKernelGGL(commit_rows_kernel, dim3((unsigned)chunks, (unsigned)n_entries), dim3(256), 0,
+                     (hipStream_t)stream, table_dev, t_dev);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_categorical_head_f32(const float* h, const float* w_pi, const float* b_pi,
+                                          const float* w_v, const float* b_v,
+                                          const float* uniforms, int64_t n, int K, int A,
+                                          float* prob, float* value, int64_t* action,
+                                          rlpyt_stream_t stream) {
+  RL_CHECK_ARG(n >= 0 && K > 0 && A > 0 && A <= 32, RLPYT_EINVAL,
+               "rlpyt_categorical_head_f32: need 0 < A <= 32, K > 0");
+  if (n == 0) return RLPYT_OK;
+  RL_CHECK_ARG(h && w_pi && b_pi && prob, RLPYT_EINVAL, "rlpyt_categorical_head_f32: null pointer");
+  RL_CHECK_ARG((action == nullptr) || (uniforms != nullptr), RLPYT_EINVAL,
+               "rlpyt_categorical_head_f32: sampling needs uniforms");
+  RL_CHECK_ARG((value == nullptr) == (w_v == nullptr), RLPYT_EINVAL,
+               "rlpyt_categorical_head_f32: value and w_v go together");
+  const dim3 grid((unsigned)ceil_div(n, 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (A <= 8)
+    hipLaunchKernelGGL((categorical_head_kernel<8>), grid, block, 0, s, h, w_pi, b_pi, w_v, b_v,
+                       uniforms, n, K, A, prob, value, action);
+  else
+    hipLaunchKernelGGL((categorical_head_kernel<32>), grid, block, 0, s, h, w_pi, b_pi, w_v, b_v,
+                       uniforms, n, K, A, prob, value, action);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}

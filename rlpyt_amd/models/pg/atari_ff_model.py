@@ -65,6 +65,27 @@ class AtariFfModel(torch.nn.Module):
         c1, c2 = self.conv.conv.conv[0], self.conv.conv.conv[2]
         return ops.atari_conv_stack(obs, flat_idx, c1.weight, c1.bias, c2.weight, c2.bias)
 
+    uses_prev_inputs = False   # prev_action / prev_reward are ignored (as in the reference)
+
+    @torch.no_grad()
+    def sample_step(self, image, prev_action=None, prev_reward=None):
+        """Sampling forward on the device: (action, prob, value) for ``[B, C, H, W]`` uint8
+        observations -- conv stack, FC trunk, then heads + softmax + categorical draw fused in
+        one kernel (inverse-CDF on ``torch.rand``; same distribution as the reference's
+        ``torch.multinomial``, rlpyt/distributions/categorical.py:28-31)."""
+        from ... import ops
+        lead_dim, T, B, img_shape = infer_leading_dims(image, 3)
+        assert lead_dim == 1, "sample_step takes [B, C, H, W] observations"
+        if image.dtype == torch.uint8 and self.fused_conv:
+            feat = self._conv_features(image.contiguous(), None)
+            fc_out = self.conv.head(feat)
+        else:
+            fc_out = self.conv(prepare_image(image, B, img_shape))
+        u = torch.rand(B, device=image.device)
+        prob, value, action = ops.categorical_head(fc_out, self.pi.weight, self.pi.bias,
+                                                   self.value.weight, self.value.bias, u)
+        return action, prob, value
+
     def forward(self, image, prev_action, prev_reward):
         """[T,B,C,H,W] / [B,C,H,W] / [C,H,W] -> (pi, value) with the same lead dims."""
         if isinstance(image, ObsGather):

@@ -442,6 +442,89 @@ def atari_conv_stack(obs, flat_idx, w1, b1, w2, b2, scale=1. / 255):
 
 
 # --------------------------------------------------------------------------------------
+# per-time-step sampler kernels (csrc/step.hip)
+# --------------------------------------------------------------------------------------
+_ROW_COPY_DTYPE = [("dst", "<u8"), ("src", "<u8"), ("row_stride", "<i8"), ("col_off", "<i8"),
+                   ("nbytes", "<i8"), ("dt", "<i4"), ("reserved", "<i4")]
+
+
+class RowCommit:
+    """A fixed list of row writes ``dst[t + dt, lo:hi] = src`` executed by ONE kernel launch
+    with ``t`` read from a device counter (``rlpyt_commit_rows``): the sampler's per-step
+    writes into the ``[T, B]`` batch (rlpyt/samplers/parallel/gpu/collectors.py:30-47).
+
+    ``entries``: tuples ``(dst, src, lo, dt)`` with ``dst`` a contiguous ``[T', B, ...]``
+    device tensor and ``src`` a contiguous ``[hi - lo, ...]`` device tensor, or
+    ``(dst, src, None, 0)`` for a plain copy ``dst[...] = src``.  The table lives in device
+    memory at a fixed address; ``set_entries`` may be called again (e.g. after hipGraph
+    capture, once the sources' addresses are known)."""
+
+    def __init__(self, n_entries, device):
+        import numpy as np
+        self._np = np
+        self.n = int(n_entries)
+        self.device = device
+        self.table = torch.zeros(self.n * 48, dtype=torch.uint8, device=device)
+        self.max_bytes = 0
+        self._keep = None
+
+    def set_entries(self, entries):
+        np = self._np
+        assert len(entries) == self.n
+        host = np.zeros(self.n, dtype=_ROW_COPY_DTYPE)
+        assert host.itemsize == 48
+        keep = []
+        for i, (dst, src, lo, dt) in enumerate(entries):
+            assert dst.is_cuda and src.is_cuda and dst.is_contiguous() and src.is_contiguous()
+            assert dst.dtype == src.dtype
+            nbytes = src.numel() * src.element_size()
+            if lo is None:
+                assert dst.numel() == src.numel()
+                row_stride = col_off = 0
+            else:
+                assert dst.dim() >= 2 and tuple(dst.shape[2:]) == tuple(src.shape[1:])
+                per_col = src.element_size()
+                for d in dst.shape[2:]:
+                    per_col *= d
+                row_stride, col_off = per_col * dst.shape[1], per_col * lo
+                assert lo + src.shape[0] <= dst.shape[1]
+            host[i] = (dst.data_ptr(), src.data_ptr(), row_stride, col_off, nbytes, dt, 0)
+            keep.append((dst, src))
+            self.max_bytes = max(self.max_bytes, nbytes)
+        self._keep = keep
+        self.table.copy_(torch.from_numpy(host.view(np.uint8).copy()))
+
+    def launch(self, t_dev):
+        _lib.require_gpu()
+        check(lib.rlpyt_commit_rows(ptr(self.table), self.n, self.max_bytes, ptr(t_dev), stream()),
+              "rlpyt_commit_rows")
+
+
+def categorical_head(h, w_pi, b_pi, w_v=None, b_v=None, uniforms=None):
+    """Policy / value heads + softmax (+ inverse-CDF action sampling when ``uniforms`` is
+    given) in one kernel -- the no-grad sampling forward of
+    rlpyt/models/pg/atari_ff_model.py:56-58 + rlpyt/distributions/categorical.py:28-31.
+    Returns ``(prob [n,A], value [n] | None, action int64 [n] | None)``."""
+    _lib.require_gpu()
+    h = _f32(h)
+    n, K = h.shape
+    A = w_pi.shape[0]
+    w_pi, b_pi = _f32(w_pi.detach()), _f32(b_pi.detach())
+    prob = torch.empty((n, A), dtype=torch.float32, device=h.device)
+    value = action = wv = bv = None
+    if w_v is not None:
+        wv, bv = _f32(w_v.detach()).reshape(-1), _f32(b_v.detach()).reshape(-1)
+        value = torch.empty(n, dtype=torch.float32, device=h.device)
+    if uniforms is not None:
+        uniforms = _f32(uniforms).reshape(-1)
+        action = torch.empty(n, dtype=torch.int64, device=h.device)
+    check(lib.rlpyt_categorical_head_f32(ptr(h), ptr(w_pi), ptr(b_pi), ptr(wv), ptr(bv),
+                                         ptr(uniforms), n, K, A, ptr(prob), ptr(value),
+                                         ptr(action), stream()), "rlpyt_categorical_head_f32")
+    return prob, value, action
+
+
+# --------------------------------------------------------------------------------------
 # gathers
 # --------------------------------------------------------------------------------------
 def _row_bytes(x, lead):

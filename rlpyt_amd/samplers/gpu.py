@@ -383,6 +383,16 @@ class GpuSampler(BaseSampler):
             G.done_stage = G.misc_stage[4 * Bg:5 * Bg].view(torch.bool)
             G.action_out = buffer_from_example(ex["action"], (Bg,), device=dev)
             G.t_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            G.pre_commit = G.post_commit = None
+            if cuda:
+                from .. import ops
+                pre = ([(d, x, G.lo, 0) for d, x in zip(buffer_leaves(observation),
+                                                        buffer_leaves(G.obs_stage))]
+                       + [(all_reward, G.reward_stage, G.lo, 0), (all_done, G.done_stage, G.lo, 0)])
+                G.pre_commit = ops.RowCommit(len(pre), dev)
+                G.pre_commit.set_entries(pre)
+                n_post = 2 * len(buffer_leaves(all_action)) + len(buffer_leaves(agent_info))
+                G.post_commit = ops.RowCommit(n_post, dev)
             G.event = torch.cuda.Event() if cuda else None
             # one HIP stream per pipeline group: the H2D of one group overlaps the forward of
             # the other (a single group keeps torch's current stream)
@@ -407,29 +417,38 @@ class GpuSampler(BaseSampler):
         lo, hi = G.lo, G.hi
         _map(lambda d, s: d[:, lo:hi].index_copy_(0, t_idx, s.unsqueeze(0)), dst, src)
 
-    def _step_body(self, G):
+    def _step_body(self, G, capturing=False):
         """Device work of one time step of group ``G`` (graph-capturable: fixed addresses,
         the time index is the device counter ``G.t_dev``).
 
         Staging holds obs_t and the (reward, done) produced by env step t-1 (at t=0: the
         carry from the previous batch).  Commits obs -> row t, reward -> all_reward[t]
         (= reward[t-1] = prev_reward[t]), done -> all_done[t] (= done[t-1]); runs
-        ``agent.step``; writes action -> all_action[t+1] (= action[t]) and agent_info[t]."""
+        ``agent.step``; writes action -> all_action[t+1] (= action[t]) and agent_info[t].
+        On the GPU the row writes are two ``rlpyt_commit_rows`` launches (all leaves at
+        once); elsewhere torch ``index_copy_`` does the same thing leaf by leaf."""
         s, t = self.samples, G.t_dev
         lo, hi = G.lo, G.hi
-        self._commit_rows(s.env.observation, G.obs_stage, G, t)
-        self._all_reward[:, lo:hi].index_copy_(0, t, G.reward_stage.unsqueeze(0))
-        self._all_done[:, lo:hi].index_copy_(0, t, G.done_stage.unsqueeze(0))
-        prev_action = _map(lambda x: x[:, lo:hi].index_select(0, t).squeeze(0),
-                           self._all_action)
-        prev_reward = G.reward_stage
-        if self.mid_batch_reset:
-            # after a reset the agent sees null prev action/reward
-            # (action_server.py:49-53); the stored rows stay untouched.
-            dn = G.done_stage
-            prev_action = _map(lambda x: torch.where(
-                dn.reshape((-1,) + (1,) * (x.dim() - 1)), torch.zeros_like(x), x), prev_action)
-            prev_reward = torch.where(dn, torch.zeros_like(prev_reward), prev_reward)
+        if G.pre_commit is not None:
+            G.pre_commit.launch(t)
+        else:
+            self._commit_rows(s.env.observation, G.obs_stage, G, t)
+            self._all_reward[:, lo:hi].index_copy_(0, t, G.reward_stage.unsqueeze(0))
+            self._all_done[:, lo:hi].index_copy_(0, t, G.done_stage.unsqueeze(0))
+        if getattr(self.agent, "uses_prev_inputs", True):
+            prev_action = _map(lambda x: x[:, lo:hi].index_select(0, t).squeeze(0),
+                               self._all_action)
+            prev_reward = G.reward_stage
+            if self.mid_batch_reset:
+                # after a reset the agent sees null prev action/reward
+                # (action_server.py:49-53); the stored rows stay untouched.
+                dn = G.done_stage
+                prev_action = _map(lambda x: torch.where(
+                    dn.reshape((-1,) + (1,) * (x.dim() - 1)), torch.zeros_like(x), x),
+                    prev_action)
+                prev_reward = torch.where(dn, torch.zeros_like(prev_reward), prev_reward)
+        else:
+            prev_action = prev_reward = None
         action, agent_info = self.agent.step(G.obs_stage, prev_action, prev_reward)
         if not self.mid_batch_reset:
             # wait-reset: finished envs record blank action / agent_info
@@ -439,9 +458,20 @@ class GpuSampler(BaseSampler):
             def blank(x):
                 return x * keep.reshape((-1,) + (1,) * (x.dim() - 1)).to(x.dtype)
             action, agent_info = _map(blank, action), _map(blank, agent_info)
-        self._commit_rows(self._all_action, action, G, t + 1)
-        self._commit_rows(s.agent.agent_info, agent_info, G, t)
-        _copy_leaves(G.action_out, action)
+        if capturing:
+            # one launch writes action[t], agent_info[t] and the host-bound action copy; the
+            # sources live in the graph's private pool, so the table is filled after capture
+            a_src = [x.contiguous() for x in buffer_leaves(action)]
+            i_src = [x.contiguous() for x in buffer_leaves(agent_info)]
+            G.post_entries = (
+                [(d, x, lo, 1) for d, x in zip(buffer_leaves(self._all_action), a_src)]
+                + [(d, x, lo, 0) for d, x in zip(buffer_leaves(s.agent.agent_info), i_src)]
+                + [(d, x, None, 0) for d, x in zip(buffer_leaves(G.action_out), a_src)])
+            G.post_commit.launch(t)
+        else:
+            self._commit_rows(self._all_action, action, G, t + 1)
+            self._commit_rows(s.agent.agent_info, agent_info, G, t)
+            _copy_leaves(G.action_out, action)
         t.add_(1)
 
     def _tail_body(self, G):
@@ -507,7 +537,8 @@ class GpuSampler(BaseSampler):
         t_keep = G.t_dev.clone()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            self._step_body(G)
+            self._step_body(G, capturing=True)
+        G.post_commit.set_entries(G.post_entries)
         G.t_dev.copy_(t_keep)       # capture does not execute, keep the counter anyway
         torch.cuda.synchronize()
         logger.log(f"GpuSampler: captured the step graph of pipeline group {G.idx}.")

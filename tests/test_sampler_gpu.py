@@ -59,3 +59,67 @@ def test_sampler_rows_consistent_on_device(n_workers, n_groups, use_graph):
     if use_graph:
         assert all(G.graph is not None for G in s.groups)
     s.shutdown()
+
+
+def test_commit_rows_matches_indexing():
+    """rlpyt_commit_rows: dst[t + dt, lo:hi] = src for several leaves in one launch, t from a
+    device counter; bit-exact vs torch indexing, incl. unaligned byte counts."""
+    from rlpyt_amd import ops
+    T, B, lo, Bg = 7, 10, 3, 5
+    g = torch.Generator().manual_seed(0)
+    obs = torch.zeros((T, B, 4, 13, 5), dtype=torch.uint8, device="cuda")       # 260 B / col
+    rew = torch.zeros((T + 1, B), dtype=torch.float32, device="cuda")
+    done = torch.zeros((T + 1, B), dtype=torch.bool, device="cuda")
+    act = torch.zeros((T + 1, B), dtype=torch.int64, device="cuda")
+    out = torch.zeros(Bg, dtype=torch.int64, device="cuda")
+    s_obs = torch.randint(0, 256, (Bg, 4, 13, 5), dtype=torch.uint8, generator=g).cuda()
+    s_rew = torch.randn(Bg, generator=g).cuda()
+    s_done = (torch.rand(Bg, generator=g) < 0.5).cuda()
+    s_act = torch.randint(0, 6, (Bg,), generator=g).cuda()
+    rc = ops.RowCommit(5, torch.device("cuda:0"))
+    rc.set_entries([(obs, s_obs, lo, 0), (rew, s_rew, lo, 0), (done, s_done, lo, 0),
+                    (act, s_act, lo, 1), (out, s_act, None, 0)])
+    t_dev = torch.tensor([4], dtype=torch.int64, device="cuda")
+    rc.launch(t_dev)
+    torch.cuda.synchronize()
+    exp_obs = torch.zeros_like(obs)
+    exp_obs[4, lo:lo + Bg] = s_obs
+    assert torch.equal(obs, exp_obs)
+    exp = torch.zeros_like(rew); exp[4, lo:lo + Bg] = s_rew  # noqa: E702
+    assert torch.equal(rew, exp)
+    exp = torch.zeros_like(done); exp[4, lo:lo + Bg] = s_done  # noqa: E702
+    assert torch.equal(done, exp)
+    exp = torch.zeros_like(act); exp[5, lo:lo + Bg] = s_act  # noqa: E702
+    assert torch.equal(act, exp)
+    assert torch.equal(out, s_act)
+
+
+@pytest.mark.parametrize("n,K,A", [(256, 512, 6), (5, 64, 18), (1, 512, 2)])
+def test_categorical_head_matches_torch(n, K, A):
+    """Heads + softmax within f32 tolerance (rtol 1e-5) of torch; the drawn action is exactly
+    the inverse-CDF index min{a: cumsum(prob)[a] > u} of the kernel's own probabilities, and
+    over many uniforms the empirical frequencies match the probabilities."""
+    from rlpyt_amd import ops
+    g = torch.Generator().manual_seed(n + A)
+    h = torch.randn(n, K, generator=g).cuda()
+    w_pi, b_pi = (torch.randn(A, K, generator=g) * 0.05).cuda(), torch.randn(A, generator=g).cuda()
+    w_v, b_v = (torch.randn(1, K, generator=g) * 0.05).cuda(), torch.randn(1, generator=g).cuda()
+    u = torch.rand(n, generator=g).cuda()
+    prob, value, action = ops.categorical_head(h, w_pi, b_pi, w_v, b_v, u)
+    ref_p = torch.softmax(h.double() @ w_pi.double().t() + b_pi.double(), -1)
+    ref_v = (h.double() @ w_v.double().t()).squeeze(-1) + b_v.double()
+    np.testing.assert_allclose(prob.cpu().numpy(), ref_p.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(value.cpu().numpy(), ref_v.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    cum = np.cumsum(prob.cpu().numpy().astype(np.float32), axis=1, dtype=np.float32)
+    exp = np.minimum((cum <= u.cpu().numpy()[:, None]).sum(1), A - 1)
+    assert np.array_equal(action.cpu().numpy(), exp)
+    # distribution check on one row
+    N = 200000
+    hh = h[:1].expand(N, K).contiguous()
+    uu = torch.rand(N, generator=g).cuda()
+    p1, _, a1 = ops.categorical_head(hh, w_pi, b_pi, w_v, b_v, uu)
+    freq = torch.bincount(a1, minlength=A).double().cpu().numpy() / N
+    np.testing.assert_allclose(freq, p1[0].double().cpu().numpy(), atol=5e-3)
+    # no-sampling / no-value variants
+    p2, v2, a2 = ops.categorical_head(h, w_pi, b_pi)
+    assert v2 is None and a2 is None and torch.equal(p2, prob)
