@@ -239,6 +239,18 @@ int rlpyt_categorical_head_f32(const float* h /*[n,K]*/, const float* w_pi /*[A,
                                int64_t n, int K, int A, float* prob, float* value,
                                int64_t* action, rlpyt_stream_t stream);
 
+/* Frame-stack push for frame-stacked environments (rlpyt/envs/atari/atari_env.py:115-118:
+ * the observation is the last C frames, newest last): the host uploads only the newest
+ * frame of each env and row t of the HBM batch is rebuilt on the device,
+ *   obs[t, lo+b] = slot[b] >= 0 ? full_rows[slot[b]]                (reset env / first step)
+ *                               : concat(obs[t-1, lo+b, 1:], new_frame[b]),
+ * t = *t_dev (t >= 1 wherever slot[b] < 0).  obs u8 [T,B,C,HW]; new_frame u8 [Bg,HW];
+ * full_rows u8 [<=Bg,C,HW]; slot i32 [Bg]; stage u8 [Bg,C,HW] (nullable) receives a copy of
+ * the rebuilt rows.  Bit-exact byte moves. */
+int rlpyt_frame_push(uint8_t* obs, const int64_t* t_dev, int64_t B, int64_t lo, int64_t Bg,
+                     int C, int64_t HW, const uint8_t* new_frame, const uint8_t* full_rows,
+                     const int32_t* slot, uint8_t* stage /*nullable*/, rlpyt_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * AtariFfModel convolution stack on fp32 MFMA -- rlpyt/models/pg/atari_ff_model.py:40-63 with
  * rlpyt/models/conv2d.py:8-117 at its default geometry: uint8 [4,104,80] -> conv(4->16, k8,

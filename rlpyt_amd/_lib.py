@@ -82,6 +82,8 @@ _SIGNATURES = {
     "rlpyt_commit_rows": (c_int, [_p, c_int, c_int64, _p, _p]),
     "rlpyt_categorical_head_f32": (c_int, [_p, _p, _p, _p, _p, _p, c_int64, c_int, c_int, _p, _p,
                                            _p, _p]),
+    "rlpyt_frame_push": (c_int, [_p, _p, c_int64, c_int64, c_int64, c_int, c_int64, _p, _p, _p, _p,
+                                 _p]),
     "rlpyt_atari_conv1_fwd_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, _p, c_float, _p, _p]),
     "rlpyt_atari_conv2_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p]),
     "rlpyt_atari_conv2_dgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p]),

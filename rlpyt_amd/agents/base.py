@@ -33,6 +33,7 @@ class BaseAgent:
         self.distribution = None
         self.device = torch.device("cpu")
         self._mode = None
+        self.sample_generator = None   # torch.Generator for action draws (None: default)
         if self.model_kwargs is None:
             self.model_kwargs = dict()
 

@@ -36,12 +36,12 @@ class CategoricalPgAgent(BaseAgent):
             prev_action = prev_reward = None
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         if fused:
-            action, pi, value = m.sample_step(obs, pa, pr)
+            action, pi, value = m.sample_step(obs, pa, pr, generator=self.sample_generator)
             dist_info = DistInfo(prob=pi)
         else:
             pi, value = m(obs, pa, pr)
             dist_info = DistInfo(prob=pi)
-            action = self.distribution.sample(dist_info)
+            action = self.distribution.sample(dist_info, generator=self.sample_generator)
         agent_info = AgentInfo(dist_info=dist_info, value=value)
         return self._out(AgentStep(action=action, agent_info=agent_info))
 

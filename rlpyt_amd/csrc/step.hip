@@ -130,3 +130,60 @@ extern "C" int rlpyt_categorical_head_f32(const float* h, const float* w_pi, con
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
+
+// --------------------------------------------------------------------------------------
+// Frame-stack push: observations of frame-stacked envs (rlpyt/envs/atari/atari_env.py:
+// 115-118 keeps obs = the last C frames, newest last) differ from the previous step's only
+// by one frame, so the host uploads just that frame (C x less PCIe traffic) and the stack is
+// rebuilt in HBM:  obs[t, lo+b] = slot[b] >= 0 ? full_rows[slot[b]]            (env was reset /
+//                                                                               first step of a batch)
+//                               : concat(obs[t-1, lo+b, 1:], new_frame[b]).
+// Also mirrors the row into `stage` (nullable) for agents that want a fixed-address input.
+// One workgroup-row per env (grid.y), 16-byte lanes; t is read from device memory.
+namespace rlpyt {
+namespace {
+__global__ __launch_bounds__(256) void frame_push_kernel(
+    uint8_t* __restrict__ obs, const int64_t* __restrict__ t_dev, int64_t B, int64_t lo, int C,
+    int64_t HW, const uint8_t* __restrict__ new_frame, const uint8_t* __restrict__ full_rows,
+    const int32_t* __restrict__ slot, uint8_t* __restrict__ stage) {
+  const int64_t b = blockIdx.y;
+  const int64_t t = *t_dev;
+  const int64_t row_bytes = (int64_t)C * HW;
+  uint8_t* __restrict__ dst = obs + (t * B + lo + b) * row_bytes;
+  uint8_t* __restrict__ dst2 = stage != nullptr ? stage + b * row_bytes : nullptr;
+  const int sl = slot[b];
+  const int64_t n16 = row_bytes >> 4, hw16 = HW >> 4;
+  const uint4* __restrict__ full = reinterpret_cast<const uint4*>(full_rows + (int64_t)(sl < 0 ? 0 : sl) * row_bytes);
+  const uint4* __restrict__ prev = reinterpret_cast<const uint4*>(obs + ((t - 1) * B + lo + b) * row_bytes);
+  const uint4* __restrict__ nf = reinterpret_cast<const uint4*>(new_frame + b * HW);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint4 v;
+    if (sl >= 0) v = full[i];
+    else if (i < n16 - hw16) v = prev[i + hw16];
+    else v = nf[i - (n16 - hw16)];
+    reinterpret_cast<uint4*>(dst)[i] = v;
+    if (dst2 != nullptr) reinterpret_cast<uint4*>(dst2)[i] = v;
+  }
+}
+}  // namespace
+}  // namespace rlpyt
+
+extern "C" int rlpyt_frame_push(uint8_t* obs, const int64_t* t_dev, int64_t B, int64_t lo,
+                                int64_t Bg, int C, int64_t HW, const uint8_t* new_frame,
+                                const uint8_t* full_rows, const int32_t* slot, uint8_t* stage,
+                                rlpyt_stream_t stream) {
+  RL_CHECK_ARG(B > 0 && lo >= 0 && Bg >= 0 && lo + Bg <= B && C > 0 && HW > 0, RLPYT_EINVAL,
+               "rlpyt_frame_push: bad sizes");
+  if (Bg == 0) return RLPYT_OK;
+  RL_CHECK_ARG(obs && t_dev && new_frame && full_rows && slot, RLPYT_EINVAL,
+               "rlpyt_frame_push: null pointer");
+  RL_CHECK_ARG(HW % 16 == 0 && ((reinterpret_cast<uintptr_t>(obs) | reinterpret_cast<uintptr_t>(new_frame) |
+                                 reinterpret_cast<uintptr_t>(full_rows) | reinterpret_cast<uintptr_t>(stage)) & 15) == 0,
+               RLPYT_ESHAPE, "rlpyt_frame_push: H*W must be a multiple of 16 and buffers 16-byte aligned");
+  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div((int64_t)C * HW / 16, 256), 4);
+  hipLaunchKernelGGL(frame_push_kernel, dim3(gx, (unsigned)Bg), dim3(256), 0, (hipStream_t)stream, obs,
+                     t_dev, B, lo, C, HW, new_frame, full_rows, slot, stage);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}

@@ -52,10 +52,10 @@ class Categorical(DiscreteMixin, Distribution):
     def mean_kl(self, old_dist_info, new_dist_info, valid=None):
         return valid_mean(self.kl(old_dist_info, new_dist_info), valid)
 
-    def sample(self, dist_info):
+    def sample(self, dist_info, generator=None):
         """``torch.multinomial`` over the trailing dim, on whatever device prob lives."""
         p = dist_info.prob
-        s = torch.multinomial(p.reshape(-1, self.dim), num_samples=1)
+        s = torch.multinomial(p.reshape(-1, self.dim), num_samples=1, generator=generator)
         return s.reshape(p.shape[:-1]).type(self.dtype)
 
     def entropy(self, dist_info):

@@ -24,6 +24,10 @@ class SyntheticPong(Env):
 
     Actions (ALE Pong's 6): 0,1 = stay; 2,4 = up; 3,5 = down."""
 
+    # the observation is the last ``num_img_obs`` frames, newest last, shifted by one per step
+    # (like rlpyt/envs/atari/atari_env.py:115-118): samplers may upload only obs[-1]
+    obs_newest_frame_last = True
+
     def __init__(self, num_img_obs=4, points_to_end=3, max_steps=2000, step_cost_us=0.,
                  opponent_skill=0.6, seed=0):
         self._n = num_img_obs

@@ -500,6 +500,24 @@ class RowCommit:
               "rlpyt_commit_rows")
 
 
+def frame_push(obs, t_dev, lo, new_frame, full_rows, slot, stage=None):
+    """Rebuild row ``t`` (device counter) of a frame-stacked uint8 observation batch
+    ``[T,B,C,*img]`` for columns ``lo:lo+Bg`` from the newest frames ``[Bg,*img]``:
+    shifted previous stack + new frame, or a full row ``full_rows[slot[b]]`` where
+    ``slot[b] >= 0`` (reset envs, first step of a batch)."""
+    _lib.require_gpu()
+    assert obs.dtype == torch.uint8 and obs.is_contiguous() and obs.dim() >= 4
+    B, C = obs.shape[1], obs.shape[2]
+    HW = 1
+    for d in obs.shape[3:]:
+        HW *= d
+    Bg = new_frame.shape[0]
+    assert slot.dtype == torch.int32 and slot.numel() == Bg
+    check(lib.rlpyt_frame_push(ptr(obs), ptr(t_dev), B, int(lo), Bg, C, HW, ptr(new_frame),
+                               ptr(full_rows), ptr(slot), ptr(stage), stream()),
+          "rlpyt_frame_push")
+
+
 def categorical_head(h, w_pi, b_pi, w_v=None, b_v=None, uniforms=None):
     """Policy / value heads + softmax (+ inverse-CDF action sampling when ``uniforms`` is
     given) in one kernel -- the no-grad sampling forward of

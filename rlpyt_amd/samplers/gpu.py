@@ -48,6 +48,9 @@ from .base import BaseSampler
 from .collections import AgentSamplesBsv, AgentSamples, EnvSamples, Samples
 
 StepBuffer = namedarraytuple("StepBuffer", ["observation", "action", "reward", "done"])
+# frame-stacked envs additionally publish the newest frame and a "stack was reset" flag
+StepBufferFs = namedarraytuple("StepBufferFs", ["observation", "action", "reward", "done",
+                                                "frame", "reset"])
 
 
 class EnvRunner:
@@ -65,6 +68,7 @@ class EnvRunner:
         # wait-reset: the observation returned with done is held back until the next
         # batch starts (collectors.py:65-68,103-104)
         self.temp_observation = None if mid_batch_reset else [None] * len(envs)
+        self.frames = "frame" in step_np._fields
 
     def start(self, max_decorrelation_steps=0):
         """Reset (and optionally decorrelate with random actions,
@@ -119,16 +123,22 @@ class EnvRunner:
             a = step.action[b]
             o, r, d, info = env.step(a)
             self.traj_infos[b].step(step.observation[b], a, r, d, None, info)
+            fresh = False     # True: the frame stack does not continue the previous one
             if getattr(info, "traj_done", d):
                 completed.append(self.traj_infos[b].terminate(o))
                 self.traj_infos[b] = self.TrajInfoCls()
                 if mbr:
                     o = env.reset()
+                    fresh = True
                 else:
                     self.need_reset[b] = True
             if d and not mbr:
                 self.temp_observation[b] = o
                 o = 0
+                fresh = True
+            if self.frames:
+                step.frame[b] = o[-1] if not isinstance(o, int) else 0
+                step.reset[b] = fresh
             step.observation[b] = o
             step.reward[b] = r
             step.done[b] = d
@@ -236,12 +246,13 @@ class GpuSampler(BaseSampler):
     GRAPH_WARMUP_CALLS = 3   # eager calls per group before capture (MIOpen/hipBLASLt find)
 
     def __init__(self, *args, n_workers=0, mid_batch_reset=True, pin_step_buffer=True,
-                 n_groups=None, use_graph=True, **kwargs):
+                 n_groups=None, use_graph=True, frame_dedup=True, **kwargs):
         super().__init__(*args, **kwargs)
         self.n_workers = int(n_workers)
         self.mid_batch_reset = bool(mid_batch_reset)
         self.pin_step_buffer = pin_step_buffer
         self.use_graph = bool(use_graph)
+        self.frame_dedup = bool(frame_dedup)
         B = self.batch_spec.B
         if n_groups is None:
             n_groups = 2 if (self.n_workers > 0 and B >= 2 * max(self.n_workers, 1)) else 1
@@ -284,6 +295,12 @@ class GpuSampler(BaseSampler):
         self.env_info_np = (buffer_from_example(env_info, (T, B), share_memory=shared)
                             if env_info else None)
         self._bootstrap = bootstrap_value
+        # frame-stacked uint8 image observations (newest frame last): only the newest frame
+        # needs to cross PCIe each step
+        self._dedup_capable = bool(
+            self.frame_dedup and getattr(self.EnvCls, "obs_newest_frame_last", False)
+            and isinstance(o, np.ndarray) and o.dtype == np.uint8 and o.ndim == 3
+            and (o[0].size % 16 == 0))
         gb = np.linspace(0, B, self.n_groups + 1).astype(int)
         n_w = max(self.n_workers, 1)
         self.groups = []
@@ -291,15 +308,21 @@ class GpuSampler(BaseSampler):
         for g in range(self.n_groups):
             lo, hi = int(gb[g]), int(gb[g + 1])
             Bg = hi - lo
-            # reward f32[Bg] and done bool[Bg] share ONE block so they travel in one H2D
-            nbytes = 4 * Bg + ((Bg + 15) // 16) * 16
+            # reward f32[Bg], slot i32[Bg], done bool[Bg], reset bool[Bg] share ONE block so
+            # they travel in one H2D
+            nbytes = 8 * Bg + ((2 * Bg + 15) // 16) * 16
             misc = (np_mp_array(nbytes, np.uint8) if shared else np.zeros(nbytes, np.uint8))
             misc[:] = 0
-            step_np = StepBuffer(
+            fields = dict(
                 observation=buffer_from_example(o, (Bg,), share_memory=shared),
                 action=buffer_from_example(a_t, (Bg,), share_memory=shared),
                 reward=misc[:4 * Bg].view(np.float32),
-                done=misc[4 * Bg:5 * Bg].view(np.bool_))
+                done=misc[8 * Bg:9 * Bg].view(np.bool_))
+            if self._dedup_capable:
+                step_np = StepBufferFs(frame=buffer_from_example(o[-1], (Bg,), share_memory=shared),
+                                       reset=misc[9 * Bg:10 * Bg].view(np.bool_), **fields)
+            else:
+                step_np = StepBuffer(**fields)
             G = AttrDict(idx=g, lo=lo, hi=hi, Bg=Bg, step_np=step_np, misc_np=misc, calls=0,
                          graph=None)
             self.groups.append(G)
@@ -380,15 +403,26 @@ class GpuSampler(BaseSampler):
             G.obs_stage = buffer_from_example(ex["observation"], (Bg,), device=dev)
             G.misc_stage = torch.zeros(G.misc_np.size, dtype=torch.uint8, device=dev)
             G.reward_stage = G.misc_stage[:4 * Bg].view(torch.float32)
-            G.done_stage = G.misc_stage[4 * Bg:5 * Bg].view(torch.bool)
+            G.done_stage = G.misc_stage[8 * Bg:9 * Bg].view(torch.bool)
+            G.dedup = self._dedup_capable and cuda
+            if G.dedup:
+                G.slot_np = G.misc_np[4 * Bg:8 * Bg].view(np.int32)
+                G.slot_stage = G.misc_stage[4 * Bg:8 * Bg].view(torch.int32)
+                G.frame_h = torch.from_numpy(G.step_np.frame)
+                G.frame_stage = torch.zeros((Bg,) + tuple(observation.shape[3:]),
+                                            dtype=torch.uint8, device=dev)
+                G.full_rows = torch.zeros((Bg,) + tuple(observation.shape[2:]),
+                                          dtype=torch.uint8, device=dev)
+                G.slot_all = np.arange(Bg, dtype=np.int32)
             G.action_out = buffer_from_example(ex["action"], (Bg,), device=dev)
             G.t_dev = torch.zeros(1, dtype=torch.int64, device=dev)
             G.pre_commit = G.post_commit = None
             if cuda:
                 from .. import ops
-                pre = ([(d, x, G.lo, 0) for d, x in zip(buffer_leaves(observation),
-                                                        buffer_leaves(G.obs_stage))]
-                       + [(all_reward, G.reward_stage, G.lo, 0), (all_done, G.done_stage, G.lo, 0)])
+                pre = [(all_reward, G.reward_stage, G.lo, 0), (all_done, G.done_stage, G.lo, 0)]
+                if not G.dedup:
+                    pre += [(d, x, G.lo, 0) for d, x in zip(buffer_leaves(observation),
+                                                            buffer_leaves(G.obs_stage))]
                 G.pre_commit = ops.RowCommit(len(pre), dev)
                 G.pre_commit.set_entries(pre)
                 n_post = 2 * len(buffer_leaves(all_action)) + len(buffer_leaves(agent_info))
@@ -397,10 +431,18 @@ class GpuSampler(BaseSampler):
             # one HIP stream per pipeline group: the H2D of one group overlaps the forward of
             # the other (a single group keeps torch's current stream)
             G.stream = torch.cuda.Stream(device=dev) if (cuda and self.n_groups > 1) else None
+            # one RNG stream per group: hipGraphs that replay concurrently must not share the
+            # generator's device-side philox offset, or the draws depend on timing
+            G.gen = None
+            if cuda and self.n_groups > 1:
+                G.gen = torch.Generator(device=dev)
+                G.gen.manual_seed(int(torch.initial_seed() % (2 ** 31)) + 7919 * (G.idx + 1))
             # pin the shared step buffer so the per-step copies are true async DMA
             if cuda and self.pin_step_buffer:
                 from .. import _lib
                 arrs = buffer_leaves(G.step_np.observation) + buffer_leaves(G.step_np.action)
+                if G.dedup:
+                    arrs = arrs + [G.step_np.frame]
                 for arr in arrs + [G.misc_np]:
                     rc = _lib.lib.rlpyt_host_register(ctypes.c_void_p(arr.ctypes.data),
                                                       int(arr.nbytes))
@@ -430,6 +472,10 @@ class GpuSampler(BaseSampler):
         s, t = self.samples, G.t_dev
         lo, hi = G.lo, G.hi
         if G.pre_commit is not None:
+            if G.dedup:
+                from .. import ops
+                ops.frame_push(s.env.observation, t, lo, G.frame_stage, G.full_rows,
+                               G.slot_stage, stage=G.obs_stage)
             G.pre_commit.launch(t)
         else:
             self._commit_rows(s.env.observation, G.obs_stage, G, t)
@@ -449,7 +495,9 @@ class GpuSampler(BaseSampler):
                 prev_reward = torch.where(dn, torch.zeros_like(prev_reward), prev_reward)
         else:
             prev_action = prev_reward = None
+        self.agent.sample_generator = G.gen
         action, agent_info = self.agent.step(G.obs_stage, prev_action, prev_reward)
+        self.agent.sample_generator = None
         if not self.mid_batch_reset:
             # wait-reset: finished envs record blank action / agent_info
             # (collectors.py:85-91)
@@ -494,19 +542,36 @@ class GpuSampler(BaseSampler):
             s.agent.bootstrap_value[0, lo:hi] = self.agent.value(G.obs_stage, prev_action,
                                                                  prev_reward)
 
-    def _upload(self, G, nb):
-        _copy_leaves(G.obs_stage, G.step_pyt.observation, non_blocking=nb)
+    def _upload(self, G, nb, first=True):
+        """Host step buffer -> device staging.  Frame-stacked envs: only the newest frame of
+        every env (+ the full stack of the few envs whose stack was reset); ``first``
+        (first step of a batch, bootstrap tail) uploads full observations."""
+        if G.dedup:
+            if first:
+                G.slot_np[:] = G.slot_all
+                G.full_rows.copy_(G.step_pyt.observation, non_blocking=nb)
+            else:
+                G.slot_np[:] = -1
+                rs = np.flatnonzero(G.step_np.reset)
+                if rs.size:
+                    G.slot_np[rs] = G.slot_all[:rs.size]
+                    obs_h = G.step_pyt.observation
+                    for k, b in enumerate(rs):
+                        G.full_rows[k].copy_(obs_h[b], non_blocking=nb)
+                G.frame_stage.copy_(G.frame_h, non_blocking=nb)
+        else:
+            _copy_leaves(G.obs_stage, G.step_pyt.observation, non_blocking=nb)
         G.misc_stage.copy_(G.misc_h, non_blocking=nb)
 
     def _on_stream(self, G):
         return torch.cuda.stream(G.stream) if G.stream is not None else _NullCtx()
 
-    def _issue(self, G):
+    def _issue(self, G, first=False):
         """Enqueue H2D staging -> (graph of) step body -> D2H action on the group's stream."""
         cuda = self.device.type == "cuda"
         t0 = time.perf_counter()
         with self._on_stream(G):
-            self._upload(G, cuda)
+            self._upload(G, cuda, first=first)
             if cuda and self.use_graph:
                 if G.graph is None and G.calls >= self.GRAPH_WARMUP_CALLS:
                     G.graph = self._capture(G)
@@ -536,7 +601,11 @@ class GpuSampler(BaseSampler):
         torch.cuda.synchronize()
         t_keep = G.t_dev.clone()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        if G.gen is not None:
+            graph.register_generator_state(G.gen)
+        # capture on the group's OWN stream: library workspaces (hipBLASLt split-K buffers)
+        # are keyed by stream, and two groups' graphs replay concurrently
+        with torch.cuda.graph(graph, stream=G.stream):
             self._step_body(G, capturing=True)
         G.post_commit.set_entries(G.post_entries)
         G.t_dev.copy_(t_keep)       # capture does not execute, keep the counter anyway
@@ -574,7 +643,7 @@ class GpuSampler(BaseSampler):
                     t0 = time.perf_counter()
                     self._wait_obs(G)
                     tm["wait_env_s"] += time.perf_counter() - t0
-                self._issue(G)
+                self._issue(G, first=(t == 0))
                 if not par:
                     self._finish(G)
                     t0 = time.perf_counter()
@@ -590,7 +659,8 @@ class GpuSampler(BaseSampler):
                 self._wait_obs(G)
                 tm["wait_env_s"] += time.perf_counter() - t0
             with self._on_stream(G):
-                self._upload(G, cuda)
+                _copy_leaves(G.obs_stage, G.step_pyt.observation, non_blocking=cuda)
+                G.misc_stage.copy_(G.misc_h, non_blocking=cuda)
                 self._tail_body(G)
         if cuda:
             for G in self.groups:

@@ -123,3 +123,37 @@ def test_categorical_head_matches_torch(n, K, A):
     # no-sampling / no-value variants
     p2, v2, a2 = ops.categorical_head(h, w_pi, b_pi)
     assert v2 is None and a2 is None and torch.equal(p2, prob)
+
+
+@pytest.mark.parametrize("n_workers,n_groups,mbr", [(0, 1, True), (2, 2, True), (0, 1, False)])
+def test_frame_dedup_upload_is_bit_identical(n_workers, n_groups, mbr):
+    """Uploading only the newest frame and rebuilding the stack in HBM (rlpyt_frame_push) gives
+    exactly the batches of the full-observation upload, through env resets (short episodes)
+    and under both reset modes."""
+    def run(dedup):
+        s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=7), batch_T=6, batch_B=8,
+                       n_workers=n_workers, n_groups=n_groups, mid_batch_reset=mbr,
+                       frame_dedup=dedup, max_decorrelation_steps=0)
+        a = AtariFfAgent()
+        torch.manual_seed(11)
+        np.random.seed(11)
+        s.initialize(a, seed=4, bootstrap_value=True)
+        torch.cuda.set_device(0)
+        a.to_device(0)
+        torch.manual_seed(12)
+        out = []
+        for itr in range(5):
+            smp, _ = s.obtain_samples(itr)
+            torch.cuda.synchronize()
+            out.append([x.clone() for x in (smp.env.observation, smp.agent.action,
+                                            smp.env.reward, smp.env.done,
+                                            smp.agent.agent_info.value,
+                                            smp.agent.bootstrap_value)])
+        assert s.groups[0].dedup == dedup
+        s.shutdown()
+        return out
+    a, b = run(True), run(False)
+    assert any(x[3].any() for x in a)          # resets really happened
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
