@@ -542,26 +542,34 @@ class GpuSampler(BaseSampler):
             s.agent.bootstrap_value[0, lo:hi] = self.agent.value(G.obs_stage, prev_action,
                                                                  prev_reward)
 
-    def _upload(self, G, nb, first=True):
-        """Host step buffer -> device staging.  Frame-stacked envs: only the newest frame of
-        every env (+ the full stack of the few envs whose stack was reset); ``first``
-        (first step of a batch, bootstrap tail) uploads full observations."""
+    def _upload_special(self, G, nb, first):
+        """Host-dependent part of the upload (frame-stacked envs only): full stacks for the
+        first step of a batch and for the few envs whose stack was reset."""
+        if not G.dedup:
+            return
+        if first:
+            G.slot_np[:] = G.slot_all
+            G.full_rows.copy_(G.step_pyt.observation, non_blocking=nb)
+        else:
+            G.slot_np[:] = -1
+            rs = np.flatnonzero(G.step_np.reset)
+            if rs.size:
+                G.slot_np[rs] = G.slot_all[:rs.size]
+                obs_h = G.step_pyt.observation
+                for k, b in enumerate(rs):
+                    G.full_rows[k].copy_(obs_h[b], non_blocking=nb)
+
+    def _upload_steady(self, G, nb):
+        """Fixed-address part of the upload: newest frames (or whole observations) + the
+        reward/slot/done/reset block."""
         if G.dedup:
-            if first:
-                G.slot_np[:] = G.slot_all
-                G.full_rows.copy_(G.step_pyt.observation, non_blocking=nb)
-            else:
-                G.slot_np[:] = -1
-                rs = np.flatnonzero(G.step_np.reset)
-                if rs.size:
-                    G.slot_np[rs] = G.slot_all[:rs.size]
-                    obs_h = G.step_pyt.observation
-                    for k, b in enumerate(rs):
-                        G.full_rows[k].copy_(obs_h[b], non_blocking=nb)
-                G.frame_stage.copy_(G.frame_h, non_blocking=nb)
+            G.frame_stage.copy_(G.frame_h, non_blocking=nb)
         else:
             _copy_leaves(G.obs_stage, G.step_pyt.observation, non_blocking=nb)
         G.misc_stage.copy_(G.misc_h, non_blocking=nb)
+
+    def _download(self, G, nb):
+        _copy_leaves(G.step_pyt.action, G.action_out, non_blocking=nb)
 
     def _on_stream(self, G):
         return torch.cuda.stream(G.stream) if G.stream is not None else _NullCtx()
@@ -571,18 +579,16 @@ class GpuSampler(BaseSampler):
         cuda = self.device.type == "cuda"
         t0 = time.perf_counter()
         with self._on_stream(G):
-            self._upload(G, cuda, first=first)
-            if cuda and self.use_graph:
-                if G.graph is None and G.calls >= self.GRAPH_WARMUP_CALLS:
-                    G.graph = self._capture(G)
-                if G.graph is not None:
-                    G.graph.replay()
-                else:
-                    self._step_body(G)
+            self._upload_special(G, cuda, first)
+            if cuda and self.use_graph and G.graph is None and G.calls >= self.GRAPH_WARMUP_CALLS:
+                G.graph = self._capture(G)
+            self._upload_steady(G, cuda)
+            if G.graph is not None:
+                G.graph.replay()
             else:
                 self._step_body(G)
+            self._download(G, cuda)
             G.calls += 1
-            _copy_leaves(G.step_pyt.action, G.action_out, non_blocking=cuda)
             if cuda:
                 G.event.record()
         self.timing["device_issue_s"] += time.perf_counter() - t0
@@ -595,9 +601,11 @@ class GpuSampler(BaseSampler):
             self.timing["device_wait_s"] += time.perf_counter() - t0
 
     def _capture(self, G):
-        """Capture ``_step_body`` of one group into a hipGraph (torch.cuda.CUDAGraph is the
-        HIP graph API on ROCm).  Warm-up calls ran eagerly before, so MIOpen / hipBLASLt
-        have picked their kernels and no allocation or search happens under capture."""
+        """Capture the device work of one group's step into a hipGraph (torch.cuda.CUDAGraph
+        is the HIP graph API on ROCm).  Warm-up calls ran eagerly before, so hipBLASLt has
+        picked its kernels and no allocation or search happens under capture.  The H2D / D2H
+        copies stay outside: as memcpy nodes they measured slower on ROCm 7.2 (124 vs 92+39 us
+        per group-step) and stalled a single-stream capture."""
         torch.cuda.synchronize()
         t_keep = G.t_dev.clone()
         graph = torch.cuda.CUDAGraph()

@@ -58,7 +58,8 @@ def main():
         st.synchronize()
         return a_.elapsed_time(b_) / n * 1e3
     res["Bg"] = G.Bg
-    res["h2d_us"] = ev(lambda: s._upload(G, True))
+    res["h2d_us"] = ev(lambda: s._upload_steady(G, True))
+    res["dedup"] = bool(G.dedup)
     if G.graph is not None:
         def rep():
             G.t_dev.zero_()
