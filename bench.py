@@ -34,6 +34,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, den
 KERNEL_NAMES = {
     "conv1_fwd": "conv1_fwd_kernel (gather + u8->f32 + conv 4->16 k8 s4 + bias + ReLU, fp32 MFMA)",
     "conv2_fwd": "conv2_fwd_kernel (conv 16->32 k4 s2 p1 + bias + ReLU, fp32 MFMA)",
+    "conv2_bwd": "conv2_bwd_kernel (dgrad + ReLU masks + weight/bias grad in one pass, fp32 MFMA)",
     "conv2_dgrad": "conv2_dgrad_kernel (transposed conv + ReLU masks, fp32 MFMA)",
     "conv2_wgrad": "conv2_wgrad_kernel (+ bias grad, fp32 MFMA)",
     "conv1_wgrad": "conv1_wgrad_kernel (gather + u8->f32 + weight/bias grad, fp32 MFMA)",
@@ -173,7 +174,9 @@ def main():
                         "master_wait_env_ms": sampler.timing["wait_env_s"] / args.steps / T * 1e3,
                         "master_issue_ms": sampler.timing["device_issue_s"] / args.steps / T * 1e3,
                         "master_wait_device_ms":
-                            sampler.timing["device_wait_s"] / args.steps / T * 1e3},
+                            sampler.timing["device_wait_s"] / args.steps / T * 1e3,
+                        "per_batch_ms": {k[:-2]: sampler.timing[k] / args.steps * 1e3
+                                         for k in ("pre_s", "loop_s", "tail_s", "post_s")}},
             "last_loss": opt_info.loss[-1] if opt_info.loss else None,
         }
         if ksum:

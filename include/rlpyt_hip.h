@@ -221,7 +221,9 @@ int rlpyt_obs_to_nhwc_f32(const uint8_t* src, const int64_t* flat_idx /*nullable
  * rlpyt/models/pg/atari_ff_model.py:56-58 and rlpyt/distributions/categorical.py:28-31
  * (sample_mode forward only): prob = softmax(h w_pi^T + b_pi) [n,A]; value = h w_v^T + b_v
  * [n] (w_v/value nullable together); action[i] = min{a : sum_{a'<=a} prob[i,a'] >
- * uniforms[i]} (inverse CDF; action nullable = no sampling).  A <= 32. */
+ * uniforms[i]} (inverse CDF; action nullable = no sampling).  With u_row_dev the uniforms
+ * of this call are row *u_row_dev of a [T', n] table drawn once per batch, so a captured
+ * hipGraph contains no RNG state.  A <= 32. */
 typedef struct rlpyt_row_copy {
   void* dst;
   const void* src;
@@ -235,9 +237,49 @@ int rlpyt_commit_rows(const rlpyt_row_copy* table_dev, int n_entries, int64_t ma
                       const int64_t* t_dev /*nullable*/, rlpyt_stream_t stream);
 int rlpyt_categorical_head_f32(const float* h /*[n,K]*/, const float* w_pi /*[A,K]*/,
                                const float* b_pi, const float* w_v /*[K], nullable*/,
-                               const float* b_v, const float* uniforms /*[n], nullable*/,
+                               const float* b_v, const float* uniforms /*[n] or [T',n], nullable*/,
+                               const int64_t* u_row_dev /*nullable: row *u_row_dev of uniforms*/,
                                int64_t n, int K, int A, float* prob, float* value,
                                int64_t* action, rlpyt_stream_t stream);
+
+/* The sampler master's steady-state loop over time steps [t_begin, t_end) in native code --
+ * the role of ActionServer.serve_actions (rlpyt/samplers/parallel/gpu/action_server.py:44-58)
+ * once each pipeline group's per-step device work is a captured hipGraph.  Per step, for every
+ * group: wait for its env workers (rlpyt_seq_wait on obs_word), enqueue the H2D copies of the
+ * page-locked step buffer (frame-stacked envs: newest frames + the full stack of reset envs,
+ * t == 0: all full stacks), hipGraphLaunch, enqueue the D2H action copies, record `event`;
+ * then for every group: hipEventSynchronize + rlpyt_seq_post(act_word).  `acts` / `rounds`
+ * are the running hand-off counters (updated in place).  timing[3] accumulates seconds spent
+ * waiting for envs / issuing / waiting for the device.  Host pointers; blocks the caller. */
+typedef struct rlpyt_copy_desc {
+  void* dst;
+  const void* src;
+  int64_t nbytes;
+} rlpyt_copy_desc;
+typedef struct rlpyt_step_group {
+  uint32_t* act_word;
+  uint32_t* obs_word;
+  uint32_t acts;
+  uint32_t rounds;
+  int32_t n_workers;
+  int32_t n_h2d;
+  rlpyt_copy_desc h2d[8];
+  int32_t n_d2h;
+  int32_t dedup;
+  rlpyt_copy_desc d2h[4];
+  int32_t Bg;
+  int32_t reserved;
+  const uint8_t* reset_flags; /* host [Bg], written by the workers */
+  int32_t* slot_host;         /* host [Bg], part of the page-locked misc block */
+  uint8_t* full_rows_dev;     /* device [Bg, row_bytes] */
+  const uint8_t* obs_host;    /* host [Bg, row_bytes], page-locked */
+  int64_t row_bytes;
+  void* graph_exec; /* hipGraphExec_t */
+  void* stream;     /* hipStream_t */
+  void* event;      /* hipEvent_t */
+} rlpyt_step_group;
+int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t_begin, int t_end,
+                        int spin_iters, int timeout_ms, double* timing /*[3], nullable*/);
 
 /* Frame-stack push for frame-stacked environments (rlpyt/envs/atari/atari_env.py:115-118:
  * the observation is the last C frames, newest last): the host uploads only the newest
@@ -275,6 +317,10 @@ int rlpyt_atari_conv2_dgrad_f32(const float* g2, const float* y2, const float* y
 int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void);
 int rlpyt_atari_conv2_wgrad_f32(const float* g2, const float* y2, const float* y1, int64_t M,
                                 float* workspace, float* dw2, float* db2, rlpyt_stream_t stream);
+/* conv2 backward in one pass (dgrad + ReLU mask + weight/bias gradients; g2 / y2 / y1 read once) */
+int rlpyt_atari_conv2_bwd_f32(const float* g2, const float* y2, const float* y1, int64_t M,
+                              const float* w2, float* dy1, float* workspace, float* dw2,
+                              float* db2, rlpyt_stream_t stream);
 int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* flat_idx /*nullable*/, int T,
                                 int64_t B, int64_t M, const float* dy1, float scale,
                                 float* workspace, float* dw1, float* db1, rlpyt_stream_t stream);

@@ -20,6 +20,21 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librlpyt_hip.so")
 ABI_VERSION = 1
 
 
+class CopyDesc(ctypes.Structure):
+    _fields_ = [("dst", c_void_p), ("src", c_void_p), ("nbytes", c_int64)]
+
+
+class StepGroup(ctypes.Structure):
+    """Mirror of ``rlpyt_step_group`` (include/rlpyt_hip.h)."""
+    _fields_ = [("act_word", c_void_p), ("obs_word", c_void_p), ("acts", c_uint32),
+                ("rounds", c_uint32), ("n_workers", ctypes.c_int32), ("n_h2d", ctypes.c_int32),
+                ("h2d", CopyDesc * 8), ("n_d2h", ctypes.c_int32), ("dedup", ctypes.c_int32),
+                ("d2h", CopyDesc * 4), ("Bg", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("reset_flags", c_void_p), ("slot_host", c_void_p), ("full_rows_dev", c_void_p),
+                ("obs_host", c_void_p), ("row_bytes", c_int64), ("graph_exec", c_void_p),
+                ("stream", c_void_p), ("event", c_void_p)]
+
+
 class HipExtensionMissing(ImportError):
     pass
 
@@ -80,8 +95,9 @@ _SIGNATURES = {
     "rlpyt_obs_to_nhwc_f32": (c_int, [_p, _p, _p, c_int, c_int64, c_int, c_int64, c_int64,
                                       c_float, _p]),
     "rlpyt_commit_rows": (c_int, [_p, c_int, c_int64, _p, _p]),
-    "rlpyt_categorical_head_f32": (c_int, [_p, _p, _p, _p, _p, _p, c_int64, c_int, c_int, _p, _p,
-                                           _p, _p]),
+    "rlpyt_categorical_head_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int64, c_int, c_int, _p,
+                                           _p, _p, _p]),
+    "rlpyt_sampler_serve": (c_int, [_p, c_int, c_int, c_int, c_int, c_int, _p]),
     "rlpyt_frame_push": (c_int, [_p, _p, c_int64, c_int64, c_int64, c_int, c_int64, _p, _p, _p, _p,
                                  _p]),
     "rlpyt_atari_conv1_fwd_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, _p, c_float, _p, _p]),
@@ -89,6 +105,7 @@ _SIGNATURES = {
     "rlpyt_atari_conv2_dgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p]),
     "rlpyt_atari_conv_wgrad_workspace_bytes": (c_int64, []),
     "rlpyt_atari_conv2_wgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p, _p]),
+    "rlpyt_atari_conv2_bwd_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p, _p, _p, _p]),
     "rlpyt_atari_conv1_wgrad_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, c_float, _p, _p,
                                             _p, _p]),
     "rlpyt_gather_rows": (c_int, [_p, _p, _p, _p, c_int, c_int64, c_int64, c_int64, _p]),

@@ -34,6 +34,9 @@ class BaseAgent:
         self.device = torch.device("cpu")
         self._mode = None
         self.sample_generator = None   # torch.Generator for action draws (None: default)
+        # (uniform table [T', B], device row index) for agents whose sampling forward can draw
+        # from pre-generated uniforms (keeps RNG state out of captured hipGraphs)
+        self.sample_uniforms = None
         if self.model_kwargs is None:
             self.model_kwargs = dict()
 
@@ -85,6 +88,10 @@ class BaseAgent:
         """False when the model ignores prev_action / prev_reward (e.g. AtariFfModel): the
         sampler then skips building them every step."""
         return getattr(self.sampling_model, "uses_prev_inputs", True)
+
+    @property
+    def supports_sample_uniforms(self):
+        return False
 
     def collector_initialize(self, global_B=1, env_ranks=None):
         pass

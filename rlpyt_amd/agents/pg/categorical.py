@@ -19,6 +19,10 @@ class CategoricalPgAgent(BaseAgent):
         pi, value = self.model(obs, pa, pr)
         return self._out((DistInfo(prob=pi), value))
 
+    @property
+    def supports_sample_uniforms(self):
+        return hasattr(self.sampling_model, "sample_step") and self.device.type == "cuda"
+
     def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
         super().initialize(env_spaces, share_memory, global_B=global_B, env_ranks=env_ranks)
         self.distribution = Categorical(dim=env_spaces.action.n)
@@ -36,7 +40,8 @@ class CategoricalPgAgent(BaseAgent):
             prev_action = prev_reward = None
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         if fused:
-            action, pi, value = m.sample_step(obs, pa, pr, generator=self.sample_generator)
+            action, pi, value = m.sample_step(obs, pa, pr, generator=self.sample_generator,
+                                              uniforms=self.sample_uniforms)
             dist_info = DistInfo(prob=pi)
         else:
             pi, value = m(obs, pa, pr)

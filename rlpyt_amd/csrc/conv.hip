@@ -56,10 +56,14 @@ __device__ __forceinline__ int64_t image_row(const int64_t* flat_idx, int64_t m,
 //   A = w1 (rows co, 64 K-steps held in 64 VGPRs), B = raw bytes of the image in LDS.
 //   K index k = c*64 + ky*8 + kx = 4*s + kq  ->  step s = (c, ky, kx>>2), kq = kx & 3.
 // ======================================================================================
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(
+constexpr int C1F_THREADS = 256;  // 4 waves share the 15 tile pairs of one image (5 waves measured slower)
+
+__global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
     const uint8_t* __restrict__ obs, const int64_t* __restrict__ flat_idx, int T, int64_t B,
     const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ y1,
-    int64_t M, float scale) {
+    int64_t M, float scale, int split) {
+  // split = workgroups per image (1, 2 or 4): small sampling batches spread the 15 tile
+  // pairs of an image over several CUs to cut latency; each part stages the whole image.
   __shared__ __attribute__((aligned(16))) uint8_t img[IMG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
@@ -70,13 +74,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias[r] = b1[4 * kq + r];
 
-  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+  for (int64_t mm = blockIdx.x; mm < M * split; mm += gridDim.x) {
+    const int64_t m = mm / split;
+    const int part = (int)(mm - m * split);
     const uint4* __restrict__ src =
         reinterpret_cast<const uint4*>(obs + image_row(flat_idx, m, T, B) * IMG);
     __syncthreads();  // the previous image's readers are done
-    for (int i = tid; i < IMG / 16; i += 256) reinterpret_cast<uint4*>(img)[i] = src[i];
+    for (int i = tid; i < IMG / 16; i += C1F_THREADS) reinterpret_cast<uint4*>(img)[i] = src[i];
     __syncthreads();
-    for (int p = wave; p < 15; p += 4) {   // 30 tiles of 16 positions, two at a time
+    // 30 tiles of 16 positions, two at a time
+    for (int p = part * (C1F_THREADS / 64) + wave; p < 15; p += split * (C1F_THREADS / 64)) {
       const int pos0 = p * 32 + j, pos1 = pos0 + 16;
       const int q0 = min(pos0, P1 - 1), q1 = min(pos1, P1 - 1);
       const int a0 = (q0 / W1) * (4 * W0) + (q0 % W1) * 4 + kq;
@@ -363,6 +370,158 @@ __global__ __launch_bounds__(256) void conv2_wgrad_kernel(
 }
 
 // ======================================================================================
+// conv2 backward, fused: dgrad (+ ReLU mask of conv1) and wgrad (+ bias grad) of the two
+// kernels above in ONE pass over the images, so g2 / y2 / y1 are read from HBM once:
+//   per image 27.6 KB (g2, y2) + 30.4 KB (y1) in, 30.4 KB (dy1) out, 1920 MFMAs.
+// 8 waves: dgrad -> wave (parity class w & 3, tile half w >> 2);
+//          wgrad -> wave (ky = w & 3, position-group parity w >> 2), two partial rows per
+//          workgroup.  gm2 lives once in LDS as [co][pos] (stride 120): the wgrad reads it as
+//          float4 over pos, the dgrad as scalars; y1 lives in the zero-bordered plane
+//          (stride 18) and also supplies the ReLU mask of the dgrad epilogue.
+// ======================================================================================
+constexpr int B2_THREADS = 512;
+
+__global__ __launch_bounds__(B2_THREADS, 4) void conv2_bwd_kernel(
+    const float* __restrict__ g2, const float* __restrict__ y2, const float* __restrict__ y1,
+    const float* __restrict__ w2, float* __restrict__ dy1, float* __restrict__ partial, int64_t M) {
+  __shared__ __attribute__((aligned(16))) float gm[C2 * GS_W];        // 15,360 B
+  __shared__ __attribute__((aligned(16))) float pad[PPIX * PS_W];     // 37,440 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int q = wave & 3, half = wave >> 2;
+  // ---- dgrad role: parity class q
+  const int py = q >> 1, px = q & 1;
+  const int na = py ? 12 : 13, nb = px ? 9 : 10, npx = na * nb;
+  const int ntile = (npx + 15) >> 4;
+  const int tile_lo = half ? ((ntile + 1) >> 1) : 0, tile_hi = half ? ntile : ((ntile + 1) >> 1);
+  float wd[32];
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const int co = sg * 16 + 4 * kq + sp;
+        const int ky = 1 - py + 2 * (dd >> 1), kx = 1 - px + 2 * (dd & 1);
+        wd[(dd * 2 + sg) * 4 + sp] = w2[co * 256 + j * 16 + ky * 4 + kx];
+      }
+  // ---- wgrad role: ky = q, position groups sg = half, half + 2, ...
+  // patch origin (float offset into pad) of every output position, looked up per K-step
+  __shared__ int porig[NSG2 * 16];
+  for (int i = tid; i < NSG2 * 16; i += B2_THREADS) {
+    const int pos = min(i, P2 - 1);
+    const int oy = pos / W2, ox = pos - oy * W2;
+    porig[i] = ((2 * oy) * PW + 2 * ox) * PS_W;
+  }
+  const int plane = q * PW * PS_W + j;
+  for (int i = tid; i < C2 * GS_W; i += B2_THREADS) gm[i] = 0.f;   // pos 108..119 stay zero
+  for (int i = tid; i < PPIX * PS_W; i += B2_THREADS) pad[i] = 0.f;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[kx][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+
+  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+    __syncthreads();
+    for (int i = tid; i < F2; i += B2_THREADS) {
+      const int co = i / P2, pos = i - co * P2;
+      const float g = g2[m * F2 + i], y = y2[m * F2 + i];
+      gm[co * GS_W + pos] = y > 0.f ? g : 0.f;
+    }
+    stage_y1_padded<PS_W>(pad, y1 + m * Y1, tid, B2_THREADS);
+    __syncthreads();
+    // ---------------- dgrad: this wave's tiles of parity class q ----------------
+    for (int tile = tile_lo; tile < tile_hi; tile += 2) {
+      int off[2][4];
+      int pix[2];
+      bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = (tile + u) * 16 + j;
+        ok[u] = (tile + u < tile_hi) && (p < npx);
+        const int pc = min(p, npx - 1);
+        const int a = pc / nb, b = pc - a * nb;
+        pix[u] = (2 * a + py) * W1 + 2 * b + px;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          const int oy = a + py - (dd >> 1), ox = b + px - (dd & 1);
+          const bool v = (oy >= 0) && (oy < H2) && (ox >= 0) && (ox < W2);
+          off[u][dd] = (v ? oy * W2 + ox : P2) + 4 * kq * GS_W;   // column 108 is zero
+        }
+      }
+      f32x4 dacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+          for (int sp = 0; sp < 4; ++sp) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const float bval = gm[off[u][dd] + (sg * 16 + sp) * GS_W];
+              dacc[u] = mfma16(wd[(dd * 2 + sg) * 4 + sp], bval, dacc[u]);
+            }
+          }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (ok[u]) {
+          const int iy = pix[u] / W1, ix = pix[u] - iy * W1;
+          const float* yp = pad + ((iy + 1) * PW + ix + 1) * PS_W + 4 * kq;
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = yp[r] > 0.f ? dacc[u][r] : 0.f;
+          *reinterpret_cast<f32x4*>(dy1 + m * Y1 + pix[u] * C1 + 4 * kq) = o;
+        }
+      }
+    }
+    // ---------------- wgrad: ky = q, this wave's position groups ----------------
+#pragma unroll
+    for (int si = 0; si < 4; ++si) {
+      const int sg = half + 2 * si;
+      if (sg < NSG2) {
+        f32x4 av[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          av[ct] = *reinterpret_cast<const f32x4*>(gm + (ct * 16 + j) * GS_W + 16 * sg + 4 * kq);
+        if (q == 0) {
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) bsum[ct] += (av[ct][0] + av[ct][1]) + (av[ct][2] + av[ct][3]);
+        }
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+          const float* bp = pad + plane + porig[16 * sg + 4 * kq + sp];
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx) {
+            const float bval = bp[kx * PS_W];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[kx][ct] = mfma16(av[ct][sp], bval, acc[kx][ct]);
+          }
+        }
+      }
+    }
+  }
+  float* out = partial + ((int64_t)blockIdx.x * 2 + half) * PART2;
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(ct * 16 + 4 * kq + r) * 256 + j * 16 + q * 4 + kx] = acc[kx][ct][r];
+  if (q == 0) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      float v = bsum[ct];
+      v += __shfl_xor(v, 16, kWave);
+      v += __shfl_xor(v, 32, kWave);
+      if (kq == 0) out[DW2_N + ct * 16 + j] = v;
+    }
+  }
+}
+
+// ======================================================================================
 // conv1 backward-weights (+ bias): dW1[co,c,ky,kx] = scale * sum_{m,pos} dy1[m,pos,co] * x[m,c,4oy+ky,4ox+kx]
 // Persistent workgroups, wave w <-> input channel c = w; 4 tiles of 16 K-columns
 // (ky pair x 8 kx) per wave.  A = dy1 [pos][co] in LDS (stride 20), B = image bytes.
@@ -371,15 +530,23 @@ __global__ __launch_bounds__(256) void conv2_wgrad_kernel(
 constexpr int DS_1 = 20, NSG1 = 30;
 constexpr int DW1_N = C1 * 256, PART1 = DW1_N + C1;  // 4096 + 16
 
-__global__ __launch_bounds__(256) void conv1_wgrad_kernel(
+constexpr int W1_THREADS = 512;  // 8 waves: (input channel c = w & 3) x (position-group parity w >> 2)
+
+__global__ __launch_bounds__(W1_THREADS) void conv1_wgrad_kernel(
     const uint8_t* __restrict__ obs, const int64_t* __restrict__ flat_idx, int T, int64_t B,
     const float* __restrict__ dy1, float* __restrict__ partial, int64_t M, float scale) {
   __shared__ __attribute__((aligned(16))) uint8_t img[IMG];             // 33,280 B
   __shared__ __attribute__((aligned(16))) float dl[NSG1 * 16 * DS_1];   // 38,400 B
+  __shared__ int xoff[NSG1 * 16];                                       // patch origin of a position
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
-  const int xlane = wave * HW0 + (j >> 3) * W0 + (j & 7);
-  for (int i = tid; i < NSG1 * 16 * DS_1; i += 256) dl[i] = 0.f;  // rows 475..479 stay zero
+  const int c = wave & 3, half = wave >> 2;
+  const int xlane = c * HW0 + (j >> 3) * W0 + (j & 7);
+  for (int i = tid; i < NSG1 * 16 * DS_1; i += W1_THREADS) dl[i] = 0.f;  // rows 475..479 stay zero
+  for (int i = tid; i < NSG1 * 16; i += W1_THREADS) {
+    const int pos = min(i, P1 - 1);
+    xoff[i] = (pos / W1) * (4 * W0) + (pos % W1) * 4;
+  }
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -390,33 +557,31 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(
         reinterpret_cast<const uint4*>(obs + image_row(flat_idx, m, T, B) * IMG);
     const f32x4* __restrict__ dsrc = reinterpret_cast<const f32x4*>(dy1 + m * Y1);
     __syncthreads();
-    for (int i = tid; i < IMG / 16; i += 256) reinterpret_cast<uint4*>(img)[i] = src[i];
-    for (int i = tid; i < Y1 / 4; i += 256)
+    for (int i = tid; i < IMG / 16; i += W1_THREADS) reinterpret_cast<uint4*>(img)[i] = src[i];
+    for (int i = tid; i < Y1 / 4; i += W1_THREADS)
       *reinterpret_cast<f32x4*>(dl + (i >> 2) * DS_1 + 4 * (i & 3)) = dsrc[i];
     __syncthreads();
-#pragma unroll 2
-    for (int sg = 0; sg < NSG1; ++sg) {
+    for (int sg = half; sg < NSG1; sg += 2) {
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp) {
         const int posr = 16 * sg + 4 * kq + sp;
         const float a = dl[posr * DS_1 + j];
-        if (wave == 0) bsum += a;
-        const int pos = min(posr, P1 - 1);
-        const int oy = pos / W1, ox = pos - oy * W1;
-        const uint8_t* xp = img + xlane + oy * (4 * W0) + ox * 4;
+        if (c == 0) bsum += a;
+        const uint8_t* xp = img + xlane + xoff[posr];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma16(a, (float)xp[t * 2 * W0], acc[t]);
       }
     }
   }
-  // D[row = co = 4*kq + r][col = j] -> dW1[co][c = wave][ky = 2t + (j>>3)][kx = j&7]
-  float* out = partial + (int64_t)blockIdx.x * PART1;
+  // D[row = co = 4*kq + r][col = j] -> dW1[co][c][ky = 2t + (j>>3)][kx = j&7]; the two
+  // position-parity halves of a workgroup write separate partial rows
+  float* out = partial + ((int64_t)blockIdx.x * 2 + half) * PART1;
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      out[(4 * kq + r) * 256 + wave * 64 + t * 16 + j] = acc[t][r] * scale;
-  if (wave == 0) {
+      out[(4 * kq + r) * 256 + c * 64 + t * 16 + j] = acc[t][r] * scale;
+  if (c == 0) {
     float v = bsum;
     v += __shfl_xor(v, 16, kWave);
     v += __shfl_xor(v, 32, kWave);
@@ -460,6 +625,7 @@ int grid_for(int64_t M, int per_cu) {
 }
 
 constexpr int kWgradGrid = 512;  // persistent workgroups of the weight-gradient kernels
+constexpr int kPartialRows = 2 * kWgradGrid;  // the 8-wave kernels write two partial rows each
 
 }  // namespace
 }  // namespace rlpyt
@@ -476,8 +642,10 @@ extern "C" int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat
   RL_CHECK_ARG(obs && w1 && b1 && y1, RLPYT_EINVAL, "rlpyt_atari_conv1_fwd_f32: null pointer");
   RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(y1), RLPYT_ESHAPE,
                "rlpyt_atari_conv1_fwd_f32: obs / y1 must be 16-byte aligned");
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for(M, 4)), dim3(256), 0, (hipStream_t)stream,
-                     obs, flat_idx, T, B, w1, b1, y1, M, scale);
+  int cus = grid_for(1 << 30, 1);
+  const int split = (M * 2 <= cus) ? 4 : (M <= cus ? 2 : 1);  // M <= 128: 4, M <= 256: 2
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for(M * split, 4)), dim3(C1F_THREADS), 0,
+                     (hipStream_t)stream, obs, flat_idx, T, B, w1, b1, y1, M, scale, split);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
@@ -509,7 +677,7 @@ extern "C" int rlpyt_atari_conv2_dgrad_f32(const float* g2, const float* y2, con
 }
 
 extern "C" int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void) {
-  return (int64_t)kWgradGrid * (PART1 > PART2 ? PART1 : PART2) * (int64_t)sizeof(float);
+  return (int64_t)kPartialRows * (PART1 > PART2 ? PART1 : PART2) * (int64_t)sizeof(float);
 }
 
 extern "C" int rlpyt_atari_conv2_wgrad_f32(const float* g2, const float* y2, const float* y1,
@@ -540,11 +708,31 @@ extern "C" int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* fl
                "rlpyt_atari_conv1_wgrad_f32: obs / dy1 must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const int g = (int)std::min<int64_t>(M, kWgradGrid);
-  hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(g), dim3(256), 0, s, obs, flat_idx, T, B, dy1,
+  hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(g), dim3(W1_THREADS), 0, s, obs, flat_idx, T, B, dy1,
                      workspace, M, scale);
   RL_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART1 + 63) / 64), dim3(256), 0, s, workspace,
-                     g, PART1, dw1, DW1_N, db1);
+                     2 * g, PART1, dw1, DW1_N, db1);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_atari_conv2_bwd_f32(const float* g2, const float* y2, const float* y1,
+                                         int64_t M, const float* w2, float* dy1,
+                                         float* workspace, float* dw2, float* db2,
+                                         rlpyt_stream_t stream) {
+  RL_CHECK_ARG(M > 0, RLPYT_EINVAL, "rlpyt_atari_conv2_bwd_f32: bad sizes");
+  RL_CHECK_ARG(g2 && y2 && y1 && w2 && dy1 && workspace && dw2 && db2, RLPYT_EINVAL,
+               "rlpyt_atari_conv2_bwd_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(dy1), RLPYT_ESHAPE,
+               "rlpyt_atari_conv2_bwd_f32: y1 / dy1 must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int g = (int)std::min<int64_t>(M, kWgradGrid);
+  hipLaunchKernelGGL(conv2_bwd_kernel, dim3(g), dim3(B2_THREADS), 0, s, g2, y2, y1, w2, dy1,
+                     workspace, M);
+  RL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(256), 0, s, workspace,
+                     2 * g, PART2, dw2, DW2_N, db2);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

@@ -37,8 +37,8 @@ template <int AMAX>
 __global__ __launch_bounds__(256) void categorical_head_kernel(
     const float* __restrict__ h, const float* __restrict__ w_pi, const float* __restrict__ b_pi,
     const float* __restrict__ w_v, const float* __restrict__ b_v,
-    const float* __restrict__ uniforms, int64_t n, int K, int A, float* __restrict__ prob,
-    float* __restrict__ value, int64_t* __restrict__ action) {
+    const float* __restrict__ uniforms, const int64_t* __restrict__ u_row_dev, int64_t n, int K,
+    int A, float* __restrict__ prob, float* __restrict__ value, int64_t* __restrict__ action) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= n) return;
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void categorical_head_kernel(
     const float inv = 1.f / den;
     float cum = 0.f;
     int pick = -1, last_pos = 0;
-    const float u = uniforms != nullptr ? uniforms[row] : 0.f;
+    const int64_t urow = u_row_dev != nullptr ? *u_row_dev : 0;
+    const float u = uniforms != nullptr ? uniforms[urow * n + row] : 0.f;
 #pragma unroll
     for (int a = 0; a < AMAX; ++a)
       if (a < A) {
@@ -108,9 +109,9 @@ extern "C" int rlpyt_commit_rows(const rlpyt_row_copy* table_dev, int n_entries,
 
 extern "C" int rlpyt_categorical_head_f32(const float* h, const float* w_pi, const float* b_pi,
                                           const float* w_v, const float* b_v,
-                                          const float* uniforms, int64_t n, int K, int A,
-                                          float* prob, float* value, int64_t* action,
-                                          rlpyt_stream_t stream) {
+                                          const float* uniforms, const int64_t* u_row_dev,
+                                          int64_t n, int K, int A, float* prob, float* value,
+                                          int64_t* action, rlpyt_stream_t stream) {
   RL_CHECK_ARG(n >= 0 && K > 0 && A > 0 && A <= 32, RLPYT_EINVAL,
                "rlpyt_categorical_head_f32: need 0 < A <= 32, K > 0");
   if (n == 0) return RLPYT_OK;
@@ -123,10 +124,10 @@ extern "C" int rlpyt_categorical_head_f32(const float* h, const float* w_pi, con
   hipStream_t s = (hipStream_t)stream;
   if (A <= 8)
     hipLaunchKernelGGL((categorical_head_kernel<8>), grid, block, 0, s, h, w_pi, b_pi, w_v, b_v,
-                       uniforms, n, K, A, prob, value, action);
+                       uniforms, u_row_dev, n, K, A, prob, value, action);
   else
     hipLaunchKernelGGL((categorical_head_kernel<32>), grid, block, 0, s, h, w_pi, b_pi, w_v, b_v,
-                       uniforms, n, K, A, prob, value, action);
+                       uniforms, u_row_dev, n, K, A, prob, value, action);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

@@ -68,7 +68,8 @@ class AtariFfModel(torch.nn.Module):
     uses_prev_inputs = False   # prev_action / prev_reward are ignored (as in the reference)
 
     @torch.no_grad()
-    def sample_step(self, image, prev_action=None, prev_reward=None, generator=None):
+    def sample_step(self, image, prev_action=None, prev_reward=None, generator=None,
+                    uniforms=None):
         """Sampling forward on the device: (action, prob, value) for ``[B, C, H, W]`` uint8
         observations -- conv stack, FC trunk, then heads + softmax + categorical draw fused in
         one kernel (inverse-CDF on ``torch.rand``; same distribution as the reference's
@@ -81,9 +82,12 @@ class AtariFfModel(torch.nn.Module):
             fc_out = self.conv.head(feat)
         else:
             fc_out = self.conv(prepare_image(image, B, img_shape))
-        u = torch.rand(B, device=image.device, generator=generator)
+        if uniforms is not None:      # (table [T', B], device row index): no RNG op here
+            u, u_row = uniforms
+        else:
+            u, u_row = torch.rand(B, device=image.device, generator=generator), None
         prob, value, action = ops.categorical_head(fc_out, self.pi.weight, self.pi.bias,
-                                                   self.value.weight, self.value.bias, u)
+                                                   self.value.weight, self.value.bias, u, u_row)
         return action, prob, value
 
     def forward(self, image, prev_action, prev_reward):

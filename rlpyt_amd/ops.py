@@ -417,13 +417,10 @@ class _AtariConvStack(torch.autograd.Function):
         db1 = torch.empty(16, dtype=torch.float32, device=dev)
         dw2 = torch.empty((32, 16, 4, 4), dtype=torch.float32, device=dev)
         db2 = torch.empty(32, dtype=torch.float32, device=dev)
-        with ktimer.region("conv2_dgrad", M * 4 * (2 * 3456 + 2 * 7600), M * _FL_C2D):
-            check(lib.rlpyt_atari_conv2_dgrad_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2c), ptr(dy1),
-                                                  stream()), "rlpyt_atari_conv2_dgrad_f32")
-        with ktimer.region("conv2_wgrad", M * 4 * (2 * 3456 + 7600), M * _FL_C2):
-            check(lib.rlpyt_atari_conv2_wgrad_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(ws), ptr(dw2),
-                                                  ptr(db2), stream()),
-                  "rlpyt_atari_conv2_wgrad_f32")
+        with ktimer.region("conv2_bwd", M * 4 * (2 * 3456 + 2 * 7600), M * (_FL_C2D + _FL_C2)):
+            check(lib.rlpyt_atari_conv2_bwd_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2c), ptr(dy1),
+                                                ptr(ws), ptr(dw2), ptr(db2), stream()),
+                  "rlpyt_atari_conv2_bwd_f32")
         with ktimer.region("conv1_wgrad", M * (33280 + 4 * 7600), M * _FL_C1):
             check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs), ptr(idx), T, B, M, ptr(dy1), scale,
                                                   ptr(ws), ptr(dw1), ptr(db1), stream()),
@@ -518,10 +515,12 @@ def frame_push(obs, t_dev, lo, new_frame, full_rows, slot, stage=None):
           "rlpyt_frame_push")
 
 
-def categorical_head(h, w_pi, b_pi, w_v=None, b_v=None, uniforms=None):
+def categorical_head(h, w_pi, b_pi, w_v=None, b_v=None, uniforms=None, u_row=None):
     """Policy / value heads + softmax (+ inverse-CDF action sampling when ``uniforms`` is
     given) in one kernel -- the no-grad sampling forward of
     rlpyt/models/pg/atari_ff_model.py:56-58 + rlpyt/distributions/categorical.py:28-31.
+    ``u_row`` (int64 device scalar tensor): ``uniforms`` is a ``[T', n]`` table and row
+    ``*u_row`` is used -- lets a captured hipGraph sample without any RNG state inside.
     Returns ``(prob [n,A], value [n] | None, action int64 [n] | None)``."""
     _lib.require_gpu()
     h = _f32(h)
@@ -534,11 +533,13 @@ def categorical_head(h, w_pi, b_pi, w_v=None, b_v=None, uniforms=None):
         wv, bv = _f32(w_v.detach()).reshape(-1), _f32(b_v.detach()).reshape(-1)
         value = torch.empty(n, dtype=torch.float32, device=h.device)
     if uniforms is not None:
-        uniforms = _f32(uniforms).reshape(-1)
+        uniforms = _f32(uniforms)
+        assert uniforms.shape[-1] == n and (u_row is not None or uniforms.numel() == n)
         action = torch.empty(n, dtype=torch.int64, device=h.device)
     check(lib.rlpyt_categorical_head_f32(ptr(h), ptr(w_pi), ptr(b_pi), ptr(wv), ptr(bv),
-                                         ptr(uniforms), n, K, A, ptr(prob), ptr(value),
-                                         ptr(action), stream()), "rlpyt_categorical_head_f32")
+                                         ptr(uniforms), ptr(u_row), n, K, A, ptr(prob),
+                                         ptr(value), ptr(action), stream()),
+          "rlpyt_categorical_head_f32")
     return prob, value, action
 
 

@@ -161,8 +161,9 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus):
         rn.start(ctrl.max_decorrelation_steps)
     ctrl.barrier_out.wait()
     seq = _StepSync(ctrl.sync_words, len(runners), ctrl.n_workers)
+    ti_keys, ti_table, ti_count = ctrl.ti_keys, ctrl.ti_table, ctrl.ti_count
     while True:
-        ctrl.barrier_in.wait()
+        seq.worker_wait_batch()
         if ctrl.quit.value:
             break
         completed = []
@@ -174,9 +175,22 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus):
                 seq.worker_wait_act(g)
                 rn.step_all(t, completed)
                 seq.worker_arrive(g)
-        for info in completed:
-            ctrl.traj_infos_queue.put(dict(info))
-        ctrl.barrier_out.wait()
+        # completed-trajectory statistics -> this worker's rows of the shared table (numeric
+        # TrajInfo fields); anything that does not fit goes through the queue instead
+        n = len(completed)
+        try:
+            if n > ti_table.shape[1]:
+                raise ValueError
+            for i, info in enumerate(completed):
+                if len(info) != len(ti_keys):
+                    raise ValueError
+                ti_table[rank, i] = [float(info[k]) for k in ti_keys]
+            ti_count[rank] = n
+        except (ValueError, TypeError, KeyError):
+            ti_count[rank] = -n
+            for info in completed:
+                ctrl.traj_infos_queue.put(dict(info))
+        seq.worker_batch_done()
 
 
 class _StepSync:
@@ -199,6 +213,11 @@ class _StepSync:
         self.n_workers = n_workers
         self.acts = [0] * n_groups       # action sets published / consumed so far
         self.rounds = [0] * n_groups     # arrival rounds completed so far
+        # batch hand-off (replaces two n+1-party barriers per batch): word 0 of the extra
+        # block = batches started, word 16 = workers finished
+        self.batch_word = ctypes.c_void_p(base + 128 * n_groups)
+        self.done_word = ctypes.c_void_p(base + 128 * n_groups + 64)
+        self.batches = 0
 
     # -- worker side
     def worker_arrive(self, g):
@@ -209,7 +228,24 @@ class _StepSync:
         self.acts[g] += 1
         self._lib.rlpyt_seq_wait(self.act[g], self.acts[g] & 0xffffffff, self.WORKER_SPIN, 0)
 
+    def worker_wait_batch(self):
+        self.batches += 1
+        self._lib.rlpyt_seq_wait(self.batch_word, self.batches & 0xffffffff, self.WORKER_SPIN, 0)
+
+    def worker_batch_done(self):
+        self._lib.rlpyt_seq_arrive(self.done_word, (self.batches * self.n_workers) & 0xffffffff)
+
     # -- master side
+    def master_start_batch(self):
+        self.batches += 1
+        self._lib.rlpyt_seq_post(self.batch_word, self.batches & 0xffffffff)
+
+    def master_wait_batch_done(self, timeout_ms=120000):
+        rc = self._lib.rlpyt_seq_wait(self.done_word, (self.batches * self.n_workers) & 0xffffffff,
+                                      self.MASTER_SPIN, timeout_ms)
+        if rc != 0:
+            raise RuntimeError(f"GpuSampler: env workers did not finish the batch (rc={rc}).")
+
     def master_wait_obs(self, g, timeout_ms=120000):
         self.rounds[g] += 1
         rc = self._lib.rlpyt_seq_wait(self.obs[g], (self.rounds[g] * self.n_workers) & 0xffffffff,
@@ -246,20 +282,23 @@ class GpuSampler(BaseSampler):
     GRAPH_WARMUP_CALLS = 3   # eager calls per group before capture (MIOpen/hipBLASLt find)
 
     def __init__(self, *args, n_workers=0, mid_batch_reset=True, pin_step_buffer=True,
-                 n_groups=None, use_graph=True, frame_dedup=True, **kwargs):
+                 n_groups=None, use_graph=True, frame_dedup=True, native_loop=True, **kwargs):
         super().__init__(*args, **kwargs)
         self.n_workers = int(n_workers)
         self.mid_batch_reset = bool(mid_batch_reset)
         self.pin_step_buffer = pin_step_buffer
         self.use_graph = bool(use_graph)
         self.frame_dedup = bool(frame_dedup)
+        self.native_loop = bool(native_loop)
+        self._native = None
         B = self.batch_spec.B
         if n_groups is None:
             n_groups = 2 if (self.n_workers > 0 and B >= 2 * max(self.n_workers, 1)) else 1
         self.n_groups = max(1, min(int(n_groups), B))
         self._pinned_ptrs = []
         self.workers = []
-        self.timing = dict(wait_env_s=0., device_issue_s=0., device_wait_s=0., batches=0)
+        self.timing = dict(wait_env_s=0., device_issue_s=0., device_wait_s=0., batches=0,
+                           pre_s=0., loop_s=0., tail_s=0., post_s=0.)
 
     # ------------------------------------------------------------------------ initialize
     def initialize(self, agent, affinity=None, seed=None, bootstrap_value=False,
@@ -351,10 +390,22 @@ class GpuSampler(BaseSampler):
         n = self.n_workers
         self.ctrl = AttrDict(
             quit=ctx.RawValue(ctypes.c_bool, False),
-            barrier_in=ctx.Barrier(n + 1), barrier_out=ctx.Barrier(n + 1),
-            sync_words=np_mp_array(32 * len(self.groups), np.uint32), n_workers=n,
+            barrier_out=ctx.Barrier(n + 1),
+            sync_words=np_mp_array(32 * (len(self.groups) + 1), np.uint32), n_workers=n,
             traj_infos_queue=ctx.Queue(),
             max_decorrelation_steps=self.max_decorrelation_steps)
+        # completed-trajectory statistics come back through a fork-shared float table
+        # (one block of rows per worker) instead of a pickling queue
+        proto = self.TrajInfoCls()
+        self._ti_proto = dict(proto)
+        keys = [k for k, v in proto.items() if isinstance(v, (int, float, bool, np.number))]
+        if len(keys) != len(proto):
+            keys = []        # non-numeric fields: everything goes through the queue
+        envs_per_worker = max(sum(len(rn.envs) for rn in rs) for rs in self.runners)
+        cap = self.batch_spec.T * envs_per_worker + 4 if keys else 0
+        self.ctrl.ti_keys = keys
+        self.ctrl.ti_table = np_mp_array((n, max(cap, 1), max(len(keys), 1)), np.float64)
+        self.ctrl.ti_count = np_mp_array(n, np.int32)
         cpus = affinity.get("workers_cpus", None)
         self.workers = []
         for w in range(n):
@@ -417,6 +468,11 @@ class GpuSampler(BaseSampler):
             G.action_out = buffer_from_example(ex["action"], (Bg,), device=dev)
             G.t_dev = torch.zeros(1, dtype=torch.int64, device=dev)
             G.pre_commit = G.post_commit = None
+            # uniforms for the whole batch are drawn once per batch (one RNG call instead of
+            # one per step, and the captured step graph holds no RNG state)
+            G.u_all = None
+            if cuda and getattr(self.agent, "supports_sample_uniforms", False):
+                G.u_all = torch.zeros((T, Bg), dtype=torch.float32, device=dev)
             if cuda:
                 from .. import ops
                 pre = [(all_reward, G.reward_stage, G.lo, 0), (all_done, G.done_stage, G.lo, 0)]
@@ -496,8 +552,9 @@ class GpuSampler(BaseSampler):
         else:
             prev_action = prev_reward = None
         self.agent.sample_generator = G.gen
+        self.agent.sample_uniforms = None if G.u_all is None else (G.u_all, t)
         action, agent_info = self.agent.step(G.obs_stage, prev_action, prev_reward)
-        self.agent.sample_generator = None
+        self.agent.sample_generator = self.agent.sample_uniforms = None
         if not self.mid_batch_reset:
             # wait-reset: finished envs record blank action / agent_info
             # (collectors.py:85-91)
@@ -600,6 +657,69 @@ class GpuSampler(BaseSampler):
             G.event.synchronize()
             self.timing["device_wait_s"] += time.perf_counter() - t0
 
+    # ------------------------------------------------------------------ native step loop
+    def _native_ready(self):
+        """All groups captured, RNG-free graphs: the per-step loop can run in C
+        (``rlpyt_sampler_serve``)."""
+        if getattr(self, "_native", None) is not None:
+            return True
+        if not all(G.graph is not None and G.u_all is not None for G in self.groups):
+            return False
+        from .. import _lib
+        arr = (_lib.StepGroup * len(self.groups))()
+        for G, sg in zip(self.groups, arr):
+            sg.act_word, sg.obs_word = self.sync.act[G.idx], self.sync.obs[G.idx]
+            sg.n_workers = self.n_workers
+            h2d = []
+            if G.dedup:
+                h2d.append((G.frame_stage, G.frame_h))
+            else:
+                h2d += list(zip(buffer_leaves(G.obs_stage), buffer_leaves(G.step_pyt.observation)))
+            h2d.append((G.misc_stage, G.misc_h))
+            d2h = list(zip(buffer_leaves(G.step_pyt.action), buffer_leaves(G.action_out)))
+            if len(h2d) > 8 or len(d2h) > 4:
+                self.native_loop = False
+                return False
+            sg.n_h2d, sg.n_d2h = len(h2d), len(d2h)
+            for i, (d, x) in enumerate(h2d):
+                sg.h2d[i].dst, sg.h2d[i].src = d.data_ptr(), x.data_ptr()
+                sg.h2d[i].nbytes = x.numel() * x.element_size()
+            for i, (d, x) in enumerate(d2h):
+                sg.d2h[i].dst, sg.d2h[i].src = d.data_ptr(), x.data_ptr()
+                sg.d2h[i].nbytes = x.numel() * x.element_size()
+            sg.dedup, sg.Bg = int(G.dedup), G.Bg
+            if G.dedup:
+                sg.reset_flags = G.step_np.reset.ctypes.data
+                sg.slot_host = G.slot_np.ctypes.data
+                sg.full_rows_dev = G.full_rows.data_ptr()
+                sg.obs_host = G.step_np.observation.ctypes.data
+                sg.row_bytes = G.step_np.observation[0].nbytes
+            sg.graph_exec = G.graph.raw_cuda_graph_exec()
+            sg.stream = (G.stream or torch.cuda.current_stream(self.device)).cuda_stream
+            G.event.record(G.stream or torch.cuda.current_stream(self.device))
+            sg.event = G.event.cuda_event
+        self._native = arr
+        self._native_timing = (ctypes.c_double * 3)()
+        logger.log("GpuSampler: time-step loop handed to rlpyt_sampler_serve (native).")
+        return True
+
+    def _serve_native(self, T):
+        from .. import _lib
+        arr = self._native
+        for G, sg in zip(self.groups, arr):
+            sg.acts, sg.rounds = self.sync.acts[G.idx] & 0xffffffff, self.sync.rounds[G.idx] & 0xffffffff
+        tmg = self._native_timing
+        tmg[0] = tmg[1] = tmg[2] = 0.
+        _lib.check(_lib.lib.rlpyt_sampler_serve(arr, len(self.groups), 0, T, _StepSync.MASTER_SPIN,
+                                                120000, tmg), "rlpyt_sampler_serve")
+        for G in self.groups:
+            self.sync.acts[G.idx] += T
+            self.sync.rounds[G.idx] += T
+            G.calls += T
+        self.timing["wait_env_s"] += tmg[0]
+        self.timing["device_issue_s"] += tmg[1]
+        self.timing["device_wait_s"] += tmg[2]
+
     def _capture(self, G):
         """Capture the device work of one group's step into a hipGraph (torch.cuda.CUDAGraph
         is the HIP graph API on ROCm).  Warm-up calls ran eagerly before, so hipBLASLt has
@@ -609,7 +729,7 @@ class GpuSampler(BaseSampler):
         torch.cuda.synchronize()
         t_keep = G.t_dev.clone()
         graph = torch.cuda.CUDAGraph()
-        if G.gen is not None:
+        if G.gen is not None and G.u_all is None:
             graph.register_generator_state(G.gen)
         # capture on the group's OWN stream: library workspaces (hipBLASLt split-K buffers)
         # are keyed by stream, and two groups' graphs replay concurrently
@@ -629,8 +749,10 @@ class GpuSampler(BaseSampler):
         agent.sample_mode(itr)
         completed = []
         par = self.n_workers > 0
+        tm = self.timing
+        tp0 = time.perf_counter()
         if par:
-            self.ctrl.barrier_in.wait()
+            self.sync.master_start_batch()
         else:
             for rn in self.runners[0]:
                 rn.begin_batch()
@@ -639,33 +761,37 @@ class GpuSampler(BaseSampler):
             if G.stream is not None:
                 G.stream.wait_stream(torch.cuda.current_stream())   # see the updated weights
             with self._on_stream(G):
+                if G.u_all is not None:
+                    G.u_all.uniform_(generator=G.gen)
                 G.t_dev.zero_()
                 # leading prev_action row (collectors.py:23-24); prev_reward[0] and the
                 # done carry are committed from the staging block by the first step
                 _map(lambda d, s: d[0, G.lo:G.hi].copy_(s, non_blocking=True),
                      self._all_action, G.step_pyt.action)
-        tm = self.timing
-        for t in range(T):
-            for G in self.groups:
-                if par:
-                    t0 = time.perf_counter()
-                    self._wait_obs(G)
-                    tm["wait_env_s"] += time.perf_counter() - t0
-                self._issue(G, first=(t == 0))
-                if not par:
-                    self._finish(G)
-                    t0 = time.perf_counter()
-                    self.runners[0][G.idx].step_all(t, completed)
-                    tm["wait_env_s"] += time.perf_counter() - t0
-            if par:
+        tp1 = time.perf_counter()
+        if par and cuda and self.native_loop and self._native_ready():
+            self._serve_native(T)
+        else:
+            for t in range(T):
                 for G in self.groups:
-                    self._finish(G)
-                    self.sync.master_post_act(G.idx)
+                    if par:
+                        t0 = time.perf_counter()
+                        self._wait_obs(G)
+                        tm["wait_env_s"] += time.perf_counter() - t0
+                    self._issue(G, first=(t == 0))
+                    if not par:
+                        self._finish(G)
+                        t0 = time.perf_counter()
+                        self.runners[0][G.idx].step_all(t, completed)
+                        tm["wait_env_s"] += time.perf_counter() - t0
+                if par:
+                    for G in self.groups:
+                        self._finish(G)
+                        self.sync.master_post_act(G.idx)
+        tp2 = time.perf_counter()
         for G in self.groups:
             if par:
-                t0 = time.perf_counter()
                 self._wait_obs(G)
-                tm["wait_env_s"] += time.perf_counter() - t0
             with self._on_stream(G):
                 _copy_leaves(G.obs_stage, G.step_pyt.observation, non_blocking=cuda)
                 G.misc_stage.copy_(G.misc_h, non_blocking=cuda)
@@ -680,25 +806,42 @@ class GpuSampler(BaseSampler):
             if np.any(dn):
                 _map(lambda x: x.__setitem__(dn, 0), G.step_np.action)
                 G.step_np.reward[dn] = 0
+        tp3 = time.perf_counter()
         if par:
-            self.ctrl.barrier_out.wait()
-            completed = self._drain_traj_infos()
+            self.sync.master_wait_batch_done()
+            completed = self._collect_traj_infos()
+        tp4 = time.perf_counter()
         tm["batches"] += 1
+        tm["pre_s"] += tp1 - tp0
+        tm["loop_s"] += tp2 - tp1
+        tm["tail_s"] += tp3 - tp2
+        tm["post_s"] += tp4 - tp3
         return self.samples, completed
 
     def _wait_obs(self, G):
         self.sync.master_wait_obs(G.idx)
 
-    def _drain_traj_infos(self):
+    def _collect_traj_infos(self):
+        """Completed-trajectory statistics of this batch from the shared table (queue for
+        the workers that could not use it)."""
         out = []
+        keys, table, count = self.ctrl.ti_keys, self.ctrl.ti_table, self.ctrl.ti_count
+        proto = self._ti_proto
+        n_queue = 0
+        for w in range(self.n_workers):
+            n = int(count[w])
+            if n < 0:
+                n_queue += -n
+                continue
+            for row in table[w, :n]:
+                ti = self.TrajInfoCls()
+                for k, v in zip(keys, row):
+                    ti[k] = int(v) if (isinstance(proto[k], int) and v.is_integer()) else float(v)
+                out.append(ti)
         q = self.ctrl.traj_infos_queue
-        while True:
-            try:
-                d = q.get(block=True, timeout=0.002 if not out else 0.0005)
-            except queue_mod.Empty:
-                break
+        for _ in range(n_queue):
             ti = self.TrajInfoCls()
-            ti.update(d)
+            ti.update(q.get(block=True, timeout=5))
             out.append(ti)
         return out
 
@@ -708,10 +851,7 @@ class GpuSampler(BaseSampler):
     def shutdown(self):
         if self.n_workers > 0 and self.workers:
             self.ctrl.quit.value = True
-            try:
-                self.ctrl.barrier_in.wait(timeout=5)
-            except Exception:
-                pass
+            self.sync.master_start_batch()
             for p in self.workers:
                 p.join(timeout=5)
                 if p.is_alive():

@@ -47,7 +47,7 @@ def _close(actual, desired, rel=2e-5, what=""):
     assert err <= tol, f"{what}: max err {err:.3e} > tol {tol:.3e} (max ref {np.abs(d).max():.3e})"
 
 
-@pytest.mark.parametrize("M", [1, 7, 300])
+@pytest.mark.parametrize("M", [1, 7, 200, 300])
 def test_conv_forward_kernels(ops, M):
     from rlpyt_amd._lib import check, lib, ptr, stream
     g = torch.Generator().manual_seed(M)
@@ -119,6 +119,16 @@ def test_conv_backward_kernels(ops, M):
                                           ptr(db2), stream()), "wgrad2")
     _close(dw2, p64[2].grad, what="conv2 wgrad")
     _close(db2, p64[3].grad, what="conv2 bias grad")
+    # fused conv2 backward (dgrad + wgrad in one pass) gives the same three results
+    dy1f = torch.full((M, 475, 16), float("nan"), device="cuda")
+    dw2f = torch.full((32, 16, 4, 4), float("nan"), device="cuda")
+    db2f = torch.full((32,), float("nan"), device="cuda")
+    check(lib.rlpyt_atari_conv2_bwd_f32(ptr(g2d), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1f), ptr(ws),
+                                        ptr(dw2f), ptr(db2f), stream()), "conv2 bwd fused")
+    _close(dy1f, dy1_ref, what="fused conv2 dgrad")
+    _close(dw2f, p64[2].grad, what="fused conv2 wgrad")
+    _close(db2f, p64[3].grad, what="fused conv2 bias grad")
+    assert not torch.isnan(dy1f).any()
     dw1 = torch.full((16, 4, 8, 8), float("nan"), device="cuda")
     db1 = torch.full((16,), float("nan"), device="cuda")
     dy1_in = dy1_ref.float().cuda().contiguous()

@@ -157,3 +157,33 @@ def test_frame_dedup_upload_is_bit_identical(n_workers, n_groups, mbr):
     for x, y in zip(a, b):
         for u, v in zip(x, y):
             assert torch.equal(u, v)
+
+
+def test_native_step_loop_matches_python_loop():
+    """rlpyt_sampler_serve (the C time-step loop: futex waits, H2D, hipGraphLaunch, D2H, event
+    sync, action hand-off) produces exactly the batches of the Python loop."""
+    def run(native):
+        s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=7), batch_T=6, batch_B=8,
+                       n_workers=2, n_groups=2, native_loop=native, max_decorrelation_steps=0)
+        a = AtariFfAgent()
+        torch.manual_seed(21)
+        np.random.seed(21)
+        s.initialize(a, seed=6, bootstrap_value=True)
+        torch.cuda.set_device(0)
+        a.to_device(0)
+        torch.manual_seed(22)
+        out = []
+        for itr in range(5):
+            smp, infos = s.obtain_samples(itr)
+            torch.cuda.synchronize()
+            out.append([x.clone() for x in (smp.env.observation, smp.agent.action,
+                                            smp.env.reward, smp.env.done,
+                                            smp.agent.agent_info.dist_info.prob,
+                                            smp.agent.bootstrap_value)])
+        assert (s._native is not None) == native
+        s.shutdown()
+        return out
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
