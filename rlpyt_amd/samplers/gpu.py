@@ -160,7 +160,7 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus):
     for rn in runners:
         rn.start(ctrl.max_decorrelation_steps)
     ctrl.barrier_out.wait()
-    seq = _StepSync(ctrl.sync_words, len(runners), ctrl.n_workers)
+    seq = _StepSync(ctrl.sync_words, len(runners), ctrl.n_workers, ctrl.worker_spin)
     ti_keys, ti_table, ti_count = ctrl.ti_keys, ctrl.ti_table, ctrl.ti_count
     while True:
         seq.worker_wait_batch()
@@ -201,9 +201,11 @@ class _StepSync:
     per-worker semaphore pair."""
 
     MASTER_SPIN = 4000     # ~40 us of polling before sleeping (hand-offs are ~100 us apart)
+    # workers poll only briefly: letting 64 workers poll through the device phase of every step
+    # (so that the master never has to wake them) measured 2-3x SLOWER on the bench host
     WORKER_SPIN = 300
 
-    def __init__(self, words, n_groups, n_workers):
+    def __init__(self, words, n_groups, n_workers, worker_spin=None):
         from .. import _lib
         self._lib = _lib.lib
         base = words.ctypes.data
@@ -215,6 +217,8 @@ class _StepSync:
         self.rounds = [0] * n_groups     # arrival rounds completed so far
         # batch hand-off (replaces two n+1-party barriers per batch): word 0 of the extra
         # block = batches started, word 16 = workers finished
+        if worker_spin is not None:
+            self.WORKER_SPIN = int(worker_spin)
         self.batch_word = ctypes.c_void_p(base + 128 * n_groups)
         self.done_word = ctypes.c_void_p(base + 128 * n_groups + 64)
         self.batches = 0
@@ -230,7 +234,7 @@ class _StepSync:
 
     def worker_wait_batch(self):
         self.batches += 1
-        self._lib.rlpyt_seq_wait(self.batch_word, self.batches & 0xffffffff, self.WORKER_SPIN, 0)
+        self._lib.rlpyt_seq_wait(self.batch_word, self.batches & 0xffffffff, 300, 0)
 
     def worker_batch_done(self):
         self._lib.rlpyt_seq_arrive(self.done_word, (self.batches * self.n_workers) & 0xffffffff)
@@ -392,6 +396,7 @@ class GpuSampler(BaseSampler):
             quit=ctx.RawValue(ctypes.c_bool, False),
             barrier_out=ctx.Barrier(n + 1),
             sync_words=np_mp_array(32 * (len(self.groups) + 1), np.uint32), n_workers=n,
+            worker_spin=None,
             traj_infos_queue=ctx.Queue(),
             max_decorrelation_steps=self.max_decorrelation_steps)
         # completed-trajectory statistics come back through a fork-shared float table
