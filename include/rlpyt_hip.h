@@ -132,6 +132,23 @@ int rlpyt_ppo_loss_fwd_bwd_f32(const float* prob_new /*[M,A]*/, const float* val
                                float* grad_prob, float* grad_value, void* workspace,
                                rlpyt_stream_t stream);
 
+/* PPO loss with the policy / value heads fused in -- rlpyt/models/pg/atari_ff_model.py:56-58 +
+ * rlpyt/algos/pg/ppo.py:133-153, forward and backward in one pass over the trunk output:
+ *   logits = h w_pi^T + b_pi; pi = softmax(logits); v = h w_v^T + b_v; PPO loss as above.
+ * h f32 [M,K] (K = 256 or 512), w_pi [A,K] (A <= 8), w_v [K].  Outputs: out_scalars[5] as
+ * rlpyt_ppo_loss_fwd_bwd_f32; grad_h [M,K] = dL/dh; grad_params [A*K + K + A + 1] =
+ * dL/dw_pi | dL/dw_v | dL/db_pi | dL/db_v (fixed-order partial reduction: deterministic).
+ * workspace: rlpyt_ppo_head_loss_workspace_bytes(K, A) bytes. */
+int64_t rlpyt_ppo_head_loss_workspace_bytes(int K, int A);
+int rlpyt_ppo_head_loss_fwd_bwd_f32(const float* h, const float* w_pi, const float* b_pi,
+                                    const float* w_v, const float* b_v, const float* prob_old,
+                                    const int64_t* action, const float* advantage,
+                                    const float* return_, const float* valid /*nullable*/,
+                                    int64_t M, int K, int A, float ratio_clip,
+                                    float value_loss_coeff, float entropy_loss_coeff,
+                                    float* out_scalars, float* grad_h, float* grad_params,
+                                    void* workspace, rlpyt_stream_t stream);
+
 /* A2C.loss -- rlpyt/algos/pg/a2c.py:63-103: pi_loss = -valid_mean(log(p[a]+eps) * A). */
 int rlpyt_a2c_loss_fwd_bwd_f32(const float* prob /*[M,A]*/, const float* value /*[M]*/,
                                const int64_t* action, const float* advantage,
@@ -274,12 +291,23 @@ typedef struct rlpyt_step_group {
   uint8_t* full_rows_dev;     /* device [Bg, row_bytes] */
   const uint8_t* obs_host;    /* host [Bg, row_bytes], page-locked */
   int64_t row_bytes;
+  int64_t* t_host;  /* host, inside the page-locked misc block: receives the step index */
   void* graph_exec; /* hipGraphExec_t */
   void* stream;     /* hipStream_t */
   void* event;      /* hipEvent_t */
 } rlpyt_step_group;
 int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t_begin, int t_end,
                         int spin_iters, int timeout_ms, double* timing /*[3], nullable*/);
+
+/* Small-batch fully connected layer (+ optional ReLU) for the sampling forward -- the
+ * 3456 -> 512 trunk of rlpyt/models/pg/atari_ff_model.py:52-55 (rlpyt/models/mlp.py) at
+ * M <= 256 rows: y[m,n] = act(sum_k x[m,k] w[n,k] + bias[n]) on fp32 MFMA with the K range
+ * split over workgroups and a fixed-order partial sum (deterministic).  x [M,K], w [N,K]
+ * (torch nn.Linear layout), bias [N] nullable, y [M,N]; N % 16 == 0, K % 16 == 0;
+ * workspace: rlpyt_fc_small_workspace_bytes(M, N) bytes. */
+int64_t rlpyt_fc_small_workspace_bytes(int M, int N);
+int rlpyt_fc_small_f32(const float* x, const float* w, const float* bias /*nullable*/, float* y,
+                       int M, int N, int K, int relu, float* workspace, rlpyt_stream_t stream);
 
 /* Frame-stack push for frame-stacked environments (rlpyt/envs/atari/atari_env.py:115-118:
  * the observation is the last C frames, newest last): the host uploads only the newest

@@ -31,7 +31,8 @@ class StepGroup(ctypes.Structure):
                 ("h2d", CopyDesc * 8), ("n_d2h", ctypes.c_int32), ("dedup", ctypes.c_int32),
                 ("d2h", CopyDesc * 4), ("Bg", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("reset_flags", c_void_p), ("slot_host", c_void_p), ("full_rows_dev", c_void_p),
-                ("obs_host", c_void_p), ("row_bytes", c_int64), ("graph_exec", c_void_p),
+                ("obs_host", c_void_p), ("row_bytes", c_int64), ("t_host", c_void_p),
+                ("graph_exec", c_void_p),
                 ("stream", c_void_p), ("event", c_void_p)]
 
 
@@ -78,6 +79,9 @@ _SIGNATURES = {
     "rlpyt_pg_loss_workspace_bytes": (c_int64, [c_int64]),
     "rlpyt_ppo_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,
                                            c_float, c_float, _p, _p, _p, _p, _p]),
+    "rlpyt_ppo_head_loss_workspace_bytes": (c_int64, [c_int, c_int]),
+    "rlpyt_ppo_head_loss_fwd_bwd_f32": (c_int, [_p] * 10 + [c_int64, c_int, c_int, c_float, c_float,
+                                                          c_float, _p, _p, _p, _p, _p]),
     "rlpyt_a2c_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,
                                            c_float, _p, _p, _p, _p, _p]),
     "rlpyt_dqn_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,
@@ -98,6 +102,8 @@ _SIGNATURES = {
     "rlpyt_categorical_head_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int64, c_int, c_int, _p,
                                            _p, _p, _p]),
     "rlpyt_sampler_serve": (c_int, [_p, c_int, c_int, c_int, c_int, c_int, _p]),
+    "rlpyt_fc_small_workspace_bytes": (c_int64, [c_int, c_int]),
+    "rlpyt_fc_small_f32": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, _p, _p]),
     "rlpyt_frame_push": (c_int, [_p, _p, c_int64, c_int64, c_int64, c_int, c_int64, _p, _p, _p, _p,
                                  _p]),
     "rlpyt_atari_conv1_fwd_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, _p, c_float, _p, _p]),

@@ -23,6 +23,19 @@ class CategoricalPgAgent(BaseAgent):
     def supports_sample_uniforms(self):
         return hasattr(self.sampling_model, "sample_step") and self.device.type == "cuda"
 
+    @property
+    def supports_fused_head_loss(self):
+        return bool(getattr(self.sampling_model, "fused_head_loss", False))
+
+    def trunk(self, observation, prev_action, prev_reward):
+        """Training forward up to the heads: the trunk output ``[M, fc]`` (differentiable) and
+        the head modules, for ``ops.ppo_head_loss``.  Goes through ``self.model`` so that a
+        DistributedDataParallel wrapper sees the forward."""
+        obs, _, _ = self._to_model_device(observation, None, None)
+        h = self.model(obs, None, None, features_only=True)
+        m = self.sampling_model
+        return h, m.pi, m.value
+
     def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
         super().initialize(env_spaces, share_memory, global_B=global_B, env_ranks=env_ranks)
         self.distribution = Categorical(dim=env_spaces.action.n)

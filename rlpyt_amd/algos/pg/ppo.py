@@ -30,7 +30,7 @@ class PPO(PolicyGradientAlgo):
                  entropy_loss_coeff=0.01, OptimCls=torch.optim.Adam, optim_kwargs=None,
                  clip_grad_norm=1., initial_optim_state_dict=None, gae_lambda=1,
                  minibatches=4, epochs=4, ratio_clip=0.1, linear_lr_schedule=True,
-                 normalize_advantage=False):
+                 normalize_advantage=False, fused_head_loss=True):
         if optim_kwargs is None:
             optim_kwargs = dict()
         save__init__args(locals())
@@ -100,6 +100,13 @@ class PPO(PolicyGradientAlgo):
              init_rnn_state=None):
         """Fused PPO loss on a minibatch (already gathered, all in HBM).  Returns
         ``(loss, scalars)`` with scalars = [loss, pi_loss, value_loss, entropy, perplexity]."""
+        if init_rnn_state is None and self.fused_head_loss and getattr(
+                self.agent, "supports_fused_head_loss", False):
+            # heads + softmax + loss + all their gradients in one kernel pass over the trunk
+            h, pi_m, v_m = self.agent.trunk(*agent_inputs)
+            return ops.ppo_head_loss(h, pi_m.weight, pi_m.bias, v_m.weight, v_m.bias, old_prob,
+                                     action, advantage, return_, valid, self.ratio_clip,
+                                     self.value_loss_coeff, self.entropy_loss_coeff)
         if init_rnn_state is not None:
             init_rnn_state = buffer_method(init_rnn_state, "transpose", 0, 1)
             init_rnn_state = buffer_method(init_rnn_state, "contiguous")

@@ -303,6 +303,247 @@ __global__ __launch_bounds__(256) void norm_pass3_kernel(float* __restrict__ x, 
     x[i] = (x[i] - mean) / den;
 }
 
+
+// ======================================================================================
+// PPO loss with the policy / value heads fused in (rlpyt/models/pg/atari_ff_model.py:56-58 +
+// rlpyt/algos/pg/ppo.py:133-153, forward AND backward):
+//   logits = h Wpi^T + bpi ; pi = softmax(logits) ; v = h Wv^T + bv ; PPO loss(pi, v, ...)
+//   -> loss scalars, dL/dh [M,K], per-wave partial sums of dL/dWpi, dL/dbpi, dL/dWv, dL/dbv.
+// Replaces 2 forward GEMMs, softmax, the prob-level loss kernel, softmax backward, 4 backward
+// GEMMs and 2 bias reductions by one pass over h (16 B of HBM traffic per element of h) plus a
+// partial-sum reduction.  One wave per row: lane l owns h[l + 64 i]; the (A+1) x K head weights
+// and the (A+1) x K weight-gradient accumulators stay in VGPRs for the wave's lifetime.
+// Loss arithmetic is statement-for-statement that of pg_loss_kernel<0> above.
+// ======================================================================================
+constexpr int kHeadAMax = 8;
+constexpr int kHeadWavesPerBlock = 4;
+
+template <int KI>  // K = 64 * KI
+__global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
+    const float* __restrict__ h, const float* __restrict__ w_pi, const float* __restrict__ b_pi,
+    const float* __restrict__ w_v, const float* __restrict__ b_v,
+    const float* __restrict__ prob_old, const int64_t* __restrict__ action,
+    const float* __restrict__ advantage, const float* __restrict__ return_,
+    const float* __restrict__ valid, int64_t M, int A, float ratio_clip, float c_v, float c_e,
+    float* __restrict__ grad_h, float* __restrict__ wpart, LossWs* __restrict__ ws,
+    int n_valid_part) {
+  __shared__ double scratch[6 * 16];
+  constexpr int K = 64 * KI;
+  double denom = (double)M;
+  if (valid != nullptr) denom = sum_partials(ws->valid_part, n_valid_part, scratch);
+  const float inv = (float)(1.0 / denom);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * kHeadWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * kHeadWavesPerBlock;
+
+  float wp[kHeadAMax][KI], wv[KI], gw[kHeadAMax][KI], gwv[KI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+#pragma unroll
+    for (int a = 0; a < kHeadAMax; ++a) {
+      wp[a][i] = a < A ? w_pi[a * K + lane + 64 * i] : 0.f;
+      gw[a][i] = 0.f;
+    }
+    wv[i] = w_v[lane + 64 * i];
+    gwv[i] = 0.f;
+  }
+  float bp[kHeadAMax], gb[kHeadAMax];
+#pragma unroll
+  for (int a = 0; a < kHeadAMax; ++a) {
+    bp[a] = a < A ? b_pi[a] : 0.f;
+    gb[a] = 0.f;
+  }
+  const float bv = b_v[0];
+  float gbv = 0.f;
+  double acc[5] = {0, 0, 0, 0, 0};  // surrogate, value err, H, exp(H), count
+
+  float hn[KI];   // next row, prefetched while the current one is processed
+  if (wave_id < M) {
+#pragma unroll
+    for (int i = 0; i < KI; ++i) hn[i] = h[wave_id * K + lane + 64 * i];
+  }
+  for (int64_t m = wave_id; m < M; m += n_waves) {
+    float hv[KI];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) hv[i] = hn[i];
+    if (m + n_waves < M) {
+#pragma unroll
+      for (int i = 0; i < KI; ++i) hn[i] = h[(m + n_waves) * K + lane + 64 * i];
+    }
+    float lg[kHeadAMax], vsum = 0.f;
+#pragma unroll
+    for (int a = 0; a < kHeadAMax; ++a) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < KI; ++i) t = fmaf(hv[i], wp[a][i], t);
+      lg[a] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < KI; ++i) vsum = fmaf(hv[i], wv[i], vsum);
+#pragma unroll
+    for (int a = 0; a < kHeadAMax; ++a) lg[a] = wave_sum(lg[a]) + bp[a];
+    const float val = wave_sum(vsum) + bv;
+    // softmax (every lane redundantly: the scalars are needed by all lanes below)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < kHeadAMax; ++a)
+      if (a < A) mx = fmaxf(mx, lg[a]);
+    float p[kHeadAMax], den = 0.f;
+#pragma unroll
+    for (int a = 0; a < kHeadAMax; ++a) {
+      p[a] = a < A ? expf(lg[a] - mx) : 0.f;
+      den += p[a];
+    }
+    const float rden = 1.f / den;
+#pragma unroll
+    for (int a = 0; a < kHeadAMax; ++a) p[a] *= rden;
+    // ---- PPO loss terms and dL/dp, dL/dv (as pg_loss_kernel<0>)
+    const float vmask = valid ? valid[m] : 1.0f;
+    const float w = vmask * inv;
+    const int a_sel = (int)action[m];
+    const float adv = advantage[m];
+    float p_sel = 0.f;
+#pragma unroll
+    for (int a = 0; a < kHeadAMax; ++a)
+      if (a == a_sel) p_sel = p[a];
+    const float den_o = prob_old[m * A + a_sel] + kEpsCat;
+    const float ratio = (p_sel + kEpsCat) / den_o;
+    const float lo = 1.0f - ratio_clip, hi = 1.0f + ratio_clip;
+    const float clipped = fminf(fmaxf(ratio, lo), hi);
+    const float s1 = ratio * adv, s2 = clipped * adv;
+    const float pi_term = fminf(s1, s2);
+    const bool inside = (ratio >= lo) && (ratio <= hi);
+    float dr;
+    if (s1 < s2) dr = adv;
+    else if (s1 > s2) dr = inside ? adv : 0.f;
+    else dr = 0.5f * adv + (inside ? 0.5f * adv : 0.f);
+    const float g_sel = -w * dr / den_o;
+    const float verr_d = val - return_[m];
+    const float verr = 0.5f * verr_d * verr_d;
+    const float dv = c_v * w * verr_d;
+    float H = 0.f, gp[kHeadAMax], dot = 0.f;
+#pragma unroll
+    for (int a = 0; a < kHeadAMax; ++a) {
+      gp[a] = 0.f;
+      if (a < A) {
+        const float lp = logf(p[a] + kEpsCat);
+        H -= p[a] * lp;
+        gp[a] = c_e * w * (lp + p[a] / (p[a] + kEpsCat));
+        if (a == a_sel) gp[a] += g_sel;
+        dot += gp[a] * p[a];
+      }
+    }
+    // softmax backward: dL/dlogit_a = p_a (g_a - sum_b g_b p_b)
+    float dl[kHeadAMax];
+#pragma unroll
+    for (int a = 0; a < kHeadAMax; ++a) dl[a] = p[a] * (gp[a] - dot);
+    if (lane == 0) {
+      acc[0] += (double)(vmask * pi_term);
+      acc[1] += (double)(vmask * verr);
+      acc[2] += (double)(vmask * H);
+      acc[3] += (double)(vmask * expf(H));
+      acc[4] += (double)vmask;
+    }
+    // ---- dL/dh and weight-gradient accumulation
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      float g = dv * wv[i];
+#pragma unroll
+      for (int a = 0; a < kHeadAMax; ++a) {
+        g = fmaf(dl[a], wp[a][i], g);
+        gw[a][i] = fmaf(dl[a], hv[i], gw[a][i]);
+      }
+      gwv[i] = fmaf(dv, hv[i], gwv[i]);
+      grad_h[m * K + lane + 64 * i] = g;
+    }
+#pragma unroll
+    for (int a = 0; a < kHeadAMax; ++a) gb[a] += dl[a];
+    gbv += dv;
+  }
+  // weight-gradient partials [A*K dWpi | K dWv | A dbpi | 1 dbv]: waves 1..3 hand theirs to
+  // wave 0 through LDS, one partial row per workgroup leaves for the reduction kernel
+  extern __shared__ float hred[];   // [3][(kHeadAMax + 1) * K + kHeadAMax + 1]
+  constexpr int kRedStride = (kHeadAMax + 1) * K + kHeadAMax + 1;
+  const int wv_i = threadIdx.x >> 6;
+  if (wv_i > 0) {
+    float* r = hred + (wv_i - 1) * kRedStride;
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+#pragma unroll
+      for (int a = 0; a < kHeadAMax; ++a) r[a * K + lane + 64 * i] = gw[a][i];
+      r[kHeadAMax * K + lane + 64 * i] = gwv[i];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < kHeadAMax; ++a) r[(kHeadAMax + 1) * K + a] = gb[a];
+      r[(kHeadAMax + 1) * K + kHeadAMax] = gbv;
+    }
+  }
+  __syncthreads();
+  if (wv_i == 0) {
+    const int part = A * K + K + A + 1;
+    float* out = wpart + (int64_t)blockIdx.x * part;
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+#pragma unroll
+      for (int a = 0; a < kHeadAMax; ++a) {
+        if (a < A) {
+          float v = gw[a][i];
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3) v += hred[w3 * kRedStride + a * K + lane + 64 * i];
+          out[a * K + lane + 64 * i] = v;
+        }
+      }
+      float v = gwv[i];
+#pragma unroll
+      for (int w3 = 0; w3 < 3; ++w3) v += hred[w3 * kRedStride + kHeadAMax * K + lane + 64 * i];
+      out[A * K + lane + 64 * i] = v;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < kHeadAMax; ++a) {
+        if (a < A) {
+          float v = gb[a];
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3) v += hred[w3 * kRedStride + (kHeadAMax + 1) * K + a];
+          out[A * K + K + a] = v;
+        }
+      }
+      float v = gbv;
+#pragma unroll
+      for (int w3 = 0; w3 < 3; ++w3) v += hred[w3 * kRedStride + (kHeadAMax + 1) * K + kHeadAMax];
+      out[A * K + K + A] = v;
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) ws->part[wave_id][k] = acc[k];
+    ws->part[wave_id][5] = 0.0;
+  }
+}
+
+// out[e] = sum over the per-wave partial rows (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ wpart, int n_rows,
+                                                          int part, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < part) {
+    int g = wave;
+    for (; g + 4 < n_rows; g += 8) {
+      s0 += wpart[(int64_t)g * part + e];
+      s1 += wpart[(int64_t)(g + 4) * part + e];
+    }
+    if (g < n_rows) s0 += wpart[(int64_t)g * part + e];
+  }
+  red[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && e < part)
+    out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+constexpr int kHeadGrid = 256;  // one weight-gradient partial row per workgroup
 }  // namespace
 }  // namespace rlpyt
 
@@ -420,6 +661,62 @@ extern "C" int rlpyt_adv_normalize_f32(float* advantage, const float* valid, int
   RL_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_pass3_kernel, dim3(grid), dim3(256), 0, s, advantage, n, ws, grid, eps,
                      stats_out);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int64_t rlpyt_ppo_head_loss_workspace_bytes(int K, int A) {
+  if (K <= 0 || A <= 0) return 0;
+  const int64_t part = (int64_t)A * K + K + A + 1;
+  // LossWs | per-wave weight-gradient partials
+  return (int64_t)((sizeof(LossWs) + 255) / 256 * 256) +
+         (int64_t)kHeadGrid * part * (int64_t)sizeof(float);
+}
+
+extern "C" int rlpyt_ppo_head_loss_fwd_bwd_f32(
+    const float* h, const float* w_pi, const float* b_pi, const float* w_v, const float* b_v,
+    const float* prob_old, const int64_t* action, const float* advantage, const float* return_,
+    const float* valid, int64_t M, int K, int A, float ratio_clip, float value_loss_coeff,
+    float entropy_loss_coeff, float* out_scalars, float* grad_h, float* grad_params,
+    void* workspace, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(h && w_pi && b_pi && w_v && b_v && prob_old && action && advantage && return_ &&
+                   out_scalars && grad_h && grad_params && workspace,
+               RLPYT_EINVAL, "rlpyt_ppo_head_loss_fwd_bwd_f32: null pointer");
+  RL_CHECK_ARG(M > 0 && A > 0 && A <= kHeadAMax && (K == 512 || K == 256), RLPYT_ESHAPE,
+               "rlpyt_ppo_head_loss_fwd_bwd_f32: need M>0, 0<A<=8, K in {256,512} (M=%ld K=%d A=%d)",
+               (long)M, K, A);
+  hipStream_t s = (hipStream_t)stream;
+  LossWs* ws = reinterpret_cast<LossWs*>(workspace);
+  float* wpart = reinterpret_cast<float*>(static_cast<char*>(workspace) +
+                                          (sizeof(LossWs) + 255) / 256 * 256);
+  int n_valid_part = 0;
+  if (valid != nullptr) {
+    n_valid_part = (int)std::min<int64_t>(ceil_div(M, kLossBlock), kMaxLossGrid);
+    hipLaunchKernelGGL(valid_partial_kernel, dim3(n_valid_part), dim3(kLossBlock), 0, s, valid, M,
+                       ws->valid_part);
+    RL_LAUNCH_CHECK();
+  }
+  const int grid = (int)std::min<int64_t>(ceil_div(M, kHeadWavesPerBlock), kHeadGrid);
+  const int n_waves = grid * kHeadWavesPerBlock;
+  const int part = A * K + K + A + 1;
+  const size_t lds = (size_t)3 * ((kHeadAMax + 1) * K + kHeadAMax + 1) * sizeof(float);
+  if (K == 512)
+    hipLaunchKernelGGL((ppo_head_loss_kernel<8>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h,
+                       w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A,
+                       ratio_clip, value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws,
+                       n_valid_part);
+  else
+    hipLaunchKernelGGL((ppo_head_loss_kernel<4>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h,
+                       w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A,
+                       ratio_clip, value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws,
+                       n_valid_part);
+  RL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(head_reduce_kernel, dim3((part + 63) / 64), dim3(256), 0, s, wpart, grid,
+                     part, grad_params);
+  RL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pg_loss_finalize_kernel, dim3(1), dim3(kLossBlock), 0, s, ws, n_waves, M,
+                     valid != nullptr ? 1 : 0, 0, value_loss_coeff, entropy_loss_coeff,
+                     out_scalars);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

@@ -39,6 +39,7 @@ extern "C" int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t
       }
       double t1 = now_s();
       t_wait_env += t1 - t0;
+      *g.t_host = t;
       if (g.dedup) {
         if (t == 0) {
           for (int b = 0; b < g.Bg; ++b) g.slot_host[b] = b;

@@ -188,3 +188,112 @@ extern "C" int rlpyt_frame_push(uint8_t* obs, const int64_t* t_dev, int64_t B, i
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
+
+// --------------------------------------------------------------------------------------
+// Small-batch fully connected layer + ReLU for the sampling forward (the 3456 -> 512 trunk of
+// rlpyt/models/pg/atari_ff_model.py:52-55 via rlpyt/models/mlp.py at M = 128..256 rows):
+//   y[m, n] = relu(sum_k x[m, k] w[n, k] + b[n]).
+// At this size a library GEMM is latency-bound (~20 us); here the K range is split over
+// KSPLIT workgroups per 16-wide column tile so that all CUs stream a slice of the 7 MB weight
+// matrix at once, on fp32 MFMA (A = w rows, B = x rows, both read as float4 along K with the
+// K order inside 16 permuted identically), and a second tiny kernel sums the KSPLIT partials
+// in a fixed order, adds the bias and applies the ReLU (deterministic, no atomics).
+namespace rlpyt {
+namespace {
+typedef float fc_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kFcKSplit = 8;
+
+template <int MT>  // m-tiles of 16 rows per wave (4 waves): M <= 64 * MT
+__global__ __launch_bounds__(256) void fc_small_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ w,
+                                                       float* __restrict__ partial, int M, int N,
+                                                       int K, int kchunk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int nt = blockIdx.x, ks = blockIdx.y;
+  const int k0 = ks * kchunk;
+  const int k1 = min(k0 + kchunk, K);
+  const float* __restrict__ wrow = w + (int64_t)(nt * 16 + j) * K + 4 * kq;
+  const float* xrow[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = min((wave + 4 * t) * 16 + j, M - 1);
+    xrow[t] = x + (int64_t)m * K + 4 * kq;
+  }
+  fc_f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = fc_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = k0; k < k1; k += 16) {
+    const fc_f32x4 a = *reinterpret_cast<const fc_f32x4*>(wrow + k);
+    fc_f32x4 b[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) b[t] = *reinterpret_cast<const fc_f32x4*>(xrow[t] + k);
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sp], b[t][sp], acc[t], 0, 0, 0);
+  }
+  // D[row = n_local = 4*kq + r][col = m_local = j]
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = (wave + 4 * t) * 16 + j;
+    if (m < M)
+      *reinterpret_cast<fc_f32x4*>(partial + ((int64_t)ks * M + m) * N + nt * 16 + 4 * kq) = acc[t];
+  }
+}
+
+__global__ __launch_bounds__(256) void fc_small_finish_kernel(const float* __restrict__ partial,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ y, int64_t MN,
+                                                              int N, int ksplit, int relu) {
+  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (e >= MN) return;
+  fc_f32x4 s = *reinterpret_cast<const fc_f32x4*>(partial + e);
+  for (int k = 1; k < ksplit; ++k) {
+    const fc_f32x4 v = *reinterpret_cast<const fc_f32x4*>(partial + (int64_t)k * MN + e);
+    s += v;
+  }
+  const int n = (int)(e % N);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = s[r] + (bias != nullptr ? bias[n + r] : 0.f);
+    s[r] = relu ? fmaxf(v, 0.f) : v;
+  }
+  *reinterpret_cast<fc_f32x4*>(y + e) = s;
+}
+}  // namespace
+}  // namespace rlpyt
+
+extern "C" int64_t rlpyt_fc_small_workspace_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (int64_t)rlpyt::kFcKSplit * M * N * (int64_t)sizeof(float);
+}
+
+extern "C" int rlpyt_fc_small_f32(const float* x, const float* w, const float* bias, float* y,
+                                  int M, int N, int K, int relu, float* workspace,
+                                  rlpyt_stream_t stream) {
+  RL_CHECK_ARG(x && w && y && workspace, RLPYT_EINVAL, "rlpyt_fc_small_f32: null pointer");
+  RL_CHECK_ARG(M > 0 && M <= 256 && N > 0 && N % 16 == 0 && K > 0 && K % 16 == 0, RLPYT_ESHAPE,
+               "rlpyt_fc_small_f32: need 0 < M <= 256, N %% 16 == 0, K %% 16 == 0 (M=%d N=%d K=%d)",
+               M, N, K);
+  RL_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) |
+                 reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0,
+               RLPYT_ESHAPE, "rlpyt_fc_small_f32: buffers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int kchunk = (int)(ceil_div(ceil_div(K, rlpyt::kFcKSplit), 16) * 16);
+  const int ksplit = (int)ceil_div(K, kchunk);
+  const dim3 grid((unsigned)(N / 16), (unsigned)ksplit);
+  if (M <= 64)
+    hipLaunchKernelGGL((rlpyt::fc_small_kernel<1>), grid, dim3(256), 0, s, x, w, workspace, M, N, K, kchunk);
+  else if (M <= 128)
+    hipLaunchKernelGGL((rlpyt::fc_small_kernel<2>), grid, dim3(256), 0, s, x, w, workspace, M, N, K, kchunk);
+  else
+    hipLaunchKernelGGL((rlpyt::fc_small_kernel<4>), grid, dim3(256), 0, s, x, w, workspace, M, N, K, kchunk);
+  RL_LAUNCH_CHECK();
+  const int64_t MN = (int64_t)M * N;
+  hipLaunchKernelGGL(rlpyt::fc_small_finish_kernel, dim3((unsigned)ceil_div(MN / 4, 256)), dim3(256), 0,
+                     s, workspace, bias, y, MN, N, ksplit, relu);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}

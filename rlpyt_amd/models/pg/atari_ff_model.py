@@ -60,6 +60,14 @@ class AtariFfModel(torch.nn.Module):
         return (self.use_fused_conv and self._default_geometry and w.is_cuda
                 and w.dtype == torch.float32)
 
+    def _single_fc(self):
+        """The trunk's Linear when the head is exactly Linear -> ReLU (the default), else None."""
+        mods = list(getattr(self.conv.head, "model", torch.nn.Sequential()).children())
+        if (len(mods) == 2 and isinstance(mods[0], torch.nn.Linear)
+                and isinstance(mods[1], torch.nn.ReLU) and mods[0].out_features % 16 == 0):
+            return mods[0]
+        return None
+
     def _conv_features(self, obs, flat_idx):
         from ... import ops
         c1, c2 = self.conv.conv.conv[0], self.conv.conv.conv[2]
@@ -79,7 +87,12 @@ class AtariFfModel(torch.nn.Module):
         assert lead_dim == 1, "sample_step takes [B, C, H, W] observations"
         if image.dtype == torch.uint8 and self.fused_conv:
             feat = self._conv_features(image.contiguous(), None)
-            fc_out = self.conv.head(feat)
+            lin = self._single_fc()
+            if lin is not None and B <= 256 and feat.shape[1] % 16 == 0:
+                # split-K MFMA kernel: a library GEMM is latency-bound at this batch size
+                fc_out = ops.fc_small(feat, lin.weight, lin.bias, relu=True)
+            else:
+                fc_out = self.conv.head(feat)
         else:
             fc_out = self.conv(prepare_image(image, B, img_shape))
         if uniforms is not None:      # (table [T', B], device row index): no RNG op here
@@ -90,8 +103,17 @@ class AtariFfModel(torch.nn.Module):
                                                    self.value.weight, self.value.bias, u, u_row)
         return action, prob, value
 
-    def forward(self, image, prev_action, prev_reward):
-        """[T,B,C,H,W] / [B,C,H,W] / [C,H,W] -> (pi, value) with the same lead dims."""
+    @property
+    def fused_head_loss(self):
+        """True when ``ops.ppo_head_loss`` can take over the heads (device + sizes)."""
+        w = self.pi.weight
+        return (w.is_cuda and w.dtype == torch.float32 and w.shape[0] <= 8
+                and w.shape[1] in (256, 512))
+
+    def forward(self, image, prev_action, prev_reward, features_only=False):
+        """[T,B,C,H,W] / [B,C,H,W] / [C,H,W] -> (pi, value) with the same lead dims.
+        ``features_only``: return the trunk output ``[T*B, fc]`` instead (for the fused
+        head + loss kernel)."""
         if isinstance(image, ObsGather):
             lead_dim, T, B = 1, 1, image.flat_idx.numel()
             if self.fused_conv:
@@ -106,6 +128,8 @@ class AtariFfModel(torch.nn.Module):
                 fc_out = self.conv.head(feat)
             else:
                 fc_out = self.conv(prepare_image(image, T * B, img_shape))
+        if features_only:
+            return fc_out
         pi = F.softmax(self.pi(fc_out), dim=-1)
         v = self.value(fc_out).squeeze(-1)
         return restore_leading_dims((pi, v), lead_dim, T, B)

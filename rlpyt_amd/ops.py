@@ -198,6 +198,57 @@ def ppo_loss(prob_new, value, prob_old, action, advantage, return_, valid, ratio
                           ratio_clip, value_loss_coeff, entropy_loss_coeff)
 
 
+class _PpoHeadLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid,
+                ratio_clip, value_loss_coeff, entropy_loss_coeff):
+        _lib.require_gpu()
+        K = h.shape[-1]
+        A = w_pi.shape[0]
+        hc = _f32(h).reshape(-1, K)
+        M = hc.shape[0]
+        wp, bp = _f32(w_pi.detach()), _f32(b_pi.detach())
+        wv, bv = _f32(w_v.detach()).reshape(-1), _f32(b_v.detach()).reshape(-1)
+        po = _f32(prob_old).reshape(-1, A)
+        act = action.reshape(-1).long().contiguous()
+        adv = _f32(advantage).reshape(-1)
+        ret = _f32(return_).reshape(-1)
+        val = None if valid is None else _f32(valid).reshape(-1)
+        out = torch.empty(5, dtype=torch.float32, device=hc.device)
+        gh = torch.empty_like(hc)
+        gparams = torch.empty(A * K + K + A + 1, dtype=torch.float32, device=hc.device)
+        ws = _workspace("head_loss", lib.rlpyt_ppo_head_loss_workspace_bytes(K, A), hc.device)
+        with ktimer.region("ppo_head_loss", M * (8 * K + 8 * A + 28)):
+            check(lib.rlpyt_ppo_head_loss_fwd_bwd_f32(
+                ptr(hc), ptr(wp), ptr(bp), ptr(wv), ptr(bv), ptr(po), ptr(act), ptr(adv), ptr(ret),
+                ptr(val), M, K, A, float(ratio_clip), float(value_loss_coeff),
+                float(entropy_loss_coeff), ptr(out), ptr(gh), ptr(gparams), ptr(ws), stream()),
+                "rlpyt_ppo_head_loss_fwd_bwd_f32")
+        ctx.save_for_backward(gh, gparams)
+        ctx.meta = (h.shape, w_pi.shape, b_pi.shape, w_v.shape, b_v.shape, A, K)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        gh, gp = ctx.saved_tensors
+        hs, wps, bps, wvs, bvs, A, K = ctx.meta
+        gp = gp * g_loss
+        o = A * K
+        return ((gh * g_loss).reshape(hs), gp[:o].reshape(wps), gp[o + K:o + K + A].reshape(bps),
+                gp[o:o + K].reshape(wvs), gp[o + K + A:].reshape(bvs)) + (None,) * 8
+
+
+def ppo_head_loss(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid,
+                  ratio_clip, value_loss_coeff, entropy_loss_coeff):
+    """PPO.loss (rlpyt/algos/pg/ppo.py:117-154) with the policy / value heads of
+    rlpyt/models/pg/atari_ff_model.py:56-58 fused in: takes the trunk output ``h [M, K]`` and the
+    head parameters, returns ``(loss, scalars)`` like ``ppo_loss``; differentiable w.r.t. ``h``
+    and the four head parameters (all gradients come out of the same kernel pass)."""
+    return _PpoHeadLoss.apply(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_,
+                              valid, ratio_clip, value_loss_coeff, entropy_loss_coeff)
+
+
 class _A2cLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prob, value, action, advantage, return_, valid, value_loss_coeff,
@@ -495,6 +546,23 @@ class RowCommit:
         _lib.require_gpu()
         check(lib.rlpyt_commit_rows(ptr(self.table), self.n, self.max_bytes, ptr(t_dev), stream()),
               "rlpyt_commit_rows")
+
+
+def fc_small(x, weight, bias=None, relu=True):
+    """``act(x @ weight.T + bias)`` for a small batch (M <= 256 rows) on fp32 MFMA with a
+    split-K over the whole chip: the no-grad trunk layer of the sampling forward, where a
+    library GEMM is latency-bound (rlpyt/models/mlp.py through atari_ff_model.py:52-55)."""
+    _lib.require_gpu()
+    x = _f32(x)
+    M, K = x.shape
+    N = weight.shape[0]
+    w = _f32(weight.detach())
+    b = None if bias is None else _f32(bias.detach())
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    ws = _workspace("fc_small", lib.rlpyt_fc_small_workspace_bytes(M, N), x.device)
+    check(lib.rlpyt_fc_small_f32(ptr(x), ptr(w), ptr(b), ptr(y), M, N, K, int(bool(relu)), ptr(ws),
+                                 stream()), "rlpyt_fc_small_f32")
+    return y
 
 
 def frame_push(obs, t_dev, lo, new_frame, full_rows, slot, stage=None):

@@ -353,7 +353,9 @@ class GpuSampler(BaseSampler):
             Bg = hi - lo
             # reward f32[Bg], slot i32[Bg], done bool[Bg], reset bool[Bg] share ONE block so
             # they travel in one H2D
-            nbytes = 8 * Bg + ((2 * Bg + 15) // 16) * 16
+            # ... followed by the int64 time index of the step (master-written)
+            t_off = 8 * Bg + ((2 * Bg + 15) // 16) * 16
+            nbytes = t_off + 16
             misc = (np_mp_array(nbytes, np.uint8) if shared else np.zeros(nbytes, np.uint8))
             misc[:] = 0
             fields = dict(
@@ -367,7 +369,7 @@ class GpuSampler(BaseSampler):
             else:
                 step_np = StepBuffer(**fields)
             G = AttrDict(idx=g, lo=lo, hi=hi, Bg=Bg, step_np=step_np, misc_np=misc, calls=0,
-                         graph=None)
+                         graph=None, t_np=misc[t_off:t_off + 8].view(np.int64), t_off=t_off)
             self.groups.append(G)
             wb = np.linspace(0, Bg, n_w + 1).astype(int)
             for w in range(n_w):
@@ -471,7 +473,8 @@ class GpuSampler(BaseSampler):
                                           dtype=torch.uint8, device=dev)
                 G.slot_all = np.arange(Bg, dtype=np.int32)
             G.action_out = buffer_from_example(ex["action"], (Bg,), device=dev)
-            G.t_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            # the time index travels with the reward/done block: no counter kernel per step
+            G.t_dev = G.misc_stage[G.t_off:G.t_off + 8].view(torch.int64)
             G.pre_commit = G.post_commit = None
             # uniforms for the whole batch are drawn once per batch (one RNG call instead of
             # one per step, and the captured step graph holds no RNG state)
@@ -522,7 +525,7 @@ class GpuSampler(BaseSampler):
 
     def _step_body(self, G, capturing=False):
         """Device work of one time step of group ``G`` (graph-capturable: fixed addresses,
-        the time index is the device counter ``G.t_dev``).
+        the time index ``G.t_dev`` arrives with the reward/done block of the step).
 
         Staging holds obs_t and the (reward, done) produced by env step t-1 (at t=0: the
         carry from the previous batch).  Commits obs -> row t, reward -> all_reward[t]
@@ -582,7 +585,6 @@ class GpuSampler(BaseSampler):
             self._commit_rows(self._all_action, action, G, t + 1)
             self._commit_rows(s.agent.agent_info, agent_info, G, t)
             _copy_leaves(G.action_out, action)
-        t.add_(1)
 
     def _tail_body(self, G):
         """After the last env step of the batch: commit reward/done of step T-1 and compute
@@ -636,10 +638,11 @@ class GpuSampler(BaseSampler):
     def _on_stream(self, G):
         return torch.cuda.stream(G.stream) if G.stream is not None else _NullCtx()
 
-    def _issue(self, G, first=False):
+    def _issue(self, G, t, first=False):
         """Enqueue H2D staging -> (graph of) step body -> D2H action on the group's stream."""
         cuda = self.device.type == "cuda"
         t0 = time.perf_counter()
+        G.t_np[0] = t
         with self._on_stream(G):
             self._upload_special(G, cuda, first)
             if cuda and self.use_graph and G.graph is None and G.calls >= self.GRAPH_WARMUP_CALLS:
@@ -699,6 +702,7 @@ class GpuSampler(BaseSampler):
                 sg.full_rows_dev = G.full_rows.data_ptr()
                 sg.obs_host = G.step_np.observation.ctypes.data
                 sg.row_bytes = G.step_np.observation[0].nbytes
+            sg.t_host = G.t_np.ctypes.data
             sg.graph_exec = G.graph.raw_cuda_graph_exec()
             sg.stream = (G.stream or torch.cuda.current_stream(self.device)).cuda_stream
             G.event.record(G.stream or torch.cuda.current_stream(self.device))
@@ -732,7 +736,6 @@ class GpuSampler(BaseSampler):
         copies stay outside: as memcpy nodes they measured slower on ROCm 7.2 (124 vs 92+39 us
         per group-step) and stalled a single-stream capture."""
         torch.cuda.synchronize()
-        t_keep = G.t_dev.clone()
         graph = torch.cuda.CUDAGraph()
         if G.gen is not None and G.u_all is None:
             graph.register_generator_state(G.gen)
@@ -741,7 +744,6 @@ class GpuSampler(BaseSampler):
         with torch.cuda.graph(graph, stream=G.stream):
             self._step_body(G, capturing=True)
         G.post_commit.set_entries(G.post_entries)
-        G.t_dev.copy_(t_keep)       # capture does not execute, keep the counter anyway
         torch.cuda.synchronize()
         logger.log(f"GpuSampler: captured the step graph of pipeline group {G.idx}.")
         return graph
@@ -768,7 +770,6 @@ class GpuSampler(BaseSampler):
             with self._on_stream(G):
                 if G.u_all is not None:
                     G.u_all.uniform_(generator=G.gen)
-                G.t_dev.zero_()
                 # leading prev_action row (collectors.py:23-24); prev_reward[0] and the
                 # done carry are committed from the staging block by the first step
                 _map(lambda d, s: d[0, G.lo:G.hi].copy_(s, non_blocking=True),
@@ -783,7 +784,7 @@ class GpuSampler(BaseSampler):
                         t0 = time.perf_counter()
                         self._wait_obs(G)
                         tm["wait_env_s"] += time.perf_counter() - t0
-                    self._issue(G, first=(t == 0))
+                    self._issue(G, t, first=(t == 0))
                     if not par:
                         self._finish(G)
                         t0 = time.perf_counter()

@@ -62,12 +62,10 @@ def main():
     res["dedup"] = bool(G.dedup)
     if G.graph is not None:
         def rep():
-            G.t_dev.zero_()
             G.graph.replay()
         res["graph_us"] = ev(rep)
     else:
         def body():
-            G.t_dev.zero_()
             s._step_body(G)
         res["eager_body_us"] = ev(body)
     print(json.dumps(res), flush=True)
