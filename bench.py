@@ -197,6 +197,12 @@ def main():
                                    "frac": g["GBps"] / HBM_PEAK_GBPS, "traffic": None,
                                    "avg_us": g["avg_us"], "launches": g["launches"],
                                    "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
+            # HBM traffic of that kernel from the separate rocprofv3 --pmc passes (a PMC pass
+            # cannot run inside this timed process); committed under profiles/
+            traffic = pmc_traffic(name, g)
+            if traffic is not None:
+                out["roofline"]["traffic"] = traffic["bytes_per_launch"]
+                out["roofline"]["traffic_source"] = traffic["source"]
             out["kernels"] = {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv)
                                   for kk, vv in v.items()} for k, v in ksum.items()}
         out["roofline_gae_scaled"] = gae_scaled_roofline()
@@ -206,6 +212,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(name, g):
+    """HBM bytes per launch of kernel ``name`` from profiles/r1_conv_pmc_counters.json
+    ((2 * FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md), rescaled by algorithmic
+    bytes when the bench launch is not the profiled M = 8192 one."""
+    path = os.path.join(ROOT, "profiles", "r1_conv_pmc_counters.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"][name]
+    except (OSError, KeyError, ValueError):
+        return None
+    scale = g["alg_bytes_per_launch"] / k["alg_bytes"] if k.get("alg_bytes") else 1.
+    return {"bytes_per_launch": k["hbm_bytes_corrected"] * scale,
+            "source": "profiles/r1_conv_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / "
+                      "WRITE_SIZE passes over scripts/conv_bench.py, M=8192)"}
 
 
 def gae_scaled_roofline(T=128, log2n=20, iters=20):
