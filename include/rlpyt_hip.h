@@ -138,12 +138,16 @@ int rlpyt_ppo_loss_fwd_bwd_f32(const float* prob_new /*[M,A]*/, const float* val
  * h f32 [M,K] (K = 256 or 512), w_pi [A,K] (A <= 8), w_v [K].  Outputs: out_scalars[5] as
  * rlpyt_ppo_loss_fwd_bwd_f32; grad_h [M,K] = dL/dh; grad_params [A*K + K + A + 1] =
  * dL/dw_pi | dL/dw_v | dL/db_pi | dL/db_v (fixed-order partial reduction: deterministic).
+ * With flat_idx [M] the per-sample inputs (prob_old, action, advantage, return_) are the
+ * [T,B,...] batch arrays, read at (idx % T, idx / T) inside the kernel (no gather launches);
+ * valid must then be NULL.
  * workspace: rlpyt_ppo_head_loss_workspace_bytes(K, A) bytes. */
 int64_t rlpyt_ppo_head_loss_workspace_bytes(int K, int A);
 int rlpyt_ppo_head_loss_fwd_bwd_f32(const float* h, const float* w_pi, const float* b_pi,
                                     const float* w_v, const float* b_v, const float* prob_old,
                                     const int64_t* action, const float* advantage,
                                     const float* return_, const float* valid /*nullable*/,
+                                    const int64_t* flat_idx /*nullable*/, int T, int64_t B,
                                     int64_t M, int K, int A, float ratio_clip,
                                     float value_loss_coeff, float entropy_loss_coeff,
                                     float* out_scalars, float* grad_h, float* grad_params,
@@ -304,10 +308,24 @@ int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t_begin, int
  * M <= 256 rows: y[m,n] = act(sum_k x[m,k] w[n,k] + bias[n]) on fp32 MFMA with the K range
  * split over workgroups and a fixed-order partial sum (deterministic).  x [M,K], w [N,K]
  * (torch nn.Linear layout), bias [N] nullable, y [M,N]; N % 16 == 0, K % 16 == 0;
- * workspace: rlpyt_fc_small_workspace_bytes(M, N) bytes. */
+ * workspace: rlpyt_fc_small_workspace_bytes(M, N) bytes; with y == NULL only the split-K
+ * partials [ksplit, M, N] are left in workspace (consumed by rlpyt_pg_sample_head_f32). */
 int64_t rlpyt_fc_small_workspace_bytes(int M, int N);
+int rlpyt_fc_small_ksplit(int K); /* number of K slices = leading dim of the partials */
 int rlpyt_fc_small_f32(const float* x, const float* w, const float* bias /*nullable*/, float* y,
                        int M, int N, int K, int relu, float* workspace, rlpyt_stream_t stream);
+
+/* Sampling head of the fused AtariFf step: h = relu(sum_s partial[s] + fc_bias) (the split-K
+ * partials of rlpyt_fc_small_f32), policy / value heads + softmax + inverse-CDF draw
+ * (uniforms[t, row]) as rlpyt_categorical_head_f32, and the row writes of the step:
+ * prob_rows[t, lo+row, :], value_rows[t, lo+row], action_rows[t+1, lo+row], action_out[row];
+ * t = *t_dev.  One launch instead of trunk-finish + head + commit nodes. */
+int rlpyt_pg_sample_head_f32(const float* partial, int ksplit, const float* fc_bias,
+                             const float* w_pi, const float* b_pi, const float* w_v,
+                             const float* b_v, const float* uniforms /*[T', n]*/,
+                             const int64_t* t_dev, int64_t n, int K, int A, float* prob_rows,
+                             float* value_rows, int64_t* action_rows, int64_t B, int64_t lo,
+                             int64_t* action_out, rlpyt_stream_t stream);
 
 /* Frame-stack push for frame-stacked environments (rlpyt/envs/atari/atari_env.py:115-118:
  * the observation is the last C frames, newest last): the host uploads only the newest
@@ -316,10 +334,14 @@ int rlpyt_fc_small_f32(const float* x, const float* w, const float* bias /*nulla
  *                               : concat(obs[t-1, lo+b, 1:], new_frame[b]),
  * t = *t_dev (t >= 1 wherever slot[b] < 0).  obs u8 [T,B,C,HW]; new_frame u8 [Bg,HW];
  * full_rows u8 [<=Bg,C,HW]; slot i32 [Bg]; stage u8 [Bg,C,HW] (nullable) receives a copy of
- * the rebuilt rows.  Bit-exact byte moves. */
+ * the rebuilt rows.  With reward_rows the step's scalar rows all_reward[t, lo:lo+Bg] and
+ * all_done[t, lo:lo+Bg] are committed by the same launch.  Bit-exact byte moves. */
 int rlpyt_frame_push(uint8_t* obs, const int64_t* t_dev, int64_t B, int64_t lo, int64_t Bg,
                      int C, int64_t HW, const uint8_t* new_frame, const uint8_t* full_rows,
-                     const int32_t* slot, uint8_t* stage /*nullable*/, rlpyt_stream_t stream);
+                     const int32_t* slot, uint8_t* stage /*nullable*/,
+                     float* reward_rows /*nullable: [T',B] f32*/, const float* reward_src /*[Bg]*/,
+                     uint8_t* done_rows /*[T',B] bool*/, const uint8_t* done_src /*[Bg]*/,
+                     rlpyt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * AtariFfModel convolution stack on fp32 MFMA -- rlpyt/models/pg/atari_ff_model.py:40-63 with

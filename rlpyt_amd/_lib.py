@@ -80,8 +80,9 @@ _SIGNATURES = {
     "rlpyt_ppo_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,
                                            c_float, c_float, _p, _p, _p, _p, _p]),
     "rlpyt_ppo_head_loss_workspace_bytes": (c_int64, [c_int, c_int]),
-    "rlpyt_ppo_head_loss_fwd_bwd_f32": (c_int, [_p] * 10 + [c_int64, c_int, c_int, c_float, c_float,
-                                                          c_float, _p, _p, _p, _p, _p]),
+    "rlpyt_ppo_head_loss_fwd_bwd_f32": (c_int, [_p] * 11 + [c_int, c_int64, c_int64, c_int, c_int,
+                                                          c_float, c_float, c_float, _p, _p, _p, _p,
+                                                          _p]),
     "rlpyt_a2c_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,
                                            c_float, _p, _p, _p, _p, _p]),
     "rlpyt_dqn_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,
@@ -105,7 +106,10 @@ _SIGNATURES = {
     "rlpyt_fc_small_workspace_bytes": (c_int64, [c_int, c_int]),
     "rlpyt_fc_small_f32": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, _p, _p]),
     "rlpyt_frame_push": (c_int, [_p, _p, c_int64, c_int64, c_int64, c_int, c_int64, _p, _p, _p, _p,
-                                 _p]),
+                                 _p, _p, _p, _p, _p]),
+    "rlpyt_fc_small_ksplit": (c_int, [c_int]),
+    "rlpyt_pg_sample_head_f32": (c_int, [_p, c_int] + [_p] * 7 + [c_int64, c_int, c_int, _p, _p, _p,
+                                                              c_int64, c_int64, _p, _p]),
     "rlpyt_atari_conv1_fwd_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, _p, c_float, _p, _p]),
     "rlpyt_atari_conv2_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p]),
     "rlpyt_atari_conv2_dgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p]),

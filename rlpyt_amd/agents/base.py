@@ -99,6 +99,13 @@ class BaseAgent:
     def step(self, observation, prev_action, prev_reward):
         raise NotImplementedError
 
+    def step_into(self, observation, prev_action, prev_reward, binding):
+        """Optional fast path of ``step`` for HBM-resident samplers: run the sampling forward
+        AND write action[t+1] / agent_info[t] rows of the bound batch (``binding``: the sampler's
+        ``StepBinding``) plus the host-bound action copy.  Return False to decline (the caller
+        then uses ``step`` and commits the rows itself)."""
+        return False
+
     def reset(self):
         pass
 

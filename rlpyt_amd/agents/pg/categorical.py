@@ -5,7 +5,11 @@ from ...distributions.categorical import Categorical, DistInfo
 from ...utils.collections import namedarraytuple
 from ..base import AgentStep, BaseAgent
 
+from collections import namedtuple
+
 AgentInfo = namedarraytuple("AgentInfo", ["dist_info", "value"])
+_HeadOut = namedtuple("_HeadOut", ["prob_rows", "value_rows", "action_rows", "action_out",
+                                   "uniforms", "t_dev", "lo"])
 
 
 class CategoricalPgAgent(BaseAgent):
@@ -62,6 +66,19 @@ class CategoricalPgAgent(BaseAgent):
             action = self.distribution.sample(dist_info, generator=self.sample_generator)
         agent_info = AgentInfo(dist_info=dist_info, value=value)
         return self._out(AgentStep(action=action, agent_info=agent_info))
+
+    @torch.no_grad()
+    def step_into(self, observation, prev_action, prev_reward, binding):
+        m = self.sampling_model
+        if self.uses_prev_inputs or not hasattr(m, "sample_step_into"):
+            return False
+        info = binding.agent_info_rows
+        if not (isinstance(binding.action_rows, torch.Tensor) and hasattr(info, "dist_info")):
+            return False
+        out = _HeadOut(prob_rows=info.dist_info.prob, value_rows=info.value,
+                       action_rows=binding.action_rows, action_out=binding.action_out,
+                       uniforms=binding.uniforms, t_dev=binding.t_dev, lo=binding.lo)
+        return bool(m.sample_step_into(observation, out))
 
     @torch.no_grad()
     def value(self, observation, prev_action, prev_reward):

@@ -53,8 +53,11 @@ class PPO(PolicyGradientAlgo):
         if hasattr(self.agent, "update_obs_rms"):
             self.agent.update_obs_rms(agent_inputs.observation)
         return_, advantage, valid = self.process_returns(samples)
-        action = mv(samples.agent.action)
-        old_prob = mv(samples.agent.agent_info.dist_info.prob)
+        action = mv(samples.agent.action).contiguous()
+        old_prob = mv(samples.agent.agent_info.dist_info.prob).contiguous()
+        uses_prev = getattr(self.agent, "uses_prev_inputs", True)
+        fused_idx = (self.fused_head_loss and not recurrent and not uses_prev
+                     and getattr(self.agent, "supports_fused_head_loss", False))
         if recurrent:
             init_rnn_state = samples.agent.agent_info.prev_rnn_state[0]
         T, B = samples.env.reward.shape[:2]
@@ -64,23 +67,35 @@ class PPO(PolicyGradientAlgo):
         # [T,B] fields the gather kernel can slice need contiguous storage; prev_action /
         # prev_reward are [:-1] views of [T+1,B] arrays (contiguous as [T,B] blocks).
         for _ in range(self.epochs):
-            for idxs in iterate_mb_idxs(batch_size, mb_size, shuffle=True):
+            # one upload of the epoch's shuffled index chunks (utils/misc.py:6-17 order kept)
+            chunks = list(iterate_mb_idxs(batch_size, mb_size, shuffle=True))
+            epoch_idx = torch.from_numpy(np.ascontiguousarray(np.concatenate(chunks))).to(
+                dev, non_blocking=True) if chunks else None
+            for k in range(len(chunks)):
                 self.optimizer.zero_grad(set_to_none=True)
                 if recurrent:
                     raise NotImplementedError("recurrent PPO is outside the hot-path scope")
-                idx_dev = torch.from_numpy(np.ascontiguousarray(idxs)).to(dev, non_blocking=True)
-                mb_inputs = AgentInputs(
-                    observation=self.agent.gather_observation(agent_inputs.observation,
-                                                              idx_dev),
-                    prev_action=ops.gather_tb(agent_inputs.prev_action.contiguous(), idx_dev),
-                    prev_reward=ops.gather_tb(agent_inputs.prev_reward.contiguous(), idx_dev))
-                mb_action = ops.gather_tb(action.contiguous(), idx_dev)
-                mb_return = ops.gather_tb(return_, idx_dev)
-                mb_adv = ops.gather_tb(advantage, idx_dev)
-                mb_valid = None if valid is None else ops.gather_tb(valid, idx_dev)
-                mb_old_prob = ops.gather_tb(old_prob.contiguous(), idx_dev)
-                loss, scalars = self.loss(mb_inputs, mb_action, mb_return, mb_adv, mb_valid,
-                                          mb_old_prob)
+                idx_dev = epoch_idx[k * mb_size:(k + 1) * mb_size]
+                mb_obs = self.agent.gather_observation(agent_inputs.observation, idx_dev)
+                if fused_idx and valid is None:
+                    # index mode: the conv kernels and the head+loss kernel read the [T,B] batch
+                    # arrays at (idx % T, idx // T) themselves -- no gather launch at all
+                    loss, scalars = self.loss(AgentInputs(mb_obs, None, None), action, return_,
+                                              advantage, None, old_prob, flat_idx=idx_dev)
+                else:
+                    if uses_prev:
+                        mb_pa = ops.gather_tb(agent_inputs.prev_action.contiguous(), idx_dev)
+                        mb_pr = ops.gather_tb(agent_inputs.prev_reward.contiguous(), idx_dev)
+                    else:
+                        mb_pa = mb_pr = None
+                    mb_inputs = AgentInputs(observation=mb_obs, prev_action=mb_pa, prev_reward=mb_pr)
+                    mb_action = ops.gather_tb(action, idx_dev)
+                    mb_return = ops.gather_tb(return_, idx_dev)
+                    mb_adv = ops.gather_tb(advantage, idx_dev)
+                    mb_valid = None if valid is None else ops.gather_tb(valid, idx_dev)
+                    mb_old_prob = ops.gather_tb(old_prob, idx_dev)
+                    loss, scalars = self.loss(mb_inputs, mb_action, mb_return, mb_adv, mb_valid,
+                                              mb_old_prob)
                 loss.backward()
                 grad_norm = torch.nn.utils.clip_grad_norm_(self.agent.parameters(),
                                                            self.clip_grad_norm)
@@ -97,16 +112,20 @@ class PPO(PolicyGradientAlgo):
         return opt_info
 
     def loss(self, agent_inputs, action, return_, advantage, valid, old_prob,
-             init_rnn_state=None):
+             init_rnn_state=None, flat_idx=None):
         """Fused PPO loss on a minibatch (already gathered, all in HBM).  Returns
-        ``(loss, scalars)`` with scalars = [loss, pi_loss, value_loss, entropy, perplexity]."""
+        ``(loss, scalars)`` with scalars = [loss, pi_loss, value_loss, entropy, perplexity].
+        ``flat_idx``: the loss inputs are whole ``[T,B,...]`` arrays and sample m is row
+        ``(idx % T, idx // T)`` (fused head+loss kernel only)."""
         if init_rnn_state is None and self.fused_head_loss and getattr(
                 self.agent, "supports_fused_head_loss", False):
             # heads + softmax + loss + all their gradients in one kernel pass over the trunk
             h, pi_m, v_m = self.agent.trunk(*agent_inputs)
             return ops.ppo_head_loss(h, pi_m.weight, pi_m.bias, v_m.weight, v_m.bias, old_prob,
                                      action, advantage, return_, valid, self.ratio_clip,
-                                     self.value_loss_coeff, self.entropy_loss_coeff)
+                                     self.value_loss_coeff, self.entropy_loss_coeff,
+                                     flat_idx=flat_idx)
+        assert flat_idx is None, "index-mode loss needs the fused head+loss kernel"
         if init_rnn_state is not None:
             init_rnn_state = buffer_method(init_rnn_state, "transpose", 0, 1)
             init_rnn_state = buffer_method(init_rnn_state, "contiguous")

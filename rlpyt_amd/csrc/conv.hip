@@ -140,13 +140,15 @@ __device__ __forceinline__ void stage_y1_padded(float* pad, const float* __restr
 // ======================================================================================
 constexpr int PS_F = 20;
 
+template <int NT>  // position tiles per wave: 4 = one workgroup per image, 2 = two per image
 __global__ __launch_bounds__(256) void conv2_fwd_kernel(
     const float* __restrict__ y1, const float* __restrict__ w2, const float* __restrict__ b2,
     float* __restrict__ y2, int64_t M) {
+  constexpr int SPLIT = 4 / NT;   // small sampling batches use 2 workgroups per image
   __shared__ __attribute__((aligned(16))) float pad[PPIX * PS_F];  // 41,600 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
-  const int ct = wave & 1, t0 = wave >> 1;  // co tile; position tiles t0, t0+2, t0+4, t0+6
+  const int ct = wave & 1, t0 = wave >> 1;  // co tile; position tiles t0 + 2*part + 2*SPLIT*i
   float wa[64];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk)
@@ -156,37 +158,39 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(
   float bias[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias[r] = b2[ct * 16 + 4 * kq + r];
-  int base[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pos = min((t0 + 2 * i) * 16 + j, P2 - 1);
-    const int oy = pos / W2, ox = pos - oy * W2;
-    base[i] = ((2 * oy) * PW + 2 * ox) * PS_F + 4 * kq;
-  }
   for (int i = tid; i < PPIX * PS_F; i += 256) pad[i] = 0.f;  // border stays zero
 
-  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+  for (int64_t mm = blockIdx.x; mm < M * SPLIT; mm += gridDim.x) {
+    const int64_t m = mm / SPLIT;
+    const int part = (int)(mm - m * SPLIT);
+    int base[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int pos = min((t0 + 2 * part + 2 * SPLIT * i) * 16 + j, P2 - 1);
+      const int oy = pos / W2, ox = pos - oy * W2;
+      base[i] = ((2 * oy) * PW + 2 * ox) * PS_F + 4 * kq;
+    }
     __syncthreads();
     stage_y1_padded<PS_F>(pad, y1 + m * Y1, tid, 256);
     __syncthreads();
-    f32x4 acc[4];
+    f32x4 acc[NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       const int off = ((kk >> 2) * PW + (kk & 3)) * PS_F;
-      f32x4 bv[4];
+      f32x4 bv[NT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(pad + base[i] + off);
+      for (int i = 0; i < NT; ++i) bv[i] = *reinterpret_cast<const f32x4*>(pad + base[i] + off);
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = mfma16(wa[kk * 4 + sp], bv[i][sp], acc[i]);
+        for (int i = 0; i < NT; ++i) acc[i] = mfma16(wa[kk * 4 + sp], bv[i][sp], acc[i]);
     }
     float* out = y2 + m * F2 + (ct * 16 + 4 * kq) * P2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pos = (t0 + 2 * i) * 16 + j;
+    for (int i = 0; i < NT; ++i) {
+      const int pos = (t0 + 2 * part + 2 * SPLIT * i) * 16 + j;
       if (pos < P2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[r * P2 + pos] = fmaxf(acc[i][r] + bias[r], 0.f);
@@ -375,16 +379,17 @@ __global__ __launch_bounds__(256) void conv2_wgrad_kernel(
 //   per image 27.6 KB (g2, y2) + 30.4 KB (y1) in, 30.4 KB (dy1) out, 1920 MFMAs.
 // 8 waves: dgrad -> wave (parity class w & 3, tile half w >> 2);
 //          wgrad -> wave (ky = w & 3, position-group parity w >> 2), two partial rows per
-//          workgroup.  gm2 lives once in LDS as [co][pos] (stride 120): the wgrad reads it as
+//          workgroup.  gm2 lives once in LDS as [co][pos] (stride 124): the wgrad reads it as
 //          float4 over pos, the dgrad as scalars; y1 lives in the zero-bordered plane
 //          (stride 18) and also supplies the ReLU mask of the dgrad epilogue.
 // ======================================================================================
 constexpr int B2_THREADS = 512;
+constexpr int GS_B = 124;  // gm row stride: 4*GS_B = 16 (mod 32) -> the dgrad's ds_read_b32 lane halves hit disjoint banks
 
 __global__ __launch_bounds__(B2_THREADS, 4) void conv2_bwd_kernel(
     const float* __restrict__ g2, const float* __restrict__ y2, const float* __restrict__ y1,
     const float* __restrict__ w2, float* __restrict__ dy1, float* __restrict__ partial, int64_t M) {
-  __shared__ __attribute__((aligned(16))) float gm[C2 * GS_W];        // 15,360 B
+  __shared__ __attribute__((aligned(16))) float gm[C2 * GS_B];        // 15,872 B
   __shared__ __attribute__((aligned(16))) float pad[PPIX * PS_W];     // 37,440 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(B2_THREADS, 4) void conv2_bwd_kernel(
     porig[i] = ((2 * oy) * PW + 2 * ox) * PS_W;
   }
   const int plane = q * PW * PS_W + j;
-  for (int i = tid; i < C2 * GS_W; i += B2_THREADS) gm[i] = 0.f;   // pos 108..119 stay zero
+  for (int i = tid; i < C2 * GS_B; i += B2_THREADS) gm[i] = 0.f;   // pos 108..119 stay zero
   for (int i = tid; i < PPIX * PS_W; i += B2_THREADS) pad[i] = 0.f;
   f32x4 acc[4][2];
 #pragma unroll
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(B2_THREADS, 4) void conv2_bwd_kernel(
     for (int i = tid; i < F2; i += B2_THREADS) {
       const int co = i / P2, pos = i - co * P2;
       const float g = g2[m * F2 + i], y = y2[m * F2 + i];
-      gm[co * GS_W + pos] = y > 0.f ? g : 0.f;
+      gm[co * GS_B + pos] = y > 0.f ? g : 0.f;
     }
     stage_y1_padded<PS_W>(pad, y1 + m * Y1, tid, B2_THREADS);
     __syncthreads();
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(B2_THREADS, 4) void conv2_bwd_kernel(
         for (int dd = 0; dd < 4; ++dd) {
           const int oy = a + py - (dd >> 1), ox = b + px - (dd & 1);
           const bool v = (oy >= 0) && (oy < H2) && (ox >= 0) && (ox < W2);
-          off[u][dd] = (v ? oy * W2 + ox : P2) + 4 * kq * GS_W;   // column 108 is zero
+          off[u][dd] = (v ? oy * W2 + ox : P2) + 4 * kq * GS_B;   // column 108 is zero
         }
       }
       f32x4 dacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(B2_THREADS, 4) void conv2_bwd_kernel(
           for (int sp = 0; sp < 4; ++sp) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-              const float bval = gm[off[u][dd] + (sg * 16 + sp) * GS_W];
+              const float bval = gm[off[u][dd] + (sg * 16 + sp) * GS_B];
               dacc[u] = mfma16(wd[(dd * 2 + sg) * 4 + sp], bval, dacc[u]);
             }
           }
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(B2_THREADS, 4) void conv2_bwd_kernel(
         f32x4 av[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-          av[ct] = *reinterpret_cast<const f32x4*>(gm + (ct * 16 + j) * GS_W + 16 * sg + 4 * kq);
+          av[ct] = *reinterpret_cast<const f32x4*>(gm + (ct * 16 + j) * GS_B + 16 * sg + 4 * kq);
         if (q == 0) {
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) bsum[ct] += (av[ct][0] + av[ct][1]) + (av[ct][2] + av[ct][3]);
@@ -561,13 +566,37 @@ __global__ __launch_bounds__(W1_THREADS) void conv1_wgrad_kernel(
     for (int i = tid; i < Y1 / 4; i += W1_THREADS)
       *reinterpret_cast<f32x4*>(dl + (i >> 2) * DS_1 + 4 * (i & 3)) = dsrc[i];
     __syncthreads();
+    // the A value and the patch origin of a position group are fetched one group ahead, so the
+    // image-byte reads of a group do not wait on a dependent LDS round trip
+    float a_nx[4];
+    int xo_nx[4];
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      const int posr = 16 * half + 4 * kq + sp;
+      a_nx[sp] = dl[posr * DS_1 + j];
+      xo_nx[sp] = xoff[posr];
+    }
     for (int sg = half; sg < NSG1; sg += 2) {
+      float a_cur[4];
+      int xo_cur[4];
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp) {
-        const int posr = 16 * sg + 4 * kq + sp;
-        const float a = dl[posr * DS_1 + j];
+        a_cur[sp] = a_nx[sp];
+        xo_cur[sp] = xo_nx[sp];
+      }
+      if (sg + 2 < NSG1) {
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+          const int posr = 16 * (sg + 2) + 4 * kq + sp;
+          a_nx[sp] = dl[posr * DS_1 + j];
+          xo_nx[sp] = xoff[posr];
+        }
+      }
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const float a = a_cur[sp];
         if (c == 0) bsum += a;
-        const uint8_t* xp = img + xlane + xoff[posr];
+        const uint8_t* xp = img + xlane + xo_cur[sp];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma16(a, (float)xp[t * 2 * W0], acc[t]);
       }
@@ -656,8 +685,12 @@ extern "C" int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float
   if (M == 0) return RLPYT_OK;
   RL_CHECK_ARG(y1 && w2 && b2 && y2, RLPYT_EINVAL, "rlpyt_atari_conv2_fwd_f32: null pointer");
   RL_CHECK_ARG(RL_ALIGNED16(y1), RLPYT_ESHAPE, "rlpyt_atari_conv2_fwd_f32: y1 must be 16-byte aligned");
-  hipLaunchKernelGGL(conv2_fwd_kernel, dim3(grid_for(M, 3)), dim3(256), 0, (hipStream_t)stream,
-                     y1, w2, b2, y2, M);
+  if (M <= grid_for(1 << 30, 1))   // small (sampling) batch: two workgroups per image
+    hipLaunchKernelGGL((conv2_fwd_kernel<2>), dim3(grid_for(2 * M, 3)), dim3(256), 0,
+                       (hipStream_t)stream, y1, w2, b2, y2, M);
+  else
+    hipLaunchKernelGGL((conv2_fwd_kernel<4>), dim3(grid_for(M, 3)), dim3(256), 0, (hipStream_t)stream,
+                       y1, w2, b2, y2, M);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
     const float* __restrict__ advantage, const float* __restrict__ return_,
     const float* __restrict__ valid, int64_t M, int A, float ratio_clip, float c_v, float c_e,
     float* __restrict__ grad_h, float* __restrict__ wpart, LossWs* __restrict__ ws,
-    int n_valid_part) {
+    int n_valid_part, const int64_t* __restrict__ flat_idx, int T, int64_t B) {
   __shared__ double scratch[6 * 16];
   constexpr int K = 64 * KI;
   double denom = (double)M;
@@ -397,16 +397,22 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
     const float rden = 1.f / den;
 #pragma unroll
     for (int a = 0; a < kHeadAMax; ++a) p[a] *= rden;
-    // ---- PPO loss terms and dL/dp, dL/dv (as pg_loss_kernel<0>)
-    const float vmask = valid ? valid[m] : 1.0f;
+    // ---- PPO loss terms and dL/dp, dL/dv (as pg_loss_kernel<0>); with flat_idx the per-sample
+    //      inputs are the [T,B] batch arrays read at (idx % T, idx / T) (ppo.py:94-95)
+    int64_t r = m;
+    if (flat_idx != nullptr) {
+      const int64_t idx = flat_idx[m];
+      r = (idx % T) * B + (idx / T);
+    }
+    const float vmask = valid ? valid[r] : 1.0f;
     const float w = vmask * inv;
-    const int a_sel = (int)action[m];
-    const float adv = advantage[m];
+    const int a_sel = (int)action[r];
+    const float adv = advantage[r];
     float p_sel = 0.f;
 #pragma unroll
     for (int a = 0; a < kHeadAMax; ++a)
       if (a == a_sel) p_sel = p[a];
-    const float den_o = prob_old[m * A + a_sel] + kEpsCat;
+    const float den_o = prob_old[r * A + a_sel] + kEpsCat;
     const float ratio = (p_sel + kEpsCat) / den_o;
     const float lo = 1.0f - ratio_clip, hi = 1.0f + ratio_clip;
     const float clipped = fminf(fmaxf(ratio, lo), hi);
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
     else if (s1 > s2) dr = inside ? adv : 0.f;
     else dr = 0.5f * adv + (inside ? 0.5f * adv : 0.f);
     const float g_sel = -w * dr / den_o;
-    const float verr_d = val - return_[m];
+    const float verr_d = val - return_[r];
     const float verr = 0.5f * verr_d * verr_d;
     const float dv = c_v * w * verr_d;
     float H = 0.f, gp[kHeadAMax], dot = 0.f;
@@ -676,9 +682,13 @@ extern "C" int64_t rlpyt_ppo_head_loss_workspace_bytes(int K, int A) {
 extern "C" int rlpyt_ppo_head_loss_fwd_bwd_f32(
     const float* h, const float* w_pi, const float* b_pi, const float* w_v, const float* b_v,
     const float* prob_old, const int64_t* action, const float* advantage, const float* return_,
-    const float* valid, int64_t M, int K, int A, float ratio_clip, float value_loss_coeff,
-    float entropy_loss_coeff, float* out_scalars, float* grad_h, float* grad_params,
-    void* workspace, rlpyt_stream_t stream) {
+    const float* valid, const int64_t* flat_idx, int T, int64_t B, int64_t M, int K, int A,
+    float ratio_clip, float value_loss_coeff, float entropy_loss_coeff, float* out_scalars,
+    float* grad_h, float* grad_params, void* workspace, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(flat_idx == nullptr || (T > 0 && B > 0), RLPYT_EINVAL,
+               "rlpyt_ppo_head_loss_fwd_bwd_f32: flat_idx needs T, B");
+  RL_CHECK_ARG(flat_idx == nullptr || valid == nullptr, RLPYT_ESHAPE,
+               "rlpyt_ppo_head_loss_fwd_bwd_f32: index mode takes valid == NULL (gather it first)");
   RL_CHECK_ARG(h && w_pi && b_pi && w_v && b_v && prob_old && action && advantage && return_ &&
                    out_scalars && grad_h && grad_params && workspace,
                RLPYT_EINVAL, "rlpyt_ppo_head_loss_fwd_bwd_f32: null pointer");
@@ -704,12 +714,12 @@ extern "C" int rlpyt_ppo_head_loss_fwd_bwd_f32(
     hipLaunchKernelGGL((ppo_head_loss_kernel<8>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h,
                        w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A,
                        ratio_clip, value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws,
-                       n_valid_part);
+                       n_valid_part, flat_idx, T, B);
   else
     hipLaunchKernelGGL((ppo_head_loss_kernel<4>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h,
                        w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A,
                        ratio_clip, value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws,
-                       n_valid_part);
+                       n_valid_part, flat_idx, T, B);
   RL_LAUNCH_CHECK();
   hipLaunchKernelGGL(head_reduce_kernel, dim3((part + 63) / 64), dim3(256), 0, s, wpart, grid,
                      part, grad_params);

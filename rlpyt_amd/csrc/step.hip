@@ -146,9 +146,18 @@ namespace {
 __global__ __launch_bounds__(256) void frame_push_kernel(
     uint8_t* __restrict__ obs, const int64_t* __restrict__ t_dev, int64_t B, int64_t lo, int C,
     int64_t HW, const uint8_t* __restrict__ new_frame, const uint8_t* __restrict__ full_rows,
-    const int32_t* __restrict__ slot, uint8_t* __restrict__ stage) {
+    const int32_t* __restrict__ slot, uint8_t* __restrict__ stage, float* __restrict__ reward_rows,
+    const float* __restrict__ reward_src, uint8_t* __restrict__ done_rows,
+    const uint8_t* __restrict__ done_src) {
   const int64_t b = blockIdx.y;
   const int64_t t = *t_dev;
+  if (reward_rows != nullptr && blockIdx.x == 0 && b == 0) {
+    // the step's scalar rows ride along: all_reward[t, lo:lo+Bg], all_done[t, lo:lo+Bg]
+    for (int i = threadIdx.x; i < (int)gridDim.y; i += blockDim.x) {
+      reward_rows[t * B + lo + i] = reward_src[i];
+      done_rows[t * B + lo + i] = done_src[i];
+    }
+  }
   const int64_t row_bytes = (int64_t)C * HW;
   uint8_t* __restrict__ dst = obs + (t * B + lo + b) * row_bytes;
   uint8_t* __restrict__ dst2 = stage != nullptr ? stage + b * row_bytes : nullptr;
@@ -173,18 +182,22 @@ __global__ __launch_bounds__(256) void frame_push_kernel(
 extern "C" int rlpyt_frame_push(uint8_t* obs, const int64_t* t_dev, int64_t B, int64_t lo,
                                 int64_t Bg, int C, int64_t HW, const uint8_t* new_frame,
                                 const uint8_t* full_rows, const int32_t* slot, uint8_t* stage,
-                                rlpyt_stream_t stream) {
+                                float* reward_rows, const float* reward_src, uint8_t* done_rows,
+                                const uint8_t* done_src, rlpyt_stream_t stream) {
   RL_CHECK_ARG(B > 0 && lo >= 0 && Bg >= 0 && lo + Bg <= B && C > 0 && HW > 0, RLPYT_EINVAL,
                "rlpyt_frame_push: bad sizes");
   if (Bg == 0) return RLPYT_OK;
   RL_CHECK_ARG(obs && t_dev && new_frame && full_rows && slot, RLPYT_EINVAL,
                "rlpyt_frame_push: null pointer");
+  RL_CHECK_ARG((reward_rows == nullptr) || (reward_src && done_rows && done_src), RLPYT_EINVAL,
+               "rlpyt_frame_push: reward/done rows go together");
   RL_CHECK_ARG(HW % 16 == 0 && ((reinterpret_cast<uintptr_t>(obs) | reinterpret_cast<uintptr_t>(new_frame) |
                                  reinterpret_cast<uintptr_t>(full_rows) | reinterpret_cast<uintptr_t>(stage)) & 15) == 0,
                RLPYT_ESHAPE, "rlpyt_frame_push: H*W must be a multiple of 16 and buffers 16-byte aligned");
   const unsigned gx = (unsigned)std::min<int64_t>(ceil_div((int64_t)C * HW / 16, 256), 4);
   hipLaunchKernelGGL(frame_push_kernel, dim3(gx, (unsigned)Bg), dim3(256), 0, (hipStream_t)stream, obs,
-                     t_dev, B, lo, C, HW, new_frame, full_rows, slot, stage);
+                     t_dev, B, lo, C, HW, new_frame, full_rows, slot, stage, reward_rows, reward_src,
+                     done_rows, done_src);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
@@ -270,10 +283,16 @@ extern "C" int64_t rlpyt_fc_small_workspace_bytes(int M, int N) {
   return (int64_t)rlpyt::kFcKSplit * M * N * (int64_t)sizeof(float);
 }
 
+extern "C" int rlpyt_fc_small_ksplit(int K) {
+  if (K <= 0) return 0;
+  const int kchunk = (int)(rlpyt::ceil_div(rlpyt::ceil_div(K, rlpyt::kFcKSplit), 16) * 16);
+  return (int)rlpyt::ceil_div(K, kchunk);
+}
+
 extern "C" int rlpyt_fc_small_f32(const float* x, const float* w, const float* bias, float* y,
                                   int M, int N, int K, int relu, float* workspace,
                                   rlpyt_stream_t stream) {
-  RL_CHECK_ARG(x && w && y && workspace, RLPYT_EINVAL, "rlpyt_fc_small_f32: null pointer");
+  RL_CHECK_ARG(x && w && workspace, RLPYT_EINVAL, "rlpyt_fc_small_f32: null pointer");
   RL_CHECK_ARG(M > 0 && M <= 256 && N > 0 && N % 16 == 0 && K > 0 && K % 16 == 0, RLPYT_ESHAPE,
                "rlpyt_fc_small_f32: need 0 < M <= 256, N %% 16 == 0, K %% 16 == 0 (M=%d N=%d K=%d)",
                M, N, K);
@@ -291,9 +310,117 @@ extern "C" int rlpyt_fc_small_f32(const float* x, const float* w, const float* b
   else
     hipLaunchKernelGGL((rlpyt::fc_small_kernel<4>), grid, dim3(256), 0, s, x, w, workspace, M, N, K, kchunk);
   RL_LAUNCH_CHECK();
+  if (y == nullptr) return RLPYT_OK;   // caller consumes the split-K partials itself
   const int64_t MN = (int64_t)M * N;
   hipLaunchKernelGGL(rlpyt::fc_small_finish_kernel, dim3((unsigned)ceil_div(MN / 4, 256)), dim3(256), 0,
                      s, workspace, bias, y, MN, N, ksplit, relu);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// Sampling head of the fused AtariFf step: finishes the split-K trunk (sum of partials + bias +
+// ReLU, in registers), runs the policy / value heads, softmax and the inverse-CDF draw, and
+// writes prob[t], value[t], action[t+1] of the HBM batch plus the host-bound action copy --
+// three graph nodes (trunk finish, head, row commit) in one.  One wave per row.
+namespace rlpyt {
+namespace {
+template <int KI>
+__global__ __launch_bounds__(256) void pg_sample_head_kernel(
+    const float* __restrict__ partial, int ksplit, const float* __restrict__ fc_bias,
+    const float* __restrict__ w_pi, const float* __restrict__ b_pi, const float* __restrict__ w_v,
+    const float* __restrict__ b_v, const float* __restrict__ uniforms,
+    const int64_t* __restrict__ t_dev, int64_t n, int A, float* __restrict__ prob_rows,
+    float* __restrict__ value_rows, int64_t* __restrict__ action_rows, int64_t B, int64_t lo,
+    int64_t* __restrict__ action_out) {
+  constexpr int K = 64 * KI;
+  constexpr int AMAX = 8;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t t = *t_dev;
+  float hv[KI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+    const int k = lane + 64 * i;
+    float v = partial[row * K + k];   // same summation order as fc_small_finish_kernel
+    for (int sidx = 1; sidx < ksplit; ++sidx) v += partial[((int64_t)sidx * n + row) * K + k];
+    hv[i] = fmaxf(v + fc_bias[k], 0.f);
+  }
+  float acc[AMAX + 1];
+#pragma unroll
+  for (int a = 0; a <= AMAX; ++a) acc[a] = 0.f;
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+    const int k = lane + 64 * i;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) acc[a] = fmaf(hv[i], w_pi[a * K + k], acc[a]);
+    acc[AMAX] = fmaf(hv[i], w_v[k], acc[AMAX]);
+  }
+#pragma unroll
+  for (int a = 0; a <= AMAX; ++a) acc[a] = wave_sum(acc[a]);
+  if (lane == 0) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) {
+        acc[a] += b_pi[a];
+        mx = fmaxf(mx, acc[a]);
+      }
+    float den = 0.f;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) {
+        acc[a] = expf(acc[a] - mx);
+        den += acc[a];
+      }
+    const float inv = 1.f / den;
+    float cum = 0.f;
+    int pick = -1, last_pos = 0;
+    const float u = uniforms[t * n + row];
+    float* __restrict__ pr = prob_rows + (t * B + lo + row) * A;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) {
+        const float p = acc[a] * inv;
+        pr[a] = p;
+        cum += p;
+        if (p > 0.f) last_pos = a;
+        if (pick < 0 && cum > u) pick = a;
+      }
+    value_rows[t * B + lo + row] = acc[AMAX] + b_v[0];
+    const int64_t act = pick >= 0 ? pick : last_pos;
+    action_rows[(t + 1) * B + lo + row] = act;
+    action_out[row] = act;
+  }
+}
+}  // namespace
+}  // namespace rlpyt
+
+extern "C" int rlpyt_pg_sample_head_f32(const float* partial, int ksplit, const float* fc_bias,
+                                        const float* w_pi, const float* b_pi, const float* w_v,
+                                        const float* b_v, const float* uniforms,
+                                        const int64_t* t_dev, int64_t n, int K, int A,
+                                        float* prob_rows, float* value_rows, int64_t* action_rows,
+                                        int64_t B, int64_t lo, int64_t* action_out,
+                                        rlpyt_stream_t stream) {
+  RL_CHECK_ARG(partial && fc_bias && w_pi && b_pi && w_v && b_v && uniforms && t_dev && prob_rows &&
+                   value_rows && action_rows && action_out,
+               RLPYT_EINVAL, "rlpyt_pg_sample_head_f32: null pointer");
+  RL_CHECK_ARG(n > 0 && ksplit > 0 && A > 0 && A <= 8 && (K == 512 || K == 256) && lo >= 0 &&
+                   lo + n <= B,
+               RLPYT_ESHAPE, "rlpyt_pg_sample_head_f32: need 0<A<=8, K in {256,512}, lo+n<=B");
+  const dim3 grid((unsigned)ceil_div(n, 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 512)
+    hipLaunchKernelGGL((rlpyt::pg_sample_head_kernel<8>), grid, block, 0, s, partial, ksplit, fc_bias,
+                       w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows,
+                       action_rows, B, lo, action_out);
+  else
+    hipLaunchKernelGGL((rlpyt::pg_sample_head_kernel<4>), grid, block, 0, s, partial, ksplit, fc_bias,
+                       w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows,
+                       action_rows, B, lo, action_out);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

@@ -110,6 +110,26 @@ class AtariFfModel(torch.nn.Module):
         return (w.is_cuda and w.dtype == torch.float32 and w.shape[0] <= 8
                 and w.shape[1] in (256, 512))
 
+    @torch.no_grad()
+    def sample_step_into(self, image, out):
+        """Sampling forward that also performs the step's row writes (``out``: the sampler's
+        ``StepBinding``): conv stack -> split-K trunk -> ONE kernel that finishes the trunk, runs
+        the heads + softmax + draw and writes prob[t], value[t], action[t+1] and the host-bound
+        action copy.  Returns False when this fused path does not apply."""
+        from ... import ops
+        lin = self._single_fc()
+        if not (isinstance(image, torch.Tensor) and image.is_cuda and image.dtype == torch.uint8
+                and image.dim() == 4 and self.fused_conv and self.fused_head_loss
+                and lin is not None and image.shape[0] <= 256 and lin.in_features % 16 == 0):
+            return False
+        B = image.shape[0]
+        feat = self._conv_features(image.contiguous(), None)
+        partial, ksplit = ops.fc_small_partials(feat, lin.weight)
+        ops.pg_sample_head(partial, ksplit, lin.bias, self.pi.weight, self.pi.bias,
+                           self.value.weight, self.value.bias, out.uniforms, out.t_dev, B,
+                           out.prob_rows, out.value_rows, out.action_rows, out.lo, out.action_out)
+        return True
+
     def forward(self, image, prev_action, prev_reward, features_only=False):
         """[T,B,C,H,W] / [B,C,H,W] / [C,H,W] -> (pi, value) with the same lead dims.
         ``features_only``: return the trunk output ``[T*B, fc]`` instead (for the fused

@@ -201,7 +201,7 @@ def ppo_loss(prob_new, value, prob_old, action, advantage, return_, valid, ratio
 class _PpoHeadLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid,
-                ratio_clip, value_loss_coeff, entropy_loss_coeff):
+                ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None):
         _lib.require_gpu()
         K = h.shape[-1]
         A = w_pi.shape[0]
@@ -209,6 +209,12 @@ class _PpoHeadLoss(torch.autograd.Function):
         M = hc.shape[0]
         wp, bp = _f32(w_pi.detach()), _f32(b_pi.detach())
         wv, bv = _f32(w_v.detach()).reshape(-1), _f32(b_v.detach()).reshape(-1)
+        T = B = 0
+        if flat_idx is not None:     # loss inputs are [T,B,...] batch arrays, indexed in-kernel
+            assert valid is None and prob_old.dim() == 3
+            T, B = prob_old.shape[:2]
+            flat_idx = flat_idx.long().contiguous()
+            assert flat_idx.numel() == M
         po = _f32(prob_old).reshape(-1, A)
         act = action.reshape(-1).long().contiguous()
         adv = _f32(advantage).reshape(-1)
@@ -221,7 +227,8 @@ class _PpoHeadLoss(torch.autograd.Function):
         with ktimer.region("ppo_head_loss", M * (8 * K + 8 * A + 28)):
             check(lib.rlpyt_ppo_head_loss_fwd_bwd_f32(
                 ptr(hc), ptr(wp), ptr(bp), ptr(wv), ptr(bv), ptr(po), ptr(act), ptr(adv), ptr(ret),
-                ptr(val), M, K, A, float(ratio_clip), float(value_loss_coeff),
+                ptr(val), ptr(flat_idx), int(T), int(B), M, K, A, float(ratio_clip),
+                float(value_loss_coeff),
                 float(entropy_loss_coeff), ptr(out), ptr(gh), ptr(gparams), ptr(ws), stream()),
                 "rlpyt_ppo_head_loss_fwd_bwd_f32")
         ctx.save_for_backward(gh, gparams)
@@ -236,17 +243,19 @@ class _PpoHeadLoss(torch.autograd.Function):
         gp = gp * g_loss
         o = A * K
         return ((gh * g_loss).reshape(hs), gp[:o].reshape(wps), gp[o + K:o + K + A].reshape(bps),
-                gp[o:o + K].reshape(wvs), gp[o + K + A:].reshape(bvs)) + (None,) * 8
+                gp[o:o + K].reshape(wvs), gp[o + K + A:].reshape(bvs)) + (None,) * 9
 
 
 def ppo_head_loss(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid,
-                  ratio_clip, value_loss_coeff, entropy_loss_coeff):
+                  ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None):
     """PPO.loss (rlpyt/algos/pg/ppo.py:117-154) with the policy / value heads of
     rlpyt/models/pg/atari_ff_model.py:56-58 fused in: takes the trunk output ``h [M, K]`` and the
     head parameters, returns ``(loss, scalars)`` like ``ppo_loss``; differentiable w.r.t. ``h``
-    and the four head parameters (all gradients come out of the same kernel pass)."""
+    and the four head parameters (all gradients come out of the same kernel pass).  With
+    ``flat_idx`` (int64 ``[M]``) the loss inputs are the whole ``[T,B,...]`` batch arrays and the
+    kernel reads sample m at ``(idx % T, idx // T)`` -- no minibatch gather launches."""
     return _PpoHeadLoss.apply(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_,
-                              valid, ratio_clip, value_loss_coeff, entropy_loss_coeff)
+                              valid, ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx)
 
 
 class _A2cLoss(torch.autograd.Function):
@@ -565,11 +574,46 @@ def fc_small(x, weight, bias=None, relu=True):
     return y
 
 
-def frame_push(obs, t_dev, lo, new_frame, full_rows, slot, stage=None):
+def fc_small_partials(x, weight):
+    """Split-K partial products ``[ksplit, M, N]`` of ``x @ weight.T`` (no bias / activation):
+    the first half of ``fc_small``, for consumers that finish the sum themselves."""
+    _lib.require_gpu()
+    x = _f32(x)
+    M, K = x.shape
+    N = weight.shape[0]
+    w = _f32(weight.detach())
+    ws = _workspace("fc_small", lib.rlpyt_fc_small_workspace_bytes(M, N), x.device)
+    check(lib.rlpyt_fc_small_f32(ptr(x), ptr(w), None, None, M, N, K, 0, ptr(ws), stream()),
+          "rlpyt_fc_small_f32")
+    return ws, lib.rlpyt_fc_small_ksplit(K)
+
+
+def pg_sample_head(partial, ksplit, fc_bias, w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, prob_rows,
+                   value_rows, action_rows, lo, action_out):
+    """Trunk finish + heads + softmax + draw + the step's row writes in one launch
+    (``rlpyt_pg_sample_head_f32``): writes ``prob_rows[t, lo:lo+n]``, ``value_rows[t, lo:lo+n]``,
+    ``action_rows[t+1, lo:lo+n]`` and ``action_out[:n]`` with ``t = *t_dev``."""
+    _lib.require_gpu()
+    A, K = w_pi.shape
+    B = prob_rows.shape[1]
+    assert prob_rows.is_contiguous() and value_rows.is_contiguous() and action_rows.is_contiguous()
+    assert action_rows.dtype == torch.int64 and action_out.dtype == torch.int64
+    assert uniforms.shape[-1] == n and uniforms.is_contiguous()
+    check(lib.rlpyt_pg_sample_head_f32(
+        ptr(partial), int(ksplit), ptr(_f32(fc_bias.detach())), ptr(_f32(w_pi.detach())),
+        ptr(_f32(b_pi.detach())), ptr(_f32(w_v.detach()).reshape(-1)),
+        ptr(_f32(b_v.detach()).reshape(-1)), ptr(uniforms), ptr(t_dev), int(n), K, A,
+        ptr(prob_rows), ptr(value_rows), ptr(action_rows), B, int(lo), ptr(action_out), stream()),
+        "rlpyt_pg_sample_head_f32")
+
+
+def frame_push(obs, t_dev, lo, new_frame, full_rows, slot, stage=None, scalar_rows=None):
     """Rebuild row ``t`` (device counter) of a frame-stacked uint8 observation batch
     ``[T,B,C,*img]`` for columns ``lo:lo+Bg`` from the newest frames ``[Bg,*img]``:
     shifted previous stack + new frame, or a full row ``full_rows[slot[b]]`` where
-    ``slot[b] >= 0`` (reset envs, first step of a batch)."""
+    ``slot[b] >= 0`` (reset envs, first step of a batch).  ``scalar_rows`` =
+    ``(all_reward [T',B] f32, reward_src [Bg], all_done [T',B] bool, done_src [Bg])`` commits
+    the step's reward / done rows in the same launch."""
     _lib.require_gpu()
     assert obs.dtype == torch.uint8 and obs.is_contiguous() and obs.dim() >= 4
     B, C = obs.shape[1], obs.shape[2]
@@ -578,9 +622,14 @@ def frame_push(obs, t_dev, lo, new_frame, full_rows, slot, stage=None):
         HW *= d
     Bg = new_frame.shape[0]
     assert slot.dtype == torch.int32 and slot.numel() == Bg
+    rr = rs = dr = ds = None
+    if scalar_rows is not None:
+        rr, rs, dr, ds = scalar_rows
+        assert rr.dtype == torch.float32 and rr.shape[1] == B and dr.shape[1] == B
+        dr, ds = dr.view(torch.uint8), ds.view(torch.uint8)
     check(lib.rlpyt_frame_push(ptr(obs), ptr(t_dev), B, int(lo), Bg, C, HW, ptr(new_frame),
-                               ptr(full_rows), ptr(slot), ptr(stage), stream()),
-          "rlpyt_frame_push")
+                               ptr(full_rows), ptr(slot), ptr(stage), ptr(rr), ptr(rs), ptr(dr),
+                               ptr(ds), stream()), "rlpyt_frame_push")
 
 
 def categorical_head(h, w_pi, b_pi, w_v=None, b_v=None, uniforms=None, u_row=None):

@@ -32,6 +32,7 @@ Buffer layout contract: ``action`` / ``prev_action`` are the 
 """
 import ctypes
 import multiprocessing as mp
+from collections import namedtuple
 import queue as queue_mod
 import time
 
@@ -48,6 +49,9 @@ from .base import BaseSampler
 from .collections import AgentSamplesBsv, AgentSamples, EnvSamples, Samples
 
 StepBuffer = namedarraytuple("StepBuffer", ["observation", "action", "reward", "done"])
+# what an agent's ``step_into`` gets to write the rows of a step itself (see BaseAgent.step_into)
+StepBinding = namedtuple("StepBinding", ["action_rows", "agent_info_rows", "action_out",
+                                         "uniforms", "t_dev", "lo"])
 # frame-stacked envs additionally publish the newest frame and a "stack was reset" flag
 StepBufferFs = namedarraytuple("StepBufferFs", ["observation", "action", "reward", "done",
                                                 "frame", "reset"])
@@ -286,7 +290,8 @@ class GpuSampler(BaseSampler):
     GRAPH_WARMUP_CALLS = 3   # eager calls per group before capture (MIOpen/hipBLASLt find)
 
     def __init__(self, *args, n_workers=0, mid_batch_reset=True, pin_step_buffer=True,
-                 n_groups=None, use_graph=True, frame_dedup=True, native_loop=True, **kwargs):
+                 n_groups=None, use_graph=True, frame_dedup=True, native_loop=True, fused_step=True,
+                 **kwargs):
         super().__init__(*args, **kwargs)
         self.n_workers = int(n_workers)
         self.mid_batch_reset = bool(mid_batch_reset)
@@ -294,6 +299,7 @@ class GpuSampler(BaseSampler):
         self.use_graph = bool(use_graph)
         self.frame_dedup = bool(frame_dedup)
         self.native_loop = bool(native_loop)
+        self.fused_step = bool(fused_step)
         self._native = None
         B = self.batch_spec.B
         if n_groups is None:
@@ -537,10 +543,14 @@ class GpuSampler(BaseSampler):
         lo, hi = G.lo, G.hi
         if G.pre_commit is not None:
             if G.dedup:
+                # one launch: rebuild the frame stacks of row t + commit the reward/done rows
                 from .. import ops
                 ops.frame_push(s.env.observation, t, lo, G.frame_stage, G.full_rows,
-                               G.slot_stage, stage=G.obs_stage)
-            G.pre_commit.launch(t)
+                               G.slot_stage, stage=G.obs_stage,
+                               scalar_rows=(self._all_reward, G.reward_stage, self._all_done,
+                                            G.done_stage))
+            else:
+                G.pre_commit.launch(t)
         else:
             self._commit_rows(s.env.observation, G.obs_stage, G, t)
             self._all_reward[:, lo:hi].index_copy_(0, t, G.reward_stage.unsqueeze(0))
@@ -559,6 +569,14 @@ class GpuSampler(BaseSampler):
                 prev_reward = torch.where(dn, torch.zeros_like(prev_reward), prev_reward)
         else:
             prev_action = prev_reward = None
+        if (G.u_all is not None and self.mid_batch_reset and self.fused_step
+                and isinstance(self._all_action, torch.Tensor)):
+            # the agent runs the forward AND writes the step's rows (fused head kernel)
+            binding = StepBinding(action_rows=self._all_action, agent_info_rows=s.agent.agent_info,
+                                  action_out=G.action_out, uniforms=G.u_all, t_dev=t, lo=lo)
+            if self.agent.step_into(G.obs_stage, prev_action, prev_reward, binding):
+                G.post_entries = None
+                return
         self.agent.sample_generator = G.gen
         self.agent.sample_uniforms = None if G.u_all is None else (G.u_all, t)
         action, agent_info = self.agent.step(G.obs_stage, prev_action, prev_reward)
@@ -743,7 +761,8 @@ class GpuSampler(BaseSampler):
         # are keyed by stream, and two groups' graphs replay concurrently
         with torch.cuda.graph(graph, stream=G.stream):
             self._step_body(G, capturing=True)
-        G.post_commit.set_entries(G.post_entries)
+        if G.post_entries is not None:
+            G.post_commit.set_entries(G.post_entries)
         torch.cuda.synchronize()
         logger.log(f"GpuSampler: captured the step graph of pipeline group {G.idx}.")
         return graph

@@ -207,3 +207,33 @@ def test_fc_small_matches_torch(M, K, N):
     y2 = ops.fc_small(xd, wd, None, relu=False)
     ref2 = x.double() @ w.double().t()
     assert (y2.double().cpu() - ref2).abs().max().item() <= 2e-5 * ref2.abs().max().item() + 1e-6
+
+
+def test_fused_step_matches_unfused_step():
+    """The fused step (frame_push + row commit in one launch; trunk finish + heads + draw + row
+    writes in one launch) produces exactly the batches of the node-per-op step graph."""
+    def run(fused):
+        s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=7), batch_T=6, batch_B=8,
+                       n_workers=2, n_groups=2, fused_step=fused, max_decorrelation_steps=0)
+        a = AtariFfAgent()
+        torch.manual_seed(31)
+        np.random.seed(31)
+        s.initialize(a, seed=8, bootstrap_value=True)
+        torch.cuda.set_device(0)
+        a.to_device(0)
+        torch.manual_seed(32)
+        out = []
+        for itr in range(4):
+            smp, _ = s.obtain_samples(itr)
+            torch.cuda.synchronize()
+            out.append([x.clone() for x in (smp.env.observation, smp.agent.action,
+                                            smp.env.reward, smp.env.done,
+                                            smp.agent.agent_info.dist_info.prob,
+                                            smp.agent.agent_info.value,
+                                            smp.agent.bootstrap_value)])
+        s.shutdown()
+        return out
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
