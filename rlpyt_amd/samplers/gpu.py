@@ -151,8 +151,9 @@ class EnvRunner:
 
 
 def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus):
-    """Forked sampler worker (rlpyt/samplers/parallel/worker.py:37-101).  ``runners`` holds
-    this worker's environments of every pipeline group, served in group order."""
+    """Forked sampler worker (rlpyt/samplers/parallel/worker.py:37-101).  ``runners`` =
+    [(group index, EnvRunner)]: this worker's environments, served in group order (with
+    dedicated workers per pipeline group there is exactly one entry)."""
     try:
         if cpus is not None:
             import psutil
@@ -161,21 +162,21 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus):
         pass
     torch.set_num_threads(1)
     set_seed(seed)
-    for rn in runners:
+    for _, rn in runners:
         rn.start(ctrl.max_decorrelation_steps)
     ctrl.barrier_out.wait()
-    seq = _StepSync(ctrl.sync_words, len(runners), ctrl.n_workers, ctrl.worker_spin)
+    seq = _StepSync(ctrl.sync_words, ctrl.group_workers, ctrl.n_workers, ctrl.worker_spin)
     ti_keys, ti_table, ti_count = ctrl.ti_keys, ctrl.ti_table, ctrl.ti_count
     while True:
         seq.worker_wait_batch()
         if ctrl.quit.value:
             break
         completed = []
-        for g, rn in enumerate(runners):
+        for g, rn in runners:
             rn.begin_batch()
             seq.worker_arrive(g)
         for t in range(batch_T):
-            for g, rn in enumerate(runners):
+            for g, rn in runners:
                 seq.worker_wait_act(g)
                 rn.step_all(t, completed)
                 seq.worker_arrive(g)
@@ -209,14 +210,16 @@ class _StepSync:
     # (so that the master never has to wake them) measured 2-3x SLOWER on the bench host
     WORKER_SPIN = 300
 
-    def __init__(self, words, n_groups, n_workers, worker_spin=None):
+    def __init__(self, words, group_workers, n_workers, worker_spin=None):
         from .. import _lib
         self._lib = _lib.lib
         base = words.ctypes.data
+        n_groups = len(group_workers)
         # words[2g] = act sequence, words[2g+1] = arrival counter; 64 B apart per group
         self.act = [ctypes.c_void_p(base + 128 * g) for g in range(n_groups)]
         self.obs = [ctypes.c_void_p(base + 128 * g + 64) for g in range(n_groups)]
-        self.n_workers = n_workers
+        self.n_workers = n_workers              # all workers (batch hand-off)
+        self.group_workers = list(group_workers)  # workers serving each group (step hand-off)
         self.acts = [0] * n_groups       # action sets published / consumed so far
         self.rounds = [0] * n_groups     # arrival rounds completed so far
         # batch hand-off (replaces two n+1-party barriers per batch): word 0 of the extra
@@ -230,7 +233,8 @@ class _StepSync:
     # -- worker side
     def worker_arrive(self, g):
         self.rounds[g] += 1
-        self._lib.rlpyt_seq_arrive(self.obs[g], (self.rounds[g] * self.n_workers) & 0xffffffff)
+        self._lib.rlpyt_seq_arrive(self.obs[g],
+                                   (self.rounds[g] * self.group_workers[g]) & 0xffffffff)
 
     def worker_wait_act(self, g):
         self.acts[g] += 1
@@ -256,7 +260,8 @@ class _StepSync:
 
     def master_wait_obs(self, g, timeout_ms=120000):
         self.rounds[g] += 1
-        rc = self._lib.rlpyt_seq_wait(self.obs[g], (self.rounds[g] * self.n_workers) & 0xffffffff,
+        rc = self._lib.rlpyt_seq_wait(self.obs[g],
+                                      (self.rounds[g] * self.group_workers[g]) & 0xffffffff,
                                       self.MASTER_SPIN, timeout_ms)
         if rc != 0:
             raise RuntimeError("GpuSampler: env workers did not report within "
@@ -291,7 +296,7 @@ class GpuSampler(BaseSampler):
 
     def __init__(self, *args, n_workers=0, mid_batch_reset=True, pin_step_buffer=True,
                  n_groups=None, use_graph=True, frame_dedup=True, native_loop=True, fused_step=True,
-                 **kwargs):
+                 split_workers=True, **kwargs):
         super().__init__(*args, **kwargs)
         self.n_workers = int(n_workers)
         self.mid_batch_reset = bool(mid_batch_reset)
@@ -300,6 +305,7 @@ class GpuSampler(BaseSampler):
         self.frame_dedup = bool(frame_dedup)
         self.native_loop = bool(native_loop)
         self.fused_step = bool(fused_step)
+        self._split_workers = bool(split_workers)
         self._native = None
         B = self.batch_spec.B
         if n_groups is None:
@@ -352,6 +358,8 @@ class GpuSampler(BaseSampler):
             and (o[0].size % 16 == 0))
         gb = np.linspace(0, B, self.n_groups + 1).astype(int)
         n_w = max(self.n_workers, 1)
+        self.split_workers = bool(self._split_workers and self.n_workers >= 2 * self.n_groups
+                                  and self.n_groups > 1)
         self.groups = []
         runners = [[] for _ in range(n_w)]       # [worker][group]
         for g in range(self.n_groups):
@@ -377,19 +385,25 @@ class GpuSampler(BaseSampler):
             G = AttrDict(idx=g, lo=lo, hi=hi, Bg=Bg, step_np=step_np, misc_np=misc, calls=0,
                          graph=None, t_np=misc[t_off:t_off + 8].view(np.int64), t_off=t_off)
             self.groups.append(G)
-            wb = np.linspace(0, Bg, n_w + 1).astype(int)
-            for w in range(n_w):
-                l, h = int(wb[w]), int(wb[w + 1])
-                runners[w].append(EnvRunner(
+            # workers of this group: every worker (each then serves all groups in turn), or a
+            # dedicated subset w = g (mod n_groups) -- then a post wakes only the group's
+            # workers and the groups' env stepping runs on different cores at the same time
+            ws = ([w for w in range(n_w) if w % self.n_groups == g] if self.split_workers
+                  else list(range(n_w)))
+            wb = np.linspace(0, Bg, len(ws) + 1).astype(int)
+            for k, w in enumerate(ws):
+                l, h = int(wb[k]), int(wb[k + 1])
+                runners[w].append((g, EnvRunner(
                     envs[lo + l:lo + h], step_np[l:h],
                     None if self.env_info_np is None else self.env_info_np[:, lo + l:lo + h],
-                    self.TrajInfoCls, self.mid_batch_reset))
+                    self.TrajInfoCls, self.mid_batch_reset)))
+            G.n_workers = len(ws)
         self.runners = runners
         if self.n_workers > 0:
             self._launch_workers(affinity)
         else:
             set_state = np.random.get_state()
-            for rn in runners[0]:
+            for _, rn in runners[0]:
                 rn.start(self.max_decorrelation_steps)
             np.random.set_state(set_state)
         self._device_ready = False
@@ -404,6 +418,7 @@ class GpuSampler(BaseSampler):
             quit=ctx.RawValue(ctypes.c_bool, False),
             barrier_out=ctx.Barrier(n + 1),
             sync_words=np_mp_array(32 * (len(self.groups) + 1), np.uint32), n_workers=n,
+            group_workers=[G.n_workers for G in self.groups],
             worker_spin=None,
             traj_infos_queue=ctx.Queue(),
             max_decorrelation_steps=self.max_decorrelation_steps)
@@ -414,7 +429,7 @@ class GpuSampler(BaseSampler):
         keys = [k for k, v in proto.items() if isinstance(v, (int, float, bool, np.number))]
         if len(keys) != len(proto):
             keys = []        # non-numeric fields: everything goes through the queue
-        envs_per_worker = max(sum(len(rn.envs) for rn in rs) for rs in self.runners)
+        envs_per_worker = max(sum(len(rn.envs) for _, rn in rs) for rs in self.runners)
         cap = self.batch_spec.T * envs_per_worker + 4 if keys else 0
         self.ctrl.ti_keys = keys
         self.ctrl.ti_table = np_mp_array((n, max(cap, 1), max(len(keys), 1)), np.float64)
@@ -429,7 +444,7 @@ class GpuSampler(BaseSampler):
                 self.seed + 1000 * (self.rank + 1) + w, wc), daemon=True)
             p.start()
             self.workers.append(p)
-        self.sync = _StepSync(self.ctrl.sync_words, len(self.groups), n)
+        self.sync = _StepSync(self.ctrl.sync_words, self.ctrl.group_workers, n)
         self.ctrl.barrier_out.wait()  # decorrelation done, step buffers filled
 
     # ------------------------------------------------------------- device-side allocation
@@ -695,7 +710,7 @@ class GpuSampler(BaseSampler):
         arr = (_lib.StepGroup * len(self.groups))()
         for G, sg in zip(self.groups, arr):
             sg.act_word, sg.obs_word = self.sync.act[G.idx], self.sync.obs[G.idx]
-            sg.n_workers = self.n_workers
+            sg.n_workers = G.n_workers
             h2d = []
             if G.dedup:
                 h2d.append((G.frame_stage, G.frame_h))
@@ -780,7 +795,7 @@ class GpuSampler(BaseSampler):
         if par:
             self.sync.master_start_batch()
         else:
-            for rn in self.runners[0]:
+            for _, rn in self.runners[0]:
                 rn.begin_batch()
         cuda = self.device.type == "cuda"
         for G in self.groups:
@@ -807,7 +822,7 @@ class GpuSampler(BaseSampler):
                     if not par:
                         self._finish(G)
                         t0 = time.perf_counter()
-                        self.runners[0][G.idx].step_all(t, completed)
+                        self.runners[0][G.idx][1].step_all(t, completed)
                         tm["wait_env_s"] += time.perf_counter() - t0
                 if par:
                     for G in self.groups:

@@ -120,7 +120,7 @@ def test_sampler_batches_are_contiguous_in_time():
     s.shutdown()
 
 
-@pytest.mark.parametrize("n_workers,n_groups", [(2, 2), (0, 2), (3, 1)])
+@pytest.mark.parametrize("n_workers,n_groups", [(2, 2), (0, 2), (3, 1), (4, 2)])
 def test_sampler_pipeline_groups_keep_trajectories_contiguous(n_workers, n_groups):
     """Pipeline groups are column ranges of the same [T,B] batch: every column stays one
     env's contiguous trajectory, within a batch and across batches, and prev_* rows are the
@@ -131,6 +131,7 @@ def test_sampler_pipeline_groups_keep_trajectories_contiguous(n_workers, n_group
     a = AtariFfAgent()
     s.initialize(a, seed=2, bootstrap_value=True)
     assert s.n_groups == n_groups
+    assert s.split_workers == (n_workers >= 2 * n_groups and n_groups > 1)   # dedicated workers
     smp, _ = s.obtain_samples(0)
     obs = smp.env.observation.clone()
     for t in range(4):     # frame stack shifts by exactly one frame per step, every column

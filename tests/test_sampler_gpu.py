@@ -14,7 +14,8 @@ logger.set_quiet(True)
 
 
 @pytest.mark.parametrize("n_workers,n_groups,use_graph", [(2, 2, True), (2, 1, True),
-                                                          (0, 1, True), (2, 2, False)])
+                                                          (0, 1, True), (2, 2, False),
+                                                          (4, 2, True)])
 def test_sampler_rows_consistent_on_device(n_workers, n_groups, use_graph):
     T, B = 6, 8
     s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=9), batch_T=T, batch_B=B,
