@@ -296,7 +296,7 @@ class GpuSampler(BaseSampler):
 
     def __init__(self, *args, n_workers=0, mid_batch_reset=True, pin_step_buffer=True,
                  n_groups=None, use_graph=True, frame_dedup=True, native_loop=True, fused_step=True,
-                 split_workers=True, **kwargs):
+                 split_workers=False, **kwargs):
         super().__init__(*args, **kwargs)
         self.n_workers = int(n_workers)
         self.mid_batch_reset = bool(mid_batch_reset)
@@ -385,9 +385,10 @@ class GpuSampler(BaseSampler):
             G = AttrDict(idx=g, lo=lo, hi=hi, Bg=Bg, step_np=step_np, misc_np=misc, calls=0,
                          graph=None, t_np=misc[t_off:t_off + 8].view(np.int64), t_off=t_off)
             self.groups.append(G)
-            # workers of this group: every worker (each then serves all groups in turn), or a
-            # dedicated subset w = g (mod n_groups) -- then a post wakes only the group's
-            # workers and the groups' env stepping runs on different cores at the same time
+            # workers of this group: every worker (each then serves all groups in turn; default),
+            # or with split_workers a dedicated subset w = g (mod n_groups).  Measured on the
+            # bench host (B=256, 2 groups): shared 32 workers 459 K SPS, dedicated 32 -> 432 K,
+            # dedicated 64 -> 447 K: the shared layout keeps every core busy in both phases
             ws = ([w for w in range(n_w) if w % self.n_groups == g] if self.split_workers
                   else list(range(n_w)))
             wb = np.linspace(0, Bg, len(ws) + 1).astype(int)

@@ -126,7 +126,7 @@ def test_sampler_pipeline_groups_keep_trajectories_contiguous(n_workers, n_group
     env's contiguous trajectory, within a batch and across batches, and prev_* rows are the
     shifted action / reward rows."""
     s = GpuSampler(SyntheticPong, dict(points_to_end=100, max_steps=10 ** 6), batch_T=5,
-                   batch_B=6, n_workers=n_workers, n_groups=n_groups,
+                   batch_B=6, n_workers=n_workers, n_groups=n_groups, split_workers=True,
                    max_decorrelation_steps=0)
     a = AtariFfAgent()
     s.initialize(a, seed=2, bootstrap_value=True)

@@ -20,7 +20,7 @@ def test_sampler_rows_consistent_on_device(n_workers, n_groups, use_graph):
     T, B = 6, 8
     s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=9), batch_T=T, batch_B=B,
                    n_workers=n_workers, n_groups=n_groups, use_graph=use_graph,
-                   max_decorrelation_steps=0)
+                   split_workers=(n_workers == 4), max_decorrelation_steps=0)
     a = AtariFfAgent()
     s.initialize(a, seed=3, bootstrap_value=True)
     torch.cuda.set_device(0)
