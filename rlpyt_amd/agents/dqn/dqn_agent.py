@@ -88,7 +88,7 @@ class DqnAgent(EpsilonGreedyAgentMixin, BaseAgent):
         prev_action = self.distribution.to_onehot(prev_action)
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         q = self.model(obs, pa, pr)
-        action = self.distribution.sample(q)
+        action = self.distribution.sample(q, generator=self.sample_generator)
         return self._out(AgentStep(action=action, agent_info=AgentInfo(q=q)))
 
     def target(self, observation, prev_action, prev_reward):

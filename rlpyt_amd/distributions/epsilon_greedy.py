@@ -11,14 +11,14 @@ class EpsilonGreedy(DiscreteMixin, Distribution):
         super().__init__(**kwargs)
         self._epsilon = epsilon
 
-    def sample(self, q):
+    def sample(self, q, generator=None):
         arg_select = torch.argmax(q, dim=-1)
         eps = self._epsilon
         if isinstance(eps, torch.Tensor):
             eps = eps.to(q.device)
-        mask = torch.rand(arg_select.shape, device=q.device) < eps
+        mask = torch.rand(arg_select.shape, device=q.device, generator=generator) < eps
         arg_rand = torch.randint(low=0, high=q.shape[-1], size=arg_select.shape,
-                                 device=q.device)
+                                 device=q.device, generator=generator)
         return torch.where(mask, arg_rand, arg_select)
 
     @property
@@ -36,9 +36,9 @@ class CategoricalEpsilonGreedy(EpsilonGreedy):
         super().__init__(**kwargs)
         self.z = z
 
-    def sample(self, p, z=None):
+    def sample(self, p, z=None, generator=None):
         q = torch.tensordot(p, z if z is not None else self.z, dims=1)
-        return super().sample(q)
+        return super().sample(q, generator=generator)
 
     def set_z(self, z):
         self.z = z

@@ -1,0 +1,55 @@
+"""End-to-end GPU run of BASELINE config #3 at test size: GpuSampler (HBM batch, step graphs)
+-> DQN with the HBM-resident prioritized frame replay (sum tree + frame gather kernels) ->
+fused DQN loss; checks the data path, not learning."""
+import numpy as np
+import pytest
+import torch
+
+from rlpyt_amd.agents.dqn.dqn_agent import AtariDqnAgent
+from rlpyt_amd.algos.dqn.dqn import DQN
+from rlpyt_amd.envs.synthetic import SyntheticPong
+from rlpyt_amd.samplers.gpu import GpuSampler
+from rlpyt_amd.utils import logger
+
+pytestmark = pytest.mark.gpu
+logger.set_quiet(True)
+
+
+@pytest.mark.parametrize("prioritized,double", [(True, True), (False, False)])
+def test_dqn_end_to_end(prioritized, double):
+    T, B = 4, 8
+    sampler = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=11), batch_T=T, batch_B=B,
+                         n_workers=2, max_decorrelation_steps=0)
+    agent = AtariDqnAgent(eps_final=0.1)
+    algo = DQN(batch_size=16, min_steps_learn=2 * T * B, replay_size=512, replay_ratio=8,
+               target_update_interval=4, n_step_return=2, prioritized_replay=prioritized,
+               double_dqn=double, learning_rate=1e-4)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    examples = sampler.initialize(agent, seed=1, bootstrap_value=False)
+    torch.cuda.set_device(0)
+    agent.to_device(0)
+    algo.initialize(agent=agent, n_itr=12, batch_spec=sampler.batch_spec,
+                    mid_batch_reset=sampler.mid_batch_reset, examples=examples)
+    losses, stored = [], []
+    for itr in range(10):
+        agent.sample_mode(itr)
+        samples, _ = sampler.obtain_samples(itr)
+        stored.append(samples.env.observation[:, :, -1].clone())   # newest frame of every step
+        agent.train_mode(itr)
+        info = algo.optimize_agent(itr, samples)
+        losses += list(info.loss)
+    assert algo.update_counter == (10 - algo.min_itr_learn) * algo.updates_per_optimize > 0
+    assert len(losses) == algo.update_counter and np.all(np.isfinite(losses))
+    rb = algo.replay_buffer
+    # the replay ring holds exactly the frames the sampler produced, in time order
+    # (newest frame of time r sits at row r + C - 1, rlpyt/replays/frame.py:27-59)
+    frames = torch.cat(stored)                      # [10*T, B, H, W]
+    assert torch.equal(rb.samples_frames[3:3 + frames.shape[0]], frames)
+    batch = rb.sample_batch(16)
+    obs = batch.agent_inputs.observation
+    assert obs.is_cuda and obs.dtype == torch.uint8 and obs.shape == (16, 4, 104, 80)
+    assert batch.return_.shape == (16,) and torch.isfinite(batch.return_).all()
+    if prioritized:
+        assert batch.is_weights.shape == (16,) and float(batch.is_weights.max()) <= 1.0 + 1e-6
+    sampler.shutdown()
