@@ -156,3 +156,69 @@ class BaseAgent:
         """Leave outputs in HBM unless running in reference drop-in mode."""
         from ..utils.buffer import buffer_to
         return buffer_to(x, device="cpu") if self.host_outputs else x
+
+
+class RecurrentAgentMixin:
+    """Recurrent state management during sampling (rlpyt/agents/base.py:252-304), re-shaped for
+    the HBM-resident sampler: the state of every pipeline group (``select_slot``) is ONE
+    persistent ``[N, B_g, H]`` device buffer updated in place, so the step can live in a captured
+    hipGraph; resets after ``done`` are a masked multiply on the device (``reset_where``) instead
+    of per-environment host indexing (``reset_one``, kept for API compatibility)."""
+    recurrent = True
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._rnn_states = {}
+        self._stash = None
+        self._slot = 0
+
+    def select_slot(self, slot):
+        self._slot = slot
+
+    @property
+    def prev_rnn_state(self):
+        return self._rnn_states.get(self._slot)
+
+    def advance_rnn_state(self, new_rnn_state):
+        from ..utils.buffer import buffer_func, buffer_leaves
+        cur = self._rnn_states.get(self._slot)
+        if cur is None:
+            self._rnn_states[self._slot] = buffer_func(new_rnn_state, lambda x: x.clone())
+        else:
+            for d, s in zip(buffer_leaves(cur), buffer_leaves(new_rnn_state)):
+                d.copy_(s)
+
+    def reset(self):
+        self._rnn_states = {}
+
+    def reset_one(self, idx):
+        from ..utils.buffer import buffer_leaves
+        cur = self._rnn_states.get(self._slot)
+        if cur is not None:
+            for x in buffer_leaves(cur):
+                x[:, idx] = 0
+
+    def reset_where(self, mask):
+        """Zero the state of the environments where ``mask`` ([B_g] bool, same device)."""
+        from ..utils.buffer import buffer_leaves
+        cur = self._rnn_states.get(self._slot)
+        if cur is not None:
+            for x in buffer_leaves(cur):
+                x.mul_((~mask).reshape(1, -1, 1).to(x.dtype))
+
+    def train_mode(self, itr):
+        if self._mode == "sample":
+            self._stash = self._rnn_states
+        self._rnn_states = {}
+        super().train_mode(itr)
+
+    def sample_mode(self, itr):
+        if self._mode != "sample" and self._stash is not None:
+            self._rnn_states = self._stash
+        super().sample_mode(itr)
+
+    def eval_mode(self, itr):
+        if self._mode == "sample":
+            self._stash = self._rnn_states
+        self._rnn_states = {}
+        super().eval_mode(itr)

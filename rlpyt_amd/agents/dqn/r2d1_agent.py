@@ -1,0 +1,57 @@
+"""Recurrent DQN agent (rlpyt/agents/dqn/r2d1_agent.py:12-59, atari/atari_r2d1_agent.py): Q-values,
+epsilon-greedy draw and the LSTM state all stay in HBM; ``agent_info.prev_rnn_state`` is stored
+``[B, N, H]`` as in the reference."""
+import torch
+
+from ...models.dqn.atari_r2d1_model import AtariR2d1Model
+from ...utils.buffer import buffer_func, buffer_method
+from ...utils.collections import namedarraytuple
+from ..base import AgentStep, RecurrentAgentMixin
+from .dqn_agent import DqnAgent
+
+AgentInfo = namedarraytuple("AgentInfo", ["q", "prev_rnn_state"])
+
+
+class R2d1AgentBase(DqnAgent):
+    def __call__(self, observation, prev_action, prev_reward, init_rnn_state):
+        """``init_rnn_state`` already ``[N, B, H]``; returns (q, rnn_state), both on device."""
+        prev_action = self.distribution.to_onehot(prev_action)
+        obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
+        q, rnn_state = self.model(obs, pa, pr, init_rnn_state)
+        return self._out(q), rnn_state
+
+    @torch.no_grad()
+    def step(self, observation, prev_action, prev_reward):
+        prev_action = self.distribution.to_onehot(prev_action)
+        obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
+        q, rnn_state = self.sampling_model(obs, pa, pr, self.prev_rnn_state)
+        action = self.distribution.sample(q, generator=self.sample_generator)
+        prev = self.prev_rnn_state
+        if prev is None:
+            prev = buffer_func(rnn_state, torch.zeros_like)
+        # [N,B,H] -> [B,N,H] for storage (r2d1_agent.py:37-40); a real copy, because the
+        # persistent state buffer is overwritten in place just below
+        prev_rnn_state = buffer_func(prev, lambda x: x.transpose(0, 1).clone(
+            memory_format=torch.contiguous_format))
+        agent_info = AgentInfo(q=q, prev_rnn_state=prev_rnn_state)
+        self.advance_rnn_state(rnn_state)
+        return self._out(AgentStep(action=action, agent_info=agent_info))
+
+    def target(self, observation, prev_action, prev_reward, init_rnn_state):
+        prev_action = self.distribution.to_onehot(prev_action)
+        obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
+        target_q, rnn_state = self.target_model(obs, pa, pr, init_rnn_state)
+        return self._out(target_q), rnn_state
+
+
+class R2d1Agent(RecurrentAgentMixin, R2d1AgentBase):
+    pass
+
+
+class AtariR2d1Agent(R2d1Agent):
+    def __init__(self, ModelCls=AtariR2d1Model, **kwargs):
+        super().__init__(ModelCls=ModelCls, **kwargs)
+
+    def make_env_to_model_kwargs(self, env_spaces):
+        return dict(image_shape=env_spaces.observation.shape,
+                    output_size=env_spaces.action.n)

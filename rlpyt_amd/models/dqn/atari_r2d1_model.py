@@ -1,0 +1,44 @@
+"""AtariR2d1Model: conv 32-64-64 -> FC 512 (ReLU) -> LSTM(512 + A + 1 -> 512) -> MLP / dueling head
+-> Q[A] (architecture, argument and parameter names of
+rlpyt/models/dqn/atari_r2d1_model.py:13-77, so state dicts interchange).
+
+On the device the uint8 frames are converted by ``rlpyt_obs_to_nhwc_f32`` (one kernel, no f32
+NCHW copy); the LSTM runs through torch's ``nn.LSTM`` (MIOpen RNN on ROCm) and always keeps the
+B dimension in the returned state ``RnnState(h, c)`` of shape ``[N, B, H]``."""
+import torch
+
+from ...utils.collections import namedarraytuple
+from ...utils.tensor import infer_leading_dims, restore_leading_dims
+from ..conv2d import Conv2dHeadModel
+from ..mlp import MlpModel
+from ..pg.atari_ff_model import prepare_image
+from .dueling import DuelingHeadModel
+
+RnnState = namedarraytuple("RnnState", ["h", "c"])
+
+
+class AtariR2d1Model(torch.nn.Module):
+    def __init__(self, image_shape, output_size, fc_size=512, lstm_size=512, head_size=512,
+                 dueling=False, use_maxpool=False, channels=None, kernel_sizes=None,
+                 strides=None, paddings=None):
+        super().__init__()
+        self.dueling = dueling
+        self.conv = Conv2dHeadModel(
+            image_shape=image_shape, channels=channels or [32, 64, 64],
+            kernel_sizes=kernel_sizes or [8, 4, 3], strides=strides or [4, 2, 1],
+            paddings=paddings or [0, 1, 1], use_maxpool=use_maxpool, hidden_sizes=fc_size)
+        self.lstm = torch.nn.LSTM(self.conv.output_size + output_size + 1, lstm_size)
+        self.head = (DuelingHeadModel(lstm_size, head_size, output_size) if dueling
+                     else MlpModel(lstm_size, head_size, output_size=output_size))
+
+    def forward(self, observation, prev_action, prev_reward, init_rnn_state):
+        """Leading dims [T,B], [B] or []; prev_action one-hot; returns (q, RnnState [N,B,H])."""
+        lead_dim, T, B, img_shape = infer_leading_dims(observation, 3)
+        conv_out = self.conv(prepare_image(observation, T * B, img_shape))
+        lstm_input = torch.cat([conv_out.reshape(T, B, -1),
+                                prev_action.reshape(T, B, -1).to(conv_out.dtype),
+                                prev_reward.reshape(T, B, 1).to(conv_out.dtype)], dim=2)
+        state = None if init_rnn_state is None else tuple(x.contiguous() for x in init_rnn_state)
+        lstm_out, (hn, cn) = self.lstm(lstm_input, state)
+        q = self.head(lstm_out.reshape(T * B, -1))
+        return restore_leading_dims(q, lead_dim, T, B), RnnState(h=hn, c=cn)

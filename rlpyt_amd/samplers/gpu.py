@@ -342,6 +342,10 @@ class GpuSampler(BaseSampler):
         r = np.asarray(r, dtype="float32")
         agent.reset()
         a_t, agent_info = agent.step(*torchify_buffer(AgentInputs(o, np.asarray(a), r)))
+        if "prev_rnn_state" in agent_info:   # drop the B dim of the example (buffer.py:73-75)
+            agent_info = agent_info._replace(
+                prev_rnn_state=_map(lambda x: x[0], agent_info.prev_rnn_state))
+        agent.reset()
         examples = dict(observation=o, reward=r, done=np.asarray(d, dtype=bool),
                         env_info=env_info, action=a_t, agent_info=agent_info)
         self.examples = examples
@@ -585,6 +589,12 @@ class GpuSampler(BaseSampler):
                 prev_reward = torch.where(dn, torch.zeros_like(prev_reward), prev_reward)
         else:
             prev_action = prev_reward = None
+        if self.agent.recurrent:
+            # one persistent [N, B_g, H] state per pipeline group; after a reset the env starts
+            # from a zero state (action_server.py:49-53)
+            self.agent.select_slot(G.idx)
+            if self.mid_batch_reset:
+                self.agent.reset_where(G.done_stage)
         if (G.u_all is not None and self.mid_batch_reset and self.fused_step
                 and isinstance(self._all_action, torch.Tensor)):
             # the agent runs the forward AND writes the step's rows (fused head kernel)
@@ -639,6 +649,9 @@ class GpuSampler(BaseSampler):
                 prev_reward = torch.where(dn, torch.zeros_like(prev_reward), prev_reward)
             s.agent.bootstrap_value[0, lo:hi] = self.agent.value(G.obs_stage, prev_action,
                                                                  prev_reward)
+        if self.agent.recurrent:     # end of batch: finished envs restart from a zero state
+            self.agent.select_slot(G.idx)   # (action_server.py:63-68)
+            self.agent.reset_where(G.done_stage)
 
     def _upload_special(self, G, nb, first):
         """Host-dependent part of the upload (frame-stacked envs only): full stacks for the

@@ -53,3 +53,52 @@ def test_dqn_end_to_end(prioritized, double):
     if prioritized:
         assert batch.is_weights.shape == (16,) and float(batch.is_weights.max()) <= 1.0 + 1e-6
     sampler.shutdown()
+
+
+@pytest.mark.parametrize("prioritized", [True, False])
+def test_r2d1_end_to_end(prioritized):
+    """BASELINE config #5 at test size: recurrent agent under the HBM sampler (LSTM state per
+    pipeline group, captured step graphs), sequence replay with stored RNN states and input
+    priorities, warm-up + training segments, fused R2D1 loss kernel."""
+    from rlpyt_amd.agents.dqn.r2d1_agent import AtariR2d1Agent
+    from rlpyt_amd.algos.dqn.r2d1 import R2D1
+    T, B = 8, 4
+    sampler = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=13), batch_T=T, batch_B=B,
+                         n_workers=2, mid_batch_reset=False, max_decorrelation_steps=0)
+    agent = AtariR2d1Agent(model_kwargs=dict(fc_size=64, lstm_size=32, head_size=32),
+                           eps_final=0.1)
+    algo = R2D1(batch_T=8, batch_B=6, warmup_T=8, store_rnn_state_interval=8,
+                min_steps_learn=5 * T * B, replay_size=T * B * 16, n_step_return=2,
+                target_update_interval=2, prioritized_replay=prioritized,
+                input_priorities=prioritized, learning_rate=1e-4)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    examples = sampler.initialize(agent, seed=2, bootstrap_value=False)
+    torch.cuda.set_device(0)
+    agent.to_device(0)
+    algo.initialize(agent=agent, n_itr=12, batch_spec=sampler.batch_spec,
+                    mid_batch_reset=sampler.mid_batch_reset, examples=examples)
+    losses, pris = [], []
+    for itr in range(10):
+        agent.sample_mode(itr)
+        samples, _ = sampler.obtain_samples(itr)
+        info = samples.agent.agent_info
+        assert info.prev_rnn_state.h.shape == (T, B, 1, 32) and info.q.shape == (T, B, 6)
+        # wait-reset: blank rows after done within a batch
+        done = samples.env.done
+        first = done.int().argmax(0)
+        for b in range(B):
+            if done[:, b].any():
+                f = int(first[b])
+                assert bool(done[f:, b].all()) and bool((samples.agent.action[f + 1:, b] == 0).all())
+        agent.train_mode(itr)
+        opt = algo.optimize_agent(itr, samples)
+        losses += list(opt.loss)
+        pris += list(opt.priority)
+    assert algo.update_counter == (10 - algo.min_itr_learn) * algo.updates_per_optimize > 0
+    assert len(losses) == algo.update_counter and np.all(np.isfinite(losses))
+    assert len(pris) == algo.update_counter * 6 and np.all(np.isfinite(pris)) and min(pris) >= 0
+    batch = algo.replay_buffer.sample_batch(6)
+    assert batch.all_observation.shape == (16 + 2, 6, 4, 104, 80) and batch.all_observation.is_cuda
+    assert batch.init_rnn_state.h.shape == (6, 1, 32)
+    sampler.shutdown()

@@ -255,3 +255,44 @@ def test_sync_rl_two_ranks_gloo():
     assert w0 == w1 == 2 and s1 == s0 + 100
     assert torch.allclose(p0, p1, atol=0, rtol=0)
     assert not torch.equal(o0, o1)
+
+
+def test_sampler_recurrent_agent_state_bookkeeping():
+    """Recurrent agent under the sampler (CPU): the stored ``prev_rnn_state[t]`` is the LSTM state
+    the agent entered step t with, so re-running the model over a column's observation sequence
+    from ``prev_rnn_state[0]`` reproduces the recorded Q-values, across batches and through
+    env resets (state zeroed where the previous step was done)."""
+    from rlpyt_amd.agents.dqn.r2d1_agent import AtariR2d1Agent
+    T, B = 5, 3
+    s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=7), batch_T=T, batch_B=B,
+                   n_workers=0, max_decorrelation_steps=0)
+    a = AtariR2d1Agent(model_kwargs=dict(fc_size=32, lstm_size=8, head_size=16), eps_final=0.5)
+    torch.manual_seed(0)
+    s.initialize(a, seed=3, bootstrap_value=False)
+    carry = None
+    for itr in range(4):
+        a.sample_mode(itr)
+        smp, _ = s.obtain_samples(itr)
+        info = smp.agent.agent_info
+        assert info.prev_rnn_state.h.shape == (T, B, 1, 8) and info.q.shape == (T, B, 6)
+        onehot = torch.nn.functional.one_hot(smp.agent.prev_action, 6).float()
+        done_prev = torch.cat([torch.zeros(1, B, dtype=torch.bool) if carry is None else carry[None],
+                               smp.env.done[:-1]])
+        with torch.no_grad():
+            for b in range(B):
+                h = info.prev_rnn_state.h[0, b].unsqueeze(1)      # [N,1,H]
+                c = info.prev_rnn_state.c[0, b].unsqueeze(1)
+                for t in range(T):
+                    if done_prev[t, b]:
+                        assert float(info.prev_rnn_state.h[t, b].abs().max()) == 0.
+                        h, c = torch.zeros_like(h), torch.zeros_like(c)
+                    np.testing.assert_allclose(info.prev_rnn_state.h[t, b].numpy(),
+                                               h[:, 0].numpy(), rtol=1e-5, atol=1e-6)
+                    # null prev_action after a reset = action index 0 (action_server.py:50)
+                    pa = onehot.new_tensor([1., 0, 0, 0, 0, 0]) if done_prev[t, b] else onehot[t, b]
+                    pr = torch.zeros(()) if done_prev[t, b] else smp.env.prev_reward[t, b]
+                    q, (h, c) = a.model(smp.env.observation[t, b], pa, pr, (h, c))
+                    np.testing.assert_allclose(q.numpy(), info.q[t, b].numpy(), rtol=1e-4,
+                                               atol=1e-5)
+        carry = smp.env.done[-1].clone()
+    s.shutdown()
