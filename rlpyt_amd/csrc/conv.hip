@@ -67,9 +67,14 @@ __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
   __shared__ __attribute__((aligned(16))) uint8_t img[IMG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
+  // the 16 KB of weights pass through the (not yet used) image buffer: coalesced 16-byte global
+  // loads instead of a 64-way gather per lane -- the gather dominated small sampling launches
+  for (int i = tid; i < C1 * 256 / 4; i += C1F_THREADS)
+    reinterpret_cast<uint4*>(img)[i] = reinterpret_cast<const uint4*>(w1)[i];
+  __syncthreads();
   float wa[64];
 #pragma unroll
-  for (int s = 0; s < 64; ++s) wa[s] = w1[j * 256 + 4 * s + kq];
+  for (int s = 0; s < 64; ++s) wa[s] = reinterpret_cast<const float*>(img)[j * 256 + 4 * s + kq];
   float bias[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias[r] = b1[4 * kq + r];
@@ -149,15 +154,20 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
   const int ct = wave & 1, t0 = wave >> 1;  // co tile; position tiles t0 + 2*part + 2*SPLIT*i
+  // the 32 KB of weights pass through the (not yet used) activation plane: coalesced loads
+  for (int i = tid; i < C2 * 256 / 4; i += 256)
+    reinterpret_cast<f32x4*>(pad)[i] = reinterpret_cast<const f32x4*>(w2)[i];
+  __syncthreads();
   float wa[64];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp)
-      wa[kk * 4 + sp] = w2[(ct * 16 + j) * 256 + (4 * kq + sp) * 16 + kk];
+      wa[kk * 4 + sp] = pad[(ct * 16 + j) * 256 + (4 * kq + sp) * 16 + kk];
   float bias[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias[r] = b2[ct * 16 + 4 * kq + r];
+  __syncthreads();
   for (int i = tid; i < PPIX * PS_F; i += 256) pad[i] = 0.f;  // border stays zero
 
   for (int64_t mm = blockIdx.x; mm < M * SPLIT; mm += gridDim.x) {
@@ -669,8 +679,8 @@ extern "C" int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat
   RL_CHECK_ARG(M >= 0 && T > 0 && B > 0, RLPYT_EINVAL, "rlpyt_atari_conv1_fwd_f32: bad sizes");
   if (M == 0) return RLPYT_OK;
   RL_CHECK_ARG(obs && w1 && b1 && y1, RLPYT_EINVAL, "rlpyt_atari_conv1_fwd_f32: null pointer");
-  RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(y1), RLPYT_ESHAPE,
-               "rlpyt_atari_conv1_fwd_f32: obs / y1 must be 16-byte aligned");
+  RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(y1) && RL_ALIGNED16(w1), RLPYT_ESHAPE,
+               "rlpyt_atari_conv1_fwd_f32: obs / y1 / w1 must be 16-byte aligned");
   int cus = grid_for(1 << 30, 1);
   const int split = (M * 2 <= cus) ? 4 : (M <= cus ? 2 : 1);  // M <= 128: 4, M <= 256: 2
   hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for(M * split, 4)), dim3(C1F_THREADS), 0,
@@ -684,7 +694,8 @@ extern "C" int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float
   RL_CHECK_ARG(M >= 0, RLPYT_EINVAL, "rlpyt_atari_conv2_fwd_f32: bad sizes");
   if (M == 0) return RLPYT_OK;
   RL_CHECK_ARG(y1 && w2 && b2 && y2, RLPYT_EINVAL, "rlpyt_atari_conv2_fwd_f32: null pointer");
-  RL_CHECK_ARG(RL_ALIGNED16(y1), RLPYT_ESHAPE, "rlpyt_atari_conv2_fwd_f32: y1 must be 16-byte aligned");
+  RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(w2), RLPYT_ESHAPE,
+               "rlpyt_atari_conv2_fwd_f32: y1 / w2 must be 16-byte aligned");
   if (M <= grid_for(1 << 30, 1))   // small (sampling) batch: two workgroups per image
     hipLaunchKernelGGL((conv2_fwd_kernel<2>), dim3(grid_for(2 * M, 3)), dim3(256), 0,
                        (hipStream_t)stream, y1, w2, b2, y2, M);

@@ -236,7 +236,25 @@ __global__ __launch_bounds__(256) void fc_small_kernel(const float* __restrict__
   fc_f32x4 acc[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = fc_f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k = k0; k < k1; k += 16) {
+  constexpr int U = 3;   // K-groups of 16 fetched together: loads of a slab are independent
+  int k = k0;
+  for (; k + 16 * U <= k1; k += 16 * U) {
+    fc_f32x4 a[U], b[U][MT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = *reinterpret_cast<const fc_f32x4*>(wrow + k + 16 * u);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) b[u][t] = *reinterpret_cast<const fc_f32x4*>(xrow[t] + k + 16 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][sp], b[u][t][sp], acc[t], 0, 0, 0);
+  }
+  for (; k < k1; k += 16) {
     const fc_f32x4 a = *reinterpret_cast<const fc_f32x4*>(wrow + k);
     fc_f32x4 b[MT];
 #pragma unroll
@@ -343,8 +361,15 @@ __global__ __launch_bounds__(256) void pg_sample_head_kernel(
 #pragma unroll
   for (int i = 0; i < KI; ++i) {
     const int k = lane + 64 * i;
-    float v = partial[row * K + k];   // same summation order as fc_small_finish_kernel
-    for (int sidx = 1; sidx < ksplit; ++sidx) v += partial[((int64_t)sidx * n + row) * K + k];
+    // all split-K slices are fetched before the first add (independent loads); the adds keep the
+    // summation order of fc_small_finish_kernel (x + 0 is exact for the unused slices)
+    float pv[kFcKSplit];
+#pragma unroll
+    for (int sidx = 0; sidx < kFcKSplit; ++sidx)
+      pv[sidx] = sidx < ksplit ? partial[((int64_t)sidx * n + row) * K + k] : 0.f;
+    float v = pv[0];
+#pragma unroll
+    for (int sidx = 1; sidx < kFcKSplit; ++sidx) v += pv[sidx];
     hv[i] = fmaxf(v + fc_bias[k], 0.f);
   }
   float acc[AMAX + 1];
@@ -408,8 +433,8 @@ extern "C" int rlpyt_pg_sample_head_f32(const float* partial, int ksplit, const 
   RL_CHECK_ARG(partial && fc_bias && w_pi && b_pi && w_v && b_v && uniforms && t_dev && prob_rows &&
                    value_rows && action_rows && action_out,
                RLPYT_EINVAL, "rlpyt_pg_sample_head_f32: null pointer");
-  RL_CHECK_ARG(n > 0 && ksplit > 0 && A > 0 && A <= 8 && (K == 512 || K == 256) && lo >= 0 &&
-                   lo + n <= B,
+  RL_CHECK_ARG(n > 0 && ksplit > 0 && ksplit <= rlpyt::kFcKSplit && A > 0 && A <= 8 &&
+                   (K == 512 || K == 256) && lo >= 0 && lo + n <= B,
                RLPYT_ESHAPE, "rlpyt_pg_sample_head_f32: need 0<A<=8, K in {256,512}, lo+n<=B");
   const dim3 grid((unsigned)ceil_div(n, 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
