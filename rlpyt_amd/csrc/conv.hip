@@ -517,7 +517,33 @@ __global__ __launch_bounds__(B2_THREADS, 4) void conv2_bwd_kernel(
       }
     }
   }
-  float* out = partial + ((int64_t)blockIdx.x * 2 + half) * PART2;
+  // the position-parity halves of the workgroup meet in LDS (pad is free now): one partial row
+  // per workgroup leaves for the reduction kernel
+  __syncthreads();
+  {
+    float* red = pad + (q * 64 + lane) * 35;   // 34 floats per lane, odd stride
+    if (half == 1) {
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(kx * 2 + ct) * 4 + r] = acc[kx][ct][r];
+      red[32] = bsum[0];
+      red[33] = bsum[1];
+    }
+    __syncthreads();
+    if (half == 1) return;
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[kx][ct][r] += red[(kx * 2 + ct) * 4 + r];
+    bsum[0] += red[32];
+    bsum[1] += red[33];
+  }
+  float* out = partial + (int64_t)blockIdx.x * PART2;
 #pragma unroll
   for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
@@ -612,9 +638,27 @@ __global__ __launch_bounds__(W1_THREADS) void conv1_wgrad_kernel(
       }
     }
   }
-  // D[row = co = 4*kq + r][col = j] -> dW1[co][c][ky = 2t + (j>>3)][kx = j&7]; the two
-  // position-parity halves of a workgroup write separate partial rows
-  float* out = partial + ((int64_t)blockIdx.x * 2 + half) * PART1;
+  // the two position-parity halves of the workgroup meet in LDS (dl is free now)
+  __syncthreads();
+  {
+    float* red = dl + (c * 64 + lane) * 17;   // 17 floats per lane
+    if (half == 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[t * 4 + r] = acc[t][r];
+      red[16] = bsum;
+    }
+    __syncthreads();
+    if (half == 1) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] += red[t * 4 + r];
+    bsum += red[16];
+  }
+  // D[row = co = 4*kq + r][col = j] -> dW1[co][c][ky = 2t + (j>>3)][kx = j&7]
+  float* out = partial + (int64_t)blockIdx.x * PART1;
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -664,7 +708,7 @@ int grid_for(int64_t M, int per_cu) {
 }
 
 constexpr int kWgradGrid = 512;  // persistent workgroups of the weight-gradient kernels
-constexpr int kPartialRows = 2 * kWgradGrid;  // the 8-wave kernels write two partial rows each
+constexpr int kPartialRows = kWgradGrid;  // one partial row per persistent workgroup
 
 }  // namespace
 }  // namespace rlpyt
@@ -756,7 +800,7 @@ extern "C" int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* fl
                      workspace, M, scale);
   RL_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART1 + 63) / 64), dim3(256), 0, s, workspace,
-                     2 * g, PART1, dw1, DW1_N, db1);
+                     g, PART1, dw1, DW1_N, db1);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
@@ -776,7 +820,7 @@ extern "C" int rlpyt_atari_conv2_bwd_f32(const float* g2, const float* y2, const
                      workspace, M);
   RL_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(256), 0, s, workspace,
-                     2 * g, PART2, dw2, DW2_N, db2);
+                     g, PART2, dw2, DW2_N, db2);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
