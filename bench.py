@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--batch-T", type=int, default=128)
     ap.add_argument("--batch-B", type=int, default=256)
     ap.add_argument("--workers", type=int, default=-1, help="env worker processes per rank "
-                    "(-1: host cores / ranks, capped at B/8)")
+                    "(-1: host cores / ranks, capped at B/10)")
     ap.add_argument("--env-cost-us", type=float, default=0., help="declared extra host cost "
                     "per env step (busy wait) to emulate an ALE-like emulator")
     ap.add_argument("--groups", type=int, default=-1, help="sampler pipeline groups (-1: auto)")
@@ -85,9 +85,9 @@ def main():
     ncpu = os.cpu_count() or 8
     workers = args.workers
     if workers < 0:
-        # 8 envs per worker (4 per pipeline group): waking more workers per step costs the
-        # master more than their extra parallelism returns (measured 16/32/48/64 -> 32 best)
-        workers = max(min((ncpu - 2 * world) // world, B // 8), 0)
+        # ~10 envs per worker: waking more workers per step costs the master more than their
+        # extra parallelism returns (measured 12..64 workers at B=256: 20-32 best, flat)
+        workers = max(min((ncpu - 2 * world) // world, B // 10), 0)
     env_kwargs = dict(step_cost_us=args.env_cost_us)
     n_itr_total = args.warmup + args.steps
 

@@ -13,7 +13,7 @@ rlpyt/samplers/parallel/{base,worker}.py), re-designed for a 288 GB device:
   counter, so the same graph serves every time step), (ii) runs the batched
   action-selection forward, (iii) samples the actions on the device and (iv) writes
   action / agent_info rows; only ``action[B]`` travels back to the host;
-* the environments are split into ``n_groups`` pipeline groups (default 2 with workers):
+* the environments are split into ``n_groups`` pipeline groups (default 2-3 with workers):
   while the device serves group g, the host cores step the environments of the other
   group, so per time step the wall time is max(device, host) instead of their sum.
   Groups are column ranges of the same ``[T, B]`` batch -- every column is still one
@@ -289,8 +289,8 @@ class GpuSampler(BaseSampler):
     """See module docstring.  ``mid_batch_reset=True`` behaves like GpuResetCollector,
     ``False`` like GpuWaitResetCollector.
 
-    ``n_groups``: pipeline groups (None: 2 when worker processes are used and B allows it,
-    else 1).  ``use_graph``: capture the per-step device work in a hipGraph (GPU only)."""
+    ``n_groups``: pipeline groups (None: 3 for B >= 192 with worker processes, 2 for smaller
+    batches when B allows it, else 1).  ``use_graph``: capture the per-step device work in a hipGraph (GPU only)."""
 
     GRAPH_WARMUP_CALLS = 3   # eager calls per group before capture (MIOpen/hipBLASLt find)
 
@@ -309,7 +309,11 @@ class GpuSampler(BaseSampler):
         self._native = None
         B = self.batch_spec.B
         if n_groups is None:
+            # measured at B=256 on the bench host (several runs each): 1 group 405 K SPS, 2 groups
+            # 472-476 K, 3 groups 477-501 K, 4 groups 452-468 K
             n_groups = 2 if (self.n_workers > 0 and B >= 2 * max(self.n_workers, 1)) else 1
+            if n_groups == 2 and B >= 192:
+                n_groups = 3
         self.n_groups = max(1, min(int(n_groups), B))
         self._pinned_ptrs = []
         self.workers = []
