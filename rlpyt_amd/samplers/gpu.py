@@ -73,6 +73,17 @@ class EnvRunner:
         # batch starts (collectors.py:65-68,103-104)
         self.temp_observation = None if mid_batch_reset else [None] * len(envs)
         self.frames = "frame" in step_np._fields
+        # set by the sampler once it knows that the master uploads only newest frames: the full
+        # observation is then written to the step buffer only when the master will read it (last
+        # step of a batch, fresh stacks) -- a 33 KB copy less per env step on the host cores,
+        # whose time is what bounds the rollout once the device side is fast
+        self.lazy_obs = None          # object with a boolean ``.value`` (fork-shared) or None
+        self.batch_T = None
+        self.last_obs = [None] * len(envs)
+        info_leaves = buffer_leaves(env_info_np) if env_info_np is not None else None
+        # flat namedtuple env_info (the usual case): one array per field, written directly
+        self._info_arrays = info_leaves if (
+            info_leaves and not any(isinstance(v, tuple) for v in env_info_np)) else None
 
     def start(self, max_decorrelation_steps=0):
         """Reset (and optionally decorrelate with random actions,
@@ -97,6 +108,7 @@ class EnvRunner:
             step.action[b] = a
             step.reward[b] = r
             step.done[b] = False
+            self.last_obs[b] = o
 
     def begin_batch(self):
         """Between batches under wait-reset: reinstate held observations, reset finished
@@ -118,19 +130,26 @@ class EnvRunner:
         """Apply ``step.action`` to every env; write obs/reward/done for the next step."""
         step = self.step
         mbr = self.mid_batch_reset
+        obs_buf, act_buf, rew_buf, done_buf = step.observation, step.action, step.reward, step.done
+        frames = self.frames
+        if frames:
+            frame_buf, reset_buf = step.frame, step.reset
+        lazy = (frames and self.lazy_obs is not None and self.lazy_obs.value
+                and self.batch_T is not None and t != self.batch_T - 1)
+        info_arrays, last_obs, traj_infos = self._info_arrays, self.last_obs, self.traj_infos
         for b, env in enumerate(self.envs):
-            if not mbr and step.done[b]:
+            if not mbr and done_buf[b]:
                 # wait-reset: a finished env idles with done=True and blank reward
                 # (collectors.py:85-91); the master blanks its action / agent_info rows.
-                step.reward[b] = 0
+                rew_buf[b] = 0
                 continue
-            a = step.action[b]
+            a = act_buf[b]
             o, r, d, info = env.step(a)
-            self.traj_infos[b].step(step.observation[b], a, r, d, None, info)
+            traj_infos[b].step(last_obs[b], a, r, d, None, info)
             fresh = False     # True: the frame stack does not continue the previous one
             if getattr(info, "traj_done", d):
-                completed.append(self.traj_infos[b].terminate(o))
-                self.traj_infos[b] = self.TrajInfoCls()
+                completed.append(traj_infos[b].terminate(o))
+                traj_infos[b] = self.TrajInfoCls()
                 if mbr:
                     o = env.reset()
                     fresh = True
@@ -140,14 +159,20 @@ class EnvRunner:
                 self.temp_observation[b] = o
                 o = 0
                 fresh = True
-            if self.frames:
-                step.frame[b] = o[-1] if not isinstance(o, int) else 0
-                step.reset[b] = fresh
-            step.observation[b] = o
-            step.reward[b] = r
-            step.done[b] = d
-            if self.env_info is not None and info:
-                self.env_info[t, b] = info
+            last_obs[b] = o
+            if frames:
+                frame_buf[b] = o[-1] if not isinstance(o, int) else 0
+                reset_buf[b] = fresh
+            if fresh or not lazy:
+                obs_buf[b] = o
+            rew_buf[b] = r
+            done_buf[b] = d
+            if info and self.env_info is not None:
+                if info_arrays is not None:
+                    for arr, v in zip(info_arrays, info):
+                        arr[t, b] = v
+                else:
+                    self.env_info[t, b] = info
 
 
 def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus):
@@ -366,6 +391,8 @@ class GpuSampler(BaseSampler):
             and (o[0].size % 16 == 0))
         gb = np.linspace(0, B, self.n_groups + 1).astype(int)
         n_w = max(self.n_workers, 1)
+        # fork-shared switch "the master uploads newest frames only" (set in _ensure_device)
+        self._lazy_obs = mp.get_context("fork").RawValue(ctypes.c_bool, False)
         self.split_workers = bool(self._split_workers and self.n_workers >= 2 * self.n_groups
                                   and self.n_groups > 1)
         self.groups = []
@@ -402,10 +429,12 @@ class GpuSampler(BaseSampler):
             wb = np.linspace(0, Bg, len(ws) + 1).astype(int)
             for k, w in enumerate(ws):
                 l, h = int(wb[k]), int(wb[k + 1])
-                runners[w].append((g, EnvRunner(
+                rn = EnvRunner(
                     envs[lo + l:lo + h], step_np[l:h],
                     None if self.env_info_np is None else self.env_info_np[:, lo + l:lo + h],
-                    self.TrajInfoCls, self.mid_batch_reset)))
+                    self.TrajInfoCls, self.mid_batch_reset)
+                rn.lazy_obs, rn.batch_T = self._lazy_obs, T
+                runners[w].append((g, rn))
             G.n_workers = len(ws)
         self.runners = runners
         if self.n_workers > 0:
@@ -545,6 +574,7 @@ class GpuSampler(BaseSampler):
                     else:
                         logger.log(f"hipHostRegister failed ({_lib.last_error()}); "
                                    "falling back to pageable copies.")
+        self._lazy_obs.value = bool(all(G.dedup for G in self.groups))
         self._device_ready = True
 
     # ------------------------------------------------------------------ per-step device work
