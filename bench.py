@@ -61,6 +61,12 @@ def parse():
     ap.add_argument("--cpu-baseline-B", type=int, default=0,
                     help="B of the bounded CPU sample (0: sized for ~15 s of CPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--same-gpu", action="store_true",
+                    help="debug: every rank uses cuda:0 (with --backend gloo) to exercise the "
+                         "N>1 code path on a single-GPU box")
+    ap.add_argument("--check-params", action="store_true",
+                    help="debug: assert that all ranks hold identical parameters at the end")
     return ap.parse_args()
 
 
@@ -105,9 +111,11 @@ def main():
                linear_lr_schedule=True, normalize_advantage=False)
     examples = sampler.initialize(agent, seed=seed + 1, bootstrap_value=True, rank=rank,
                                   world_size=world)
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     agent.to_device(local_rank)
     if world > 1:
         agent.data_parallel()
@@ -153,6 +161,14 @@ def main():
     elapsed = el.item()
     ksum = ktimer.summary() if not args.no_kernel_timing else {}
     sampler.shutdown()
+    if args.check_params and world > 1:
+        flat = torch.cat([p.detach().reshape(-1) for p in agent.parameters()])
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "ranks diverged: DDP gradient averaging is broken"
+        if rank == 0:
+            print("check-params: all ranks hold bit-identical parameters", file=sys.stderr)
 
     if rank == 0:
         steps_total = T * B * world * args.steps

@@ -727,7 +727,14 @@ class GpuSampler(BaseSampler):
         with self._on_stream(G):
             self._upload_special(G, cuda, first)
             if cuda and self.use_graph and G.graph is None and G.calls >= self.GRAPH_WARMUP_CALLS:
-                G.graph = self._capture(G)
+                try:
+                    G.graph = self._capture(G)
+                except Exception as e:  # noqa: BLE001  (keep sampling: eager step is correct)
+                    logger.log(f"GpuSampler: hipGraph capture failed ({type(e).__name__}: {e}); "
+                               "continuing with eager per-step launches.")
+                    self.use_graph = False
+                    G.graph = None
+                    torch.cuda.synchronize()
             self._upload_steady(G, cuda)
             if G.graph is not None:
                 G.graph.replay()
@@ -793,6 +800,16 @@ class GpuSampler(BaseSampler):
         logger.log("GpuSampler: time-step loop handed to rlpyt_sampler_serve (native).")
         return True
 
+    def _native_ready_safe(self):
+        try:
+            return self._native_ready()
+        except Exception as e:  # noqa: BLE001
+            logger.log(f"GpuSampler: native step loop unavailable ({type(e).__name__}: {e}); "
+                       "using the Python loop.")
+            self.native_loop = False
+            self._native = None
+            return False
+
     def _serve_native(self, T):
         from .. import _lib
         arr = self._native
@@ -822,7 +839,9 @@ class GpuSampler(BaseSampler):
             graph.register_generator_state(G.gen)
         # capture on the group's OWN stream: library workspaces (hipBLASLt split-K buffers)
         # are keyed by stream, and two groups' graphs replay concurrently
-        with torch.cuda.graph(graph, stream=G.stream):
+        # thread_local: helper threads of this process (e.g. the RCCL watchdog polling its events
+        # under DistributedDataParallel) must not invalidate the capture
+        with torch.cuda.graph(graph, stream=G.stream, capture_error_mode="thread_local"):
             self._step_body(G, capturing=True)
         if G.post_entries is not None:
             G.post_commit.set_entries(G.post_entries)
@@ -857,7 +876,7 @@ class GpuSampler(BaseSampler):
                 _map(lambda d, s: d[0, G.lo:G.hi].copy_(s, non_blocking=True),
                      self._all_action, G.step_pyt.action)
         tp1 = time.perf_counter()
-        if par and cuda and self.native_loop and self._native_ready():
+        if par and cuda and self.native_loop and self._native_ready_safe():
             self._serve_native(T)
         else:
             for t in range(T):
