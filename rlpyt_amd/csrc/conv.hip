@@ -593,15 +593,43 @@ __global__ __launch_bounds__(W1_THREADS) void conv1_wgrad_kernel(
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
 
+  // software pipeline over images: the next image (33 KB) and its dy1 (30 KB) are fetched into
+  // registers while the current one is being contracted, so the staging phase between the two
+  // barriers only moves registers to LDS and the global-load latency hides behind the MFMAs
+  constexpr int NPI = (IMG / 16 + W1_THREADS - 1) / W1_THREADS;   // 5 uint4 per thread
+  constexpr int NPD = (Y1 / 4 + W1_THREADS - 1) / W1_THREADS;     // 4 float4 per thread
+  uint4 pimg[NPI];
+  f32x4 pdy[NPD];
+#define RLPYT_W1_PREFETCH(mi)                                                                  \
+  {                                                                                            \
+    const uint4* __restrict__ src_ =                                                           \
+        reinterpret_cast<const uint4*>(obs + image_row(flat_idx, (mi), T, B) * IMG);           \
+    const f32x4* __restrict__ dsrc_ = reinterpret_cast<const f32x4*>(dy1 + (mi) * Y1);         \
+    _Pragma("unroll") for (int k = 0; k < NPI; ++k) {                                          \
+      const int i = tid + k * W1_THREADS;                                                      \
+      pimg[k] = i < IMG / 16 ? src_[i] : uint4{0u, 0u, 0u, 0u};                                \
+    }                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < NPD; ++k) {                                          \
+      const int i = tid + k * W1_THREADS;                                                      \
+      pdy[k] = i < Y1 / 4 ? dsrc_[i] : f32x4{0.f, 0.f, 0.f, 0.f};                              \
+    }                                                                                          \
+  }
+  if ((int64_t)blockIdx.x < M) RLPYT_W1_PREFETCH((int64_t)blockIdx.x)
+
   for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
-    const uint4* __restrict__ src =
-        reinterpret_cast<const uint4*>(obs + image_row(flat_idx, m, T, B) * IMG);
-    const f32x4* __restrict__ dsrc = reinterpret_cast<const f32x4*>(dy1 + m * Y1);
     __syncthreads();
-    for (int i = tid; i < IMG / 16; i += W1_THREADS) reinterpret_cast<uint4*>(img)[i] = src[i];
-    for (int i = tid; i < Y1 / 4; i += W1_THREADS)
-      *reinterpret_cast<f32x4*>(dl + (i >> 2) * DS_1 + 4 * (i & 3)) = dsrc[i];
+#pragma unroll
+    for (int k = 0; k < NPI; ++k) {
+      const int i = tid + k * W1_THREADS;
+      if (i < IMG / 16) reinterpret_cast<uint4*>(img)[i] = pimg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NPD; ++k) {
+      const int i = tid + k * W1_THREADS;
+      if (i < Y1 / 4) *reinterpret_cast<f32x4*>(dl + (i >> 2) * DS_1 + 4 * (i & 3)) = pdy[k];
+    }
     __syncthreads();
+    if (m + gridDim.x < M) RLPYT_W1_PREFETCH(m + gridDim.x)
     // the A value and the patch origin of a position group are fetched one group ahead, so the
     // image-byte reads of a group do not wait on a dependent LDS round trip
     float a_nx[4];
