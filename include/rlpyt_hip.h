@@ -48,6 +48,10 @@ int rlpyt_hip_device_info(char* name, int cap);
  * asynchronous H2D / D2H copies.  Host pointers; synchronous. */
 int rlpyt_host_register(void* host_ptr, int64_t bytes);
 int rlpyt_host_unregister(void* host_ptr);
+/* Device-side address of a range pinned with rlpyt_host_register (mapped into the device's
+ * address space): kernels may read the workers' newest frames and write the sampled actions
+ * in place -- no staging copy, no DMA descriptor latency on the per-step critical path. */
+int rlpyt_host_device_pointer(void* host_ptr, void** dev_ptr);
 
 /* Step hand-off between the sampler master and its forked env workers: replaces the
  * 2 x n_workers semaphores per time step of rlpyt/samplers/parallel/gpu/action_server.py:44-58

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "rlpyt_hip_device_info": (c_int, [c_char_p, c_int]),
     "rlpyt_host_register": (c_int, [_p, c_int64]),
     "rlpyt_host_unregister": (c_int, [_p]),
+    "rlpyt_host_device_pointer": (c_int, [_p, POINTER(c_void_p)]),
     "rlpyt_seq_wait": (c_int, [_p, c_uint32, c_int, c_int]),
     "rlpyt_seq_post": (c_int, [_p, c_uint32]),
     "rlpyt_seq_arrive": (c_int, [_p, c_uint32]),
@@ -177,6 +178,24 @@ def ptr(t):
 
 def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _DevView:
+    """Minimal __cuda_array_interface__ carrier: lets torch view a raw device address."""
+
+    def __init__(self, ptr_, shape, typestr):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr,
+                                             data=(int(ptr_), False), version=2, strides=None)
+
+
+def host_mapped_tensor(arr, device):
+    """Device tensor aliasing a page-locked (``rlpyt_host_register``-ed) numpy array: kernels
+    read / write the host buffer in place over PCIe."""
+    dptr = c_void_p()
+    check(lib.rlpyt_host_device_pointer(c_void_p(arr.ctypes.data), ctypes.byref(dptr)),
+          "rlpyt_host_device_pointer")
+    assert arr.flags["C_CONTIGUOUS"]
+    return torch.as_tensor(_DevView(dptr.value, arr.shape, arr.dtype.str), device=device)
 
 
 def device_info():

@@ -36,7 +36,14 @@ extern "C" int rlpyt_hip_device_info(char* name, int cap) {
 
 extern "C" int rlpyt_host_register(void* host_ptr, int64_t bytes) {
   RL_CHECK_ARG(host_ptr != nullptr && bytes > 0, RLPYT_EINVAL, "rlpyt_host_register: bad range");
-  RL_HIP(hipHostRegister(host_ptr, (size_t)bytes, hipHostRegisterDefault));
+  RL_HIP(hipHostRegister(host_ptr, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_host_device_pointer(void* host_ptr, void** dev_ptr) {
+  RL_CHECK_ARG(host_ptr != nullptr && dev_ptr != nullptr, RLPYT_EINVAL,
+               "rlpyt_host_device_pointer: null pointer");
+  RL_HIP(hipHostGetDevicePointer(dev_ptr, host_ptr, 0));
   return RLPYT_OK;
 }
 

@@ -238,3 +238,33 @@ def test_fused_step_matches_unfused_step():
     for x, y in zip(a, b):
         for u, v in zip(x, y):
             assert torch.equal(u, v)
+
+
+def test_zero_copy_step_buffer_matches_dma():
+    """Kernels reading the newest frames / writing the actions in place in the page-locked step
+    buffer (zero-copy) give exactly the batches of the DMA path."""
+    def run(zc):
+        s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=7), batch_T=6, batch_B=8,
+                       n_workers=2, n_groups=2, zero_copy=zc, max_decorrelation_steps=0)
+        a = AtariFfAgent()
+        torch.manual_seed(41)
+        np.random.seed(41)
+        s.initialize(a, seed=9, bootstrap_value=True)
+        torch.cuda.set_device(0)
+        a.to_device(0)
+        torch.manual_seed(42)
+        out = []
+        for itr in range(5):
+            smp, _ = s.obtain_samples(itr)
+            torch.cuda.synchronize()
+            out.append([x.clone() for x in (smp.env.observation, smp.agent.action,
+                                            smp.env.reward, smp.env.done,
+                                            smp.agent.agent_info.dist_info.prob,
+                                            smp.agent.bootstrap_value)])
+        assert all(G.zc == zc for G in s.groups)
+        s.shutdown()
+        return out
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
