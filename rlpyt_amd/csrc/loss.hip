@@ -341,7 +341,10 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
   for (int i = 0; i < KI; ++i) {
 #pragma unroll
     for (int a = 0; a < kHeadAMax; ++a) {
-      wp[a][i] = a < A ? w_pi[a * K + lane + 64 * i] : 0.f;
+      // unconditional clamped load + select: predicated loads compile to one branch and one
+      // s_waitcnt vmcnt(0) each, i.e. ~60 serialized L2 round trips per wave
+      const float wl = w_pi[min(a, A - 1) * K + lane + 64 * i];
+      wp[a][i] = a < A ? wl : 0.f;
       gw[a][i] = 0.f;
     }
     wv[i] = w_v[lane + 64 * i];
@@ -350,7 +353,8 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
   float bp[kHeadAMax], gb[kHeadAMax];
 #pragma unroll
   for (int a = 0; a < kHeadAMax; ++a) {
-    bp[a] = a < A ? b_pi[a] : 0.f;
+    const float bl = b_pi[min(a, A - 1)];
+    bp[a] = a < A ? bl : 0.f;
     gb[a] = 0.f;
   }
   const float bv = b_v[0];

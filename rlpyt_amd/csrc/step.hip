@@ -46,12 +46,15 @@ __global__ __launch_bounds__(256) void categorical_head_kernel(
   float acc[AMAX + 1];
 #pragma unroll
   for (int a = 0; a <= AMAX; ++a) acc[a] = 0.f;
+  const float* __restrict__ wv_ = w_v != nullptr ? w_v : w_pi;   // always a valid address
+  const float vscale = w_v != nullptr ? 1.f : 0.f;
   for (int k = lane; k < K; k += 64) {
     const float x = hr[k];
+    // unconditional clamped loads (a >= A re-reads row A-1, its result is ignored below):
+    // predicated loads would serialize into one L2 round trip each
 #pragma unroll
-    for (int a = 0; a < AMAX; ++a)
-      if (a < A) acc[a] = fmaf(x, w_pi[a * K + k], acc[a]);
-    if (w_v != nullptr) acc[AMAX] = fmaf(x, w_v[k], acc[AMAX]);
+    for (int a = 0; a < AMAX; ++a) acc[a] = fmaf(x, w_pi[min(a, A - 1) * K + k], acc[a]);
+    acc[AMAX] = fmaf(x, wv_[k] * vscale, acc[AMAX]);
   }
 #pragma unroll
   for (int a = 0; a <= AMAX; ++a) acc[a] = wave_sum(acc[a]);
@@ -357,31 +360,46 @@ __global__ __launch_bounds__(256) void pg_sample_head_kernel(
   const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= n) return;
   const int64_t t = *t_dev;
+  // Every load below is unconditional (indices clamped, unused values masked afterwards): with
+  // predicated loads the compiler emitted a branch and an s_waitcnt vmcnt(0) per load, i.e. ~60
+  // serialized L2 round trips (20 us for this kernel); now they are all in flight together.
   float hv[KI];
 #pragma unroll
   for (int i = 0; i < KI; ++i) {
     const int k = lane + 64 * i;
-    // all split-K slices are fetched before the first add (independent loads); the adds keep the
-    // summation order of fc_small_finish_kernel (x + 0 is exact for the unused slices)
     float pv[kFcKSplit];
 #pragma unroll
-    for (int sidx = 0; sidx < kFcKSplit; ++sidx)
-      pv[sidx] = sidx < ksplit ? partial[((int64_t)sidx * n + row) * K + k] : 0.f;
+    for (int sidx = 0; sidx < kFcKSplit; ++sidx) {
+      const int ss = min(sidx, ksplit - 1);
+      pv[sidx] = partial[((int64_t)ss * n + row) * K + k];
+    }
+    // the adds keep the summation order of fc_small_finish_kernel (x + 0 is exact)
     float v = pv[0];
 #pragma unroll
-    for (int sidx = 1; sidx < kFcKSplit; ++sidx) v += pv[sidx];
+    for (int sidx = 1; sidx < kFcKSplit; ++sidx) v += (sidx < ksplit ? pv[sidx] : 0.f);
     hv[i] = fmaxf(v + fc_bias[k], 0.f);
   }
+  float wp[AMAX][KI], wvv[KI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+    const int k = lane + 64 * i;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) wp[a][i] = w_pi[min(a, A - 1) * K + k];
+    wvv[i] = w_v[k];
+  }
+  float bpi[AMAX];
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a) bpi[a] = b_pi[min(a, A - 1)];
+  const float bvv = b_v[0];
+  const float u = uniforms[t * n + row];
   float acc[AMAX + 1];
 #pragma unroll
   for (int a = 0; a <= AMAX; ++a) acc[a] = 0.f;
 #pragma unroll
   for (int i = 0; i < KI; ++i) {
-    const int k = lane + 64 * i;
 #pragma unroll
-    for (int a = 0; a < AMAX; ++a)
-      if (a < A) acc[a] = fmaf(hv[i], w_pi[a * K + k], acc[a]);
-    acc[AMAX] = fmaf(hv[i], w_v[k], acc[AMAX]);
+    for (int a = 0; a < AMAX; ++a) acc[a] = fmaf(hv[i], wp[a][i], acc[a]);
+    acc[AMAX] = fmaf(hv[i], wvv[i], acc[AMAX]);
   }
 #pragma unroll
   for (int a = 0; a <= AMAX; ++a) acc[a] = wave_sum(acc[a]);
@@ -390,7 +408,7 @@ __global__ __launch_bounds__(256) void pg_sample_head_kernel(
 #pragma unroll
     for (int a = 0; a < AMAX; ++a)
       if (a < A) {
-        acc[a] += b_pi[a];
+        acc[a] += bpi[a];
         mx = fmaxf(mx, acc[a]);
       }
     float den = 0.f;
@@ -403,7 +421,6 @@ __global__ __launch_bounds__(256) void pg_sample_head_kernel(
     const float inv = 1.f / den;
     float cum = 0.f;
     int pick = -1, last_pos = 0;
-    const float u = uniforms[t * n + row];
     float* __restrict__ pr = prob_rows + (t * B + lo + row) * A;
 #pragma unroll
     for (int a = 0; a < AMAX; ++a)
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(256) void pg_sample_head_kernel(
         if (p > 0.f) last_pos = a;
         if (pick < 0 && cum > u) pick = a;
       }
-    value_rows[t * B + lo + row] = acc[AMAX] + b_v[0];
+    value_rows[t * B + lo + row] = acc[AMAX] + bvv;
     const int64_t act = pick >= 0 ? pick : last_pos;
     action_rows[(t + 1) * B + lo + row] = act;
     action_out[row] = act;
