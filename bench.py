@@ -88,12 +88,16 @@ def main():
     logger.set_quiet(True)
 
     T, B = args.batch_T, args.batch_B
+    from rlpyt_amd.utils.misc import usable_cpus
     ncpu = os.cpu_count() or 8
+    cpus = usable_cpus()          # honours the cgroup quota (16 CPUs on the 256-thread bench box)
     workers = args.workers
     if workers < 0:
         # ~10 envs per worker: waking more workers per step costs the master more than their
-        # extra parallelism returns (measured 12..64 workers at B=256: 20-32 best, flat)
-        workers = max(min((ncpu - 2 * world) // world, B // 10), 0)
+        # extra parallelism returns (measured 12..64 workers at B=256: 20-32 best, flat).
+        # Workers sleep on a futex most of a step (25 of them keep ~10 CPUs busy), so the pool
+        # may exceed this rank's CPU share by ~1.6x but not more, or the quota throttles it.
+        workers = max(min(int(round(1.6 * cpus / world)) - 1, B // 10), 1)
     env_kwargs = dict(step_cost_us=args.env_cost_us)
     n_itr_total = args.warmup + args.steps
 
@@ -185,6 +189,7 @@ def main():
                        "T": T, "B": B, "env_workers_per_gpu": workers,
                        "sampler_pipeline_groups": sampler.n_groups,
                        "env_step_cost_us": args.env_cost_us, "host_cores": ncpu,
+                       "host_cpu_quota": cpus,
                        "parallelism": f"dp{world}"},
             "sampling_frac_of_step": t_sample / (elapsed if elapsed > 0 else 1.),
             "sampler": {"pipeline_groups": sampler.n_groups, "hip_graph": not args.no_graph,

@@ -196,6 +196,28 @@ int rlpyt_r2d1_loss_fwd_bwd_f32(const float* qs, const float* target_qs,
                                 float* priorities /*[B]*/, float* grad_qs, void* workspace,
                                 rlpyt_stream_t stream);
 
+/* CategoricalDQN.loss -- rlpyt/algos/dqn/cat_dqn.py:34-93 (after the network forward passes).
+ *   next_z[j]  = clamp(return_ + (1-done_n) * (z[j] * disc_n), V_min, V_max)
+ *   a'         = argmax_a sum_j sel[a,j] z[j], sel = next_ps (double DQN) or target_ps
+ *   target_p[i]= sum_j target_ps[a',j] * clamp(1 - |next_z[j] - z[i]| / delta_z, 0, 1)
+ *   p          = clamp(ps[action], 1e-6, 1);  losses = -sum_i target_p[i] log p[i] (* is_weights)
+ *   KL         = clamp(sum_i tc[i] (log tc[i] - log p[i]), 1e-6, 1e6), tc = clamp(target_p, 1e-6, 1)
+ *   loss       = mean(losses), or with `valid`: sum(losses*valid)/sum(valid) and KL *= valid
+ * ps / target_ps / next_ps f32 [M,A,P] probabilities (P <= 64 atoms), z f32 [P] the atom grid
+ * (torch.linspace(V_min, V_max, P)), delta_z = (V_max - V_min)/(P-1).
+ * out_scalars (2 floats): loss, normaliser (M or sum(valid)).  kl_div [M].
+ * grad_ps [M,A,P] = dLoss/dps (zero except the taken action's row; zero where the 1e-6 / 1
+ * clamp of p is active, as torch.clamp's backward). */
+int64_t rlpyt_cat_dqn_loss_workspace_bytes(void);
+int rlpyt_cat_dqn_loss_fwd_bwd_f32(const float* ps, const float* target_ps,
+                                   const float* next_ps /*nullable*/, const int64_t* action,
+                                   const float* return_, const uint8_t* done_n,
+                                   const float* is_weights /*nullable [M]*/,
+                                   const float* valid /*nullable [M]*/, const float* z /*[P]*/,
+                                   int64_t M, int A, int P, float v_min, float v_max,
+                                   float disc_n, float* out_scalars, float* kl_div,
+                                   float* grad_ps, void* workspace, rlpyt_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Observation running mean / std -- rlpyt/models/running_mean_std.py:21-45 and the
  * normalise+clip of rlpyt/models/pg/mujoco_ff_model.py:68-73.  x is [n, D] row-major.

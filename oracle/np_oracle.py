@@ -185,6 +185,42 @@ def dqn_loss_torch(qs, target_qs, next_qs, action, return_, done_n, is_weights, 
     return torch.mean(losses), td
 
 
+def cat_dqn_loss_torch(ps, target_ps, next_ps, action, return_, done_n, is_weights, done,
+                       V_min, V_max, discount, n_step):
+    """rlpyt/algos/dqn/cat_dqn.py:42-93 (torch CPU) -> (loss, KL_div).  ``ps`` / ``target_ps``
+    / ``next_ps`` [B,A,P] are the network outputs the method obtains from the agent
+    (``next_ps`` given = double DQN); ``done`` given = the ``not mid_batch_reset`` branch
+    (valid_from_done over the batch axis, exactly as written there)."""
+    import torch
+    EPS = 1e-6  # cat_dqn.py:8
+    n_atoms = ps.shape[-1]
+    ar = torch.arange(action.numel())
+    delta_z = (V_max - V_min) / (n_atoms - 1)
+    z = torch.linspace(V_min, V_max, n_atoms)
+    next_z = z * (discount ** n_step)
+    next_z = torch.outer(1 - done_n.float(), next_z)
+    next_z = torch.clamp(return_.unsqueeze(1) + next_z, V_min, V_max)
+    coeffs = torch.clamp(1 - abs(next_z.unsqueeze(1) - z.view(1, -1, 1)) / delta_z, 0, 1)
+    with torch.no_grad():
+        sel = next_ps if next_ps is not None else target_ps
+        next_a = torch.argmax(torch.tensordot(sel, z, dims=1), dim=-1)
+        target_p = (target_ps[ar, next_a].unsqueeze(1) * coeffs).sum(-1)
+    p = torch.clamp(ps[ar, action], EPS, 1)
+    losses = -torch.sum(target_p * torch.log(p), dim=1)
+    if is_weights is not None:
+        losses = losses * is_weights
+    target_p = torch.clamp(target_p, EPS, 1)
+    kl = torch.sum(target_p * (torch.log(target_p) - torch.log(p.detach())), dim=1)
+    kl = torch.clamp(kl, EPS, 1 / EPS)
+    if done is not None:
+        valid = torch.from_numpy(valid_from_done(done.numpy().astype(np.float32)))
+        loss = _valid_mean(losses, valid)
+        kl = kl * valid
+    else:
+        loss = torch.mean(losses)
+    return loss, kl
+
+
 # --------------------------------------------------------------------------------------
 # rlpyt/replays/sum_tree.py
 # --------------------------------------------------------------------------------------

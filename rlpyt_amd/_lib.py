@@ -92,6 +92,10 @@ _SIGNATURES = {
     "rlpyt_r2d1_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int,
                                             c_float, c_float, c_float, c_float, _p, _p, _p, _p,
                                             _p, _p]),
+    "rlpyt_cat_dqn_loss_workspace_bytes": (c_int64, []),
+    "rlpyt_cat_dqn_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, c_int64, c_int,
+                                               c_int, c_float, c_float, c_float, _p, _p, _p, _p,
+                                               _p]),
     "rlpyt_obs_rms_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "rlpyt_obs_batch_stats_f32": (c_int, [_p, c_int64, c_int64, _p, _p, _p, _p]),
     "rlpyt_obs_rms_merge_f32": (c_int, [_p, _p, _p, _p, _p, c_float, c_int64, _p]),

@@ -382,6 +382,49 @@ def r2d1_loss(qs, target_qs, next_qs, action, return_, done_n, valid, is_weights
                            disc_n, delta_clip, value_scale_eps, pri_eta)
 
 
+class _CatDqnLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ps, target_ps, next_ps, action, return_, done_n, is_weights, valid, z,
+                v_min, v_max, disc_n):
+        _lib.require_gpu()
+        A, P = ps.shape[-2], ps.shape[-1]
+        p = _f32(ps).reshape(-1, A, P)
+        M = p.shape[0]
+        tp = _f32(target_ps).reshape(-1, A, P)
+        nps = None if next_ps is None else _f32(next_ps).reshape(-1, A, P)
+        act = action.reshape(-1).long().contiguous()
+        ret = _f32(return_).reshape(-1)
+        dn = _as_done_u8(done_n).reshape(-1)
+        isw = None if is_weights is None else _f32(is_weights).reshape(-1)
+        val = None if valid is None else _f32(valid).reshape(-1)
+        zz = _f32(z).to(p.device)
+        out = torch.empty(2, dtype=torch.float32, device=p.device)
+        kl = torch.empty(M, dtype=torch.float32, device=p.device)
+        gp = torch.empty_like(p)
+        ws = _workspace("catdqn", lib.rlpyt_cat_dqn_loss_workspace_bytes(), p.device)
+        check(lib.rlpyt_cat_dqn_loss_fwd_bwd_f32(
+            ptr(p), ptr(tp), ptr(nps), ptr(act), ptr(ret), ptr(dn), ptr(isw), ptr(val), ptr(zz),
+            M, A, P, float(v_min), float(v_max), float(disc_n), ptr(out), ptr(kl), ptr(gp),
+            ptr(ws), stream()), "rlpyt_cat_dqn_loss_fwd_bwd_f32")
+        ctx.save_for_backward(gp)
+        ctx.shape = ps.shape
+        ctx.mark_non_differentiable(kl)
+        return out[0], kl
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_kl):
+        (gp,) = ctx.saved_tensors
+        return ((gp * g_loss).reshape(ctx.shape),) + (None,) * 11
+
+
+def cat_dqn_loss(ps, target_ps, next_ps, action, return_, done_n, is_weights, valid, z, v_min,
+                 v_max, disc_n):
+    """CategoricalDQN.loss after the network passes (rlpyt/algos/dqn/cat_dqn.py:42-93):
+    returns (loss, KL_div [M])."""
+    return _CatDqnLoss.apply(ps, target_ps, next_ps, action, return_, done_n, is_weights, valid,
+                             z, v_min, v_max, disc_n)
+
+
 # --------------------------------------------------------------------------------------
 # observation running mean / std (rlpyt/models/running_mean_std.py)
 # --------------------------------------------------------------------------------------

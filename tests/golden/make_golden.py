@@ -18,6 +18,7 @@ import torch
 
 REF = os.environ.get("RLPYT_REFERENCE", "/root/reference")
 sys.path.insert(0, REF)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 from rlpyt.algos.utils import (discount_return, discount_return_n_step,  # noqa: E402
@@ -578,6 +579,99 @@ def gen_r2d1_rms():
     save("r2d1_rms", **out)
 
 
+def gen_catdqn():
+    """CategoricalDQN.loss (rlpyt/algos/dqn/cat_dqn.py:34-93) -- the reference METHOD itself,
+    run on a stub agent that hands back preset network outputs."""
+    from collections import namedtuple
+    from rlpyt.algos.dqn.cat_dqn import CategoricalDQN
+    Samples = namedtuple("Samples", ["agent_inputs", "target_inputs", "action", "return_",
+                                     "done", "done_n", "is_weights"])
+
+    class StubAgent:
+        def __init__(self, n_atoms, ps, target_ps, next_ps, agent_inputs):
+            self.n_atoms, self.ps, self.target_ps, self.next_ps = n_atoms, ps, target_ps, next_ps
+            self._agent_inputs = agent_inputs
+
+        def __call__(self, *inputs):
+            return self.ps if inputs[0] is self._agent_inputs[0] else self.next_ps
+
+        def target(self, *inputs):
+            return self.target_ps
+
+    out = {}
+    cases = [  # name, M, A, P, V_min, V_max, double, pri, mid_batch_reset, logit scale, n_step
+        ("cat", 128, 6, 51, -10, 10, False, True, True, 1.0, 1),
+        ("cat_double", 32, 18, 51, -10, 10, True, False, True, 2.0, 3),
+        ("cat_valid", 64, 4, 21, -5, 20, False, True, False, 1.0, 3),
+        ("cat_peaky", 48, 3, 64, -1, 1, True, True, True, 12.0, 1),  # p < 1e-6: clamp active
+    ]
+    for name, M, A, P, v_min, v_max, double, pri, mbr, scale, n_step in cases:
+        g = torch.Generator().manual_seed(80 + M)
+        ps = torch.softmax(scale * torch.randn(M, A, P, generator=g), dim=-1).requires_grad_(True)
+        target_ps = torch.softmax(scale * torch.randn(M, A, P, generator=g), dim=-1)
+        next_ps = torch.softmax(scale * torch.randn(M, A, P, generator=g), dim=-1)
+        action = torch.randint(0, A, (M,), generator=g)
+        return_ = (v_max - v_min) * 0.2 * torch.randn(M, generator=g)
+        done_n = torch.rand(M, generator=g) < 0.1
+        done = torch.rand(M, generator=g) < 0.03
+        isw = torch.rand(M, generator=g) + 0.1
+        algo = CategoricalDQN(V_min=v_min, V_max=v_max, discount=0.99, n_step_return=n_step,
+                              double_dqn=double, prioritized_replay=pri, batch_size=M)
+        a_in, t_in = (torch.zeros(1),), (torch.ones(1),)
+        algo.agent = StubAgent(P, ps, target_ps, next_ps if double else None, a_in)
+        algo.mid_batch_reset = mbr
+        loss, kl = algo.loss(Samples(a_in, t_in, action, return_, done, done_n,
+                                     isw.clone() if pri else None))
+        loss.backward()
+        out.update({f"{name}_ps": ps.detach().numpy(), f"{name}_target_ps": target_ps.numpy(),
+                    f"{name}_next_ps": next_ps.numpy(), f"{name}_action": action.numpy(),
+                    f"{name}_ret": return_.numpy(), f"{name}_done_n": done_n.numpy(),
+                    f"{name}_done": done.numpy(), f"{name}_isw": isw.numpy(),
+                    f"{name}_double": np.bool_(double), f"{name}_pri": np.bool_(pri),
+                    f"{name}_mbr": np.bool_(mbr), f"{name}_vmin": np.float64(v_min),
+                    f"{name}_vmax": np.float64(v_max), f"{name}_n_step": np.int64(n_step),
+                    f"{name}_discount": np.float64(0.99),
+                    f"{name}_loss": np.float32(loss.item()), f"{name}_kl": kl.detach().numpy(),
+                    f"{name}_grad_ps": ps.grad.numpy()})
+    save("catdqn", **out)
+
+
+from model_cases import MODEL_CASES, MODEL_SEED, model_inputs, scalarize  # noqa: E402
+
+
+def gen_models():
+    """Full-size hot-path models built by the REFERENCE classes under a fixed seed: parameter
+    names / shapes / per-tensor checksums (the new framework's models must initialise to the
+    same values under the same seed), forward outputs and per-parameter gradient norms."""
+    import importlib
+    out = {}
+    for name, path, _mine, kwargs, recurrent in MODEL_CASES:
+        mod, cls = path.rsplit(".", 1)
+        Model = getattr(importlib.import_module(mod), cls)
+        torch.manual_seed(MODEL_SEED)
+        model = Model(image_shape=(4, 104, 80), output_size=6, **kwargs)
+        sd = model.state_dict()
+        out[f"{name}_names"] = np.array(list(sd.keys()))
+        out[f"{name}_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        out[f"{name}_sums"] = np.array([v.double().sum().item() for v in sd.values()])
+        out[f"{name}_abs_sums"] = np.array([v.double().abs().sum().item() for v in sd.values()])
+        inputs = model_inputs(recurrent)
+        res = model(*inputs)
+        res = res if isinstance(res, tuple) else (res,)
+        scalarize(res).backward()
+        k = 0
+        for o in res:
+            for leaf in ([o] if isinstance(o, torch.Tensor) else list(o)):
+                out[f"{name}_out{k}"] = leaf.detach().numpy()
+                k += 1
+        out[f"{name}_grad_norms"] = np.array([p.grad.double().norm().item()
+                                              for p in model.parameters()])
+        small = [(n, p) for n, p in model.named_parameters() if p.numel() <= 1024]
+        for n, p in small:
+            out[f"{name}_grad__{n}"] = p.grad.numpy()
+    save("models", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
@@ -590,3 +684,5 @@ if __name__ == "__main__":
     gen_replay()
     gen_seq_replay()
     gen_r2d1_rms()
+    gen_catdqn()
+    gen_models()

@@ -102,3 +102,59 @@ def test_r2d1_end_to_end(prioritized):
     assert batch.all_observation.shape == (16 + 2, 6, 4, 104, 80) and batch.all_observation.is_cuda
     assert batch.init_rnn_state.h.shape == (6, 1, 32)
     sampler.shutdown()
+
+
+@pytest.mark.parametrize("prioritized,double,dueling", [(True, True, True), (False, False, False)])
+def test_catdqn_end_to_end(prioritized, double, dueling):
+    """Categorical DQN through the same HBM sampler / replay path: the
+    agent_info leaf is the [A, n_atoms] distribution, priorities come from the KL kernel."""
+    from rlpyt_amd.agents.dqn.catdqn_agent import AtariCatDqnAgent
+    from rlpyt_amd.algos.dqn.cat_dqn import CategoricalDQN
+    T, B = 4, 8
+    sampler = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=11), batch_T=T, batch_B=B,
+                         n_workers=2, max_decorrelation_steps=0)
+    agent = AtariCatDqnAgent(n_atoms=21, eps_final=0.1,
+                             model_kwargs=dict(fc_sizes=64, dueling=dueling))
+    algo = CategoricalDQN(V_min=-2, V_max=2, batch_size=16, min_steps_learn=2 * T * B,
+                          replay_size=512, replay_ratio=8, target_update_interval=4,
+                          n_step_return=2, prioritized_replay=prioritized, double_dqn=double,
+                          learning_rate=1e-4)
+    assert algo.optim_kwargs["eps"] == 0.01 / 16
+    torch.manual_seed(0)
+    np.random.seed(0)
+    examples = sampler.initialize(agent, seed=1, bootstrap_value=False)
+    torch.cuda.set_device(0)
+    agent.to_device(0)
+    algo.initialize(agent=agent, n_itr=12, batch_spec=sampler.batch_spec,
+                    mid_batch_reset=sampler.mid_batch_reset, examples=examples)
+    assert agent.distribution.z.is_cuda and float(agent.distribution.z[0]) == -2.0
+    losses, kls = [], []
+    for itr in range(8):
+        agent.sample_mode(itr)
+        samples, _ = sampler.obtain_samples(itr)
+        p = samples.agent.agent_info.p
+        assert p.shape == (T, B, 6, 21)
+        torch.testing.assert_close(p.sum(-1), torch.ones_like(p[..., 0]), rtol=0, atol=1e-5)
+        agent.train_mode(itr)
+        info = algo.optimize_agent(itr, samples)
+        losses += list(info.loss)
+        kls += list(info.tdAbsErr)
+    assert algo.update_counter == (8 - algo.min_itr_learn) * algo.updates_per_optimize > 0
+    assert len(losses) == algo.update_counter and np.all(np.isfinite(losses))
+    assert np.all(np.isfinite(kls)) and min(kls) >= 1e-6 * (1 - 1e-6)   # KL clamp floor
+    # one more loss evaluation compared with the CPU oracle on the same network outputs
+    from oracle import np_oracle as O
+    batch = algo.replay_buffer.sample_batch(16)
+    with torch.no_grad():
+        ps = agent(*batch.agent_inputs)
+        tps = agent.target(*batch.target_inputs)
+        nps = agent(*batch.target_inputs) if double else None
+    loss, kl = algo.loss(batch)
+    c = lambda x: None if x is None else x.detach().cpu()  # noqa: E731
+    loss_c, kl_c = O.cat_dqn_loss_torch(c(ps), c(tps), c(nps), c(batch.action), c(batch.return_),
+                                        c(batch.done_n),
+                                        c(batch.is_weights) if prioritized else None, None,
+                                        -2, 2, algo.discount, algo.n_step_return)
+    np.testing.assert_allclose(loss.item(), loss_c.item(), rtol=2e-5)
+    np.testing.assert_allclose(kl.cpu().numpy(), kl_c.numpy(), rtol=1e-4, atol=1e-6)
+    sampler.shutdown()

@@ -102,6 +102,23 @@ def test_dqn_loss(name):
     np.testing.assert_allclose(qs.grad.numpy(), g[f"{name}_grad_qs"], rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("name", ["cat", "cat_double", "cat_valid", "cat_peaky"])
+def test_cat_dqn_loss(name):
+    """Oracle restatement of CategoricalDQN.loss vs the reference method's own outputs."""
+    g = load_golden("catdqn")
+    t = lambda k: torch.from_numpy(g[f"{name}_{k}"])  # noqa: E731
+    ps = t("ps").requires_grad_(True)
+    loss, kl = O.cat_dqn_loss_torch(
+        ps, t("target_ps"), t("next_ps") if bool(g[f"{name}_double"]) else None, t("action"),
+        t("ret"), t("done_n"), t("isw") if bool(g[f"{name}_pri"]) else None,
+        None if bool(g[f"{name}_mbr"]) else t("done"), float(g[f"{name}_vmin"]),
+        float(g[f"{name}_vmax"]), float(g[f"{name}_discount"]), int(g[f"{name}_n_step"]))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[f"{name}_loss"], rtol=1e-6)
+    np.testing.assert_allclose(kl.numpy(), g[f"{name}_kl"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(ps.grad.numpy(), g[f"{name}_grad_ps"], rtol=1e-6, atol=1e-9)
+
+
 def replay_sumtree_stream(g, name, make_tree, sample, update, advance, root, tree_of=None):
     """Shared driver: replays a recorded reference stream against an implementation."""
     T, B = int(g[f"{name}_T"]), int(g[f"{name}_B"])
