@@ -182,6 +182,56 @@ class MinibatchRl(MinibatchRlBase):
         self._new_completed_trajs = 0
 
 
+class MinibatchRlEval(MinibatchRlBase):
+    """Offline tracking: pauses at every log interval to run evaluation trajectories through
+    ``sampler.evaluate_agent`` (minibatch_rl.py:286-357)."""
+
+    _eval = True
+
+    def train(self):
+        n_itr = self.startup()
+        eval_traj_infos, eval_time = self.evaluate_agent(0)
+        self.log_diagnostics(0, eval_traj_infos, eval_time)
+        for itr in range(n_itr):
+            logger.set_iteration(itr)
+            self.agent.sample_mode(itr)
+            samples, traj_infos = self.sampler.obtain_samples(itr)
+            self.agent.train_mode(itr)
+            opt_info = self.algo.optimize_agent(itr, samples)
+            self.store_diagnostics(itr, traj_infos, opt_info)
+            if (itr + 1) % self.log_interval_itrs == 0:
+                eval_traj_infos, eval_time = self.evaluate_agent(itr)
+                self.log_diagnostics(itr, eval_traj_infos, eval_time)
+        self.shutdown()
+
+    def evaluate_agent(self, itr):
+        if itr >= self.min_itr_learn - 1 or itr == 0:
+            logger.log("Evaluating agent...")
+            self.agent.eval_mode(itr)
+            eval_time = -time.time()
+            traj_infos = self.sampler.evaluate_agent(itr)
+            eval_time += time.time()
+        else:
+            traj_infos, eval_time = [], 0.0
+        logger.log("Evaluation runs complete.")
+        return traj_infos, eval_time
+
+    def initialize_logging(self):
+        super().initialize_logging()
+        self._cum_eval_time = 0
+
+    def log_diagnostics(self, itr, eval_traj_infos, eval_time, prefix="Diagnostics/"):
+        if not eval_traj_infos:
+            logger.log("WARNING: had no complete trajectories in eval.")
+        steps_in_eval = sum(info["Length"] for info in eval_traj_infos)
+        with logger.tabular_prefix(prefix):
+            logger.record_tabular("StepsInEval", steps_in_eval)
+            logger.record_tabular("TrajsInEval", len(eval_traj_infos))
+            self._cum_eval_time += eval_time
+            logger.record_tabular("CumEvalTime", self._cum_eval_time)
+        super().log_diagnostics(itr, eval_traj_infos, eval_time, prefix=prefix)
+
+
 class SyncRl(MinibatchRl):
     """Data-parallel training, one process per GPU (sync_rl.py:11-193 semantics)."""
 

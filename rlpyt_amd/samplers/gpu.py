@@ -175,7 +175,58 @@ class EnvRunner:
                     self.env_info[t, b] = info
 
 
-def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus):
+EVAL_TRAJ_CHECK = 20    # time steps between checks of the completed-trajectory count
+
+
+class EvalRunner:
+    """Offline-evaluation env stepping against the eval step buffer (the worker side of
+    rlpyt/samplers/parallel/gpu/collectors.py:129-161): separate env instances, every finished
+    trajectory's info goes to ``sink`` at once, the env restarts immediately."""
+
+    def __init__(self, envs, step_np, TrajInfoCls, max_T):
+        self.envs, self.step, self.TrajInfoCls, self.max_T = envs, step_np, TrajInfoCls, max_T
+        self.traj_infos = None
+
+    def begin(self):
+        step = self.step
+        self.traj_infos = [self.TrajInfoCls() for _ in self.envs]
+        for b, env in enumerate(self.envs):
+            step.observation[b] = env.reset()
+            step.action[b] = env.action_space.null_value()
+        step.reward[:] = 0
+        step.done[:] = False
+
+    def step_all(self, sink):
+        step = self.step
+        for b, env in enumerate(self.envs):
+            a = step.action[b]
+            o, r, d, info = env.step(a)
+            self.traj_infos[b].step(step.observation[b], a, r, d, None, info)
+            if getattr(info, "traj_done", d):
+                sink(self.traj_infos[b].terminate(o))
+                self.traj_infos[b] = self.TrajInfoCls()
+                o = env.reset()
+            step.observation[b] = o
+            step.reward[b] = r
+            step.done[b] = d
+
+    def collect(self, seq, ctrl, g_eval):
+        """Worker-side evaluation run: one arrival up front, then one per action set received
+        (also for the final "stop" message), so both sides always count the same rounds."""
+        q = ctrl.eval_traj_infos_queue
+        self.begin()
+        seq.worker_arrive(g_eval)
+        for _ in range(self.max_T):
+            seq.worker_wait_act(g_eval)
+            if ctrl.stop_eval.value:
+                seq.worker_arrive(g_eval)
+                break
+            self.step_all(lambda info: q.put(dict(info)))
+            seq.worker_arrive(g_eval)
+        q.put(None)    # end sentinel of this worker
+
+
+def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus, eval_runner=None):
     """Forked sampler worker (rlpyt/samplers/parallel/worker.py:37-101).  ``runners`` =
     [(group index, EnvRunner)]: this worker's environments, served in group order (with
     dedicated workers per pipeline group there is exactly one entry)."""
@@ -196,6 +247,10 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus):
         seq.worker_wait_batch()
         if ctrl.quit.value:
             break
+        if ctrl.do_eval.value:      # offline evaluation instead of a training batch
+            eval_runner.collect(seq, ctrl, len(ctrl.group_workers) - 1)
+            seq.worker_batch_done()
+            continue
         completed = []
         for g, rn in runners:
             rn.begin_batch()
@@ -438,6 +493,7 @@ class GpuSampler(BaseSampler):
                 runners[w].append((g, rn))
             G.n_workers = len(ws)
         self.runners = runners
+        self._init_eval(o, a_t, n_w, shared)
         if self.n_workers > 0:
             self._launch_workers(affinity)
         else:
@@ -450,14 +506,44 @@ class GpuSampler(BaseSampler):
                    f"pipeline groups={self.n_groups}.")
         return AttrDict(examples)
 
+    def _init_eval(self, obs_example, action_example, n_w, shared):
+        """Separate evaluation environments and their step buffer
+        (rlpyt/samplers/parallel/base.py:88-98, worker.py:68-82): ``eval_n_envs`` is spread
+        evenly over the workers (at least one each)."""
+        self.eval = None
+        if not self.eval_n_envs or self.eval_n_envs <= 0:
+            return
+        per = max(1, self.eval_n_envs // n_w)
+        Be = per * n_w
+        if Be != self.eval_n_envs:
+            logger.log(f"GpuSampler: using {Be} evaluation environments ({per} per worker).")
+        self.eval_n_envs = Be
+        self.eval_max_T = max_T = max(1, int(self.eval_max_steps // Be))
+        kwargs = self.eval_env_kwargs if self.eval_env_kwargs is not None else self.env_kwargs
+        envs = [self.EnvCls(**kwargs) for _ in range(Be)]
+        for i, env in enumerate(envs):
+            env.seed(self.seed + 50000 + self.rank * Be + i)
+        step_np = StepBuffer(
+            observation=buffer_from_example(obs_example, (Be,), share_memory=shared),
+            action=buffer_from_example(action_example, (Be,), share_memory=shared),
+            reward=buffer_from_example(np.asarray(0, dtype=np.float32), (Be,), share_memory=shared),
+            done=buffer_from_example(np.asarray(False), (Be,), share_memory=shared))
+        runners = [EvalRunner(envs[w * per:(w + 1) * per], step_np[w * per:(w + 1) * per],
+                              self.TrajInfoCls, max_T) for w in range(n_w)]
+        self.eval = AttrDict(Be=Be, step_np=step_np, runners=runners, device_ready=False)
+
     def _launch_workers(self, affinity):
         ctx = mp.get_context("fork")
         n = self.n_workers
         self.ctrl = AttrDict(
             quit=ctx.RawValue(ctypes.c_bool, False),
             barrier_out=ctx.Barrier(n + 1),
-            sync_words=np_mp_array(32 * (len(self.groups) + 1), np.uint32), n_workers=n,
-            group_workers=[G.n_workers for G in self.groups],
+            do_eval=ctx.RawValue(ctypes.c_bool, False),
+            stop_eval=ctx.RawValue(ctypes.c_bool, False),
+            eval_traj_infos_queue=ctx.Queue(),
+            # one pair of hand-off words per pipeline group + one for evaluation + batch words
+            sync_words=np_mp_array(32 * (len(self.groups) + 2), np.uint32), n_workers=n,
+            group_workers=[G.n_workers for G in self.groups] + [n],
             worker_spin=None,
             traj_infos_queue=ctx.Queue(),
             max_decorrelation_steps=self.max_decorrelation_steps)
@@ -480,7 +566,8 @@ class GpuSampler(BaseSampler):
             wc = [wc] if isinstance(wc, int) else wc
             p = ctx.Process(target=_worker_loop, args=(
                 w, self.runners[w], self.ctrl, self.batch_spec.T,
-                self.seed + 1000 * (self.rank + 1) + w, wc), daemon=True)
+                self.seed + 1000 * (self.rank + 1) + w, wc,
+                None if self.eval is None else self.eval.runners[w]), daemon=True)
             p.start()
             self.workers.append(p)
         self.sync = _StepSync(self.ctrl.sync_words, self.ctrl.group_workers, n)
@@ -974,8 +1061,108 @@ class GpuSampler(BaseSampler):
             out.append(ti)
         return out
 
+    def _ensure_eval_device(self):
+        E = self.eval
+        if E.device_ready:
+            return
+        dev = self.agent.device
+        E.step_pyt = torchify_buffer(E.step_np)
+        E.obs_dev = buffer_from_example(self.examples["observation"], (E.Be,), device=dev)
+        E.act_dev = buffer_from_example(self.examples["action"], (E.Be,), device=dev)
+        E.rew_dev = torch.zeros(E.Be, dtype=torch.float32, device=dev)
+        E.done_dev = torch.zeros(E.Be, dtype=torch.bool, device=dev)
+        E.device_ready = True
+
     def evaluate_agent(self, itr):
-        raise NotImplementedError("offline evaluation is not part of the hot path (SURVEY 8)")
+        """Offline evaluation with the agent's current parameters (the caller has put the agent
+        in eval mode): role of ``ParallelSamplerBase.evaluate_agent`` +
+        ``ActionServer.serve_actions_evaluation`` (rlpyt/samplers/parallel/base.py:115-145,
+        gpu/action_server.py:76-120).  Separate env instances are stepped by the same worker
+        processes; the batched forward runs on the device, observations go up and actions come
+        down once per step (eager launches -- evaluation is outside the timed training path).
+        Stops after ``eval_max_steps`` env steps or, if given, once ``eval_max_trajectories``
+        have completed (checked every EVAL_TRAJ_CHECK steps).  Returns the completed TrajInfos."""
+        if self.eval is None:
+            raise RuntimeError("GpuSampler.evaluate_agent: construct the sampler with "
+                               "eval_n_envs > 0 (and eval_max_steps) to evaluate offline.")
+        self._ensure_eval_device()
+        E, agent = self.eval, self.agent
+        par = self.n_workers > 0
+        cuda = agent.device.type == "cuda"
+        step_np, step_pyt = E.step_np, E.step_pyt
+        traj_infos = []
+
+        def take(info):
+            ti = self.TrajInfoCls()
+            ti.update(info)
+            traj_infos.append(ti)
+
+        def drain(block_for_sentinels=0):
+            q, n_sent = self.ctrl.eval_traj_infos_queue, 0
+            while True:
+                try:
+                    item = q.get(block=block_for_sentinels > 0, timeout=20)
+                except queue_mod.Empty:
+                    if block_for_sentinels > 0:
+                        raise RuntimeError("GpuSampler.evaluate_agent: an env worker did not "
+                                           "finish its evaluation run.")
+                    return
+                if item is None:
+                    n_sent += 1
+                    if n_sent >= block_for_sentinels > 0:
+                        return
+                else:
+                    take(item)
+
+        agent.reset()
+        if agent.recurrent:
+            agent.select_slot("eval")
+        g_eval = len(self.groups)
+        if par:
+            self.ctrl.stop_eval.value = False
+            self.ctrl.do_eval.value = True
+            self.sync.master_start_batch()
+        else:
+            E.runners[0].begin()
+        stop = False
+        for t in range(self.eval_max_T):
+            if par:
+                if t % EVAL_TRAJ_CHECK == 0:
+                    drain()
+                self.sync.master_wait_obs(g_eval)
+            dn = step_np.done
+            if np.any(dn):      # null prev action / reward after a reset (action_server.py:95-98)
+                _map(lambda x: x.__setitem__(dn, 0), step_np.action)
+                step_np.reward[dn] = 0
+            _copy_leaves(E.obs_dev, step_pyt.observation, non_blocking=False)
+            _copy_leaves(E.act_dev, step_pyt.action)
+            E.rew_dev.copy_(step_pyt.reward)
+            if agent.recurrent:
+                E.done_dev.copy_(step_pyt.done)
+                agent.reset_where(E.done_dev)
+            action, _agent_info = agent.step(E.obs_dev, E.act_dev, E.rew_dev)
+            _copy_leaves(step_pyt.action, action)     # D2H (synchronous)
+            if self.eval_max_trajectories is not None and t % EVAL_TRAJ_CHECK == 0:
+                stop = len(traj_infos) >= self.eval_max_trajectories
+            if par:
+                self.ctrl.stop_eval.value = stop
+                self.sync.master_post_act(g_eval)
+            elif not stop:
+                E.runners[0].step_all(take)
+            if stop:
+                logger.log(f"Evaluation reached max num trajectories "
+                           f"({self.eval_max_trajectories}).")
+                break
+        if not stop and self.eval_max_trajectories is not None:
+            logger.log(f"Evaluation reached max num time steps ({self.eval_max_T}).")
+        if par:
+            self.sync.master_wait_obs(g_eval)     # the workers' closing arrival
+            self.sync.master_wait_batch_done()
+            drain(block_for_sentinels=self.n_workers)
+            self.ctrl.do_eval.value = False
+        if cuda:
+            torch.cuda.current_stream().synchronize()
+        return traj_infos
 
     def shutdown(self):
         if self.n_workers > 0 and self.workers:

@@ -19,7 +19,8 @@ logger.set_quiet(True)
 def test_dqn_end_to_end(prioritized, double):
     T, B = 4, 8
     sampler = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=11), batch_T=T, batch_B=B,
-                         n_workers=2, max_decorrelation_steps=0)
+                         n_workers=2, max_decorrelation_steps=0, eval_n_envs=4,
+                         eval_max_steps=4 * 30, eval_max_trajectories=8)
     agent = AtariDqnAgent(eps_final=0.1)
     algo = DQN(batch_size=16, min_steps_learn=2 * T * B, replay_size=512, replay_ratio=8,
                target_update_interval=4, n_step_return=2, prioritized_replay=prioritized,
@@ -52,6 +53,13 @@ def test_dqn_end_to_end(prioritized, double):
     assert batch.return_.shape == (16,) and torch.isfinite(batch.return_).all()
     if prioritized:
         assert batch.is_weights.shape == (16,) and float(batch.is_weights.max()) <= 1.0 + 1e-6
+    # offline evaluation on the device (MinibatchRlEval path), then training continues
+    agent.eval_mode(10)
+    infos = sampler.evaluate_agent(10)
+    assert len(infos) >= 8 and all(1 <= ti["Length"] <= 11 for ti in infos)
+    agent.sample_mode(10)
+    samples, _ = sampler.obtain_samples(10)
+    assert torch.isfinite(samples.env.reward).all()
     sampler.shutdown()
 
 
@@ -64,7 +72,8 @@ def test_r2d1_end_to_end(prioritized):
     from rlpyt_amd.algos.dqn.r2d1 import R2D1
     T, B = 8, 4
     sampler = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=13), batch_T=T, batch_B=B,
-                         n_workers=2, mid_batch_reset=False, max_decorrelation_steps=0)
+                         n_workers=2, mid_batch_reset=False, max_decorrelation_steps=0,
+                         eval_n_envs=2, eval_max_steps=2 * 40)
     agent = AtariR2d1Agent(model_kwargs=dict(fc_size=64, lstm_size=32, head_size=32),
                            eps_final=0.1)
     algo = R2D1(batch_T=8, batch_B=6, warmup_T=8, store_rnn_state_interval=8,
@@ -101,6 +110,13 @@ def test_r2d1_end_to_end(prioritized):
     batch = algo.replay_buffer.sample_batch(6)
     assert batch.all_observation.shape == (16 + 2, 6, 4, 104, 80) and batch.all_observation.is_cuda
     assert batch.init_rnn_state.h.shape == (6, 1, 32)
+    # recurrent offline evaluation keeps its own LSTM state; the sampling state survives it
+    agent.eval_mode(10)
+    infos = sampler.evaluate_agent(10)
+    assert len(infos) >= 2 * 3 and all(ti["Length"] <= 13 for ti in infos)
+    agent.sample_mode(10)
+    samples, _ = sampler.obtain_samples(10)
+    assert samples.agent.agent_info.prev_rnn_state.h.shape == (T, B, 1, 32)
     sampler.shutdown()
 
 
