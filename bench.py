@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--cpu-baseline-B", type=int, default=0,
                     help="B of the bounded CPU sample (0: sized for ~15 s of CPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-fused-push", action="store_true",
+                    help="debug: separate frame_push / conv1 / conv2 launches in the sampling step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-gpu", action="store_true",
                     help="debug: every rank uses cuda:0 (with --backend gloo) to exercise the "
@@ -108,7 +110,7 @@ def main():
     sampler = GpuSampler(SyntheticPong, env_kwargs, batch_T=T, batch_B=B, n_workers=workers,
                          TrajInfoCls=AtariTrajInfo, max_decorrelation_steps=100,
                          n_groups=None if args.groups < 0 else args.groups,
-                         use_graph=not args.no_graph)
+                         use_graph=not args.no_graph, fused_push=not args.no_fused_push)
     agent = AtariFfAgent()
     algo = PPO(discount=0.99, learning_rate=1e-3, value_loss_coeff=1., entropy_loss_coeff=0.01,
                clip_grad_norm=1., gae_lambda=0.98, minibatches=4, epochs=4, ratio_clip=0.1,
@@ -231,6 +233,11 @@ def main():
         out["roofline_gae_scaled"] = gae_scaled_roofline()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, args.cpu_baseline_B, env_kwargs)
+            # the isolated hot-path functions, HIP kernel beside the CPU restatement
+            # on the same synthetic inputs (also yields the replay-kernel HBM rooflines)
+            fn = isolated_functions(T, B)
+            out["roofline_replay"] = fn.pop("roofline_replay")
+            out["cpu_baseline"]["functions"] = fn
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -277,6 +284,134 @@ def gae_scaled_roofline(T=128, log2n=20, iters=20):
             "achieved": nbytes / secs / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": nbytes / secs / 1e9 / HBM_PEAK_GBPS, "avg_us": secs * 1e6,
             "alg_bytes_per_launch": nbytes}
+
+
+def _hip_us(fn, iters=30, warmup=3):
+    for _ in range(warmup):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / iters
+
+
+def _cpu_us(fn, budget_s=0.5, max_reps=20):
+    fn()
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_reps and (time.perf_counter() - t0 < budget_s or n == 0):
+        fn()
+        n += 1
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+def isolated_functions(T, B):
+    """Per-function latency at the BASELINE shapes (SURVEY 8(d) synthetic inputs): the HIP kernel
+    through the C ABI (HIP events, data resident in HBM) and the oracle's CPU restatement of the
+    reference function (host arrays, this box's cores), both in microseconds per call."""
+    import numpy as np
+
+    from oracle import np_oracle as O
+    from rlpyt_amd import ops
+    rng = np.random.RandomState(0)
+    g = torch.Generator().manual_seed(0)
+    res = {}
+
+    def both(name, hip, cpu, **extra):
+        res[name] = dict(hip_us=round(_hip_us(hip), 2), cpu_us=round(_cpu_us(cpu), 1), **extra)
+        res[name]["ratio"] = round(res[name]["cpu_us"] / res[name]["hip_us"], 1)
+
+    # ---- scans at [T, B] ------------------------------------------------------------------
+    reward = (0.5 * torch.randn(T, B, generator=g))
+    value = torch.randn(T, B, generator=g)
+    done = torch.rand(T, B, generator=g) < 0.01
+    bv = torch.randn(1, B, generator=g)
+    r_d, v_d, d_d, bv_d = reward.cuda(), value.cuda(), done.cuda(), bv.cuda()
+    r_n, v_n, d_n, bv_n = reward.numpy(), value.numpy(), done.numpy(), bv.numpy()
+    both("gae", lambda: ops.gae(r_d, v_d, d_d, bv_d, 0.99, 0.98),
+         lambda: O.generalized_advantage_estimation(r_n, v_n, d_n, bv_n, 0.99, 0.98),
+         shape=[T, B])
+    both("discount_return", lambda: ops.discount_return(r_d, d_d, bv_d, 0.99),
+         lambda: O.discount_return(r_n, d_n, bv_n, 0.99), shape=[T, B])
+    both("valid_from_done", lambda: ops.valid_from_done(d_d), lambda: O.valid_from_done(d_n),
+         shape=[T, B])
+    # ---- PPO loss forward + backward at M = T*B/4, A = 6 ------------------------------------
+    M, A = T * B // 4, 6
+    pn = torch.softmax(torch.randn(M, A, generator=g), -1)
+    po = torch.softmax(torch.randn(M, A, generator=g), -1)
+    val, adv, ret = (torch.randn(M, generator=g) for _ in range(3))
+    act = torch.randint(0, A, (M,), generator=g)
+    pn_d, po_d, val_d, adv_d, ret_d, act_d = (x.cuda() for x in (pn, po, val, adv, ret, act))
+
+    def ppo_hip():
+        p, v = pn_d.clone().requires_grad_(True), val_d.clone().requires_grad_(True)
+        ops.ppo_loss(p, v, po_d, act_d, adv_d, ret_d, None, 0.1, 1., 0.01)[0].backward()
+
+    def ppo_cpu():
+        p, v = pn.clone().requires_grad_(True), val.clone().requires_grad_(True)
+        O.ppo_loss_torch(p, v, po, act, adv, ret, None, 0.1, 1., 0.01)[0].backward()
+    both("ppo_loss_fwd_bwd", ppo_hip, ppo_cpu, shape=[M, A])
+    # ---- prioritized replay at the DQN config: 1M-leaf f64 tree, batch 128 ------------------
+    Tr, Br, n = 62500, 16, 128
+    tree_d = ops.DeviceSumTree(Tr, Br, 1, 3, default_value=1.0)
+    tree_c = O.SumTree(Tr, Br, 1, 3, default_value=1.0)
+    pri = np.abs(rng.randn(2000, Br)) ** 0.6
+    tree_d.advance(2000)
+    tree_c.advance(2000)
+    u = rng.rand(n)
+    u_d = torch.from_numpy(u).cuda()
+    newp = np.abs(rng.randn(n)) ** 0.6
+    newp_d = torch.from_numpy(newp).cuda()
+    del pri
+
+    def tree_hip():
+        tree_d.sample(u_d)
+        tree_d.update_batch_priorities(newp_d)
+
+    def tree_cpu():
+        tree_c.sample_with(u)
+        tree_c.update_batch_priorities(newp)
+    both("sumtree_sample_update", tree_hip, tree_cpu, leaves=Tr * Br, n=n)
+    us = _hip_us(lambda: tree_d.sample(u_d))
+    replay = {"sumtree_sample": {"bound": "latency", "avg_us": round(us, 2),
+                                 "ns_per_sample": round(us * 1e3 / n, 1),
+                                 "levels": int(tree_d.tree_levels)}}
+    # ---- frame gathers (uint8, bit-exact): DQN batch and the R2D1 sequence batch ------------
+    C, H, W, Tf, Bf = 4, 104, 80, 4096, 16
+    frames = torch.randint(0, 256, (Tf + C - 1, Bf, H, W), dtype=torch.uint8, generator=g)
+    fdone = torch.rand(Tf, Bf, generator=g) < 0.005
+    f_d, fd_d = frames.cuda(), fdone.cuda()
+    f_n, fd_n = frames.numpy(), fdone.numpy()
+    ti = rng.randint(C, Tf - 200, size=n)
+    bi = rng.randint(0, Bf, size=n)
+    ti_d, bi_d = torch.from_numpy(ti).cuda(), torch.from_numpy(bi).cuda()
+    out_d = torch.empty((n, C, H, W), dtype=torch.uint8, device="cuda")
+    both("frames_gather", lambda: ops.frames_gather(f_d, fd_d, ti_d, bi_d, C, out=out_d),
+         lambda: O.frames_gather(f_n, fd_n, ti, bi, C), n=n)
+    nb = n * C * H * W * 2
+    replay["frames_gather"] = {"bound": "hbm", "avg_us": res["frames_gather"]["hip_us"],
+                               "alg_bytes_per_launch": nb,
+                               "achieved": nb / res["frames_gather"]["hip_us"] / 1e3,
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+    ns, seq_T = 64, 125
+    out_s = torch.empty((seq_T, ns, C, H, W), dtype=torch.uint8, device="cuda")
+    both("frames_gather_seq",
+         lambda: ops.frames_gather_seq(f_d, fd_d, ti_d[:ns], bi_d[:ns], C, seq_T, out=out_s),
+         lambda: O.frames_gather_seq(f_n, fd_n, ti[:ns], bi[:ns], C, seq_T), n=ns, seq_T=seq_T)
+    nb = ns * (seq_T + C - 1) * H * W + seq_T * ns * C * H * W      # SURVEY 8(d): 334 MB
+    replay["frames_gather_seq"] = {"bound": "hbm",
+                                   "avg_us": res["frames_gather_seq"]["hip_us"],
+                                   "alg_bytes_per_launch": nb,
+                                   "achieved": nb / res["frames_gather_seq"]["hip_us"] / 1e3,
+                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+    for k in ("frames_gather", "frames_gather_seq"):
+        replay[k]["frac"] = replay[k]["achieved"] / HBM_PEAK_GBPS
+    res["roofline_replay"] = replay
+    return res
 
 
 def cpu_baseline(T, B_cpu, env_kwargs):

@@ -291,11 +291,14 @@ int rlpyt_categorical_head_f32(const float* h /*[n,K]*/, const float* w_pi /*[A,
 
 /* The sampler master's steady-state loop over time steps [t_begin, t_end) in native code --
  * the role of ActionServer.serve_actions (rlpyt/samplers/parallel/gpu/action_server.py:44-58)
- * once each pipeline group's per-step device work is a captured hipGraph.  Per step, for every
- * group: wait for its env workers (rlpyt_seq_wait on obs_word), enqueue the H2D copies of the
- * page-locked step buffer (frame-stacked envs: newest frames + the full stack of reset envs,
- * t == 0: all full stacks), hipGraphLaunch, enqueue the D2H action copies, record `event`;
- * then for every group: hipEventSynchronize + rlpyt_seq_post(act_word).  `acts` / `rounds`
+ * once each pipeline group's per-step device work is a captured hipGraph.  Event-driven: each
+ * group cycles on its own -- env workers arrived (obs_word reached rounds * n_workers) ->
+ * enqueue the H2D copies of the page-locked step buffer (frame-stacked envs: newest frames +
+ * the full stack of reset envs, t == 0: all full stacks), hipGraphLaunch, enqueue the D2H
+ * action copies, record `event` -> event fired (hipEventQuery) -> rlpyt_seq_post(act_word) --
+ * and the caller's thread services whichever hand-off is ready, so groups overlap freely and
+ * may be at different time steps (each step's index reaches the device through t_host).
+ * Returns RLPYT_ETIMEOUT after timeout_ms without any progress.  `acts` / `rounds`
  * are the running hand-off counters (updated in place).  timing[3] accumulates seconds spent
  * waiting for envs / issuing / waiting for the device.  Host pointers; blocks the caller. */
 typedef struct rlpyt_copy_desc {
@@ -388,6 +391,18 @@ int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat_idx /*null
                               float scale, float* y1, rlpyt_stream_t stream);
 int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float* w2, const float* b2,
                               float* y2, rlpyt_stream_t stream);
+/* Sampling-step front end in ONE launch (one environment per workgroup): the frame-stack push of
+ * rlpyt_frame_push (obs[t, lo+b] rebuilt from slot / full_rows / obs[t-1] / new_frame, t = *t_dev,
+ * optional reward/done row commit) followed by conv1 and conv2 of rlpyt_atari_conv{1,2}_fwd_f32 on
+ * the rebuilt stack, which stays in LDS -- y1 never exists in HBM.  y2 f32 [Bg, 3456]; results
+ * are bit-identical to the three separate launches (same accumulation order). */
+int rlpyt_atari_sample_convs_f32(uint8_t* obs, const int64_t* t_dev, int64_t B, int64_t lo,
+                                 int64_t Bg, const uint8_t* new_frame, const uint8_t* full_rows,
+                                 const int32_t* slot, float* reward_rows /*nullable*/,
+                                 const float* reward_src, uint8_t* done_rows,
+                                 const uint8_t* done_src, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, float scale, float* y2,
+                                 rlpyt_stream_t stream);
 int rlpyt_atari_conv2_dgrad_f32(const float* g2, const float* y2, const float* y1, int64_t M,
                                 const float* w2, float* dy1, rlpyt_stream_t stream);
 int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void);

@@ -117,6 +117,8 @@ _SIGNATURES = {
                                                               c_int64, c_int64, _p, _p]),
     "rlpyt_atari_conv1_fwd_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, _p, c_float, _p, _p]),
     "rlpyt_atari_conv2_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p]),
+    "rlpyt_atari_sample_convs_f32": (c_int, [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, _p, _p,
+                                             _p, _p, _p, _p, _p, _p, c_float, _p, _p]),
     "rlpyt_atari_conv2_dgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p]),
     "rlpyt_atari_conv_wgrad_workspace_bytes": (c_int64, []),
     "rlpyt_atari_conv2_wgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p, _p]),

@@ -103,7 +103,10 @@ class BaseAgent:
         """Optional fast path of ``step`` for HBM-resident samplers: run the sampling forward
         AND write action[t+1] / agent_info[t] rows of the bound batch (``binding``: the sampler's
         ``StepBinding``) plus the host-bound action copy.  Return False to decline (the caller
-        then uses ``step`` and commits the rows itself)."""
+        then uses ``step`` and commits the rows itself).  When ``binding.push`` is set (the
+        sampler's ``FramePush``) the sampler has NOT yet rebuilt row ``t`` of the frame-stacked
+        observation batch: an agent that accepts must do that too (``observation`` is then
+        None); declining makes the sampler push the frames itself and ask again without it."""
         return False
 
     def reset(self):

@@ -78,6 +78,9 @@ class CategoricalPgAgent(BaseAgent):
         out = _HeadOut(prob_rows=info.dist_info.prob, value_rows=info.value,
                        action_rows=binding.action_rows, action_out=binding.action_out,
                        uniforms=binding.uniforms, t_dev=binding.t_dev, lo=binding.lo)
+        push = getattr(binding, "push", None)
+        if push is not None:      # the model also rebuilds the frame stacks of row t
+            return bool(m.sample_step_into(None, out, push=push))
         return bool(m.sample_step_into(observation, out))
 
     @torch.no_grad()

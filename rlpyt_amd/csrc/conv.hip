@@ -725,6 +725,182 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// ======================================================================================
+// Sampling-step front end: frame-stack push + conv1 + conv2 of ONE environment per workgroup.
+// The rollout's per-step device work is latency-bound (85..256 images per launch): as three
+// kernels (frame_push, conv1_fwd, conv2_fwd) it paid three launches and two HBM round trips
+// for ~2.5 us of MFMA work per image.  Here one 16-wave workgroup
+//   1. rebuilds the env's frame stack (slot >= 0: a full row uploaded by the host, else the
+//      previous row shifted by one frame + the newest frame), writes it to obs[t] and keeps it
+//      in LDS; workgroup 0 also commits the step's reward / done rows;
+//   2. conv1: the 15 tile pairs of the image, one per wave, results (bias, ReLU) go straight
+//      into the zero-bordered LDS plane conv2 reads -- y1 never exists in HBM;
+//   3. conv2: 7 position tiles x 2 channel tiles, one per wave, y2 -> HBM (NCHW-flat).
+// Both weight sets are staged in LDS with row strides chosen so the per-lane operand reads
+// (stride 256 floats in the plain layout: 16..32-way bank conflicts) are at most 2-way.
+// Accumulation orders equal conv1_fwd_kernel / conv2_fwd_kernel: results are bit-identical.
+// ======================================================================================
+constexpr int SC_THREADS = 1024;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Global loads whose issue point the compiler cannot move: left alone it sinks every prologue
+// load to its first use and emits load, wait, store, load, wait, store (one HBM latency per
+// load instead of one for all); `volatile` is worse (a full wait after each load).  The data
+// are only valid after loads_wait().
+__device__ __forceinline__ u32x4 load16_issue(const void* p) {
+  u32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ float load4_issue(const void* p) {
+  float r;
+  asm volatile("global_load_dword %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ void loads_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+constexpr int WS1 = 260;                  // staged conv1 weights: [16][260] floats
+constexpr int WS2 = 260, WS2_KQ = 65;     // staged conv2 weights: [32][4 x 65] floats
+
+__global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
+    uint8_t* __restrict__ obs_w, const uint8_t* __restrict__ obs_r,
+    const int64_t* __restrict__ t_dev, int64_t B, int64_t lo,
+    const uint8_t* __restrict__ new_frame, const uint8_t* __restrict__ full_rows,
+    const int32_t* __restrict__ slot, float* __restrict__ reward_rows,
+    const float* __restrict__ reward_src, uint8_t* __restrict__ done_rows,
+    const uint8_t* __restrict__ done_src, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    float scale, float* __restrict__ y2) {
+  // obs_w / obs_r are the SAME batch array: row t is only written (through obs_w), row t-1 only
+  // read (through obs_r), so the two restrict views never touch the same bytes -- with a single
+  // pointer the compiler must order each row-(t-1) load after the previous row-t store
+  // (load, wait, store, load, wait, ... instead of all loads in flight together)
+  __shared__ __attribute__((aligned(16))) uint8_t img[IMG];            // 33,280 B
+  __shared__ float bs[C1 + C2];                                        // biases
+  __shared__ __attribute__((aligned(16))) float w1s[C1 * WS1];         // 16,640 B
+  __shared__ __attribute__((aligned(16))) float w2s[C2 * WS2];         // 33,280 B
+  __shared__ __attribute__((aligned(16))) float pad[PPIX * PS_F];      // 41,600 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int64_t b = blockIdx.x;
+  const int64_t t = *t_dev;
+  if (reward_rows != nullptr && b == 0) {
+    for (int i = tid; i < (int)gridDim.x; i += SC_THREADS) {
+      reward_rows[t * B + lo + i] = reward_src[i];
+      done_rows[t * B + lo + i] = done_src[i];
+    }
+  }
+  // ---- 1. all global loads of the prologue in flight together ----------------------------
+  constexpr int N16 = IMG / 16, HW16 = HW0 / 16;           // 2080 and 520 16-byte words
+  const int sl = slot[b];
+  const u32x4* __restrict__ full =
+      reinterpret_cast<const u32x4*>(full_rows + (int64_t)(sl < 0 ? 0 : sl) * IMG);
+  const u32x4* __restrict__ prev =
+      reinterpret_cast<const u32x4*>(obs_r + ((t - 1) * B + lo + b) * IMG);
+  const u32x4* __restrict__ nf = reinterpret_cast<const u32x4*>(new_frame + b * HW0);
+  u32x4 v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = min(tid + k * SC_THREADS, N16 - 1);      // clamped: unconditional loads
+    const u32x4* p = sl >= 0 ? full + i : (i < N16 - HW16 ? prev + i + HW16 : nf + (i - (N16 - HW16)));
+    v[k] = load16_issue(p);
+  }
+  const u32x4 a1 = load16_issue(reinterpret_cast<const u32x4*>(w1) + tid);   // 1024 x 16 B
+  const u32x4 a2 = load16_issue(reinterpret_cast<const u32x4*>(w2) + tid);   // 2048 x 16 B
+  const u32x4 a3 = load16_issue(reinterpret_cast<const u32x4*>(w2) + tid + SC_THREADS);
+  const int bi = min(tid, C1 + C2 - 1);
+  const float bias_in = load4_issue(bi < C1 ? b1 + bi : b2 + (bi - C1));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {                                        // border stays zero
+    const int i = tid + k * SC_THREADS;
+    if (i < PPIX * PS_F / 4) reinterpret_cast<f32x4*>(pad)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(obs_w + (t * B + lo + b) * IMG);
+  loads_wait();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = tid + k * SC_THREADS;
+    if (i < N16) {
+      reinterpret_cast<u32x4*>(img)[i] = v[k];
+      dst[i] = v[k];
+    }
+  }
+  if (tid < C1 + C2) bs[tid] = bias_in;
+  *reinterpret_cast<u32x4*>(w1s + (tid >> 6) * WS1 + (tid & 63) * 4) = a1;
+  {
+    const float* f2 = reinterpret_cast<const float*>(&a2);
+    const float* f3 = reinterpret_cast<const float*>(&a3);
+    const int k = (tid & 63) * 4;                                      // k = kq'*64 + rem
+    float* d2 = w2s + (tid >> 6) * WS2 + (k >> 6) * WS2_KQ + (k & 63);
+    float* d3 = d2 + 16 * WS2;                                         // rows 16..31
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d2[e] = f2[e]; d3[e] = f3[e]; }
+  }
+  __syncthreads();
+  // ---- 2. conv1: tile pair `wave` -> padded LDS plane ------------------------------------
+  float wa[64];
+  if (wave < 15) {
+#pragma unroll
+    for (int s = 0; s < 64; ++s) wa[s] = w1s[j * WS1 + 4 * s + kq];
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = bs[4 * kq + r];
+    const int pos0 = wave * 32 + j, pos1 = pos0 + 16;
+    const int q0 = min(pos0, P1 - 1), q1 = min(pos1, P1 - 1);
+    const int a0 = (q0 / W1) * (4 * W0) + (q0 % W1) * 4 + kq;
+    const int a1o = (q1 / W1) * (4 * W0) + (q1 % W1) * 4 + kq;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+      const int off = (s >> 4) * HW0 + ((s >> 1) & 7) * W0 + (s & 1) * 4;
+      const float x0 = (float)img[a0 + off];
+      const float x1 = (float)img[a1o + off];
+      acc0 = mfma16(wa[s], x0, acc0);
+      acc1 = mfma16(wa[s], x1, acc1);
+    }
+    if (pos0 < P1) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc0[r] * scale + bias[r], 0.f);
+      *reinterpret_cast<f32x4*>(pad + ((pos0 / W1 + 1) * PW + pos0 % W1 + 1) * PS_F + 4 * kq) = o;
+    }
+    if (pos1 < P1) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc1[r] * scale + bias[r], 0.f);
+      *reinterpret_cast<f32x4*>(pad + ((pos1 / W1 + 1) * PW + pos1 % W1 + 1) * PS_F + 4 * kq) = o;
+    }
+  }
+  __syncthreads();
+  // ---- 3. conv2: channel tile ct, position tile `tile` -----------------------------------
+  const int ct = wave & 1, tile = wave >> 1;
+  if (tile < 7) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp)
+        wa[kk * 4 + sp] = w2s[(ct * 16 + j) * WS2 + kq * WS2_KQ + sp * 16 + kk];
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = bs[C1 + ct * 16 + 4 * kq + r];
+    const int pos = min(tile * 16 + j, P2 - 1);
+    const int oy = pos / W2, ox = pos - oy * W2;
+    const int base = ((2 * oy) * PW + 2 * ox) * PS_F + 4 * kq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int off = ((kk >> 2) * PW + (kk & 3)) * PS_F;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(pad + base + off);
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) acc = mfma16(wa[kk * 4 + sp], bv[sp], acc);
+    }
+    if (tile * 16 + j < P2) {
+      float* out = y2 + b * F2 + (ct * 16 + 4 * kq) * P2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[r * P2 + pos] = fmaxf(acc[r] + bias[r], 0.f);
+    }
+  }
+}
+
 int grid_for(int64_t M, int per_cu) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -774,6 +950,29 @@ extern "C" int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float
   else
     hipLaunchKernelGGL((conv2_fwd_kernel<4>), dim3(grid_for(M, 3)), dim3(256), 0, (hipStream_t)stream,
                        y1, w2, b2, y2, M);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_atari_sample_convs_f32(
+    uint8_t* obs, const int64_t* t_dev, int64_t B, int64_t lo, int64_t Bg,
+    const uint8_t* new_frame, const uint8_t* full_rows, const int32_t* slot, float* reward_rows,
+    const float* reward_src, uint8_t* done_rows, const uint8_t* done_src, const float* w1,
+    const float* b1, const float* w2, const float* b2, float scale, float* y2,
+    rlpyt_stream_t stream) {
+  RL_CHECK_ARG(B > 0 && lo >= 0 && Bg >= 0 && lo + Bg <= B, RLPYT_EINVAL,
+               "rlpyt_atari_sample_convs_f32: bad sizes");
+  if (Bg == 0) return RLPYT_OK;
+  RL_CHECK_ARG(obs && t_dev && new_frame && full_rows && slot && w1 && b1 && w2 && b2 && y2,
+               RLPYT_EINVAL, "rlpyt_atari_sample_convs_f32: null pointer");
+  RL_CHECK_ARG((reward_rows == nullptr) || (reward_src && done_rows && done_src), RLPYT_EINVAL,
+               "rlpyt_atari_sample_convs_f32: reward/done rows go together");
+  RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(new_frame) && RL_ALIGNED16(full_rows) &&
+                   RL_ALIGNED16(w1) && RL_ALIGNED16(w2),
+               RLPYT_ESHAPE, "rlpyt_atari_sample_convs_f32: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(sample_convs_kernel, dim3((unsigned)Bg), dim3(SC_THREADS), 0,
+                     (hipStream_t)stream, obs, obs, t_dev, B, lo, new_frame, full_rows, slot,
+                     reward_rows, reward_src, done_rows, done_src, w1, b1, w2, b2, scale, y2);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

@@ -111,19 +111,34 @@ class AtariFfModel(torch.nn.Module):
                 and w.shape[1] in (256, 512))
 
     @torch.no_grad()
-    def sample_step_into(self, image, out):
+    def sample_step_into(self, image, out, push=None):
         """Sampling forward that also performs the step's row writes (``out``: the sampler's
         ``StepBinding``): conv stack -> split-K trunk -> ONE kernel that finishes the trunk, runs
         the heads + softmax + draw and writes prob[t], value[t], action[t+1] and the host-bound
-        action copy.  Returns False when this fused path does not apply."""
+        action copy.  With ``push`` (the sampler's ``FramePush``: frame-stacked uint8 batch whose
+        row ``t`` is rebuilt on the device) the frame push and both convolutions are one launch
+        and ``image`` is not read.  Returns False when this fused path does not apply."""
         from ... import ops
         lin = self._single_fc()
-        if not (isinstance(image, torch.Tensor) and image.is_cuda and image.dtype == torch.uint8
-                and image.dim() == 4 and self.fused_conv and self.fused_head_loss
-                and lin is not None and image.shape[0] <= 256 and lin.in_features % 16 == 0):
+        if push is not None:
+            obs = push.obs
+            ok = (obs.is_cuda and obs.dtype == torch.uint8 and obs.dim() == 5
+                  and tuple(obs.shape[2:]) == (4, 104, 80) and push.new_frame.shape[0] <= 256)
+        else:
+            ok = (isinstance(image, torch.Tensor) and image.is_cuda
+                  and image.dtype == torch.uint8 and image.dim() == 4 and image.shape[0] <= 256)
+        if not (ok and self.fused_conv and self.fused_head_loss and lin is not None
+                and lin.in_features % 16 == 0):
             return False
-        B = image.shape[0]
-        feat = self._conv_features(image.contiguous(), None)
+        if push is not None:
+            B = push.new_frame.shape[0]
+            c1, c2 = self.conv.conv.conv[0], self.conv.conv.conv[2]
+            feat = ops.atari_sample_convs(obs, out.t_dev, out.lo, push.new_frame, push.full_rows,
+                                          push.slot, c1.weight, c1.bias, c2.weight, c2.bias,
+                                          scalar_rows=push.scalar_rows)
+        else:
+            B = image.shape[0]
+            feat = self._conv_features(image.contiguous(), None)
         partial, ksplit = ops.fc_small_partials(feat, lin.weight)
         ops.pg_sample_head(partial, ksplit, lin.bias, self.pi.weight, self.pi.bias,
                            self.value.weight, self.value.bias, out.uniforms, out.t_dev, B,

@@ -675,6 +675,30 @@ def frame_push(obs, t_dev, lo, new_frame, full_rows, slot, stage=None, scalar_ro
                                ptr(ds), stream()), "rlpyt_frame_push")
 
 
+def atari_sample_convs(obs, t_dev, lo, new_frame, full_rows, slot, w1, b1, w2, b2,
+                       scalar_rows=None, scale=1. / 255, out=None):
+    """``frame_push`` + conv1 + conv2 of the AtariFfModel geometry in one launch (sampling
+    forward, no grad): rebuilds row ``t`` of ``obs [T,B,4,104,80]`` for columns ``lo:lo+Bg``
+    exactly like ``frame_push`` and returns the conv features ``[Bg, 3456]`` of the rebuilt
+    stacks (bit-identical to ``atari_conv_stack`` on that row)."""
+    _lib.require_gpu()
+    assert obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape[2:]) == (4, 104, 80)
+    B, Bg = obs.shape[1], new_frame.shape[0]
+    assert slot.dtype == torch.int32 and slot.numel() == Bg
+    rr = rs = dr = ds = None
+    if scalar_rows is not None:
+        rr, rs, dr, ds = scalar_rows
+        assert rr.dtype == torch.float32 and rr.shape[1] == B and dr.shape[1] == B
+        dr, ds = dr.view(torch.uint8), ds.view(torch.uint8)
+    if out is None:
+        out = torch.empty((Bg, 3456), dtype=torch.float32, device=obs.device)
+    check(lib.rlpyt_atari_sample_convs_f32(
+        ptr(obs), ptr(t_dev), B, int(lo), Bg, ptr(new_frame), ptr(full_rows), ptr(slot), ptr(rr),
+        ptr(rs), ptr(dr), ptr(ds), ptr(w1.contiguous()), ptr(b1), ptr(w2.contiguous()), ptr(b2),
+        float(scale), ptr(out), stream()), "rlpyt_atari_sample_convs_f32")
+    return out
+
+
 def categorical_head(h, w_pi, b_pi, w_v=None, b_v=None, uniforms=None, u_row=None):
     """Policy / value heads + softmax (+ inverse-CDF action sampling when ``uniforms`` is
     given) in one kernel -- the no-grad sampling forward of

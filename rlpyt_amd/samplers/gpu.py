@@ -13,7 +13,7 @@ rlpyt/samplers/parallel/{base,worker}.py), re-designed for a 288 GB device:
   counter, so the same graph serves every time step), (ii) runs the batched
   action-selection forward, (iii) samples the actions on the device and (iv) writes
   action / agent_info rows; only ``action[B]`` travels back to the host;
-* the environments are split into ``n_groups`` pipeline groups (default 2-3 with workers):
+* the environments are split into ``n_groups`` pipeline groups (default 2-4 with workers):
   while the device serves group g, the host cores step the environments of the other
   group, so per time step the wall time is max(device, host) instead of their sum.
   Groups are column ranges of the same ``[T, B]`` batch -- every column is still one
@@ -51,7 +51,10 @@ from .collections import AgentSamplesBsv, AgentSamples, EnvSamples, Samples
 StepBuffer = namedarraytuple("StepBuffer", ["observation", "action", "reward", "done"])
 # what an agent's ``step_into`` gets to write the rows of a step itself (see BaseAgent.step_into)
 StepBinding = namedtuple("StepBinding", ["action_rows", "agent_info_rows", "action_out",
-                                         "uniforms", "t_dev", "lo"])
+                                         "uniforms", "t_dev", "lo", "push"])
+# frame-stack rebuild of row t handed to the agent together with the step (see step_into):
+# the arguments of ``ops.frame_push`` minus the staging copy
+FramePush = namedtuple("FramePush", ["obs", "new_frame", "full_rows", "slot", "scalar_rows"])
 # frame-stacked envs additionally publish the newest frame and a "stack was reset" flag
 StepBufferFs = namedarraytuple("StepBufferFs", ["observation", "action", "reward", "done",
                                                 "frame", "reset"])
@@ -369,14 +372,14 @@ class GpuSampler(BaseSampler):
     """See module docstring.  ``mid_batch_reset=True`` behaves like GpuResetCollector,
     ``False`` like GpuWaitResetCollector.
 
-    ``n_groups``: pipeline groups (None: 3 for B >= 192 with worker processes, 2 for smaller
+    ``n_groups``: pipeline groups (None: 4 for B >= 192 with worker processes, 2 for smaller
     batches when B allows it, else 1).  ``use_graph``: capture the per-step device work in a hipGraph (GPU only)."""
 
     GRAPH_WARMUP_CALLS = 3   # eager calls per group before capture (MIOpen/hipBLASLt find)
 
     def __init__(self, *args, n_workers=0, mid_batch_reset=True, pin_step_buffer=True,
                  n_groups=None, use_graph=True, frame_dedup=True, native_loop=True, fused_step=True,
-                 split_workers=False, zero_copy=False, **kwargs):
+                 fused_push=True, split_workers=False, zero_copy=False, **kwargs):
         super().__init__(*args, **kwargs)
         self.n_workers = int(n_workers)
         self.mid_batch_reset = bool(mid_batch_reset)
@@ -385,16 +388,18 @@ class GpuSampler(BaseSampler):
         self.frame_dedup = bool(frame_dedup)
         self.native_loop = bool(native_loop)
         self.fused_step = bool(fused_step)
+        self.fused_push = bool(fused_push)
         self._split_workers = bool(split_workers)
         self.zero_copy = bool(zero_copy)
         self._native = None
         B = self.batch_spec.B
         if n_groups is None:
-            # measured at B=256 on the bench host (several runs each): 1 group 405 K SPS, 2 groups
-            # 472-476 K, 3 groups 477-501 K, 4 groups 452-468 K
+            # measured at B=256 on the bench host with the two-thread native step loop (~25 env
+            # workers): 2 groups 516 K SPS, 3 groups 533-541 K, 4 groups 561 K, 5 groups 555 K,
+            # 6 groups 541 K, 8 groups 496 K (with the earlier single-thread loop 3 was best)
             n_groups = 2 if (self.n_workers > 0 and B >= 2 * max(self.n_workers, 1)) else 1
             if n_groups == 2 and B >= 192:
-                n_groups = 3
+                n_groups = 4
         self.n_groups = max(1, min(int(n_groups), B))
         self._pinned_ptrs = []
         self.workers = []
@@ -700,6 +705,21 @@ class GpuSampler(BaseSampler):
         once); elsewhere torch ``index_copy_`` does the same thing leaf by leaf."""
         s, t = self.samples, G.t_dev
         lo, hi = G.lo, G.hi
+        fusable = (G.u_all is not None and self.mid_batch_reset and self.fused_step
+                   and isinstance(self._all_action, torch.Tensor))
+        if (fusable and G.dedup and G.pre_commit is not None and self.fused_push
+                and not self.agent.recurrent and not getattr(self.agent, "uses_prev_inputs", True)):
+            # frame push + forward + row writes all inside the agent's kernels
+            binding = StepBinding(
+                action_rows=self._all_action, agent_info_rows=s.agent.agent_info,
+                action_out=G.action_out, uniforms=G.u_all, t_dev=t, lo=lo,
+                push=FramePush(obs=s.env.observation, new_frame=G.frame_stage,
+                               full_rows=G.full_rows, slot=G.slot_stage,
+                               scalar_rows=(self._all_reward, G.reward_stage, self._all_done,
+                                            G.done_stage)))
+            if self.agent.step_into(None, None, None, binding):
+                G.post_entries = None
+                return
         if G.pre_commit is not None:
             if G.dedup:
                 # one launch: rebuild the frame stacks of row t + commit the reward/done rows
@@ -734,11 +754,11 @@ class GpuSampler(BaseSampler):
             self.agent.select_slot(G.idx)
             if self.mid_batch_reset:
                 self.agent.reset_where(G.done_stage)
-        if (G.u_all is not None and self.mid_batch_reset and self.fused_step
-                and isinstance(self._all_action, torch.Tensor)):
+        if fusable:
             # the agent runs the forward AND writes the step's rows (fused head kernel)
             binding = StepBinding(action_rows=self._all_action, agent_info_rows=s.agent.agent_info,
-                                  action_out=G.action_out, uniforms=G.u_all, t_dev=t, lo=lo)
+                                  action_out=G.action_out, uniforms=G.u_all, t_dev=t, lo=lo,
+                                  push=None)
             if self.agent.step_into(G.obs_stage, prev_action, prev_reward, binding):
                 G.post_entries = None
                 return

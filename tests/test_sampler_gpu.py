@@ -268,3 +268,76 @@ def test_zero_copy_step_buffer_matches_dma():
     for x, y in zip(a, b):
         for u, v in zip(x, y):
             assert torch.equal(u, v)
+
+
+def test_sample_convs_kernel_matches_separate_launches():
+    """rlpyt_atari_sample_convs_f32 (frame push + conv1 + conv2, one env per workgroup) against
+    rlpyt_frame_push followed by the two forward conv kernels: bit-identical rows and features,
+    for shifted stacks, reset slots and the reward/done row commit."""
+    from rlpyt_amd import ops
+    T, B, lo, Bg = 5, 12, 3, 7
+    g = torch.Generator().manual_seed(0)
+    obs_a = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    obs_b = obs_a.clone()
+    new_frame = torch.randint(0, 256, (Bg, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    full_rows = torch.randint(0, 256, (Bg, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    slot = torch.tensor([-1, 1, -1, -1, 0, -1, -1], dtype=torch.int32).cuda()
+    w1 = (0.05 * torch.randn(16, 4, 8, 8, generator=g)).cuda()
+    b1 = (0.1 * torch.randn(16, generator=g)).cuda()
+    w2 = (0.05 * torch.randn(32, 16, 4, 4, generator=g)).cuda()
+    b2 = (0.1 * torch.randn(32, generator=g)).cuda()
+    rew_src = torch.randn(Bg, generator=g).cuda()
+    done_src = (torch.rand(Bg, generator=g) < 0.5).cuda()
+    for t in (2, 4):
+        t_dev = torch.tensor([t], dtype=torch.int64).cuda()
+        rows_a = (torch.zeros(T + 1, B).cuda(), rew_src, torch.zeros(T + 1, B, dtype=torch.bool).cuda(),
+                  done_src)
+        rows_b = (torch.zeros(T + 1, B).cuda(), rew_src, torch.zeros(T + 1, B, dtype=torch.bool).cuda(),
+                  done_src)
+        stage = torch.empty((Bg, 4, 104, 80), dtype=torch.uint8, device="cuda")
+        ops.frame_push(obs_a, t_dev, lo, new_frame, full_rows, slot, stage=stage, scalar_rows=rows_a)
+        ref = ops.atari_conv_stack(stage, None, w1, b1, w2, b2)
+        got = ops.atari_sample_convs(obs_b, t_dev, lo, new_frame, full_rows, slot, w1, b1, w2, b2,
+                                     scalar_rows=rows_b)
+        torch.cuda.synchronize()
+        assert torch.equal(obs_a, obs_b)
+        assert torch.equal(rows_a[0], rows_b[0]) and torch.equal(rows_a[2], rows_b[2])
+        assert float(rows_b[0][t, lo:lo + Bg].abs().sum()) > 0
+        assert got.shape == (Bg, 3456) and torch.equal(got, ref.reshape(Bg, -1))
+        # against torch's own convolutions in float64 (the tolerance of tests/test_conv_gpu.py)
+        x = stage.double() / 255
+        y = torch.relu(torch.nn.functional.conv2d(x, w1.double(), b1.double(), stride=4))
+        y = torch.relu(torch.nn.functional.conv2d(y, w2.double(), b2.double(), stride=2, padding=1))
+        err = (got.double() - y.reshape(Bg, -1)).abs().max().item()
+        assert err <= 2e-5 * y.abs().max().item() + 1e-6, err
+
+
+def test_fused_push_step_matches_separate_push():
+    """Sampler level: with the frame push folded into the agent's conv launch the batches are
+    exactly those of the separate frame_push launch, through resets, over several batches."""
+    def run(fused_push):
+        s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=7), batch_T=6, batch_B=8,
+                       n_workers=2, n_groups=2, fused_push=fused_push, max_decorrelation_steps=0)
+        a = AtariFfAgent()
+        torch.manual_seed(51)
+        np.random.seed(51)
+        s.initialize(a, seed=10, bootstrap_value=True)
+        torch.cuda.set_device(0)
+        a.to_device(0)
+        torch.manual_seed(52)
+        out = []
+        for itr in range(5):
+            smp, _ = s.obtain_samples(itr)
+            torch.cuda.synchronize()
+            out.append([x.clone() for x in (smp.env.observation, smp.agent.action,
+                                            smp.env.reward, smp.env.done,
+                                            smp.agent.agent_info.dist_info.prob,
+                                            smp.agent.agent_info.value,
+                                            smp.agent.bootstrap_value)])
+        s.shutdown()
+        return out
+    a, b = run(True), run(False)
+    assert any(x[3].any() for x in a)          # resets really happened
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
