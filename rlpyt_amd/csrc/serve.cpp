@@ -76,9 +76,22 @@ int issue_group_step(rlpyt_step_group& g, int t) {
 namespace {
 enum : int { WAIT_OBS = 0, WAIT_DEV = 1, DONE = 2, FAILED = 3 };
 
+// Idle policy of both threads: poll for `spin_iters` consecutive empty passes (hand-offs are
+// ~50 us apart when the pipeline is full), then sleep ~20 us per pass until something moves --
+// with slow environments, or when the process tree runs under a tight CPU quota (spin_iters = 0),
+// polling threads would only take cores away from the env workers.
+inline void idle_pause(int& idle, int spin_iters) {
+  if (++idle > spin_iters) {
+    struct timespec ts = {0, 20 * 1000};
+    nanosleep(&ts, nullptr);
+  } else {
+    __builtin_ia32_pause();
+  }
+}
+
 struct ServeShared {
   rlpyt_step_group* groups;
-  int n_groups, t_end, device;
+  int n_groups, t_end, device, spin_iters;
   std::atomic<int> state[16];
   int tcur[16];
   std::atomic<int> remaining;
@@ -89,6 +102,7 @@ struct ServeShared {
 void retire_loop(ServeShared* sh) {
   (void)hipSetDevice(sh->device);
   double idle = 0., t_prev = now_s();
+  int idle_passes = 0;
   while (sh->remaining.load(std::memory_order_acquire) > 0 &&
          sh->error.load(std::memory_order_relaxed) == 0) {
     bool progressed = false, in_flight = false;
@@ -119,7 +133,9 @@ void retire_loop(ServeShared* sh) {
     const double t_now = now_s();
     if (!progressed) {
       if (in_flight) idle += t_now - t_prev;
-      __builtin_ia32_pause();
+      idle_pause(idle_passes, sh->spin_iters);
+    } else {
+      idle_passes = 0;
     }
     t_prev = t_now;
   }
@@ -132,9 +148,9 @@ extern "C" int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t
   RL_CHECK_ARG(groups != nullptr && n_groups > 0 && n_groups <= 16 && t_begin >= 0 &&
                    t_end >= t_begin,
                RLPYT_EINVAL, "rlpyt_sampler_serve: bad arguments");
-  (void)spin_iters;
   if (t_begin == t_end) return RLPYT_OK;
   ServeShared sh;
+  sh.spin_iters = spin_iters;
   sh.groups = groups;
   sh.n_groups = n_groups;
   sh.t_end = t_end;
@@ -151,7 +167,7 @@ extern "C" int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t
   std::thread retire(retire_loop, &sh);
   double t_wait_env = 0., t_issue = 0.;
   double t_prev = now_s(), t_progress = t_prev;
-  int rc_out = RLPYT_OK;
+  int rc_out = RLPYT_OK, idle_passes = 0;
   while (sh.remaining.load(std::memory_order_acquire) > 0) {
     if (sh.error.load(std::memory_order_relaxed) != 0) break;
     bool progressed = false, waiting_env = false;
@@ -176,6 +192,7 @@ extern "C" int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t
     const double t_now = now_s();
     if (progressed) {
       t_progress = t_now;
+      idle_passes = 0;
     } else {
       if (waiting_env) t_wait_env += t_now - t_prev;
       if (timeout_ms > 0 && (t_now - t_progress) * 1e3 > (double)timeout_ms) {
@@ -190,7 +207,7 @@ extern "C" int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t
           break;
         }
       }
-      __builtin_ia32_pause();
+      idle_pause(idle_passes, spin_iters);
     }
     t_prev = t_now;
   }

@@ -939,6 +939,16 @@ class GpuSampler(BaseSampler):
             self._native = None
             return False
 
+    def _serve_spin(self):
+        """Idle passes the two serve threads may poll before they start sleeping: polling needs
+        two spare cores per rank on top of the env workers; under a tight CPU quota (several
+        ranks in one quota-limited container) the threads sleep between hand-offs instead."""
+        if getattr(self, "_spin", None) is None:
+            from ..utils.misc import usable_cpus
+            per_rank = usable_cpus() / max(self.world_size, 1)
+            self._spin = 20000 if per_rank >= 6 else 0
+        return self._spin
+
     def _serve_native(self, T):
         from .. import _lib
         arr = self._native
@@ -946,7 +956,7 @@ class GpuSampler(BaseSampler):
             sg.acts, sg.rounds = self.sync.acts[G.idx] & 0xffffffff, self.sync.rounds[G.idx] & 0xffffffff
         tmg = self._native_timing
         tmg[0] = tmg[1] = tmg[2] = 0.
-        _lib.check(_lib.lib.rlpyt_sampler_serve(arr, len(self.groups), 0, T, _StepSync.MASTER_SPIN,
+        _lib.check(_lib.lib.rlpyt_sampler_serve(arr, len(self.groups), 0, T, self._serve_spin(),
                                                 120000, tmg), "rlpyt_sampler_serve")
         for G in self.groups:
             self.sync.acts[G.idx] += T
