@@ -354,7 +354,8 @@ def isolated_functions(T, B):
     def ppo_cpu():
         p, v = pn.clone().requires_grad_(True), val.clone().requires_grad_(True)
         O.ppo_loss_torch(p, v, po, act, adv, ret, None, 0.1, 1., 0.01)[0].backward()
-    both("ppo_loss_fwd_bwd", ppo_hip, ppo_cpu, shape=[M, A])
+    both("ppo_loss_fwd_bwd", ppo_hip, ppo_cpu, shape=[M, A],
+         note="whole autograd op (clone + forward + backward), not the bare kernel")
     # ---- prioritized replay at the DQN config: 1M-leaf f64 tree, batch 128 ------------------
     Tr, Br, n = 62500, 16, 128
     tree_d = ops.DeviceSumTree(Tr, Br, 1, 3, default_value=1.0)

@@ -726,21 +726,26 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 // ======================================================================================
-// Sampling-step front end: frame-stack push + conv1 + conv2 of ONE environment per workgroup.
-// The rollout's per-step device work is latency-bound (85..256 images per launch): as three
+// Sampling-step front end: frame-stack push + conv1 + conv2, four workgroups per environment.
+// The rollout's per-step device work is latency-bound (64..256 images per launch): as three
 // kernels (frame_push, conv1_fwd, conv2_fwd) it paid three launches and two HBM round trips
-// for ~2.5 us of MFMA work per image.  Here one 16-wave workgroup
-//   1. rebuilds the env's frame stack (slot >= 0: a full row uploaded by the host, else the
-//      previous row shifted by one frame + the newest frame), writes it to obs[t] and keeps it
-//      in LDS; workgroup 0 also commits the step's reward / done rows;
-//   2. conv1: the 15 tile pairs of the image, one per wave, results (bias, ReLU) go straight
-//      into the zero-bordered LDS plane conv2 reads -- y1 never exists in HBM;
-//   3. conv2: 7 position tiles x 2 channel tiles, one per wave, y2 -> HBM (NCHW-flat).
-// Both weight sets are staged in LDS with row strides chosen so the per-lane operand reads
-// (stride 256 floats in the plain layout: 16..32-way bank conflicts) are at most 2-way.
-// Accumulation orders equal conv1_fwd_kernel / conv2_fwd_kernel: results are bit-identical.
+// for ~10 us of MFMA work per image.  Here every workgroup (16 waves) owns 3 of the 12 conv2
+// output rows of one environment and
+//   1. rebuilds the 36 image rows per frame those need (slot >= 0: a full row uploaded by the
+//      host, else the previous row shifted by one frame + the newest frame) into LDS and writes
+//      its quarter of the stack to obs[t]; workgroup 0 also commits the reward / done rows;
+//   2. conv1 of the <= 8 y1 rows it needs (28 % recomputed across the four parts), one
+//      16-position tile per wave, results (bias, ReLU) straight into the zero-bordered LDS
+//      plane conv2 reads -- y1 never exists in HBM;
+//   3. conv2 of its 27 positions (2 position x 2 channel tiles, one wave each), y2 -> HBM.
+// One environment per workgroup measured 18.5 us at 64 envs: 2816 MFMAs x 32 clk on the 4 SIMDs
+// of ONE CU are 9.4 us by themselves while three quarters of the chip idle; split four ways the
+// MFMA work per CU is ~3 us.  Both weight sets are staged in LDS with row strides chosen so the
+// per-lane operand reads (stride 256 floats in the plain layout: 16..32-way bank conflicts) are
+// at most 2-way.  Accumulation orders equal conv1_fwd_kernel / conv2_fwd_kernel: bit-identical.
 // ======================================================================================
 constexpr int SC_THREADS = 1024;
+constexpr int SC_PARTS = 4;               // workgroups per environment (3 conv2 output rows each)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Global loads whose issue point the compiler cannot move: left alone it sinks every prologue
@@ -781,29 +786,33 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
   __shared__ __attribute__((aligned(16))) float pad[PPIX * PS_F];      // 41,600 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
-  const int64_t b = blockIdx.x;
+  const int64_t b = blockIdx.x / SC_PARTS;
+  const int part = (int)(blockIdx.x % SC_PARTS);
   const int64_t t = *t_dev;
-  if (reward_rows != nullptr && b == 0) {
-    for (int i = tid; i < (int)gridDim.x; i += SC_THREADS) {
+  if (reward_rows != nullptr && blockIdx.x == 0) {
+    for (int i = tid; i < (int)(gridDim.x / SC_PARTS); i += SC_THREADS) {
       reward_rows[t * B + lo + i] = reward_src[i];
       done_rows[t * B + lo + i] = done_src[i];
     }
   }
+  // This part owns conv2 output rows [3*part, 3*part+3).  They read y1 rows [ya, yb)
+  // (2*oy-1 .. 2*oy+2), which read image rows [4*ya, 4*ya + 36); of the rebuilt stack the part
+  // writes rows [26*part, 26*part+26) of every frame to obs[t] (always inside what it loaded).
+  const int ya = max(6 * part - 1, 0), yb = 6 * part + 7;              // <= 8 y1 rows
+  const int r0 = 4 * ya;                                               // first image row loaded
   // ---- 1. all global loads of the prologue in flight together ----------------------------
-  constexpr int N16 = IMG / 16, HW16 = HW0 / 16;           // 2080 and 520 16-byte words
+  constexpr int HW16 = HW0 / 16, ROW16 = W0 / 16;                      // 520, 5 words of 16 B
+  constexpr int LROWS = 36, LW = LROWS * ROW16;                        // 180 words per frame
   const int sl = slot[b];
   const u32x4* __restrict__ full =
       reinterpret_cast<const u32x4*>(full_rows + (int64_t)(sl < 0 ? 0 : sl) * IMG);
   const u32x4* __restrict__ prev =
       reinterpret_cast<const u32x4*>(obs_r + ((t - 1) * B + lo + b) * IMG);
   const u32x4* __restrict__ nf = reinterpret_cast<const u32x4*>(new_frame + b * HW0);
-  u32x4 v[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int i = min(tid + k * SC_THREADS, N16 - 1);      // clamped: unconditional loads
-    const u32x4* p = sl >= 0 ? full + i : (i < N16 - HW16 ? prev + i + HW16 : nf + (i - (N16 - HW16)));
-    v[k] = load16_issue(p);
-  }
+  const int lt = min(tid, C0 * LW - 1);                                // clamped: unconditional load
+  const int fc = lt / LW, fw = r0 * ROW16 + (lt - fc * LW);            // frame, word inside it
+  const int iw = fc * HW16 + fw;                                       // word inside the stack
+  const u32x4 v = load16_issue(sl >= 0 ? full + iw : (fc < C0 - 1 ? prev + iw + HW16 : nf + fw));
   const u32x4 a1 = load16_issue(reinterpret_cast<const u32x4*>(w1) + tid);   // 1024 x 16 B
   const u32x4 a2 = load16_issue(reinterpret_cast<const u32x4*>(w2) + tid);   // 2048 x 16 B
   const u32x4 a3 = load16_issue(reinterpret_cast<const u32x4*>(w2) + tid + SC_THREADS);
@@ -816,13 +825,10 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
   }
   u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(obs_w + (t * B + lo + b) * IMG);
   loads_wait();
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int i = tid + k * SC_THREADS;
-    if (i < N16) {
-      reinterpret_cast<u32x4*>(img)[i] = v[k];
-      dst[i] = v[k];
-    }
+  if (tid < C0 * LW) {
+    reinterpret_cast<u32x4*>(img)[iw] = v;
+    const int row = fw / ROW16;
+    if (row >= 26 * part && row < 26 * part + 26) dst[iw] = v;
   }
   if (tid < C1 + C2) bs[tid] = bias_in;
   *reinterpret_cast<u32x4*>(w1s + (tid >> 6) * WS1 + (tid & 63) * 4) = a1;
@@ -836,44 +842,35 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
     for (int e = 0; e < 4; ++e) { d2[e] = f2[e]; d3[e] = f3[e]; }
   }
   __syncthreads();
-  // ---- 2. conv1: tile pair `wave` -> padded LDS plane ------------------------------------
+  // ---- 2. conv1 of y1 rows [ya, yb): one 16-position tile per wave -> padded LDS plane ----
   float wa[64];
-  if (wave < 15) {
+  const int npos = (yb - ya) * W1;                                     // <= 152
+  if (wave * 16 < npos) {
 #pragma unroll
     for (int s = 0; s < 64; ++s) wa[s] = w1s[j * WS1 + 4 * s + kq];
     float bias[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[r] = bs[4 * kq + r];
-    const int pos0 = wave * 32 + j, pos1 = pos0 + 16;
-    const int q0 = min(pos0, P1 - 1), q1 = min(pos1, P1 - 1);
-    const int a0 = (q0 / W1) * (4 * W0) + (q0 % W1) * 4 + kq;
-    const int a1o = (q1 / W1) * (4 * W0) + (q1 % W1) * 4 + kq;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int lpos = wave * 16 + j;
+    const int q = ya * W1 + min(lpos, npos - 1);
+    const int a0 = (q / W1) * (4 * W0) + (q % W1) * 4 + kq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 64; ++s) {
       const int off = (s >> 4) * HW0 + ((s >> 1) & 7) * W0 + (s & 1) * 4;
-      const float x0 = (float)img[a0 + off];
-      const float x1 = (float)img[a1o + off];
-      acc0 = mfma16(wa[s], x0, acc0);
-      acc1 = mfma16(wa[s], x1, acc1);
+      acc = mfma16(wa[s], (float)img[a0 + off], acc);
     }
-    if (pos0 < P1) {
+    if (lpos < npos) {
       f32x4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc0[r] * scale + bias[r], 0.f);
-      *reinterpret_cast<f32x4*>(pad + ((pos0 / W1 + 1) * PW + pos0 % W1 + 1) * PS_F + 4 * kq) = o;
-    }
-    if (pos1 < P1) {
-      f32x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc1[r] * scale + bias[r], 0.f);
-      *reinterpret_cast<f32x4*>(pad + ((pos1 / W1 + 1) * PW + pos1 % W1 + 1) * PS_F + 4 * kq) = o;
+      for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r] * scale + bias[r], 0.f);
+      *reinterpret_cast<f32x4*>(pad + ((q / W1 + 1) * PW + q % W1 + 1) * PS_F + 4 * kq) = o;
     }
   }
   __syncthreads();
-  // ---- 3. conv2: channel tile ct, position tile `tile` -----------------------------------
-  const int ct = wave & 1, tile = wave >> 1;
-  if (tile < 7) {
+  // ---- 3. conv2 rows [3*part, 3*part+3): 27 positions = 2 tiles x 2 channel tiles ---------
+  if (wave < 4) {
+    const int ct = wave & 1, tile = wave >> 1;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
@@ -882,8 +879,9 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
     float bias[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[r] = bs[C1 + ct * 16 + 4 * kq + r];
-    const int pos = min(tile * 16 + j, P2 - 1);
-    const int oy = pos / W2, ox = pos - oy * W2;
+    const int lp = tile * 16 + j, lpc = min(lp, 3 * W2 - 1);
+    const int oy = 3 * part + lpc / W2, ox = lpc % W2;
+    const int pos = oy * W2 + ox;
     const int base = ((2 * oy) * PW + 2 * ox) * PS_F + 4 * kq;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -893,7 +891,7 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp) acc = mfma16(wa[kk * 4 + sp], bv[sp], acc);
     }
-    if (tile * 16 + j < P2) {
+    if (lp < 3 * W2) {
       float* out = y2 + b * F2 + (ct * 16 + 4 * kq) * P2;
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[r * P2 + pos] = fmaxf(acc[r] + bias[r], 0.f);
@@ -970,7 +968,7 @@ extern "C" int rlpyt_atari_sample_convs_f32(
   RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(new_frame) && RL_ALIGNED16(full_rows) &&
                    RL_ALIGNED16(w1) && RL_ALIGNED16(w2),
                RLPYT_ESHAPE, "rlpyt_atari_sample_convs_f32: buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(sample_convs_kernel, dim3((unsigned)Bg), dim3(SC_THREADS), 0,
+  hipLaunchKernelGGL(sample_convs_kernel, dim3((unsigned)(Bg * SC_PARTS)), dim3(SC_THREADS), 0,
                      (hipStream_t)stream, obs, obs, t_dev, B, lo, new_frame, full_rows, slot,
                      reward_rows, reward_src, done_rows, done_src, w1, b1, w2, b2, scale, y2);
   RL_LAUNCH_CHECK();
