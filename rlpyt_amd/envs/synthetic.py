@@ -14,7 +14,7 @@ import numpy as np
 from ..spaces import FloatBox, IntBox
 from .base import Env, EnvStep
 
-AtariEnvInfo = namedtuple("EnvInfo", ["game_score", "traj_done"])
+AtariEnvInfo = namedtuple("AtariEnvInfo", ["game_score", "traj_done"])  # typename = module attribute: picklable
 
 H, W = 104, 80
 

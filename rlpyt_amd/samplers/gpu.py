@@ -72,6 +72,7 @@ class EnvRunner:
         self.mid_batch_reset = mid_batch_reset
         self.traj_infos = [TrajInfoCls() for _ in envs]
         self.need_reset = np.zeros(len(envs), dtype=bool)
+        self.force_full = np.zeros(len(envs), dtype=bool)   # next obs must be uploaded whole
         # wait-reset: the observation returned with done is held back until the next
         # batch starts (collectors.py:65-68,103-104)
         self.temp_observation = None if mid_batch_reset else [None] * len(envs)
@@ -114,17 +115,27 @@ class EnvRunner:
             self.last_obs[b] = o
 
     def begin_batch(self):
-        """Between batches under wait-reset: reinstate held observations, reset finished
-        envs, clear ``done`` (collectors.py:73-76,117-126)."""
+        """Between batches under wait-reset: reset finished envs, reinstate held observations,
+        clear ``done`` (collectors.py:73-76,117-126).
+
+        Reference behaviour kept on purpose: ``reset_if_needed`` writes the reset observation
+        into the step buffer, then the next ``collect_batch`` overwrites it with the held
+        terminal observation for EVERY env whose ``done`` flag is set -- so after a finished
+        trajectory the first row of the next batch shows the last observation of the old episode
+        while the env itself has been reset (the golden batches of the reference's
+        GpuWaitResetCollector pin this, tests/test_sampler_parity.py)."""
         if self.mid_batch_reset:
             return
         step = self.step
         for b in np.where(step.done)[0]:
             if self.need_reset[b]:
-                step.observation[b] = self.envs[b].reset()
+                self.last_obs[b] = self.envs[b].reset()
+                step.observation[b] = self.last_obs[b]
                 step.action[b] = 0
                 step.reward[b] = 0
-            elif self.temp_observation[b] is not None:
+                # the next observation does not continue the stack row 0 shows
+                self.force_full[b] = True
+            if self.temp_observation[b] is not None:
                 step.observation[b] = self.temp_observation[b]
         self.need_reset[:] = False
         step.done[:] = False
@@ -163,6 +174,8 @@ class EnvRunner:
                 o = 0
                 fresh = True
             last_obs[b] = o
+            if self.force_full[b]:
+                fresh, self.force_full[b] = True, False
             if frames:
                 frame_buf[b] = o[-1] if not isinstance(o, int) else 0
                 reset_buf[b] = fresh
@@ -424,11 +437,13 @@ class GpuSampler(BaseSampler):
         agent.initialize(envs[0].spaces, share_memory=False, global_B=global_B,
                          env_ranks=env_ranks)
         # ---- examples (host, before any HIP call so that forking stays safe) ----------
-        env0 = envs[0]
+        # from a throw-away env instance, as the reference does (samplers/buffer.py:60-80): the
+        # B training envs must start from their freshly seeded state
+        env0 = self.EnvCls(**self.env_kwargs)
         o = env0.reset()
         a = env0.action_space.sample()
         o, r, d, env_info = env0.step(a)
-        env0.reset()
+        del env0
         r = np.asarray(r, dtype="float32")
         agent.reset()
         a_t, agent_info = agent.step(*torchify_buffer(AgentInputs(o, np.asarray(a), r)))
@@ -798,14 +813,11 @@ class GpuSampler(BaseSampler):
         self._all_reward[T, lo:hi] = G.reward_stage
         self._all_done[T, lo:hi] = G.done_stage
         if "bootstrap_value" in s.agent:
+            # as the reference: the value call sees the last action / reward as they are -- the
+            # null-after-reset of prev inputs happens AFTER it (action_server.py:60-68); for an
+            # env that just finished the bootstrap value is masked by (1 - done) anyway
             prev_action = _map(lambda x: x[T, lo:hi], self._all_action)
             prev_reward = G.reward_stage
-            if self.mid_batch_reset:
-                dn = G.done_stage
-                prev_action = _map(lambda x: torch.where(
-                    dn.reshape((-1,) + (1,) * (x.dim() - 1)), torch.zeros_like(x), x),
-                    prev_action)
-                prev_reward = torch.where(dn, torch.zeros_like(prev_reward), prev_reward)
             s.agent.bootstrap_value[0, lo:hi] = self.agent.value(G.obs_stage, prev_action,
                                                                  prev_reward)
         if self.agent.recurrent:     # end of batch: finished envs restart from a zero state

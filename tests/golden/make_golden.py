@@ -672,17 +672,80 @@ def gen_models():
     save("models", **out)
 
 
+def gen_sampler():
+    """The reference GpuSampler itself (GpuResetCollector / GpuWaitResetCollector worker
+    processes + ActionServer.serve_actions, rlpyt/samplers/parallel/gpu/*.py) on CPU, stepping
+    this repo's synthetic env under a deterministic policy: four consecutive batches, every field
+    of the samples buffer, and the completed trajectory infos."""
+    import sampler_cases as C
+    from rlpyt.agents.base import AgentStep, BaseAgent
+    from rlpyt.samplers.parallel.gpu.collectors import GpuResetCollector, GpuWaitResetCollector
+    from rlpyt.samplers.parallel.gpu.sampler import GpuSampler as RefGpuSampler
+    from rlpyt.utils.collections import namedarraytuple
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from rlpyt_amd.envs.synthetic import SyntheticPong
+    AgentInfo = C.bind_agent_info(namedarraytuple)
+
+    class DetAgent(BaseAgent):
+        def __init__(self):
+            super().__init__(ModelCls=None)
+
+        def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
+            self.n = env_spaces.action.n
+            self.env_spaces, self.share_memory = env_spaces, share_memory
+
+        def to_device(self, cuda_idx=None):
+            pass
+
+        def step(self, observation, prev_action, prev_reward):
+            a, v = C.det_policy(observation, prev_action, prev_reward, self.n)
+            return AgentStep(action=a, agent_info=AgentInfo(value=v))
+
+        def value(self, observation, prev_action, prev_reward):
+            return C.det_policy(observation, prev_action, prev_reward, self.n)[1] + 1
+
+        def sample_mode(self, itr):
+            pass
+
+        train_mode = eval_mode = sample_mode
+
+        def sync_shared_memory(self):
+            pass
+
+    out = {}
+    for name, mode, T, n_batches in C.CASES:
+        Coll = GpuResetCollector if mode == "reset" else GpuWaitResetCollector
+        s = RefGpuSampler(EnvCls=SyntheticPong, env_kwargs=C.ENV_KWARGS, batch_T=T, batch_B=C.B,
+                          CollectorCls=Coll, max_decorrelation_steps=0)
+        s.initialize(DetAgent(), affinity=dict(workers_cpus=list(range(C.N_WORKERS)), cuda_idx=None,
+                                               set_affinity=False),
+                     seed=C.SEED, bootstrap_value=True)
+        for itr in range(n_batches):
+            smp, infos = s.obtain_samples(itr)
+            k = f"{name}{itr}_"
+            out.update({
+                k + "obs_crc": C.obs_crc(smp.env.observation.numpy()),
+                k + "reward": smp.env.reward.numpy().copy(),
+                k + "prev_reward": smp.env.prev_reward.numpy().copy(),
+                k + "done": smp.env.done.numpy().copy(),
+                k + "game_score": smp.env.env_info.game_score.numpy().copy(),
+                k + "traj_done": smp.env.env_info.traj_done.numpy().copy(),
+                k + "action": smp.agent.action.numpy().copy(),
+                k + "prev_action": smp.agent.prev_action.numpy().copy(),
+                k + "value": smp.agent.agent_info.value.numpy().copy(),
+                k + "bootstrap_value": smp.agent.bootstrap_value.numpy().copy(),
+                k + "traj_len_ret": np.array(sorted((ti["Length"], ti["Return"]) for ti in infos),
+                                             dtype=np.float64).reshape(-1, 2)})
+        s.shutdown()
+    save("sampler", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
-    gen_scans()
-    gen_nstep()
-    gen_normalize()
-    gen_losses()
-    gen_sumtree()
-    gen_frames()
-    gen_replay()
-    gen_seq_replay()
-    gen_r2d1_rms()
-    gen_catdqn()
-    gen_models()
+    gens = dict(scans=gen_scans, nstep=gen_nstep, normalize=gen_normalize, losses=gen_losses,
+                sumtree=gen_sumtree, frames=gen_frames, replay=gen_replay,
+                seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
+                models=gen_models, sampler=gen_sampler)
+    for name in (sys.argv[1:] or list(gens)):      # python make_golden.py [subset ...]
+        gens[name]()

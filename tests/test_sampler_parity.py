@@ -1,0 +1,91 @@
+"""Rollout parity with the reference's own GPU sampler: tests/golden/sampler.npz
+was recorded by running rlpyt's GpuSampler -- GpuResetCollector / GpuWaitResetCollector worker
+processes + ActionServer.serve_actions -- on CPU over this repo's synthetic env under a
+deterministic policy that depends on the observation and on the prev_action / prev_reward it is
+handed.  This repo's GpuSampler must reproduce every field of every batch: observations (CRC),
+reward / prev_reward, done, env_info, action / prev_action, agent_info, bootstrap_value, and the
+completed-trajectory statistics, for any worker count and pipeline-group layout."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from rlpyt_amd.agents.base import AgentStep, BaseAgent
+from rlpyt_amd.envs.synthetic import SyntheticPong
+from rlpyt_amd.samplers.gpu import GpuSampler
+from rlpyt_amd.utils import logger
+from rlpyt_amd.utils.collections import namedarraytuple
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import sampler_cases as C  # noqa: E402
+
+logger.set_quiet(True)
+AgentInfo = namedarraytuple("AgentInfo", ["value"])
+
+
+class DetAgent(BaseAgent):
+    """The same deterministic policy the golden run used (tests/golden/sampler_cases.py)."""
+
+    def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
+        self.n = env_spaces.action.n
+        self.env_spaces, self.share_memory = env_spaces, share_memory
+
+    def step(self, observation, prev_action, prev_reward):
+        a, v = C.det_policy(observation, prev_action, prev_reward, self.n)
+        return AgentStep(action=a, agent_info=AgentInfo(value=v))
+
+    def value(self, observation, prev_action, prev_reward):
+        return C.det_policy(observation, prev_action, prev_reward, self.n)[1] + 1
+
+    def sample_mode(self, itr):
+        pass
+
+    train_mode = eval_mode = sample_mode
+
+    def parameters(self):
+        return []
+
+
+class RefSeededPong(SyntheticPong):
+    """SyntheticPong seeded the way the reference's two-worker sampler seeds env i."""
+
+    def seed(self, seed):
+        i = seed - C.SEED
+        super().seed(C.reference_env_seed(C.SEED, i))
+
+
+@pytest.mark.parametrize("n_workers,n_groups", [(0, 1), (2, 2), (3, 1), (0, 2)])
+@pytest.mark.parametrize("case", C.CASES, ids=[c[0] for c in C.CASES])
+def test_batches_match_reference_gpu_sampler(case, n_workers, n_groups):
+    name, mode, T, n_batches = case
+    g = load_golden("sampler")
+    s = GpuSampler(RefSeededPong, C.ENV_KWARGS, batch_T=T, batch_B=C.B, n_workers=n_workers,
+                   n_groups=n_groups, mid_batch_reset=(mode == "reset"), max_decorrelation_steps=0)
+    agent = DetAgent()
+    s.initialize(agent, seed=C.SEED, bootstrap_value=True)
+    got_infos, ref_infos = [], []
+    for itr in range(n_batches):
+        smp, infos = s.obtain_samples(itr)
+        k = f"{name}{itr}_"
+        assert np.array_equal(C.obs_crc(smp.env.observation.numpy()), g[k + "obs_crc"]), (itr, "obs")
+        for field, got in [("reward", smp.env.reward), ("prev_reward", smp.env.prev_reward),
+                          ("done", smp.env.done), ("action", smp.agent.action),
+                          ("prev_action", smp.agent.prev_action),
+                          ("value", smp.agent.agent_info.value),
+                          ("bootstrap_value", smp.agent.bootstrap_value),
+                          ("game_score", smp.env.env_info.game_score),
+                          ("traj_done", smp.env.env_info.traj_done)]:
+            got = got.numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+            assert np.array_equal(got, g[k + field]), (itr, field, got, g[k + field])
+        got_infos += [(float(ti["Length"]), float(ti["Return"])) for ti in infos]
+        ref_infos += [tuple(r) for r in g[k + "traj_len_ret"].tolist()]
+    # the reference drains its trajectory queue asynchronously (infos of the last batches may
+    # still be in flight when the run stops): what it returned must be a sub-multiset of ours
+    from collections import Counter
+    got_c, ref_c = Counter(got_infos), Counter(ref_infos)
+    assert len(ref_infos) > 0 and not (ref_c - got_c), (ref_c - got_c)
+    assert len(got_infos) - len(ref_infos) <= 2 * C.B
+    s.shutdown()
