@@ -1,0 +1,41 @@
+"""Iteration-level parity cases shared by ``make_golden.py`` (reference PPO / A2C +
+AtariFfAgent on CPU) and ``tests/test_algo_parity.py`` (this repo's classes on the GPU): the same
+seeded sample batch, the same seeds for parameter init and minibatch shuffling."""
+import numpy as np
+import torch
+
+T, B, A = 8, 6, 6
+INIT_SEED, SHUFFLE_SEED, N_ITR, N_RUN = 4321, 3, 4, 2
+
+# name, algo, algo kwargs, mid_batch_reset
+CASES = [
+    ("ppo", "PPO", dict(discount=0.99, learning_rate=1e-3, value_loss_coeff=1.,
+                        entropy_loss_coeff=0.01, clip_grad_norm=1., gae_lambda=0.98,
+                        minibatches=4, epochs=2, ratio_clip=0.1, linear_lr_schedule=True,
+                        normalize_advantage=False), True),
+    ("ppo_norm_valid", "PPO", dict(discount=0.95, learning_rate=5e-4, value_loss_coeff=0.5,
+                                   entropy_loss_coeff=0.02, clip_grad_norm=0.5, gae_lambda=1,
+                                   minibatches=2, epochs=1, ratio_clip=0.2,
+                                   linear_lr_schedule=False, normalize_advantage=True), False),
+    ("a2c", "A2C", dict(discount=0.99, learning_rate=1e-3, value_loss_coeff=0.5,
+                        entropy_loss_coeff=0.01, clip_grad_norm=1., gae_lambda=0.97,
+                        normalize_advantage=False), True),
+]
+
+
+def batch_inputs():
+    """Env-side fields of the sample batch (the agent-side fields -- old probabilities, values,
+    bootstrap value -- come from the reference agent's own forward and live in the fixture)."""
+    g = torch.Generator().manual_seed(77)
+    obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, generator=g)
+    keep = torch.rand((T, B, 4, 104, 80), generator=g) < 0.15
+    obs = obs * keep.to(torch.uint8)
+    all_action = torch.randint(0, A, (T + 1, B), generator=g)
+    all_reward = torch.randint(-1, 2, (T + 1, B), generator=g).float()
+    done = torch.rand(T, B, generator=g) < 0.08
+    return dict(observation=obs, all_action=all_action, all_reward=all_reward, done=done)
+
+
+def param_stats(params):
+    return (np.array([p.detach().double().sum().item() for p in params]),
+            np.array([p.detach().double().abs().sum().item() for p in params]))

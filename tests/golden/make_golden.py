@@ -740,12 +740,68 @@ def gen_sampler():
     save("sampler", **out)
 
 
+def gen_algos():
+    """Whole update iterations of the REFERENCE algorithms: PPO.optimize_agent / A2C.optimize_agent
+    (rlpyt/algos/pg/{ppo,a2c,base}.py) with the reference AtariFfAgent on CPU, two consecutive
+    iterations each: the per-update diagnostics and the parameters after every iteration."""
+    import algo_cases as C
+    from rlpyt.agents.pg.atari import AtariFfAgent
+    from rlpyt.agents.pg.base import AgentInfo
+    from rlpyt.algos.pg.a2c import A2C
+    from rlpyt.algos.pg.ppo import PPO
+    from rlpyt.envs.base import EnvSpaces
+    from rlpyt.samplers.collections import AgentSamplesBsv, BatchSpec, EnvSamples, Samples
+    from rlpyt.spaces.int_box import IntBox
+    spaces = EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
+                       action=IntBox(0, C.A))
+    inp = C.batch_inputs()
+    out = {}
+    for name, algo_name, kwargs, mbr in C.CASES:
+        torch.manual_seed(C.INIT_SEED)
+        agent = AtariFfAgent()
+        agent.initialize(spaces)
+        obs = inp["observation"]
+        prev_action, action = inp["all_action"][:-1], inp["all_action"][1:]
+        prev_reward, reward = inp["all_reward"][:-1], inp["all_reward"][1:]
+        with torch.no_grad():      # the behaviour policy = the initial parameters
+            dist_info, value = agent(obs, prev_action, prev_reward)
+            _, bv = agent(obs[-1], action[-1], reward[-1])
+            bv = (bv + 0.25).unsqueeze(0)
+        samples = Samples(
+            agent=AgentSamplesBsv(action=action, prev_action=prev_action,
+                                  agent_info=AgentInfo(dist_info=dist_info, value=value),
+                                  bootstrap_value=bv),
+            env=EnvSamples(observation=obs, reward=reward, prev_reward=prev_reward,
+                           done=inp["done"], env_info=()))
+        algo = (PPO if algo_name == "PPO" else A2C)(**kwargs)
+        algo.initialize(agent=agent, n_itr=C.N_ITR, batch_spec=BatchSpec(C.T, C.B),
+                        mid_batch_reset=mbr, examples=None, world_size=1, rank=0)
+        out.update({f"{name}_old_prob": dist_info.prob.numpy().copy(),
+                    f"{name}_old_value": value.numpy().copy(),
+                    f"{name}_bootstrap_value": bv.numpy().copy()})
+        np.random.seed(C.SHUFFLE_SEED)
+        for itr in range(C.N_RUN):
+            agent.train_mode(itr)
+            info = algo.optimize_agent(itr, samples)
+            for f in ("loss", "gradNorm", "entropy", "perplexity"):
+                out[f"{name}_itr{itr}_{f}"] = np.atleast_1d(np.array(getattr(info, f),
+                                                                    dtype=np.float64))
+            params = list(agent.parameters())
+            sums, abs_sums = C.param_stats(params)
+            out[f"{name}_itr{itr}_param_sums"] = sums
+            out[f"{name}_itr{itr}_param_abs_sums"] = abs_sums
+            for n, p in agent.model.named_parameters():
+                if p.numel() <= 4096:
+                    out[f"{name}_itr{itr}_param__{n}"] = p.detach().numpy().copy()
+    save("algos", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     gens = dict(scans=gen_scans, nstep=gen_nstep, normalize=gen_normalize, losses=gen_losses,
                 sumtree=gen_sumtree, frames=gen_frames, replay=gen_replay,
                 seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
-                models=gen_models, sampler=gen_sampler)
+                models=gen_models, sampler=gen_sampler, algos=gen_algos)
     for name in (sys.argv[1:] or list(gens)):      # python make_golden.py [subset ...]
         gens[name]()
