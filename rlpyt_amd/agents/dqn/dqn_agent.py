@@ -66,11 +66,12 @@ class DqnAgent(EpsilonGreedyAgentMixin, BaseAgent):
         self.initial_model_state_dict = None
         super().initialize(env_spaces, share_memory, global_B=global_B, env_ranks=env_ranks)
         self.target_model = self.ModelCls(**self.env_model_kwargs, **self.model_kwargs)
+        # as the reference (dqn_agent.py:39-43): without an initial state dict the target network
+        # keeps its OWN random initialisation until the first target update -- pinned by the
+        # reference's DQN iterations in tests/golden/dqn_iterations.npz
         if init_sd is not None:
             self.model.load_state_dict(init_sd["model"])
             self.target_model.load_state_dict(init_sd["model"])
-        else:
-            self.target_model.load_state_dict(self.model.state_dict())
         self.distribution = EpsilonGreedy(dim=env_spaces.action.n)
         self.eps_sample = self.eps_init
         if env_ranks is not None:

@@ -39,3 +39,34 @@ def batch_inputs():
 def param_stats(params):
     return (np.array([p.detach().double().sum().item() for p in params]),
             np.array([p.detach().double().abs().sum().item() for p in params]))
+
+
+# ---- DQN family: replay-driven iterations -------------------------------------------------
+DQN_T, DQN_B, DQN_ITRS = 4, 8, 6
+# name, algo kwargs (both sides), notes: uniform replay keeps the sampled indices independent of
+# fp32 round-off over many updates; the prioritized case runs fewer updates (priorities feed back
+# into the sampling, so late-update drift could pick different rows)
+DQN_CASES = [
+    ("dqn_uniform", dict(discount=0.99, batch_size=16, min_steps_learn=64, replay_size=512,
+                         replay_ratio=2, target_update_interval=3, n_step_return=2,
+                         learning_rate=1e-4, clip_grad_norm=10., double_dqn=True,
+                         prioritized_replay=False, delta_clip=1.), 6),
+    ("dqn_pri", dict(discount=0.99, batch_size=16, min_steps_learn=64, replay_size=512,
+                     replay_ratio=2, target_update_interval=2, n_step_return=1,
+                     learning_rate=1e-4, clip_grad_norm=10., double_dqn=False,
+                     prioritized_replay=True, delta_clip=1.), 4),
+]
+
+
+def dqn_batches(n_itr=DQN_ITRS):
+    """Sampler batches fed to optimize_agent, one per iteration (fields of SamplesToBuffer)."""
+    g = torch.Generator().manual_seed(177)
+    out = []
+    for _ in range(n_itr):
+        obs = torch.randint(0, 256, (DQN_T, DQN_B, 4, 104, 80), dtype=torch.uint8, generator=g)
+        keep = torch.rand((DQN_T, DQN_B, 4, 104, 80), generator=g) < 0.15
+        out.append(dict(observation=obs * keep.to(torch.uint8),
+                        action=torch.randint(0, A, (DQN_T, DQN_B), generator=g),
+                        reward=torch.randint(-1, 2, (DQN_T, DQN_B), generator=g).float(),
+                        done=torch.rand(DQN_T, DQN_B, generator=g) < 0.1))
+    return out

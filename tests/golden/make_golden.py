@@ -796,12 +796,58 @@ def gen_algos():
     save("algos", **out)
 
 
+def gen_dqn_iterations():
+    """The reference DQN.optimize_agent (rlpyt/algos/dqn/dqn.py:158-190) with its AtariDqnAgent
+    and frame replay buffers on CPU: append, sample, loss, clip, Adam, priority and target
+    updates, over several iterations of fixed sampler batches."""
+    import algo_cases as C
+    from collections import namedtuple
+    from rlpyt.agents.dqn.atari.atari_dqn_agent import AtariDqnAgent
+    from rlpyt.algos.dqn.dqn import DQN
+    from rlpyt.envs.base import EnvSpaces
+    from rlpyt.samplers.collections import BatchSpec
+    from rlpyt.spaces.int_box import IntBox
+    spaces = EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
+                       action=IntBox(0, C.A))
+    Env = namedtuple("Env", ["observation", "reward", "done"])
+    Agent = namedtuple("Agent", ["action"])
+    Smp = namedtuple("Smp", ["agent", "env"])
+    out = {}
+    for name, kwargs, n_itr in C.DQN_CASES:
+        batches = C.dqn_batches(n_itr)
+        torch.manual_seed(C.INIT_SEED)
+        agent = AtariDqnAgent()
+        agent.initialize(spaces)
+        algo = DQN(**kwargs)
+        b0 = batches[0]
+        examples = dict(observation=b0["observation"][0, 0], action=b0["action"][0, 0],
+                        reward=b0["reward"][0, 0], done=b0["done"][0, 0])
+        algo.initialize(agent=agent, n_itr=n_itr, batch_spec=BatchSpec(C.DQN_T, C.DQN_B),
+                        mid_batch_reset=True, examples=examples, world_size=1, rank=0)
+        np.random.seed(C.SHUFFLE_SEED)
+        for itr, b in enumerate(batches):
+            agent.train_mode(itr)
+            info = algo.optimize_agent(itr, Smp(agent=Agent(action=b["action"]),
+                                                env=Env(observation=b["observation"],
+                                                        reward=b["reward"], done=b["done"])))
+            for f in ("loss", "gradNorm", "tdAbsErr"):
+                out[f"{name}_itr{itr}_{f}"] = np.array(getattr(info, f), dtype=np.float64)
+            out[f"{name}_itr{itr}_param_abs_sums"] = C.param_stats(list(agent.model.parameters()))[1]
+            out[f"{name}_itr{itr}_target_abs_sums"] = C.param_stats(
+                list(agent.target_model.parameters()))[1]
+            if kwargs["prioritized_replay"]:
+                out[f"{name}_itr{itr}_tree_root"] = np.float64(
+                    algo.replay_buffer.priority_tree.tree[0])
+        out[f"{name}_update_counter"] = np.int64(algo.update_counter)
+    save("dqn_iterations", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     gens = dict(scans=gen_scans, nstep=gen_nstep, normalize=gen_normalize, losses=gen_losses,
                 sumtree=gen_sumtree, frames=gen_frames, replay=gen_replay,
                 seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
-                models=gen_models, sampler=gen_sampler, algos=gen_algos)
+                models=gen_models, sampler=gen_sampler, algos=gen_algos, dqn_iterations=gen_dqn_iterations)
     for name in (sys.argv[1:] or list(gens)):      # python make_golden.py [subset ...]
         gens[name]()

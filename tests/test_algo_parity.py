@@ -87,3 +87,60 @@ def test_iterations_match_reference(case):
             assert diff.max() <= 2.2 * lr * n_updates, (n, diff.max())
             assert (diff > 0.1 * lr).mean() <= 0.05, (n, (diff > 0.1 * lr).mean())
     assert algo.update_counter == n_updates
+
+
+@pytest.mark.parametrize("case", C.DQN_CASES, ids=[c[0] for c in C.DQN_CASES])
+def test_dqn_iterations_match_reference(case):
+    """DQN.optimize_agent over several iterations (append to the HBM frame replay, sample --
+    same np.random stream as the reference --, fused loss, clip, Adam, priority and target
+    updates) vs the reference's own run with its AtariDqnAgent on CPU.  The conv stack of this
+    model family runs through MIOpen; tolerances as for the PPO iterations."""
+    from collections import namedtuple
+    from rlpyt_amd.agents.dqn.dqn_agent import AtariDqnAgent
+    from rlpyt_amd.algos.dqn.dqn import DQN
+    from rlpyt_amd.envs.base import EnvSpaces
+    from rlpyt_amd.samplers.collections import BatchSpec
+    from rlpyt_amd.spaces import IntBox
+    name, kwargs, n_itr = case
+    g = load_golden("dqn_iterations")
+    spaces = EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
+                       action=IntBox(0, C.A))
+    Env = namedtuple("Env", ["observation", "reward", "done"])
+    Agent = namedtuple("Agent", ["action"])
+    Smp = namedtuple("Smp", ["agent", "env"])
+    batches = C.dqn_batches(n_itr)
+    torch.manual_seed(C.INIT_SEED)
+    agent = AtariDqnAgent()
+    agent.initialize(spaces)
+    agent.to_device(0)
+    algo = DQN(**kwargs)
+    b0 = batches[0]
+    examples = dict(observation=b0["observation"][0, 0], action=b0["action"][0, 0],
+                    reward=b0["reward"][0, 0], done=b0["done"][0, 0])
+    algo.initialize(agent=agent, n_itr=n_itr, batch_spec=BatchSpec(C.DQN_T, C.DQN_B),
+                    mid_batch_reset=True, examples=examples, world_size=1, rank=0)
+    np.random.seed(C.SHUFFLE_SEED)
+    first = True
+    for itr, b in enumerate(batches):
+        agent.train_mode(itr)
+        info = algo.optimize_agent(itr, Smp(
+            agent=Agent(action=b["action"].cuda()),
+            env=Env(observation=b["observation"].cuda(), reward=b["reward"].cuda(),
+                    done=b["done"].cuda())))
+        for f in ("loss", "gradNorm", "tdAbsErr"):
+            got = np.array(getattr(info, f), dtype=np.float64)
+            ref = g[f"{name}_itr{itr}_{f}"]
+            assert got.shape == ref.shape, (itr, f, got.shape, ref.shape)
+            if got.size and first and f != "tdAbsErr":
+                np.testing.assert_allclose(got[0], ref[0], rtol=1e-3, atol=1e-5, err_msg=f)
+            np.testing.assert_allclose(got, ref, rtol=2e-2, atol=5e-3, err_msg=f"{f} itr {itr}")
+        if len(info.loss):
+            first = False
+        abs_sums = C.param_stats([p.cpu() for p in agent.model.parameters()])[1]
+        np.testing.assert_allclose(abs_sums, g[f"{name}_itr{itr}_param_abs_sums"], rtol=2e-4)
+        t_sums = C.param_stats([p.cpu() for p in agent.target_model.parameters()])[1]
+        np.testing.assert_allclose(t_sums, g[f"{name}_itr{itr}_target_abs_sums"], rtol=2e-4)
+        if kwargs["prioritized_replay"]:
+            root = float(algo.replay_buffer.priority_tree.tree_tensor()[0])
+            np.testing.assert_allclose(root, float(g[f"{name}_itr{itr}_tree_root"]), rtol=2e-3)
+    assert algo.update_counter == int(g[f"{name}_update_counter"])
