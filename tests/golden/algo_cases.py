@@ -47,6 +47,10 @@ DQN_T, DQN_B, DQN_ITRS = 4, 8, 6
 # fp32 round-off over many updates; the prioritized case runs fewer updates (priorities feed back
 # into the sampling, so late-update drift could pick different rows)
 DQN_CASES = [
+    ("catdqn_pri", dict(V_min=-3, V_max=3, discount=0.99, batch_size=16, min_steps_learn=64,
+                        replay_size=512, replay_ratio=2, target_update_interval=3,
+                        n_step_return=2, learning_rate=1e-4, clip_grad_norm=10., double_dqn=True,
+                        prioritized_replay=True), 4),
     ("dqn_uniform", dict(discount=0.99, batch_size=16, min_steps_learn=64, replay_size=512,
                          replay_ratio=2, target_update_interval=3, n_step_return=2,
                          learning_rate=1e-4, clip_grad_norm=10., double_dqn=True,

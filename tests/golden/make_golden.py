@@ -816,9 +816,13 @@ def gen_dqn_iterations():
     for name, kwargs, n_itr in C.DQN_CASES:
         batches = C.dqn_batches(n_itr)
         torch.manual_seed(C.INIT_SEED)
-        agent = AtariDqnAgent()
+        if name.startswith("catdqn"):
+            from rlpyt.agents.dqn.atari.atari_catdqn_agent import AtariCatDqnAgent
+            from rlpyt.algos.dqn.cat_dqn import CategoricalDQN
+            agent, algo = AtariCatDqnAgent(n_atoms=51), CategoricalDQN(**kwargs)
+        else:
+            agent, algo = AtariDqnAgent(), DQN(**kwargs)
         agent.initialize(spaces)
-        algo = DQN(**kwargs)
         b0 = batches[0]
         examples = dict(observation=b0["observation"][0, 0], action=b0["action"][0, 0],
                         reward=b0["reward"][0, 0], done=b0["done"][0, 0])

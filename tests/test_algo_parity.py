@@ -91,7 +91,7 @@ def test_iterations_match_reference(case):
 
 @pytest.mark.parametrize("case", C.DQN_CASES, ids=[c[0] for c in C.DQN_CASES])
 def test_dqn_iterations_match_reference(case):
-    """DQN.optimize_agent over several iterations (append to the HBM frame replay, sample --
+    """DQN / CategoricalDQN.optimize_agent over several iterations (append to the HBM frame replay, sample --
     same np.random stream as the reference --, fused loss, clip, Adam, priority and target
     updates) vs the reference's own run with its AtariDqnAgent on CPU.  The conv stack of this
     model family runs through MIOpen; tolerances as for the PPO iterations."""
@@ -110,10 +110,14 @@ def test_dqn_iterations_match_reference(case):
     Smp = namedtuple("Smp", ["agent", "env"])
     batches = C.dqn_batches(n_itr)
     torch.manual_seed(C.INIT_SEED)
-    agent = AtariDqnAgent()
+    if name.startswith("catdqn"):
+        from rlpyt_amd.agents.dqn.catdqn_agent import AtariCatDqnAgent
+        from rlpyt_amd.algos.dqn.cat_dqn import CategoricalDQN
+        agent, algo = AtariCatDqnAgent(n_atoms=51), CategoricalDQN(**kwargs)
+    else:
+        agent, algo = AtariDqnAgent(), DQN(**kwargs)
     agent.initialize(spaces)
     agent.to_device(0)
-    algo = DQN(**kwargs)
     b0 = batches[0]
     examples = dict(observation=b0["observation"][0, 0], action=b0["action"][0, 0],
                     reward=b0["reward"][0, 0], done=b0["done"][0, 0])
