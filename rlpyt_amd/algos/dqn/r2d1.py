@@ -102,7 +102,7 @@ class R2D1(DQN):
             if self.prioritized_replay:
                 self.replay_buffer.update_batch_priorities(priorities)
             stats.append(torch.stack([loss.detach(), grad_norm.to(loss.dtype)]))
-            tds.append(td_abs_errors.reshape(-1)[::8])
+            tds.append(td_abs_errors[::8].reshape(-1))     # every 8th time step (r2d1.py:166)
             pris.append(priorities)
             self.update_counter += 1
             if self.update_counter % self.target_update_interval == 0:

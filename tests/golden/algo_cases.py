@@ -74,3 +74,30 @@ def dqn_batches(n_itr=DQN_ITRS):
                         reward=torch.randint(-1, 2, (DQN_T, DQN_B), generator=g).float(),
                         done=torch.rand(DQN_T, DQN_B, generator=g) < 0.1))
     return out
+
+
+# ---- R2D1: sequence replay + LSTM ---------------------------------------------------------------
+R2D1_T, R2D1_B, R2D1_ITRS, R2D1_H = 8, 4, 9, 32
+R2D1_MODEL = dict(fc_size=64, lstm_size=R2D1_H, head_size=32)
+R2D1_KWARGS = dict(batch_T=8, batch_B=6, warmup_T=8, store_rnn_state_interval=8,
+                   min_steps_learn=5 * R2D1_T * R2D1_B, replay_size=R2D1_T * R2D1_B * 16,
+                   n_step_return=2, target_update_interval=2, prioritized_replay=True,
+                   input_priorities=True, learning_rate=1e-4, double_dqn=True)
+
+
+def r2d1_batches():
+    """Sampler batches (env side + the agent_info a recurrent DQN agent records)."""
+    g = torch.Generator().manual_seed(277)
+    T, B, H = R2D1_T, R2D1_B, R2D1_H
+    out = []
+    for _ in range(R2D1_ITRS):
+        obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, generator=g)
+        keep = torch.rand((T, B, 4, 104, 80), generator=g) < 0.15
+        all_action = torch.randint(0, A, (T + 1, B), generator=g)
+        all_reward = torch.randint(-1, 2, (T + 1, B), generator=g).float()
+        out.append(dict(observation=obs * keep.to(torch.uint8), all_action=all_action,
+                        all_reward=all_reward, done=torch.rand(T, B, generator=g) < 0.04,
+                        q=torch.randn(T, B, A, generator=g),
+                        h=0.3 * torch.randn(T, B, 1, H, generator=g),
+                        c=0.3 * torch.randn(T, B, 1, H, generator=g)))
+    return out

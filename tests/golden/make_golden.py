@@ -846,12 +846,65 @@ def gen_dqn_iterations():
     save("dqn_iterations", **out)
 
 
+def gen_r2d1_iterations():
+    """The reference R2D1.optimize_agent (rlpyt/algos/dqn/r2d1.py:133-345) with its
+    AtariR2d1Agent and prioritized sequence frame replay on CPU: input priorities, append with
+    stored LSTM states, sequence sampling, warm-up + training passes, loss, priorities, target
+    updates."""
+    import algo_cases as C
+    from collections import namedtuple
+    from rlpyt.agents.dqn.atari.atari_r2d1_agent import AtariR2d1Agent
+    from rlpyt.agents.dqn.r2d1_agent import AgentInfo
+    from rlpyt.algos.dqn.r2d1 import R2D1
+    from rlpyt.envs.base import EnvSpaces
+    from rlpyt.models.dqn.atari_r2d1_model import RnnState
+    from rlpyt.samplers.collections import BatchSpec
+    from rlpyt.spaces.int_box import IntBox
+    spaces = EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
+                       action=IntBox(0, C.A))
+    Env = namedtuple("Env", ["observation", "reward", "prev_reward", "done"])
+    Agent = namedtuple("Agent", ["action", "prev_action", "agent_info"])
+    Smp = namedtuple("Smp", ["agent", "env"])
+    batches = C.r2d1_batches()
+    torch.manual_seed(C.INIT_SEED)
+    agent = AtariR2d1Agent(model_kwargs=dict(C.R2D1_MODEL))
+    agent.initialize(spaces)
+    algo = R2D1(**C.R2D1_KWARGS)
+    b0 = batches[0]
+    examples = dict(observation=b0["observation"][0, 0], action=b0["all_action"][1, 0],
+                    reward=b0["all_reward"][1, 0], done=b0["done"][0, 0],
+                    agent_info=AgentInfo(q=b0["q"][0, 0],
+                                         prev_rnn_state=RnnState(h=b0["h"][0, 0], c=b0["c"][0, 0])))
+    algo.initialize(agent=agent, n_itr=C.R2D1_ITRS, batch_spec=BatchSpec(C.R2D1_T, C.R2D1_B),
+                    mid_batch_reset=False, examples=examples, world_size=1, rank=0)
+    np.random.seed(C.SHUFFLE_SEED)
+    out = {}
+    for itr, b in enumerate(batches):
+        agent.train_mode(itr)
+        smp = Smp(agent=Agent(action=b["all_action"][1:], prev_action=b["all_action"][:-1],
+                              agent_info=AgentInfo(q=b["q"],
+                                                   prev_rnn_state=RnnState(h=b["h"], c=b["c"]))),
+                  env=Env(observation=b["observation"], reward=b["all_reward"][1:],
+                          prev_reward=b["all_reward"][:-1], done=b["done"]))
+        info = algo.optimize_agent(itr, smp)
+        out[f"r2d1_itr{itr}_loss"] = np.array(info.loss, dtype=np.float64)
+        out[f"r2d1_itr{itr}_gradNorm"] = np.array(info.gradNorm, dtype=np.float64)
+        out[f"r2d1_itr{itr}_priority"] = np.array([float(p) for p in info.priority])
+        out[f"r2d1_itr{itr}_param_abs_sums"] = C.param_stats(list(agent.model.parameters()))[1]
+        out[f"r2d1_itr{itr}_target_abs_sums"] = C.param_stats(
+            list(agent.target_model.parameters()))[1]
+        out[f"r2d1_itr{itr}_tree_root"] = np.float64(algo.replay_buffer.priority_tree.tree[0])
+    out["r2d1_update_counter"] = np.int64(algo.update_counter)
+    save("r2d1_iterations", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     gens = dict(scans=gen_scans, nstep=gen_nstep, normalize=gen_normalize, losses=gen_losses,
                 sumtree=gen_sumtree, frames=gen_frames, replay=gen_replay,
                 seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
-                models=gen_models, sampler=gen_sampler, algos=gen_algos, dqn_iterations=gen_dqn_iterations)
+                models=gen_models, sampler=gen_sampler, algos=gen_algos, dqn_iterations=gen_dqn_iterations,
+                r2d1_iterations=gen_r2d1_iterations)
     for name in (sys.argv[1:] or list(gens)):      # python make_golden.py [subset ...]
         gens[name]()

@@ -148,3 +148,64 @@ def test_dqn_iterations_match_reference(case):
             root = float(algo.replay_buffer.priority_tree.tree_tensor()[0])
             np.testing.assert_allclose(root, float(g[f"{name}_itr{itr}_tree_root"]), rtol=2e-3)
     assert algo.update_counter == int(g[f"{name}_update_counter"])
+
+
+def test_r2d1_iterations_match_reference():
+    """R2D1.optimize_agent (input priorities, sequence replay with stored LSTM states, warm-up +
+    training passes, fused loss / priorities kernel, target updates) vs the reference's own run
+    with its AtariR2d1Agent on CPU (small fc / LSTM sizes, full-size conv stack).  Conv and LSTM
+    run through MIOpen here; tolerances as for the DQN iterations."""
+    from collections import namedtuple
+    from rlpyt_amd.agents.dqn.r2d1_agent import AgentInfo, AtariR2d1Agent
+    from rlpyt_amd.algos.dqn.r2d1 import R2D1
+    from rlpyt_amd.envs.base import EnvSpaces
+    from rlpyt_amd.models.dqn.atari_r2d1_model import RnnState
+    from rlpyt_amd.samplers.collections import BatchSpec
+    from rlpyt_amd.spaces import IntBox
+    g = load_golden("r2d1_iterations")
+    spaces = EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
+                       action=IntBox(0, C.A))
+    Env = namedtuple("Env", ["observation", "reward", "prev_reward", "done"])
+    Agent = namedtuple("Agent", ["action", "prev_action", "agent_info"])
+    Smp = namedtuple("Smp", ["agent", "env"])
+    batches = C.r2d1_batches()
+    torch.manual_seed(C.INIT_SEED)
+    agent = AtariR2d1Agent(model_kwargs=dict(C.R2D1_MODEL))
+    agent.initialize(spaces)
+    agent.to_device(0)
+    algo = R2D1(**C.R2D1_KWARGS)
+    b0 = batches[0]
+    examples = dict(observation=b0["observation"][0, 0], action=b0["all_action"][1, 0],
+                    reward=b0["all_reward"][1, 0], done=b0["done"][0, 0],
+                    agent_info=AgentInfo(q=b0["q"][0, 0],
+                                         prev_rnn_state=RnnState(h=b0["h"][0, 0], c=b0["c"][0, 0])))
+    algo.initialize(agent=agent, n_itr=C.R2D1_ITRS, batch_spec=BatchSpec(C.R2D1_T, C.R2D1_B),
+                    mid_batch_reset=False, examples=examples, world_size=1, rank=0)
+    np.random.seed(C.SHUFFLE_SEED)
+    first = True
+    for itr, b in enumerate(batches):
+        agent.train_mode(itr)
+        d = {k: v.cuda() for k, v in b.items()}
+        smp = Smp(agent=Agent(action=d["all_action"][1:], prev_action=d["all_action"][:-1],
+                              agent_info=AgentInfo(q=d["q"],
+                                                   prev_rnn_state=RnnState(h=d["h"], c=d["c"]))),
+                  env=Env(observation=d["observation"], reward=d["all_reward"][1:],
+                          prev_reward=d["all_reward"][:-1], done=d["done"]))
+        info = algo.optimize_agent(itr, smp)
+        for f in ("loss", "gradNorm", "priority"):
+            got = np.array(getattr(info, f), dtype=np.float64)
+            ref = g[f"r2d1_itr{itr}_{f}"]
+            assert got.shape == ref.shape, (itr, f, got.shape, ref.shape)
+            if got.size and first and f == "loss":
+                np.testing.assert_allclose(got[0], ref[0], rtol=1e-3, atol=1e-5)
+            np.testing.assert_allclose(got, ref, rtol=2e-2, atol=5e-3, err_msg=f"{f} itr {itr}")
+        if len(info.loss):
+            first = False
+        root = float(algo.replay_buffer.priority_tree.tree_tensor()[0])
+        np.testing.assert_allclose(root, float(g[f"r2d1_itr{itr}_tree_root"]), rtol=2e-3,
+                                   atol=1e-6, err_msg=f"tree root itr {itr}")
+        abs_sums = C.param_stats([p.cpu() for p in agent.model.parameters()])[1]
+        np.testing.assert_allclose(abs_sums, g[f"r2d1_itr{itr}_param_abs_sums"], rtol=2e-4)
+        t_sums = C.param_stats([p.cpu() for p in agent.target_model.parameters()])[1]
+        np.testing.assert_allclose(t_sums, g[f"r2d1_itr{itr}_target_abs_sums"], rtol=2e-4)
+    assert algo.update_counter == int(g["r2d1_update_counter"])
