@@ -737,6 +737,22 @@ def gen_sampler():
                 k + "traj_len_ret": np.array(sorted((ti["Length"], ti["Return"]) for ti in infos),
                                              dtype=np.float64).reshape(-1, 2)})
         s.shutdown()
+    # offline evaluation (parallel/base.py:115-145, gpu/action_server.py:76-120,
+    # gpu/collectors.py:129-161): every eval env runs eval_max_steps // eval_n_envs steps, all
+    # completed trajectories are returned (no trajectory cap: that stop is time-based there)
+    s = RefGpuSampler(EnvCls=SyntheticPong, env_kwargs=C.ENV_KWARGS, batch_T=5, batch_B=C.B,
+                      max_decorrelation_steps=0, eval_n_envs=C.EVAL_N_ENVS,
+                      eval_env_kwargs=C.EVAL_ENV_KWARGS, eval_max_steps=C.EVAL_MAX_STEPS)
+    s.initialize(DetAgent(), affinity=dict(workers_cpus=list(range(C.N_WORKERS)), cuda_idx=None,
+                                           set_affinity=False),
+                 seed=C.SEED, bootstrap_value=True)
+    for k in range(2):      # evaluate, train a batch, evaluate again (fresh eval envs each time)
+        infos = s.evaluate_agent(k)
+        out[f"eval{k}_len_ret"] = np.array(sorted((ti["Length"], ti["Return"]) for ti in infos),
+                                           dtype=np.float64).reshape(-1, 2)
+        smp, _ = s.obtain_samples(k)
+        out[f"eval{k}_next_batch_action"] = smp.agent.action.numpy().copy()
+    s.shutdown()
     save("sampler", **out)
 
 

@@ -34,6 +34,10 @@ def reference_env_seed(base_seed, i, n_workers=N_WORKERS, batch_B=B):
     return base_seed + i // per + i % per
 
 
+EVAL_N_ENVS, EVAL_MAX_STEPS = 4, 4 * 60      # 60 time steps of 4 eval envs
+EVAL_ENV_KWARGS = dict(points_to_end=1, max_steps=21)
+
+
 def obs_crc(observation):
     """uint32 CRC of every [t, b] observation (keeps the fixture small)."""
     o = np.ascontiguousarray(np.asarray(observation))

@@ -54,6 +54,8 @@ class RefSeededPong(SyntheticPong):
 
     def seed(self, seed):
         i = seed - C.SEED
+        if i >= 50000:      # this repo's evaluation envs are seeded from seed + 50000 + i
+            i -= 50000
         super().seed(C.reference_env_seed(C.SEED, i))
 
 
@@ -88,4 +90,25 @@ def test_batches_match_reference_gpu_sampler(case, n_workers, n_groups):
     got_c, ref_c = Counter(got_infos), Counter(ref_infos)
     assert len(ref_infos) > 0 and not (ref_c - got_c), (ref_c - got_c)
     assert len(got_infos) - len(ref_infos) <= 2 * C.B
+    s.shutdown()
+
+
+@pytest.mark.parametrize("n_workers", [0, 2])
+def test_evaluation_matches_reference_gpu_sampler(n_workers):
+    """``evaluate_agent`` against the reference GpuSampler's evaluation (eval collectors in the
+    workers + ``serve_actions_evaluation``): the same completed trajectories for a step budget,
+    twice in a row (the eval envs live on between evaluations), and the training batches in
+    between are the ones an evaluation-free run produces."""
+    g = load_golden("sampler")
+    s = GpuSampler(RefSeededPong, C.ENV_KWARGS, batch_T=5, batch_B=C.B, n_workers=n_workers,
+                   max_decorrelation_steps=0, eval_n_envs=C.EVAL_N_ENVS,
+                   eval_env_kwargs=C.EVAL_ENV_KWARGS, eval_max_steps=C.EVAL_MAX_STEPS)
+    agent = DetAgent()
+    s.initialize(agent, seed=C.SEED, bootstrap_value=True)
+    for k in range(2):
+        infos = s.evaluate_agent(k)
+        got = sorted((float(ti["Length"]), float(ti["Return"])) for ti in infos)
+        assert got == [tuple(r) for r in g[f"eval{k}_len_ret"].tolist()]
+        smp, _ = s.obtain_samples(k)
+        assert np.array_equal(smp.agent.action.numpy(), g[f"eval{k}_next_batch_action"])
     s.shutdown()
