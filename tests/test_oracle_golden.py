@@ -206,3 +206,42 @@ def test_extract_sequences():
     g = load_golden("frames")
     out = O.extract_sequences(g["es_arr"], g["es_T_idxs"], g["es_B_idxs"], int(g["es_seq_T"]))
     assert np.array_equal(out, g["es_out"])
+
+
+def test_cpu_port_update_matches_reference_ppo_iteration():
+    """The CPU port behind bench.py's ``cpu_baseline`` (oracle/ppo_cpu_port.py) is pinned too: its
+    ``optimize`` on the fixed batch of tests/golden/algos.npz reproduces the diagnostics and the
+    parameters of the reference ``PPO.optimize_agent`` run (first iteration: lr factor 1)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import algo_cases as C
+    from oracle.ppo_cpu_port import AtariFfModelCpu, PpoCpuPort
+    g = load_golden("algos")
+    name, _algo, kw, _mbr = C.CASES[0]
+    assert name == "ppo"
+    inp = C.batch_inputs()
+    port = PpoCpuPort.__new__(PpoCpuPort)
+    port.T, port.B, port.A = C.T, C.B, C.A
+    torch.manual_seed(C.INIT_SEED)
+    port.model = AtariFfModelCpu((4, 104, 80), C.A)
+    port.opt = torch.optim.Adam(port.model.parameters(), lr=kw["learning_rate"])
+    port.hp = dict(discount=kw["discount"], c_v=kw["value_loss_coeff"],
+                   c_e=kw["entropy_loss_coeff"], clip_grad_norm=kw["clip_grad_norm"],
+                   lam=kw["gae_lambda"], minibatches=kw["minibatches"], epochs=kw["epochs"],
+                   ratio_clip=kw["ratio_clip"])
+    port.buf = dict(observation=inp["observation"].numpy(), action=inp["all_action"][1:].numpy(),
+                    reward=inp["all_reward"][1:].numpy(), done=inp["done"].numpy(),
+                    prob=g["ppo_old_prob"], value=g["ppo_old_value"])
+    # same architecture, same seed => the port's forward is the recorded behaviour policy
+    with torch.no_grad():
+        pi, v = port.model(inp["observation"])
+    np.testing.assert_allclose(pi.numpy(), g["ppo_old_prob"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(v.numpy(), g["ppo_old_value"], rtol=1e-6, atol=1e-7)
+    np.random.seed(C.SHUFFLE_SEED)
+    infos = np.array(port.optimize(torch.from_numpy(g["ppo_bootstrap_value"])))
+    for k, f in enumerate(("loss", "gradNorm", "entropy", "perplexity")):
+        np.testing.assert_allclose(infos[:, k], g[f"ppo_itr0_{f}"], rtol=1e-5, atol=1e-6,
+                                   err_msg=f)
+    abs_sums = [p.detach().double().abs().sum().item() for p in port.model.parameters()]
+    np.testing.assert_allclose(abs_sums, g["ppo_itr0_param_abs_sums"], rtol=1e-6)
