@@ -533,6 +533,9 @@ class GpuSampler(BaseSampler):
         self.eval = None
         if not self.eval_n_envs or self.eval_n_envs <= 0:
             return
+        if not self.eval_max_steps:
+            raise ValueError("GpuSampler: eval_n_envs > 0 needs eval_max_steps (total env steps "
+                             "of one evaluation), as in the reference's samplers.")
         per = max(1, self.eval_n_envs // n_w)
         Be = per * n_w
         if Be != self.eval_n_envs:

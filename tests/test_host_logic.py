@@ -362,6 +362,9 @@ def test_sampler_evaluate_agent(n_workers):
 
 
 def test_sampler_evaluate_requires_eval_envs():
+    with pytest.raises(ValueError, match="eval_max_steps"):
+        GpuSampler(TinyDiscreteEnv, dict(), batch_T=2, batch_B=2, n_workers=0,
+                   eval_n_envs=2).initialize(MlpCategoricalPgAgent(), seed=0)
     s = GpuSampler(TinyDiscreteEnv, dict(), batch_T=2, batch_B=2, n_workers=0)
     s.initialize(MlpCategoricalPgAgent(), seed=0)
     with pytest.raises(RuntimeError, match="eval_n_envs"):
