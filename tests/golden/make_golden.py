@@ -719,7 +719,7 @@ def gen_sampler():
                           CollectorCls=Coll, max_decorrelation_steps=0)
         s.initialize(DetAgent(), affinity=dict(workers_cpus=list(range(C.N_WORKERS)), cuda_idx=None,
                                                set_affinity=False),
-                     seed=C.SEED, bootstrap_value=True)
+                     seed=C.SEED, bootstrap_value=True, traj_info_kwargs=dict(discount=0.9))
         for itr in range(n_batches):
             smp, infos = s.obtain_samples(itr)
             k = f"{name}{itr}_"
@@ -735,7 +735,12 @@ def gen_sampler():
                 k + "value": smp.agent.agent_info.value.numpy().copy(),
                 k + "bootstrap_value": smp.agent.bootstrap_value.numpy().copy(),
                 k + "traj_len_ret": np.array(sorted((ti["Length"], ti["Return"]) for ti in infos),
-                                             dtype=np.float64).reshape(-1, 2)})
+                                             dtype=np.float64).reshape(-1, 2),
+                # every logged TrajInfo field (samplers/collections.py:30-56), discount set the
+                # way the runner sets it through traj_info_kwargs
+                k + "traj_fields": np.array(sorted(
+                    (ti["Length"], ti["Return"], ti["NonzeroRewards"], ti["DiscountedReturn"])
+                    for ti in infos), dtype=np.float64).reshape(-1, 4)})
         s.shutdown()
     # offline evaluation (parallel/base.py:115-145, gpu/action_server.py:76-120,
     # gpu/collectors.py:129-161): every eval env runs eval_max_steps // eval_n_envs steps, all
@@ -914,6 +919,37 @@ def gen_r2d1_iterations():
     save("r2d1_iterations", **out)
 
 
+def gen_agents():
+    """Epsilon schedule of the reference DQN agents (rlpyt/agents/dqn/epsilon_greedy.py): scalar
+    and rank-aware vector epsilon (log-spaced over the GLOBAL env index -- the one rank-aware
+    piece of the DQN path under SyncRl), through sample_mode / eval_mode."""
+    from rlpyt.agents.dqn.atari.atari_dqn_agent import AtariDqnAgent
+    from rlpyt.envs.base import EnvSpaces
+    from rlpyt.spaces.int_box import IntBox
+    spaces = EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
+                       action=IntBox(0, 6))
+    out = {}
+    for name, kw, global_B, env_ranks in [
+            ("scalar", dict(eps_init=1., eps_final=0.05), 4, [0, 1, 2, 3]),
+            ("vector_rank1", dict(eps_init=1., eps_final=0.1, eps_final_min=0.001), 8,
+             [4, 5, 6, 7])]:
+        agent = AtariDqnAgent(**kw)
+        agent.initialize(spaces, global_B=global_B, env_ranks=env_ranks)
+        agent.set_epsilon_itr_min_max(2, 10)
+        eps = []
+        for itr in range(13):
+            agent.sample_mode(itr)
+            eps.append(np.broadcast_to(np.asarray(agent.distribution.epsilon, dtype=np.float64),
+                                       (len(env_ranks),)).copy())
+        out[f"{name}_sample_eps"] = np.stack(eps)
+        ev = []
+        for itr in (0, 5):
+            agent.eval_mode(itr)
+            ev.append(float(agent.distribution.epsilon))
+        out[f"{name}_eval_eps"] = np.array(ev)
+    save("agents", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
@@ -921,6 +957,6 @@ if __name__ == "__main__":
                 sumtree=gen_sumtree, frames=gen_frames, replay=gen_replay,
                 seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
                 models=gen_models, sampler=gen_sampler, algos=gen_algos, dqn_iterations=gen_dqn_iterations,
-                r2d1_iterations=gen_r2d1_iterations)
+                r2d1_iterations=gen_r2d1_iterations, agents=gen_agents)
     for name in (sys.argv[1:] or list(gens)):      # python make_golden.py [subset ...]
         gens[name]()

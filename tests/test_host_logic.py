@@ -388,3 +388,29 @@ def test_minibatch_rl_eval_runner():
     runner.train()
     assert calls == [0, 2, 5]
     assert runner._cum_eval_time > 0 and algo.update_counter == 6 * 2
+
+
+@pytest.mark.parametrize("name,kw,global_B,env_ranks", [
+    ("scalar", dict(eps_init=1., eps_final=0.05), 4, [0, 1, 2, 3]),
+    ("vector_rank1", dict(eps_init=1., eps_final=0.1, eps_final_min=0.001), 8, [4, 5, 6, 7])])
+def test_epsilon_schedule_matches_reference(name, kw, global_B, env_ranks):
+    """Epsilon annealing and the rank-aware vector epsilon (log-spaced over the global env index,
+    rlpyt/agents/dqn/epsilon_greedy.py:47-63,96-106) against values recorded from the
+    reference's AtariDqnAgent."""
+    from conftest import load_golden
+    from rlpyt_amd.agents.dqn.dqn_agent import AtariDqnAgent
+    from rlpyt_amd.envs.base import EnvSpaces
+    from rlpyt_amd.spaces import IntBox
+    g = load_golden("agents")
+    agent = AtariDqnAgent(**kw)
+    agent.initialize(EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
+                               action=IntBox(0, 6)), global_B=global_B, env_ranks=env_ranks)
+    agent.set_epsilon_itr_min_max(2, 10)
+    for itr in range(13):
+        agent.sample_mode(itr)
+        eps = np.broadcast_to(np.asarray(agent.distribution.epsilon, dtype=np.float64),
+                              (len(env_ranks),))
+        np.testing.assert_allclose(eps, g[f"{name}_sample_eps"][itr], rtol=1e-6, atol=0)
+    for k, itr in enumerate((0, 5)):
+        agent.eval_mode(itr)
+        assert float(agent.distribution.epsilon) == g[f"{name}_eval_eps"][k]

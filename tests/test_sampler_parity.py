@@ -67,7 +67,7 @@ def test_batches_match_reference_gpu_sampler(case, n_workers, n_groups):
     s = GpuSampler(RefSeededPong, C.ENV_KWARGS, batch_T=T, batch_B=C.B, n_workers=n_workers,
                    n_groups=n_groups, mid_batch_reset=(mode == "reset"), max_decorrelation_steps=0)
     agent = DetAgent()
-    s.initialize(agent, seed=C.SEED, bootstrap_value=True)
+    s.initialize(agent, seed=C.SEED, bootstrap_value=True, traj_info_kwargs=dict(discount=0.9))
     got_infos, ref_infos = [], []
     for itr in range(n_batches):
         smp, infos = s.obtain_samples(itr)
@@ -82,8 +82,9 @@ def test_batches_match_reference_gpu_sampler(case, n_workers, n_groups):
                           ("traj_done", smp.env.env_info.traj_done)]:
             got = got.numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
             assert np.array_equal(got, g[k + field]), (itr, field, got, g[k + field])
-        got_infos += [(float(ti["Length"]), float(ti["Return"])) for ti in infos]
-        ref_infos += [tuple(r) for r in g[k + "traj_len_ret"].tolist()]
+        got_infos += [(float(ti["Length"]), float(ti["Return"]), float(ti["NonzeroRewards"]),
+                       round(float(ti["DiscountedReturn"]), 9)) for ti in infos]
+        ref_infos += [tuple(r[:3]) + (round(r[3], 9),) for r in g[k + "traj_fields"].tolist()]
     # the reference drains its trajectory queue asynchronously (infos of the last batches may
     # still be in flight when the run stops): what it returned must be a sub-multiset of ours
     from collections import Counter
