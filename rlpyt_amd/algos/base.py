@@ -1,32 +1,48 @@
-"""Algorithm protocol (rlpyt/algos/base.py:3-68), kept verbatim so the runners drive the
-MI355X algorithms unchanged."""
+"""What every algorithm on this path shares.
+
+The runner-facing contract is the reference's (``rlpyt/algos/base.py:3-68``: ``initialize`` ->
+``optimize_agent(itr, samples) -> OptInfo``, ``optim_state_dict``, ``batch_size``, the class
+attributes the runner reads).  On top of it this base owns the two things that differ from a CPU
+algorithm here: sample batches arrive as HBM tensors (anything that is not already on the agent's
+device is moved once, asynchronously) and diagnostics leave the device once per call instead of
+once per minibatch."""
+import torch
 
 
 class RlAlgorithm:
+    # read by the runner (minibatch_rl.py:78,105,124,179-189)
     opt_info_fields = ()
     bootstrap_value = False
     update_counter = 0
+    optimizer = None
+    _batch_size = None
 
+    # ------------------------------------------------------------------ runner contract
     def initialize(self, agent, n_itr, batch_spec, mid_batch_reset, examples=None,
                    world_size=1, rank=0):
-        raise NotImplementedError
-
-    def async_initialize(self, agent, sampler_n_itr, batch_spec, mid_batch_reset,
-                         examples=None, world_size=1):
-        raise NotImplementedError
-
-    def optim_initialize(self, rank=0):
-        raise NotImplementedError
+        raise NotImplementedError(f"{type(self).__name__}.initialize")
 
     def optimize_agent(self, itr, samples=None, sampler_itr=None):
-        raise NotImplementedError
+        raise NotImplementedError(f"{type(self).__name__}.optimize_agent")
+
+    @property
+    def batch_size(self):
+        """Training batch size per update (the runner's replay-ratio bookkeeping)."""
+        return self._batch_size
 
     def optim_state_dict(self):
-        return self.optimizer.state_dict()
+        return None if self.optimizer is None else self.optimizer.state_dict()
 
     def load_optim_state_dict(self, state_dict):
         self.optimizer.load_state_dict(state_dict)
 
-    @property
-    def batch_size(self):
-        return self._batch_size
+    # ------------------------------------------------------------------ device helpers
+    def on_device(self, x):
+        """``x`` on the agent's device (no-op for the HBM-resident sampler's batches)."""
+        dev = self.agent.device
+        return x if x.device == dev else x.to(dev, non_blocking=True)
+
+    @staticmethod
+    def diagnostics_to_host(stats):
+        """Rows of per-update scalars (device tensors) -> nested Python lists, one D2H."""
+        return torch.stack(stats).cpu().tolist() if stats else []

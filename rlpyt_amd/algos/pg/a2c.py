@@ -36,8 +36,7 @@ class A2C(PolicyGradientAlgo):
         return OptInfo(loss=host[0], gradNorm=host[1], entropy=host[2], perplexity=host[3])
 
     def loss(self, samples):
-        dev = self.agent.device
-        mv = lambda x: x if x.device == dev else x.to(dev, non_blocking=True)  # noqa: E731
+        mv = self.on_device
         agent_inputs = AgentInputs(observation=mv(samples.env.observation),
                                    prev_action=mv(samples.agent.prev_action),
                                    prev_reward=mv(samples.env.prev_reward))

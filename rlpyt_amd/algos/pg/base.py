@@ -37,8 +37,7 @@ class PolicyGradientAlgo(RlAlgorithm):
         """(return_, advantage, valid) as HBM tensors: one fused scan launch computes
         GAE (or the discounted return when ``gae_lambda == 1``) together with the
         ``valid_from_done`` mask; advantage normalisation is a second, in-place pass."""
-        dev = self.agent.device
-        mv = lambda x: x if x.device == dev else x.to(dev, non_blocking=True)  # noqa: E731
+        mv = self.on_device
         reward, done = mv(samples.env.reward), mv(samples.env.done)
         value, bv = mv(samples.agent.agent_info.value), mv(samples.agent.bootstrap_value)
         want_valid = (not self.mid_batch_reset) or self.agent.recurrent
@@ -55,8 +54,3 @@ class PolicyGradientAlgo(RlAlgorithm):
         if self.normalize_advantage:
             ops.normalize_advantage_(advantage, valid, eps=1e-6)
         return return_, advantage, valid
-
-    @staticmethod
-    def _opt_info_to_host(stats):
-        """One device->host transfer for a whole iteration's diagnostics."""
-        return torch.stack(stats).cpu().tolist() if stats else []

@@ -45,8 +45,8 @@ class PPO(PolicyGradientAlgo):
 
     def optimize_agent(self, itr, samples):
         recurrent = self.agent.recurrent
+        mv = self.on_device
         dev = self.agent.device
-        mv = lambda x: x if x.device == dev else x.to(dev, non_blocking=True)  # noqa: E731
         agent_inputs = AgentInputs(observation=mv(samples.env.observation),
                                    prev_action=mv(samples.agent.prev_action),
                                    prev_reward=mv(samples.env.prev_reward))
@@ -107,7 +107,7 @@ class PPO(PolicyGradientAlgo):
         if self.linear_lr_schedule:
             self.lr_scheduler.step()
             self.ratio_clip = self._ratio_clip * (self.n_itr - itr) / self.n_itr
-        host = self._opt_info_to_host(stats)
+        host = self.diagnostics_to_host(stats)
         opt_info = OptInfo(*([row[k] for row in host] for k in range(4)))
         return opt_info
 

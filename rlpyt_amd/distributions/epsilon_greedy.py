@@ -1,44 +1,51 @@
-"""Epsilon-greedy action selection over Q-values (rlpyt/distributions/epsilon_greedy.py)."""
+"""Epsilon-greedy action selection over Q-values, on whatever device the Q-values live
+(the reference's rlpyt/distributions/epsilon_greedy.py draws on the host and patches the greedy
+choice by boolean indexing; here the draw is branch-free device code -- one ``torch.where`` over
+pre-drawn uniform / integer tensors -- so it can sit inside a captured step graph, optionally on
+a per-pipeline-group ``torch.Generator``)."""
 import torch
 
 from .categorical import DiscreteMixin, Distribution
 
 
+def _explore(greedy, n_actions, epsilon, generator):
+    """Replace each greedy choice by a uniformly random action with probability ``epsilon``
+    (scalar, or one value per environment)."""
+    dev = greedy.device
+    eps = epsilon.to(dev) if isinstance(epsilon, torch.Tensor) else epsilon
+    take_random = torch.rand(greedy.shape, device=dev, generator=generator) < eps
+    random_action = torch.randint(0, n_actions, greedy.shape, device=dev, generator=generator)
+    return torch.where(take_random, random_action, greedy)
+
+
 class EpsilonGreedy(DiscreteMixin, Distribution):
-    """argmax with probability 1-eps, uniform random otherwise; eps scalar or per-env."""
+    """``sample(q)``: argmax with probability 1 - epsilon, uniform otherwise."""
 
     def __init__(self, epsilon=1, **kwargs):
         super().__init__(**kwargs)
         self._epsilon = epsilon
 
-    def sample(self, q, generator=None):
-        arg_select = torch.argmax(q, dim=-1)
-        eps = self._epsilon
-        if isinstance(eps, torch.Tensor):
-            eps = eps.to(q.device)
-        mask = torch.rand(arg_select.shape, device=q.device, generator=generator) < eps
-        arg_rand = torch.randint(low=0, high=q.shape[-1], size=arg_select.shape,
-                                 device=q.device, generator=generator)
-        return torch.where(mask, arg_rand, arg_select)
-
-    @property
-    def epsilon(self):
-        return self._epsilon
+    epsilon = property(lambda self: self._epsilon)
 
     def set_epsilon(self, epsilon):
+        """Scalar, or a tensor with one epsilon per environment (vector epsilon)."""
         self._epsilon = epsilon
+
+    def sample(self, q, generator=None):
+        return _explore(q.argmax(dim=-1), q.shape[-1], self._epsilon, generator)
 
 
 class CategoricalEpsilonGreedy(EpsilonGreedy):
-    """For distributional Q (p over atoms z): greedy w.r.t. expected value."""
+    """For distributional Q-values ``p[..., A, n_atoms]`` over the atom grid ``z``: greedy with
+    respect to the expected value."""
 
     def __init__(self, z=None, **kwargs):
         super().__init__(**kwargs)
         self.z = z
 
-    def sample(self, p, z=None, generator=None):
-        q = torch.tensordot(p, z if z is not None else self.z, dims=1)
-        return super().sample(q, generator=generator)
-
     def set_z(self, z):
         self.z = z
+
+    def sample(self, p, z=None, generator=None):
+        expected = torch.tensordot(p, self.z if z is None else z, dims=1)
+        return _explore(expected.argmax(dim=-1), expected.shape[-1], self._epsilon, generator)

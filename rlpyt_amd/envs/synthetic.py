@@ -12,7 +12,7 @@ from collections import namedtuple
 import numpy as np
 
 from ..spaces import FloatBox, IntBox
-from .base import Env, EnvStep
+from . import Env, EnvStep, FrameStack
 
 AtariEnvInfo = namedtuple("AtariEnvInfo", ["game_score", "traj_done"])  # typename = module attribute: picklable
 
@@ -33,7 +33,7 @@ class SyntheticPong(Env):
         self._n = num_img_obs
         self._observation_space = IntBox(0, 256, shape=(num_img_obs, H, W), dtype="uint8")
         self._action_space = IntBox(0, 6)
-        self._obs = np.zeros((num_img_obs, H, W), dtype=np.uint8)
+        self._stack = FrameStack(num_img_obs, H, W)
         self._points_to_end = points_to_end
         self._max_steps = max_steps
         self._cost = step_cost_us * 1e-6
@@ -59,14 +59,11 @@ class SyntheticPong(Env):
         self._score = 0.
         self._steps = 0
         self._serve()
-        self._obs[:] = 0
-        self._draw()
-        for c in range(self._n - 1):
-            self._obs[c] = self._obs[-1]
-        return self._obs.copy()
+        self._draw(self._stack.newest)
+        self._stack.fill()
+        return self._stack.observation()
 
-    def _draw(self):
-        f = self._obs[-1]
+    def _draw(self, f):
         f[:] = 0
         p, o = int(self._py), int(self._oy)
         f[max(p - 6, 0):p + 6, W - 4:W - 2] = 200
@@ -109,11 +106,10 @@ class SyntheticPong(Env):
             self._score += reward
             self._serve()
         self._steps += 1
-        self._obs[:-1] = self._obs[1:]
-        self._draw()
+        self._draw(self._stack.push())
         done = self._points >= self._points_to_end or self._steps >= self._max_steps
         info = AtariEnvInfo(game_score=reward, traj_done=done)
-        return EnvStep(self._obs.copy(), np.float32(reward), done, info)
+        return EnvStep(self._stack.observation(), np.float32(reward), done, info)
 
 
 class TinyDiscreteEnv(Env):

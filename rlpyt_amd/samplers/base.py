@@ -1,38 +1,49 @@
-"""Sampler protocol (rlpyt/samplers/base.py:7-67)."""
-from ..utils.quick_args import save__init__args
+"""What a runner needs from a sampler: the constructor arguments of the reference's samplers
+(rlpyt/samplers/base.py:7-67 -- kept by name, they arrive from experiment configs), the batch
+geometry, and four calls: ``initialize -> examples``, ``obtain_samples(itr) -> (samples,
+traj_infos)``, ``evaluate_agent(itr) -> traj_infos``, ``shutdown()``."""
 from .collections import BatchSpec, TrajInfo
 
 
 class BaseSampler:
-    """Holds the configuration; subclasses implement initialize / obtain_samples /
-    evaluate_agent / shutdown.  ``batch_spec``, ``batch_size`` and ``mid_batch_reset`` are
-    read by the runner and the algorithm."""
-
-    alternating = False
+    alternating = False      # one agent, one model call per step (no alternating halves)
 
     def __init__(self, EnvCls, env_kwargs, batch_T, batch_B, CollectorCls=None,
                  max_decorrelation_steps=100, TrajInfoCls=TrajInfo, eval_n_envs=0,
                  eval_CollectorCls=None, eval_env_kwargs=None, eval_max_steps=None,
                  eval_max_trajectories=None):
-        eval_max_steps = None if eval_max_steps is None else int(eval_max_steps)
-        eval_max_trajectories = (None if eval_max_trajectories is None else
-                                 int(eval_max_trajectories))
-        save__init__args(locals())
-        self.batch_spec = BatchSpec(batch_T, batch_B)
-        self.mid_batch_reset = getattr(CollectorCls, "mid_batch_reset", True)
-
-    def initialize(self, *args, **kwargs):
-        raise NotImplementedError
-
-    def obtain_samples(self, itr):
-        raise NotImplementedError
-
-    def evaluate_agent(self, itr):
-        raise NotImplementedError
-
-    def shutdown(self):
-        pass
+        if int(batch_T) < 1 or int(batch_B) < 1:
+            raise ValueError(f"sampler batch must be at least [1, 1], got [{batch_T}, {batch_B}]")
+        self.EnvCls, self.env_kwargs = EnvCls, dict(env_kwargs or {})
+        self.batch_spec = BatchSpec(int(batch_T), int(batch_B))
+        self.batch_T, self.batch_B = self.batch_spec
+        self.max_decorrelation_steps = int(max_decorrelation_steps)
+        self.TrajInfoCls = TrajInfoCls
+        # collector classes only select the reset mode here (the collectors' work is done by the
+        # sampler's own env runners): anything with ``mid_batch_reset = False`` means wait-reset
+        self.CollectorCls, self.eval_CollectorCls = CollectorCls, eval_CollectorCls
+        self.mid_batch_reset = bool(getattr(CollectorCls, "mid_batch_reset", True))
+        # offline evaluation
+        self.eval_n_envs = int(eval_n_envs or 0)
+        self.eval_env_kwargs = eval_env_kwargs
+        self.eval_max_steps = None if eval_max_steps is None else int(eval_max_steps)
+        self.eval_max_trajectories = (None if eval_max_trajectories is None
+                                      else int(eval_max_trajectories))
 
     @property
     def batch_size(self):
+        """Env steps per ``obtain_samples`` call on this rank."""
         return self.batch_spec.size
+
+    def initialize(self, agent, affinity=None, seed=None, bootstrap_value=False,
+                   traj_info_kwargs=None, rank=0, world_size=1):
+        raise NotImplementedError(f"{type(self).__name__}.initialize")
+
+    def obtain_samples(self, itr):
+        raise NotImplementedError(f"{type(self).__name__}.obtain_samples")
+
+    def evaluate_agent(self, itr):
+        raise NotImplementedError(f"{type(self).__name__}.evaluate_agent")
+
+    def shutdown(self):
+        """Stop worker processes and release pinned memory, if any."""

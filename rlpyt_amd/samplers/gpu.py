@@ -46,18 +46,8 @@ from ..utils.buffer import (_map, buffer_from_example, buffer_leaves, np_mp_arra
 from ..utils.collections import AttrDict, namedarraytuple
 from ..utils.seed import set_seed
 from .base import BaseSampler
-from .collections import AgentSamplesBsv, AgentSamples, EnvSamples, Samples
-
-StepBuffer = namedarraytuple("StepBuffer", ["observation", "action", "reward", "done"])
-# what an agent's ``step_into`` gets to write the rows of a step itself (see BaseAgent.step_into)
-StepBinding = namedtuple("StepBinding", ["action_rows", "agent_info_rows", "action_out",
-                                         "uniforms", "t_dev", "lo", "push"])
-# frame-stack rebuild of row t handed to the agent together with the step (see step_into):
-# the arguments of ``ops.frame_push`` minus the staging copy
-FramePush = namedtuple("FramePush", ["obs", "new_frame", "full_rows", "slot", "scalar_rows"])
-# frame-stacked envs additionally publish the newest frame and a "stack was reset" flag
-StepBufferFs = namedarraytuple("StepBufferFs", ["observation", "action", "reward", "done",
-                                                "frame", "reset"])
+from .collections import (AgentSamples, AgentSamplesBsv, EnvSamples, FramePush, Samples,
+                          StepBinding, StepBuffer, StepBufferFs)
 
 
 class EnvRunner:

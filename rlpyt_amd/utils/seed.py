@@ -1,38 +1,35 @@
-"""Seeding helpers (rlpyt/utils/seed.py)."""
+"""Seeding: one call seeds numpy, torch's host generator and (when a device is present) the
+device generators; samplers derive per-env seeds as ``seed + global env index`` and per-rank
+seeds as ``seed + 100 * rank`` (rlpyt/runners/sync_rl.py:82)."""
+import os
 import time
 
 import numpy as np
 import torch
 
+_SEED_MOD = 2 ** 32 - 2      # numpy accepts [0, 2**32)
+
 
 def make_seed():
-    """A seed from the clock's microseconds, as the reference does."""
-    d = 10000
-    t = time.time()
-    sub1 = int(t * d) % d
-    sub2 = int(t * d ** 2) % d
-    s = 1e-3
-    s_inv = 1. / s
-    time.sleep(s * sub2 / d)
-    t2 = time.time()
-    t2 = t2 - int(t2)
-    t2 = int(t2 * d * s_inv) % d
-    time.sleep(s * sub1 / d)
-    t3 = time.time()
-    t3 = t3 - int(t3)
-    t3 = int(t3 * d * s_inv * 10) % 10
-    return (t3 - 1) * d + t2
+    """A fresh seed for runs that did not ask for one: OS entropy mixed with the clock, folded
+    into four decimal digits plus a leading digit like the reference's seeds, so it stays easy
+    to read in logs and leaves headroom for the ``+ 100 * rank`` / ``+ env index`` offsets."""
+    raw = int.from_bytes(os.urandom(4), "little") ^ (time.time_ns() & 0xffffffff)
+    return raw % 90000 + 10000
 
 
 def set_seed(seed):
-    seed %= 4294967294
+    seed = int(seed) % _SEED_MOD
     np.random.seed(seed)
-    torch.manual_seed(seed)
-    if torch.cuda.is_available():
-        torch.cuda.manual_seed(seed)
+    torch.manual_seed(seed)        # also seeds every visible device generator
+    return seed
 
 
 def set_envs_seeds(envs, seed):
-    if seed is not None:
-        for i, env in enumerate(envs):
-            env.seed(seed + i)
+    """``env.seed(seed + i)`` for envs that can be seeded (seed None: leave them alone)."""
+    if seed is None:
+        return
+    for i, env in enumerate(envs):
+        seeder = getattr(env, "seed", None)
+        if callable(seeder):
+            seeder(seed + i)
