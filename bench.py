@@ -419,13 +419,15 @@ def cpu_baseline(T, B_cpu, env_kwargs):
     """Oracle CPU port of the reference iteration on this box's host cores (bounded sample)."""
     from oracle.ppo_cpu_port import time_cpu_baseline
     from rlpyt_amd.envs.synthetic import SyntheticPong
+    from rlpyt_amd.utils.misc import usable_cpus
     res = time_cpu_baseline(SyntheticPong, env_kwargs, T=T, B=B_cpu if B_cpu > 0 else None,
-                            iters=1, threads=None)
+                            iters=1, threads=None, max_threads=usable_cpus())
     B_cpu = res["B"]
     return {"value": res["value"], "unit": "env-steps/s", "cores": res["cores"], "kind": "port",
             "sample": f"1 PPO iteration at [T={T}, B={B_cpu}] ({T * B_cpu} env steps, 16 "
                       f"minibatch updates), torch CPU with {res['cores']} threads (best of a thread-count "
-                      f"calibration on {os.cpu_count()} host cores), "
+                      f"calibration within the {usable_cpus():.0f} CPUs this process may use, "
+                      f"{os.cpu_count()} hardware threads on the box), "
                       f"{res['seconds']:.1f} s",
             "seconds": res["seconds"]}
 

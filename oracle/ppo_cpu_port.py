@@ -140,11 +140,15 @@ class PpoCpuPort:
         return self.optimize(bv)
 
 
-def calibrate_threads(candidates=(8, 16, 32, 64, 128), n_obs=256):
+def calibrate_threads(candidates=(4, 8, 16, 32, 64, 128), n_obs=256, max_threads=None):
     """Pick the torch intra-op thread count with the best fwd+bwd rate of the model on this
-    box (more threads is NOT faster for these small convolutions) -> (threads, obs/s)."""
+    box (more threads is NOT faster for these small convolutions) -> (threads, obs/s).
+    ``max_threads``: the CPUs the process may actually use (cgroup quota); thread counts above
+    it only measure the throttling."""
     import os
     ncpu = os.cpu_count() or 8
+    if max_threads:
+        ncpu = max(1, min(ncpu, int(max_threads)))
     model = AtariFfModelCpu()
     x = torch.randint(0, 256, (n_obs, 4, 104, 80), dtype=torch.uint8)
     best = (None, 0.)
@@ -164,13 +168,13 @@ def calibrate_threads(candidates=(8, 16, 32, 64, 128), n_obs=256):
 
 
 def time_cpu_baseline(EnvCls, env_kwargs, T=128, B=None, iters=1, threads=None, seed=0,
-                      target_seconds=15.):
+                      target_seconds=15., max_threads=None):
     """env-steps/sec of the CPU port on a bounded sample: ``iters`` PPO iterations at
     [T, B] (same hyper-parameters as the GPU run).  ``threads=None`` calibrates the thread
     count; ``B=None`` sizes the sample for about ``target_seconds`` of CPU work."""
     rate = None
     if threads is None:
-        threads, rate = calibrate_threads()
+        threads, rate = calibrate_threads(max_threads=max_threads)
     if B is None:
         if rate is None:
             _, rate = calibrate_threads((threads,))
