@@ -59,15 +59,19 @@ class RefSeededPong(SyntheticPong):
         super().seed(C.reference_env_seed(C.SEED, i))
 
 
-@pytest.mark.parametrize("n_workers,n_groups", [(0, 1), (2, 2), (3, 1), (0, 2)])
+@pytest.mark.parametrize("n_workers,n_groups,split", [(0, 1, False), (2, 2, False), (3, 1, False),
+                                                       (0, 2, False), (4, 2, True)])
 @pytest.mark.parametrize("case", C.CASES, ids=[c[0] for c in C.CASES])
-def test_batches_match_reference_gpu_sampler(case, n_workers, n_groups):
+def test_batches_match_reference_gpu_sampler(case, n_workers, n_groups, split):
     name, mode, T, n_batches = case
     g = load_golden("sampler")
     s = GpuSampler(RefSeededPong, C.ENV_KWARGS, batch_T=T, batch_B=C.B, n_workers=n_workers,
-                   n_groups=n_groups, mid_batch_reset=(mode == "reset"), max_decorrelation_steps=0)
+                   n_groups=n_groups, mid_batch_reset=(mode == "reset"), max_decorrelation_steps=0,
+                   split_workers=split)
+    assert s.n_workers == n_workers
     agent = DetAgent()
     s.initialize(agent, seed=C.SEED, bootstrap_value=True, traj_info_kwargs=dict(discount=0.9))
+    assert s.split_workers == split      # dedicated workers per pipeline group when asked for
     got_infos, ref_infos = [], []
     for itr in range(n_batches):
         smp, infos = s.obtain_samples(itr)
