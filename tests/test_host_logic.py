@@ -414,3 +414,72 @@ def test_epsilon_schedule_matches_reference(name, kw, global_B, env_ranks):
     for k, itr in enumerate((0, 5)):
         agent.eval_mode(itr)
         assert float(agent.distribution.epsilon) == g[f"{name}_eval_eps"][k]
+
+
+# ------------------------------------------------------------------- host-side primitives
+def test_seq_words_handoff_between_processes():
+    """rlpyt_seq_post / wait / arrive (csrc/hostsync.cpp): the futex sequence words behind every
+    master <-> worker hand-off.  No HIP call involved, so this runs without a GPU."""
+    import ctypes
+    import multiprocessing as mp
+    import time
+    from rlpyt_amd import _lib
+    from rlpyt_amd.utils.buffer import np_mp_array
+    lib = _lib.lib
+    words = np_mp_array(64, np.uint32)          # word 0: master -> workers, word 16: arrivals
+    words[:] = 0
+    post = ctypes.c_void_p(words.ctypes.data)
+    arr = ctypes.c_void_p(words.ctypes.data + 64)
+    n_workers, rounds = 3, 50
+
+    def worker():
+        for r in range(1, rounds + 1):
+            assert lib.rlpyt_seq_wait(post, r, 50, 5000) == 0
+            lib.rlpyt_seq_arrive(arr, r * n_workers)
+
+    ctx = mp.get_context("fork")
+    procs = [ctx.Process(target=worker) for _ in range(n_workers)]
+    for p in procs:
+        p.start()
+    for r in range(1, rounds + 1):
+        lib.rlpyt_seq_post(post, r)
+        assert lib.rlpyt_seq_wait(arr, r * n_workers, 100, 5000) == 0
+        assert int(words[16]) == r * n_workers
+    for p in procs:
+        p.join(timeout=5)
+        assert p.exitcode == 0
+    # a wait nobody answers times out with RLPYT_ETIMEOUT instead of hanging
+    t0 = time.perf_counter()
+    assert lib.rlpyt_seq_wait(post, rounds + 1, 10, 60) == -5
+    assert 0.05 <= time.perf_counter() - t0 < 1.0
+    # sequence comparison is wrap-around safe: a target "behind" the word counts as reached
+    words[0] = 5
+    assert lib.rlpyt_seq_wait(post, 0xfffffff0, 10, 50) == 0      # (int32)(5 - 0xfffffff0) > 0
+    words[0] = 0xfffffffe
+    assert lib.rlpyt_seq_wait(post, 3, 10, 50) == -5              # 3 is ahead of 0xfffffffe
+
+
+def test_usable_cpus_honours_limits(monkeypatch):
+    import builtins
+    import io
+    import os
+    from rlpyt_amd.utils import misc
+    n = misc.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            return io.StringIO("250000 100000\n")
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert misc.usable_cpus() == min(2.5, n if n < 2.5 else 2.5)
+
+    def unlimited(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            return io.StringIO("max 100000\n")
+        if str(path).startswith("/sys/fs/cgroup/cpu/"):
+            raise OSError
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", unlimited)
+    assert misc.usable_cpus() == float(min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
