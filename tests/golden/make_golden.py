@@ -950,6 +950,76 @@ def gen_agents():
     save("agents", **out)
 
 
+def gen_runner_keys():
+    """The tabular diagnostics the REFERENCE runners log (MinibatchRl / MinibatchRlEval,
+    rlpyt/runners/minibatch_rl.py) -- names and order -- with SerialSampler + PPO on the tiny
+    discrete env; ``StepsPerSecond`` among them is BASELINE.json's metric."""
+    import json
+    import types
+    pp = types.ModuleType("pyprind")     # the reference's progress bar dependency is absent here
+
+    class ProgBar:
+        def __init__(self, n, **k):
+            self.active = True
+
+        def update(self, *a, **k):
+            pass
+
+        def stop(self):
+            self.active = False
+    pp.ProgBar = ProgBar
+    sys.modules["pyprind"] = pp
+    from rlpyt.agents.pg.categorical import CategoricalPgAgent
+    from rlpyt.algos.pg.ppo import PPO
+    from rlpyt.runners.minibatch_rl import MinibatchRl, MinibatchRlEval
+    from rlpyt.samplers.serial.sampler import SerialSampler
+    from rlpyt.utils.logging import logger
+    from rlpyt.utils.tensor import infer_leading_dims, restore_leading_dims
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from rlpyt_amd.envs.synthetic import TinyDiscreteEnv
+
+    class TinyModel(torch.nn.Module):
+        def __init__(self, n_obs, n_act):
+            super().__init__()
+            self.body, self.pi = torch.nn.Linear(n_obs, 16), torch.nn.Linear(16, n_act)
+            self.v = torch.nn.Linear(16, 1)
+
+        def forward(self, obs, prev_action, prev_reward):
+            lead_dim, T, B, _ = infer_leading_dims(obs, 1)
+            h = torch.tanh(self.body(obs.view(T * B, -1)))
+            return restore_leading_dims((torch.softmax(self.pi(h), -1), self.v(h).squeeze(-1)),
+                                        lead_dim, T, B)
+
+    class TinyAgent(CategoricalPgAgent):
+        def __init__(self, **kw):
+            super().__init__(ModelCls=TinyModel, **kw)
+
+        def make_env_to_model_kwargs(self, env_spaces):
+            return dict(n_obs=env_spaces.observation.shape[0], n_act=env_spaces.action.n)
+
+    keys, cur = {}, ["train"]
+    orig = logger.dump_tabular
+
+    def capture(*a, **k):
+        keys.setdefault(cur[0], []).append([kk for kk, _ in logger._tabular])
+        return orig(*a, **k)
+    logger.dump_tabular = capture
+    for name, Runner, skw in (("train", MinibatchRl, {}),
+                              ("eval", MinibatchRlEval, dict(eval_n_envs=2, eval_max_steps=200,
+                                                             eval_max_trajectories=10,
+                                                             eval_env_kwargs={}))):
+        cur[0] = name
+        sampler = SerialSampler(EnvCls=TinyDiscreteEnv, env_kwargs={}, batch_T=8, batch_B=4,
+                                max_decorrelation_steps=0, **skw)
+        Runner(algo=PPO(minibatches=2, epochs=1), agent=TinyAgent(), sampler=sampler,
+               n_steps=8 * 4 * 6, log_interval_steps=8 * 4 * 3, affinity=dict(cuda_idx=None),
+               seed=0).train()
+    logger.dump_tabular = orig
+    with open(os.path.join(HERE, "runner_keys.json"), "w") as f:
+        json.dump({k: v[-1] for k, v in keys.items()}, f, indent=1)
+    print("runner_keys.json:", {k: len(v[-1]) for k, v in keys.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
@@ -957,6 +1027,7 @@ if __name__ == "__main__":
                 sumtree=gen_sumtree, frames=gen_frames, replay=gen_replay,
                 seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
                 models=gen_models, sampler=gen_sampler, algos=gen_algos, dqn_iterations=gen_dqn_iterations,
-                r2d1_iterations=gen_r2d1_iterations, agents=gen_agents)
+                r2d1_iterations=gen_r2d1_iterations, agents=gen_agents,
+                runner_keys=gen_runner_keys)
     for name in (sys.argv[1:] or list(gens)):      # python make_golden.py [subset ...]
         gens[name]()

@@ -483,3 +483,31 @@ def test_usable_cpus_honours_limits(monkeypatch):
         return real_open(path, *a, **k)
     monkeypatch.setattr(builtins, "open", unlimited)
     assert misc.usable_cpus() == float(min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+
+
+@pytest.mark.parametrize("which", ["train", "eval"])
+def test_runner_diagnostics_match_reference(which):
+    """The runners log the tabular diagnostics of the reference's MinibatchRl / MinibatchRlEval --
+    same names, same order (tests/golden/runner_keys.json, recorded from the reference runners);
+    ``Diagnostics/StepsPerSecond`` is the metric BASELINE.json quotes."""
+    import json
+    import os
+    from rlpyt_amd.runners.minibatch_rl import MinibatchRl, MinibatchRlEval
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                           "runner_keys.json")) as f:
+        ref = json.load(f)[which]
+    skw = {} if which == "train" else dict(eval_n_envs=2, eval_max_steps=200,
+                                           eval_max_trajectories=10)
+    sampler = GpuSampler(TinyDiscreteEnv, dict(), batch_T=8, batch_B=4, n_workers=0,
+                         max_decorrelation_steps=0, **skw)
+    Runner = MinibatchRl if which == "train" else MinibatchRlEval
+    runner = Runner(algo=OraclePPO(minibatches=2, epochs=1), agent=MlpCategoricalPgAgent(),
+                    sampler=sampler, n_steps=8 * 4 * 6, seed=0, log_interval_steps=8 * 4 * 3)
+    rows = []
+    orig = logger.dump_tabular
+    logger.dump_tabular = lambda *a, **k: (rows.append(list(logger.get_tabular())), orig(*a, **k))
+    try:
+        runner.train()
+    finally:
+        logger.dump_tabular = orig
+    assert rows and rows[-1] == ref, (sorted(set(ref) ^ set(rows[-1])), rows[-1][:14], ref[:14])
