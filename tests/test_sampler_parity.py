@@ -117,3 +117,36 @@ def test_evaluation_matches_reference_gpu_sampler(n_workers):
         smp, _ = s.obtain_samples(k)
         assert np.array_equal(smp.agent.action.numpy(), g[f"eval{k}_next_batch_action"])
     s.shutdown()
+
+
+@pytest.mark.parametrize("T,B,mode,layout", [
+    (3, 5, "reset", (2, 2, False)), (3, 5, "wait", (5, 1, False)), (7, 6, "reset", (3, 3, False)),
+    (7, 6, "wait", (4, 2, True)), (4, 9, "reset", (6, 3, True)), (4, 9, "wait", (2, 4, False)),
+    (1, 4, "reset", (2, 2, False)), (1, 4, "wait", (2, 2, False))])
+def test_every_layout_reproduces_the_serial_batches(T, B, mode, layout):
+    """Beyond the recorded shapes: for other [T, B] (incl. T = 1 and B not divisible by the
+    worker / group counts) every worker / pipeline-group layout must produce exactly the batches
+    of the serial single-group sampler -- the layout the reference vectors pin."""
+    def run(n_workers, n_groups, split):
+        s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=11), batch_T=T, batch_B=B,
+                       n_workers=n_workers, n_groups=n_groups, split_workers=split,
+                       mid_batch_reset=(mode == "reset"), max_decorrelation_steps=0)
+        s.initialize(DetAgent(), seed=21, bootstrap_value=True)
+        out, n_infos = [], 0
+        for itr in range(40 // T + 6):
+            smp, infos = s.obtain_samples(itr)
+            n_infos += len(infos)
+            out.append([x.numpy().copy() if isinstance(x, torch.Tensor) else np.array(x)
+                        for x in (smp.env.reward, smp.env.done, smp.agent.action,
+                                  smp.agent.prev_action, smp.env.prev_reward,
+                                  smp.agent.agent_info.value, smp.agent.bootstrap_value,
+                                  smp.env.env_info.traj_done)]
+                       + [C.obs_crc(smp.env.observation.numpy())])
+        s.shutdown()
+        return out, n_infos
+    ref, n_ref = run(0, 1, False)
+    got, n_got = run(*layout)
+    assert n_ref == n_got > 0
+    for a, b in zip(ref, got):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
