@@ -43,6 +43,20 @@ int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
 
+/* Which kernel variant ran.  Several entry points pick between size / alignment-gated kernel
+ * instantiations (e.g. rlpyt_frames_gather_seq switches to a wide kernel at n*seq_T >= 2048);
+ * every launch is counted per instantiation so that a parity test can assert WHICH one produced
+ * the result it checked (tests/test_variants.py).  Names are the device kernels' demangled names
+ * without namespaces / argument lists, e.g. "scan_exact_kernel<0, 4, 8, true>".
+ *   rlpyt_hip_last_variant()   name of the last kernel this thread launched ("" if none);
+ *   rlpyt_hip_variant_reset()  zero all counters;
+ *   rlpyt_hip_variant_dump()   "name\tcount\n" lines for every instantiation launched since the
+ *                              reset; returns the bytes needed (call with buf = NULL to size).
+ * A launch recorded into a hipGraph counts once, at capture.  Host-side, no HIP stream work. */
+const char* rlpyt_hip_last_variant(void);
+void rlpyt_hip_variant_reset(void);
+int64_t rlpyt_hip_variant_dump(char* buf, int64_t cap);
+
 /* Page-lock (pin) an existing host range so the sampler's fork-shared step buffer
  * (rlpyt/samplers/parallel/gpu/sampler.py:134-139) can be the source / destination of
  * asynchronous H2D / D2H copies.  Host pointers; synchronous. */

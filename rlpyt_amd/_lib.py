@@ -62,6 +62,9 @@ _SIGNATURES = {
     "rlpyt_hip_last_error": (c_char_p, []),
     "rlpyt_hip_abi_version": (c_int, []),
     "rlpyt_hip_device_info": (c_int, [c_char_p, c_int]),
+    "rlpyt_hip_last_variant": (c_char_p, []),
+    "rlpyt_hip_variant_reset": (None, []),
+    "rlpyt_hip_variant_dump": (c_int64, [c_char_p, c_int64]),
     "rlpyt_host_register": (c_int, [_p, c_int64]),
     "rlpyt_host_unregister": (c_int, [_p]),
     "rlpyt_host_device_pointer": (c_int, [_p, POINTER(c_void_p)]),
@@ -202,6 +205,27 @@ def host_mapped_tensor(arr, device):
           "rlpyt_host_device_pointer")
     assert arr.flags["C_CONTIGUOUS"]
     return torch.as_tensor(_DevView(dptr.value, arr.shape, arr.dtype.str), device=device)
+
+
+def last_variant():
+    """Name of the last kernel instantiation this thread launched (``rlpyt_hip_last_variant``)."""
+    return lib.rlpyt_hip_last_variant().decode()
+
+
+def variant_reset():
+    lib.rlpyt_hip_variant_reset()
+
+
+def variant_counts():
+    """{kernel instantiation: launches since the last ``variant_reset``}."""
+    need = lib.rlpyt_hip_variant_dump(None, 0)
+    buf = ctypes.create_string_buffer(int(need) + 1)
+    lib.rlpyt_hip_variant_dump(buf, need + 1)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, _, cnt = line.rpartition("\t")
+        out[name] = out.get(name, 0) + int(cnt)
+    return out
 
 
 def device_info():

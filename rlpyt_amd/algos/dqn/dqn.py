@@ -110,14 +110,14 @@ class DQN(RlAlgorithm):
             if self.prioritized_replay:
                 self.replay_buffer.update_batch_priorities(td_abs_errors)
             stats.append(torch.stack([loss.detach(), grad_norm.to(loss.dtype)]))
-            tds.append(td_abs_errors)
+            tds.append(td_abs_errors[::8])      # per update, as dqn.py:186
             self.update_counter += 1
             if self.update_counter % self.target_update_interval == 0:
                 self.agent.update_target(self.target_update_tau)
         host = torch.stack(stats).cpu().tolist()
         opt_info.loss.extend(r[0] for r in host)
         opt_info.gradNorm.extend(r[1] for r in host)
-        opt_info.tdAbsErr.extend(torch.cat(tds).cpu().tolist()[::8])
+        opt_info.tdAbsErr.extend(torch.cat(tds).cpu().tolist())
         self.update_itr_hyperparams(itr)
         return opt_info
 

@@ -149,13 +149,13 @@ extern "C" int rlpyt_cat_dqn_loss_fwd_bwd_f32(
   // cat_dqn.py:42: delta_z in double, used as a float32 divisor by the tensor ops
   const float delta_z = (float)(((double)v_max - (double)v_min) / (double)(P - 1));
   const int grid = (int)std::min<int64_t>(ceil_div(M, kCatWaves), kCatMaxGrid);
-  hipLaunchKernelGGL(cat_denom_kernel, dim3(1), dim3(kCatBlock), 0, s, valid, M, ws);
+  RL_LAUNCH(cat_denom_kernel, dim3(1), dim3(kCatBlock), 0, s, valid, M, ws);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cat_dqn_loss_kernel, dim3(grid), dim3(kCatBlock), 0, s, ps, target_ps,
+  RL_LAUNCH(cat_dqn_loss_kernel, dim3(grid), dim3(kCatBlock), 0, s, ps, target_ps,
                      next_ps, action, return_, done_n, is_weights, valid, z, M, A, P, v_min,
                      v_max, delta_z, disc_n, kl_div, grad_ps, ws);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cat_dqn_finalize_kernel, dim3(1), dim3(kCatBlock), 0, s, ws, grid,
+  RL_LAUNCH(cat_dqn_finalize_kernel, dim3(1), dim3(kCatBlock), 0, s, ws, grid,
                      out_scalars);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;

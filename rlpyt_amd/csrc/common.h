@@ -39,6 +39,26 @@ void set_error(const char* fmt, ...);
     }                                                                              \
   } while (0)
 
+// ---- kernel-variant registry (rlpyt_hip_variant_*) -----------------------------------------
+// Every launch site goes through RL_LAUNCH, which counts the launch per kernel INSTANTIATION
+// (host stub address; resolved to the device kernel's name on request), so that a parity test
+// can assert which size / alignment-gated variant actually ran (tests/test_variants.py).
+struct VariantSlot {
+  const void* host_fn;
+  const char* site;          // stringified kernel expression at the launch site
+  unsigned long long count;  // launches (graph captures count once, at capture)
+};
+VariantSlot* variant_slot(const void* host_fn, const char* site);
+void variant_hit(VariantSlot* slot);
+
+#define RL_LAUNCH(kernel, grid, block, lds, stream, ...)                                    \
+  do {                                                                                      \
+    static ::rlpyt::VariantSlot* _rl_slot =                                                 \
+        ::rlpyt::variant_slot(reinterpret_cast<const void*>(kernel), #kernel);             \
+    ::rlpyt::variant_hit(_rl_slot);                                                         \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                      \
+  } while (0)
+
 __host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr int kWave = 64;  // CDNA wavefront width

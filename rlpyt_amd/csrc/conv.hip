@@ -929,7 +929,7 @@ extern "C" int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat
                "rlpyt_atari_conv1_fwd_f32: obs / y1 / w1 must be 16-byte aligned");
   int cus = grid_for(1 << 30, 1);
   const int split = (M * 2 <= cus) ? 4 : (M <= cus ? 2 : 1);  // M <= 128: 4, M <= 256: 2
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for(M * split, 4)), dim3(C1F_THREADS), 0,
+  RL_LAUNCH(conv1_fwd_kernel, dim3(grid_for(M * split, 4)), dim3(C1F_THREADS), 0,
                      (hipStream_t)stream, obs, flat_idx, T, B, w1, b1, y1, M, scale, split);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -943,10 +943,10 @@ extern "C" int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float
   RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(w2), RLPYT_ESHAPE,
                "rlpyt_atari_conv2_fwd_f32: y1 / w2 must be 16-byte aligned");
   if (M <= grid_for(1 << 30, 1))   // small (sampling) batch: two workgroups per image
-    hipLaunchKernelGGL((conv2_fwd_kernel<2>), dim3(grid_for(2 * M, 3)), dim3(256), 0,
+    RL_LAUNCH((conv2_fwd_kernel<2>), dim3(grid_for(2 * M, 3)), dim3(256), 0,
                        (hipStream_t)stream, y1, w2, b2, y2, M);
   else
-    hipLaunchKernelGGL((conv2_fwd_kernel<4>), dim3(grid_for(M, 3)), dim3(256), 0, (hipStream_t)stream,
+    RL_LAUNCH((conv2_fwd_kernel<4>), dim3(grid_for(M, 3)), dim3(256), 0, (hipStream_t)stream,
                        y1, w2, b2, y2, M);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -968,7 +968,7 @@ extern "C" int rlpyt_atari_sample_convs_f32(
   RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(new_frame) && RL_ALIGNED16(full_rows) &&
                    RL_ALIGNED16(w1) && RL_ALIGNED16(w2),
                RLPYT_ESHAPE, "rlpyt_atari_sample_convs_f32: buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(sample_convs_kernel, dim3((unsigned)(Bg * SC_PARTS)), dim3(SC_THREADS), 0,
+  RL_LAUNCH(sample_convs_kernel, dim3((unsigned)(Bg * SC_PARTS)), dim3(SC_THREADS), 0,
                      (hipStream_t)stream, obs, obs, t_dev, B, lo, new_frame, full_rows, slot,
                      reward_rows, reward_src, done_rows, done_src, w1, b1, w2, b2, scale, y2);
   RL_LAUNCH_CHECK();
@@ -983,7 +983,7 @@ extern "C" int rlpyt_atari_conv2_dgrad_f32(const float* g2, const float* y2, con
   RL_CHECK_ARG(g2 && y2 && y1 && w2 && dy1, RLPYT_EINVAL, "rlpyt_atari_conv2_dgrad_f32: null pointer");
   RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(dy1), RLPYT_ESHAPE,
                "rlpyt_atari_conv2_dgrad_f32: y1 / dy1 must be 16-byte aligned");
-  hipLaunchKernelGGL(conv2_dgrad_kernel, dim3(grid_for(M, 6)), dim3(256), 0, (hipStream_t)stream,
+  RL_LAUNCH(conv2_dgrad_kernel, dim3(grid_for(M, 6)), dim3(256), 0, (hipStream_t)stream,
                      g2, y2, y1, w2, dy1, M);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -1002,9 +1002,9 @@ extern "C" int rlpyt_atari_conv2_wgrad_f32(const float* g2, const float* y2, con
   RL_CHECK_ARG(RL_ALIGNED16(y1), RLPYT_ESHAPE, "rlpyt_atari_conv2_wgrad_f32: y1 must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const int g = (int)std::min<int64_t>(M, kWgradGrid);
-  hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(g), dim3(256), 0, s, g2, y2, y1, workspace, M);
+  RL_LAUNCH(conv2_wgrad_kernel, dim3(g), dim3(256), 0, s, g2, y2, y1, workspace, M);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(256), 0, s, workspace,
+  RL_LAUNCH(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(256), 0, s, workspace,
                      g, PART2, dw2, DW2_N, db2);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -1021,10 +1021,10 @@ extern "C" int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* fl
                "rlpyt_atari_conv1_wgrad_f32: obs / dy1 must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const int g = (int)std::min<int64_t>(M, kWgradGrid);
-  hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(g), dim3(W1_THREADS), 0, s, obs, flat_idx, T, B, dy1,
+  RL_LAUNCH(conv1_wgrad_kernel, dim3(g), dim3(W1_THREADS), 0, s, obs, flat_idx, T, B, dy1,
                      workspace, M, scale);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART1 + 63) / 64), dim3(256), 0, s, workspace,
+  RL_LAUNCH(reduce_partials_kernel, dim3((PART1 + 63) / 64), dim3(256), 0, s, workspace,
                      g, PART1, dw1, DW1_N, db1);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -1041,10 +1041,10 @@ extern "C" int rlpyt_atari_conv2_bwd_f32(const float* g2, const float* y2, const
                "rlpyt_atari_conv2_bwd_f32: y1 / dy1 must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const int g = (int)std::min<int64_t>(M, kWgradGrid);
-  hipLaunchKernelGGL(conv2_bwd_kernel, dim3(g), dim3(B2_THREADS), 0, s, g2, y2, y1, w2, dy1,
+  RL_LAUNCH(conv2_bwd_kernel, dim3(g), dim3(B2_THREADS), 0, s, g2, y2, y1, w2, dy1,
                      workspace, M);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(256), 0, s, workspace,
+  RL_LAUNCH(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(256), 0, s, workspace,
                      g, PART2, dw2, DW2_N, db2);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;

@@ -75,12 +75,12 @@ int launch_gather_v(const void* src, void* dst, Map map, int64_t M, int64_t elem
   if (nvec >= 256) {
     const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(nvec, 1024), 64);
     const unsigned gy = (unsigned)std::min<int64_t>(M, 65535);
-    hipLaunchKernelGGL((gather_wide_kernel<V, Map>), dim3(gx, gy), dim3(256), 0, s,
+    RL_LAUNCH((gather_wide_kernel<V, Map>), dim3(gx, gy), dim3(256), 0, s,
                        (const V*)src, (V*)dst, map, M, nvec);
   } else {
     const int64_t total = M * nvec;
     const unsigned g = (unsigned)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
-    hipLaunchKernelGGL((gather_flat_kernel<V, Map>), dim3(g), dim3(256), 0, s, (const V*)src,
+    RL_LAUNCH((gather_flat_kernel<V, Map>), dim3(g), dim3(256), 0, s, (const V*)src,
                        (V*)dst, map, M, nvec);
   }
   RL_LAUNCH_CHECK();
@@ -185,7 +185,7 @@ int launch_frames_v(const uint8_t* frames, const uint8_t* done, const int64_t* t
   const int64_t nvec = HW / (int64_t)sizeof(V);
   const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(nvec, 256), 16);
   const unsigned gz = (unsigned)std::min<int64_t>(n * seq_T, 65535);
-  hipLaunchKernelGGL((frames_gather_kernel<V>), dim3(gx, C, gz), dim3(256), 0, s,
+  RL_LAUNCH((frames_gather_kernel<V>), dim3(gx, C, gz), dim3(256), 0, s,
                      (const V*)frames, done, t_idx, b_idx, (V*)obs, n, seq_T, T, B, C, nvec);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -202,7 +202,7 @@ int launch_frames(const uint8_t* frames, const uint8_t* done, const int64_t* t_i
   if ((a & 15) == 0 && C <= 32 && n * seq_T >= 2048) {
     const int64_t nvec = HW / 16;
     const unsigned g = (unsigned)std::min<int64_t>(n * seq_T, 256 * 32);
-    hipLaunchKernelGGL(frames_gather_wide_kernel, dim3(g), dim3(256), 0, s, (const B16*)frames, done,
+    RL_LAUNCH(frames_gather_wide_kernel, dim3(g), dim3(256), 0, s, (const B16*)frames, done,
                        t_idx, b_idx, (B16*)obs, n, seq_T, T, B, C, nvec);
     RL_LAUNCH_CHECK();
     return RLPYT_OK;
@@ -315,7 +315,7 @@ extern "C" int rlpyt_gather_sequences(const void* src, const int64_t* t_idx,
     const int64_t nvec = elem_bytes / (int64_t)sizeof(V);                                  \
     const unsigned g =                                                                     \
         (unsigned)std::min<int64_t>(ceil_div(total_bytes / (int64_t)sizeof(V), 256), 4096); \
-    hipLaunchKernelGGL((gather_seq_kernel<V>), dim3(g), dim3(256), 0, s, (const V*)src, t_idx, \
+    RL_LAUNCH((gather_seq_kernel<V>), dim3(g), dim3(256), 0, s, (const V*)src, t_idx, \
                        b_idx, (V*)dst, n, seq_T, T, B, nvec);                              \
   } while (0)
   if ((a & 15) == 0) RL_SEQ(B16);
@@ -410,11 +410,11 @@ extern "C" int rlpyt_obs_to_nhwc_f32(const uint8_t* src, const int64_t* flat_idx
                     ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
   if (fast) {
     const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(HW / 4, 256), 16);
-    hipLaunchKernelGGL((obs_to_nhwc_f32_kernel<4>), dim3(gx, gy), dim3(256), 0, s, src, flat_idx,
+    RL_LAUNCH((obs_to_nhwc_f32_kernel<4>), dim3(gx, gy), dim3(256), 0, s, src, flat_idx,
                        dst, T, B, HW, M, scale);
   } else {
     const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(HW * C, 256), 64);
-    hipLaunchKernelGGL(obs_to_nhwc_f32_generic_kernel, dim3(gx, gy), dim3(256), 0, s, src,
+    RL_LAUNCH(obs_to_nhwc_f32_generic_kernel, dim3(gx, gy), dim3(256), 0, s, src,
                        flat_idx, dst, T, B, C, HW, M, scale);
   }
   RL_LAUNCH_CHECK();

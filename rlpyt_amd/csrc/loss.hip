@@ -580,16 +580,16 @@ int launch_pg_loss(const float* prob_new, const float* value, const float* prob_
   int n_valid_part = 0;
   if (valid != nullptr) {
     n_valid_part = grid;
-    hipLaunchKernelGGL(valid_partial_kernel, dim3(grid), dim3(kLossBlock), 0, s, valid, M,
+    RL_LAUNCH(valid_partial_kernel, dim3(grid), dim3(kLossBlock), 0, s, valid, M,
                        ws->valid_part);
     RL_LAUNCH_CHECK();
   }
   const size_t lds = (size_t)kLossBlock * A * sizeof(float);
-  hipLaunchKernelGGL((pg_loss_kernel<MODE>), dim3(grid), dim3(kLossBlock), lds, s, prob_new,
+  RL_LAUNCH((pg_loss_kernel<MODE>), dim3(grid), dim3(kLossBlock), lds, s, prob_new,
                      value, prob_old, action, advantage, return_, valid, M, A, ratio_clip, c_v,
                      c_e, grad_prob, grad_value, ws, n_valid_part);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(pg_loss_finalize_kernel, dim3(1), dim3(kLossBlock), 0, s, ws, grid, M,
+  RL_LAUNCH(pg_loss_finalize_kernel, dim3(1), dim3(kLossBlock), 0, s, ws, grid, M,
                      valid != nullptr ? 1 : 0, MODE, c_v, c_e, out_scalars);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -645,11 +645,11 @@ extern "C" int rlpyt_dqn_loss_fwd_bwd_f32(const float* qs, const float* target_q
   LossWs* ws = reinterpret_cast<LossWs*>(workspace);
   hipStream_t s = (hipStream_t)stream;
   const int grid = (int)std::min<int64_t>(ceil_div(M, kLossBlock), kMaxLossGrid);
-  hipLaunchKernelGGL(dqn_loss_kernel, dim3(grid), dim3(kLossBlock), 0, s, qs, target_qs, next_qs,
+  RL_LAUNCH(dqn_loss_kernel, dim3(grid), dim3(kLossBlock), 0, s, qs, target_qs, next_qs,
                      action, return_, done_n, is_weights, M, A, disc_n, delta_clip, td_abs,
                      grad_qs, ws);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dqn_loss_finalize_kernel, dim3(1), dim3(kLossBlock), 0, s, ws, grid, M,
+  RL_LAUNCH(dqn_loss_finalize_kernel, dim3(1), dim3(kLossBlock), 0, s, ws, grid, M,
                      out_scalars);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -664,12 +664,12 @@ extern "C" int rlpyt_adv_normalize_f32(float* advantage, const float* valid, int
   NormWs* ws = reinterpret_cast<NormWs*>(workspace);
   hipStream_t s = (hipStream_t)stream;
   const int grid = (int)std::min<int64_t>(ceil_div(n, 256 * 4), kNormMaxGrid);
-  hipLaunchKernelGGL(norm_pass1_kernel, dim3(grid), dim3(256), 0, s, advantage, valid, n, ws);
+  RL_LAUNCH(norm_pass1_kernel, dim3(grid), dim3(256), 0, s, advantage, valid, n, ws);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(norm_pass2_kernel, dim3(grid), dim3(256), 0, s, advantage, valid, n, ws,
+  RL_LAUNCH(norm_pass2_kernel, dim3(grid), dim3(256), 0, s, advantage, valid, n, ws,
                      grid);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(norm_pass3_kernel, dim3(grid), dim3(256), 0, s, advantage, n, ws, grid, eps,
+  RL_LAUNCH(norm_pass3_kernel, dim3(grid), dim3(256), 0, s, advantage, n, ws, grid, eps,
                      stats_out);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -706,7 +706,7 @@ extern "C" int rlpyt_ppo_head_loss_fwd_bwd_f32(
   int n_valid_part = 0;
   if (valid != nullptr) {
     n_valid_part = (int)std::min<int64_t>(ceil_div(M, kLossBlock), kMaxLossGrid);
-    hipLaunchKernelGGL(valid_partial_kernel, dim3(n_valid_part), dim3(kLossBlock), 0, s, valid, M,
+    RL_LAUNCH(valid_partial_kernel, dim3(n_valid_part), dim3(kLossBlock), 0, s, valid, M,
                        ws->valid_part);
     RL_LAUNCH_CHECK();
   }
@@ -715,20 +715,20 @@ extern "C" int rlpyt_ppo_head_loss_fwd_bwd_f32(
   const int part = A * K + K + A + 1;
   const size_t lds = (size_t)3 * ((kHeadAMax + 1) * K + kHeadAMax + 1) * sizeof(float);
   if (K == 512)
-    hipLaunchKernelGGL((ppo_head_loss_kernel<8>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h,
+    RL_LAUNCH((ppo_head_loss_kernel<8>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h,
                        w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A,
                        ratio_clip, value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws,
                        n_valid_part, flat_idx, T, B);
   else
-    hipLaunchKernelGGL((ppo_head_loss_kernel<4>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h,
+    RL_LAUNCH((ppo_head_loss_kernel<4>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h,
                        w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A,
                        ratio_clip, value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws,
                        n_valid_part, flat_idx, T, B);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(head_reduce_kernel, dim3((part + 63) / 64), dim3(256), 0, s, wpart, grid,
+  RL_LAUNCH(head_reduce_kernel, dim3((part + 63) / 64), dim3(256), 0, s, wpart, grid,
                      part, grad_params);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(pg_loss_finalize_kernel, dim3(1), dim3(kLossBlock), 0, s, ws, n_waves, M,
+  RL_LAUNCH(pg_loss_finalize_kernel, dim3(1), dim3(kLossBlock), 0, s, ws, n_waves, M,
                      valid != nullptr ? 1 : 0, 0, value_loss_coeff, entropy_loss_coeff,
                      out_scalars);
   RL_LAUNCH_CHECK();

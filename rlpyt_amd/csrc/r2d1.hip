@@ -138,14 +138,14 @@ extern "C" int rlpyt_r2d1_loss_fwd_bwd_f32(
                "rlpyt_r2d1_loss_fwd_bwd_f32: value_scale_eps must be > 0");
   hipStream_t s = (hipStream_t)stream;
   SeqWs* ws = (SeqWs*)workspace;
-  hipLaunchKernelGGL(r2d1_column_kernel, dim3(B), dim3(256), 0, s, qs, target_qs, next_qs,
+  RL_LAUNCH(r2d1_column_kernel, dim3(B), dim3(256), 0, s, qs, target_qs, next_qs,
                      action, return_, done_n, valid, is_weights, T, B, A, disc_n, delta_clip,
                      value_scale_eps, pri_eta, td_abs_valid, priorities, grad_qs, ws);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(r2d1_finalize_kernel, dim3(1), dim3(256), 0, s, ws, B, out_scalars);
+  RL_LAUNCH(r2d1_finalize_kernel, dim3(1), dim3(256), 0, s, ws, B, out_scalars);
   RL_LAUNCH_CHECK();
   const int64_t n = (int64_t)T * B * A;
-  hipLaunchKernelGGL(scale_by_device_scalar_kernel,
+  RL_LAUNCH(scale_by_device_scalar_kernel,
                      dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 2048)), dim3(256), 0, s,
                      grad_qs, n, out_scalars + 1);
   RL_LAUNCH_CHECK();

@@ -109,10 +109,10 @@ extern "C" int rlpyt_obs_batch_stats_f32(const float* x, int64_t n, int64_t D, f
   const int n_part = (int)ceil_div(n, kRmsRowsPerBlock);
   RL_CHECK_ARG(n_part <= 65535, RLPYT_ESHAPE, "rlpyt_obs_batch_stats_f32: n too large");
   const unsigned gx = (unsigned)ceil_div(D, 256);
-  hipLaunchKernelGGL(rms_partial_kernel, dim3(gx, n_part), dim3(256), 0, s, x, n, D,
+  RL_LAUNCH(rms_partial_kernel, dim3(gx, n_part), dim3(256), 0, s, x, n, D,
                      (double*)workspace);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rms_finalize_kernel, dim3(gx), dim3(256), 0, s, (const double*)workspace,
+  RL_LAUNCH(rms_finalize_kernel, dim3(gx), dim3(256), 0, s, (const double*)workspace,
                      n_part, n, D, mean, var);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -124,10 +124,10 @@ extern "C" int rlpyt_obs_rms_merge_f32(float* mean, float* var, float* count,
   RL_CHECK_ARG(mean && var && count && batch_mean && batch_var && D > 0, RLPYT_EINVAL,
                "rlpyt_obs_rms_merge_f32: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(rms_merge_kernel, dim3((unsigned)ceil_div(D, 256)), dim3(256), 0, s, mean,
+  RL_LAUNCH(rms_merge_kernel, dim3((unsigned)ceil_div(D, 256)), dim3(256), 0, s, mean,
                      var, count, batch_mean, batch_var, batch_count, D);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rms_count_kernel, dim3(1), dim3(1), 0, s, count, batch_count);
+  RL_LAUNCH(rms_count_kernel, dim3(1), dim3(1), 0, s, count, batch_count);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
@@ -139,7 +139,7 @@ extern "C" int rlpyt_obs_normalize_f32(const float* x, const float* mean, const 
   if (n == 0) return RLPYT_OK;
   RL_CHECK_ARG(x && mean && var && out, RLPYT_EINVAL, "rlpyt_obs_normalize_f32: null pointer");
   const unsigned g = (unsigned)std::min<int64_t>(ceil_div(n * D, 256), 256 * 16);
-  hipLaunchKernelGGL(rms_normalize_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, mean,
+  RL_LAUNCH(rms_normalize_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, mean,
                      var, out, n, D, var_clip, obs_clip);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;

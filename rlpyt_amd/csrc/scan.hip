@@ -342,7 +342,7 @@ int launch_scan(const float* reward, const float* value, const uint8_t* done,
     int L = (int)ceil_div(T, S);
     S = (int)ceil_div(T, L);
     const int64_t grid = ceil_div(N, kWave);
-    hipLaunchKernelGGL((scan_segmented_kernel<MODE, VALID>), dim3((unsigned)grid),
+    RL_LAUNCH((scan_segmented_kernel<MODE, VALID>), dim3((unsigned)grid),
                        dim3(S * kWave), 0, s, reward, value, done, bootstrap, advantage,
                        return_, valid, T, N, L, g, gl);
     RL_LAUNCH_CHECK();
@@ -356,19 +356,19 @@ int launch_scan(const float* reward, const float* value, const uint8_t* done,
                     (valid == nullptr || aligned16(valid));
   if (can4 && N >= (int64_t)4 * 256 * 1024) {
     const int64_t grid = ceil_div(N / 4, 256);
-    hipLaunchKernelGGL((scan_exact_kernel<MODE, 4, 8, VALID>), dim3((unsigned)grid), dim3(256),
+    RL_LAUNCH((scan_exact_kernel<MODE, 4, 8, VALID>), dim3((unsigned)grid), dim3(256),
                        0, s, reward, value, done, bootstrap, advantage, return_, valid, T, N, g,
                        gl);
   } else if (N >= 64 * 1024) {
     const int64_t grid = ceil_div(N, 256);
-    hipLaunchKernelGGL((scan_exact_kernel<MODE, 1, 8, VALID>), dim3((unsigned)grid), dim3(256),
+    RL_LAUNCH((scan_exact_kernel<MODE, 1, 8, VALID>), dim3((unsigned)grid), dim3(256),
                        0, s, reward, value, done, bootstrap, advantage, return_, valid, T, N, g,
                        gl);
   } else {
     // Few columns: one wave per workgroup to spread over CUs, deep chunks so a whole
     // [T<=32k] column segment of loads is in flight per wait.
     const int64_t grid = ceil_div(N, 64);
-    hipLaunchKernelGGL((scan_exact_kernel<MODE, 1, 32, VALID>), dim3((unsigned)grid), dim3(64),
+    RL_LAUNCH((scan_exact_kernel<MODE, 1, 32, VALID>), dim3((unsigned)grid), dim3(64),
                        0, s, reward, value, done, bootstrap, advantage, return_, valid, T, N, g,
                        gl);
   }
@@ -434,11 +434,11 @@ extern "C" int rlpyt_valid_from_done(const uint8_t* done, float* valid, int T, i
   if (T == 0 || N == 0) return RLPYT_OK;
   hipStream_t s = (hipStream_t)stream;
   if (N % 4 == 0 && aligned4(done) && aligned16(valid) && N >= 4 * 256 * 256) {
-    hipLaunchKernelGGL((valid_kernel<4>), dim3((unsigned)ceil_div(N / 4, 256)), dim3(256), 0, s,
+    RL_LAUNCH((valid_kernel<4>), dim3((unsigned)ceil_div(N / 4, 256)), dim3(256), 0, s,
                        done, valid, T, N);
   } else {
     const int bs = N >= 64 * 256 ? 256 : 64;
-    hipLaunchKernelGGL((valid_kernel<1>), dim3((unsigned)ceil_div(N, bs)), dim3(bs), 0, s, done,
+    RL_LAUNCH((valid_kernel<1>), dim3((unsigned)ceil_div(N, bs)), dim3(bs), 0, s, done,
                        valid, T, N);
   }
   RL_LAUNCH_CHECK();
@@ -466,10 +466,10 @@ extern "C" int rlpyt_nstep_return_f32(const float* reward, const uint8_t* done, 
   const int64_t total = (int64_t)T_out * (can4 ? N / 4 : N);
   const int64_t grid = std::min<int64_t>(ceil_div(total, 256), 256 * 8);
   if (can4)
-    hipLaunchKernelGGL((nstep_kernel<4>), dim3((unsigned)grid), dim3(256), 0, s, reward, done,
+    RL_LAUNCH((nstep_kernel<4>), dim3((unsigned)grid), dim3(256), 0, s, reward, done,
                        return_, done_n, T_in, T_out, N, n_step, coef);
   else
-    hipLaunchKernelGGL((nstep_kernel<1>), dim3((unsigned)grid), dim3(256), 0, s, reward, done,
+    RL_LAUNCH((nstep_kernel<1>), dim3((unsigned)grid), dim3(256), 0, s, reward, done,
                        return_, done_n, T_in, T_out, N, n_step, coef);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;

@@ -104,7 +104,7 @@ extern "C" int rlpyt_commit_rows(const rlpyt_row_copy* table_dev, int n_entries,
   if (n_entries == 0) return RLPYT_OK;
   RL_CHECK_ARG(table_dev != nullptr, RLPYT_EINVAL, "rlpyt_commit_rows: null table");
   const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(max_entry_bytes, 256 * 64), 1024));
-  hipLaunchKernelGGL(commit_rows_kernel, dim3((unsigned)chunks, (unsigned)n_entries), dim3(256), 0,
+  RL_LAUNCH(commit_rows_kernel, dim3((unsigned)chunks, (unsigned)n_entries), dim3(256), 0,
                      (hipStream_t)stream, table_dev, t_dev);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -126,10 +126,10 @@ extern "C" int rlpyt_categorical_head_f32(const float* h, const float* w_pi, con
   const dim3 grid((unsigned)ceil_div(n, 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (A <= 8)
-    hipLaunchKernelGGL((categorical_head_kernel<8>), grid, block, 0, s, h, w_pi, b_pi, w_v, b_v,
+    RL_LAUNCH((categorical_head_kernel<8>), grid, block, 0, s, h, w_pi, b_pi, w_v, b_v,
                        uniforms, u_row_dev, n, K, A, prob, value, action);
   else
-    hipLaunchKernelGGL((categorical_head_kernel<32>), grid, block, 0, s, h, w_pi, b_pi, w_v, b_v,
+    RL_LAUNCH((categorical_head_kernel<32>), grid, block, 0, s, h, w_pi, b_pi, w_v, b_v,
                        uniforms, u_row_dev, n, K, A, prob, value, action);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -198,7 +198,7 @@ extern "C" int rlpyt_frame_push(uint8_t* obs, const int64_t* t_dev, int64_t B, i
                                  reinterpret_cast<uintptr_t>(full_rows) | reinterpret_cast<uintptr_t>(stage)) & 15) == 0,
                RLPYT_ESHAPE, "rlpyt_frame_push: H*W must be a multiple of 16 and buffers 16-byte aligned");
   const unsigned gx = (unsigned)std::min<int64_t>(ceil_div((int64_t)C * HW / 16, 256), 4);
-  hipLaunchKernelGGL(frame_push_kernel, dim3(gx, (unsigned)Bg), dim3(256), 0, (hipStream_t)stream, obs,
+  RL_LAUNCH(frame_push_kernel, dim3(gx, (unsigned)Bg), dim3(256), 0, (hipStream_t)stream, obs,
                      t_dev, B, lo, C, HW, new_frame, full_rows, slot, stage, reward_rows, reward_src,
                      done_rows, done_src);
   RL_LAUNCH_CHECK();
@@ -325,15 +325,15 @@ extern "C" int rlpyt_fc_small_f32(const float* x, const float* w, const float* b
   const int ksplit = (int)ceil_div(K, kchunk);
   const dim3 grid((unsigned)(N / 16), (unsigned)ksplit);
   if (M <= 64)
-    hipLaunchKernelGGL((rlpyt::fc_small_kernel<1>), grid, dim3(256), 0, s, x, w, workspace, M, N, K, kchunk);
+    RL_LAUNCH((rlpyt::fc_small_kernel<1>), grid, dim3(256), 0, s, x, w, workspace, M, N, K, kchunk);
   else if (M <= 128)
-    hipLaunchKernelGGL((rlpyt::fc_small_kernel<2>), grid, dim3(256), 0, s, x, w, workspace, M, N, K, kchunk);
+    RL_LAUNCH((rlpyt::fc_small_kernel<2>), grid, dim3(256), 0, s, x, w, workspace, M, N, K, kchunk);
   else
-    hipLaunchKernelGGL((rlpyt::fc_small_kernel<4>), grid, dim3(256), 0, s, x, w, workspace, M, N, K, kchunk);
+    RL_LAUNCH((rlpyt::fc_small_kernel<4>), grid, dim3(256), 0, s, x, w, workspace, M, N, K, kchunk);
   RL_LAUNCH_CHECK();
   if (y == nullptr) return RLPYT_OK;   // caller consumes the split-K partials itself
   const int64_t MN = (int64_t)M * N;
-  hipLaunchKernelGGL(rlpyt::fc_small_finish_kernel, dim3((unsigned)ceil_div(MN / 4, 256)), dim3(256), 0,
+  RL_LAUNCH(rlpyt::fc_small_finish_kernel, dim3((unsigned)ceil_div(MN / 4, 256)), dim3(256), 0,
                      s, workspace, bias, y, MN, N, ksplit, relu);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -456,11 +456,11 @@ extern "C" int rlpyt_pg_sample_head_f32(const float* partial, int ksplit, const 
   const dim3 grid((unsigned)ceil_div(n, 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (K == 512)
-    hipLaunchKernelGGL((rlpyt::pg_sample_head_kernel<8>), grid, block, 0, s, partial, ksplit, fc_bias,
+    RL_LAUNCH((rlpyt::pg_sample_head_kernel<8>), grid, block, 0, s, partial, ksplit, fc_bias,
                        w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows,
                        action_rows, B, lo, action_out);
   else
-    hipLaunchKernelGGL((rlpyt::pg_sample_head_kernel<4>), grid, block, 0, s, partial, ksplit, fc_bias,
+    RL_LAUNCH((rlpyt::pg_sample_head_kernel<4>), grid, block, 0, s, partial, ksplit, fc_bias,
                        w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows,
                        action_rows, B, lo, action_out);
   RL_LAUNCH_CHECK();

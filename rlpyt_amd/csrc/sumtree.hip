@@ -36,10 +36,25 @@ struct rlpyt_sumtree {
   int* d_count;               // device: number of unique idxs
   int64_t prev_cap, diff_cap;
   int n_prev;
+  int device;                 // HIP device the tree lives on (hipGetDevice at create time)
 };
 
 namespace rlpyt {
 namespace {
+
+// The handle owns HBM on ONE device; calls that allocate or launch for it make that device
+// current for their duration (the caller's current device may be another rank's GPU).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev && dev >= 0)
+      switched = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
 
 struct Run {          // contiguous leaves [leaf0, leaf0+count) with diffs at diffs[off...]
   int64_t leaf0, count, off;
@@ -294,6 +309,8 @@ extern "C" int rlpyt_sumtree_create(rlpyt_sumtree** out, int T, int B, int off_b
   t->off_backward = off_backward; t->off_forward = off_forward;
   t->default_value = default_value;
   t->input_priority_shift = input_priority_shift;
+  t->device = -1;
+  (void)hipGetDevice(&t->device);
   // tree_levels = int(np.ceil(np.log2(size + 1)) + 1)   (sum_tree.py:39)
   int lv = 0;
   while (((int64_t)1 << lv) < t->size + 1) ++lv;  // ceil(log2(size+1))
@@ -319,6 +336,7 @@ extern "C" int rlpyt_sumtree_create(rlpyt_sumtree** out, int T, int B, int off_b
 
 extern "C" void rlpyt_sumtree_destroy(rlpyt_sumtree* t) {
   if (!t) return;
+  DeviceGuard dev_guard(t->device);
   if (t->tree) (void)hipFree(t->tree);
   if (t->input_priorities) (void)hipFree(t->input_priorities);
   if (t->prev_idx) (void)hipFree(t->prev_idx);
@@ -330,13 +348,14 @@ extern "C" void rlpyt_sumtree_destroy(rlpyt_sumtree* t) {
 
 extern "C" int rlpyt_sumtree_reset(rlpyt_sumtree* t, rlpyt_stream_t stream) {
   RL_CHECK_ARG(t != nullptr, RLPYT_EINVAL, "rlpyt_sumtree_reset: null handle");
+  DeviceGuard dev_guard(t->device);
   hipStream_t s = (hipStream_t)stream;
   RL_HIP(hipMemsetAsync(t->tree, 0, t->n_nodes * sizeof(double), s));
   t->t = 0;
   t->initial_wrap_guard = true;
   t->n_prev = -1;
   if (t->input_priorities) {
-    hipLaunchKernelGGL(fill_f64_kernel, dim3(1024), dim3(256), 0, s, t->input_priorities,
+    RL_LAUNCH(fill_f64_kernel, dim3(1024), dim3(256), 0, s, t->input_priorities,
                        t->size, t->default_value);
     RL_LAUNCH_CHECK();
   }
@@ -372,26 +391,31 @@ extern "C" int rlpyt_sumtree_advance(rlpyt_sumtree* tr, int T_new, const double*
   int64_t high_on_t = pymod((int64_t)t + T_new - b - 1, T) + 1;
   int64_t low_off_t = pymod((int64_t)t + T_new - b, T);
   int64_t high_off_t = pymod((int64_t)t + T_new + f - 1, T) + 1;
-  if (tr->initial_wrap_guard) {
+  const bool guard_was_up = tr->initial_wrap_guard;
+  bool guard_after = guard_was_up;
+  if (guard_was_up) {
     low_on_t = std::max<int64_t>(f, t - b);
     high_on_t = low_off_t = std::max<int64_t>(low_on_t, (int64_t)t + T_new - b);
-    if (t + T_new - b >= f) tr->initial_wrap_guard = false;
+    if (t + T_new - b >= f) guard_after = false;
   }
+  // validate first: an error return leaves guard, cursor and tree untouched (a retry takes the
+  // same path); the guard flag is committed with the cursor once the launches are issued
   RL_CHECK_ARG(high_on_t <= T && low_off_t <= T, RLPYT_ESHAPE,
                "rlpyt_sumtree_advance: advance of %d rows overruns the ring during start-up",
                T_new);
+  DeviceGuard dev_guard(tr->device);
   if (priorities != nullptr) {
     RL_CHECK_ARG(tr->input_priorities != nullptr, RLPYT_ESTATE,
                  "rlpyt_sumtree_advance: Must enable input priorities.");
     const int input_t = t - tr->input_priority_shift;   // sum_tree.py:90-97
     const int64_t total = (int64_t)T_new * B;
-    hipLaunchKernelGGL(write_input_pri_kernel,
+    RL_LAUNCH(write_input_pri_kernel,
                        dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256),
                        0, s, tr->input_priorities, priorities, kind, input_t, T_new, T, B);
     RL_LAUNCH_CHECK();
-    if (tr->initial_wrap_guard && input_t < 0) {
+    if (guard_was_up && input_t < 0) {
       const int64_t rows = -input_t;  // input_priorities[input_t:] = default
-      hipLaunchKernelGGL(fill_f64_kernel, dim3(64), dim3(256), 0, s,
+      RL_LAUNCH(fill_f64_kernel, dim3(64), dim3(256), 0, s,
                          tr->input_priorities + ((int64_t)T - rows) * B, rows * B,
                          tr->default_value);
       RL_LAUNCH_CHECK();
@@ -416,7 +440,7 @@ extern "C" int rlpyt_sumtree_advance(rlpyt_sumtree* tr, int T_new, const double*
     Runs all{};
     for (int i = 0; i < on.n; ++i) {
       const Run r = on.r[i];
-      hipLaunchKernelGGL(advance_apply_kernel,
+      RL_LAUNCH(advance_apply_kernel,
                          dim3((unsigned)std::min<int64_t>(ceil_div(r.count, 256), 2048)),
                          dim3(256), 0, s, tr->tree, tr->low_idx, tr->input_priorities,
                          tr->default_value, r, 1, tr->diffs);
@@ -424,17 +448,18 @@ extern "C" int rlpyt_sumtree_advance(rlpyt_sumtree* tr, int T_new, const double*
     }
     for (int i = 0; i < off.n; ++i) {
       const Run r = off.r[i];
-      hipLaunchKernelGGL(advance_apply_kernel,
+      RL_LAUNCH(advance_apply_kernel,
                          dim3((unsigned)std::min<int64_t>(ceil_div(r.count, 256), 2048)),
                          dim3(256), 0, s, tr->tree, tr->low_idx, (const double*)nullptr, 0.0, r,
                          0, tr->diffs);
       all.r[all.n++] = r;
     }
     RL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(propagate_kernel, dim3(tr->levels - 1), dim3(256), 0, s, tr->tree,
+    RL_LAUNCH(propagate_kernel, dim3(tr->levels - 1), dim3(256), 0, s, tr->tree,
                        tr->levels, all, (const int64_t*)nullptr, tr->diffs, (const int*)nullptr);
     RL_LAUNCH_CHECK();
   }
+  tr->initial_wrap_guard = guard_after;
   tr->t = (int)pymod((int64_t)t + T_new, T);
   return RLPYT_OK;
 }
@@ -445,11 +470,12 @@ extern "C" int rlpyt_sumtree_sample(rlpyt_sumtree* t, const double* uniforms, in
   RL_CHECK_ARG(t && uniforms && T_idxs && B_idxs, RLPYT_EINVAL,
                "rlpyt_sumtree_sample: null pointer");
   RL_CHECK_ARG(n >= 0, RLPYT_EINVAL, "rlpyt_sumtree_sample: negative n");
+  DeviceGuard dev_guard(t->device);
   int rc = ensure_prev(t, std::max(n, 1));
   if (rc != RLPYT_OK) return rc;
   t->n_prev = n;
   if (n == 0) return RLPYT_OK;
-  hipLaunchKernelGGL(find_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64), 0,
+  RL_LAUNCH(find_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64), 0,
                      (hipStream_t)stream, t->tree, t->levels, t->low_idx, t->B, uniforms, n,
                      t->prev_idx, T_idxs, B_idxs, priorities);
   RL_LAUNCH_CHECK();
@@ -466,20 +492,21 @@ extern "C" int rlpyt_sumtree_update(rlpyt_sumtree* t, const double* new_prioriti
   RL_CHECK_ARG(n <= kUniqMax, RLPYT_ESHAPE, "rlpyt_sumtree_update: batch %d > %d unsupported", n,
                kUniqMax);
   if (n == 0) return RLPYT_OK;
+  DeviceGuard dev_guard(t->device);
   hipStream_t s = (hipStream_t)stream;
   int rc = ensure_diffs(t, n);
   if (rc != RLPYT_OK) return rc;
   int* first_pos = reinterpret_cast<int*>(t->uniq_idx + t->prev_cap);
-  hipLaunchKernelGGL(unique_first_kernel, dim3(1), dim3(1024), 0, s, t->prev_idx, n, t->uniq_idx,
+  RL_LAUNCH(unique_first_kernel, dim3(1), dim3(1024), 0, s, t->prev_idx, n, t->uniq_idx,
                      first_pos, t->d_count);
   RL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(update_leaves_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,
+  RL_LAUNCH(update_leaves_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,
                      t->tree, t->uniq_idx, first_pos, t->d_count, new_priorities, t->diffs);
   RL_LAUNCH_CHECK();
   Runs one{};
   one.n = 1;
   one.r[0].leaf0 = 0; one.r[0].count = n; one.r[0].off = 0;
-  hipLaunchKernelGGL(propagate_kernel, dim3(t->levels - 1), dim3(256), 0, s, t->tree, t->levels,
+  RL_LAUNCH(propagate_kernel, dim3(t->levels - 1), dim3(256), 0, s, t->tree, t->levels,
                      one, t->uniq_idx, t->diffs, t->d_count);
   RL_LAUNCH_CHECK();
   // (The reference also replaces prev_tree_idxs by the unique set, sum_tree.py:135; a

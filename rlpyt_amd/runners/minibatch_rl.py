@@ -34,6 +34,12 @@ class MinibatchRlBase:
         self.world_size = 1
 
     def startup(self):
+        # Every kernel wrapper launches on torch's CURRENT device / stream and the replay /
+        # sum-tree handles allocate on it: make the rank's GPU current before anything touches
+        # the device (sampler buffers, agent.to_device, workspaces).
+        cuda_idx = self.affinity.get("cuda_idx", None)
+        if cuda_idx is not None and torch.cuda.is_available():
+            torch.cuda.set_device(cuda_idx)
         torch_threads = self.affinity.get("master_torch_threads", None)
         if torch_threads is not None:
             torch.set_num_threads(torch_threads)
@@ -97,9 +103,8 @@ class MinibatchRlBase:
             v.extend(new_v if isinstance(new_v, list) else [new_v])
 
     def log_diagnostics(self, itr, traj_infos=None, eval_time=0, prefix="Diagnostics/"):
-        if itr > 0:
-            pass
-        self.save_itr_snapshot(itr)
+        if itr >= self.min_itr_learn - 1:      # minibatch_rl.py:168-169
+            self.save_itr_snapshot(itr)
         new_time = time.time()
         self._cum_time = new_time - self._start_time
         train_time_elapsed = new_time - self._last_time - eval_time
@@ -252,8 +257,14 @@ class SyncRl(MinibatchRl):
             kw = dict(init_method=self.init_method) if self.init_method else {}
             dist.init_process_group(backend=backend, rank=rank, world_size=world_size, **kw)
         self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+        if self.affinity.get("cuda_idx", None) is not None and torch.cuda.is_available():
+            torch.cuda.set_device(self.affinity["cuda_idx"])
         if self.seed is None:
-            self.seed = make_seed()
+            # the master draws the seed, the workers derive theirs from it (sync_rl.py:52,82):
+            # rank 0's draw is broadcast so that a run is reproducible from rank 0's log
+            box = [make_seed() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.seed = int(box[0])
         self.seed = self.seed + 100 * self.rank  # sync_rl.py:82
         if self.rank > 0:
             logger.set_quiet(True)  # workers do no logging (sync_rl.py:178-179)
@@ -278,6 +289,8 @@ def _sync_entry(rank, world_size, port, backend, build_fn, args):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world_size), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
+    if torch.cuda.is_available():   # rank r <-> GPU r (all ranks on GPU 0 on a 1-GPU box)
+        torch.cuda.set_device(rank % torch.cuda.device_count())
     dist.init_process_group(backend=backend, rank=rank, world_size=world_size,
                             init_method=f"tcp://127.0.0.1:{port}")
     try:
