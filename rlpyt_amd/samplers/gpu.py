@@ -380,11 +380,15 @@ class GpuSampler(BaseSampler):
 
     GRAPH_WARMUP_CALLS = 3   # eager calls per group before capture (MIOpen/hipBLASLt find)
 
-    def __init__(self, *args, n_workers=0, mid_batch_reset=True, pin_step_buffer=True,
+    def __init__(self, *args, n_workers=None, mid_batch_reset=True, pin_step_buffer=True,
                  n_groups=None, use_graph=True, frame_dedup=True, native_loop=True, fused_step=True,
                  fused_push=True, split_workers=False, zero_copy=False, **kwargs):
         super().__init__(*args, **kwargs)
-        self.n_workers = int(n_workers)
+        # n_workers=None: one env worker per entry of affinity["workers_cpus"], the reference's
+        # rule (rlpyt/samplers/parallel/base.py:157-172), resolved in initialize(); an explicit
+        # count (0 = envs stepped in the master process) overrides the affinity.
+        self._n_workers_arg = None if n_workers is None else int(n_workers)
+        self._n_groups_arg = n_groups
         self.mid_batch_reset = bool(mid_batch_reset)
         self.pin_step_buffer = pin_step_buffer
         self.use_graph = bool(use_graph)
@@ -395,7 +399,27 @@ class GpuSampler(BaseSampler):
         self._split_workers = bool(split_workers)
         self.zero_copy = bool(zero_copy)
         self._native = None
+        self._resolve_layout(None)
+        self._pinned_ptrs = []
+        self.workers = []
+        self.timing = dict(wait_env_s=0., device_issue_s=0., device_wait_s=0., batches=0,
+                           pre_s=0., loop_s=0., tail_s=0., post_s=0.)
+
+    def _resolve_layout(self, affinity):
+        """Worker-process count and pipeline-group count.  Workers: the ctor's ``n_workers``, else
+        ``len(affinity["workers_cpus"])`` capped at B (rlpyt/samplers/parallel/base.py:157-165),
+        else 0."""
         B = self.batch_spec.B
+        n = self._n_workers_arg
+        if n is None:
+            cpus = (affinity or {}).get("workers_cpus", None)
+            n = 0 if cpus is None else len(cpus)
+            if n > B:
+                logger.log(f"WARNING: requested fewer envs ({B}) than available worker processes "
+                           f"({n}). Using fewer workers.")
+                n = B
+        self.n_workers = int(n)
+        n_groups = self._n_groups_arg
         if n_groups is None:
             # measured at B=256 on the bench host with the two-thread native step loop (~25 env
             # workers): 2 groups 516 K SPS, 3 groups 533-541 K, 4 groups 561 K, 5 groups 555 K,
@@ -404,18 +428,20 @@ class GpuSampler(BaseSampler):
             if n_groups == 2 and B >= 192:
                 n_groups = 4
         self.n_groups = max(1, min(int(n_groups), B))
-        self._pinned_ptrs = []
-        self.workers = []
-        self.timing = dict(wait_env_s=0., device_issue_s=0., device_wait_s=0., batches=0,
-                           pre_s=0., loop_s=0., tail_s=0., post_s=0.)
 
     # ------------------------------------------------------------------------ initialize
     def initialize(self, agent, affinity=None, seed=None, bootstrap_value=False,
-                   traj_info_kwargs=None, rank=0, world_size=1):
+                   traj_info_kwargs=None, world_size=1, rank=0, worker_process=None):
+        """Signature of the reference's samplers (rlpyt/samplers/parallel/base.py:27-37;
+        ``worker_process`` selects an alternative worker main there -- only the default exists
+        here)."""
+        if worker_process is not None:
+            raise NotImplementedError("GpuSampler runs its own env-worker loop (worker_process)")
         T, B = self.batch_spec
         self.agent, self.rank, self.world_size = agent, rank, world_size
         self.seed = seed if seed is not None else 0
         affinity = affinity or dict()
+        self._resolve_layout(affinity)
         if traj_info_kwargs:
             for k, v in traj_info_kwargs.items():
                 setattr(self.TrajInfoCls, "_" + k, v)
@@ -572,7 +598,9 @@ class GpuSampler(BaseSampler):
         self.ctrl.ti_keys = keys
         self.ctrl.ti_table = np_mp_array((n, max(cap, 1), max(len(keys), 1)), np.float64)
         self.ctrl.ti_count = np_mp_array(n, np.int32)
-        cpus = affinity.get("workers_cpus", None)
+        # CPU pinning as the reference (parallel/base.py:236-237): worker w on workers_cpus[w],
+        # unless affinity["set_affinity"] is False
+        cpus = affinity.get("workers_cpus", None) if affinity.get("set_affinity", True) else None
         self.workers = []
         for w in range(n):
             wc = None if cpus is None else cpus[w % len(cpus)]

@@ -1020,6 +1020,76 @@ def gen_runner_keys():
     print("runner_keys.json:", {k: len(v[-1]) for k, v in keys.items()})
 
 
+# reference class / function -> the attribute names of the duck-typed protocol the runner and
+# the sibling components touch; ``protocol_cases.py`` holds the map to
+# this repo's classes.
+def gen_protocol():
+    """``inspect.signature`` of every protocol method the reference's runners / algos / samplers
+    call on each other, recorded from the REFERENCE classes: the drop-in boundary as
+    data.  tests/test_protocol.py holds this repo's classes to it (same parameter names, order of
+    the positional ones, defaults; extra parameters only with defaults)."""
+    import importlib
+    import inspect
+    import json
+    _install_pyprind_shim()
+    from protocol_cases import PROTOCOL
+
+    def describe(fn):
+        sig = inspect.signature(fn)
+        out = []
+        for name, prm in sig.parameters.items():
+            d = prm.default
+            has = d is not inspect.Parameter.empty
+            simple = isinstance(d, (int, float, bool, str, type(None)))
+            out.append(dict(name=name, kind=prm.kind.name, has_default=has,
+                            default=(d if (has and simple) else (repr(type(d).__name__) if has else None))))
+        return out
+
+    rec = {}
+    for ref_path, (_ours, members) in PROTOCOL.items():
+        mod, _, attr = ref_path.rpartition(".")
+        obj = getattr(importlib.import_module(mod), attr)
+        entry = {}
+        if inspect.isclass(obj):
+            for m in members:
+                if not hasattr(obj, m):
+                    raise AttributeError(f"{ref_path} has no {m}")
+                member = inspect.getattr_static(obj, m)
+                if isinstance(member, property):
+                    entry[m] = "property"
+                elif callable(getattr(obj, m)):
+                    entry[m] = describe(getattr(obj, m))
+                else:
+                    v = getattr(obj, m)
+                    entry[m] = dict(attr=(list(v) if isinstance(v, (tuple, list)) else v))
+        else:
+            entry["__call__"] = describe(obj)
+        rec[ref_path] = entry
+    with open(os.path.join(HERE, "protocol.json"), "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    print("protocol.json:", len(rec), "reference classes / functions,",
+          sum(len(v) for v in rec.values()), "members")
+
+
+def _install_pyprind_shim():
+    import types
+    if "pyprind" in sys.modules:
+        return
+    pp = types.ModuleType("pyprind")     # the reference's progress bar dependency is absent here
+
+    class ProgBar:
+        def __init__(self, n, **k):
+            self.active = True
+
+        def update(self, *a, **k):
+            pass
+
+        def stop(self):
+            self.active = False
+    pp.ProgBar = ProgBar
+    sys.modules["pyprind"] = pp
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
@@ -1028,6 +1098,6 @@ if __name__ == "__main__":
                 seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
                 models=gen_models, sampler=gen_sampler, algos=gen_algos, dqn_iterations=gen_dqn_iterations,
                 r2d1_iterations=gen_r2d1_iterations, agents=gen_agents,
-                runner_keys=gen_runner_keys)
+                runner_keys=gen_runner_keys, protocol=gen_protocol)
     for name in (sys.argv[1:] or list(gens)):      # python make_golden.py [subset ...]
         gens[name]()

@@ -1,0 +1,208 @@
+"""N > 1 on the PRODUCT path: two ranks, each its own process, both on
+cuda:0 (a 1-GPU test box), process group over gloo, running the real ``PPO`` + ``AtariFfAgent``:
+MFMA conv stack in index mode, hipBLASLt trunk, fused head + loss kernel whose head-parameter
+gradients reach autograd only through a custom Function -- the piece that could silently bypass
+DistributedDataParallel's gradient hooks (rlpyt/agents/base.py:118-136, runners/sync_rl.py:60-101).
+
+Checks
+* parameters are bit-identical across the ranks after every iteration (ranks hold different data);
+* they equal, within fp32 tolerance, a ONE-process run that applies the mean of the two ranks'
+  minibatch gradients (same shuffle, same clip, SGD so that the comparison is linear in the
+  gradient);
+* the fused kernels really ran in the rank processes (launch counters);
+* ``SyncRl`` end to end (sampler + runner) over the same two-rank layout.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+T, B, A = 8, 4, 6
+INIT_SEED, SHUFFLE_SEED = 11, 5
+PPO_KW = dict(discount=0.99, learning_rate=0.05, value_loss_coeff=1., entropy_loss_coeff=0.01,
+              OptimCls=torch.optim.SGD, clip_grad_norm=1., gae_lambda=0.95, minibatches=2,
+              epochs=2, ratio_clip=0.1, linear_lr_schedule=False, normalize_advantage=False)
+N_ITR = 2
+
+
+def _spaces():
+    from rlpyt_amd.envs.base import EnvSpaces
+    from rlpyt_amd.spaces import IntBox
+    return EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
+                     action=IntBox(0, A))
+
+
+def _agent():
+    from rlpyt_amd.agents.pg.atari import AtariFfAgent
+    torch.manual_seed(INIT_SEED)
+    agent = AtariFfAgent()
+    agent.initialize(_spaces())
+    agent.to_device(0)
+    return agent
+
+
+def _samples(agent, rank):
+    """A fixed [T, B] sample batch per rank; the behaviour policy is the agent's initial one."""
+    from rlpyt_amd.agents.pg.categorical import AgentInfo
+    from rlpyt_amd.distributions.categorical import DistInfo
+    from rlpyt_amd.samplers.collections import AgentSamplesBsv, EnvSamples, Samples
+    g = torch.Generator().manual_seed(100 * rank + 1)
+    obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    all_action = torch.randint(0, A, (T + 1, B), generator=g).cuda()
+    all_reward = torch.randint(-1, 2, (T + 1, B), generator=g).float().cuda()
+    done = (torch.rand(T, B, generator=g) < 0.1).cuda()
+    with torch.no_grad():
+        pi, v = agent(obs, None, None)
+        bv = agent.value(obs[-1], None, None).reshape(1, B)
+    return Samples(
+        agent=AgentSamplesBsv(action=all_action[1:], prev_action=all_action[:-1],
+                              agent_info=AgentInfo(dist_info=DistInfo(prob=pi.prob.clone()),
+                                                   value=v.clone()),
+                              bootstrap_value=bv.clone()),
+        env=EnvSamples(observation=obs, reward=all_reward[1:], prev_reward=all_reward[:-1],
+                       done=done, env_info=()))
+
+
+def _flat(agent):
+    return torch.cat([p.detach().reshape(-1) for p in agent.parameters()]).cpu()
+
+
+def _rank_main(rank, world_size, port, outdir):
+    import torch.distributed as dist
+    from rlpyt_amd import _lib
+    from rlpyt_amd.algos.pg.ppo import PPO
+    from rlpyt_amd.samplers.collections import BatchSpec
+    from rlpyt_amd.utils import logger
+    logger.set_quiet(True)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size,
+                            init_method=f"tcp://127.0.0.1:{port}")
+    agent = _agent()
+    samples = _samples(agent, rank)          # BEFORE the DDP wrap: same forward on every rank
+    agent.data_parallel()
+    algo = PPO(**PPO_KW)
+    algo.initialize(agent=agent, n_itr=N_ITR, batch_spec=BatchSpec(T, B), mid_batch_reset=True,
+                    examples=None, world_size=world_size, rank=rank)
+    assert agent.supports_fused_head_loss
+    np.random.seed(SHUFFLE_SEED)
+    _lib.variant_reset()
+    out = dict(params=[], info=[])
+    for itr in range(N_ITR):
+        agent.train_mode(itr)
+        info = algo.optimize_agent(itr, samples)
+        out["params"].append(_flat(agent))
+        out["info"].append({k: list(getattr(info, k)) for k in info._fields})
+    torch.cuda.synchronize()
+    out["variants"] = _lib.variant_counts()
+    out["ddp"] = type(agent.model).__name__
+    torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _one_process_mean_gradient_run():
+    """The same updates in one process: per minibatch, the two ranks' losses are averaged before
+    backward (== DDP's gradient mean), then the same clip + SGD step."""
+    from rlpyt_amd.agents.base import AgentInputs
+    from rlpyt_amd.algos.pg.ppo import PPO
+    from rlpyt_amd.samplers.collections import BatchSpec
+    from rlpyt_amd.utils.misc import iterate_mb_idxs
+    agent = _agent()
+    samples = [_samples(agent, r) for r in range(2)]
+    algo = PPO(**PPO_KW)
+    algo.initialize(agent=agent, n_itr=N_ITR, batch_spec=BatchSpec(T, B), mid_batch_reset=True,
+                    examples=None, world_size=1, rank=0)
+    np.random.seed(SHUFFLE_SEED)
+    params, losses = [], []
+    mb = T * B // PPO_KW["minibatches"]
+    for itr in range(N_ITR):
+        agent.train_mode(itr)
+        prepared = []
+        for s in samples:
+            ret, adv, valid = algo.process_returns(s)
+            assert valid is None
+            prepared.append((s.env.observation, s.agent.action.contiguous(), ret, adv,
+                             s.agent.agent_info.dist_info.prob.contiguous()))
+        for _ in range(PPO_KW["epochs"]):
+            for idx in iterate_mb_idxs(T * B, mb, shuffle=True):
+                idx_dev = torch.from_numpy(np.ascontiguousarray(idx)).cuda()
+                algo.optimizer.zero_grad(set_to_none=True)
+                per_rank = []
+                for obs, action, ret, adv, old_prob in prepared:
+                    mb_obs = agent.gather_observation(obs, idx_dev)
+                    loss, sc = algo.loss(AgentInputs(mb_obs, None, None), action, ret, adv, None,
+                                         old_prob, flat_idx=idx_dev)
+                    (loss / 2).backward()
+                    per_rank.append(sc[0].item())
+                torch.nn.utils.clip_grad_norm_(agent.parameters(), algo.clip_grad_norm)
+                algo.optimizer.step()
+                losses.append(per_rank)
+        params.append(_flat(agent))
+    return params, np.array(losses)
+
+
+def test_two_ranks_product_ppo_matches_mean_gradient_run(tmp_path):
+    import torch.multiprocessing as tmp
+    tmp.spawn(_rank_main, args=(2, 29541, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    for res in (r0, r1):       # the product path ran in the rank processes, under DDP
+        assert res["ddp"] == "DistributedDataParallel"
+        for k in ("ppo_head_loss_kernel<8>", "conv2_bwd_kernel", "conv1_wgrad_kernel",
+                  "conv1_fwd_kernel", "scan_exact_kernel<0, 1, 32, false>"):
+            assert res["variants"].get(k, 0) > 0, (k, sorted(res["variants"]))
+    # ranks saw different data ...
+    assert r0["info"][0]["loss"] != r1["info"][0]["loss"]
+    # ... and hold bit-identical parameters after every iteration
+    for p0, p1 in zip(r0["params"], r1["params"]):
+        assert torch.equal(p0, p1)
+    ref_params, ref_losses = _one_process_mean_gradient_run()
+    n_upd = PPO_KW["minibatches"] * PPO_KW["epochs"]
+    got_losses = np.array([[a, b] for a, b in zip(sum((i["loss"] for i in r0["info"]), []),
+                                                  sum((i["loss"] for i in r1["info"]), []))])
+    assert got_losses.shape == (N_ITR * n_upd, 2)
+    # fp32 tolerance: reductions (loss sums, weight-gradient partials, the all-reduce itself) have
+    # no defined order; SGD keeps the comparison linear in the gradient
+    np.testing.assert_allclose(got_losses, ref_losses, rtol=2e-4, atol=2e-5)
+    for got, ref in zip(r0["params"], ref_params):
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-6)
+    moved = (r0["params"][-1] - _flat(_agent())).abs().max().item()
+    assert moved > 1e-4        # the updates were not no-ops
+
+
+def _sync_rl_rank(rank, world_size, outdir):
+    """build_fn of ``launch_sync``: the whole runner on each rank."""
+    from rlpyt_amd.agents.pg.atari import AtariFfAgent
+    from rlpyt_amd.algos.pg.ppo import PPO
+    from rlpyt_amd.envs.synthetic import SyntheticPong
+    from rlpyt_amd.runners.minibatch_rl import SyncRl
+    from rlpyt_amd.samplers.gpu import GpuSampler
+    from rlpyt_amd.utils import logger
+    logger.set_quiet(True)
+    sampler = GpuSampler(SyntheticPong, dict(), batch_T=8, batch_B=8, max_decorrelation_steps=0)
+    algo = PPO(minibatches=2, epochs=2, gae_lambda=0.95)
+    agent = AtariFfAgent()
+    runner = SyncRl(algo=algo, agent=agent, sampler=sampler, n_steps=8 * 8 * 2 * 3, seed=3,
+                    affinity=dict(cuda_idx=0, workers_cpus=[0, 1]),
+                    log_interval_steps=8 * 8 * 2 * 3)
+    runner.train()
+    torch.save(dict(params=_flat(agent), world=runner.world_size, seed=runner.seed,
+                    workers=sampler.n_workers, updates=algo.update_counter,
+                    obs_sum=int(sampler.samples.env.observation.sum(dtype=torch.int64).item())),
+               os.path.join(outdir, f"sync{rank}.pt"))
+
+
+def test_sync_rl_two_ranks_same_gpu(tmp_path):
+    """``SyncRl`` over two spawned ranks (gloo, both on cuda:0): the reference's launch_workers /
+    data_parallel flow with the HBM sampler, worker count taken from affinity["workers_cpus"]."""
+    from rlpyt_amd.runners.minibatch_rl import launch_sync
+    launch_sync(2, _sync_rl_rank, args=(str(tmp_path),), backend="gloo", port=29543)
+    a, b = torch.load(tmp_path / "sync0.pt"), torch.load(tmp_path / "sync1.pt")
+    assert a["world"] == b["world"] == 2 and b["seed"] == a["seed"] + 100
+    assert a["workers"] == b["workers"] == 2
+    assert a["updates"] == b["updates"] == 3 * 4
+    assert a["obs_sum"] != b["obs_sum"]               # different environments per rank
+    assert torch.equal(a["params"], b["params"])      # same model everywhere
