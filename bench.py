@@ -3,18 +3,27 @@
 
 A "step" = one full PPO iteration of the hot path on one synthetic batch:
   rollout of T x B env steps (host envs, batched action selection on the device, sample
-  batch resident in HBM) -> fused GAE scan -> epochs x minibatches of {device gather,
-  AtariFfModel forward, fused PPO loss fwd+bwd kernel, backward, grad-clip, Adam}
+  batch resident in HBM) -> fused GAE scan -> epochs x minibatches of {index-mode MFMA conv
+  stack, hipBLASLt trunk, fused heads + PPO loss kernel, backward, clip + Adam in two launches}
   (under N>1: DistributedDataParallel all-reduces the 7.14 MB of gradients per minibatch).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      -- the dominant own kernel of the timed region (the HBM->HBM minibatch
-                   observation gather), HIP-event timed live inside the timed steps;
-  kernels       -- the same live measurement for the other path kernels (GAE scan, PPO loss);
+  roofline      -- the dominant own kernel of the timed region by total HIP-event time (one of the
+                   fp32-MFMA conv kernels), timed live inside the timed steps;
+  kernels       -- the same live measurement for every own kernel of the update;
   roofline_gae_scaled -- the GAE scan at T=128, N=2^20 columns (the shape at which the
                    HBM criterion of BASELINE.md section 3 is meaningful), timed in this run;
-  cpu_baseline  -- the oracle's CPU port of the reference iteration (oracle/ppo_cpu_port.py)
-                   timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+  value_env200us -- the same metric with a declared ALE-like host cost of 200 us per env step
+                   (busy wait in the env workers; `value` itself is measured at 0 us: the
+                   framework's own ceiling);
+  cpu_baseline  -- the oracle's CPU port of the reference iteration (oracle/ppo_cpu_port.py,
+                   pinned to the reference's PPO.optimize_agent) timed on this box's host cores at
+                   the full [128, 256] batch (rank 0, N=1 only);
+  multi_gpu     -- (N>1) world size as torch.distributed sees it, per-rank usable CPUs, the
+                   all-reduce time of one gradient set measured live, per-GPU SPS.
+`--config dqn` / `--config r2d1` run BASELINE configs #3 / #5 end to end instead (full-size HBM
+replay, prioritized tree, frame / sequence gathers) and report SPS, updates/s and the replay
+kernels' rooflines taken from those buffers.
 Data: synthetic Atari-shaped env (no ALE in the image), random-init weights.
 """
 import argparse
@@ -55,11 +64,22 @@ def parse():
                     "(-1: host cores / ranks, capped at B/10)")
     ap.add_argument("--env-cost-us", type=float, default=0., help="declared extra host cost "
                     "per env step (busy wait) to emulate an ALE-like emulator")
+    ap.add_argument("--config", default="ppo", choices=["ppo", "dqn", "r2d1"],
+                    help="ppo = BASELINE config #2/#4 (the metric); dqn = #3; r2d1 = #5")
+    ap.add_argument("--env-cost-leg-us", type=float, default=200.,
+                    help="second, shorter leg with this declared env cost (0: skip)")
+    ap.add_argument("--env-cost-leg-steps", type=int, default=2)
+    ap.add_argument("--pin-workers", action="store_true",
+                    help="pin env worker w of rank r to CPU affinity['workers_cpus'][w] "
+                         "(the reference's set_affinity)")
+    ap.add_argument("--replay-fill-itrs", type=int, default=-1,
+                    help="dqn / r2d1: sampling-only iterations before the timed ones (-1: auto)")
     ap.add_argument("--groups", type=int, default=-1, help="sampler pipeline groups (-1: auto)")
     ap.add_argument("--no-graph", action="store_true", help="no hipGraph for the sampling step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-B", type=int, default=0,
-                    help="B of the bounded CPU sample (0: sized for ~15 s of CPU work)")
+    ap.add_argument("--cpu-baseline-B", type=int, default=256,
+                    help="B of the CPU sample (default: the full batch, one iteration ~20 s; "
+                         "0: sized for ~15 s of CPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--split-workers", action="store_true",
                     help="each env worker serves one pipeline group only (A/B lead, see DESIGN.md)")
@@ -76,6 +96,8 @@ def parse():
 
 def main():
     args = parse()
+    if args.config != "ppo":
+        return replay_config_main(args)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -102,14 +124,26 @@ def main():
         # Workers sleep on a futex most of a step (25 of them keep ~10 CPUs busy), so the pool
         # may exceed this rank's CPU share by ~1.6x but not more, or the quota throttles it.
         workers = max(min(int(round(1.6 * cpus / world)) - 1, B // 10), 1)
-    env_kwargs = dict(step_cost_us=args.env_cost_us)
-    n_itr_total = args.warmup + args.steps
+    import multiprocessing as mp
+    # declared host cost per env step, in fork-shared memory so that the second leg can change it
+    # under the already forked env workers
+    cost_ref = mp.get_context("fork").RawValue("d", float(args.env_cost_us))
+    env_kwargs = dict(step_cost_ref=cost_ref)
+    leg_steps = args.env_cost_leg_steps if (args.env_cost_leg_us > 0 and args.env_cost_us == 0) else 0
+    n_itr_total = args.warmup + args.steps + (1 + leg_steps if leg_steps else 0)
+    # worker processes and their CPUs the reference's way: one worker per entry of
+    # affinity["workers_cpus"] (rlpyt/samplers/parallel/base.py:157-172); rank r takes the r-th
+    # block of the hardware threads
+    per_rank = max(ncpu // max(world, 1), 1)
+    workers_cpus = [rank * per_rank + (w % per_rank) for w in range(workers)]
+    affinity = dict(cuda_idx=local_rank, workers_cpus=workers_cpus,
+                    set_affinity=bool(args.pin_workers))
 
     # --- build the stack in the reference's order: sampler (forks workers) BEFORE any HIP
     #     call, then device placement, then DDP, then the algorithm ------------------------
     seed = 0 + 100 * rank
     set_seed(seed)
-    sampler = GpuSampler(SyntheticPong, env_kwargs, batch_T=T, batch_B=B, n_workers=workers,
+    sampler = GpuSampler(SyntheticPong, env_kwargs, batch_T=T, batch_B=B,
                          TrajInfoCls=AtariTrajInfo, max_decorrelation_steps=100,
                          n_groups=None if args.groups < 0 else args.groups,
                          use_graph=not args.no_graph, fused_push=not args.no_fused_push,
@@ -118,8 +152,9 @@ def main():
     algo = PPO(discount=0.99, learning_rate=1e-3, value_loss_coeff=1., entropy_loss_coeff=0.01,
                clip_grad_norm=1., gae_lambda=0.98, minibatches=4, epochs=4, ratio_clip=0.1,
                linear_lr_schedule=True, normalize_advantage=False)
-    examples = sampler.initialize(agent, seed=seed + 1, bootstrap_value=True, rank=rank,
-                                  world_size=world)
+    examples = sampler.initialize(agent, affinity=affinity, seed=seed + 1, bootstrap_value=True,
+                                  rank=rank, world_size=world)
+    assert sampler.n_workers == min(workers, B)
     if args.same_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -169,6 +204,52 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
     ksum = ktimer.summary() if not args.no_kernel_timing else {}
+    # ---- second leg: the same iteration with a declared ALE-like emulator cost per env step ----
+    leg = None
+    if leg_steps:
+        cost_ref.value = float(args.env_cost_leg_us)
+        one_step(args.warmup + args.steps)               # untimed: workers pick up the new cost
+        sync()
+        tl = time.perf_counter()
+        ts_leg = 0.
+        for k in range(leg_steps):
+            itr = args.warmup + args.steps + 1 + k
+            t1 = time.perf_counter()
+            agent.sample_mode(itr)
+            samples, _infos = sampler.obtain_samples(itr)
+            ts_leg += time.perf_counter() - t1
+            agent.train_mode(itr)
+            algo.optimize_agent(itr, samples)
+        sync()
+        el2 = torch.tensor([time.perf_counter() - tl], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(el2, op=dist.ReduceOp.MAX)
+        leg = dict(elapsed=el2.item(), steps=leg_steps, sampling=ts_leg)
+        cost_ref.value = float(args.env_cost_us)
+    # ---- N > 1: what the process group looks like, and one gradient all-reduce timed live --------
+    multi = None
+    if world > 1:
+        nparam = sum(p.numel() for p in agent.parameters())
+        buf = torch.zeros(nparam, dtype=torch.float32, device="cuda")
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ta = time.perf_counter()
+        n_ar = 32
+        for _ in range(n_ar):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ar_us = (time.perf_counter() - ta) / n_ar * 1e6
+        cpu_list = [None] * world
+        dist.all_gather_object(cpu_list, dict(rank=rank, usable_cpus=cpus, device=torch.cuda.current_device(),
+                                              env_workers=sampler.n_workers))
+        multi = dict(dist_world_size=dist.get_world_size(), backend=dist.get_backend(),
+                     ranks=cpu_list, grad_bytes=nparam * 4,
+                     allreduce_us_per_minibatch=ar_us,
+                     allreduce_ms_per_iteration=ar_us * algo.epochs * algo.minibatches / 1e3,
+                     note="stand-alone all-reduce of one gradient-sized buffer after the timed "
+                          "region (inside the iteration DDP overlaps it with backward)")
     sampler.shutdown()
     if args.check_params and world > 1:
         flat = torch.cat([p.detach().reshape(-1) for p in agent.parameters()])
@@ -207,6 +288,21 @@ def main():
                                          for k in ("pre_s", "loop_s", "tail_s", "post_s")}},
             "last_loss": opt_info.loss[-1] if opt_info.loss else None,
         }
+        out["config"]["env_worker_cpus"] = ("pinned (affinity['workers_cpus'])" if args.pin_workers
+                                            else "not pinned (set_affinity=False)")
+        if leg is not None:
+            key = f"value_env{int(args.env_cost_leg_us)}us"
+            out[key] = T * B * world * leg["steps"] / leg["elapsed"]
+            out[key + "_detail"] = {
+                "env_step_cost_us": args.env_cost_leg_us, "steps": leg["steps"],
+                "ms_per_step": leg["elapsed"] / leg["steps"] * 1e3,
+                "sampling_frac_of_step": leg["sampling"] / leg["elapsed"],
+                "note": "declared ALE-like emulator cost: busy wait in the env workers; the "
+                        f"{T * B} env steps of a batch then cost {T * B * args.env_cost_leg_us / 1e6:.2f} "
+                        f"CPU-seconds against the {cpus:.0f} CPUs this process may use"}
+        if multi is not None:
+            multi["per_gpu_value"] = out["value"] / world
+            out["multi_gpu"] = multi
         if ksum:
             # dominant own kernel of the timed region = largest total HIP-event time
             name, g = max(ksum.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])
@@ -235,7 +331,7 @@ def main():
                                   for kk, vv in v.items()} for k, v in ksum.items()}
         out["roofline_gae_scaled"] = gae_scaled_roofline()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(T, args.cpu_baseline_B, env_kwargs)
+            out["cpu_baseline"] = cpu_baseline(T, args.cpu_baseline_B, dict(step_cost_us=args.env_cost_us))
             # the isolated hot-path functions, HIP kernel beside the CPU restatement
             # on the same synthetic inputs (also yields the replay-kernel HBM rooflines)
             fn = isolated_functions(T, B)
@@ -419,7 +515,8 @@ def isolated_functions(T, B):
 
 
 def cpu_baseline(T, B_cpu, env_kwargs):
-    """Oracle CPU port of the reference iteration on this box's host cores (bounded sample)."""
+    """Oracle CPU port of the reference iteration on this box's host cores: by default ONE whole
+    iteration at the bench batch [T, 256] (SerialSampler-style rollout + GAE loop + 16 updates)."""
     from oracle.ppo_cpu_port import time_cpu_baseline
     from rlpyt_amd.envs.synthetic import SyntheticPong
     from rlpyt_amd.utils.misc import usable_cpus
@@ -427,12 +524,185 @@ def cpu_baseline(T, B_cpu, env_kwargs):
                             iters=1, threads=None, max_threads=usable_cpus())
     B_cpu = res["B"]
     return {"value": res["value"], "unit": "env-steps/s", "cores": res["cores"], "kind": "port",
+            "kind_note": "CPU port of the reference iteration (rlpyt SerialSampler + PPO + AtariFfAgent "
+                         "semantics); /root/reference is not on the bench box.  The port's update is "
+                         "pinned to the reference's own PPO.optimize_agent run at 1e-5 "
+                         "(tests/test_oracle_golden.py) and was timed beside the real reference in "
+                         "the build container: port 1516 SPS vs reference 1416 SPS (+7 %, "
+                         "scripts/ref_vs_port.py)",
             "sample": f"1 PPO iteration at [T={T}, B={B_cpu}] ({T * B_cpu} env steps, 16 "
                       f"minibatch updates), torch CPU with {res['cores']} threads (best of a thread-count "
                       f"calibration within the {usable_cpus():.0f} CPUs this process may use, "
                       f"{os.cpu_count()} hardware threads on the box), "
                       f"{res['seconds']:.1f} s",
             "seconds": res["seconds"]}
+
+
+# ============================================================================================
+# BASELINE configs #3 (DQN, prioritized 1 M-frame replay) and #5 (R2D2 / R2D1 sequence replay)
+# ============================================================================================
+def replay_config_main(args):
+    """End-to-end iterations of the replay-based configs on one GPU: sampler -> append into the
+    HBM ring -> {tree sample, frame / sequence gather, model, fused loss, priority update} x
+    updates.  Hyper-parameters of rlpyt/experiments/configs/atari/dqn/atari_dqn.py
+    ("prioritized": sampler [2, 16], batch 128, replay 1e6, replay_ratio 8) and atari_r2d1.py
+    ("r2d1_long": sampler [40, 192], batch_T 80 + warmup 40, batch_B 64, n_step 5, replay 4e6)."""
+    import numpy as np
+
+    from rlpyt_amd import ops
+    from rlpyt_amd.envs.synthetic import SyntheticPong
+    from rlpyt_amd.samplers.collections import AtariTrajInfo
+    from rlpyt_amd.samplers.gpu import GpuSampler
+    from rlpyt_amd.utils import ktimer, logger
+    from rlpyt_amd.utils.misc import usable_cpus
+    from rlpyt_amd.utils.seed import set_seed
+    logger.set_quiet(True)
+    assert args.gpus == 1 and int(os.environ.get("WORLD_SIZE", 1)) == 1, \
+        "--config dqn / r2d1 are single-GPU configs (BASELINE #3 / #5)"
+    cpus = usable_cpus()
+    set_seed(0)
+    if args.config == "dqn":
+        from rlpyt_amd.agents.dqn.dqn_agent import AtariDqnAgent
+        from rlpyt_amd.algos.dqn.dqn import DQN
+        T, B = 2, 16
+        agent = AtariDqnAgent()
+        algo = DQN(discount=0.99, batch_size=128, learning_rate=1e-4, clip_grad_norm=10.,
+                   min_steps_learn=0, double_dqn=False, prioritized_replay=True, n_step_return=1,
+                   replay_size=int(1e6))
+        workers, fill = 2, (2000 if args.replay_fill_itrs < 0 else args.replay_fill_itrs)
+        steps = args.steps if args.steps != 5 else 300
+        warmup = args.warmup if args.warmup != 2 else 20
+        name = "DQN AtariDqnAgent, PrioritizedReplayFrameBuffer 1e6 frames, sampler [2,16], batch 128"
+    else:
+        from rlpyt_amd.agents.dqn.r2d1_agent import AtariR2d1Agent
+        from rlpyt_amd.algos.dqn.r2d1 import R2D1
+        T, B = 40, 192
+        agent = AtariR2d1Agent(eps_final=0.1, eps_final_min=0.0005)
+        algo = R2D1(discount=0.997, batch_T=80, batch_B=64, warmup_T=40, store_rnn_state_interval=40,
+                    replay_ratio=1, learning_rate=1e-4, clip_grad_norm=80., min_steps_learn=0,
+                    double_dqn=True, prioritized_replay=True, n_step_return=5, pri_alpha=0.9,
+                    pri_beta_init=0.6, pri_beta_final=0.6, input_priority_shift=2,
+                    replay_size=int(4e6))
+        workers = max(min(int(round(1.6 * cpus)) - 1, B // 10), 1)
+        fill = 12 if args.replay_fill_itrs < 0 else args.replay_fill_itrs
+        steps = args.steps if args.steps != 5 else 20
+        warmup = args.warmup if args.warmup != 2 else 3
+        name = ("R2D1 AtariR2d1Agent (conv + LSTM 512), PrioritizedSequenceReplayFrameBuffer 4e6 "
+                "frames, sampler [40,192], sequences [40+80+5, 64]")
+    sampler = GpuSampler(SyntheticPong, dict(step_cost_us=args.env_cost_us), batch_T=T, batch_B=B,
+                         n_workers=workers, TrajInfoCls=AtariTrajInfo, max_decorrelation_steps=100,
+                         mid_batch_reset=(args.config == "dqn"),
+                         n_groups=None if args.groups < 0 else args.groups,
+                         use_graph=not args.no_graph)
+    examples = sampler.initialize(agent, seed=1, bootstrap_value=False)
+    torch.cuda.set_device(0)
+    agent.to_device(0)
+    n_itr = fill + warmup + steps
+    algo.initialize(agent=agent, n_itr=n_itr, batch_spec=sampler.batch_spec,
+                    mid_batch_reset=sampler.mid_batch_reset, examples=examples)
+    rb = algo.replay_buffer
+    learn_from = fill
+    algo.min_itr_learn = learn_from            # sampling-only iterations fill the ring first
+
+    def one(itr):
+        agent.sample_mode(itr)
+        samples, _ = sampler.obtain_samples(itr)
+        agent.train_mode(itr)
+        return algo.optimize_agent(itr, samples)
+
+    for itr in range(fill + warmup):
+        one(itr)
+    torch.cuda.synchronize()
+    u0 = algo.update_counter
+    t0 = time.perf_counter()
+    t_sample = 0.
+    for k in range(steps):
+        itr = fill + warmup + k
+        ts = time.perf_counter()
+        agent.sample_mode(itr)
+        samples, _ = sampler.obtain_samples(itr)
+        t_sample += time.perf_counter() - ts
+        agent.train_mode(itr)
+        info = algo.optimize_agent(itr, samples)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    updates = algo.update_counter - u0
+    sampler.shutdown()
+
+    # ---- replay kernels on the REAL buffers (HIP events), at the config's batch shape ------------
+    replay = {}
+    frames = rb.samples_frames
+    C = 4
+    Tr = frames.shape[0] - (C - 1)
+    Br = frames.shape[1]
+    hw = frames.shape[2] * frames.shape[3]
+    tree = rb.priority_tree
+    filled_T = min(int(rb.t) if not getattr(rb, "_buffer_full", False) else Tr, Tr)
+    g = torch.Generator().manual_seed(0)
+    if args.config == "dqn":
+        n = 128
+        u = torch.rand(n, generator=g, dtype=torch.float64).cuda()
+        us = _hip_us(lambda: tree.sample(u))
+        replay["sumtree_sample"] = {"bound": "latency", "avg_us": round(us, 2),
+                                    "ns_per_sample": round(us * 1e3 / n, 1),
+                                    "levels": int(tree.tree_levels), "leaves": Tr * Br}
+        ti = torch.randint(4, max(filled_T - 4, 8), (n,), generator=g).cuda()
+        bi = torch.randint(0, Br, (n,), generator=g).cuda()
+        out_d = torch.empty((n, C) + tuple(frames.shape[2:]), dtype=torch.uint8, device="cuda")
+        us = _hip_us(lambda: ops.frames_gather(frames, rb.samples.done, ti, bi, C, out=out_d))
+        nb = n * C * hw * 2
+        replay["frames_gather"] = {"bound": "hbm", "avg_us": round(us, 2), "alg_bytes_per_launch": nb,
+                                   "achieved": nb / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": nb / us / 1e3 / HBM_PEAK_GBPS,
+                                   "note": "8.5 MB per launch: latency-class at this batch size"}
+        us = _hip_us(lambda: rb.sample_batch(n), iters=20)
+        replay["sample_batch_total_us"] = round(us, 1)
+    else:
+        n, seq_T = 64, 125
+        rsi = 40
+        hi = max((filled_T - seq_T - 8) // rsi, 1)
+        ti = (torch.randint(0, hi, (n,), generator=g) * rsi).cuda()
+        bi = torch.randint(0, Br, (n,), generator=g).cuda()
+        out_s = torch.empty((seq_T, n, C) + tuple(frames.shape[2:]), dtype=torch.uint8, device="cuda")
+        us = _hip_us(lambda: ops.frames_gather_seq(frames, rb.samples.done, ti, bi, C, seq_T, out=out_s),
+                     iters=20)
+        nb = n * (seq_T + C - 1) * hw + seq_T * n * C * hw      # SURVEY 8(d): 334 MB
+        replay["frames_gather_seq"] = {"bound": "hbm", "avg_us": round(us, 2),
+                                       "alg_bytes_per_launch": nb, "achieved": nb / us / 1e3,
+                                       "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": nb / us / 1e3 / HBM_PEAK_GBPS,
+                                       "kernel": "frames_gather_wide_kernel [125, 64, 4, 104, 80]"}
+        u = torch.rand(n, generator=g, dtype=torch.float64).cuda()
+        us = _hip_us(lambda: tree.sample(u))
+        replay["sumtree_sample"] = {"bound": "latency", "avg_us": round(us, 2),
+                                    "ns_per_sample": round(us * 1e3 / n, 1),
+                                    "levels": int(tree.tree_levels)}
+        us = _hip_us(lambda: rb.sample_batch(n), iters=10)
+        replay["sample_batch_total_us"] = round(us, 1)
+    key = "frames_gather" if args.config == "dqn" else "frames_gather_seq"
+    out = {
+        "metric": f"env-steps/sec (SPS), {args.config.upper()} Atari end to end, 1 GPU "
+                  "(BASELINE config #%d)" % (3 if args.config == "dqn" else 5),
+        "value": T * B * steps / elapsed, "unit": "env-steps/s", "n_gpus": 1, "steps": steps,
+        "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (Atari-shaped SyntheticPong env on host cores, random-init model)",
+        "config": {"workload": name, "T": T, "B": B, "env_workers": workers,
+                   "env_step_cost_us": args.env_cost_us, "host_cpu_quota": cpus,
+                   "replay_frames": int(Tr * Br), "replay_ring_T": int(Tr), "replay_B": int(Br),
+                   "frame_store_GB": round(frames.numel() / 1e9, 2),
+                   "tree_leaves": int(tree.T * tree.B), "tree_levels": int(tree.tree_levels),
+                   "ring_rows_filled": int(filled_T), "fill_iterations": fill,
+                   "updates_per_iteration": algo.updates_per_optimize,
+                   "batch_size": int(algo.batch_size)},
+        "updates_per_s": updates / elapsed, "updates": updates,
+        "sampling_frac_of_step": t_sample / elapsed,
+        "roofline": dict(kernel=replay[key].get("kernel", key), **{k: v for k, v in replay[key].items()
+                                                                   if k != "kernel"}, traffic=None),
+        "roofline_replay": replay,
+        "last_loss": (info.loss[-1] if info.loss else None),
+    }
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

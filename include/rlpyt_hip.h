@@ -489,6 +489,34 @@ int rlpyt_sumtree_sample(rlpyt_sumtree* t, const double* uniforms, int n, int64_
 int rlpyt_sumtree_update(rlpyt_sumtree* t, const double* new_priorities, int n,
                          rlpyt_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Gradient clipping + Adam for a whole model in two launches (multi-tensor).
+ * Replaces, per minibatch update, the host sequence of rlpyt/algos/pg/ppo.py:100-104
+ * (a2c.py:52-56, dqn/dqn.py:176-180, dqn/r2d1.py):
+ *     grad_norm = torch.nn.utils.clip_grad_norm_(agent.parameters(), clip_grad_norm)
+ *     optimizer.step()            -- torch.optim.Adam (rlpyt/algos/pg/base.py:34-37)
+ * `tensors_host`: HOST array of n_tensors (<= RLPYT_ADAM_MAX_TENSORS) records of DEVICE
+ * pointers (param, grad, exp_avg, exp_avg_sq; f32; 16-byte aligned tensors take the vector
+ * path, others a scalar one) and element counts; read
+ * during the call only.  `step` is the 1-based update count (bias corrections are formed on the
+ * host in double).  max_norm <= 0 disables clipping.  `grad_norm_out` (nullable, device, 1 float)
+ * receives the total 2-norm BEFORE clipping, as clip_grad_norm_ returns it.  The gradient
+ * tensors are not modified (the clip coefficient is applied on the fly).
+ * `workspace`: >= rlpyt_clip_adam_workspace_bytes() bytes of device scratch. */
+#define RLPYT_ADAM_MAX_TENSORS 32
+typedef struct rlpyt_adam_tensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} rlpyt_adam_tensor;
+int64_t rlpyt_clip_adam_workspace_bytes(void);
+int rlpyt_clip_adam_step_f32(const rlpyt_adam_tensor* tensors_host, int n_tensors, double lr,
+                             double beta1, double beta2, double eps, double weight_decay,
+                             int64_t step, double max_norm, void* workspace,
+                             float* grad_norm_out, rlpyt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

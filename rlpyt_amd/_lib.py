@@ -36,6 +36,11 @@ class StepGroup(ctypes.Structure):
                 ("stream", c_void_p), ("event", c_void_p)]
 
 
+class AdamTensor(ctypes.Structure):
+    """Mirror of ``rlpyt_adam_tensor`` (include/rlpyt_hip.h)."""
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
+
+
 class HipExtensionMissing(ImportError):
     pass
 
@@ -135,6 +140,9 @@ _SIGNATURES = {
                                         c_int, c_int64, _p]),
     "rlpyt_gather_sequences": (c_int, [_p, _p, _p, _p, c_int64, c_int, c_int, c_int64, c_int64,
                                        _p]),
+    "rlpyt_clip_adam_workspace_bytes": (c_int64, []),
+    "rlpyt_clip_adam_step_f32": (c_int, [_p, c_int, c_double, c_double, c_double, c_double, c_double,
+                                         c_int64, c_double, _p, _p, _p]),
     "rlpyt_sumtree_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_double,
                                      c_int, c_int]),
     "rlpyt_sumtree_destroy": (None, [_p]),

@@ -96,6 +96,10 @@ class BaseAgent:
     def collector_initialize(self, global_B=1, env_ranks=None):
         pass
 
+    def select_envs(self, lo=None, hi=None):
+        """Called by the sampler before it steps environments [lo, hi) of this rank (one pipeline
+        group); None = all.  Agents with per-environment sampling state use it (vector epsilon)."""
+
     def step(self, observation, prev_action, prev_reward):
         raise NotImplementedError
 

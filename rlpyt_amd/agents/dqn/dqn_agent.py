@@ -43,6 +43,11 @@ class EpsilonGreedyAgentMixin:
     def set_sample_epsilon_greedy(self, epsilon):
         self.distribution.set_epsilon(epsilon)
 
+    def select_envs(self, lo=None, hi=None):
+        """The sampler is about to step environments [lo, hi) of this rank (one pipeline group):
+        vector epsilon is sliced accordingly."""
+        self.distribution.select_envs(lo, hi)
+
     def sample_mode(self, itr):
         super().sample_mode(itr)
         if itr <= self.eps_itr_max:
@@ -74,12 +79,16 @@ class DqnAgent(EpsilonGreedyAgentMixin, BaseAgent):
             self.target_model.load_state_dict(init_sd["model"])
         self.distribution = EpsilonGreedy(dim=env_spaces.action.n)
         self.eps_sample = self.eps_init
+        self._n_local_envs = None if env_ranks is None else len(env_ranks)
         if env_ranks is not None:
             self.make_vec_eps(global_B, env_ranks)
 
     def to_device(self, cuda_idx=None):
         super().to_device(cuda_idx)
         self.target_model.to(self.device)
+        # epsilon in persistent device buffers: visible to step graphs captured earlier
+        self.distribution.bind_device(self.device, getattr(self, "_n_local_envs", None))
+        self.distribution.set_epsilon(self.eps_sample)
 
     def state_dict(self):
         return dict(model=self.model.state_dict(), target=self.target_model.state_dict())

@@ -36,6 +36,34 @@ class RlAlgorithm:
     def load_optim_state_dict(self, state_dict):
         self.optimizer.load_state_dict(state_dict)
 
+    # ------------------------------------------------------------------ optimizer
+    def make_optimizer(self, params, OptimCls, lr, optim_kwargs=None):
+        """``OptimCls(params, lr=lr, **optim_kwargs)`` as the reference builds it
+        (rlpyt/algos/pg/base.py:34-37, dqn/dqn.py:108-112) -- except that plain
+        ``torch.optim.Adam`` over float32 device parameters becomes ``ClipAdam`` (same class
+        hierarchy, hyper-parameters and state_dict; clip + step in two launches)."""
+        optim_kwargs = dict(optim_kwargs or {})
+        params = list(params)
+        if (OptimCls is torch.optim.Adam and params and all(
+                p.is_cuda and p.dtype == torch.float32 for p in params)
+                and not any(optim_kwargs.get(k) for k in ("amsgrad", "maximize", "capturable",
+                                                          "differentiable"))):
+            from ..optim import ClipAdam
+            return ClipAdam(params, lr=lr, **optim_kwargs)
+        if (OptimCls in (torch.optim.Adam, torch.optim.AdamW) and "fused" not in optim_kwargs
+                and "foreach" not in optim_kwargs and params and params[0].is_cuda):
+            optim_kwargs["fused"] = True    # one multi-tensor kernel per step on the device
+        return OptimCls(params, lr=lr, **optim_kwargs)
+
+    def clip_and_step(self):
+        """Gradient-norm clipping + optimizer step (rlpyt/algos/pg/ppo.py:100-104); returns the
+        gradient norm (device scalar)."""
+        if hasattr(self.optimizer, "clip_and_step"):
+            return self.optimizer.clip_and_step(self.clip_grad_norm)
+        grad_norm = torch.nn.utils.clip_grad_norm_(self.agent.parameters(), self.clip_grad_norm)
+        self.optimizer.step()
+        return grad_norm
+
     # ------------------------------------------------------------------ device helpers
     def on_device(self, x):
         """``x`` on the agent's device (no-op for the HBM-resident sampler's batches)."""

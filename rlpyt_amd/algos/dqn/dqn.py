@@ -58,8 +58,8 @@ class DQN(RlAlgorithm):
 
     def optim_initialize(self, rank=0):
         self.rank = rank
-        self.optimizer = self.OptimCls(self.agent.parameters(), lr=self.learning_rate,
-                                       **self.optim_kwargs)
+        self.optimizer = self.make_optimizer(self.agent.parameters(), self.OptimCls,
+                                             self.learning_rate, self.optim_kwargs)
         if self.initial_optim_state_dict is not None:
             self.optimizer.load_state_dict(self.initial_optim_state_dict)
         if self.prioritized_replay:
@@ -104,9 +104,7 @@ class DQN(RlAlgorithm):
             self.optimizer.zero_grad(set_to_none=True)
             loss, td_abs_errors = self.loss(samples_from_replay)
             loss.backward()
-            grad_norm = torch.nn.utils.clip_grad_norm_(self.agent.parameters(),
-                                                       self.clip_grad_norm)
-            self.optimizer.step()
+            grad_norm = self.clip_and_step()
             if self.prioritized_replay:
                 self.replay_buffer.update_batch_priorities(td_abs_errors)
             stats.append(torch.stack([loss.detach(), grad_norm.to(loss.dtype)]))

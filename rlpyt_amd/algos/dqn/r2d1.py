@@ -96,9 +96,7 @@ class R2D1(DQN):
             self.optimizer.zero_grad(set_to_none=True)
             loss, td_abs_errors, priorities = self.loss(samples_from_replay)
             loss.backward()
-            grad_norm = torch.nn.utils.clip_grad_norm_(self.agent.parameters(),
-                                                       self.clip_grad_norm)
-            self.optimizer.step()
+            grad_norm = self.clip_and_step()
             if self.prioritized_replay:
                 self.replay_buffer.update_batch_priorities(priorities)
             stats.append(torch.stack([loss.detach(), grad_norm.to(loss.dtype)]))

@@ -27,9 +27,7 @@ class A2C(PolicyGradientAlgo):
         self.optimizer.zero_grad(set_to_none=True)
         loss, scalars = self.loss(samples)
         loss.backward()
-        grad_norm = torch.nn.utils.clip_grad_norm_(self.agent.parameters(),
-                                                   self.clip_grad_norm)
-        self.optimizer.step()
+        grad_norm = self.clip_and_step()
         host = torch.stack([scalars[0], grad_norm.to(scalars.dtype), scalars[3],
                             scalars[4]]).cpu().tolist()
         self.update_counter += 1

@@ -18,12 +18,8 @@ class PolicyGradientAlgo(RlAlgorithm):
 
     def initialize(self, agent, n_itr, batch_spec, mid_batch_reset=False, examples=None,
                    world_size=1, rank=0):
-        optim_kwargs = dict(self.optim_kwargs)
-        params = list(agent.parameters())
-        if (self.OptimCls in (torch.optim.Adam, torch.optim.AdamW) and "fused" not in optim_kwargs
-                and "foreach" not in optim_kwargs and params and params[0].is_cuda):
-            optim_kwargs["fused"] = True    # one multi-tensor kernel per step on the device
-        self.optimizer = self.OptimCls(params, lr=self.learning_rate, **optim_kwargs)
+        self.optimizer = self.make_optimizer(agent.parameters(), self.OptimCls, self.learning_rate,
+                                             self.optim_kwargs)
         if self.initial_optim_state_dict is not None:
             self.optimizer.load_state_dict(self.initial_optim_state_dict)
         self.agent = agent

@@ -97,9 +97,7 @@ class PPO(PolicyGradientAlgo):
                     loss, scalars = self.loss(mb_inputs, mb_action, mb_return, mb_adv, mb_valid,
                                               mb_old_prob)
                 loss.backward()
-                grad_norm = torch.nn.utils.clip_grad_norm_(self.agent.parameters(),
-                                                           self.clip_grad_norm)
-                self.optimizer.step()
+                grad_norm = self.clip_and_step()
                 # loss, gradNorm, entropy, perplexity -- kept on the device until the end
                 stats.append(torch.stack([scalars[0], grad_norm.to(scalars.dtype), scalars[3],
                                           scalars[4]]))

@@ -16,9 +16,11 @@ constexpr int kLossBlock = 256;
 constexpr int kMaxLossGrid = 1024;
 constexpr float kEpsCat = 1e-8f;  // rlpyt/distributions/categorical.py:9
 
+constexpr int kMaxLossPart = 2048;  // partial rows: <= kMaxLossGrid workgroups, or one per wave of
+                                    // the head kernel (512 workgroups x 4 waves)
 struct LossWs {            // layout of the caller's workspace
   double valid_part[kMaxLossGrid];
-  double part[kMaxLossGrid][6];
+  double part[kMaxLossPart][6];
 };
 
 __global__ __launch_bounds__(kLossBlock) void valid_partial_kernel(
@@ -318,8 +320,10 @@ __global__ __launch_bounds__(256) void norm_pass3_kernel(float* __restrict__ x, 
 constexpr int kHeadAMax = 8;
 constexpr int kHeadWavesPerBlock = 4;
 
-template <int KI>  // K = 64 * KI
-__global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
+template <int KI, int AM>  // K = 64 * KI; AM = action slots held in registers (>= A): 4, 6 or 8.
+// Two 4-wave workgroups per CU need <= 256 VGPRs per wave: with AM = 8 for every A the 2 x 8 x KI
+// weight and weight-gradient registers pushed the kernel to 1 wave per SIMD (measured 2x slower).
+__global__ __launch_bounds__(64 * kHeadWavesPerBlock, 2) void ppo_head_loss_kernel(
     const float* __restrict__ h, const float* __restrict__ w_pi, const float* __restrict__ b_pi,
     const float* __restrict__ w_v, const float* __restrict__ b_v,
     const float* __restrict__ prob_old, const int64_t* __restrict__ action,
@@ -336,11 +340,11 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
   const int64_t wave_id = (int64_t)blockIdx.x * kHeadWavesPerBlock + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * kHeadWavesPerBlock;
 
-  float wp[kHeadAMax][KI], wv[KI], gw[kHeadAMax][KI], gwv[KI];
+  float wp[AM][KI], wv[KI], gw[AM][KI], gwv[KI];
 #pragma unroll
   for (int i = 0; i < KI; ++i) {
 #pragma unroll
-    for (int a = 0; a < kHeadAMax; ++a) {
+    for (int a = 0; a < AM; ++a) {
       // unconditional clamped load + select: predicated loads compile to one branch and one
       // s_waitcnt vmcnt(0) each, i.e. ~60 serialized L2 round trips per wave
       const float wl = w_pi[min(a, A - 1) * K + lane + 64 * i];
@@ -350,9 +354,9 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
     wv[i] = w_v[lane + 64 * i];
     gwv[i] = 0.f;
   }
-  float bp[kHeadAMax], gb[kHeadAMax];
+  float bp[AM], gb[AM];
 #pragma unroll
-  for (int a = 0; a < kHeadAMax; ++a) {
+  for (int a = 0; a < AM; ++a) {
     const float bl = b_pi[min(a, A - 1)];
     bp[a] = a < A ? bl : 0.f;
     gb[a] = 0.f;
@@ -361,22 +365,53 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
   float gbv = 0.f;
   double acc[5] = {0, 0, 0, 0, 0};  // surrogate, value err, H, exp(H), count
 
-  float hn[KI];   // next row, prefetched while the current one is processed
+  // Software pipeline over the wave's rows.  A row's critical path used to hold THREE dependent
+  // global loads (flat_idx[m] -> action[r] -> prob_old[r, a_sel]: ~5 us per row, the whole kernel
+  // ran at 5 % of HBM peak): now the row index is fetched two rows ahead and every per-sample
+  // scalar (action, advantage, return, valid, the whole prob_old row) one row ahead, together
+  // with the next row of h, so a row only waits for arithmetic.
+  struct RowIn {
+    int64_t r;
+    int a_sel;
+    float adv, ret, vmask, po[AM];
+  };
+  auto row_of = [&](int64_t m) -> int64_t {      // [T,B] row of sample m (ppo.py:94-95)
+    if (flat_idx == nullptr) return m;
+    const int64_t idx = flat_idx[m];
+    return (idx % T) * B + (idx / T);
+  };
+  auto fetch_row = [&](int64_t r, RowIn& in) {
+    in.r = r;
+    in.a_sel = (int)action[r];
+    in.adv = advantage[r];
+    in.ret = return_[r];
+    in.vmask = valid ? valid[r] : 1.0f;
+#pragma unroll
+    for (int a = 0; a < AM; ++a) in.po[a] = prob_old[r * A + min(a, A - 1)];
+  };
+  float hn[KI];   // next row of h
+  RowIn nx{};
+  int64_t r_nn = 0;  // row index of the row after next
   if (wave_id < M) {
 #pragma unroll
     for (int i = 0; i < KI; ++i) hn[i] = h[wave_id * K + lane + 64 * i];
+    fetch_row(row_of(wave_id), nx);
+    if (wave_id + n_waves < M) r_nn = row_of(wave_id + n_waves);
   }
   for (int64_t m = wave_id; m < M; m += n_waves) {
     float hv[KI];
 #pragma unroll
     for (int i = 0; i < KI; ++i) hv[i] = hn[i];
+    const RowIn in = nx;
     if (m + n_waves < M) {
 #pragma unroll
       for (int i = 0; i < KI; ++i) hn[i] = h[(m + n_waves) * K + lane + 64 * i];
+      fetch_row(r_nn, nx);
+      if (m + 2 * n_waves < M) r_nn = row_of(m + 2 * n_waves);
     }
-    float lg[kHeadAMax], vsum = 0.f;
+    float lg[AM], vsum = 0.f;
 #pragma unroll
-    for (int a = 0; a < kHeadAMax; ++a) {
+    for (int a = 0; a < AM; ++a) {
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < KI; ++i) t = fmaf(hv[i], wp[a][i], t);
@@ -385,38 +420,35 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
 #pragma unroll
     for (int i = 0; i < KI; ++i) vsum = fmaf(hv[i], wv[i], vsum);
 #pragma unroll
-    for (int a = 0; a < kHeadAMax; ++a) lg[a] = wave_sum(lg[a]) + bp[a];
+    for (int a = 0; a < AM; ++a) lg[a] = wave_sum(lg[a]) + bp[a];
     const float val = wave_sum(vsum) + bv;
     // softmax (every lane redundantly: the scalars are needed by all lanes below)
     float mx = -INFINITY;
 #pragma unroll
-    for (int a = 0; a < kHeadAMax; ++a)
+    for (int a = 0; a < AM; ++a)
       if (a < A) mx = fmaxf(mx, lg[a]);
-    float p[kHeadAMax], den = 0.f;
+    float p[AM], den = 0.f;
 #pragma unroll
-    for (int a = 0; a < kHeadAMax; ++a) {
+    for (int a = 0; a < AM; ++a) {
       p[a] = a < A ? expf(lg[a] - mx) : 0.f;
       den += p[a];
     }
     const float rden = 1.f / den;
 #pragma unroll
-    for (int a = 0; a < kHeadAMax; ++a) p[a] *= rden;
-    // ---- PPO loss terms and dL/dp, dL/dv (as pg_loss_kernel<0>); with flat_idx the per-sample
-    //      inputs are the [T,B] batch arrays read at (idx % T, idx / T) (ppo.py:94-95)
-    int64_t r = m;
-    if (flat_idx != nullptr) {
-      const int64_t idx = flat_idx[m];
-      r = (idx % T) * B + (idx / T);
-    }
-    const float vmask = valid ? valid[r] : 1.0f;
+    for (int a = 0; a < AM; ++a) p[a] *= rden;
+    // ---- PPO loss terms and dL/dp, dL/dv (as pg_loss_kernel<0>)
+    const float vmask = in.vmask;
     const float w = vmask * inv;
-    const int a_sel = (int)action[r];
-    const float adv = advantage[r];
-    float p_sel = 0.f;
+    const int a_sel = in.a_sel;
+    const float adv = in.adv;
+    float p_sel = 0.f, po_sel = 0.f;
 #pragma unroll
-    for (int a = 0; a < kHeadAMax; ++a)
-      if (a == a_sel) p_sel = p[a];
-    const float den_o = prob_old[r * A + a_sel] + kEpsCat;
+    for (int a = 0; a < AM; ++a)
+      if (a == a_sel) {
+        p_sel = p[a];
+        po_sel = in.po[a];
+      }
+    const float den_o = po_sel + kEpsCat;
     const float ratio = (p_sel + kEpsCat) / den_o;
     const float lo = 1.0f - ratio_clip, hi = 1.0f + ratio_clip;
     const float clipped = fminf(fmaxf(ratio, lo), hi);
@@ -428,12 +460,12 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
     else if (s1 > s2) dr = inside ? adv : 0.f;
     else dr = 0.5f * adv + (inside ? 0.5f * adv : 0.f);
     const float g_sel = -w * dr / den_o;
-    const float verr_d = val - return_[r];
+    const float verr_d = val - in.ret;
     const float verr = 0.5f * verr_d * verr_d;
     const float dv = c_v * w * verr_d;
-    float H = 0.f, gp[kHeadAMax], dot = 0.f;
+    float H = 0.f, gp[AM], dot = 0.f;
 #pragma unroll
-    for (int a = 0; a < kHeadAMax; ++a) {
+    for (int a = 0; a < AM; ++a) {
       gp[a] = 0.f;
       if (a < A) {
         const float lp = logf(p[a] + kEpsCat);
@@ -444,9 +476,9 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
       }
     }
     // softmax backward: dL/dlogit_a = p_a (g_a - sum_b g_b p_b)
-    float dl[kHeadAMax];
+    float dl[AM];
 #pragma unroll
-    for (int a = 0; a < kHeadAMax; ++a) dl[a] = p[a] * (gp[a] - dot);
+    for (int a = 0; a < AM; ++a) dl[a] = p[a] * (gp[a] - dot);
     if (lane == 0) {
       acc[0] += (double)(vmask * pi_term);
       acc[1] += (double)(vmask * verr);
@@ -459,7 +491,7 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
     for (int i = 0; i < KI; ++i) {
       float g = dv * wv[i];
 #pragma unroll
-      for (int a = 0; a < kHeadAMax; ++a) {
+      for (int a = 0; a < AM; ++a) {
         g = fmaf(dl[a], wp[a][i], g);
         gw[a][i] = fmaf(dl[a], hv[i], gw[a][i]);
       }
@@ -467,26 +499,26 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
       grad_h[m * K + lane + 64 * i] = g;
     }
 #pragma unroll
-    for (int a = 0; a < kHeadAMax; ++a) gb[a] += dl[a];
+    for (int a = 0; a < AM; ++a) gb[a] += dl[a];
     gbv += dv;
   }
   // weight-gradient partials [A*K dWpi | K dWv | A dbpi | 1 dbv]: waves 1..3 hand theirs to
   // wave 0 through LDS, one partial row per workgroup leaves for the reduction kernel
-  extern __shared__ float hred[];   // [3][(kHeadAMax + 1) * K + kHeadAMax + 1]
-  constexpr int kRedStride = (kHeadAMax + 1) * K + kHeadAMax + 1;
+  extern __shared__ float hred[];   // [3][(AM + 1) * K + AM + 1]
+  constexpr int kRedStride = (AM + 1) * K + AM + 1;
   const int wv_i = threadIdx.x >> 6;
   if (wv_i > 0) {
     float* r = hred + (wv_i - 1) * kRedStride;
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
 #pragma unroll
-      for (int a = 0; a < kHeadAMax; ++a) r[a * K + lane + 64 * i] = gw[a][i];
-      r[kHeadAMax * K + lane + 64 * i] = gwv[i];
+      for (int a = 0; a < AM; ++a) r[a * K + lane + 64 * i] = gw[a][i];
+      r[AM * K + lane + 64 * i] = gwv[i];
     }
     if (lane == 0) {
 #pragma unroll
-      for (int a = 0; a < kHeadAMax; ++a) r[(kHeadAMax + 1) * K + a] = gb[a];
-      r[(kHeadAMax + 1) * K + kHeadAMax] = gbv;
+      for (int a = 0; a < AM; ++a) r[(AM + 1) * K + a] = gb[a];
+      r[(AM + 1) * K + AM] = gbv;
     }
   }
   __syncthreads();
@@ -496,7 +528,7 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
 #pragma unroll
-      for (int a = 0; a < kHeadAMax; ++a) {
+      for (int a = 0; a < AM; ++a) {
         if (a < A) {
           float v = gw[a][i];
 #pragma unroll
@@ -506,22 +538,22 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock) void ppo_head_loss_kernel(
       }
       float v = gwv[i];
 #pragma unroll
-      for (int w3 = 0; w3 < 3; ++w3) v += hred[w3 * kRedStride + kHeadAMax * K + lane + 64 * i];
+      for (int w3 = 0; w3 < 3; ++w3) v += hred[w3 * kRedStride + AM * K + lane + 64 * i];
       out[A * K + lane + 64 * i] = v;
     }
     if (lane == 0) {
 #pragma unroll
-      for (int a = 0; a < kHeadAMax; ++a) {
+      for (int a = 0; a < AM; ++a) {
         if (a < A) {
           float v = gb[a];
 #pragma unroll
-          for (int w3 = 0; w3 < 3; ++w3) v += hred[w3 * kRedStride + (kHeadAMax + 1) * K + a];
+          for (int w3 = 0; w3 < 3; ++w3) v += hred[w3 * kRedStride + (AM + 1) * K + a];
           out[A * K + K + a] = v;
         }
       }
       float v = gbv;
 #pragma unroll
-      for (int w3 = 0; w3 < 3; ++w3) v += hred[w3 * kRedStride + (kHeadAMax + 1) * K + kHeadAMax];
+      for (int w3 = 0; w3 < 3; ++w3) v += hred[w3 * kRedStride + (AM + 1) * K + AM];
       out[A * K + K + A] = v;
     }
   }
@@ -553,7 +585,8 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
     out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-constexpr int kHeadGrid = 256;  // one weight-gradient partial row per workgroup
+constexpr int kHeadGrid = 512;  // one weight-gradient partial row per workgroup; two 4-wave
+                                // workgroups per CU (the kernel is latency-bound: 8 waves per CU halve it)
 }  // namespace
 }  // namespace rlpyt
 
@@ -714,16 +747,16 @@ extern "C" int rlpyt_ppo_head_loss_fwd_bwd_f32(
   const int n_waves = grid * kHeadWavesPerBlock;
   const int part = A * K + K + A + 1;
   const size_t lds = (size_t)3 * ((kHeadAMax + 1) * K + kHeadAMax + 1) * sizeof(float);
-  if (K == 512)
-    RL_LAUNCH((ppo_head_loss_kernel<8>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h,
-                       w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A,
-                       ratio_clip, value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws,
-                       n_valid_part, flat_idx, T, B);
-  else
-    RL_LAUNCH((ppo_head_loss_kernel<4>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h,
-                       w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A,
-                       ratio_clip, value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws,
-                       n_valid_part, flat_idx, T, B);
+#define RL_HEAD(KI_, AM_)                                                                         \
+  RL_LAUNCH((ppo_head_loss_kernel<KI_, AM_>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h, \
+            w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A, ratio_clip,    \
+            value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws, n_valid_part, flat_idx, T, B)
+  if (K == 512) {
+    if (A <= 4) RL_HEAD(8, 4); else if (A <= 6) RL_HEAD(8, 6); else RL_HEAD(8, 8);
+  } else {
+    if (A <= 4) RL_HEAD(4, 4); else if (A <= 6) RL_HEAD(4, 6); else RL_HEAD(4, 8);
+  }
+#undef RL_HEAD
   RL_LAUNCH_CHECK();
   RL_LAUNCH(head_reduce_kernel, dim3((part + 63) / 64), dim3(256), 0, s, wpart, grid,
                      part, grad_params);

@@ -19,20 +19,66 @@ def _explore(greedy, n_actions, epsilon, generator):
 
 
 class EpsilonGreedy(DiscreteMixin, Distribution):
-    """``sample(q)``: argmax with probability 1 - epsilon, uniform otherwise."""
+    """``sample(q)``: argmax with probability 1 - epsilon, uniform otherwise.
+
+    On the device epsilon lives in PERSISTENT buffers that ``set_epsilon`` overwrites in place
+    (``bind_device``): the sampler's captured step graphs compare against device memory, so a new
+    epsilon (the schedule of ``sample_mode``, ``eval_mode``) reaches graphs captured earlier -- a
+    Python scalar would be frozen into the graph at capture time.  With vector epsilon (one value
+    per environment, rlpyt/agents/dqn/epsilon_greedy.py:47-63) a pipeline group sees its own slice
+    (``select_envs``)."""
 
     def __init__(self, epsilon=1, **kwargs):
         super().__init__(**kwargs)
         self._epsilon = epsilon
+        self._buf = self._scalar_buf = None
+        self._env_slice = None
 
     epsilon = property(lambda self: self._epsilon)
 
     def set_epsilon(self, epsilon):
         """Scalar, or a tensor with one epsilon per environment (vector epsilon)."""
         self._epsilon = epsilon
+        self._refresh()
+
+    def bind_device(self, device, n_envs=None):
+        if torch.device(device).type != "cuda":
+            return
+        self._scalar_buf = torch.zeros(1, dtype=torch.float32, device=device)
+        self._buf = (torch.zeros(int(n_envs), dtype=torch.float32, device=device)
+                     if n_envs else None)
+        self._refresh()
+
+    def select_envs(self, lo=None, hi=None):
+        self._env_slice = None if lo is None else (int(lo), int(hi))
+
+    def _refresh(self):
+        if self._scalar_buf is None:
+            return
+        e = torch.as_tensor(self._epsilon, dtype=torch.float32).reshape(-1)
+        self._scalar_buf.copy_(e[:1])
+        if self._buf is not None and e.numel() in (1, self._buf.numel()):
+            self._buf.copy_(e.expand(self._buf.numel()))
+
+    def _eps_for(self, n):
+        """Epsilon operand for a batch of ``n`` environments."""
+        if self._scalar_buf is None:                       # host path
+            e = self._epsilon
+            if isinstance(e, torch.Tensor) and e.numel() > 1 and self._env_slice is not None \
+                    and self._env_slice[1] - self._env_slice[0] == n:
+                return e[self._env_slice[0]:self._env_slice[1]]
+            return e
+        if self._buf is not None:
+            if self._env_slice is not None and self._env_slice[1] - self._env_slice[0] == n:
+                return self._buf[self._env_slice[0]:self._env_slice[1]]
+            if self._buf.numel() == n:
+                return self._buf
+        return self._scalar_buf
 
     def sample(self, q, generator=None):
-        return _explore(q.argmax(dim=-1), q.shape[-1], self._epsilon, generator)
+        greedy = q.argmax(dim=-1)
+        return _explore(greedy, q.shape[-1], self._eps_for(greedy.shape[0] if greedy.dim() else 1),
+                        generator)
 
 
 class CategoricalEpsilonGreedy(EpsilonGreedy):
@@ -48,4 +94,6 @@ class CategoricalEpsilonGreedy(EpsilonGreedy):
 
     def sample(self, p, z=None, generator=None):
         expected = torch.tensordot(p, self.z if z is None else z, dims=1)
-        return _explore(expected.argmax(dim=-1), expected.shape[-1], self._epsilon, generator)
+        greedy = expected.argmax(dim=-1)
+        return _explore(greedy, expected.shape[-1],
+                        self._eps_for(greedy.shape[0] if greedy.dim() else 1), generator)

@@ -29,7 +29,7 @@ class SyntheticPong(Env):
     obs_newest_frame_last = True
 
     def __init__(self, num_img_obs=4, points_to_end=3, max_steps=2000, step_cost_us=0.,
-                 opponent_skill=0.6, seed=0):
+                 opponent_skill=0.6, seed=0, step_cost_ref=None):
         self._n = num_img_obs
         self._observation_space = IntBox(0, 256, shape=(num_img_obs, H, W), dtype="uint8")
         self._action_space = IntBox(0, 6)
@@ -37,6 +37,9 @@ class SyntheticPong(Env):
         self._points_to_end = points_to_end
         self._max_steps = max_steps
         self._cost = step_cost_us * 1e-6
+        # optional fork-shared object with a ``.value`` in microseconds (e.g. mp.RawValue("d")):
+        # lets a bench change the declared emulator cost of already forked env workers
+        self._cost_ref = step_cost_ref
         self._skill = opponent_skill
         self._rng = np.random.RandomState(seed)
         self.reset()
@@ -72,8 +75,9 @@ class SyntheticPong(Env):
         f[max(y - 1, 0):y + 2, max(x - 1, 0):x + 2] = 255
 
     def step(self, action):
-        if self._cost:
-            end = time.perf_counter() + self._cost
+        cost = self._cost if self._cost_ref is None else self._cost_ref.value * 1e-6
+        if cost:
+            end = time.perf_counter() + cost
             while time.perf_counter() < end:
                 pass
         a = int(action)

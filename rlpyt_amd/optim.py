@@ -1,0 +1,98 @@
+"""``ClipAdam``: torch.optim.Adam whose update, together with the gradient-norm clipping that
+precedes it in every algorithm of this path, runs as TWO kernel launches for the whole model
+(``rlpyt_clip_adam_step_f32``, csrc/optim.hip).
+
+The reference does, per minibatch (rlpyt/algos/pg/ppo.py:100-104, a2c.py:52-56, dqn/dqn.py:176-180)::
+
+    grad_norm = torch.nn.utils.clip_grad_norm_(self.agent.parameters(), self.clip_grad_norm)
+    self.optimizer.step()
+
+-- on the device that is a dozen launch-bound kernels for 7 MB of parameters.  The algorithms here
+call ``optimizer.clip_and_step(max_norm)`` when the optimizer offers it and fall back to the two
+reference statements otherwise (any other ``OptimCls`` keeps working).
+
+This is a subclass of ``torch.optim.Adam``: same constructor, same ``param_groups`` (LR schedulers
+work unchanged), same ``state_dict`` layout (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter), so
+optimizer snapshots interchange with the reference's.  ``step()`` alone is torch's own.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AdamTensor, check, lib
+
+MAX_TENSORS = 32
+
+
+class ClipAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **kwargs):
+        kwargs.pop("fused", None)       # this IS the fused path
+        kwargs.pop("foreach", None)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kwargs)
+        self._ws = None
+        self._norm = None
+
+    def supports_fused(self):
+        if len(self.param_groups) != 1 or len(self.param_groups[0]["params"]) > MAX_TENSORS:
+            return False
+        for group in self.param_groups:
+            if group.get("amsgrad") or group.get("maximize") or group.get("decoupled_weight_decay"):
+                return False
+            for p in group["params"]:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    return False
+        return True
+
+    @torch.no_grad()
+    def clip_and_step(self, max_norm):
+        """``clip_grad_norm_(params, max_norm)`` + ``step()``; returns the total gradient norm
+        (device scalar tensor, before clipping) like ``clip_grad_norm_``.  ``max_norm`` None or
+        <= 0: no clipping."""
+        if not self.supports_fused():
+            params = [p for g in self.param_groups for p in g["params"]]
+            norm = (torch.nn.utils.clip_grad_norm_(params, max_norm) if max_norm
+                    else torch.zeros((), device=params[0].device))
+            self.step()
+            return norm
+        _lib.require_gpu()
+        dev = self.param_groups[0]["params"][0].device
+        if self._ws is None or self._ws.device != dev:
+            self._ws = torch.empty(lib.rlpyt_clip_adam_workspace_bytes(), dtype=torch.uint8,
+                                   device=dev)
+            self._norm = torch.zeros((), dtype=torch.float32, device=dev)
+        # the clip norm is over ALL parameters (clip_grad_norm_ semantics); a call updates up to
+        # MAX_TENSORS tensors of one hyper-parameter group
+        group = self.param_groups[0]
+        rows = []
+        step = None
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            g = p.grad
+            if not (g.is_contiguous() and g.dtype == torch.float32):
+                g = g.contiguous().float()
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            step = int(st["step"].item()) if step is None else step
+            rows.append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+        if not rows:
+            return self._norm.zero_()
+        assert len(rows) <= MAX_TENSORS, f"ClipAdam: {len(rows)} tensors > {MAX_TENSORS}"
+        table = (AdamTensor * len(rows))()
+        for k, (p, g, m, v) in enumerate(rows):
+            table[k] = AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+        b1, b2 = group["betas"]
+        lr = group["lr"]
+        check(lib.rlpyt_clip_adam_step_f32(
+            ctypes.cast(table, ctypes.c_void_p), len(rows), float(lr), float(b1), float(b2),
+            float(group["eps"]), float(group["weight_decay"]), step,
+            float(max_norm) if max_norm else 0., ctypes.c_void_p(self._ws.data_ptr()),
+            ctypes.c_void_p(self._norm.data_ptr()),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "rlpyt_clip_adam_step_f32")
+        self._keep = rows          # the launch is asynchronous: keep the gradient tensors alive
+        return self._norm

@@ -784,6 +784,7 @@ class GpuSampler(BaseSampler):
                 prev_reward = torch.where(dn, torch.zeros_like(prev_reward), prev_reward)
         else:
             prev_action = prev_reward = None
+        self.agent.select_envs(lo, hi)
         if self.agent.recurrent:
             # one persistent [N, B_g, H] state per pipeline group; after a reset the env starts
             # from a zero state (action_server.py:49-53)
@@ -1178,6 +1179,7 @@ class GpuSampler(BaseSampler):
                     take(item)
 
         agent.reset()
+        agent.select_envs(None, None)
         if agent.recurrent:
             agent.select_slot("eval")
         g_eval = len(self.groups)

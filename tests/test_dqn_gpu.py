@@ -174,3 +174,40 @@ def test_catdqn_end_to_end(prioritized, double, dueling):
     np.testing.assert_allclose(loss.item(), loss_c.item(), rtol=2e-5)
     np.testing.assert_allclose(kl.cpu().numpy(), kl_c.numpy(), rtol=1e-4, atol=1e-6)
     sampler.shutdown()
+
+
+@pytest.mark.parametrize("vector_eps", [False, True])
+def test_epsilon_schedule_reaches_captured_step_graphs(vector_eps):
+    """The sampler captures the per-step device work of every pipeline group in a hipGraph during
+    the first batch.  Epsilon must not be frozen into those graphs: with a schedule that drops to
+    zero after iteration 0, every later action equals argmax(q) of the recorded Q-values; with a
+    per-environment (vector) epsilon of {0, 1} exactly the eps = 0 environments act greedily,
+    whichever pipeline group they fall in (rlpyt/agents/dqn/epsilon_greedy.py:47-89)."""
+    T, B = 6, 8
+    sampler = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=50), batch_T=T, batch_B=B,
+                         n_workers=2, n_groups=2, max_decorrelation_steps=0)
+    agent = AtariDqnAgent(eps_init=1., eps_final=0., eps_itr_min=0, eps_itr_max=1)
+    torch.manual_seed(1)
+    sampler.initialize(agent, seed=5, bootstrap_value=False)
+    torch.cuda.set_device(0)
+    agent.to_device(0)
+    agent.eps_itr_min, agent.eps_itr_max = 0, 1
+    if vector_eps:
+        agent.eps_final = torch.tensor([0., 1., 0., 0., 1., 1., 0., 1.])   # spans both groups
+    greedy_frac = []
+    for itr in range(4):
+        agent.sample_mode(itr)
+        samples, _ = sampler.obtain_samples(itr)
+        q, act = samples.agent.agent_info.q, samples.agent.action
+        same = (q.argmax(-1) == act)                      # [T, B]
+        greedy_frac.append(same.float().mean().item())
+        if itr >= 1:
+            if vector_eps:
+                zero = agent.eps_final == 0
+                assert bool(same[:, zero.cuda()].all()), "eps = 0 environments must act greedily"
+                assert not bool(same[:, (~zero).cuda()].all()), "eps = 1 environments explore"
+            else:
+                assert bool(same.all()), f"itr {itr}: epsilon 0 but {1 - greedy_frac[-1]:.2f} of the actions are random"
+    assert greedy_frac[0] < 0.6        # iteration 0 ran with epsilon 1 (uniform over 6 actions)
+    assert all(G.graph is not None for G in sampler.groups)
+    sampler.shutdown()

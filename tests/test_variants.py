@@ -197,12 +197,12 @@ def _rms():
     P.test_running_mean_std_golden(_ops())
 
 
-def _head_loss_case(K):
+def _head_loss_case(K, A=6):
     def run():
         """Fused heads + PPO loss against the reference's statement sequence in f64."""
         ops = _ops()
-        g = torch.Generator().manual_seed(K)
-        M, A = 300, 6
+        g = torch.Generator().manual_seed(K + A)
+        M = 300
         h = torch.relu(torch.randn(M, K, generator=g))
         wp, bp = torch.randn(A, K, generator=g) * 0.05, torch.randn(A, generator=g) * 0.1
         wv, bv = torch.randn(1, K, generator=g) * 0.05, torch.randn(1, generator=g) * 0.1
@@ -228,8 +228,9 @@ def _head_loss_case(K):
     return run
 
 
-CASES["ppo_head_loss_kernel<8>"] = _head_loss_case(512)
-CASES["ppo_head_loss_kernel<4>"] = _head_loss_case(256)
+for _ki, _K in ((8, 512), (4, 256)):
+    for _am, _A in ((4, 3), (6, 6), (8, 8)):      # action slots held in registers: A <= 4, <= 6, <= 8
+        CASES[f"ppo_head_loss_kernel<{_ki}, {_am}>"] = _head_loss_case(_K, _A)
 CASES["head_reduce_kernel"] = _head_loss_case(512)
 
 
@@ -479,6 +480,47 @@ def _conv_bwd():
 def _sample_convs():
     import test_sampler_gpu as S
     S.test_sample_convs_kernel_matches_separate_launches()
+
+
+# ------------------------------------------------------------------------------- optimizer
+@case("clip_adam_norm_kernel", "clip_adam_apply_kernel")
+def _clip_adam():
+    """ClipAdam.clip_and_step == torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (the
+    reference's two statements, rlpyt/algos/pg/ppo.py:100-104) in float64 on the CPU, over several
+    steps with clipping active and inactive, odd tensor sizes (scalar tails), and a state_dict
+    round trip into a plain torch.optim.Adam.  fp32 tolerance: rtol 2e-6 on parameters."""
+    from rlpyt_amd.optim import ClipAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(16, 4, 8, 8), (16,), (3456, 37), (5,), (7, 3), (1,)]
+    params64 = [torch.randn(s, generator=g, dtype=torch.float64).requires_grad_(True) for s in shapes]
+    params32 = [p.detach().float().cuda().requires_grad_(True) for p in params64]
+    ref = torch.optim.Adam(params64, lr=3e-3, betas=(0.9, 0.99), eps=1e-5)
+    opt = ClipAdam(params32, lr=3e-3, betas=(0.9, 0.99), eps=1e-5)
+    assert opt.supports_fused()
+    for it in range(6):
+        scale = 10.0 if it % 2 == 0 else 1e-3        # clipped / not clipped
+        for k, (p64, p32) in enumerate(zip(params64, params32)):
+            gr = torch.randn(p64.shape, generator=g, dtype=torch.float64) * scale
+            p64.grad = gr.clone()
+            if k == 3:      # a gradient that is a view at an odd offset of a packed buffer
+                packed = torch.zeros(p32.numel() + 3, device="cuda")
+                packed[3:] = gr.float().cuda().reshape(-1)
+                p32.grad = packed[3:].view(p32.shape)
+            else:
+                p32.grad = gr.float().cuda()
+        n_ref = torch.nn.utils.clip_grad_norm_(params64, 1.0)
+        ref.step()
+        n = opt.clip_and_step(1.0)
+        np.testing.assert_allclose(n.item(), n_ref.item(), rtol=1e-6)
+        for p64, p32 in zip(params64, params32):
+            np.testing.assert_allclose(host(p32.detach()), p64.detach().numpy(), rtol=2e-6, atol=1e-7)
+    # same state layout as torch.optim.Adam: the snapshot loads into the plain optimizer
+    plain = torch.optim.Adam([torch.zeros_like(p) for p in params32], lr=1.)
+    plain.load_state_dict(opt.state_dict())
+    st = plain.state[plain.param_groups[0]["params"][2]]
+    assert float(st["step"]) == 6 and st["exp_avg"].shape == (3456, 37)
+    np.testing.assert_allclose(host(st["exp_avg_sq"]), ref.state[params64[2]]["exp_avg_sq"].numpy(),
+                               rtol=1e-5, atol=1e-12)
 
 
 # --------------------------------------------------------------------------------- sum tree
