@@ -54,7 +54,11 @@ __device__ __forceinline__ int64_t image_row(const int64_t* flat_idx, int64_t m,
 // ======================================================================================
 // conv1 forward: y1[m, pos, co] = relu(scale * sum_k w1[co,k] * x[m, patch(pos,k)] + b1[co])
 //   A = w1 (rows co, 64 K-steps held in 64 VGPRs), B = raw bytes of the image in LDS.
-//   K index k = c*64 + ky*8 + kx = 4*s + kq  ->  step s = (c, ky, kx>>2), kq = kx & 3.
+//   K order (any order works as long as A and B agree): MFMA k-slot kq = (ky_lo, kx_hi), step
+//   s = (c, ky_hi, kx_lo) <-> element (c, ky = 2 ky_hi + ky_lo, kx = 4 kx_hi + kx_lo): the four
+//   steps that differ only in kx_lo read the four bytes of ONE aligned dword, so a lane issues
+//   16 ds_read_b32 per position tile instead of 64 ds_read_u8 (round 1: the LDS instruction
+//   stream, not the matrix pipe, paced this kernel).
 // ======================================================================================
 constexpr int C1F_THREADS = 256;  // 4 waves share the 15 tile pairs of one image (5 waves measured slower)
 
@@ -74,7 +78,10 @@ __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
   __syncthreads();
   float wa[64];
 #pragma unroll
-  for (int s = 0; s < 64; ++s) wa[s] = reinterpret_cast<const float*>(img)[j * 256 + 4 * s + kq];
+  for (int s = 0; s < 64; ++s) {
+    const int kc = s >> 4, ky = 2 * ((s >> 2) & 3) + (kq >> 1), kx = 4 * (kq & 1) + (s & 3);
+    wa[s] = reinterpret_cast<const float*>(img)[j * 256 + kc * 64 + ky * 8 + kx];
+  }
   float bias[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias[r] = b1[4 * kq + r];
@@ -91,16 +98,41 @@ __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
     for (int p = part * (C1F_THREADS / 64) + wave; p < 15; p += split * (C1F_THREADS / 64)) {
       const int pos0 = p * 32 + j, pos1 = pos0 + 16;
       const int q0 = min(pos0, P1 - 1), q1 = min(pos1, P1 - 1);
-      const int a0 = (q0 / W1) * (4 * W0) + (q0 % W1) * 4 + kq;
-      const int a1 = (q1 / W1) * (4 * W0) + (q1 % W1) * 4 + kq;
+      const int a0 = (q0 / W1) * (4 * W0) + (q0 % W1) * 4 + (kq >> 1) * W0 + 4 * (kq & 1);
+      const int a1 = (q1 / W1) * (4 * W0) + (q1 % W1) * 4 + (kq >> 1) * W0 + 4 * (kq & 1);
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      // (c, ky_hi) pairs: one dword = 4 K-steps; the dwords of the next pair of groups are
+      // requested before the 16 MFMAs of the current pair (hipcc alone: read -> wait -> MFMA)
+      uint32_t wc[4], wn[4];
 #pragma unroll
-      for (int s = 0; s < 64; ++s) {
-        const int off = (s >> 4) * HW0 + ((s >> 1) & 7) * W0 + (s & 1) * 4;
-        const float x0 = (float)img[a0 + off];
-        const float x1 = (float)img[a1 + off];
-        acc0 = mfma16(wa[s], x0, acc0);
-        acc1 = mfma16(wa[s], x1, acc1);
+      for (int u = 0; u < 2; ++u) {
+        const int off = (u >> 2) * HW0 + 2 * (u & 3) * W0;
+        wc[2 * u] = *reinterpret_cast<const uint32_t*>(img + a0 + off);
+        wc[2 * u + 1] = *reinterpret_cast<const uint32_t*>(img + a1 + off);
+      }
+#pragma unroll
+      for (int gp = 0; gp < 8; ++gp) {
+        if (gp < 7) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int g = 2 * gp + 2 + u;
+            const int off = (g >> 2) * HW0 + 2 * (g & 3) * W0;
+            wn[2 * u] = *reinterpret_cast<const uint32_t*>(img + a0 + off);
+            wn[2 * u + 1] = *reinterpret_cast<const uint32_t*>(img + a1 + off);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int sidx = 4 * (2 * gp + u) + e;
+            acc0 = mfma16(wa[sidx], (float)((wc[2 * u] >> (8 * e)) & 0xffu), acc0);
+            acc1 = mfma16(wa[sidx], (float)((wc[2 * u + 1] >> (8 * e)) & 0xffu), acc1);
+          }
+        __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wc[u] = wn[u];
       }
       float* out = y1 + m * Y1 + 4 * kq;
       if (pos0 < P1) {
@@ -847,11 +879,25 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
 
 // ======================================================================================
 // conv1 backward-weights (+ bias): dW1[co,c,ky,kx] = scale * sum_{m,pos} dy1[m,pos,co] * x[m,c,4oy+ky,4ox+kx]
-// Persistent workgroups, wave w <-> input channel c = w; 4 tiles of 16 K-columns
-// (ky pair x 8 kx) per wave.  A = dy1 [pos][co] in LDS (stride 20), B = image bytes.
-//   K = positions: 30 groups of 16 (475 -> 480, rows 475..479 zero).
+// Persistent workgroups, 8 waves = (input channel c = w & 3) x (position-group parity w >> 2);
+// a wave owns the 64 K-columns (ky, kx) of its channel as 4 tiles of 16.
+//   K = positions: 30 groups of 16 (475 -> 480, rows 475..479 of dl stay zero).
+// LDS operand traffic bounded round 1's version (16 ds_read_u8 + 8 reads of A / patch-origin
+// table per 16 MFMAs, the table reads on the dependent path): the column / K-slot maps are now
+// chosen so that ONE 4-byte read feeds 4 MFMAs on the B side:
+//   * column j of every tile = (ky = j >> 1, kx_hi = j & 1), tile t = kx_lo: the four bytes
+//     x[c, 4oy+ky, 4ox + 4kx_hi + 0..3] are one aligned dword -> B values of tiles 0..3
+//     (v_cvt_f32_ubyte0..3);
+//   * K-slot kq of a group covers positions p0 + {0, 1, 8, 9}, p0 = 16 sg + 2 kq: the two kq
+//     lanes that share a 32-lane LDS pass sit 2 positions apart, which interleaves their bank
+//     sets exactly for the image dwords (ky * 20 + kx_hi + {0, 2} mod 32: 32 distinct banks) and,
+//     with a row stride of 24 floats, for the A reads dl[pos][co] (2 * 24 = 16 mod 32);
+//   * patch origins by increments (p0 += 32 per step: ox += 13, oy += 1, one wrap test) instead
+//     of an LDS table on the dependent path.
+// 8 LDS reads per 16 MFMAs instead of 24; the next group's reads are issued before the current
+// group's MFMAs.
 // ======================================================================================
-constexpr int DS_1 = 20, NSG1 = 30;
+constexpr int DS_1 = 24, NSG1 = 30;
 constexpr int DW1_N = C1 * 256, PART1 = DW1_N + C1;  // 4096 + 16
 
 constexpr int W1_THREADS = 512;  // 8 waves: (input channel c = w & 3) x (position-group parity w >> 2)
@@ -860,17 +906,13 @@ __global__ __launch_bounds__(W1_THREADS) void conv1_wgrad_kernel(
     const uint8_t* __restrict__ obs, const int64_t* __restrict__ flat_idx, int T, int64_t B,
     const float* __restrict__ dy1, float* __restrict__ partial, int64_t M, float scale) {
   __shared__ __attribute__((aligned(16))) uint8_t img[IMG];             // 33,280 B
-  __shared__ __attribute__((aligned(16))) float dl[NSG1 * 16 * DS_1];   // 38,400 B
-  __shared__ int xoff[NSG1 * 16];                                       // patch origin of a position
+  __shared__ __attribute__((aligned(16))) float dl[NSG1 * 16 * DS_1];   // 46,080 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
   const int c = wave & 3, half = wave >> 2;
-  const int xlane = c * HW0 + (j >> 3) * W0 + (j & 7);
+  // byte offset of this lane's column (ky = j >> 1, kx_hi = j & 1) inside a patch of channel c
+  const int xlane = c * HW0 + (j >> 1) * W0 + 4 * (j & 1);
   for (int i = tid; i < NSG1 * 16 * DS_1; i += W1_THREADS) dl[i] = 0.f;  // rows 475..479 stay zero
-  for (int i = tid; i < NSG1 * 16; i += W1_THREADS) {
-    const int pos = min(i, P1 - 1);
-    xoff[i] = (pos / W1) * (4 * W0) + (pos % W1) * 4;
-  }
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -899,6 +941,19 @@ __global__ __launch_bounds__(W1_THREADS) void conv1_wgrad_kernel(
   }
   if ((int64_t)blockIdx.x < M) RLPYT_W1_PREFETCH((int64_t)blockIdx.x)
 
+  // operands of one position group at p0 = 16 sg + 2 kq (image byte offset fo, column ox):
+  // A = dy1[p0 + {0,1,8,9}][co = j], B = the image dwords of those positions' patches
+#define RLPYT_W1_LOAD(a_, w_, p0_, fo_, ox_)                                                   \
+  _Pragma("unroll") for (int sp = 0; sp < 4; ++sp) {                                           \
+    const int d_ = (sp & 1) + 8 * (sp >> 1);                                                   \
+    a_[sp] = dl[((p0_) + d_) * DS_1 + j];                                                      \
+    /* position p0 + d: same image row, or the next one (19 positions per row) */              \
+    const int wrap_ = ((ox_) + d_ >= W1) ? (4 * W0 - 4 * W1) : 0;                              \
+    w_[sp] = *reinterpret_cast<const uint32_t*>(img + xlane + (fo_) + 4 * d_ + wrap_);         \
+  }
+  const int p_first = 16 * half + 2 * kq;
+  const int oy_first = (p_first * 27) >> 9, ox_first = p_first - oy_first * W1;
+
   for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
     __syncthreads();
 #pragma unroll
@@ -913,42 +968,46 @@ __global__ __launch_bounds__(W1_THREADS) void conv1_wgrad_kernel(
     }
     __syncthreads();
     if (m + gridDim.x < M) RLPYT_W1_PREFETCH(m + gridDim.x)
-    // the A value and the patch origin of a position group are fetched one group ahead, so the
-    // image-byte reads of a group do not wait on a dependent LDS round trip
+    // operands one group ahead of their use
+    int p0 = p_first, ox = ox_first, fo = oy_first * (4 * W0) + ox_first * 4;
     float a_nx[4];
-    int xo_nx[4];
-#pragma unroll
-    for (int sp = 0; sp < 4; ++sp) {
-      const int posr = 16 * half + 4 * kq + sp;
-      a_nx[sp] = dl[posr * DS_1 + j];
-      xo_nx[sp] = xoff[posr];
-    }
+    uint32_t w_nx[4];
+    RLPYT_W1_LOAD(a_nx, w_nx, p0, fo, ox)
+#pragma unroll 1
     for (int sg = half; sg < NSG1; sg += 2) {
-      float a_cur[4];
-      int xo_cur[4];
+      float a[4];
+      uint32_t w[4];
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp) {
-        a_cur[sp] = a_nx[sp];
-        xo_cur[sp] = xo_nx[sp];
+        a[sp] = a_nx[sp];
+        w[sp] = w_nx[sp];
       }
-      if (sg + 2 < NSG1) {
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {
-          const int posr = 16 * (sg + 2) + 4 * kq + sp;
-          a_nx[sp] = dl[posr * DS_1 + j];
-          xo_nx[sp] = xoff[posr];
-        }
+      // next group of this wave: p0 += 32 positions = one image row + 13 columns
+      // (past the last group the reads fall into zero rows of dl / stay inside LDS: unused)
+      p0 += 32;
+      ox += 32 - W1;
+      fo += 4 * W0 + 4 * (32 - W1);
+      if (ox >= W1) {
+        ox -= W1;
+        fo += 4 * W0 - 4 * W1;
       }
+      const int p0c = min(p0, NSG1 * 16 - 16 + 6);
+      // next group's reads are ISSUED before this group's MFMAs (left alone hipcc sinks them to the
+      // loop end and waits for them at the top); VALU / SALU may cross the fences, reads / MFMAs not
+      RLPYT_W1_LOAD(a_nx, w_nx, p0c, fo, ox)
+      __builtin_amdgcn_sched_barrier(0x6);
+      if (c == 0) bsum += (a[0] + a[1]) + (a[2] + a[3]);
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp) {
-        const float a = a_cur[sp];
-        if (c == 0) bsum += a;
-        const uint8_t* xp = img + xlane + xo_cur[sp];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma16(a, (float)xp[t * 2 * W0], acc[t]);
+        for (int t = 0; t < 4; ++t)
+          acc[t] = mfma16(a[sp], (float)((w[sp] >> (8 * t)) & 0xffu), acc[t]);
       }
+      __builtin_amdgcn_sched_barrier(0x6);
     }
   }
+#undef RLPYT_W1_LOAD
+#undef RLPYT_W1_PREFETCH
   // the two position-parity halves of the workgroup meet in LDS (dl is free now)
   __syncthreads();
   {
@@ -968,13 +1027,14 @@ __global__ __launch_bounds__(W1_THREADS) void conv1_wgrad_kernel(
       for (int r = 0; r < 4; ++r) acc[t][r] += red[t * 4 + r];
     bsum += red[16];
   }
-  // D[row = co = 4*kq + r][col = j] -> dW1[co][c][ky = 2t + (j>>3)][kx = j&7]
+  // D[row = co = 4*kq + r][col = j = (ky, kx_hi)] of tile t = kx_lo
+  //   -> dW1[co][c][ky = j >> 1][kx = 4 (j & 1) + t]: 4 consecutive kx per lane
   float* out = partial + (int64_t)blockIdx.x * PART1;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      out[(4 * kq + r) * 256 + c * 64 + t * 16 + j] = acc[t][r] * scale;
+  for (int r = 0; r < 4; ++r) {
+    const f32x4 v = {acc[0][r] * scale, acc[1][r] * scale, acc[2][r] * scale, acc[3][r] * scale};
+    *reinterpret_cast<f32x4*>(out + (4 * kq + r) * 256 + c * 64 + (j >> 1) * 8 + 4 * (j & 1)) = v;
+  }
   if (c == 0) {
     float v = bsum;
     v += __shfl_xor(v, 16, kWave);
@@ -1129,19 +1189,26 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
   float wa[64];
   const int npos = (yb - ya) * W1;                                     // <= 152
   if (wave * 16 < npos) {
+    // K order of conv1_fwd_kernel (k-slot = (ky_lo, kx_hi), step = (c, ky_hi, kx_lo)): same
+    // accumulation order, bit-identical results, one dword read per 4 K-steps
 #pragma unroll
-    for (int s = 0; s < 64; ++s) wa[s] = w1s[j * WS1 + 4 * s + kq];
+    for (int s = 0; s < 64; ++s) {
+      const int kc = s >> 4, ky = 2 * ((s >> 2) & 3) + (kq >> 1), kx = 4 * (kq & 1) + (s & 3);
+      wa[s] = w1s[j * WS1 + kc * 64 + ky * 8 + kx];
+    }
     float bias[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[r] = bs[4 * kq + r];
     const int lpos = wave * 16 + j;
     const int q = ya * W1 + min(lpos, npos - 1);
-    const int a0 = (q / W1) * (4 * W0) + (q % W1) * 4 + kq;
+    const int a0 = (q / W1) * (4 * W0) + (q % W1) * 4 + (kq >> 1) * W0 + 4 * (kq & 1);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 64; ++s) {
-      const int off = (s >> 4) * HW0 + ((s >> 1) & 7) * W0 + (s & 1) * 4;
-      acc = mfma16(wa[s], (float)img[a0 + off], acc);
+    for (int g = 0; g < 16; ++g) {
+      const int off = (g >> 2) * HW0 + 2 * (g & 3) * W0;
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(img + a0 + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma16(wa[4 * g + e], (float)((w >> (8 * e)) & 0xffu), acc);
     }
     if (lpos < npos) {
       f32x4 o;
