@@ -3,7 +3,8 @@ import torch
 
 from ...models.pg.atari_ff_model import AtariFfModel
 from ...models.pg.mlp_pg_model import MlpPgModel
-from .categorical import CategoricalPgAgent
+from ...models.pg.atari_lstm_model import AtariLstmModel
+from .categorical import CategoricalPgAgent, RecurrentCategoricalPgAgent
 
 
 class AtariMixin:
@@ -35,6 +36,13 @@ class AtariMixin:
 
 class AtariFfAgent(AtariMixin, CategoricalPgAgent):
     def __init__(self, ModelCls=AtariFfModel, **kwargs):
+        super().__init__(ModelCls=ModelCls, **kwargs)
+
+
+class AtariLstmAgent(AtariMixin, RecurrentCategoricalPgAgent):
+    """rlpyt/agents/pg/atari.py:27-30."""
+
+    def __init__(self, ModelCls=AtariLstmModel, **kwargs):
         super().__init__(ModelCls=ModelCls, **kwargs)
 
 

@@ -3,11 +3,12 @@ import torch
 
 from ...distributions.categorical import Categorical, DistInfo
 from ...utils.collections import namedarraytuple
-from ..base import AgentStep, BaseAgent
+from ..base import AgentStep, BaseAgent, RecurrentAgentMixin
 
 from collections import namedtuple
 
 AgentInfo = namedarraytuple("AgentInfo", ["dist_info", "value"])
+AgentInfoRnn = namedarraytuple("AgentInfoRnn", ["dist_info", "value", "prev_rnn_state"])
 _HeadOut = namedtuple("_HeadOut", ["prob_rows", "value_rows", "action_rows", "action_out",
                                    "uniforms", "t_dev", "lo"])
 
@@ -92,3 +93,52 @@ class CategoricalPgAgent(BaseAgent):
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         _pi, value = self.sampling_model(obs, pa, pr)
         return self._out(value)
+
+
+class RecurrentCategoricalPgAgentBase(BaseAgent):
+    """Recurrent categorical policy-gradient agent (rlpyt/agents/pg/categorical.py:54-106):
+    the model takes and returns an LSTM state; ``step`` records the state the agent ENTERED the
+    step with (``prev_rnn_state``, stored ``[B, N, H]``) so that the algorithm can restart whole
+    columns from row 0 of a batch."""
+
+    def __call__(self, observation, prev_action, prev_reward, init_rnn_state):
+        """``init_rnn_state`` already ``[N, B, H]``; returns (DistInfo, value, next_rnn_state)."""
+        prev_action = self.distribution.to_onehot(prev_action)
+        obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
+        pi, value, next_rnn_state = self.model(obs, pa, pr, init_rnn_state)
+        dist_info, value = self._out((DistInfo(prob=pi), value))
+        return dist_info, value, next_rnn_state      # the state stays on the device
+
+    def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
+        super().initialize(env_spaces, share_memory, global_B=global_B, env_ranks=env_ranks)
+        self.distribution = Categorical(dim=env_spaces.action.n)
+
+    @torch.no_grad()
+    def step(self, observation, prev_action, prev_reward):
+        from ...utils.buffer import buffer_func
+        prev_action = self.distribution.to_onehot(prev_action)
+        obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
+        pi, value, rnn_state = self.sampling_model(obs, pa, pr, self.prev_rnn_state)
+        dist_info = DistInfo(prob=pi)
+        action = self.distribution.sample(dist_info, generator=self.sample_generator)
+        prev = self.prev_rnn_state
+        if prev is None:
+            prev = buffer_func(rnn_state, torch.zeros_like)
+        # [N,B,H] -> [B,N,H] for storage (categorical.py:84-88); a real copy, because the
+        # persistent state buffer is overwritten in place just below
+        prev_rnn_state = buffer_func(prev, lambda x: x.transpose(0, 1).clone(
+            memory_format=torch.contiguous_format))
+        agent_info = AgentInfoRnn(dist_info=dist_info, value=value, prev_rnn_state=prev_rnn_state)
+        self.advance_rnn_state(rnn_state)
+        return self._out(AgentStep(action=action, agent_info=agent_info))
+
+    @torch.no_grad()
+    def value(self, observation, prev_action, prev_reward):
+        prev_action = self.distribution.to_onehot(prev_action)
+        obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
+        _pi, value, _rnn_state = self.sampling_model(obs, pa, pr, self.prev_rnn_state)
+        return self._out(value)
+
+
+class RecurrentCategoricalPgAgent(RecurrentAgentMixin, RecurrentCategoricalPgAgentBase):
+    pass

@@ -3,12 +3,21 @@ returns from the fused scan, loss + gradients from the fused A2C kernel."""
 import torch
 
 from ... import ops
+from ...utils.buffer import buffer_method
 from ...agents.base import AgentInputs
 from ...utils.quick_args import save__init__args
 from .base import OptInfo, PolicyGradientAlgo
 
 
+def mv_tree(x, mv):
+    """``mv`` over every leaf of a (nested) namedarraytuple."""
+    from ...utils.buffer import buffer_func
+    return buffer_func(x, mv)
+
+
 class A2C(PolicyGradientAlgo):
+    supports_recurrent = True
+
     def __init__(self, discount=0.99, learning_rate=0.001, value_loss_coeff=0.5,
                  entropy_loss_coeff=0.01, OptimCls=torch.optim.Adam, optim_kwargs=None,
                  clip_grad_norm=1., initial_optim_state_dict=None, gae_lambda=1,
@@ -39,8 +48,13 @@ class A2C(PolicyGradientAlgo):
                                    prev_action=mv(samples.agent.prev_action),
                                    prev_reward=mv(samples.env.prev_reward))
         if self.agent.recurrent:
-            raise NotImplementedError("recurrent A2C is outside the hot-path scope")
-        dist_info, value = self.agent(*agent_inputs)
+            # whole columns restart from the state recorded at row 0 (a2c.py:80-85)
+            init_rnn_state = buffer_method(mv_tree(samples.agent.agent_info.prev_rnn_state[0], mv),
+                                           "transpose", 0, 1)
+            init_rnn_state = buffer_method(init_rnn_state, "contiguous")
+            dist_info, value, _rnn_state = self.agent(*agent_inputs, init_rnn_state)
+        else:
+            dist_info, value = self.agent(*agent_inputs)
         return_, advantage, valid = self.process_returns(samples)
         return ops.a2c_loss(dist_info.prob, value, mv(samples.agent.action), advantage, return_,
                             valid, self.value_loss_coeff, self.entropy_loss_coeff)

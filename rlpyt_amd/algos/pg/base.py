@@ -22,6 +22,12 @@ class PolicyGradientAlgo(RlAlgorithm):
                                              self.optim_kwargs)
         if self.initial_optim_state_dict is not None:
             self.optimizer.load_state_dict(self.initial_optim_state_dict)
+        if getattr(agent, "recurrent", False) and not getattr(self, "supports_recurrent", False):
+            # fail at initialize(), not in the middle of the first minibatch loop
+            raise NotImplementedError(
+                f"{type(self).__name__}: recurrent policy-gradient agents "
+                "(rlpyt/agents/pg/categorical.py:54-106, rlpyt/algos/pg/ppo.py:84-86) are not "
+                "built on this path yet; use a feed-forward agent (AtariFfAgent).")
         self.agent = agent
         self.n_itr = n_itr
         self.batch_spec = batch_spec

@@ -15,7 +15,7 @@ import torch
 
 from ... import ops
 from ...agents.base import AgentInputs
-from ...utils.buffer import buffer_method
+from ...utils.buffer import buffer_func, buffer_method
 from ...utils.collections import namedarraytuple
 from ...utils.misc import iterate_mb_idxs
 from ...utils.quick_args import save__init__args
@@ -26,6 +26,8 @@ LossInputs = namedarraytuple("LossInputs", ["agent_inputs", "action", "return_",
 
 
 class PPO(PolicyGradientAlgo):
+    supports_recurrent = True
+
     def __init__(self, discount=0.99, learning_rate=0.001, value_loss_coeff=1.,
                  entropy_loss_coeff=0.01, OptimCls=torch.optim.Adam, optim_kwargs=None,
                  clip_grad_norm=1., initial_optim_state_dict=None, gae_lambda=1,
@@ -73,9 +75,24 @@ class PPO(PolicyGradientAlgo):
                 dev, non_blocking=True) if chunks else None
             for k in range(len(chunks)):
                 self.optimizer.zero_grad(set_to_none=True)
-                if recurrent:
-                    raise NotImplementedError("recurrent PPO is outside the hot-path scope")
                 idx_dev = epoch_idx[k * mb_size:(k + 1) * mb_size]
+                if recurrent:
+                    # whole trajectories: only the Batch axis is shuffled; every column restarts
+                    # from the LSTM state recorded at row 0 (ppo.py:84-86,93-99)
+                    col = lambda x: x.index_select(1, idx_dev)      # noqa: E731
+                    mb_inputs = AgentInputs(observation=col(agent_inputs.observation),
+                                            prev_action=col(agent_inputs.prev_action),
+                                            prev_reward=col(agent_inputs.prev_reward))
+                    rnn_state = buffer_func(init_rnn_state, lambda x: mv(x).index_select(0, idx_dev))
+                    loss, scalars = self.loss(mb_inputs, col(action), col(return_), col(advantage),
+                                              None if valid is None else col(valid),
+                                              col(old_prob), init_rnn_state=rnn_state)
+                    loss.backward()
+                    grad_norm = self.clip_and_step()
+                    stats.append(torch.stack([scalars[0], grad_norm.to(scalars.dtype), scalars[3],
+                                              scalars[4]]))
+                    self.update_counter += 1
+                    continue
                 mb_obs = self.agent.gather_observation(agent_inputs.observation, idx_dev)
                 if fused_idx and valid is None:
                     # index mode: the conv kernels and the head+loss kernel read the [T,B] batch

@@ -95,4 +95,5 @@ class ClipAdam(torch.optim.Adam):
             ctypes.c_void_p(self._norm.data_ptr()),
             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "rlpyt_clip_adam_step_f32")
         self._keep = rows          # the launch is asynchronous: keep the gradient tensors alive
+        self._opt_called = True    # (torch's LR schedulers check that a step preceded theirs)
         return self._norm

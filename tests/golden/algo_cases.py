@@ -20,7 +20,32 @@ CASES = [
     ("a2c", "A2C", dict(discount=0.99, learning_rate=1e-3, value_loss_coeff=0.5,
                         entropy_loss_coeff=0.01, clip_grad_norm=1., gae_lambda=0.97,
                         normalize_advantage=False), True),
+    # the same PPO iteration under plain SGD: the update is LINEAR in the gradient, so a tight
+    # tolerance on every later update separates a second-order bug from Adam's sign-like
+    # amplification of round-off (which the 1e-2 band of the cases above has to allow for)
+    ("ppo_sgd", "PPO", dict(discount=0.99, learning_rate=2e-2, value_loss_coeff=1.,
+                            entropy_loss_coeff=0.01, clip_grad_norm=1., gae_lambda=0.98,
+                            minibatches=4, epochs=2, ratio_clip=0.1, linear_lr_schedule=True,
+                            normalize_advantage=False, OptimCls=torch.optim.SGD), True),
+    # recurrent policy-gradient path (rlpyt/algos/pg/ppo.py:84-99, a2c.py:80-85): AtariLstmAgent,
+    # whole columns per minibatch, LSTM restarted from the state recorded at row 0, valid mask
+    ("ppo_lstm", "PPO", dict(discount=0.99, learning_rate=2e-2, value_loss_coeff=1.,
+                             entropy_loss_coeff=0.01, clip_grad_norm=1., gae_lambda=0.95,
+                             minibatches=2, epochs=2, ratio_clip=0.1, linear_lr_schedule=False,
+                             normalize_advantage=True, OptimCls=torch.optim.SGD), False),
+    ("a2c_lstm", "A2C", dict(discount=0.99, learning_rate=2e-2, value_loss_coeff=0.5,
+                             entropy_loss_coeff=0.01, clip_grad_norm=1., gae_lambda=0.97,
+                             normalize_advantage=False, OptimCls=torch.optim.SGD), False),
 ]
+# cases whose optimizer is linear in the gradient: every update is held to fp32 tolerance
+TIGHT_CASES = ("ppo_sgd", "ppo_lstm", "a2c_lstm")
+LSTM_CASES = ("ppo_lstm", "a2c_lstm")
+
+
+def lstm_init_state(lstm=512):
+    """Seeded LSTM state the columns of the recurrent cases start from: (h, c), each [B, 1, H]."""
+    g = torch.Generator().manual_seed(55)
+    return (0.1 * torch.randn(B, 1, lstm, generator=g), 0.1 * torch.randn(B, 1, lstm, generator=g))
 
 
 def batch_inputs():

@@ -777,20 +777,35 @@ def gen_algos():
                        action=IntBox(0, C.A))
     inp = C.batch_inputs()
     out = {}
+    from rlpyt.agents.pg.atari import AtariLstmAgent
+    from rlpyt.agents.pg.base import AgentInfoRnn
+    from rlpyt.models.pg.atari_lstm_model import RnnState
     for name, algo_name, kwargs, mbr in C.CASES:
         torch.manual_seed(C.INIT_SEED)
-        agent = AtariFfAgent()
+        lstm = name in C.LSTM_CASES
+        agent = AtariLstmAgent() if lstm else AtariFfAgent()
         agent.initialize(spaces)
         obs = inp["observation"]
         prev_action, action = inp["all_action"][:-1], inp["all_action"][1:]
         prev_reward, reward = inp["all_reward"][:-1], inp["all_reward"][1:]
         with torch.no_grad():      # the behaviour policy = the initial parameters
-            dist_info, value = agent(obs, prev_action, prev_reward)
-            _, bv = agent(obs[-1], action[-1], reward[-1])
-            bv = (bv + 0.25).unsqueeze(0)
+            if lstm:
+                h0, c0 = C.lstm_init_state()                       # [B, N, H]
+                init = RnnState(h=h0.transpose(0, 1).contiguous(), c=c0.transpose(0, 1).contiguous())
+                dist_info, value, _ = agent(obs, prev_action, prev_reward, init)
+                bv = (value[-1] + 0.25).unsqueeze(0)
+                prev_rnn = RnnState(h=torch.zeros((C.T,) + tuple(h0.shape)),
+                                    c=torch.zeros((C.T,) + tuple(c0.shape)))
+                prev_rnn.h[0], prev_rnn.c[0] = h0, c0              # only row 0 is read by the algos
+                agent_info = AgentInfoRnn(dist_info=dist_info, value=value, prev_rnn_state=prev_rnn)
+            else:
+                dist_info, value = agent(obs, prev_action, prev_reward)
+                _, bv = agent(obs[-1], action[-1], reward[-1])
+                bv = (bv + 0.25).unsqueeze(0)
+                agent_info = AgentInfo(dist_info=dist_info, value=value)
         samples = Samples(
             agent=AgentSamplesBsv(action=action, prev_action=prev_action,
-                                  agent_info=AgentInfo(dist_info=dist_info, value=value),
+                                  agent_info=agent_info,
                                   bootstrap_value=bv),
             env=EnvSamples(observation=obs, reward=reward, prev_reward=prev_reward,
                            done=inp["done"], env_info=()))

@@ -14,6 +14,8 @@ MODEL_CASES = [  # name, reference class path, class path in this repo, kwargs, 
     ("cat_duel", "rlpyt.models.dqn.atari_catdqn_model.AtariCatDqnModel",
      "rlpyt_amd.models.dqn.atari_catdqn_model.AtariCatDqnModel",
      dict(n_atoms=51, dueling=True), False),
+    ("lstm", "rlpyt.models.pg.atari_lstm_model.AtariLstmModel",
+     "rlpyt_amd.models.pg.atari_lstm_model.AtariLstmModel", dict(), True),
     ("r2d1", "rlpyt.models.dqn.atari_r2d1_model.AtariR2d1Model",
      "rlpyt_amd.models.dqn.atari_r2d1_model.AtariR2d1Model", dict(), True),
     ("r2d1_duel", "rlpyt.models.dqn.atari_r2d1_model.AtariR2d1Model",

@@ -41,22 +41,41 @@ def test_iterations_match_reference(case):
                        action=IntBox(0, C.A))
     inp = C.batch_inputs()
     torch.manual_seed(C.INIT_SEED)
-    agent = AtariFfAgent()
+    lstm = name in C.LSTM_CASES
+    if lstm:
+        from rlpyt_amd.agents.pg.atari import AtariLstmAgent
+        from rlpyt_amd.agents.pg.categorical import AgentInfoRnn
+        from rlpyt_amd.models.pg.atari_lstm_model import RnnState
+        agent = AtariLstmAgent()
+    else:
+        agent = AtariFfAgent()
     agent.initialize(spaces)
     agent.to_device(0)
     dev = lambda x: torch.as_tensor(x).cuda()  # noqa: E731
     all_action, all_reward = dev(inp["all_action"]), dev(inp["all_reward"])
+    old = dict(dist_info=DistInfo(prob=dev(g[f"{name}_old_prob"])), value=dev(g[f"{name}_old_value"]))
+    if lstm:
+        h0, c0 = (x.cuda() for x in C.lstm_init_state())            # [B, N, H]
+        prev = RnnState(h=torch.zeros((C.T,) + tuple(h0.shape), device="cuda"),
+                        c=torch.zeros((C.T,) + tuple(c0.shape), device="cuda"))
+        prev.h[0], prev.c[0] = h0, c0
+        agent_info = AgentInfoRnn(prev_rnn_state=prev, **old)
+    else:
+        agent_info = AgentInfo(**old)
     samples = Samples(
         agent=AgentSamplesBsv(
-            action=all_action[1:], prev_action=all_action[:-1],
-            agent_info=AgentInfo(dist_info=DistInfo(prob=dev(g[f"{name}_old_prob"])),
-                                 value=dev(g[f"{name}_old_value"])),
+            action=all_action[1:], prev_action=all_action[:-1], agent_info=agent_info,
             bootstrap_value=dev(g[f"{name}_bootstrap_value"])),
         env=EnvSamples(observation=dev(inp["observation"]), reward=all_reward[1:],
                        prev_reward=all_reward[:-1], done=dev(inp["done"]), env_info=()))
     # the behaviour policy the reference recorded is this agent's own initial policy
     with torch.no_grad():
-        pi0, v0 = agent(samples.env.observation, None, None)
+        if lstm:
+            init = RnnState(h=h0.transpose(0, 1).contiguous(), c=c0.transpose(0, 1).contiguous())
+            pi0, v0, _ = agent(samples.env.observation, samples.agent.prev_action,
+                               samples.env.prev_reward, init)
+        else:
+            pi0, v0 = agent(samples.env.observation, None, None)
     np.testing.assert_allclose(pi0.prob.cpu().numpy(), g[f"{name}_old_prob"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(v0.cpu().numpy(), g[f"{name}_old_value"], rtol=1e-4, atol=2e-5)
     algo = (PPO if algo_name == "PPO" else A2C)(**kwargs)
@@ -74,6 +93,10 @@ def test_iterations_match_reference(case):
             assert got.shape == ref.shape, (f, got.shape, ref.shape)
             if itr == 0:
                 np.testing.assert_allclose(got[0], ref[0], rtol=2e-5, atol=1e-6, err_msg=f)
+            if name in C.TIGHT_CASES:
+                # SGD: linear in the gradient, no sign-like amplification -- EVERY update of both
+                # iterations at fp32 tolerance (conv / GEMM reductions reorder sums: 2e-4)
+                np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5, err_msg=f"{f} itr {itr}")
             np.testing.assert_allclose(got, ref, rtol=1e-2, atol=2e-3, err_msg=f"{f} itr {itr}")
         n_updates += len(np.atleast_1d(info.loss))
         params = list(agent.parameters())
@@ -84,6 +107,9 @@ def test_iterations_match_reference(case):
             if key not in g:
                 continue
             diff = np.abs(p.detach().cpu().numpy() - g[key])
+            if name in C.TIGHT_CASES:
+                np.testing.assert_allclose(p.detach().cpu().numpy(), g[key], rtol=2e-4, atol=2e-6,
+                                           err_msg=n)
             assert diff.max() <= 2.2 * lr * n_updates, (n, diff.max())
             assert (diff > 0.1 * lr).mean() <= 0.05, (n, (diff > 0.1 * lr).mean())
     assert algo.update_counter == n_updates
