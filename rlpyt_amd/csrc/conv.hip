@@ -877,169 +877,258 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
   }
 }
 
-// ======================================================================================
-// conv1 backward-weights (+ bias): dW1[co,c,ky,kx] = scale * sum_{m,pos} dy1[m,pos,co] * x[m,c,4oy+ky,4ox+kx]
-// Persistent workgroups, 8 waves = (input channel c = w & 3) x (position-group parity w >> 2);
-// a wave owns the 64 K-columns (ky, kx) of its channel as 4 tiles of 16.
-//   K = positions: 30 groups of 16 (475 -> 480, rows 475..479 of dl stay zero).
-// LDS operand traffic bounded round 1's version (16 ds_read_u8 + 8 reads of A / patch-origin
-// table per 16 MFMAs, the table reads on the dependent path): the column / K-slot maps are now
-// chosen so that ONE 4-byte read feeds 4 MFMAs on the B side:
-//   * column j of every tile = (ky = j >> 1, kx_hi = j & 1), tile t = kx_lo: the four bytes
-//     x[c, 4oy+ky, 4ox + 4kx_hi + 0..3] are one aligned dword -> B values of tiles 0..3
-//     (v_cvt_f32_ubyte0..3);
-//   * K-slot kq of a group covers positions p0 + {0, 1, 8, 9}, p0 = 16 sg + 2 kq: the two kq
-//     lanes that share a 32-lane LDS pass sit 2 positions apart, which interleaves their bank
-//     sets exactly for the image dwords (ky * 20 + kx_hi + {0, 2} mod 32: 32 distinct banks) and,
-//     with a row stride of 24 floats, for the A reads dl[pos][co] (2 * 24 = 16 mod 32);
-//   * patch origins by increments (p0 += 32 per step: ox += 13, oy += 1, one wrap test) instead
-//     of an LDS table on the dependent path.
-// 8 LDS reads per 16 MFMAs instead of 24; the next group's reads are issued before the current
-// group's MFMAs.
-// ======================================================================================
-constexpr int DS_1 = 24, NSG1 = 30;
 constexpr int DW1_N = C1 * 256, PART1 = DW1_N + C1;  // 4096 + 16
 
-constexpr int W1_THREADS = 512;  // 8 waves: (input channel c = w & 3) x (position-group parity w >> 2)
+// ======================================================================================
+// conv1 backward-weights (+ bias): dW1[co,c,ky,kx] = scale * sum_{m,pos} dy1[m,pos,co] * x[m,c,4oy+ky,4ox+kx]
+// on the bf16 matrix pipe, exact ("bf16x3"):
+//   * one operand is the uint8 image: every byte is exactly representable in bf16 (8 significand
+//     bits);
+//   * the other operand, dy1 (f32), is split ONCE per element into three bf16 pieces
+//     hi + mid + lo == dy1 exactly (3 x 8 = 24 significand bits; truncation, so each remainder is
+//     exact in f32);
+//   * byte x bf16 products are exact in the f32 accumulator, so the result differs from the f32
+//     MFMA kernel of round 1 / early round 2 (0.62 of the f32 MFMA peak, 325 us at M = 8192) only
+//     by the order of the f32 accumulation -- but v_mfma_f32_16x16x32_bf16
+//     contracts K = 32 in ~17 cycles/SIMD where v_mfma_f32_16x16x4_f32 needs 32 cycles for K = 4:
+//     3 bf16 MFMAs replace 8 f32 MFMAs (5x less matrix-pipe time), and no conversion sits on the
+//     operand path (the f32 kernel pays one v_cvt_f32_ubyte per MFMA, and every plain VALU
+//     instruction costs that pipe ~3 ns, scripts/debug/mfma_valu_probe.hip).
+// The MFMA wants 8 CONSECUTIVE K-elements per lane in one 16-byte register group, so both operands
+// are laid out in LDS with K (= output position, ox fastest) contiguous:
+//   xb[c][y][r][24] bf16: image pixel (c, y, x = 4 xx + r) at [c][y][r = x & 3][xx = x >> 2]
+//     (x de-interleaved by the conv stride: the pixels under kernel column kx of 8 consecutive ox
+//     are 8 consecutive xx of phase r = kx & 3, starting at ox0 + (kx >> 2)); pitch 24 (20 + 4
+//     pad) spreads a 16-lane read over all banks; the pad and whatever lies beyond a row are
+//     finite and always meet a zero in dT;
+//   dT[s][co][8 + 608] bf16: piece s of dy1[pos = (oy, ox)][co] at K-index 24 oy + ox behind 8
+//     leading zeros; ox 19..23 and oy = 25 (K 600..607) stay zero -> 19 K-steps of 32.
+// 8 waves = (channel pair cp = w & 1) x (K-step quarter q = w >> 1, steps q, q + 4, ...); a wave
+// owns 8 column tiles (2 channels x (kx_hi, ky_hi)); tile lane n = (ky & 3 = n >> 2, kx & 3 = n & 3).
+// Per step and wave: 3 A reads + 8 B reads (ds_read_b128) feed 24 MFMAs.
+// ======================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(W1_THREADS) void conv1_wgrad_kernel(
+#ifndef RLPYT_X3_PITCH
+#define RLPYT_X3_PITCH 24
+#endif
+constexpr int X3_ROWB = RLPYT_X3_PITCH * 2;        // bytes per (c, y, phase) row
+constexpr int X3_YB = 4 * X3_ROWB;                 // 192 B per image row
+constexpr int X3_CB = H0 * X3_YB;                  // 19,968 B per channel
+constexpr int X3_XB = C0 * X3_CB;                  // 79,872 B
+constexpr int X3_STEPS = 19, X3_NBLK = 4 * X3_STEPS;   // K' = 608 = 76 blocks of 8
+constexpr int X3_DROWB = 616 * 2;                  // bytes per (piece, co) row of dT
+constexpr int X3_DSB = C1 * X3_DROWB;              // 19,712 B per piece
+constexpr int X3_DT = 3 * X3_DSB;                  // 59,136 B
+constexpr int X3_THREADS = 512;
+
+__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+#ifdef RLPYT_X3_TIMING
+#define X3_T0() long long t_prev_ = clock64(), t_acc_[6] = {0, 0, 0, 0, 0, 0};
+#define X3_T(k)                                  \
+  {                                              \
+    const long long t_now_ = clock64();          \
+    t_acc_[k] += t_now_ - t_prev_;               \
+    t_prev_ = t_now_;                            \
+  }
+#define X3_TOUT()                                                                  \
+  if (lane == 0) {                                                                 \
+    float* dbg_ = partial + (int64_t)(256 + blockIdx.x) * PART1 + wave * 8;        \
+    for (int k = 0; k < 6; ++k) dbg_[k] = (float)t_acc_[k];                        \
+  }
+#else
+#define X3_T0()
+#define X3_T(k)
+#define X3_TOUT()
+#endif
+
+__global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
     const uint8_t* __restrict__ obs, const int64_t* __restrict__ flat_idx, int T, int64_t B,
     const float* __restrict__ dy1, float* __restrict__ partial, int64_t M, float scale) {
-  __shared__ __attribute__((aligned(16))) uint8_t img[IMG];             // 33,280 B
-  __shared__ __attribute__((aligned(16))) float dl[NSG1 * 16 * DS_1];   // 46,080 B
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 15, kq = lane >> 4;
-  const int c = wave & 3, half = wave >> 2;
-  // byte offset of this lane's column (ky = j >> 1, kx_hi = j & 1) inside a patch of channel c
-  const int xlane = c * HW0 + (j >> 1) * W0 + 4 * (j & 1);
-  for (int i = tid; i < NSG1 * 16 * DS_1; i += W1_THREADS) dl[i] = 0.f;  // rows 475..479 stay zero
-  f32x4 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  // dT directly behind xb: reads that run past the last image row land on finite values
+  __shared__ __attribute__((aligned(16))) uint8_t lds[X3_XB + X3_DT];
+  __shared__ int btab[X3_NBLK];
+  uint8_t* const xb = lds;
+  uint8_t* const dT = lds + X3_XB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cp = wave & 1, q = wave >> 1;
+  const int n = lane & 15, kb = lane >> 4;
+  for (int i = tid; i < (X3_XB + X3_DT) / 16; i += X3_THREADS)
+    reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
+  // K-block b = (oy = b / 3, ox0 = 8 (b % 3)) -> byte offset of its first pixel row / xx
+  for (int b = tid; b < X3_NBLK; b += X3_THREADS) btab[b] = (b / 3) * 4 * X3_YB + (b % 3) * 16;
 
-  // software pipeline over images: the next image (33 KB) and its dy1 (30 KB) are fetched into
-  // registers while the current one is being contracted, so the staging phase between the two
-  // barriers only moves registers to LDS and the global-load latency hides behind the MFMAs
-  constexpr int NPI = (IMG / 16 + W1_THREADS - 1) / W1_THREADS;   // 5 uint4 per thread
-  constexpr int NPD = (Y1 / 4 + W1_THREADS - 1) / W1_THREADS;     // 4 float4 per thread
+  // ---- staging maps, fixed per thread ----
+  constexpr int NPI = (IMG / 16 + X3_THREADS - 1) / X3_THREADS;   // 5 uint4 per thread
+  constexpr int NPD = (Y1 / 4 + X3_THREADS - 1) / X3_THREADS;     // 4 float4 per thread
+  int xdst[NPI], ddst[NPD];
+#pragma unroll
+  for (int k = 0; k < NPI; ++k) {      // uint4 i = 16 bytes (c, y, x = 16 xq ..): xx = 4 xq .. + 3 of each phase
+    const int i = min(tid + k * X3_THREADS, IMG / 16 - 1);
+    const int c = i / (HW0 / 16), rem = i % (HW0 / 16), y = rem / (W0 / 16), xq = rem % (W0 / 16);
+    xdst[k] = c * X3_CB + y * X3_YB + xq * 8;
+  }
+#pragma unroll
+  for (int k = 0; k < NPD; ++k) {      // float4 i = dy1[pos = i >> 2][co = 4 (i & 3) .. + 3]
+    const int i = min(tid + k * X3_THREADS, Y1 / 4 - 1);
+    const int pos = i >> 2;
+    ddst[k] = (4 * (i & 3)) * X3_DROWB + 16 + (24 * (pos / W1) + pos % W1) * 2;
+  }
   uint4 pimg[NPI];
   f32x4 pdy[NPD];
-#define RLPYT_W1_PREFETCH(mi)                                                                  \
+  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};   // bias gradient: thread tid always stages channels 4 (tid & 3) ..
+#define RLPYT_X3_PREFETCH(mi)                                                                  \
   {                                                                                            \
     const uint4* __restrict__ src_ =                                                           \
         reinterpret_cast<const uint4*>(obs + image_row(flat_idx, (mi), T, B) * IMG);           \
     const f32x4* __restrict__ dsrc_ = reinterpret_cast<const f32x4*>(dy1 + (mi) * Y1);         \
     _Pragma("unroll") for (int k = 0; k < NPI; ++k) {                                          \
-      const int i = tid + k * W1_THREADS;                                                      \
-      pimg[k] = i < IMG / 16 ? src_[i] : uint4{0u, 0u, 0u, 0u};                                \
+      const int i = tid + k * X3_THREADS;                                                      \
+      if (i < IMG / 16) pimg[k] = src_[i];                                                     \
     }                                                                                          \
     _Pragma("unroll") for (int k = 0; k < NPD; ++k) {                                          \
-      const int i = tid + k * W1_THREADS;                                                      \
+      const int i = tid + k * X3_THREADS;                                                      \
       pdy[k] = i < Y1 / 4 ? dsrc_[i] : f32x4{0.f, 0.f, 0.f, 0.f};                              \
     }                                                                                          \
   }
-  if ((int64_t)blockIdx.x < M) RLPYT_W1_PREFETCH((int64_t)blockIdx.x)
+  if ((int64_t)blockIdx.x < M) RLPYT_X3_PREFETCH((int64_t)blockIdx.x)
 
-  // operands of one position group at p0 = 16 sg + 2 kq (image byte offset fo, column ox):
-  // A = dy1[p0 + {0,1,8,9}][co = j], B = the image dwords of those positions' patches
-#define RLPYT_W1_LOAD(a_, w_, p0_, fo_, ox_)                                                   \
-  _Pragma("unroll") for (int sp = 0; sp < 4; ++sp) {                                           \
-    const int d_ = (sp & 1) + 8 * (sp >> 1);                                                   \
-    a_[sp] = dl[((p0_) + d_) * DS_1 + j];                                                      \
-    /* position p0 + d: same image row, or the next one (19 positions per row) */              \
-    const int wrap_ = ((ox_) + d_ >= W1) ? (4 * W0 - 4 * W1) : 0;                              \
-    w_[sp] = *reinterpret_cast<const uint32_t*>(img + xlane + (fo_) + 4 * d_ + wrap_);         \
+  f32x4 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // operand addresses of this lane
+  const uint8_t* const a_lane = dT + n * X3_DROWB + 16 + kb * 16;                  // + s * X3_DSB + 64 step
+  const uint8_t* const b_lane = xb + 2 * cp * X3_CB + ((n >> 2) * 4 + (n & 3)) * X3_ROWB;
+  const int nst = (X3_STEPS - q + 3) >> 2;         // steps q, q + 4, ...: 5, 5, 5, 4
+
+  // one K-step: tile t = 4 cc + 2 kx_hi + ky_hi.  Tiles with kx_hi = 1 see pixel xx = ox + 1 under
+  // position ox; a misaligned (2-byte) LDS read costs ~6x an aligned one (measured), so their B
+  // operand is the SAME aligned block xx0 .. xx0 + 7 and the A operand is shifted instead:
+  // A1[k] = dT[K0 - 1 + k], built from the aligned block and the dword before it with 4
+  // v_alignbyte per piece (dT rows start with 8 zero elements, so K0 - 1 of the first block and
+  // ox = -1 of every row -- the zero pad of the row before -- read as 0).
+#define RLPYT_X3_LOAD(a_, p_, b_, st_)                                                         \
+  {                                                                                            \
+    const uint8_t* ap_ = a_lane + 64 * (st_);                                                  \
+    const uint8_t* bp_ = b_lane + btab[4 * (st_) + kb];                                        \
+    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                         \
+      a_[s_] = *reinterpret_cast<const uint4*>(ap_ + s_ * X3_DSB);                             \
+      p_[s_] = *reinterpret_cast<const uint32_t*>(ap_ + s_ * X3_DSB - 4);                      \
+    }                                                                                          \
+    _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_)                                           \
+      b_[t_] = *reinterpret_cast<const uint4*>(bp_ + (t_ >> 2) * X3_CB + (t_ & 1) * 4 * X3_YB); \
   }
-  const int p_first = 16 * half + 2 * kq;
-  const int oy_first = (p_first * 27) >> 9, ox_first = p_first - oy_first * W1;
+  // b_[t]: t = 4 cc + 2 kx_hi + ky_hi share the block of (cc, ky_hi): only 4 distinct reads
+#define RLPYT_X3_MMA(a_, p_, b_)                                                               \
+  __builtin_amdgcn_sched_barrier(0x6);                                                         \
+  _Pragma("unroll") for (int s_ = 2; s_ >= 0; --s_) { /* lo, mid, hi */                        \
+    const uint4 a1_ = {__builtin_amdgcn_alignbyte(a_[s_].x, p_[s_], 2),                        \
+                       __builtin_amdgcn_alignbyte(a_[s_].y, a_[s_].x, 2),                      \
+                       __builtin_amdgcn_alignbyte(a_[s_].z, a_[s_].y, 2),                      \
+                       __builtin_amdgcn_alignbyte(a_[s_].w, a_[s_].z, 2)};                     \
+    _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_)                                           \
+      acc[t_] = mfma_bf16((t_ & 2) ? a1_ : a_[s_], b_[t_], acc[t_]);                           \
+  }                                                                                            \
+  __builtin_amdgcn_sched_barrier(0x6);
 
+  X3_T0()
   for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
     __syncthreads();
+    X3_T(0)
+    // ---- registers -> LDS: image bytes -> bf16 phases; dy1 -> 3 bf16 pieces, transposed ----
 #pragma unroll
     for (int k = 0; k < NPI; ++k) {
-      const int i = tid + k * W1_THREADS;
-      if (i < IMG / 16) reinterpret_cast<uint4*>(img)[i] = pimg[k];
+      if (tid + k * X3_THREADS < IMG / 16) {
+        const uint32_t d[4] = {pimg[k].x, pimg[k].y, pimg[k].z, pimg[k].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // phase r: byte r of each dword = x 16 xq + 4 j + r
+          float f[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) f[jj] = (float)((d[jj] >> (8 * r)) & 0xffu);
+          uint2 o;
+          o.x = __builtin_amdgcn_perm(__float_as_uint(f[1]), __float_as_uint(f[0]), 0x07060302u);
+          o.y = __builtin_amdgcn_perm(__float_as_uint(f[3]), __float_as_uint(f[2]), 0x07060302u);
+          *reinterpret_cast<uint2*>(xb + xdst[k] + r * X3_ROWB) = o;
+        }
+      }
     }
+    X3_T(1)
 #pragma unroll
     for (int k = 0; k < NPD; ++k) {
-      const int i = tid + k * W1_THREADS;
-      if (i < Y1 / 4) *reinterpret_cast<f32x4*>(dl + (i >> 2) * DS_1 + 4 * (i & 3)) = pdy[k];
+      if (tid + k * X3_THREADS < Y1 / 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = pdy[k][e];
+          const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+          const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+          uint8_t* dst = dT + ddst[k] + e * X3_DROWB;
+          *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(__float_as_uint(x) >> 16);
+          *reinterpret_cast<uint16_t*>(dst + X3_DSB) = (uint16_t)(__float_as_uint(r1) >> 16);
+          *reinterpret_cast<uint16_t*>(dst + 2 * X3_DSB) = (uint16_t)(__float_as_uint(r2) >> 16);
+        }
+      }
+      bacc += pdy[k];
     }
+    X3_T(2)
     __syncthreads();
-    if (m + gridDim.x < M) RLPYT_W1_PREFETCH(m + gridDim.x)
-    // operands one group ahead of their use
-    int p0 = p_first, ox = ox_first, fo = oy_first * (4 * W0) + ox_first * 4;
-    float a_nx[4];
-    uint32_t w_nx[4];
-    RLPYT_W1_LOAD(a_nx, w_nx, p0, fo, ox)
+    X3_T(3)
+    if (m + gridDim.x < M) RLPYT_X3_PREFETCH(m + gridDim.x)
+    X3_T(4)
+    uint4 a0[3], a1[3], b0[8], b1[8];
+    uint32_t p0[3], p1[3];
+    RLPYT_X3_LOAD(a0, p0, b0, q)
 #pragma unroll 1
-    for (int sg = half; sg < NSG1; sg += 2) {
-      float a[4];
-      uint32_t w[4];
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {
-        a[sp] = a_nx[sp];
-        w[sp] = w_nx[sp];
-      }
-      // next group of this wave: p0 += 32 positions = one image row + 13 columns
-      // (past the last group the reads fall into zero rows of dl / stay inside LDS: unused)
-      p0 += 32;
-      ox += 32 - W1;
-      fo += 4 * W0 + 4 * (32 - W1);
-      if (ox >= W1) {
-        ox -= W1;
-        fo += 4 * W0 - 4 * W1;
-      }
-      const int p0c = min(p0, NSG1 * 16 - 16 + 6);
-      // next group's reads are ISSUED before this group's MFMAs (left alone hipcc sinks them to the
-      // loop end and waits for them at the top); VALU / SALU may cross the fences, reads / MFMAs not
-      RLPYT_W1_LOAD(a_nx, w_nx, p0c, fo, ox)
-      __builtin_amdgcn_sched_barrier(0x6);
-      if (c == 0) bsum += (a[0] + a[1]) + (a[2] + a[3]);
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          acc[t] = mfma16(a[sp], (float)((w[sp] >> (8 * t)) & 0xffu), acc[t]);
-      }
-      __builtin_amdgcn_sched_barrier(0x6);
+    for (int i = 0; i + 1 < nst; i += 2) {
+      RLPYT_X3_LOAD(a1, p1, b1, q + 4 * (i + 1))
+      RLPYT_X3_MMA(a0, p0, b0)
+      if (i + 2 < nst) RLPYT_X3_LOAD(a0, p0, b0, q + 4 * (i + 2))
+      RLPYT_X3_MMA(a1, p1, b1)
     }
+    if (nst & 1) { RLPYT_X3_MMA(a0, p0, b0) }
+    X3_T(5)
   }
-#undef RLPYT_W1_LOAD
-#undef RLPYT_W1_PREFETCH
-  // the two position-parity halves of the workgroup meet in LDS (dl is free now)
+  X3_TOUT()
+#undef RLPYT_X3_MMA
+#undef RLPYT_X3_LOAD
+#undef RLPYT_X3_PREFETCH
+  // the four K quarters of the workgroup meet in LDS (xb is free now)
   __syncthreads();
+  float* out = partial + (int64_t)blockIdx.x * PART1;
   {
-    float* red = dl + (c * 64 + lane) * 17;   // 17 floats per lane
-    if (half == 1) {
+    float* red = reinterpret_cast<float*>(lds);                 // [3][2][8][64][4] floats = 48 KB
+    float* bred = red + 3 * 2 * 8 * 64 * 4;                     // [512][4] per-thread bias sums
+    *reinterpret_cast<f32x4*>(bred + 4 * tid) = bacc;
+    if (q > 0) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[t * 4 + r] = acc[t][r];
-      red[16] = bsum;
+      for (int t = 0; t < 8; ++t)
+        *reinterpret_cast<f32x4*>(red + ((((q - 1) * 2 + cp) * 8 + t) * 64 + lane) * 4) = acc[t];
     }
     __syncthreads();
-    if (half == 1) return;
+    if (tid < C1) {                            // channel tid = 4 g + e: threads with (tid & 3) == g
+      const int g = tid >> 2, e = tid & 3;
+      float v = 0.f;
+      for (int i = 0; i < X3_THREADS / 4; ++i) v += bred[4 * (4 * i + g) + e];
+      out[DW1_N + tid] = v;
+    }
+    if (q > 0) return;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int qq = 0; qq < 3; ++qq)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][r] += red[t * 4 + r];
-    bsum += red[16];
+      for (int t = 0; t < 8; ++t)
+        acc[t] += *reinterpret_cast<const f32x4*>(red + (((qq * 2 + cp) * 8 + t) * 64 + lane) * 4);
   }
-  // D[row = co = 4*kq + r][col = j = (ky, kx_hi)] of tile t = kx_lo
-  //   -> dW1[co][c][ky = j >> 1][kx = 4 (j & 1) + t]: 4 consecutive kx per lane
-  float* out = partial + (int64_t)blockIdx.x * PART1;
+  // D[row = co = 4 kb + r][col n] of tile t -> dW1[co][c = 2 cp + (t >> 2)][ky = 4 (t & 1) + (n >> 2)]
+  //                                                       [kx = 4 ((t >> 1) & 1) + (n & 3)]
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const f32x4 v = {acc[0][r] * scale, acc[1][r] * scale, acc[2][r] * scale, acc[3][r] * scale};
-    *reinterpret_cast<f32x4*>(out + (4 * kq + r) * 256 + c * 64 + (j >> 1) * 8 + 4 * (j & 1)) = v;
-  }
-  if (c == 0) {
-    float v = bsum;
-    v += __shfl_xor(v, 16, kWave);
-    v += __shfl_xor(v, 32, kWave);
-    if (kq == 0) out[DW1_N + j] = v;
+  for (int t = 0; t < 8; ++t) {
+    const int c = 2 * cp + (t >> 2), ky = 4 * (t & 1) + (n >> 2), kx = 4 * ((t >> 1) & 1) + (n & 3);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(4 * kb + r) * 256 + c * 64 + ky * 8 + kx] = acc[t][r] * scale;
   }
 }
 
@@ -1370,8 +1459,8 @@ extern "C" int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* fl
   RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(dy1), RLPYT_ESHAPE,
                "rlpyt_atari_conv1_wgrad_f32: obs / dy1 must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const int g = (int)std::min<int64_t>(M, kWgradGrid);
-  RL_LAUNCH(conv1_wgrad_kernel, dim3(g), dim3(W1_THREADS), 0, s, obs, flat_idx, T, B, dy1,
+  const int g = std::min(grid_for(M, 1), kPartialRows);   // 136 KB of LDS: one workgroup per CU
+  RL_LAUNCH(conv1_wgrad_kernel, dim3(g), dim3(X3_THREADS), 0, s, obs, flat_idx, T, B, dy1,
                      workspace, M, scale);
   RL_LAUNCH_CHECK();
   RL_LAUNCH(reduce_partials_kernel, dim3((PART1 + 63) / 64), dim3(256), 0, s, workspace,

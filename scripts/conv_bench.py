@@ -60,7 +60,10 @@ def main():
             ops._FL_C1),
     }
     res = {"M": M}
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
     for name, (fn, fl) in kern.items():
+        if only and name not in only[0]:
+            continue
         us = timeit(fn)
         tf = M * fl / us / 1e6
         res[name] = {"us": round(us, 1), "TFLOPs": round(tf, 1), "frac_f32_peak": round(tf / F32_PEAK_TF, 3)}
