@@ -52,15 +52,60 @@ __device__ __forceinline__ int64_t image_row(const int64_t* flat_idx, int64_t m,
 }
 
 // ======================================================================================
-// conv1 forward: y1[m, pos, co] = relu(scale * sum_k w1[co,k] * x[m, patch(pos,k)] + b1[co])
-//   A = w1 (rows co, 64 K-steps held in 64 VGPRs), B = raw bytes of the image in LDS.
-//   K order (any order works as long as A and B agree): MFMA k-slot kq = (ky_lo, kx_hi), step
-//   s = (c, ky_hi, kx_lo) <-> element (c, ky = 2 ky_hi + ky_lo, kx = 4 kx_hi + kx_lo): the four
-//   steps that differ only in kx_lo read the four bytes of ONE aligned dword, so a lane issues
-//   16 ds_read_b32 per position tile instead of 64 ds_read_u8 (round 1: the LDS instruction
-//   stream, not the matrix pipe, paced this kernel).
+// bf16 matrix pipe, exact ("bf16x3"), for the two conv1 kernels.  One operand of conv1 is the uint8
+// image: every byte is exactly representable in bf16 (8 significand bits).  The other operand
+// (w1 forward, dy1 backward; f32) is split ONCE per element into three bf16 pieces with
+// hi + mid + lo == x exactly (3 x 8 = 24 significand bits; truncation, so every remainder is exact
+// in f32).  byte x piece products are exact in the f32 accumulator, so the result differs from an
+// f32-MFMA contraction (rounds 1 / early 2: 0.55-0.62 of the f32 MFMA peak) only by the order of
+// the f32 accumulation -- but v_mfma_f32_16x16x32_bf16 contracts K = 32 in ~17 cycles/SIMD where
+// v_mfma_f32_16x16x4_f32 needs 32 cycles for K = 4: 3 bf16 MFMAs replace 8 f32 MFMAs (5x less
+// matrix-pipe time), and no byte -> float conversion sits on the operand path (the f32 kernels
+// paid one v_cvt_f32_ubyte per MFMA, and every plain VALU instruction costs the f32 MFMA pipe
+// ~3 ns, scripts/debug/mfma_valu_probe.hip).
+// MFMA 16x16x32 bf16 operand map: lane l supplies A[i = l & 15][k = 8 (l >> 4) .. + 7] and
+// B[k = 8 (l >> 4) .. + 7][j = l & 15] (8 bf16 = one 16-byte register group each) and receives
+// D[row = 4 (l >> 4) + r][col = l & 15].
 // ======================================================================================
-constexpr int C1F_THREADS = 256;  // 4 waves share the 15 tile pairs of one image (5 waves measured slower)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the high halves (= truncated bf16) of two f32, earlier element in the low half
+__device__ __forceinline__ uint32_t pack_hi16(float lo_elem, float hi_elem) {
+  return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+// x - bf16_trunc(x): exact
+__device__ __forceinline__ float bf16_rem(float x) {
+  return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+}
+// 16 image bytes -> 16 bf16 (two 16-byte groups, same order)
+__device__ __forceinline__ void bytes_to_bf16(const uint4& v, uint4& lo, uint4& hi) {
+  const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+  uint32_t o[8];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    o[2 * jj] = pack_hi16((float)(d[jj] & 0xffu), (float)((d[jj] >> 8) & 0xffu));
+    o[2 * jj + 1] = pack_hi16((float)((d[jj] >> 16) & 0xffu), (float)(d[jj] >> 24));
+  }
+  lo = uint4{o[0], o[1], o[2], o[3]};
+  hi = uint4{o[4], o[5], o[6], o[7]};
+}
+struct __attribute__((aligned(8))) U4A8 { uint32_t x, y, z, w; };   // 16 B at 8-byte alignment
+
+// ======================================================================================
+// conv1 forward: y1[m, pos, co] = relu(scale * sum_k w1[co,k] * x[m, patch(pos,k)] + b1[co])
+//   A = w1 as 3 bf16 pieces (rows co; 8 K-steps x 3 pieces x 4 VGPRs, held for the whole
+//   kernel), B = the image as bf16 [c][y][x] in LDS (66,560 B -> two workgroups per CU: one
+//   converts / stages while the other contracts).
+//   K order: step st = (c, ky_hi), lane group kb = ky_lo (ky = 4 ky_hi + kb), element i = kx: the
+//   8 K-elements of a lane are 8 consecutive pixels of one image row -- one ds_read2_b64.
+//   30 tiles of 16 positions, two at a time; 24 MFMAs per tile.
+// ======================================================================================
+constexpr int C1F_THREADS = 256;
+constexpr int F3_ROWB = W0 * 2, F3_CB = H0 * F3_ROWB, F3_XB = C0 * F3_CB;   // 160, 16,640, 66,560 B
 
 __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
     const uint8_t* __restrict__ obs, const int64_t* __restrict__ flat_idx, int T, int64_t B,
@@ -68,73 +113,101 @@ __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
     int64_t M, float scale, int split) {
   // split = workgroups per image (1, 2 or 4): small sampling batches spread the 15 tile
   // pairs of an image over several CUs to cut latency; each part stages the whole image.
-  __shared__ __attribute__((aligned(16))) uint8_t img[IMG];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 15, kq = lane >> 4;
-  // the 16 KB of weights pass through the (not yet used) image buffer: coalesced 16-byte global
-  // loads instead of a 64-way gather per lane -- the gather dominated small sampling launches
+  __shared__ __attribute__((aligned(16))) uint8_t xb[F3_XB];
+  __shared__ int ptab[480];               // position -> byte offset of its patch origin
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kb = lane >> 4;
+  for (int i = tid; i < 480; i += C1F_THREADS) {
+    const int pos = min(i, P1 - 1);
+    ptab[i] = (pos / W1) * 4 * F3_ROWB + (pos % W1) * 8;
+  }
+  // the 16 KB of weights pass through the (not yet used) image buffer: coalesced 16-byte loads
   for (int i = tid; i < C1 * 256 / 4; i += C1F_THREADS)
-    reinterpret_cast<uint4*>(img)[i] = reinterpret_cast<const uint4*>(w1)[i];
+    reinterpret_cast<uint4*>(xb)[i] = reinterpret_cast<const uint4*>(w1)[i];
   __syncthreads();
-  float wa[64];
+  uint4 wa[8][3];
 #pragma unroll
-  for (int s = 0; s < 64; ++s) {
-    const int kc = s >> 4, ky = 2 * ((s >> 2) & 3) + (kq >> 1), kx = 4 * (kq & 1) + (s & 3);
-    wa[s] = reinterpret_cast<const float*>(img)[j * 256 + kc * 64 + ky * 8 + kx];
+  for (int st = 0; st < 8; ++st) {
+    const float* wr = reinterpret_cast<const float*>(xb) + n * 256 + (st >> 1) * 64 +
+                      (4 * (st & 1) + kb) * 8;
+    float x[8], r1[8], r2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x[i] = wr[i];
+      r1[i] = bf16_rem(x[i]);
+      r2[i] = bf16_rem(r1[i]);
+    }
+    wa[st][0] = uint4{pack_hi16(x[0], x[1]), pack_hi16(x[2], x[3]), pack_hi16(x[4], x[5]),
+                      pack_hi16(x[6], x[7])};
+    wa[st][1] = uint4{pack_hi16(r1[0], r1[1]), pack_hi16(r1[2], r1[3]), pack_hi16(r1[4], r1[5]),
+                      pack_hi16(r1[6], r1[7])};
+    wa[st][2] = uint4{pack_hi16(r2[0], r2[1]), pack_hi16(r2[2], r2[3]), pack_hi16(r2[4], r2[5]),
+                      pack_hi16(r2[6], r2[7])};
   }
   float bias[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bias[r] = b1[4 * kq + r];
+  for (int r = 0; r < 4; ++r) bias[r] = b1[4 * kb + r];
+
+  // software pipeline over images: the next image is fetched into registers while this one is
+  // contracted; the staging phase converts registers -> bf16 in LDS
+  constexpr int NPI = (IMG / 16 + C1F_THREADS - 1) / C1F_THREADS;   // 9 uint4 per thread
+  uint4 pimg[NPI];
+#define RLPYT_F3_PREFETCH(mm_)                                                                 \
+  {                                                                                            \
+    const uint4* __restrict__ src_ = reinterpret_cast<const uint4*>(                           \
+        obs + image_row(flat_idx, (mm_) / split, T, B) * IMG);                                 \
+    _Pragma("unroll") for (int k = 0; k < NPI; ++k) {                                          \
+      const int i = tid + k * C1F_THREADS;                                                     \
+      if (i < IMG / 16) pimg[k] = src_[i];                                                     \
+    }                                                                                          \
+  }
+  if ((int64_t)blockIdx.x < M * split) RLPYT_F3_PREFETCH((int64_t)blockIdx.x)
+  const uint8_t* const xlane = xb + kb * F3_ROWB;
 
   for (int64_t mm = blockIdx.x; mm < M * split; mm += gridDim.x) {
     const int64_t m = mm / split;
     const int part = (int)(mm - m * split);
-    const uint4* __restrict__ src =
-        reinterpret_cast<const uint4*>(obs + image_row(flat_idx, m, T, B) * IMG);
-    __syncthreads();  // the previous image's readers are done
-    for (int i = tid; i < IMG / 16; i += C1F_THREADS) reinterpret_cast<uint4*>(img)[i] = src[i];
-    __syncthreads();
-    // 30 tiles of 16 positions, two at a time
-    for (int p = part * (C1F_THREADS / 64) + wave; p < 15; p += split * (C1F_THREADS / 64)) {
-      const int pos0 = p * 32 + j, pos1 = pos0 + 16;
-      const int q0 = min(pos0, P1 - 1), q1 = min(pos1, P1 - 1);
-      const int a0 = (q0 / W1) * (4 * W0) + (q0 % W1) * 4 + (kq >> 1) * W0 + 4 * (kq & 1);
-      const int a1 = (q1 / W1) * (4 * W0) + (q1 % W1) * 4 + (kq >> 1) * W0 + 4 * (kq & 1);
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      // (c, ky_hi) pairs: one dword = 4 K-steps; the dwords of the next pair of groups are
-      // requested before the 16 MFMAs of the current pair (hipcc alone: read -> wait -> MFMA)
-      uint32_t wc[4], wn[4];
+    __syncthreads();  // the previous image's (or the weights') readers are done
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int off = (u >> 2) * HW0 + 2 * (u & 3) * W0;
-        wc[2 * u] = *reinterpret_cast<const uint32_t*>(img + a0 + off);
-        wc[2 * u + 1] = *reinterpret_cast<const uint32_t*>(img + a1 + off);
+    for (int k = 0; k < NPI; ++k) {
+      const int i = tid + k * C1F_THREADS;
+      if (i < IMG / 16) {
+        uint4 lo, hi;
+        bytes_to_bf16(pimg[k], lo, hi);
+        reinterpret_cast<uint4*>(xb)[2 * i] = lo;
+        reinterpret_cast<uint4*>(xb)[2 * i + 1] = hi;
       }
+    }
+    __syncthreads();
+    if (mm + gridDim.x < M * split) RLPYT_F3_PREFETCH(mm + gridDim.x)
+    for (int p = part * (C1F_THREADS / 64) + wave; p < 15; p += split * (C1F_THREADS / 64)) {
+      const int pos0 = p * 32 + n, pos1 = pos0 + 16;
+      const uint8_t* bp0 = xlane + ptab[pos0];
+      const uint8_t* bp1 = xlane + ptab[pos1];
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      // the operands of the next step are requested before the 6 MFMAs of the current one
+      U4A8 c0 = *reinterpret_cast<const U4A8*>(bp0), c1 = *reinterpret_cast<const U4A8*>(bp1);
 #pragma unroll
-      for (int gp = 0; gp < 8; ++gp) {
-        if (gp < 7) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int g = 2 * gp + 2 + u;
-            const int off = (g >> 2) * HW0 + 2 * (g & 3) * W0;
-            wn[2 * u] = *reinterpret_cast<const uint32_t*>(img + a0 + off);
-            wn[2 * u + 1] = *reinterpret_cast<const uint32_t*>(img + a1 + off);
-          }
+      for (int st = 0; st < 8; ++st) {
+        U4A8 n0 = c0, n1 = c1;
+        if (st < 7) {
+          const int off = ((st + 1) >> 1) * F3_CB + ((st + 1) & 1) * 4 * F3_ROWB;
+          n0 = *reinterpret_cast<const U4A8*>(bp0 + off);
+          n1 = *reinterpret_cast<const U4A8*>(bp1 + off);
         }
         __builtin_amdgcn_sched_barrier(0x6);
+        const uint4 v0 = {c0.x, c0.y, c0.z, c0.w}, v1 = {c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int sidx = 4 * (2 * gp + u) + e;
-            acc0 = mfma16(wa[sidx], (float)((wc[2 * u] >> (8 * e)) & 0xffu), acc0);
-            acc1 = mfma16(wa[sidx], (float)((wc[2 * u + 1] >> (8 * e)) & 0xffu), acc1);
-          }
+        for (int s = 2; s >= 0; --s) {   // lo, mid, hi
+          acc0 = mfma_bf16(wa[st][s], v0, acc0);
+          acc1 = mfma_bf16(wa[st][s], v1, acc1);
+        }
         __builtin_amdgcn_sched_barrier(0x6);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wc[u] = wn[u];
+        c0 = n0;
+        c1 = n1;
       }
-      float* out = y1 + m * Y1 + 4 * kq;
+      float* out = y1 + m * Y1 + 4 * kb;
       if (pos0 < P1) {
         f32x4 o;
 #pragma unroll
@@ -149,6 +222,7 @@ __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
       }
     }
   }
+#undef RLPYT_F3_PREFETCH
 }
 
 // Stage one image's y1 [475,16] into the zero-bordered plane pad[(iy+1)*PW + ix+1][PS].
@@ -907,8 +981,6 @@ constexpr int DW1_N = C1 * 256, PART1 = DW1_N + C1;  // 4096 + 16
 // owns 8 column tiles (2 channels x (kx_hi, ky_hi)); tile lane n = (ky & 3 = n >> 2, kx & 3 = n & 3).
 // Per step and wave: 3 A reads + 8 B reads (ds_read_b128) feed 24 MFMAs.
 // ======================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 #ifndef RLPYT_X3_PITCH
 #define RLPYT_X3_PITCH 24
 #endif
@@ -921,11 +993,6 @@ constexpr int X3_DROWB = 616 * 2;                  // bytes per (piece, co) row 
 constexpr int X3_DSB = C1 * X3_DROWB;              // 19,712 B per piece
 constexpr int X3_DT = 3 * X3_DSB;                  // 59,136 B
 constexpr int X3_THREADS = 512;
-
-__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 #ifdef RLPYT_X3_TIMING
 #define X3_T0() long long t_prev_ = clock64(), t_acc_[6] = {0, 0, 0, 0, 0, 0};
@@ -1174,7 +1241,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // of ONE CU are 9.4 us by themselves while three quarters of the chip idle; split four ways the
 // MFMA work per CU is ~3 us.  Both weight sets are staged in LDS with row strides chosen so the
 // per-lane operand reads (stride 256 floats in the plain layout: 16..32-way bank conflicts) are
-// at most 2-way.  Accumulation orders equal conv1_fwd_kernel / conv2_fwd_kernel: bit-identical.
+// at most 2-way.  conv2 accumulates in the order of conv2_fwd_kernel; conv1 is an f32-MFMA chain
+// (conv1_fwd_kernel: bf16x3, same exact products, other order).
 // ======================================================================================
 constexpr int SC_THREADS = 1024;
 constexpr int SC_PARTS = 4;               // workgroups per environment (3 conv2 output rows each)
@@ -1278,8 +1346,9 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
   float wa[64];
   const int npos = (yb - ya) * W1;                                     // <= 152
   if (wave * 16 < npos) {
-    // K order of conv1_fwd_kernel (k-slot = (ky_lo, kx_hi), step = (c, ky_hi, kx_lo)): same
-    // accumulation order, bit-identical results, one dword read per 4 K-steps
+    // f32 MFMA here (one tile per wave, latency-bound: splitting the weights into bf16 pieces per
+    // launch would cost more than the 64 MFMAs); k-slot = (ky_lo, kx_hi), step = (c, ky_hi,
+    // kx_lo): one dword read per 4 K-steps.  Equal to conv1_fwd_kernel up to f32 accumulation order.
 #pragma unroll
     for (int s = 0; s < 64; ++s) {
       const int kc = s >> 4, ky = 2 * ((s >> 2) & 3) + (kq >> 1), kx = 4 * (kq & 1) + (s & 3);
@@ -1368,7 +1437,7 @@ extern "C" int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat
                "rlpyt_atari_conv1_fwd_f32: obs / y1 / w1 must be 16-byte aligned");
   int cus = grid_for(1 << 30, 1);
   const int split = (M * 2 <= cus) ? 4 : (M <= cus ? 2 : 1);  // M <= 128: 4, M <= 256: 2
-  RL_LAUNCH(conv1_fwd_kernel, dim3(grid_for(M * split, 4)), dim3(C1F_THREADS), 0,
+  RL_LAUNCH(conv1_fwd_kernel, dim3(grid_for(M * split, 2)), dim3(C1F_THREADS), 0,   // 2 x 67 KB of LDS per CU
                      (hipStream_t)stream, obs, flat_idx, T, B, w1, b1, y1, M, scale, split);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
