@@ -40,13 +40,20 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense f32 peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+# bf16-split kernels (DESIGN.md "fp32 contractions on the bf16 pipe"): issued bf16 MFMA flops per
+# algorithmic fp32 flop (3 exact pieces of one operand; 6 products of two 3-piece operands)
+BF16_SPLIT = {"conv1_fwd": 3, "conv1_wgrad": 3, "conv2_fwd": 6}
 KERNEL_NAMES = {
-    "conv1_fwd": "conv1_fwd_kernel (gather + u8->f32 + conv 4->16 k8 s4 + bias + ReLU, fp32 MFMA)",
-    "conv2_fwd": "conv2_fwd_kernel (conv 16->32 k4 s2 p1 + bias + ReLU, fp32 MFMA)",
+    "conv1_fwd": "conv1_fwd_kernel (gather + u8->bf16 + conv 4->16 k8 s4 + bias + ReLU; exact "
+                 "bf16x3 split of w1, f32 accumulate)",
+    "conv2_fwd": "conv2_fwd_x6_kernel (conv 16->32 k4 s2 p1 + bias + ReLU; bf16x6 split, f32 "
+                 "accumulate, dropped terms <= 2^-26)",
     "conv2_bwd": "conv2_bwd_kernel (dgrad + ReLU masks + weight/bias grad in one pass, fp32 MFMA)",
     "conv2_dgrad": "conv2_dgrad_kernel (transposed conv + ReLU masks, fp32 MFMA)",
     "conv2_wgrad": "conv2_wgrad_kernel (+ bias grad, fp32 MFMA)",
-    "conv1_wgrad": "conv1_wgrad_kernel (gather + u8->f32 + weight/bias grad, fp32 MFMA)",
+    "conv1_wgrad": "conv1_wgrad_kernel (gather + u8->bf16 + weight/bias grad; exact bf16x3 split "
+                   "of dy1, f32 accumulate)",
     "obs_to_nhwc": "obs_to_nhwc_f32_kernel (minibatch gather + u8->f32 + CHW->HWC)",
     "gather_tb": "gather_wide_kernel (minibatch observation gather)",
     "gae": "scan_exact_kernel<GAE>", "ppo_loss": "pg_loss_kernel<PPO>",
@@ -306,7 +313,25 @@ def main():
         if ksum:
             # dominant own kernel of the timed region = largest total HIP-event time
             name, g = max(ksum.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])
-            if "TFLOPs" in g:   # dense contraction: priced against the fp32 MFMA peak
+            if name in BF16_SPLIT:
+                # fp32 contraction issued as BF16_SPLIT[name] bf16 MFMAs per algorithmic MAC: priced
+                # against BOTH ceilings, "bound" = the one it sits closer to
+                issued = g["TFLOPs"] * BF16_SPLIT[name]
+                f_hbm, f_mfma = g["GBps"] / HBM_PEAK_GBPS, issued / BF16_MFMA_PEAK_TFLOPS
+                hbm = f_hbm >= f_mfma
+                out["roofline"] = {"kernel": KERNEL_NAMES.get(name, name),
+                                   "bound": "hbm" if hbm else "mfma",
+                                   "achieved": g["GBps"] if hbm else issued,
+                                   "peak": HBM_PEAK_GBPS if hbm else BF16_MFMA_PEAK_TFLOPS,
+                                   "unit": "GB/s" if hbm else "TFLOP/s",
+                                   "frac": max(f_hbm, f_mfma), "traffic": None,
+                                   "frac_hbm": f_hbm, "frac_bf16_mfma_issued": f_mfma,
+                                   "alg_fp32_TFLOPs": g["TFLOPs"],
+                                   "alg_over_f32_mfma_peak": g["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
+                                   "avg_us": g["avg_us"], "launches": g["launches"],
+                                   "alg_flops_per_launch": g["alg_flops_per_launch"],
+                                   "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
+            elif "TFLOPs" in g:   # dense f32 contraction: priced against the fp32 MFMA peak
                 out["roofline"] = {"kernel": KERNEL_NAMES.get(name, name), "bound": "mfma",
                                    "achieved": g["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": g["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
@@ -344,10 +369,10 @@ def main():
 
 
 def pmc_traffic(name, g):
-    """HBM bytes per launch of kernel ``name`` from profiles/r1_conv_pmc_counters.json
+    """HBM bytes per launch of kernel ``name`` from profiles/r2_conv_pmc_counters.json
     ((2 * FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md), rescaled by algorithmic
     bytes when the bench launch is not the profiled M = 8192 one."""
-    path = os.path.join(ROOT, "profiles", "r1_conv_pmc_counters.json")
+    path = os.path.join(ROOT, "profiles", "r2_conv_pmc_counters.json")
     try:
         with open(path) as f:
             k = json.load(f)["kernels"][name]
@@ -355,7 +380,7 @@ def pmc_traffic(name, g):
         return None
     scale = g["alg_bytes_per_launch"] / k["alg_bytes"] if k.get("alg_bytes") else 1.
     return {"bytes_per_launch": k["hbm_bytes_corrected"] * scale,
-            "source": "profiles/r1_conv_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / "
+            "source": "profiles/r2_conv_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / "
                       "WRITE_SIZE passes over scripts/conv_bench.py, M=8192)"}
 
 

@@ -35,6 +35,50 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Debug build (-DRLPYT_TIMING): per-wave cycle totals of up to 8 phases of a persistent kernel's
+// image loop land in a device array that rlpyt_debug_timing_read() copies out
+// (scripts/debug/phase_timing.py); compiled out of the product.
+#ifdef RLPYT_TIMING
+__device__ float g_timing[512 * 16 * 8];
+#define RL_T0() long long t_prev_ = clock64(), t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RL_T(k)                                  \
+  {                                              \
+    const long long t_now_ = clock64();          \
+    t_acc_[k] += t_now_ - t_prev_;               \
+    t_prev_ = t_now_;                            \
+  }
+#define RL_TOUT()                                                                   \
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) {                                \
+    float* dbg_ = g_timing + ((int64_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8;   \
+    for (int k = 0; k < 8; ++k) dbg_[k] = (float)t_acc_[k];                         \
+  }
+#else
+#define RL_T0()
+#define RL_T(k)
+#define RL_TOUT()
+#endif
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Global loads whose issue point the compiler cannot move: left alone it sinks every prologue
+// load to its first use and emits load, wait, store, load, wait, store (one HBM latency per
+// load instead of one for all); `volatile` is worse (a full wait after each load).  The data
+// are only valid after loads_wait().
+__device__ __forceinline__ u32x4 load16_issue(const void* p) {
+  u32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ float load4_issue(const void* p) {
+  float r;
+  asm volatile("global_load_dword %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ void loads_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Wait until at most N vector-memory operations issued by this wave are outstanding (they retire
+// in issue order), tying the listed registers to the wait so no use can be scheduled above it.
+#define RLPYT_VMCNT_WAIT4(N, r0, r1, r2, r3) \
+  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)::"memory")
+
 // ---- geometry (AtariFfModel defaults) ------------------------------------------------
 constexpr int C0 = 4, H0 = 104, W0 = 80, HW0 = H0 * W0, IMG = C0 * HW0;  // 33280 B
 constexpr int C1 = 16, H1 = 25, W1 = 19, P1 = H1 * W1;                   // 475 positions
@@ -207,19 +251,19 @@ __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
         c0 = n0;
         c1 = n1;
       }
+      // UNCONDITIONAL stores: a lane past position 474 computed position 474 again (ptab clamps)
+      // and repeats its store.  Under a branch hipcc cannot count the stores that follow the
+      // next image's prefetch loads and waits for vmcnt(0) -- the stores' HBM round trip -- at
+      // the next staging.
       float* out = y1 + m * Y1 + 4 * kb;
-      if (pos0 < P1) {
-        f32x4 o;
+      f32x4 o0, o1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc0[r] * scale + bias[r], 0.f);
-        *reinterpret_cast<f32x4*>(out + pos0 * C1) = o;
+      for (int r = 0; r < 4; ++r) {
+        o0[r] = fmaxf(acc0[r] * scale + bias[r], 0.f);
+        o1[r] = fmaxf(acc1[r] * scale + bias[r], 0.f);
       }
-      if (pos1 < P1) {
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc1[r] * scale + bias[r], 0.f);
-        *reinterpret_cast<f32x4*>(out + pos1 * C1) = o;
-      }
+      *reinterpret_cast<f32x4*>(out + min(pos0, P1 - 1) * C1) = o0;
+      *reinterpret_cast<f32x4*>(out + min(pos1, P1 - 1) * C1) = o1;
     }
   }
 #undef RLPYT_F3_PREFETCH
@@ -313,6 +357,237 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(
       }
     }
   }
+}
+
+// ======================================================================================
+// conv2 forward, large batches, on the bf16 matrix pipe ("bf16x6").  Both operands are f32 here, so
+// BOTH are split into three bf16 pieces (round-to-nearest: x == x0 + x1 + x2 exactly, |x1| <=
+// 2^-9 |x|, |x2| <= 2^-18 |x|) and the six products of order <= 2 are accumulated in f32, smallest
+// first: a2b0, a0b2, a1b1, a1b0, a0b1, a0b0.  Each is exact in the accumulator; the three dropped
+// products (a1b2, a2b1, a2b2) are together <= 2^-26 |ab| -- a quarter of ONE f32 rounding -- so
+// the result is an f32 contraction to within its own accumulation-order noise, at 6 x 32 cycles
+// per 32x32x16 block instead of the 16 x 32 ... of the f32 MFMA (2.7x less matrix-pipe time).
+//   y2[m, co, pos] = relu(sum_{ky,kx,c} w2[co,c,ky,kx] * y1pad[2oy+ky, 2ox+kx, c] + b2[co])
+// v_mfma_f32_32x32x16_bf16: rows = all 32 co, columns = 32 positions, K-step = one tap x 16
+// channels (lane l: row / column l & 31, channel half h = l >> 5: 8 bf16 = 16 bytes).
+// 8 waves = (position tile pt = w & 3) x (tap half kh = w >> 2: taps 8 kh .. 8 kh + 7); the w2
+// pieces of a wave's 8 taps stay in 96 VGPRs; the two tap halves meet in LDS per image.
+// y1 pieces in LDS: plane[s][h][Y = iy + 1][p = X & 1][xi = X >> 1] x 16 B (X = ix + 1; zero
+// border): the 32 positions of a tile read consecutive 16-byte entries (ox -> xi) of one row,
+// conflict-free for ds_read_b128.
+// ======================================================================================
+constexpr int C2X_THREADS = 512;
+constexpr int C2X_ROWB = 2 * 10 * 16;              // bytes per padded row Y (2 parities x 10 entries)
+constexpr int C2X_HB = PH * C2X_ROWB;              // 8,320 B per channel half
+constexpr int C2X_SB = 2 * C2X_HB;                 // 16,640 B per piece
+constexpr int C2X_PL = 3 * C2X_SB;                 // 49,920 B
+constexpr int C2X_WS = 257;                        // staged w2 row stride (floats): conflict-free gather
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma32_bf16(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// two f32 -> packed bf16 (round to nearest even), earlier element in the low half
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo_elem, float hi_elem) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {lo_elem, hi_elem};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// (x0, x1) -> three packed bf16 pieces, hi + mid + lo == x exactly (finite, no overflow)
+__device__ __forceinline__ void split3_rn(float x0, float x1, uint32_t& hi, uint32_t& mid,
+                                          uint32_t& lo) {
+  hi = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk_bf16(r0, r1);
+  lo = cvt_pk_bf16(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
+}
+
+__global__ __launch_bounds__(C2X_THREADS) void conv2_fwd_x6_kernel(
+    const float* __restrict__ y1, const float* __restrict__ w2, const float* __restrict__ b2,
+    float* __restrict__ y2, int64_t M) {
+  // y1 pieces double-buffered (2 x 49,920 B): the next image is split and written into the other
+  // buffer in the MIDDLE of this image's MFMA stream; the two tap halves exchange HALF of their
+  // accumulators through a double-buffered 16 KB block -- one barrier per image.  The finished
+  // 16 x 32 block of a wave goes back through its (now private) exchange block so that every lane
+  // stores 16 bytes: the memory pipe takes ~16 cycles per wave-level instruction whatever its
+  // width, and 64 four-byte store instructions per image were a third of the image time.
+  // (ds_add_f32 into a shared [co][pos] image instead of the exchange: 3.5x slower, LDS float
+  // atomics serialize.)
+  __shared__ __attribute__((aligned(16))) uint8_t pl[2 * C2X_PL];
+  __shared__ __attribute__((aligned(16))) float red[2 * 8 * 8 * 64];   // 2 x 16 KB
+  __shared__ float bs[C2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pt = wave & 3, kh = wave >> 2;
+  const int j = lane & 31, h = lane >> 5;
+  // ---- w2 -> LDS (row stride 257 floats) -> this wave's 8 taps x 3 pieces ----
+  static_assert(C2 * C2X_WS * 4 <= C2X_PL, "w2 staging fits in the plane buffer");
+  {
+    f32x4 wv[C2 * 256 / 4 / C2X_THREADS];          // all loads in flight before the first LDS write
+#pragma unroll
+    for (int k = 0; k < C2 * 256 / 4 / C2X_THREADS; ++k)
+      wv[k] = reinterpret_cast<const f32x4*>(w2)[tid + k * C2X_THREADS];
+#pragma unroll
+    for (int k = 0; k < C2 * 256 / 4 / C2X_THREADS; ++k) {
+      const int i = 4 * (tid + k * C2X_THREADS);
+      float* d = reinterpret_cast<float*>(pl) + (i >> 8) * C2X_WS + (i & 255);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = wv[k][e];
+    }
+  }
+  if (tid < C2) bs[tid] = b2[tid];
+  __syncthreads();
+  uint4 wa[8][3];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float* wr = reinterpret_cast<const float*>(pl) + j * C2X_WS + (8 * h) * 16 + 8 * kh + t;
+    uint32_t p[3][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      split3_rn(wr[(2 * i) * 16], wr[(2 * i + 1) * 16], p[0][i], p[1][i], p[2][i]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) wa[t][s] = uint4{p[s][0], p[s][1], p[s][2], p[s][3]};
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C2X_PL / 16; i += C2X_THREADS)
+    reinterpret_cast<uint4*>(pl)[i] = uint4{0u, 0u, 0u, 0u};           // borders stay zero
+
+  // staging map, fixed per thread: float4 i = y1[pos = i >> 2][c = 4 (i & 3) ..]
+  constexpr int NPD = (Y1 / 4 + C2X_THREADS - 1) / C2X_THREADS;        // 4 float4 per thread
+  int ddst[NPD];
+#pragma unroll
+  for (int k = 0; k < NPD; ++k) {
+    const int i = min(tid + k * C2X_THREADS, Y1 / 4 - 1);
+    const int pos = i >> 2, q = i & 3, Y = pos / W1 + 1, X = pos % W1 + 1;
+    ddst[k] = (q >> 1) * C2X_HB + Y * C2X_ROWB + ((X & 1) * 10 + (X >> 1)) * 16 + (q & 1) * 8;
+  }
+  // The next-but-one image travels through registers.  Its loads are issued with inline asm and
+  // waited for by hand: hipcc merges the loop-entry state (no stores behind the loads) with the
+  // back-edge state (this image's stores behind them) into "wait for vmcnt(0)", which makes
+  // every staging wait for the HBM round trip of the stores issued just before it (measured:
+  // up to 3000 cycles per image).  Every wave issues exactly NPD loads (clamped index) and 2
+  // stores per image, and vector-memory operations retire in issue order.
+  u32x4 pdy[NPD];
+  static_assert(NPD == 4, "RLPYT_VMCNT_WAIT4 lists 4 registers");
+#define RLPYT_C2X_PREFETCH(mi)                                                                 \
+  {                                                                                            \
+    const u32x4* __restrict__ src_ = reinterpret_cast<const u32x4*>(y1 + (mi) * Y1);           \
+    _Pragma("unroll") for (int k = 0; k < NPD; ++k)                                            \
+      pdy[k] = load16_issue(src_ + min(tid + k * C2X_THREADS, Y1 / 4 - 1));                    \
+  }
+  // registers -> three bf16 pieces in plane buffer b_
+#define RLPYT_C2X_STAGE(b_)                                                                    \
+  _Pragma("unroll") for (int k = 0; k < NPD; ++k) {                                            \
+    if (tid + k * C2X_THREADS < Y1 / 4) {                                                      \
+      uint32_t p_[3][2];                                                                       \
+      split3_rn(__uint_as_float(pdy[k][0]), __uint_as_float(pdy[k][1]), p_[0][0], p_[1][0],    \
+                p_[2][0]);                                                                     \
+      split3_rn(__uint_as_float(pdy[k][2]), __uint_as_float(pdy[k][3]), p_[0][1], p_[1][1],    \
+                p_[2][1]);                                                                     \
+      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
+        *reinterpret_cast<uint2*>(pl + (b_) * C2X_PL + s_ * C2X_SB + ddst[k]) =                \
+            uint2{p_[s_][0], p_[s_][1]};                                                       \
+    }                                                                                          \
+  }
+  // one tap: the next tap's operands are requested before this tap's 6 MFMAs
+#define RLPYT_C2X_BREAD(dst_, t_)                                                              \
+  {                                                                                            \
+    const int ky_ = 2 * kh + ((t_) >> 2), kx_ = (t_) & 3;                                      \
+    const uint8_t* bp_ = b_cur + ky_ * C2X_ROWB + ((kx_ & 1) * 10 + (kx_ >> 1)) * 16;          \
+    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                           \
+      dst_[s_] = *reinterpret_cast<const uint4*>(bp_ + s_ * C2X_SB);                           \
+  }
+#define RLPYT_C2X_TAPS(t0_, t1_)                                                               \
+  _Pragma("unroll") for (int t = (t0_); t < (t1_); ++t) {                                      \
+    if (t < 7) RLPYT_C2X_BREAD(bn, t + 1)                                                      \
+    __builtin_amdgcn_sched_barrier(0x6);                                                       \
+    acc = mfma32_bf16(wa[t][2], bc[0], acc);                                                   \
+    acc = mfma32_bf16(wa[t][0], bc[2], acc);                                                   \
+    acc = mfma32_bf16(wa[t][1], bc[1], acc);                                                   \
+    acc = mfma32_bf16(wa[t][1], bc[0], acc);                                                   \
+    acc = mfma32_bf16(wa[t][0], bc[1], acc);                                                   \
+    acc = mfma32_bf16(wa[t][0], bc[0], acc);                                                   \
+    __builtin_amdgcn_sched_barrier(0x6);                                                       \
+    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) bc[s_] = bn[s_];                          \
+  }
+  // B address of this lane: position 32 pt + j (clamped), channel half h; tap (ky, kx) adds
+  // ky * ROWB + ((kx & 1) * 10 + (kx >> 1)) * 16
+  const int posc = min(32 * pt + j, P2 - 1);
+  const int b_off = h * C2X_HB + (2 * (posc / W2)) * C2X_ROWB + (posc % W2) * 16;
+  // accumulator exchange: this wave finishes rows r = 8 kh .. 8 kh + 7 of its tile and hands the
+  // other 8 to the wave of the other tap half; block layout [r][h][j] = 16 rows of 32 positions
+  float* const red_out = red + ((1 - kh) * 4 + pt) * 8 * 64 + lane;
+  float* const red_in = red + (kh * 4 + pt) * 8 * 64;
+  if ((int64_t)blockIdx.x < M) {
+    RLPYT_C2X_PREFETCH((int64_t)blockIdx.x)
+    __syncthreads();          // zeroed planes
+    RLPYT_VMCNT_WAIT4(0, pdy[0], pdy[1], pdy[2], pdy[3]);
+    RLPYT_C2X_STAGE(0)
+    if ((int64_t)blockIdx.x + gridDim.x < M) RLPYT_C2X_PREFETCH((int64_t)blockIdx.x + gridDim.x)
+  }
+  __syncthreads();
+  int cur = 0;
+  RL_T0()
+  for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
+    const uint8_t* const b_cur = pl + cur * C2X_PL + b_off;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint4 bc[3], bn[3];
+    // The two waves of a SIMD (same pt, kh = 0 / 1) stage at opposite ends of the tap stream, so
+    // one wave's split / LDS-write work runs under the other's MFMAs.  The registers hold image
+    // m + 1 since the middle of the previous iteration; behind those loads this wave has issued
+    // exactly the previous image's 2 stores (none before the first image).
+    const bool more = m + gridDim.x < M;
+#define RLPYT_C2X_NEXT()                                                                       \
+  if (more) {                                                                                  \
+    if (m == (int64_t)blockIdx.x) RLPYT_VMCNT_WAIT4(0, pdy[0], pdy[1], pdy[2], pdy[3]);        \
+    else RLPYT_VMCNT_WAIT4(2, pdy[0], pdy[1], pdy[2], pdy[3]);                                 \
+    RLPYT_C2X_STAGE(cur ^ 1)                                                                   \
+    if (m + 2 * (int64_t)gridDim.x < M) RLPYT_C2X_PREFETCH(m + 2 * (int64_t)gridDim.x)         \
+  }
+    if (kh == 1) { RLPYT_C2X_NEXT() }
+    RL_T(0)
+    RLPYT_C2X_BREAD(bc, 0)
+    RLPYT_C2X_TAPS(0, 8)
+    RL_T(1)
+    if (kh == 0) { RLPYT_C2X_NEXT() }
+    RL_T(2)
+#undef RLPYT_C2X_NEXT
+    float* ro = red_out + cur * (8 * 8 * 64);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ro[r * 64] = acc[8 * (1 - kh) + r];
+    __syncthreads();          // also: plane buffer cur ^ 1 complete, buffer cur free
+    RL_T(3)
+    {
+      float* blk = red_in + cur * (8 * 8 * 64);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int rr = 8 * kh + r;
+        blk[r * 64 + lane] = fmaxf(acc[rr] + blk[r * 64 + lane] + bs[(rr & 3) + 8 * (rr >> 2) + 4 * h], 0.f);
+      }
+      // 128 chunks of 4 positions: chunk c8 = (row = 2 r + h, position chunk c8 & 7)
+      // UNCONDITIONAL stores (a chunk past position 107 repeats the row's last valid chunk): the
+      // next image's registers were requested before these stores, and with a store under a
+      // branch hipcc cannot count how many memory operations follow those loads -- it waits for
+      // vmcnt(0), i.e. for the HBM round trip of the stores, before the next staging
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        int c8 = lane + 64 * k;
+        if (32 * pt + 4 * (c8 & 7) >= P2) c8 = (c8 & ~7) + (P2 - 96) / 4 - 1;
+        const int row = c8 >> 3, rr = 8 * kh + (row >> 1);
+        const int co = (rr & 3) + 8 * (rr >> 2) + 4 * (row & 1), p0 = 32 * pt + 4 * (c8 & 7);
+        *reinterpret_cast<f32x4*>(y2 + m * F2 + co * P2 + p0) =
+            *reinterpret_cast<const f32x4*>(blk + 4 * c8);
+      }
+    }
+    RL_T(4)
+  }
+  RL_TOUT()
+#undef RLPYT_C2X_TAPS
+#undef RLPYT_C2X_BREAD
+#undef RLPYT_C2X_STAGE
+#undef RLPYT_C2X_PREFETCH
 }
 
 // ======================================================================================
@@ -994,25 +1269,6 @@ constexpr int X3_DSB = C1 * X3_DROWB;              // 19,712 B per piece
 constexpr int X3_DT = 3 * X3_DSB;                  // 59,136 B
 constexpr int X3_THREADS = 512;
 
-#ifdef RLPYT_X3_TIMING
-#define X3_T0() long long t_prev_ = clock64(), t_acc_[6] = {0, 0, 0, 0, 0, 0};
-#define X3_T(k)                                  \
-  {                                              \
-    const long long t_now_ = clock64();          \
-    t_acc_[k] += t_now_ - t_prev_;               \
-    t_prev_ = t_now_;                            \
-  }
-#define X3_TOUT()                                                                  \
-  if (lane == 0) {                                                                 \
-    float* dbg_ = partial + (int64_t)(256 + blockIdx.x) * PART1 + wave * 8;        \
-    for (int k = 0; k < 6; ++k) dbg_[k] = (float)t_acc_[k];                        \
-  }
-#else
-#define X3_T0()
-#define X3_T(k)
-#define X3_TOUT()
-#endif
-
 __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
     const uint8_t* __restrict__ obs, const int64_t* __restrict__ flat_idx, int T, int64_t B,
     const float* __restrict__ dy1, float* __restrict__ partial, int64_t M, float scale) {
@@ -1103,10 +1359,10 @@ __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
   }                                                                                            \
   __builtin_amdgcn_sched_barrier(0x6);
 
-  X3_T0()
+  RL_T0()
   for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
     __syncthreads();
-    X3_T(0)
+    RL_T(0)
     // ---- registers -> LDS: image bytes -> bf16 phases; dy1 -> 3 bf16 pieces, transposed ----
 #pragma unroll
     for (int k = 0; k < NPI; ++k) {
@@ -1124,7 +1380,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
         }
       }
     }
-    X3_T(1)
+    RL_T(1)
 #pragma unroll
     for (int k = 0; k < NPD; ++k) {
       if (tid + k * X3_THREADS < Y1 / 4) {
@@ -1141,11 +1397,11 @@ __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
       }
       bacc += pdy[k];
     }
-    X3_T(2)
+    RL_T(2)
     __syncthreads();
-    X3_T(3)
+    RL_T(3)
     if (m + gridDim.x < M) RLPYT_X3_PREFETCH(m + gridDim.x)
-    X3_T(4)
+    RL_T(4)
     uint4 a0[3], a1[3], b0[8], b1[8];
     uint32_t p0[3], p1[3];
     RLPYT_X3_LOAD(a0, p0, b0, q)
@@ -1157,9 +1413,9 @@ __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
       RLPYT_X3_MMA(a1, p1, b1)
     }
     if (nst & 1) { RLPYT_X3_MMA(a0, p0, b0) }
-    X3_T(5)
+    RL_T(5)
   }
-  X3_TOUT()
+  RL_TOUT()
 #undef RLPYT_X3_MMA
 #undef RLPYT_X3_LOAD
 #undef RLPYT_X3_PREFETCH
@@ -1246,23 +1502,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // ======================================================================================
 constexpr int SC_THREADS = 1024;
 constexpr int SC_PARTS = 4;               // workgroups per environment (3 conv2 output rows each)
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// Global loads whose issue point the compiler cannot move: left alone it sinks every prologue
-// load to its first use and emits load, wait, store, load, wait, store (one HBM latency per
-// load instead of one for all); `volatile` is worse (a full wait after each load).  The data
-// are only valid after loads_wait().
-__device__ __forceinline__ u32x4 load16_issue(const void* p) {
-  u32x4 r;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
-  return r;
-}
-__device__ __forceinline__ float load4_issue(const void* p) {
-  float r;
-  asm volatile("global_load_dword %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
-  return r;
-}
-__device__ __forceinline__ void loads_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 constexpr int WS1 = 260;                  // staged conv1 weights: [16][260] floats
 constexpr int WS2 = 260, WS2_KQ = 65;     // staged conv2 weights: [32][4 x 65] floats
 
@@ -1453,9 +1693,9 @@ extern "C" int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float
   if (M <= grid_for(1 << 30, 1))   // small (sampling) batch: two workgroups per image
     RL_LAUNCH((conv2_fwd_kernel<2>), dim3(grid_for(2 * M, 3)), dim3(256), 0,
                        (hipStream_t)stream, y1, w2, b2, y2, M);
-  else
-    RL_LAUNCH((conv2_fwd_kernel<4>), dim3(grid_for(M, 3)), dim3(256), 0, (hipStream_t)stream,
-                       y1, w2, b2, y2, M);
+  else   // 116 KB of LDS, 8 waves: one workgroup per CU
+    RL_LAUNCH(conv2_fwd_x6_kernel, dim3(grid_for(M, 1)), dim3(C2X_THREADS), 0, (hipStream_t)stream,
+              y1, w2, b2, y2, M);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
@@ -1496,6 +1736,12 @@ extern "C" int rlpyt_atari_conv2_dgrad_f32(const float* g2, const float* y2, con
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
+
+#ifdef RLPYT_TIMING
+extern "C" int rlpyt_debug_timing_read(float* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timing), (size_t)n * sizeof(float));
+}
+#endif
 
 extern "C" int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void) {
   return (int64_t)kPartialRows * (PART1 > PART2 ? PART1 : PART2) * (int64_t)sizeof(float);

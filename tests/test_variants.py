@@ -461,7 +461,7 @@ def _conv_fwd_small():
         Cv.test_conv_forward_kernels(_ops(), M)
 
 
-@case("conv2_fwd_kernel<4>")
+@case("conv2_fwd_x6_kernel")
 def _conv_fwd_large():
     import test_conv_gpu as Cv
     Cv.test_conv_forward_kernels(_ops(), 300)
