@@ -1,10 +1,12 @@
-"""GPU parity of the hand-written fp32-MFMA AtariFfModel conv stack (csrc/conv.hip) against a
-float64 torch reference of the same ops (rlpyt/models/pg/atari_ff_model.py:50-55 with
-rlpyt/models/conv2d.py geometry 4->16 k8 s4 p0, 16->32 k4 s2 p1).
+"""GPU parity of the hand-written AtariFfModel conv stack (csrc/conv.hip: fp32 MFMA, and fp32
+contractions issued as exact / 2^-26-accurate bf16 splits) against a float64 torch reference of
+the same ops (rlpyt/models/pg/atari_ff_model.py:50-55 with rlpyt/models/conv2d.py geometry
+4->16 k8 s4 p0, 16->32 k4 s2 p1).
 
-Tolerance (floating point, f32 FMA chains of length 256 in the forward, up to M*475 in the
-weight gradients, different summation order than the reference): max |err| <= 2e-5 * max |ref|
-(+1e-6), stated per test."""
+Tolerance (floating point, f32 accumulation chains of length 256 in the forward, up to M*475 in
+the weight gradients, different summation order than the reference): max |err| <= 2e-5 *
+max |ref| (+1e-6), stated per test; test_bf16_split_kernels_are_f32_accurate pins the bf16-split
+kernels to torch's own f32 error level on wide-range operands."""
 import numpy as np
 import pytest
 import torch
@@ -264,3 +266,73 @@ def test_ppo_fused_and_unfused_loss_paths_agree(ops):
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-5, atol=1e-6)
     for a, b in zip(res[0][1], res[1][1]):
         _close(a, b, rel=1e-4, what="fused vs unfused PPO param grad")
+
+
+def _wide(shape, g, spread=3.0):
+    """Full-mantissa values over ~5 decades with both signs: exercises all three bf16 pieces of a
+    split operand (a 2-piece or single bf16 operand fails this by 3..5 orders of magnitude)."""
+    return torch.randn(shape, generator=g, dtype=torch.float64) * \
+        torch.exp(spread * torch.randn(shape, generator=g, dtype=torch.float64))
+
+
+def test_bf16_split_kernels_are_f32_accurate(ops):
+    """The conv kernels that run on the bf16 matrix pipe (conv1 forward / weight gradient: exact
+    bf16x3 split of the f32 operand, uint8 operand exact in bf16; conv2 forward, M > #CUs: bf16x6,
+    dropped products <= 2^-26) against float64, beside torch's OWN f32 convolutions on the same
+    device and inputs: our error must be f32-accumulation-order noise -- at most 2x torch-f32's
+    (+ 2^-22 of the output scale).  A bf16 or 2-piece computation misses this bound by orders
+    of magnitude on these wide-range operands."""
+    from rlpyt_amd._lib import check, lib, ptr, stream
+    M = 320                                            # > #CUs: the bf16x6 conv2 forward
+    g = torch.Generator().manual_seed(7)
+    obs = torch.randint(0, 256, (M, 4, 104, 80), dtype=torch.uint8, generator=g)
+    w1_64 = (_wide((16, 4, 8, 8), g) * 0.02).float().double()       # f32-representable
+    b1_64 = (_wide((16,), g, 1.0) * 0.1).float().double()
+    w2_64 = (_wide((32, 16, 4, 4), g) * 0.02).float().double()
+    b2_64 = (_wide((32,), g, 1.0) * 0.1).float().double()
+
+    def bound(err_torch, scale):
+        return 2 * err_torch + scale * 2.0 ** -22
+
+    obs_d = obs.cuda()
+    x64 = obs_d.double() / 255
+    # ---- conv1 forward
+    y1_64 = F.relu(F.conv2d(x64, w1_64.cuda(), b1_64.cuda(), stride=4))
+    y1_t = F.relu(F.conv2d(obs_d.float() / 255, w1_64.float().cuda(), b1_64.float().cuda(), stride=4))
+    w1, b1 = w1_64.float().cuda().contiguous(), b1_64.float().cuda().contiguous()
+    y1 = torch.empty(M, 475, 16, device="cuda")
+    check(lib.rlpyt_atari_conv1_fwd_f32(ptr(obs_d), None, 1, M, M, ptr(w1), ptr(b1), 1. / 255,
+                                        ptr(y1), stream()), "conv1")
+    ours = (y1.reshape(M, 25, 19, 16).permute(0, 3, 1, 2).double() - y1_64).abs().max().item()
+    theirs = (y1_t.double() - y1_64).abs().max().item()
+    assert ours <= bound(theirs, y1_64.abs().max().item()), ("conv1 fwd", ours, theirs)
+    # ---- conv2 forward on wide-range activations
+    a1_64 = _wide((M, 16, 25, 19), g, 2.0).abs().float().double().cuda()
+    y2_64 = F.relu(F.conv2d(a1_64, w2_64.cuda(), b2_64.cuda(), stride=2, padding=1))
+    y2_t = F.relu(F.conv2d(a1_64.float(), w2_64.float().cuda(), b2_64.float().cuda(), stride=2,
+                           padding=1))
+    y1_in = a1_64.float().permute(0, 2, 3, 1).reshape(M, 475, 16).contiguous()
+    w2, b2 = w2_64.float().cuda().contiguous(), b2_64.float().cuda().contiguous()
+    y2 = torch.empty(M, 3456, device="cuda")
+    check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1_in), M, ptr(w2), ptr(b2), ptr(y2), stream()), "conv2")
+    from rlpyt_amd import _lib
+    assert _lib.last_variant().startswith("conv2_fwd_x6_kernel"), _lib.last_variant()
+    ours = (y2.reshape(M, 32, 12, 9).double() - y2_64).abs().max().item()
+    theirs = (y2_t.double() - y2_64).abs().max().item()
+    assert ours <= bound(theirs, y2_64.abs().max().item()), ("conv2 fwd", ours, theirs)
+    # ---- conv1 weight gradient on wide-range dy1
+    dy1_64 = _wide((M, 16, 25, 19), g, 2.0).float().double().cuda()
+    xin = x64.clone().requires_grad_(False)
+    w_req = w1_64.cuda().clone().requires_grad_(True)
+    (F.conv2d(xin, w_req, None, stride=4) * dy1_64).sum().backward()
+    dw_t = torch.nn.grad.conv2d_weight(obs_d.float() / 255, (16, 4, 8, 8), dy1_64.float(), stride=4)
+    ws = torch.empty(lib.rlpyt_atari_conv_wgrad_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    dw1, db1 = torch.empty(16, 4, 8, 8, device="cuda"), torch.empty(16, device="cuda")
+    dy1_in = dy1_64.float().permute(0, 2, 3, 1).reshape(M, 475, 16).contiguous()
+    check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs_d), None, 1, M, M, ptr(dy1_in), 1. / 255,
+                                          ptr(ws), ptr(dw1), ptr(db1), stream()), "wgrad1")
+    ours = (dw1.double() - w_req.grad).abs().max().item()
+    theirs = (dw_t.double() - w_req.grad).abs().max().item()
+    assert ours <= bound(theirs, w_req.grad.abs().max().item()), ("conv1 wgrad", ours, theirs)
+    db_ref = dy1_64.sum(dim=(0, 2, 3))
+    assert (db1.double() - db_ref).abs().max().item() <= 1e-5 * dy1_64.abs().sum(dim=(0, 2, 3)).max().item()
