@@ -839,6 +839,11 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
   // zero column where a tap falls outside), offset of y1[pix] in the padded plane, pix * 16};
   // slots past the class's last pixel repeat it (10 tiles of 16: one tile of look-ahead)
   __shared__ __attribute__((aligned(16))) int dtab_[4 * B2_TABP * 8];  // 22,528 B
+  // wgrad patch origins: position p (clamped to 107) -> float offset of pixel (2 oy, 2 ox) in the
+  // padded y1 plane.  Every plain VALU instruction beside an f32 MFMA costs the SIMD ~3 ns (DESIGN
+  // 4a): the origin arithmetic (clamp, /9, two multiply-adds per position) was ~0.75 VALU per MFMA
+  // of the wgrad stream; now one 8-byte table read per half-step, one group ahead.
+  __shared__ __attribute__((aligned(8))) int wtab_[128];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
@@ -846,6 +851,10 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
 
   for (int i = tid; i < 2 * B2_GM; i += B2_THREADS) gm_[i] = 0.f;    // pos 108..123 stay zero
   for (int i = tid; i < 2 * B2_PAD; i += B2_THREADS) pad_[i] = 0.f;  // border stays zero
+  for (int i = tid; i < 128; i += B2_THREADS) {
+    const int pos = min(i, P2 - 1), oy = pos / W2, ox = pos - oy * W2;
+    wtab_[i] = ((2 * oy) * PW + 2 * ox) * PS_W;
+  }
   for (int i = tid; i < 4 * B2_TABP; i += B2_THREADS) {
     const int cq = i / B2_TABP, p = i - cq * B2_TABP;
     const int py = cq >> 1, px = cq & 1;
@@ -1078,6 +1087,7 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
     for (int i = 0; i < 32; ++i) asm volatile("" ::"v"(wx[i]));   // (loads complete before the loop)
   }
   const int4* xtab = reinterpret_cast<const int4*>(dtab_) + (xq * B2_TABP + xtile * 16 + j) * 2;
+  const int2* wt = reinterpret_cast<const int2*>(wtab_) + 2 * kq;
   const int xkq_gm = 4 * kq * GS_B, xkq4 = 4 * kq;
   {
     int cur = 0;
@@ -1119,11 +1129,9 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
         for (int r = 0; r < 4; ++r) o[r] = yv[r] > 0.f ? a0[r] + a1[r] : 0.f;
         *reinterpret_cast<f32x4*>(dy1 + m * Y1 + xkq4 + e1.y) = o;
       }
-#define RLPYT_B2_WLOAD(dst_, sg_, half_, ky_)                                                  \
+#define RLPYT_B2_WLOAD(dst_, tw_)   /* tw_ = origins of the half-step's two positions */       \
   _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                           \
-    const int pos_ = min(16 * (sg_) + 4 * kq + 2 * (half_) + h_, P2 - 1);                      \
-    const int oy_ = (pos_ * 57) >> 9, ox_ = pos_ - oy_ * W2;                                   \
-    const float* bp_ = pad + ((2 * oy_ + (ky_)) * PW + 2 * ox_) * PS_W + j;                    \
+    const float* bp_ = padq + (h_ ? (tw_).y : (tw_).x);                                        \
     _Pragma("unroll") for (int kx = 0; kx < 4; ++kx) dst_[h_ * 4 + kx] = bp_[kx * PS_W];       \
   }
 #define RLPYT_B2_ALOAD(dst_, sg_, half_)                                                       \
@@ -1143,8 +1151,14 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
     __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   /* 3 VALU    */                       \
   }
       float b0[8], b1[8], alo[2][2], ahi[2][2];
+      const float* padq = pad + q * PW * PS_W + j;           // row offset of ky = q, channel j
+      // origins of (group sg, half): wt[8 sg + half]; held one group ahead
+      int2 t_h1 = wt[1], t_n0 = wt[8];
       RLPYT_B2_ALOAD(alo, 0, 0)
-      RLPYT_B2_WLOAD(b0, 0, 0, q)
+      {
+        const int2 t00 = wt[0];
+        RLPYT_B2_WLOAD(b0, t00)
+      }
       // one group = two half-steps of 16 MFMAs; the operands of the NEXT half-step are requested
       // between the two 8-MFMA halves of the current one (after its own operands have been waited
       // for with nothing else in flight: requesting them first made hipcc wait for lgkmcnt(0),
@@ -1152,9 +1166,11 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
       // MFMAs may not.
       auto wgrad_group = [&](int sg) __attribute__((always_inline)) {
         const int sgn = min(sg + 1, NSG2 - 1);    // (past the last group: re-read, unused)
+        const int sgnn = min(sg + 2, NSG2 - 1);
         // half-step 0: 16 MFMAs on (alo, b0) with the 6 reads of half-step 1 interleaved
         RLPYT_B2_ALOAD(ahi, sg, 1)
-        RLPYT_B2_WLOAD(b1, sg, 1, q)
+        RLPYT_B2_WLOAD(b1, t_h1)
+        t_h1 = wt[8 * sgn + 1];
         RLPYT_B2_WMMA(acc, alo, b0, 0)
         RLPYT_B2_WMMA(acc, alo, b0, 1)
         if (q == 1) {
@@ -1165,7 +1181,8 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
         __builtin_amdgcn_sched_barrier(0);
         // half-step 1: 16 MFMAs on (ahi, b1) with the reads of the next group's half-step 0
         RLPYT_B2_ALOAD(alo, sgn, 0)
-        RLPYT_B2_WLOAD(b0, sgn, 0, q)
+        RLPYT_B2_WLOAD(b0, t_n0)
+        t_n0 = wt[8 * sgnn];
         RLPYT_B2_WMMA(acc, ahi, b1, 0)
         RLPYT_B2_WMMA(acc, ahi, b1, 1)
         if (q == 1) {
@@ -1456,27 +1473,33 @@ __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
 }
 
 // out[e] = sum_g partial[g][e]; e < n.  Fixed order -> run-to-run deterministic.
-// 64 elements per workgroup, the G partials split over the 4 waves (coalesced 256 B rows).
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
-                                                              int G, int n, float* __restrict__ out_w,
-                                                              int n_w, float* __restrict__ out_b) {
-  __shared__ float red[4][64];
+// 64 elements per workgroup, the G partials split over 16 waves with 4 independent 256-byte row
+// loads in flight each (4 waves x 2 in flight measured 11.5 us for 256 rows: a chain of 32
+// dependent load rounds; now 4).
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial,
+                                                               int G, int n, float* __restrict__ out_w,
+                                                               int n_w, float* __restrict__ out_b) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
   if (e < n) {
     int g = wave;
-    for (; g + 4 < G; g += 8) {
-      s0 += partial[(int64_t)g * n + e];
-      s1 += partial[(int64_t)(g + 4) * n + e];
+    for (; g + 48 < G; g += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += partial[(int64_t)(g + 16 * u) * n + e];
     }
-    if (g < G) s0 += partial[(int64_t)g * n + e];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (g + 16 * u < G) s[u] += partial[(int64_t)(g + 16 * u) * n + e];
   }
-  red[wave][lane] = s0 + s1;
+  red[wave][lane] = (s[0] + s[1]) + (s[2] + s[3]);
   __syncthreads();
   if (wave == 0 && e < n) {
-    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    if (e < n_w) out_w[e] = s; else out_b[e - n_w] = s;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += red[w][lane];
+    if (e < n_w) out_w[e] = v; else out_b[e - n_w] = v;
   }
 }
 
@@ -1758,7 +1781,7 @@ extern "C" int rlpyt_atari_conv2_wgrad_f32(const float* g2, const float* y2, con
   const int g = (int)std::min<int64_t>(M, kWgradGrid);
   RL_LAUNCH(conv2_wgrad_kernel, dim3(g), dim3(256), 0, s, g2, y2, y1, workspace, M);
   RL_LAUNCH_CHECK();
-  RL_LAUNCH(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(256), 0, s, workspace,
+  RL_LAUNCH(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(1024), 0, s, workspace,
                      g, PART2, dw2, DW2_N, db2);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -1778,7 +1801,7 @@ extern "C" int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* fl
   RL_LAUNCH(conv1_wgrad_kernel, dim3(g), dim3(X3_THREADS), 0, s, obs, flat_idx, T, B, dy1,
                      workspace, M, scale);
   RL_LAUNCH_CHECK();
-  RL_LAUNCH(reduce_partials_kernel, dim3((PART1 + 63) / 64), dim3(256), 0, s, workspace,
+  RL_LAUNCH(reduce_partials_kernel, dim3((PART1 + 63) / 64), dim3(1024), 0, s, workspace,
                      g, PART1, dw1, DW1_N, db1);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -1801,7 +1824,7 @@ extern "C" int rlpyt_atari_conv2_bwd_f32(const float* g2, const float* y2, const
   RL_LAUNCH(conv2_bwd_kernel, dim3(g), dim3(B2_THREADS), 0, s, g2, y2, y1, w2, dy1,
                      workspace, M);
   RL_LAUNCH_CHECK();
-  RL_LAUNCH(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(256), 0, s, workspace,
+  RL_LAUNCH(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(1024), 0, s, workspace,
                      g, PART2, dw2, DW2_N, db2);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;

@@ -564,25 +564,34 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock, 2) void ppo_head_loss_kern
   }
 }
 
-// out[e] = sum over the per-wave partial rows (fixed order -> deterministic)
-__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ wpart, int n_rows,
-                                                          int part, float* __restrict__ out) {
-  __shared__ float red[4][64];
+// out[e] = sum over the per-workgroup partial rows (fixed order -> deterministic).
+// 64 elements per workgroup, the rows split over 16 waves with 4 independent loads in flight each:
+// the reduction is a chain of dependent 256-byte loads per wave (round 2 start: 4 waves x 2 in
+// flight = 64 dependent rounds, 21 us for 7 MB); now 8 rounds.
+__global__ __launch_bounds__(1024) void head_reduce_kernel(const float* __restrict__ wpart, int n_rows,
+                                                           int part, float* __restrict__ out) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
   if (e < part) {
     int g = wave;
-    for (; g + 4 < n_rows; g += 8) {
-      s0 += wpart[(int64_t)g * part + e];
-      s1 += wpart[(int64_t)(g + 4) * part + e];
+    for (; g + 48 < n_rows; g += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += wpart[(int64_t)(g + 16 * u) * part + e];
     }
-    if (g < n_rows) s0 += wpart[(int64_t)g * part + e];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (g + 16 * u < n_rows) s[u] += wpart[(int64_t)(g + 16 * u) * part + e];
   }
-  red[wave][lane] = s0 + s1;
+  red[wave][lane] = (s[0] + s[1]) + (s[2] + s[3]);
   __syncthreads();
-  if (wave == 0 && e < part)
-    out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0 && e < part) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += red[w][lane];
+    out[e] = v;
+  }
 }
 
 constexpr int kHeadGrid = 512;  // one weight-gradient partial row per workgroup; two 4-wave
@@ -758,7 +767,7 @@ extern "C" int rlpyt_ppo_head_loss_fwd_bwd_f32(
   }
 #undef RL_HEAD
   RL_LAUNCH_CHECK();
-  RL_LAUNCH(head_reduce_kernel, dim3((part + 63) / 64), dim3(256), 0, s, wpart, grid,
+  RL_LAUNCH(head_reduce_kernel, dim3((part + 63) / 64), dim3(1024), 0, s, wpart, grid,
                      part, grad_params);
   RL_LAUNCH_CHECK();
   RL_LAUNCH(pg_loss_finalize_kernel, dim3(1), dim3(kLossBlock), 0, s, ws, n_waves, M,
