@@ -171,6 +171,24 @@ int rlpyt_ppo_head_loss_fwd_bwd_f32(const float* h, const float* w_pi, const flo
                                     float* out_scalars, float* grad_h, float* grad_params,
                                     void* workspace, rlpyt_stream_t stream);
 
+/* The same with the trunk's bias add + ReLU fused in (rlpyt/models/mlp.py:24-31: the Linear + ReLU
+ * pair in front of the heads): ``z`` f32 [M,K] is the trunk's pre-activation WITHOUT its bias
+ * (z = x W^T), trunk_bias [K]; the kernel applies h = relu(z + trunk_bias) while loading a row.
+ * grad_z [M,K] = dL/dz (= dL/dh masked by h > 0); grad_params [A*K + K + A + 1 + K] =
+ * dL/dw_pi | dL/dw_v | dL/db_pi | dL/db_v | dL/dtrunk_bias.  trunk_bias == NULL: exactly
+ * rlpyt_ppo_head_loss_fwd_bwd_f32 (z is then the post-activation trunk output, grad_params has no
+ * trunk-bias block). */
+int rlpyt_ppo_trunk_head_loss_fwd_bwd_f32(const float* z, const float* trunk_bias /*nullable*/,
+                                          const float* w_pi, const float* b_pi, const float* w_v,
+                                          const float* b_v, const float* prob_old,
+                                          const int64_t* action, const float* advantage,
+                                          const float* return_, const float* valid /*nullable*/,
+                                          const int64_t* flat_idx /*nullable*/, int T, int64_t B,
+                                          int64_t M, int K, int A, float ratio_clip,
+                                          float value_loss_coeff, float entropy_loss_coeff,
+                                          float* out_scalars, float* grad_z, float* grad_params,
+                                          void* workspace, rlpyt_stream_t stream);
+
 /* A2C.loss -- rlpyt/algos/pg/a2c.py:63-103: pi_loss = -valid_mean(log(p[a]+eps) * A). */
 int rlpyt_a2c_loss_fwd_bwd_f32(const float* prob /*[M,A]*/, const float* value /*[M]*/,
                                const int64_t* action, const float* advantage,

@@ -41,6 +41,15 @@ class CategoricalPgAgent(BaseAgent):
         m = self.sampling_model
         return h, m.pi, m.value
 
+    def trunk_pre(self, observation, prev_action, prev_reward):
+        """As ``trunk`` but returns ``(z, trunk_bias, pi, value)``: the trunk's pre-activation
+        without its bias and that bias (``ops.ppo_head_loss(..., trunk_bias=)`` applies both), or
+        the post-activation output and ``None`` where the model cannot split them."""
+        obs, _, _ = self._to_model_device(observation, None, None)
+        z, tb = self.model(obs, None, None, features_only="pre")
+        m = self.sampling_model
+        return z, tb, m.pi, m.value
+
     def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
         super().initialize(env_spaces, share_memory, global_B=global_B, env_ranks=env_ranks)
         self.distribution = Categorical(dim=env_spaces.action.n)

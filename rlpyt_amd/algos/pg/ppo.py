@@ -135,11 +135,15 @@ class PPO(PolicyGradientAlgo):
         if init_rnn_state is None and self.fused_head_loss and getattr(
                 self.agent, "supports_fused_head_loss", False):
             # heads + softmax + loss + all their gradients in one kernel pass over the trunk
-            h, pi_m, v_m = self.agent.trunk(*agent_inputs)
+            # (and the trunk's bias + ReLU where the model hands out its pre-activation)
+            if hasattr(self.agent, "trunk_pre"):
+                h, tb, pi_m, v_m = self.agent.trunk_pre(*agent_inputs)
+            else:
+                (h, pi_m, v_m), tb = self.agent.trunk(*agent_inputs), None
             return ops.ppo_head_loss(h, pi_m.weight, pi_m.bias, v_m.weight, v_m.bias, old_prob,
                                      action, advantage, return_, valid, self.ratio_clip,
                                      self.value_loss_coeff, self.entropy_loss_coeff,
-                                     flat_idx=flat_idx)
+                                     flat_idx=flat_idx, trunk_bias=tb)
         assert flat_idx is None, "index-mode loss needs the fused head+loss kernel"
         if init_rnn_state is not None:
             init_rnn_state = buffer_method(init_rnn_state, "transpose", 0, 1)

@@ -148,11 +148,18 @@ class AtariFfModel(torch.nn.Module):
     def forward(self, image, prev_action, prev_reward, features_only=False):
         """[T,B,C,H,W] / [B,C,H,W] / [C,H,W] -> (pi, value) with the same lead dims.
         ``features_only``: return the trunk output ``[T*B, fc]`` instead (for the fused
-        head + loss kernel)."""
+        head + loss kernel); ``features_only="pre"``: return ``(z, trunk_bias)`` with ``z`` the
+        trunk's pre-activation without its bias when the trunk is one Linear + ReLU on the fused
+        conv path (the head + loss kernel then applies bias and ReLU), else ``(trunk output,
+        None)``."""
+        lin = self._single_fc() if features_only == "pre" else None
         if isinstance(image, ObsGather):
             lead_dim, T, B = 1, 1, image.flat_idx.numel()
             if self.fused_conv:
-                fc_out = self.conv.head(self._conv_features(*image))
+                feat = self._conv_features(*image)
+                if lin is not None:    # x W^T only: bias + ReLU belong to the head+loss kernel
+                    return F.linear(feat, lin.weight), lin.bias
+                fc_out = self.conv.head(feat)
             else:
                 from ... import ops
                 fc_out = self.conv(ops.obs_to_nhwc_f32(*image))
@@ -160,9 +167,13 @@ class AtariFfModel(torch.nn.Module):
             lead_dim, T, B, img_shape = infer_leading_dims(image, 3)
             if image.dtype == torch.uint8 and image.is_cuda and self.fused_conv:
                 feat = self._conv_features(image.contiguous().reshape(T * B, *img_shape), None)
+                if lin is not None:
+                    return F.linear(feat, lin.weight), lin.bias
                 fc_out = self.conv.head(feat)
             else:
                 fc_out = self.conv(prepare_image(image, T * B, img_shape))
+        if features_only == "pre":
+            return fc_out, None
         if features_only:
             return fc_out
         pi = F.softmax(self.pi(fc_out), dim=-1)

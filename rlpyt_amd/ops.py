@@ -201,7 +201,7 @@ def ppo_loss(prob_new, value, prob_old, action, advantage, return_, valid, ratio
 class _PpoHeadLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid,
-                ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None):
+                ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None, trunk_bias=None):
         _lib.require_gpu()
         K = h.shape[-1]
         A = w_pi.shape[0]
@@ -209,6 +209,7 @@ class _PpoHeadLoss(torch.autograd.Function):
         M = hc.shape[0]
         wp, bp = _f32(w_pi.detach()), _f32(b_pi.detach())
         wv, bv = _f32(w_v.detach()).reshape(-1), _f32(b_v.detach()).reshape(-1)
+        tb = None if trunk_bias is None else _f32(trunk_bias.detach()).reshape(-1)
         T = B = 0
         if flat_idx is not None:     # loss inputs are [T,B,...] batch arrays, indexed in-kernel
             assert valid is None and prob_old.dim() == 3
@@ -222,40 +223,50 @@ class _PpoHeadLoss(torch.autograd.Function):
         val = None if valid is None else _f32(valid).reshape(-1)
         out = torch.empty(5, dtype=torch.float32, device=hc.device)
         gh = torch.empty_like(hc)
-        gparams = torch.empty(A * K + K + A + 1, dtype=torch.float32, device=hc.device)
+        gparams = torch.empty(A * K + K + A + 1 + (K if tb is not None else 0),
+                              dtype=torch.float32, device=hc.device)
         ws = _workspace("head_loss", lib.rlpyt_ppo_head_loss_workspace_bytes(K, A), hc.device)
         with ktimer.region("ppo_head_loss", M * (8 * K + 8 * A + 28)):
-            check(lib.rlpyt_ppo_head_loss_fwd_bwd_f32(
-                ptr(hc), ptr(wp), ptr(bp), ptr(wv), ptr(bv), ptr(po), ptr(act), ptr(adv), ptr(ret),
-                ptr(val), ptr(flat_idx), int(T), int(B), M, K, A, float(ratio_clip),
+            check(lib.rlpyt_ppo_trunk_head_loss_fwd_bwd_f32(
+                ptr(hc), ptr(tb), ptr(wp), ptr(bp), ptr(wv), ptr(bv), ptr(po), ptr(act), ptr(adv),
+                ptr(ret), ptr(val), ptr(flat_idx), int(T), int(B), M, K, A, float(ratio_clip),
                 float(value_loss_coeff),
                 float(entropy_loss_coeff), ptr(out), ptr(gh), ptr(gparams), ptr(ws), stream()),
-                "rlpyt_ppo_head_loss_fwd_bwd_f32")
+                "rlpyt_ppo_trunk_head_loss_fwd_bwd_f32")
         ctx.save_for_backward(gh, gparams)
-        ctx.meta = (h.shape, w_pi.shape, b_pi.shape, w_v.shape, b_v.shape, A, K)
+        ctx.meta = (h.shape, w_pi.shape, b_pi.shape, w_v.shape, b_v.shape, A, K,
+                    None if trunk_bias is None else trunk_bias.shape)
         ctx.mark_non_differentiable(out)
         return out[0], out
 
     @staticmethod
     def backward(ctx, g_loss, _g_out):
         gh, gp = ctx.saved_tensors
-        hs, wps, bps, wvs, bvs, A, K = ctx.meta
+        hs, wps, bps, wvs, bvs, A, K, tbs = ctx.meta
         gp = gp * g_loss
         o = A * K
+        g_tb = None if tbs is None else gp[o + K + A + 1:].reshape(tbs)
         return ((gh * g_loss).reshape(hs), gp[:o].reshape(wps), gp[o + K:o + K + A].reshape(bps),
-                gp[o:o + K].reshape(wvs), gp[o + K + A:].reshape(bvs)) + (None,) * 9
+                gp[o:o + K].reshape(wvs), gp[o + K + A:o + K + A + 1].reshape(bvs)) + \
+            (None,) * 9 + (g_tb,)
 
 
 def ppo_head_loss(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid,
-                  ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None):
+                  ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None,
+                  trunk_bias=None):
     """PPO.loss (rlpyt/algos/pg/ppo.py:117-154) with the policy / value heads of
     rlpyt/models/pg/atari_ff_model.py:56-58 fused in: takes the trunk output ``h [M, K]`` and the
     head parameters, returns ``(loss, scalars)`` like ``ppo_loss``; differentiable w.r.t. ``h``
     and the four head parameters (all gradients come out of the same kernel pass).  With
     ``flat_idx`` (int64 ``[M]``) the loss inputs are the whole ``[T,B,...]`` batch arrays and the
-    kernel reads sample m at ``(idx % T, idx // T)`` -- no minibatch gather launches."""
+    kernel reads sample m at ``(idx % T, idx // T)`` -- no minibatch gather launches.
+    With ``trunk_bias [K]``, ``h`` is the trunk's pre-activation WITHOUT its bias (``x W^T``) and
+    the kernel applies ``relu(h + trunk_bias)`` itself (the op is then differentiable w.r.t. the
+    pre-activation and the bias: the Linear's bias add, the ReLU, its backward and the bias
+    gradient reduction never launch)."""
     return _PpoHeadLoss.apply(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_,
-                              valid, ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx)
+                              valid, ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx,
+                              trunk_bias)
 
 
 class _A2cLoss(torch.autograd.Function):

@@ -236,6 +236,44 @@ def test_ppo_head_loss_fused_vs_reference(ops, M, A, with_valid):
         _close(a.grad, b.grad, rel=3e-5, what=f"head-loss grad {name}")
 
 
+@pytest.mark.parametrize("M,A,with_valid", [(8192, 6, False), (37, 4, True), (5, 8, False)])
+def test_ppo_trunk_head_loss_fused_vs_reference(ops, M, A, with_valid):
+    """ops.ppo_head_loss(trunk_bias=...): the trunk's bias add + ReLU fused in front of the heads
+    (pre-activation z = x W^T in, relu(z + b) applied by the kernel) vs the same statements in
+    float64 -- loss scalars, dL/dz (masked by the ReLU), dL/dtrunk_bias and the head gradients."""
+    from oracle import np_oracle as O
+    K = 512
+    g = torch.Generator().manual_seed(7 * M + A)
+    z = torch.randn(M, K, generator=g, dtype=torch.float64)
+    tb = torch.randn(K, generator=g, dtype=torch.float64) * 0.3
+    w_pi = torch.randn(A, K, generator=g, dtype=torch.float64) * 0.05
+    b_pi = torch.randn(A, generator=g, dtype=torch.float64) * 0.1
+    w_v = torch.randn(1, K, generator=g, dtype=torch.float64) * 0.05
+    b_v = torch.randn(1, generator=g, dtype=torch.float64) * 0.1
+    po = torch.softmax(torch.randn(M, A, generator=g, dtype=torch.float64), -1)
+    act = torch.randint(0, A, (M,), generator=g)
+    adv = torch.randn(M, generator=g, dtype=torch.float64)
+    ret = torch.randn(M, generator=g, dtype=torch.float64)
+    valid = (torch.rand(M, generator=g) < 0.8).double() if with_valid else None
+    ref_in = [t.clone().requires_grad_(True) for t in (z, w_pi, b_pi, w_v, b_v, tb)]
+    h = torch.relu(ref_in[0] + ref_in[5])
+    pi = torch.softmax(h @ ref_in[1].t() + ref_in[2], -1)
+    v = (h @ ref_in[3].t()).squeeze(-1) + ref_in[4]
+    ref = O.ppo_loss_torch(pi, v, po, act, adv, ret, valid, 0.1, 1.0, 0.01)
+    ref[0].backward()
+    dev_in = [t.float().cuda().requires_grad_(True) for t in (z, w_pi, b_pi, w_v, b_v, tb)]
+    f = lambda t: None if t is None else t.float().cuda()  # noqa: E731
+    loss, sc = ops.ppo_head_loss(*dev_in[:5], f(po), act.cuda(), f(adv), f(ret), f(valid), 0.1,
+                                 1.0, 0.01, trunk_bias=dev_in[5])
+    loss.backward()
+    np.testing.assert_allclose(sc.cpu().numpy(), [x.item() for x in ref], rtol=2e-5, atol=1e-6)
+    for name, a, b in zip(["z", "w_pi", "b_pi", "w_v", "b_v", "trunk_bias"], dev_in, ref_in):
+        _close(a.grad, b.grad, rel=3e-5, what=f"trunk+head-loss grad {name}")
+    # the masked entries are exact zeros
+    dead = (z.float().cuda() + tb.float().cuda()) <= 0
+    assert torch.all(dev_in[0].grad[dead] == 0)
+
+
 def test_ppo_fused_and_unfused_loss_paths_agree(ops):
     """PPO.loss through the fused head-loss kernel vs through agent() + ops.ppo_loss on the same
     minibatch: same loss, same parameter gradients (f32 tolerance)."""
