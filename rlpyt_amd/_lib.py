@@ -95,6 +95,7 @@ _SIGNATURES = {
     "rlpyt_ppo_trunk_head_loss_fwd_bwd_f32": (c_int, [_p] * 12 + [c_int, c_int64, c_int64, c_int, c_int,
                                                           c_float, c_float, c_float, _p, _p, _p, _p,
                                                           _p]),
+    "rlpyt_gemm_nt_f32": (c_int, [_p, _p, _p, c_int64, c_int64, c_int64, _p]),
     "rlpyt_a2c_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,
                                            c_float, _p, _p, _p, _p, _p]),
     "rlpyt_dqn_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,

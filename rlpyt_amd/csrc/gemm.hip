@@ -1,0 +1,230 @@
+// f32 GEMM  C[M,N] = A[M,K] * B[N,K]^T  on the bf16 matrix pipe ("bf16x6"), for the trunk of the
+// PPO update (rlpyt/models/mlp.py:24-31: Linear(3456, 512); forward x W^T and, with B = W^T, the
+// input gradient g W).  hipBLASLt's f32 GEMM runs these at 0.72-0.87 of the f32 MFMA peak -- there
+// is no faster f32 instruction on gfx950.  Here both operands are split into three bf16 pieces
+// (round to nearest: x == x0 + x1 + x2 exactly) while they pass from HBM to LDS and the six
+// products of order <= 2 are accumulated in f32, smallest first; the three dropped products are
+// together <= 2^-26 |ab|, a quarter of one f32 rounding (same scheme and the same accuracy test as
+// conv2_fwd_x6_kernel, csrc/conv.hip).  6 x v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace
+// 8 x v_mfma_f32_32x32x2_f32 (64 cycles, K = 2): 2.7x less matrix-pipe time per K.
+//
+// Tiling: workgroup = 128 x 128 of C, 8 waves (2 x 4), wave = 64 x 32 = 2 MFMA tiles (32
+// accumulator VGPRs); K-step 16.  LDS stage = {A, B} x 3 pieces x 128 rows x 48 B (32 B of data +
+// 16 B pad: the 8-lane groups of a ds_read_b128 then cover all 32 banks), two stages = 73,728 B
+// -> two workgroups per CU when there are enough tiles (the forward shape has 256 tiles: one
+// workgroup = 2 waves per SIMD; with 4 waves per workgroup it ran at one wave per SIMD and every
+// split / LDS phase idled the matrix pipe: 226 us).  Per K-step a thread moves 1 + 1 float4
+// HBM -> registers (one step ahead), splits them and writes 6 x 8 B to the other LDS stage; one
+// barrier per K-step.  blockIdx -> tile map keeps the column tiles of one row block on one XCD.
+#include <algorithm>
+#include "common.h"
+
+namespace rlpyt {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma32_bf16(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo_elem, float hi_elem) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {lo_elem, hi_elem};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// (x0, x1) -> three packed bf16 pieces, hi + mid + lo == x exactly (finite, no overflow)
+__device__ __forceinline__ void split3_rn(float x0, float x1, uint32_t& hi, uint32_t& mid,
+                                          uint32_t& lo) {
+  hi = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk_bf16(r0, r1);
+  lo = cvt_pk_bf16(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
+}
+
+constexpr int GT = 128;                  // tile edge
+constexpr int G_THREADS = 512;
+#ifndef RLPYT_G_BK
+#define RLPYT_G_BK 16
+#endif
+constexpr int G_BK = RLPYT_G_BK;         // K per barrier step (16 or 32)
+constexpr int G_ROWB = 2 * G_BK + 16;    // bytes per (piece, row) of a K-step: data + 16 B pad
+constexpr int G_PB = GT * G_ROWB;        // bytes per piece
+constexpr int G_OB = 3 * G_PB;           // per operand
+constexpr int G_SB = 2 * G_OB;           // per stage: 36,864 B (BK 16) / 61,440 B (BK 32)
+constexpr int G_NF = GT * G_BK / 4 / G_THREADS;   // float4 per thread, operand and K-step: 1 / 2
+
+__global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
+    int K, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * G_SB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;      // wave tile: rows 64 wm .. + 63, columns 32 wn .. + 31
+  // XCD-aware tile map.  Workgroup ids go round-robin over the 8 XCDs (4 MB of L2 each, 32 CUs =
+  // 32 concurrent workgroups).  Every XCD owns tiles_m / 8 row blocks and walks them in panels
+  // of (its row blocks) x (4 column tiles): the workgroups running together then share
+  // 8 A row-block tiles and 4 B column tiles (3 MB at K = 512) instead of one A tile and 27
+  // different B tiles (all of W^T, 7 MB: re-streamed past the L2 for every row block).
+  const int n_tiles = tiles_m * tiles_n;
+  int tm, tn;
+  if ((tiles_m & 7) == 0) {
+    const int R = tiles_m >> 3, xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int cb = li / (4 * R), rem = li - cb * 4 * R;
+    const int cw = min(4, tiles_n - 4 * cb);
+    tm = xcd * R + rem / cw;
+    tn = 4 * cb + rem % cw;
+  } else {
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    tm = tile / tiles_n;
+    tn = tile - tm * tiles_n;
+  }
+
+  // staging map: float4 f = tid + 512 i = (row = f / (BK / 4), kq = f % (BK / 4)); rows clamped
+  const float* ga[G_NF];
+  const float* gb[G_NF];
+  int sdst[G_NF];
+#pragma unroll
+  for (int i = 0; i < G_NF; ++i) {
+    const int f = tid + G_THREADS * i, row = f / (G_BK / 4), kq = f % (G_BK / 4);
+    ga[i] = A + (int64_t)min(tm * GT + row, M - 1) * K + 4 * kq;
+    gb[i] = B + (int64_t)min(tn * GT + row, N - 1) * K + 4 * kq;
+    sdst[i] = row * G_ROWB + kq * 8;
+  }
+  // two register sets: the rows of step s are requested two steps before they are split
+  f32x4 ra0[G_NF], rb0[G_NF], ra1[G_NF], rb1[G_NF];
+#define RLPYT_G_FETCH(ra, rb, k0_)                                                             \
+  _Pragma("unroll") for (int i = 0; i < G_NF; ++i) {                                           \
+    ra[i] = *reinterpret_cast<const f32x4*>(ga[i] + (k0_));                                    \
+    rb[i] = *reinterpret_cast<const f32x4*>(gb[i] + (k0_));                                    \
+  }
+#define RLPYT_G_STAGE(ra, rb, st_)                                                             \
+  _Pragma("unroll") for (int i = 0; i < G_NF; ++i) {                                           \
+    uint32_t p_[3][2], q_[3][2];                                                               \
+    split3_rn(ra[i][0], ra[i][1], p_[0][0], p_[1][0], p_[2][0]);                               \
+    split3_rn(ra[i][2], ra[i][3], p_[0][1], p_[1][1], p_[2][1]);                               \
+    split3_rn(rb[i][0], rb[i][1], q_[0][0], q_[1][0], q_[2][0]);                               \
+    split3_rn(rb[i][2], rb[i][3], q_[0][1], q_[1][1], q_[2][1]);                               \
+    uint8_t* d_ = lds + (st_) * G_SB + sdst[i];                                                \
+    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                         \
+      *reinterpret_cast<uint2*>(d_ + s_ * G_PB) = uint2{p_[s_][0], p_[s_][1]};                 \
+      *reinterpret_cast<uint2*>(d_ + G_OB + s_ * G_PB) = uint2{q_[s_][0], q_[s_][1]};          \
+    }                                                                                          \
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  // operand addresses of this lane: row (column) l & 31 of the MFMA tile, K half l >> 5
+  const int a_off = (wm * 64 + (lane & 31)) * G_ROWB + (lane >> 5) * 16;
+  const int b_off = G_OB + (wn * 32 + (lane & 31)) * G_ROWB + (lane >> 5) * 16;
+  // fragments of one K-step: 3 pieces x (2 row tiles of A + 1 column tile of B)
+#define RLPYT_G_FRAGS(af_, bf_, st_)                                                           \
+  _Pragma("unroll") for (int h = 0; h < G_BK / 16; ++h)                                        \
+  _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                              \
+    bf_[h][s] = *reinterpret_cast<const uint4*>(lds + (st_) * G_SB + b_off + h * 32 + s * G_PB); \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
+      af_[h][i][s] = *reinterpret_cast<const uint4*>(lds + (st_) * G_SB + a_off +              \
+                                                     i * 32 * G_ROWB + h * 32 + s * G_PB);     \
+  }
+  // six products per tile and K-half, smallest first
+#define RLPYT_G_TERM(af_, bf_, sa_, sb_)                                                       \
+  _Pragma("unroll") for (int h = 0; h < G_BK / 16; ++h)                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+    acc[i] = mfma32_bf16(af_[h][i][sa_], bf_[h][sb_], acc[i]);
+#define RLPYT_G_MMA(af_, bf_)                                                                  \
+  RLPYT_G_TERM(af_, bf_, 2, 0)                                                                 \
+  RLPYT_G_TERM(af_, bf_, 0, 2)                                                                 \
+  RLPYT_G_TERM(af_, bf_, 1, 1)                                                                 \
+  RLPYT_G_TERM(af_, bf_, 1, 0)                                                                 \
+  RLPYT_G_TERM(af_, bf_, 0, 1)                                                                 \
+  RLPYT_G_TERM(af_, bf_, 0, 0)
+
+  // THREE LDS stages: during step s the fragments of step s + 1 are read (its stage was completed
+  // at this step's barrier) while the MFMAs run on the fragments read during step s - 1, and the
+  // registers of step s + 2 are split into the third stage.  With two stages the fragment reads of
+  // all 8 waves started together right after every barrier and the matrix pipe waited for the LDS
+  // queue to drain (~40 % of every step, measured 190-200 us for the trunk shapes).
+  const int nk = K / G_BK;
+  uint4 af0[G_BK / 16][2][3], bf0[G_BK / 16][3], af1[G_BK / 16][2][3], bf1[G_BK / 16][3];
+  RLPYT_G_FETCH(ra0, rb0, 0)
+  if (nk > 1) RLPYT_G_FETCH(ra1, rb1, G_BK)
+  RLPYT_G_STAGE(ra0, rb0, 0)
+  if (nk > 2) RLPYT_G_FETCH(ra0, rb0, 2 * G_BK)
+  RLPYT_G_STAGE(ra1, rb1, 1)           // (nk == 1: stale registers into a stage nobody reads)
+  if (nk > 3) RLPYT_G_FETCH(ra1, rb1, 3 * G_BK)
+  __syncthreads();
+  RLPYT_G_FRAGS(af0, bf0, 0)
+  int st_next = 1, st_write = 2;     // stage of step ks + 1 / of step ks + 2
+  // one step: prefetch the next fragments, MFMAs on the current ones with the split of step
+  // ks + 2 in their gaps, then request step ks + 4 into the registers just consumed
+#define RLPYT_G_STEP(afc_, bfc_, afn_, bfn_, ra, rb, ks_)                                      \
+  {                                                                                            \
+    __syncthreads();   /* stage of step ks + 1 complete; stage of step ks + 2 free */          \
+    RLPYT_G_FRAGS(afn_, bfn_, st_next)   /* (past the last step: stale, unused) */            \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    RLPYT_G_MMA(afc_, bfc_)                                                                    \
+    RLPYT_G_STAGE(ra, rb, st_write)      /* (past the last step: into a stage nobody reads) */ \
+    /* the split (44 VALU per K-16) goes BETWEEN the MFMAs, 4 per gap: issued as a block it  */ \
+    /* runs while the matrix pipe idles (both waves of a SIMD are in the same phase)          */ \
+    _Pragma("unroll") for (int g_ = 0; g_ < 12 * (G_BK / 16); ++g_) {                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                       \
+    }                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if ((ks_) + 4 < nk) RLPYT_G_FETCH(ra, rb, ((ks_) + 4) * G_BK)                              \
+    st_next = st_next == 2 ? 0 : st_next + 1;                                                  \
+    st_write = st_write == 2 ? 0 : st_write + 1;                                               \
+  }
+  int ks = 0;
+#pragma unroll 1
+  for (; ks + 1 < nk; ks += 2) {
+    RLPYT_G_STEP(af0, bf0, af1, bf1, ra0, rb0, ks)
+    RLPYT_G_STEP(af1, bf1, af0, bf0, ra1, rb1, ks + 1)
+  }
+  if (ks < nk) RLPYT_G_STEP(af0, bf0, af1, bf1, ra0, rb0, ks)
+#undef RLPYT_G_STEP
+#undef RLPYT_G_MMA
+#undef RLPYT_G_TERM
+#undef RLPYT_G_FRAGS
+#undef RLPYT_G_STAGE
+#undef RLPYT_G_FETCH
+  // D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31] of tile i
+  const int col = tn * GT + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tm * GT + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < M && col < N) C[(int64_t)row * N + col] = acc[i][r];
+    }
+}
+
+}  // namespace
+}  // namespace rlpyt
+
+using namespace rlpyt;
+
+extern "C" int rlpyt_gemm_nt_f32(const float* a, const float* b, float* c, int64_t M, int64_t N,
+                                 int64_t K, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(a && b && c, RLPYT_EINVAL, "rlpyt_gemm_nt_f32: null pointer");
+  RL_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % G_BK == 0 && M < (1 << 30) && N < (1 << 30) &&
+                   K < (1 << 30),
+               RLPYT_ESHAPE, "rlpyt_gemm_nt_f32: need M, N > 0 and K a positive multiple of 32 "
+                             "(M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
+  RL_CHECK_ARG((reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0,
+               RLPYT_ESHAPE, "rlpyt_gemm_nt_f32: a / b must be 16-byte aligned");
+  const int tiles_m = (int)ceil_div(M, GT), tiles_n = (int)ceil_div(N, GT);
+  const int n_tiles = tiles_m * tiles_n;
+  const int grid = 8 * ((n_tiles + 7) / 8);     // whole rounds over the 8 XCDs
+  RL_LAUNCH(gemm_nt_x6_kernel, dim3(grid), dim3(G_THREADS), 0, (hipStream_t)stream, a, b, c, (int)M,
+            (int)N, (int)K, tiles_m, tiles_n);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}

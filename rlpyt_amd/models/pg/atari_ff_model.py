@@ -68,6 +68,16 @@ class AtariFfModel(torch.nn.Module):
             return mods[0]
         return None
 
+    use_split_gemm = True    # set False for the library f32 GEMM in the update trunk (A/B tests)
+
+    def _trunk_matmul(self, feat, weight):
+        """``feat @ weight.T`` of the update: update-size batches go through the bf16x6 GEMM
+        (``ops.linear_nobias``), small ones through the library."""
+        if self.use_split_gemm and feat.shape[0] >= 1024:
+            from ... import ops
+            return ops.linear_nobias(feat, weight)
+        return F.linear(feat, weight)
+
     def _conv_features(self, obs, flat_idx):
         from ... import ops
         c1, c2 = self.conv.conv.conv[0], self.conv.conv.conv[2]
@@ -158,7 +168,7 @@ class AtariFfModel(torch.nn.Module):
             if self.fused_conv:
                 feat = self._conv_features(*image)
                 if lin is not None:    # x W^T only: bias + ReLU belong to the head+loss kernel
-                    return F.linear(feat, lin.weight), lin.bias
+                    return self._trunk_matmul(feat, lin.weight), lin.bias
                 fc_out = self.conv.head(feat)
             else:
                 from ... import ops
@@ -168,7 +178,7 @@ class AtariFfModel(torch.nn.Module):
             if image.dtype == torch.uint8 and image.is_cuda and self.fused_conv:
                 feat = self._conv_features(image.contiguous().reshape(T * B, *img_shape), None)
                 if lin is not None:
-                    return F.linear(feat, lin.weight), lin.bias
+                    return self._trunk_matmul(feat, lin.weight), lin.bias
                 fc_out = self.conv.head(feat)
             else:
                 fc_out = self.conv(prepare_image(image, T * B, img_shape))

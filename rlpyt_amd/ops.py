@@ -628,6 +628,54 @@ def fc_small(x, weight, bias=None, relu=True):
     return y
 
 
+def gemm_nt(a, b):
+    """``a @ b.T`` for f32 ``a [M, K]``, ``b [N, K]`` (K a multiple of 32) on the bf16 matrix pipe
+    from exact three-piece bf16 splits of both operands (``rlpyt_gemm_nt_f32``: six products, f32
+    accumulation, dropped terms <= 2^-26 |ab| -- f32-level error, 2.7x less matrix-pipe time than
+    an f32-MFMA GEMM)."""
+    _lib.require_gpu()
+    a, b = _f32(a), _f32(b)
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with ktimer.region("gemm_nt", 4 * (M * K + N * K + M * N), 2 * M * N * K):
+        check(lib.rlpyt_gemm_nt_f32(ptr(a), ptr(b), ptr(c), M, N, K, stream()), "rlpyt_gemm_nt_f32")
+    return c
+
+
+class _LinearNoBias(torch.autograd.Function):
+    """``x @ W.T`` (torch.nn.functional.linear without bias) for the update-size trunk: forward
+    and the input gradient on ``gemm_nt`` (the latter on a transposed copy of W, 7 MB), the weight
+    gradient -- a contraction over the batch axis, where neither operand is K-contiguous --
+    through the library GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return gemm_nt(x, weight.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_nt(g, weight.detach().t().contiguous())
+        if ctx.needs_input_grad[1]:
+            gw = torch.mm(g.t(), x)
+        return gx, gw
+
+
+def linear_nobias(x, weight):
+    """``F.linear(x, weight)`` with ``gemm_nt`` forward / input-gradient (see ``_LinearNoBias``);
+    shapes it does not cover (K or N not a multiple of 32, non-f32, CPU) take ``F.linear``."""
+    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
+            and x.shape[1] % 32 == 0 and weight.shape[0] % 32 == 0):
+        return _LinearNoBias.apply(x, weight)
+    return torch.nn.functional.linear(x, weight)
+
+
 def fc_small_partials(x, weight):
     """Split-K partial products ``[ksplit, M, N]`` of ``x @ weight.T`` (no bias / activation):
     the first half of ``fc_small``, for consumers that finish the sum themselves."""

@@ -374,3 +374,35 @@ def test_bf16_split_kernels_are_f32_accurate(ops):
     assert ours <= bound(theirs, w_req.grad.abs().max().item()), ("conv1 wgrad", ours, theirs)
     db_ref = dy1_64.sum(dim=(0, 2, 3))
     assert (db1.double() - db_ref).abs().max().item() <= 1e-5 * dy1_64.abs().sum(dim=(0, 2, 3)).max().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 3456), (1000, 3456, 512), (130, 200, 96), (1, 1, 32)])
+def test_gemm_nt_bf16x6_is_f32_accurate(ops, M, N, K):
+    """ops.gemm_nt (rlpyt_gemm_nt_f32: a b^T from three-piece bf16 splits, six products) against
+    float64 beside torch's own f32 GEMM on wide-range operands: error <= 2x torch-f32's (+ 2^-22 of
+    the output scale), including ragged tile edges."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a64 = _wide((M, K), g, 2.0).float().double().cuda()
+    b64 = _wide((N, K), g, 2.0).float().double().cuda()
+    ref = a64 @ b64.t()
+    theirs = ((a64.float() @ b64.float().t()).double() - ref).abs().max().item()
+    c = ops.gemm_nt(a64.float(), b64.float())
+    ours = (c.double() - ref).abs().max().item()
+    assert ours <= 2 * theirs + ref.abs().max().item() * 2.0 ** -22, (ours, theirs)
+
+
+def test_linear_nobias_autograd(ops):
+    """ops.linear_nobias (gemm_nt forward / input gradient, library weight gradient) against
+    F.linear in float64."""
+    g = torch.Generator().manual_seed(3)
+    x64 = torch.randn(1024, 3456, generator=g, dtype=torch.float64).cuda().requires_grad_(True)
+    w64 = (torch.randn(512, 3456, generator=g, dtype=torch.float64) * 0.02).cuda().requires_grad_(True)
+    gy = torch.randn(1024, 512, generator=g, dtype=torch.float64).cuda()
+    (F.linear(x64, w64) * gy).sum().backward()
+    x = x64.detach().float().requires_grad_(True)
+    w = w64.detach().float().requires_grad_(True)
+    y = ops.linear_nobias(x, w)
+    (y * gy.float()).sum().backward()
+    _close(y, F.linear(x64, w64), rel=3e-6, what="linear_nobias fwd")
+    _close(x.grad, x64.grad, rel=3e-6, what="linear_nobias dx")
+    _close(w.grad, w64.grad, rel=2e-5, what="linear_nobias dw")

@@ -476,6 +476,12 @@ def _conv_bwd():
         Cv.test_conv_backward_kernels(_ops(), M)
 
 
+@case("gemm_nt_x6_kernel")
+def _gemm_nt():
+    import test_conv_gpu as Cv
+    Cv.test_gemm_nt_bf16x6_is_f32_accurate(_ops(), 130, 200, 96)
+
+
 @case("sample_convs_kernel")
 def _sample_convs():
     import test_sampler_gpu as S
