@@ -8,8 +8,12 @@ A "step" = one full PPO iteration of the hot path on one synthetic batch:
   (under N>1: DistributedDataParallel all-reduces the 7.14 MB of gradients per minibatch).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      -- the dominant own kernel of the timed region by total HIP-event time (one of the
-                   fp32-MFMA conv kernels), timed live inside the timed steps;
+  roofline      -- the dominant own kernel of the timed region by total HIP-event time, timed live
+                   inside the timed steps: an f32-MFMA kernel is priced against the 157.3 TFLOP/s
+                   f32 MFMA peak; a bf16-split kernel (f32 contraction issued as 3 / 6 bf16 MFMAs
+                   per MAC) against both the HBM peak and the 2.5 PFLOP/s dense bf16
+                   peak with its ISSUED flops; roofline_conv2_bwd keeps the remaining f32-MFMA
+                   kernel visible when it is not the dominant one;
   kernels       -- the same live measurement for every own kernel of the update;
   roofline_gae_scaled -- the GAE scan at T=128, N=2^20 columns (the shape at which the
                    HBM criterion of BASELINE.md section 3 is meaningful), timed in this run;
@@ -43,7 +47,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, den
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 # bf16-split kernels (DESIGN.md "fp32 contractions on the bf16 pipe"): issued bf16 MFMA flops per
 # algorithmic fp32 flop (3 exact pieces of one operand; 6 products of two 3-piece operands)
-BF16_SPLIT = {"conv1_fwd": 3, "conv1_wgrad": 3, "conv2_fwd": 6}
+BF16_SPLIT = {"conv1_fwd": 3, "conv1_wgrad": 3, "conv2_fwd": 6, "gemm_nt": 6}
 KERNEL_NAMES = {
     "conv1_fwd": "conv1_fwd_kernel (gather + u8->bf16 + conv 4->16 k8 s4 + bias + ReLU; exact "
                  "bf16x3 split of w1, f32 accumulate)",
@@ -54,6 +58,8 @@ KERNEL_NAMES = {
     "conv2_wgrad": "conv2_wgrad_kernel (+ bias grad, fp32 MFMA)",
     "conv1_wgrad": "conv1_wgrad_kernel (gather + u8->bf16 + weight/bias grad; exact bf16x3 split "
                    "of dy1, f32 accumulate)",
+    "gemm_nt": "gemm_nt_x6_kernel (update trunk x W^T and g W: f32 GEMM from three-piece bf16 splits of "
+               "both operands, six products, f32 accumulate, dropped terms <= 2^-26)",
     "obs_to_nhwc": "obs_to_nhwc_f32_kernel (minibatch gather + u8->f32 + CHW->HWC)",
     "gather_tb": "gather_wide_kernel (minibatch observation gather)",
     "gae": "scan_exact_kernel<GAE>", "ppo_loss": "pg_loss_kernel<PPO>",
@@ -346,6 +352,14 @@ def main():
                                    "frac": g["GBps"] / HBM_PEAK_GBPS, "traffic": None,
                                    "avg_us": g["avg_us"], "launches": g["launches"],
                                    "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
+            if name != "conv2_bwd" and "conv2_bwd" in ksum:
+                # the remaining f32-MFMA kernel, kept beside the dominant one
+                gb = ksum["conv2_bwd"]
+                out["roofline_conv2_bwd"] = {
+                    "kernel": KERNEL_NAMES["conv2_bwd"], "bound": "mfma", "achieved": gb["TFLOPs"],
+                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": gb["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, "avg_us": gb["avg_us"],
+                    "launches": gb["launches"]}
             # HBM traffic of that kernel from the separate rocprofv3 --pmc passes (a PMC pass
             # cannot run inside this timed process); committed under profiles/
             traffic = pmc_traffic(name, g)
