@@ -264,12 +264,25 @@ def main():
                      note="stand-alone all-reduce of one gradient-sized buffer after the timed "
                           "region (inside the iteration DDP overlaps it with backward)")
     sampler.shutdown()
+    # a throughput number over non-finite training is not a measurement
+    assert all(torch.isfinite(p).all().item() for p in agent.parameters()), \
+        "non-finite parameters after the timed iterations"
     if args.check_params and world > 1:
         flat = torch.cat([p.detach().reshape(-1) for p in agent.parameters()])
         lo, hi = flat.clone(), flat.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        assert torch.equal(lo, hi), "ranks diverged: DDP gradient averaging is broken"
+        if not torch.equal(lo, hi):
+            d = (hi - lo)
+            names = []
+            off = 0
+            for n_, p_ in agent.model.named_parameters():
+                k_ = p_.numel()
+                m_ = d[off:off + k_].abs().max().item()
+                if m_ > 0:
+                    names.append(f"{n_}: max diff {m_:.3e} (max |p| {p_.abs().max().item():.3e})")
+                off += k_
+            raise AssertionError("ranks diverged: DDP gradient averaging is broken -- " + "; ".join(names))
         if rank == 0:
             print("check-params: all ranks hold bit-identical parameters", file=sys.stderr)
 
@@ -300,6 +313,7 @@ def main():
                         "per_batch_ms": {k[:-2]: sampler.timing[k] / args.steps * 1e3
                                          for k in ("pre_s", "loop_s", "tail_s", "post_s")}},
             "last_loss": opt_info.loss[-1] if opt_info.loss else None,
+            "losses_finite": bool(np.isfinite(np.asarray(opt_info.loss, dtype=np.float64)).all()),
         }
         out["config"]["env_worker_cpus"] = ("pinned (affinity['workers_cpus'])" if args.pin_workers
                                             else "not pinned (set_affinity=False)")

@@ -44,7 +44,8 @@ class RlAlgorithm:
         hierarchy, hyper-parameters and state_dict; clip + step in two launches)."""
         optim_kwargs = dict(optim_kwargs or {})
         params = list(params)
-        if (OptimCls is torch.optim.Adam and params and all(
+        import os
+        if (os.environ.get("RLPYT_CLIP_ADAM", "1") != "0" and OptimCls is torch.optim.Adam and params and all(
                 p.is_cuda and p.dtype == torch.float32 for p in params)
                 and not any(optim_kwargs.get(k) for k in ("amsgrad", "maximize", "capturable",
                                                           "differentiable"))):

@@ -10,6 +10,7 @@ What changed underneath, relative to the reference's ``optimize_agent``:
 * per-minibatch diagnostics stay on the device; a single D2H per iteration replaces the
   reference's 4 ``.item()`` syncs per minibatch (ppo.py:106-109).
 """
+import os
 import numpy as np
 import torch
 
@@ -136,7 +137,7 @@ class PPO(PolicyGradientAlgo):
                 self.agent, "supports_fused_head_loss", False):
             # heads + softmax + loss + all their gradients in one kernel pass over the trunk
             # (and the trunk's bias + ReLU where the model hands out its pre-activation)
-            if hasattr(self.agent, "trunk_pre"):
+            if hasattr(self.agent, "trunk_pre") and os.environ.get("RLPYT_TRUNK_FUSION", "1") != "0":
                 h, tb, pi_m, v_m = self.agent.trunk_pre(*agent_inputs)
             else:
                 (h, pi_m, v_m), tb = self.agent.trunk(*agent_inputs), None

@@ -75,9 +75,23 @@ __device__ __forceinline__ float load4_issue(const void* p) {
 }
 __device__ __forceinline__ void loads_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // Wait until at most N vector-memory operations issued by this wave are outstanding (they retire
-// in issue order), tying the listed registers to the wait so no use can be scheduled above it.
-#define RLPYT_VMCNT_WAIT4(N, r0, r1, r2, r3) \
-  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)::"memory")
+// in issue order) and only THEN copy the four in-flight 16-byte registers: wait and copies are one
+// asm block, the in-flight registers are pure inputs.  (A "+v"-tied wait let hipcc copy the
+// registers in front of the s_waitcnt -- stale data from the third image of a workgroup on, found
+// as run-to-run differences at M = 8192.)
+#define RLPYT_VMCNT_WAIT_COPY4(N, d0, d1, d2, d3, s0, s1, s2, s3)                                \
+  asm volatile("s_waitcnt vmcnt(" #N ")\n\t"                                                     \
+               "v_mov_b32 %0, %16\n\tv_mov_b32 %1, %17\n\tv_mov_b32 %2, %18\n\tv_mov_b32 %3, %19\n\t"   \
+               "v_mov_b32 %4, %20\n\tv_mov_b32 %5, %21\n\tv_mov_b32 %6, %22\n\tv_mov_b32 %7, %23\n\t"   \
+               "v_mov_b32 %8, %24\n\tv_mov_b32 %9, %25\n\tv_mov_b32 %10, %26\n\tv_mov_b32 %11, %27\n\t" \
+               "v_mov_b32 %12, %28\n\tv_mov_b32 %13, %29\n\tv_mov_b32 %14, %30\n\tv_mov_b32 %15, %31"     \
+               : "=&v"(d0[0]), "=&v"(d0[1]), "=&v"(d0[2]), "=&v"(d0[3]), "=&v"(d1[0]), "=&v"(d1[1]),   \
+                 "=&v"(d1[2]), "=&v"(d1[3]), "=&v"(d2[0]), "=&v"(d2[1]), "=&v"(d2[2]), "=&v"(d2[3]),   \
+                 "=&v"(d3[0]), "=&v"(d3[1]), "=&v"(d3[2]), "=&v"(d3[3])                                \
+               : "v"(s0[0]), "v"(s0[1]), "v"(s0[2]), "v"(s0[3]), "v"(s1[0]), "v"(s1[1]), "v"(s1[2]),   \
+                 "v"(s1[3]), "v"(s2[0]), "v"(s2[1]), "v"(s2[2]), "v"(s2[3]), "v"(s3[0]), "v"(s3[1]),   \
+                 "v"(s3[2]), "v"(s3[3])                                                                \
+               : "memory")
 
 // ---- geometry (AtariFfModel defaults) ------------------------------------------------
 constexpr int C0 = 4, H0 = 104, W0 = 80, HW0 = H0 * W0, IMG = C0 * HW0;  // 33280 B
@@ -469,22 +483,22 @@ __global__ __launch_bounds__(C2X_THREADS) void conv2_fwd_x6_kernel(
   // every staging wait for the HBM round trip of the stores issued just before it (measured:
   // up to 3000 cycles per image).  Every wave issues exactly NPD loads (clamped index) and 2
   // stores per image, and vector-memory operations retire in issue order.
-  u32x4 pdy[NPD];
-  static_assert(NPD == 4, "RLPYT_VMCNT_WAIT4 lists 4 registers");
+  u32x4 pdy[NPD], qdy[NPD];            // in flight / waited-for copy
+  static_assert(NPD == 4, "RLPYT_VMCNT_WAIT_COPY4 lists 4 registers");
 #define RLPYT_C2X_PREFETCH(mi)                                                                 \
   {                                                                                            \
     const u32x4* __restrict__ src_ = reinterpret_cast<const u32x4*>(y1 + (mi) * Y1);           \
     _Pragma("unroll") for (int k = 0; k < NPD; ++k)                                            \
       pdy[k] = load16_issue(src_ + min(tid + k * C2X_THREADS, Y1 / 4 - 1));                    \
   }
-  // registers -> three bf16 pieces in plane buffer b_
+  // (waited-for copies of the) registers -> three bf16 pieces in plane buffer b_
 #define RLPYT_C2X_STAGE(b_)                                                                    \
   _Pragma("unroll") for (int k = 0; k < NPD; ++k) {                                            \
     if (tid + k * C2X_THREADS < Y1 / 4) {                                                      \
       uint32_t p_[3][2];                                                                       \
-      split3_rn(__uint_as_float(pdy[k][0]), __uint_as_float(pdy[k][1]), p_[0][0], p_[1][0],    \
+      split3_rn(__uint_as_float(qdy[k][0]), __uint_as_float(qdy[k][1]), p_[0][0], p_[1][0],    \
                 p_[2][0]);                                                                     \
-      split3_rn(__uint_as_float(pdy[k][2]), __uint_as_float(pdy[k][3]), p_[0][1], p_[1][1],    \
+      split3_rn(__uint_as_float(qdy[k][2]), __uint_as_float(qdy[k][3]), p_[0][1], p_[1][1],    \
                 p_[2][1]);                                                                     \
       _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
         *reinterpret_cast<uint2*>(pl + (b_) * C2X_PL + s_ * C2X_SB + ddst[k]) =                \
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(C2X_THREADS) void conv2_fwd_x6_kernel(
   if ((int64_t)blockIdx.x < M) {
     RLPYT_C2X_PREFETCH((int64_t)blockIdx.x)
     __syncthreads();          // zeroed planes
-    RLPYT_VMCNT_WAIT4(0, pdy[0], pdy[1], pdy[2], pdy[3]);
+    RLPYT_VMCNT_WAIT_COPY4(0, qdy[0], qdy[1], qdy[2], qdy[3], pdy[0], pdy[1], pdy[2], pdy[3]);
     RLPYT_C2X_STAGE(0)
     if ((int64_t)blockIdx.x + gridDim.x < M) RLPYT_C2X_PREFETCH((int64_t)blockIdx.x + gridDim.x)
   }
@@ -541,8 +555,10 @@ __global__ __launch_bounds__(C2X_THREADS) void conv2_fwd_x6_kernel(
     const bool more = m + gridDim.x < M;
 #define RLPYT_C2X_NEXT()                                                                       \
   if (more) {                                                                                  \
-    if (m == (int64_t)blockIdx.x) RLPYT_VMCNT_WAIT4(0, pdy[0], pdy[1], pdy[2], pdy[3]);        \
-    else RLPYT_VMCNT_WAIT4(2, pdy[0], pdy[1], pdy[2], pdy[3]);                                 \
+    if (m == (int64_t)blockIdx.x)                                                              \
+      RLPYT_VMCNT_WAIT_COPY4(0, qdy[0], qdy[1], qdy[2], qdy[3], pdy[0], pdy[1], pdy[2], pdy[3]); \
+    else                                                                                       \
+      RLPYT_VMCNT_WAIT_COPY4(2, qdy[0], qdy[1], qdy[2], qdy[3], pdy[0], pdy[1], pdy[2], pdy[3]); \
     RLPYT_C2X_STAGE(cur ^ 1)                                                                   \
     if (m + 2 * (int64_t)gridDim.x < M) RLPYT_C2X_PREFETCH(m + 2 * (int64_t)gridDim.x)         \
   }

@@ -12,6 +12,7 @@ interchange with the reference.  Other geometries fall back to MIOpen: uint8 obs
 then converted by ``rlpyt_obs_to_nhwc_f32`` into channels-last storage.  On CPU tensors the
 plain torch ops run (used by host-logic tests and example generation only).
 """
+import os
 from collections import namedtuple
 
 import torch
@@ -68,7 +69,8 @@ class AtariFfModel(torch.nn.Module):
             return mods[0]
         return None
 
-    use_split_gemm = True    # set False for the library f32 GEMM in the update trunk (A/B tests)
+    # set False (or RLPYT_SPLIT_GEMM=0) for the library f32 GEMM in the update trunk (A/B tests)
+    use_split_gemm = os.environ.get("RLPYT_SPLIT_GEMM", "1") != "0"
 
     def _trunk_matmul(self, feat, weight):
         """``feat @ weight.T`` of the update: update-size batches go through the bf16x6 GEMM

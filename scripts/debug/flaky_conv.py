@@ -1,0 +1,48 @@
+"""Run each conv kernel repeatedly on identical inputs; report runs whose output differs from the first."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from rlpyt_amd._lib import check, lib, ptr, stream  # noqa: E402
+from rlpyt_amd import ops  # noqa: E402
+
+M, T, B = 8192, 128, 256
+g = torch.Generator().manual_seed(0)
+obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+w1, b1 = (torch.randn(16, 4, 8, 8, generator=g) * 0.05).cuda(), (torch.randn(16, generator=g) * 0.1).cuda()
+w2, b2 = (torch.randn(32, 16, 4, 4, generator=g) * 0.05).cuda(), (torch.randn(32, generator=g) * 0.1).cuda()
+g2 = torch.randn(M, 3456, generator=g).cuda()
+ws = torch.empty(lib.rlpyt_atari_conv_wgrad_workspace_bytes(), dtype=torch.uint8, device="cuda")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+ref = {}
+bad = {k: 0 for k in ("y1", "y2", "dy1", "dw2", "dw1", "gemm")}
+a = torch.randn(M, 3456, generator=g).cuda()
+wt = (torch.randn(512, 3456, generator=g) * 0.02).cuda()
+for it in range(N):
+    idx = torch.randperm(T * B, generator=torch.Generator().manual_seed(5))[:M].cuda()
+    y1 = torch.empty(M, 475, 16, device="cuda")
+    y2 = torch.empty(M, 3456, device="cuda")
+    dy1 = torch.empty_like(y1)
+    dw2, db2 = torch.empty_like(w2), torch.empty_like(b2)
+    dw1, db1 = torch.empty_like(w1), torch.empty_like(b1)
+    check(lib.rlpyt_atari_conv1_fwd_f32(ptr(obs), ptr(idx), T, B, M, ptr(w1), ptr(b1), 1. / 255, ptr(y1), stream()))
+    check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1), M, ptr(w2), ptr(b2), ptr(y2), stream()))
+    check(lib.rlpyt_atari_conv2_bwd_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1), ptr(ws), ptr(dw2), ptr(db2), stream()))
+    check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs), ptr(idx), T, B, M, ptr(dy1), 1. / 255, ptr(ws), ptr(dw1), ptr(db1), stream()))
+    c = ops.gemm_nt(a, wt)
+    # concurrent noise on another stream (a second process sharing the GPU does the same)
+    cur = dict(y1=y1, y2=y2, dy1=dy1, dw2=dw2, dw1=dw1, gemm=c)
+    torch.cuda.synchronize()
+    for k, v in cur.items():
+        if it == 0:
+            ref[k] = v.clone()
+        elif not torch.equal(v, ref[k]):
+            bad[k] += 1
+            d = (v - ref[k]).abs()
+            if bad[k] <= 2:
+                nz = (d > 0).nonzero()
+                print(f"run {it}: {k} differs at {nz.shape[0]} elements, max diff {d.max().item():.3e}, "
+                      f"max |val| {v.abs().max().item():.3e}, first idx {nz[0].tolist()}", flush=True)
+print("mismatching runs out of", N - 1, ":", bad)

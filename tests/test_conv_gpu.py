@@ -49,7 +49,10 @@ def _close(actual, desired, rel=2e-5, what=""):
     assert err <= tol, f"{what}: max err {err:.3e} > tol {tol:.3e} (max ref {np.abs(d).max():.3e})"
 
 
-@pytest.mark.parametrize("M", [1, 7, 200, 300])
+# 1100: five images per persistent workgroup (256 CUs) -- the steady-state iterations of the
+# software pipelines (register prefetch two images ahead, hand-counted vmcnt waits, LDS double
+# buffers) only exist from the third image of a workgroup on
+@pytest.mark.parametrize("M", [1, 7, 200, 300, 1100])
 def test_conv_forward_kernels(ops, M):
     from rlpyt_amd._lib import check, lib, ptr, stream
     g = torch.Generator().manual_seed(M)
@@ -92,7 +95,7 @@ def test_conv_identity_weights_asymmetric(ops):
         np.testing.assert_allclose(y1[..., co].numpy(), exp.numpy(), rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("M", [1, 5, 700])
+@pytest.mark.parametrize("M", [1, 5, 700, 1100])
 def test_conv_backward_kernels(ops, M):
     from rlpyt_amd._lib import check, lib, ptr, stream
     g = torch.Generator().manual_seed(100 + M)
@@ -406,3 +409,47 @@ def test_linear_nobias_autograd(ops):
     _close(y, F.linear(x64, w64), rel=3e-6, what="linear_nobias fwd")
     _close(x.grad, x64.grad, rel=3e-6, what="linear_nobias dx")
     _close(w.grad, w64.grad, rel=2e-5, what="linear_nobias dw")
+
+
+def test_conv_kernels_run_to_run_identical_at_update_size(ops):
+    """Every conv kernel and the trunk GEMM at the update's M = 8192 (32 images per persistent
+    workgroup), ten launches on identical inputs: bit-identical outputs.  (A stale-register bug in
+    a hand-waited prefetch showed up exactly here -- from the third image of a workgroup on --
+    while every small-M parity test passed.)"""
+    from rlpyt_amd._lib import check, lib, ptr, stream
+    M, T, B = 8192, 64, 160
+    g = torch.Generator().manual_seed(0)
+    obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    idx = torch.randperm(T * B, generator=g)[:M].cuda()
+    w1, b1 = (torch.randn(16, 4, 8, 8, generator=g) * 0.05).cuda(), (torch.randn(16, generator=g) * 0.1).cuda()
+    w2, b2 = (torch.randn(32, 16, 4, 4, generator=g) * 0.05).cuda(), (torch.randn(32, generator=g) * 0.1).cuda()
+    g2 = torch.randn(M, 3456, generator=g).cuda()
+    a = torch.randn(M, 3456, generator=g).cuda()
+    wt = (torch.randn(512, 3456, generator=g) * 0.02).cuda()
+    ws = torch.empty(lib.rlpyt_atari_conv_wgrad_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    ref = None
+    for it in range(10):
+        y1 = torch.empty(M, 475, 16, device="cuda")
+        y2 = torch.empty(M, 3456, device="cuda")
+        dy1 = torch.empty_like(y1)
+        dw2, db2, dw1, db1 = (torch.empty_like(t) for t in (w2, b2, w1, b1))
+        check(lib.rlpyt_atari_conv1_fwd_f32(ptr(obs), ptr(idx), T, B, M, ptr(w1), ptr(b1), 1. / 255,
+                                            ptr(y1), stream()))
+        check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1), M, ptr(w2), ptr(b2), ptr(y2), stream()))
+        check(lib.rlpyt_atari_conv2_bwd_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1), ptr(ws),
+                                            ptr(dw2), ptr(db2), stream()))
+        check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs), ptr(idx), T, B, M, ptr(dy1), 1. / 255, ptr(ws),
+                                              ptr(dw1), ptr(db1), stream()))
+        cur = dict(y1=y1, y2=y2, dy1=dy1, dw2=dw2, db2=db2, dw1=dw1, db1=db1, gemm=ops.gemm_nt(a, wt))
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = {k: v.clone() for k, v in cur.items()}
+            # and the last images of the batch are right (float64 reference of 64 of them)
+            sel = idx[-64:]
+            x = obs.reshape(T * B, 4, 104, 80)[(sel % T) * B + sel // T].double() / 255
+            r1 = F.relu(F.conv2d(x, w1.double(), b1.double(), stride=4))
+            r2 = F.relu(F.conv2d(r1, w2.double(), b2.double(), stride=2, padding=1))
+            _close(y2[-64:], r2.reshape(64, -1), what="conv stack, last 64 images of M = 8192")
+        else:
+            for k, v in cur.items():
+                assert torch.equal(v, ref[k]), (k, it)
