@@ -313,7 +313,7 @@ def main():
                         "per_batch_ms": {k[:-2]: sampler.timing[k] / args.steps * 1e3
                                          for k in ("pre_s", "loop_s", "tail_s", "post_s")}},
             "last_loss": opt_info.loss[-1] if opt_info.loss else None,
-            "losses_finite": bool(np.isfinite(np.asarray(opt_info.loss, dtype=np.float64)).all()),
+            "losses_finite": all(x == x and abs(x) != float("inf") for x in opt_info.loss),
         }
         out["config"]["env_worker_cpus"] = ("pinned (affinity['workers_cpus'])" if args.pin_workers
                                             else "not pinned (set_affinity=False)")
