@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256) void norm_pass3_kernel(float* __restrict__ x, 
 constexpr int kHeadAMax = 8;
 constexpr int kHeadWavesPerBlock = 4;
 
-template <int KI, int AM>  // K = 64 * KI; AM = action slots held in registers (>= A): 4, 6 or 8.
+template <int KI, int AM, bool TB>  // K = 64 * KI; AM = action slots held in registers (>= A): 4, 6
+                                    // or 8; TB = trunk bias + ReLU fused in (compile-time: as a runtime
+                                    // flag its selects cost 18 us at M = 8192)
 // Two 4-wave workgroups per CU need <= 256 VGPRs per wave: with AM = 8 for every A the 2 x 8 x KI
 // weight and weight-gradient registers pushed the kernel to 1 wave per SIMD (measured 2x slower).
 __global__ __launch_bounds__(64 * kHeadWavesPerBlock, 2) void ppo_head_loss_kernel(
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock, 2) void ppo_head_loss_kern
   // ReLU, ReLU backward and bias-gradient reduction (4 launches, ~45 us at M = 8192) disappear.
   __shared__ double scratch[6 * 16];
   constexpr int K = 64 * KI;
-  const bool has_tb = trunk_bias != nullptr;   // kernel argument: uniform
+  constexpr bool has_tb = TB;
   double denom = (double)M;
   if (valid != nullptr) denom = sum_partials(ws->valid_part, n_valid_part, scratch);
   const float inv = (float)(1.0 / denom);
@@ -784,17 +786,22 @@ extern "C" int rlpyt_ppo_trunk_head_loss_fwd_bwd_f32(
   const int n_waves = grid * kHeadWavesPerBlock;
   const int part = A * K + K + A + 1 + (trunk_bias != nullptr ? K : 0);
   const size_t lds = (size_t)3 * ((kHeadAMax + 2) * K + kHeadAMax + 1) * sizeof(float);
+#define RL_HEAD_TB(KI_, AM_, TB_)                                                                 \
+  RL_LAUNCH((ppo_head_loss_kernel<KI_, AM_, TB_>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, \
+            s, h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A,          \
+            ratio_clip, value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws, n_valid_part,      \
+            flat_idx, T, B, trunk_bias)
 #define RL_HEAD(KI_, AM_)                                                                         \
-  RL_LAUNCH((ppo_head_loss_kernel<KI_, AM_>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, s, h, \
-            w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A, ratio_clip,    \
-            value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws, n_valid_part, flat_idx, T, B, \
-            trunk_bias)
+  do {                                                                                            \
+    if (trunk_bias != nullptr) RL_HEAD_TB(KI_, AM_, true); else RL_HEAD_TB(KI_, AM_, false);        \
+  } while (0)
   if (K == 512) {
     if (A <= 4) RL_HEAD(8, 4); else if (A <= 6) RL_HEAD(8, 6); else RL_HEAD(8, 8);
   } else {
     if (A <= 4) RL_HEAD(4, 4); else if (A <= 6) RL_HEAD(4, 6); else RL_HEAD(4, 8);
   }
 #undef RL_HEAD
+#undef RL_HEAD_TB
   RL_LAUNCH_CHECK();
   RL_LAUNCH(head_reduce_kernel, dim3((part + 63) / 64), dim3(1024), 0, s, wpart, grid,
                      part, grad_params);

@@ -228,9 +228,42 @@ def _head_loss_case(K, A=6):
     return run
 
 
+def _trunk_head_loss_case(K, A):
+    def run():
+        """The same with the trunk's bias add + ReLU fused in (pre-activation in, dL/dz and the
+        trunk-bias gradient out) against the same statements in f64."""
+        ops = _ops()
+        g = torch.Generator().manual_seed(3 * K + A)
+        M = 300
+        z = torch.randn(M, K, generator=g)
+        tb = torch.randn(K, generator=g) * 0.3
+        wp, bp = torch.randn(A, K, generator=g) * 0.05, torch.randn(A, generator=g) * 0.1
+        wv, bv = torch.randn(1, K, generator=g) * 0.05, torch.randn(1, generator=g) * 0.1
+        po = torch.softmax(torch.randn(M, A, generator=g), -1)
+        act = torch.randint(0, A, (M,), generator=g)
+        adv, ret = torch.randn(M, generator=g), torch.randn(M, generator=g)
+        ref_in = [t.double().requires_grad_(True) for t in (z, wp, bp, wv, bv, tb)]
+        hh = torch.relu(ref_in[0] + ref_in[5])
+        pn = torch.softmax(hh @ ref_in[1].t() + ref_in[2], -1)
+        v = (hh @ ref_in[3].t()).squeeze(-1) + ref_in[4]
+        ref = O.ppo_loss_torch(pn, v, po.double(), act, adv.double(), ret.double(), None, 0.1, 1.0, 0.01)
+        ref[0].backward()
+        d_in = [t.cuda().requires_grad_(True) for t in (z, wp, bp, wv, bv, tb)]
+        loss, sc = ops.ppo_head_loss(*d_in[:5], po.cuda(), act.cuda(), adv.cuda(), ret.cuda(), None,
+                                     0.1, 1.0, 0.01, trunk_bias=d_in[5])
+        loss.backward()
+        np.testing.assert_allclose(host(sc), [x.item() for x in ref], rtol=2e-5, atol=1e-6)
+        for a, b in zip(d_in, ref_in):
+            rg = b.grad.numpy()
+            np.testing.assert_allclose(host(a.grad), rg, rtol=1e-4,
+                                       atol=2e-6 * float(np.abs(rg).max()) + 1e-9)
+    return run
+
+
 for _ki, _K in ((8, 512), (4, 256)):
     for _am, _A in ((4, 3), (6, 6), (8, 8)):      # action slots held in registers: A <= 4, <= 6, <= 8
-        CASES[f"ppo_head_loss_kernel<{_ki}, {_am}>"] = _head_loss_case(_K, _A)
+        CASES[f"ppo_head_loss_kernel<{_ki}, {_am}, false>"] = _head_loss_case(_K, _A)
+        CASES[f"ppo_head_loss_kernel<{_ki}, {_am}, true>"] = _trunk_head_loss_case(_K, _A)
 CASES["head_reduce_kernel"] = _head_loss_case(512)
 
 
