@@ -1,18 +1,24 @@
-// AtariFfModel convolution stack on gfx950 fp32 MFMA (rlpyt/models/pg/atari_ff_model.py:40-63,
+// AtariFfModel convolution stack on the gfx950 matrix pipes (rlpyt/models/pg/atari_ff_model.py:40-63,
 // rlpyt/models/conv2d.py:8-117): the only dense contraction on the PPO hot path.
 //
 //   obs u8[4,104,80] --(x 1/255)--> conv1 4->16 k8 s4 p0 + bias + ReLU -> y1 [25*19, 16] (NHWC)
 //                                   conv2 16->32 k4 s2 p1 + bias + ReLU -> y2 [32, 12*9]  (NCHW flat,
 //                                   i.e. exactly the 3456-feature order nn.Linear's weight expects)
 //
-// Forward and backward are implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact f32 FMA chains,
-// 64 FLOP/clk/SIMD = the chip's f32 peak).  One workgroup owns one image at a time: the
-// image (or its activations / gradients) is staged once in LDS, the *weights* of the
-// contraction live in VGPRs as MFMA operands for the whole kernel, and the patch matrix is
-// never materialised -- every MFMA operand element is read from LDS at the address the
-// convolution geometry dictates.  uint8 -> f32 conversion, the minibatch gather
-// idx -> (idx % T, idx / T), the 1/255 scale, bias, ReLU (forward) and the ReLU masks
-// (backward) are fused into those kernels, so the f32 image never exists in HBM.
+// Forward and backward are implicit GEMMs on the matrix pipes.  One workgroup owns one image at a
+// time: the image (or its activations / gradients) is staged once in LDS, the *weights* of the
+// contraction live in VGPRs as MFMA operands for the whole kernel, and the patch matrix is never
+// materialised -- every MFMA operand element is read from LDS at the address the convolution
+// geometry dictates.  uint8 conversion, the minibatch gather idx -> (idx % T, idx / T), the 1/255
+// scale, bias, ReLU (forward) and the ReLU masks (backward) are fused into those kernels, so the
+// f32 image never exists in HBM.
+//
+// Arithmetic: conv2 backward and the latency-bound sampling kernel run exact f32
+// FMA chains on v_mfma_f32_16x16x4_f32 (64 FLOP/clk/SIMD, the chip's f32 peak).  conv1 forward,
+// conv1 weight gradient (bf16x3: the uint8 operand is exact in bf16, the f32 operand is split into
+// three bf16 pieces whose sum is exact) and conv2 forward at update sizes (bf16x6: both operands
+// split, six products, dropped terms <= 2^-26) run on v_mfma_f32_*_bf16 with f32 accumulation --
+// f32 in, f32 out, f32-level error, 2.7-5.3x less matrix-pipe time.
 //
 // MFMA 16x16x4 f32 operand map (cdna_hip_programming.md section 3): lane l supplies
 // A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; it receives
@@ -824,28 +830,6 @@ constexpr int GS_B = 124;
 constexpr int B2_GM = C2 * GS_B, B2_PAD = PPIX * PS_W;          // floats per buffer
 constexpr int B2_TABP = 176;                                    // pixel slots per class in the tile table (9 tiles + 2 of look-ahead)
 
-// Debug build (-DRLPYT_B2_TIMING): per-wave cycle totals of the phases of an image iteration are
-// written behind the partial rows (scripts/debug/bwd_timing.py reads them); off in the product.
-#ifdef RLPYT_B2_TIMING
-#define B2_T0() long long t_prev_ = clock64(), t_acc_[6] = {0, 0, 0, 0, 0, 0};
-#define B2_T(k)                                  \
-  {                                              \
-    const long long t_now_ = clock64();          \
-    t_acc_[k] += t_now_ - t_prev_;               \
-    t_prev_ = t_now_;                            \
-  }
-#define B2_TOUT()                                                                        \
-  if (lane == 0) {                                                                       \
-    float* dbg_ = partial + (int64_t)(kPartialRowsDbg + blockIdx.x) * PART2 + wave * 8;  \
-    for (int k = 0; k < 6; ++k) dbg_[k] = (float)t_acc_[k];                              \
-  }
-constexpr int kPartialRowsDbg = 256;
-#else
-#define B2_T0()
-#define B2_T(k)
-#define B2_TOUT()
-#endif
-
 __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
     const float* __restrict__ g2, const float* __restrict__ y2, const float* __restrict__ y1,
     const float* __restrict__ w2, float* __restrict__ dy1, float* __restrict__ partial, int64_t M) {
@@ -971,11 +955,11 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
     const int4* tab = reinterpret_cast<const int4*>(dtab_) + (q * B2_TABP + j) * 2;
     const int kq_gm = 4 * kq * GS_B, kq4 = 4 * kq;
     int cur = 0;
-    B2_T0()
+    RL_T0()
     for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
       const bool more = m + gridDim.x < M;
       if (more) RLPYT_B2_PREFETCH_D(m + gridDim.x)  // (the wgrad waves issue theirs 2 groups later)
-      B2_T(0)
+      RL_T(0)
       const float* gm = gm_ + cur * B2_GM + kq_gm;
       const float* pad = pad_ + cur * B2_PAD + kq4;
       float* dyimg = dy1 + m * Y1 + kq4;
@@ -1044,10 +1028,10 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
       dgrad_tile(b2, b0, b1, 2);
       dgrad_tile(b0, b1, b2, 3);
       dgrad_tile(b1, b2, b0, 4);
-      B2_T(1)
+      RL_T(1)
       if (more)                                   // registers -> the other buffer, mid-stream
         RLPYT_B2_STAGE_D(gm_ + (cur ^ 1) * B2_GM, pad_ + (cur ^ 1) * B2_PAD)
-      B2_T(2)
+      RL_T(2)
       dgrad_tile(b2, b0, b1, 5);
       dgrad_tile(b0, b1, b2, 6);
 #undef RLPYT_B2_TAP
@@ -1057,12 +1041,12 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
         for (int r = 0; r < 4; ++r) o[r] = yvp[r] > 0.f ? a0p[r] + a1p[r] : 0.f;
         *reinterpret_cast<f32x4*>(dyimg + pixp) = o;
       }
-      B2_T(3)
+      RL_T(3)
 #undef RLPYT_B2_DLOAD
       __syncthreads();   // every wave is done with buffer `cur` and has filled the other one
-      B2_T(4)
+      RL_T(4)
     }
-    B2_TOUT()
+    RL_TOUT()
     return;
   }
   // ============================ wgrad role: ky = q =========================================
@@ -1107,10 +1091,10 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
   const int xkq_gm = 4 * kq * GS_B, xkq4 = 4 * kq;
   {
     int cur = 0;
-    B2_T0()
+    RL_T0()
     for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
       const bool more = m + gridDim.x < M;
-      B2_T(0)
+      RL_T(0)
       const float* gm = gm_ + cur * B2_GM;
       const float* pad = pad_ + cur * B2_PAD;
       {   // ---- the spare dgrad tile (same contraction as dgrad_tile above, not pipelined) -------
@@ -1216,21 +1200,21 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
       if (more) RLPYT_B2_PREFETCH_W(m + gridDim.x)
 #pragma unroll 1
       for (int sg = 2; sg < 5; ++sg) wgrad_group(sg);
-      B2_T(1)
+      RL_T(1)
       if (more)                                   // registers -> the other buffer, mid-stream
         RLPYT_B2_STAGE_W(gm_ + (cur ^ 1) * B2_GM, pad_ + (cur ^ 1) * B2_PAD)
-      B2_T(2)
+      RL_T(2)
 #pragma unroll 1
       for (int sg = 5; sg < nsg; ++sg) wgrad_group(sg);
-      B2_T(3)
+      RL_T(3)
 #undef RLPYT_B2_WMMA
 #undef RLPYT_B2_WPATTERN
 #undef RLPYT_B2_ALOAD
 #undef RLPYT_B2_WLOAD
       __syncthreads();   // every wave is done with buffer `cur` and has filled the other one
-      B2_T(4)
+      RL_T(4)
     }
-    B2_TOUT()
+    RL_TOUT()
   }
 #undef RLPYT_B2_PREFETCH_R
 #undef RLPYT_B2_STAGE_R

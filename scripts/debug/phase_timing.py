@@ -1,5 +1,5 @@
 """Per-wave phase cycles of a persistent conv kernel (needs a -DRLPYT_TIMING build of conv.hip).
-usage: phase_timing.py conv1_wgrad|conv1_fwd|conv2_fwd  [n_waves]"""
+usage: phase_timing.py conv1_wgrad|conv1_fwd|conv2_fwd|conv2_bwd  [n_waves]"""
 import ctypes
 import os
 import sys
@@ -22,12 +22,17 @@ w1, b1 = torch.randn(16, 4, 8, 8, device="cuda") * 0.05, torch.randn(16, device=
 w2, b2 = torch.randn(32, 16, 4, 4, device="cuda") * 0.05, torch.randn(32, device="cuda")
 ws = torch.zeros(lib.rlpyt_atari_conv_wgrad_workspace_bytes() // 4, dtype=torch.float32, device="cuda")
 dw1, db1 = torch.empty(16, 4, 8, 8, device="cuda"), torch.empty(16, device="cuda")
+g2, y2b = torch.randn(M, 3456, device="cuda"), torch.rand(M, 3456, device="cuda") - 0.3
+dy1o = torch.empty(M, 475, 16, device="cuda")
+dw2, db2 = torch.empty(32, 16, 4, 4, device="cuda"), torch.empty(32, device="cuda")
 calls = {
     "conv1_wgrad": lambda: lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs), ptr(idx), T, B, M, ptr(dy1), 1. / 255,
                                                            ptr(ws), ptr(dw1), ptr(db1), stream()),
     "conv1_fwd": lambda: lib.rlpyt_atari_conv1_fwd_f32(ptr(obs), ptr(idx), T, B, M, ptr(w1), ptr(b1),
                                                        1. / 255, ptr(y1), stream()),
     "conv2_fwd": lambda: lib.rlpyt_atari_conv2_fwd_f32(ptr(y1), M, ptr(w2), ptr(b2), ptr(y2), stream()),
+    "conv2_bwd": lambda: lib.rlpyt_atari_conv2_bwd_f32(ptr(g2), ptr(y2b), ptr(y1), M, ptr(w2), ptr(dy1o), ptr(ws),
+                                                       ptr(dw2), ptr(db2), stream()),
 }
 for _ in range(3):
     check(calls[which]())
