@@ -45,30 +45,39 @@ __device__ __forceinline__ void split3_rn(float x0, float x1, uint32_t& hi, uint
   lo = cvt_pk_bf16(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
 }
 
-constexpr int GT = 128;                  // tile edge
+constexpr int GT = 128;                  // column-tile edge (and row-tile edge of the small variant)
 constexpr int G_THREADS = 512;
-#ifndef RLPYT_G_BK
-#define RLPYT_G_BK 16
-#endif
-constexpr int G_BK = RLPYT_G_BK;         // K per barrier step (16 or 32)
+constexpr int G_BK = 16;                 // K per barrier step
 constexpr int G_ROWB = 2 * G_BK + 16;    // bytes per (piece, row) of a K-step: data + 16 B pad
-constexpr int G_PB = GT * G_ROWB;        // bytes per piece
-constexpr int G_OB = 3 * G_PB;           // per operand
-constexpr int G_SB = 2 * G_OB;           // per stage: 36,864 B (BK 16) / 61,440 B (BK 32)
-constexpr int G_NF = GT * G_BK / 4 / G_THREADS;   // float4 per thread, operand and K-step: 1 / 2
 
+// TM = rows of C per workgroup: 128 (wave = 64 x 32) or 256 (wave = 64 x 64).  The kernel is bound
+// by the CU's load path (~9 B/clk/CU measured: 16 KB per K-step of a 128 x 128 tile = 1780 cycles,
+// 2.3x the matrix-pipe time); a 256 x 128 tile loads 24 KB for twice the MFMAs.  Used where the
+// shape has enough 256-row tiles to fill the chip (the input gradient: 32 x 27); the forward shape
+// (4 M outputs) is one 128 x 128 tile per CU.  For TM = 256 three padded LDS stages would need
+// 166 KB, so the B operand is stored unpadded (32 B per row) with its two 16-byte K halves swapped
+// in every other group of 4 rows -- conflict-free for the 8-lane groups of ds_read_b128 as well.
+template <int TM>
 __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
     int K, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * G_SB];
+  constexpr bool BSW = TM == 256;                    // swizzled unpadded B
+  constexpr int ROWB_B = BSW ? 2 * G_BK : G_ROWB;
+  constexpr int PB_A = TM * G_ROWB, PB_B = GT * ROWB_B;      // bytes per piece
+  constexpr int OB_A = 3 * PB_A, SB = OB_A + 3 * PB_B;       // B operand offset, stage bytes
+  constexpr int NA = TM * 4 / G_THREADS;             // float4 of A per thread and K-step: 1 / 2
+  constexpr int WM = TM / 64, WN = 8 / WM;           // wave grid: 2 x 4 / 4 x 2
+  constexpr int TNW = GT / WN, NJ = TNW / 32;        // wave tile columns 32 / 64: 1 / 2 MFMA tiles
+  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * SB];
+  static_assert(3 * SB <= 160 * 1024, "three stages fit the LDS");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1;      // wave tile: rows 64 wm .. + 63, columns 32 wn .. + 31
+  const int wm = wave % WM, wn = wave / WM;     // wave tile: rows 64 wm .. + 63, columns TNW wn ..
   // XCD-aware tile map.  Workgroup ids go round-robin over the 8 XCDs (4 MB of L2 each, 32 CUs =
   // 32 concurrent workgroups).  Every XCD owns tiles_m / 8 row blocks and walks them in panels
   // of (its row blocks) x (4 column tiles): the workgroups running together then share
-  // 8 A row-block tiles and 4 B column tiles (3 MB at K = 512) instead of one A tile and 27
-  // different B tiles (all of W^T, 7 MB: re-streamed past the L2 for every row block).
+  // few A row-block tiles and 4 B column tiles instead of one A tile and 27 different B tiles
+  // (all of W^T, 7 MB: re-streamed past the L2 for every row block).
   const int n_tiles = tiles_m * tiles_n;
   int tm, tn;
   if ((tiles_m & 7) == 0) {
@@ -85,59 +94,74 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
     tn = tile - tm * tiles_n;
   }
 
-  // staging map: float4 f = tid + 512 i = (row = f / (BK / 4), kq = f % (BK / 4)); rows clamped
-  const float* ga[G_NF];
-  const float* gb[G_NF];
-  int sdst[G_NF];
+  // staging map: float4 f = tid + 512 i = (row = f >> 2, kq = f & 3); rows clamped at the edge
+  const float* ga[NA];
+  int sdst_a[NA];
 #pragma unroll
-  for (int i = 0; i < G_NF; ++i) {
-    const int f = tid + G_THREADS * i, row = f / (G_BK / 4), kq = f % (G_BK / 4);
-    ga[i] = A + (int64_t)min(tm * GT + row, M - 1) * K + 4 * kq;
-    gb[i] = B + (int64_t)min(tn * GT + row, N - 1) * K + 4 * kq;
-    sdst[i] = row * G_ROWB + kq * 8;
+  for (int i = 0; i < NA; ++i) {
+    const int f = tid + G_THREADS * i, row = f >> 2, kq = f & 3;
+    ga[i] = A + (int64_t)min(tm * TM + row, M - 1) * K + 4 * kq;
+    sdst_a[i] = row * G_ROWB + kq * 8;
   }
+  const int brow = tid >> 2, bkq = tid & 3;
+  const float* gb = B + (int64_t)min(tn * GT + brow, N - 1) * K + 4 * bkq;
+  // swizzle: 16-byte half (bkq >> 1) of row r goes to half ^ ((r >> 2) & 1)
+  const int sdst_b = OB_A + brow * ROWB_B +
+                     (BSW ? ((((bkq >> 1) ^ ((brow >> 2) & 1)) << 4) | ((bkq & 1) << 3)) : bkq * 8);
   // two register sets: the rows of step s are requested two steps before they are split
-  f32x4 ra0[G_NF], rb0[G_NF], ra1[G_NF], rb1[G_NF];
+  f32x4 ra0[NA], ra1[NA], rb0, rb1;
 #define RLPYT_G_FETCH(ra, rb, k0_)                                                             \
-  _Pragma("unroll") for (int i = 0; i < G_NF; ++i) {                                           \
-    ra[i] = *reinterpret_cast<const f32x4*>(ga[i] + (k0_));                                    \
-    rb[i] = *reinterpret_cast<const f32x4*>(gb[i] + (k0_));                                    \
+  {                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i)                                             \
+      ra[i] = *reinterpret_cast<const f32x4*>(ga[i] + (k0_));                                  \
+    rb = *reinterpret_cast<const f32x4*>(gb + (k0_));                                          \
   }
 #define RLPYT_G_STAGE(ra, rb, st_)                                                             \
-  _Pragma("unroll") for (int i = 0; i < G_NF; ++i) {                                           \
-    uint32_t p_[3][2], q_[3][2];                                                               \
-    split3_rn(ra[i][0], ra[i][1], p_[0][0], p_[1][0], p_[2][0]);                               \
-    split3_rn(ra[i][2], ra[i][3], p_[0][1], p_[1][1], p_[2][1]);                               \
-    split3_rn(rb[i][0], rb[i][1], q_[0][0], q_[1][0], q_[2][0]);                               \
-    split3_rn(rb[i][2], rb[i][3], q_[0][1], q_[1][1], q_[2][1]);                               \
-    uint8_t* d_ = lds + (st_) * G_SB + sdst[i];                                                \
-    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                         \
-      *reinterpret_cast<uint2*>(d_ + s_ * G_PB) = uint2{p_[s_][0], p_[s_][1]};                 \
-      *reinterpret_cast<uint2*>(d_ + G_OB + s_ * G_PB) = uint2{q_[s_][0], q_[s_][1]};          \
+  {                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
+      uint32_t p_[3][2];                                                                       \
+      split3_rn(ra[i][0], ra[i][1], p_[0][0], p_[1][0], p_[2][0]);                             \
+      split3_rn(ra[i][2], ra[i][3], p_[0][1], p_[1][1], p_[2][1]);                             \
+      uint8_t* d_ = lds + (st_) * SB + sdst_a[i];                                              \
+      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
+        *reinterpret_cast<uint2*>(d_ + s_ * PB_A) = uint2{p_[s_][0], p_[s_][1]};               \
     }                                                                                          \
+    uint32_t q_[3][2];                                                                         \
+    split3_rn(rb[0], rb[1], q_[0][0], q_[1][0], q_[2][0]);                                     \
+    split3_rn(rb[2], rb[3], q_[0][1], q_[1][1], q_[2][1]);                                     \
+    uint8_t* e_ = lds + (st_) * SB + sdst_b;                                                   \
+    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                           \
+      *reinterpret_cast<uint2*>(e_ + s_ * PB_B) = uint2{q_[s_][0], q_[s_][1]};                 \
   }
-  f32x16 acc[2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // operand addresses of this lane: row (column) l & 31 of the MFMA tile, K half l >> 5
   const int a_off = (wm * 64 + (lane & 31)) * G_ROWB + (lane >> 5) * 16;
-  const int b_off = G_OB + (wn * 32 + (lane & 31)) * G_ROWB + (lane >> 5) * 16;
-  // fragments of one K-step: 3 pieces x (2 row tiles of A + 1 column tile of B)
-#define RLPYT_G_FRAGS(af_, bf_, st_)                                                           \
-  _Pragma("unroll") for (int h = 0; h < G_BK / 16; ++h)                                        \
-  _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                              \
-    bf_[h][s] = *reinterpret_cast<const uint4*>(lds + (st_) * G_SB + b_off + h * 32 + s * G_PB); \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
-      af_[h][i][s] = *reinterpret_cast<const uint4*>(lds + (st_) * G_SB + a_off +              \
-                                                     i * 32 * G_ROWB + h * 32 + s * G_PB);     \
+  int b_off[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = wn * TNW + 32 * j + (lane & 31);
+    b_off[j] = OB_A + col * ROWB_B + (BSW ? (((lane >> 5) ^ ((col >> 2) & 1)) << 4) : (lane >> 5) * 16);
   }
-  // six products per tile and K-half, smallest first
+  // fragments of one K-step: 3 pieces x (2 row tiles of A + NJ column tiles of B)
+#define RLPYT_G_FRAGS(af_, bf_, st_)                                                           \
+  _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                              \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                             \
+      bf_[j][s] = *reinterpret_cast<const uint4*>(lds + (st_) * SB + b_off[j] + s * PB_B);     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
+      af_[i][s] = *reinterpret_cast<const uint4*>(lds + (st_) * SB + a_off +                   \
+                                                  i * 32 * G_ROWB + s * PB_A);                 \
+  }
+  // six products per tile, smallest first
 #define RLPYT_G_TERM(af_, bf_, sa_, sb_)                                                       \
-  _Pragma("unroll") for (int h = 0; h < G_BK / 16; ++h)                                        \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
-    acc[i] = mfma32_bf16(af_[h][i][sa_], bf_[h][sb_], acc[i]);
+  _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                               \
+    acc[i][j] = mfma32_bf16(af_[i][sa_], bf_[j][sb_], acc[i][j]);
 #define RLPYT_G_MMA(af_, bf_)                                                                  \
   RLPYT_G_TERM(af_, bf_, 2, 0)                                                                 \
   RLPYT_G_TERM(af_, bf_, 0, 2)                                                                 \
@@ -152,7 +176,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
   // all 8 waves started together right after every barrier and the matrix pipe waited for the LDS
   // queue to drain (~40 % of every step, measured 190-200 us for the trunk shapes).
   const int nk = K / G_BK;
-  uint4 af0[G_BK / 16][2][3], bf0[G_BK / 16][3], af1[G_BK / 16][2][3], bf1[G_BK / 16][3];
+  uint4 af0[2][3], bf0[NJ][3], af1[2][3], bf1[NJ][3];
   RLPYT_G_FETCH(ra0, rb0, 0)
   if (nk > 1) RLPYT_G_FETCH(ra1, rb1, G_BK)
   RLPYT_G_STAGE(ra0, rb0, 0)
@@ -164,6 +188,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
   int st_next = 1, st_write = 2;     // stage of step ks + 1 / of step ks + 2
   // one step: prefetch the next fragments, MFMAs on the current ones with the split of step
   // ks + 2 in their gaps, then request step ks + 4 into the registers just consumed
+  constexpr int NMMA = 12 * NJ;                          // MFMAs per step
+  constexpr int NV = (22 * (NA + 1) + NMMA - 1) / NMMA;  // split VALU per MFMA gap: 4 / 3
 #define RLPYT_G_STEP(afc_, bfc_, afn_, bfn_, ra, rb, ks_)                                      \
   {                                                                                            \
     __syncthreads();   /* stage of step ks + 1 complete; stage of step ks + 2 free */          \
@@ -171,11 +197,11 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
     __builtin_amdgcn_sched_barrier(0);                                                         \
     RLPYT_G_MMA(afc_, bfc_)                                                                    \
     RLPYT_G_STAGE(ra, rb, st_write)      /* (past the last step: into a stage nobody reads) */ \
-    /* the split (44 VALU per K-16) goes BETWEEN the MFMAs, 4 per gap: issued as a block it  */ \
-    /* runs while the matrix pipe idles (both waves of a SIMD are in the same phase)          */ \
-    _Pragma("unroll") for (int g_ = 0; g_ < 12 * (G_BK / 16); ++g_) {                          \
+    /* the split VALU goes BETWEEN the MFMAs, NV per gap: issued as a block it runs while   */ \
+    /* the matrix pipe idles (both waves of a SIMD are in the same phase)                     */ \
+    _Pragma("unroll") for (int g_ = 0; g_ < NMMA; ++g_) {                                      \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                       \
+      __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                                      \
     }                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                         \
     if ((ks_) + 4 < nk) RLPYT_G_FETCH(ra, rb, ((ks_) + 4) * G_BK)                              \
@@ -195,14 +221,17 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
 #undef RLPYT_G_FRAGS
 #undef RLPYT_G_STAGE
 #undef RLPYT_G_FETCH
-  // D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31] of tile i
-  const int col = tn * GT + wn * 32 + (lane & 31);
+  // D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31] of tile (i, j)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = tm * GT + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < M && col < N) C[(int64_t)row * N + col] = acc[i][r];
+    for (int j = 0; j < NJ; ++j) {
+      const int col = tn * GT + wn * TNW + 32 * j + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tm * TM + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) C[(int64_t)row * N + col] = acc[i][j][r];
+      }
     }
 }
 
@@ -214,17 +243,26 @@ using namespace rlpyt;
 extern "C" int rlpyt_gemm_nt_f32(const float* a, const float* b, float* c, int64_t M, int64_t N,
                                  int64_t K, rlpyt_stream_t stream) {
   RL_CHECK_ARG(a && b && c, RLPYT_EINVAL, "rlpyt_gemm_nt_f32: null pointer");
-  RL_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % G_BK == 0 && M < (1 << 30) && N < (1 << 30) &&
+  RL_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 32 == 0 && M < (1 << 30) && N < (1 << 30) &&
                    K < (1 << 30),
                RLPYT_ESHAPE, "rlpyt_gemm_nt_f32: need M, N > 0 and K a positive multiple of 32 "
                              "(M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
   RL_CHECK_ARG((reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0,
                RLPYT_ESHAPE, "rlpyt_gemm_nt_f32: a / b must be 16-byte aligned");
-  const int tiles_m = (int)ceil_div(M, GT), tiles_n = (int)ceil_div(N, GT);
-  const int n_tiles = tiles_m * tiles_n;
-  const int grid = 8 * ((n_tiles + 7) / 8);     // whole rounds over the 8 XCDs
-  RL_LAUNCH(gemm_nt_x6_kernel, dim3(grid), dim3(G_THREADS), 0, (hipStream_t)stream, a, b, c, (int)M,
-            (int)N, (int)K, tiles_m, tiles_n);
+  const int tiles_n = (int)ceil_div(N, GT);
+  hipStream_t s = (hipStream_t)stream;
+  // 256-row tiles when they still fill the chip twice over (the trunk's input gradient: 32 x 27)
+  if (ceil_div(M, 256) * tiles_n >= 512) {
+    const int tiles_m = (int)ceil_div(M, 256);
+    const int grid = 8 * ((tiles_m * tiles_n + 7) / 8);     // whole rounds over the 8 XCDs
+    RL_LAUNCH((gemm_nt_x6_kernel<256>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, (int)N,
+              (int)K, tiles_m, tiles_n);
+  } else {
+    const int tiles_m = (int)ceil_div(M, GT);
+    const int grid = 8 * ((tiles_m * tiles_n + 7) / 8);
+    RL_LAUNCH((gemm_nt_x6_kernel<128>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, (int)N,
+              (int)K, tiles_m, tiles_n);
+  }
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

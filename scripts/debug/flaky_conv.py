@@ -19,9 +19,10 @@ torch.cuda.synchronize()
 ws = torch.empty(lib.rlpyt_atari_conv_wgrad_workspace_bytes(), dtype=torch.uint8, device="cuda")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 ref = {}
-bad = {k: 0 for k in ("y1", "y2", "dy1", "dw2", "dw1", "gemm")}
+bad = {k: 0 for k in ("y1", "y2", "dy1", "dw2", "dw1", "gemm", "gemm_tall")}
 a = torch.randn(max(M, 32), 3456, generator=g).cuda()
 wt = (torch.randn(512, 3456, generator=g) * 0.02).cuda()
+wtt = wt.t().contiguous()
 for it in range(N):
     idx = torch.randperm(T * B, generator=torch.Generator().manual_seed(5))[:M].cuda()
     y1 = torch.empty(M, 475, 16, device="cuda")
@@ -34,8 +35,9 @@ for it in range(N):
     check(lib.rlpyt_atari_conv2_bwd_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1), ptr(ws), ptr(dw2), ptr(db2), stream()))
     check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs), ptr(idx), T, B, M, ptr(dy1), 1. / 255, ptr(ws), ptr(dw1), ptr(db1), stream()))
     c = ops.gemm_nt(a, wt)
+    c2 = ops.gemm_nt(g2[:, :512].contiguous(), wtt) if M >= 4096 else c
     # concurrent noise on another stream (a second process sharing the GPU does the same)
-    cur = dict(y1=y1, y2=y2, dy1=dy1, dw2=dw2, dw1=dw1, gemm=c)
+    cur = dict(y1=y1, y2=y2, dy1=dy1, dw2=dw2, dw1=dw1, gemm=c, gemm_tall=c2)
     torch.cuda.synchronize()
     for k, v in cur.items():
         if it == 0:

@@ -379,7 +379,9 @@ def test_bf16_split_kernels_are_f32_accurate(ops):
     assert (db1.double() - db_ref).abs().max().item() <= 1e-5 * dy1_64.abs().sum(dim=(0, 2, 3)).max().item()
 
 
-@pytest.mark.parametrize("M,N,K", [(8192, 512, 3456), (1000, 3456, 512), (130, 200, 96), (1, 1, 32)])
+# (8192, 3456, 512) and (8000, 2100, 64): >= 512 tiles of 256 x 128 -> the 256-row-tile variant
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 3456), (8192, 3456, 512), (8000, 2100, 64),
+                                   (1000, 3456, 512), (130, 200, 96), (1, 1, 32)])
 def test_gemm_nt_bf16x6_is_f32_accurate(ops, M, N, K):
     """ops.gemm_nt (rlpyt_gemm_nt_f32: a b^T from three-piece bf16 splits, six products) against
     float64 beside torch's own f32 GEMM on wide-range operands: error <= 2x torch-f32's (+ 2^-22 of
