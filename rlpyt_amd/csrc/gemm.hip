@@ -45,6 +45,28 @@ __device__ __forceinline__ void split3_rn(float x0, float x1, uint32_t& hi, uint
   lo = cvt_pk_bf16(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
 }
 
+// Debug build (-DRLPYT_TIMING): per-wave cycle totals of the phases of the K loop
+// (scripts/debug/phase_timing.py gemm_fwd | gemm_dgrad); compiled out of the product.
+#ifdef RLPYT_TIMING
+__device__ float g_timing_gemm[512 * 16 * 8];
+#define RL_T0() long long t_prev_ = clock64(), t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RL_T(k)                                  \
+  {                                              \
+    const long long t_now_ = clock64();          \
+    t_acc_[k] += t_now_ - t_prev_;               \
+    t_prev_ = t_now_;                            \
+  }
+#define RL_TOUT()                                                                        \
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) {                                     \
+    float* dbg_ = g_timing_gemm + ((int64_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8;   \
+    for (int k = 0; k < 8; ++k) dbg_[k] = (float)t_acc_[k];                              \
+  }
+#else
+#define RL_T0()
+#define RL_T(k)
+#define RL_TOUT()
+#endif
+
 constexpr int GT = 128;                  // column-tile edge (and row-tile edge of the small variant)
 constexpr int G_THREADS = 512;
 constexpr int G_BK = 16;                 // K per barrier step
@@ -192,9 +214,12 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
   constexpr int NV = (22 * (NA + 1) + NMMA - 1) / NMMA;  // split VALU per MFMA gap: 4 / 3
 #define RLPYT_G_STEP(afc_, bfc_, afn_, bfn_, ra, rb, ks_)                                      \
   {                                                                                            \
+    RL_T(3)                                                                                    \
     __syncthreads();   /* stage of step ks + 1 complete; stage of step ks + 2 free */          \
+    RL_T(0)                                                                                    \
     RLPYT_G_FRAGS(afn_, bfn_, st_next)   /* (past the last step: stale, unused) */            \
     __builtin_amdgcn_sched_barrier(0);                                                         \
+    RL_T(1)                                                                                    \
     RLPYT_G_MMA(afc_, bfc_)                                                                    \
     RLPYT_G_STAGE(ra, rb, st_write)      /* (past the last step: into a stage nobody reads) */ \
     /* the split VALU goes BETWEEN the MFMAs, NV per gap: issued as a block it runs while   */ \
@@ -204,17 +229,20 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
       __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                                      \
     }                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                         \
+    RL_T(2)                                                                                    \
     if ((ks_) + 4 < nk) RLPYT_G_FETCH(ra, rb, ((ks_) + 4) * G_BK)                              \
     st_next = st_next == 2 ? 0 : st_next + 1;                                                  \
     st_write = st_write == 2 ? 0 : st_write + 1;                                               \
   }
   int ks = 0;
+  RL_T0()
 #pragma unroll 1
   for (; ks + 1 < nk; ks += 2) {
     RLPYT_G_STEP(af0, bf0, af1, bf1, ra0, rb0, ks)
     RLPYT_G_STEP(af1, bf1, af0, bf0, ra1, rb1, ks + 1)
   }
   if (ks < nk) RLPYT_G_STEP(af0, bf0, af1, bf1, ra0, rb0, ks)
+  RL_TOUT()
 #undef RLPYT_G_STEP
 #undef RLPYT_G_MMA
 #undef RLPYT_G_TERM
@@ -239,6 +267,12 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
 }  // namespace rlpyt
 
 using namespace rlpyt;
+
+#ifdef RLPYT_TIMING
+extern "C" int rlpyt_debug_timing_read_gemm(float* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timing_gemm), (size_t)n * sizeof(float));
+}
+#endif
 
 extern "C" int rlpyt_gemm_nt_f32(const float* a, const float* b, float* c, int64_t M, int64_t N,
                                  int64_t K, rlpyt_stream_t stream) {
