@@ -52,14 +52,14 @@ KERNEL_NAMES = {
     "conv1_fwd": "conv1_fwd_kernel (gather + u8->bf16 + conv 4->16 k8 s4 + bias + ReLU; exact "
                  "bf16x3 split of w1, f32 accumulate)",
     "conv2_fwd": "conv2_fwd_x6_kernel (conv 16->32 k4 s2 p1 + bias + ReLU; bf16x6 split, f32 "
-                 "accumulate, dropped terms <= 2^-26)",
+                 "accumulate, dropped terms <= 2^-24, 2^-27 rms)",
     "conv2_bwd": "conv2_bwd_kernel (dgrad + ReLU masks + weight/bias grad in one pass, fp32 MFMA)",
     "conv2_dgrad": "conv2_dgrad_kernel (transposed conv + ReLU masks, fp32 MFMA)",
     "conv2_wgrad": "conv2_wgrad_kernel (+ bias grad, fp32 MFMA)",
     "conv1_wgrad": "conv1_wgrad_kernel (gather + u8->bf16 + weight/bias grad; exact bf16x3 split "
                    "of dy1, f32 accumulate)",
     "gemm_nt": "gemm_nt_x6_kernel (update trunk x W^T and g W: f32 GEMM from three-piece bf16 splits of "
-               "both operands, six products, f32 accumulate, dropped terms <= 2^-26)",
+               "both operands, six products, f32 accumulate, dropped terms <= 2^-24, 2^-27 rms)",
     "obs_to_nhwc": "obs_to_nhwc_f32_kernel (minibatch gather + u8->f32 + CHW->HWC)",
     "gather_tb": "gather_wide_kernel (minibatch observation gather)",
     "gae": "scan_exact_kernel<GAE>", "ppo_loss": "pg_loss_kernel<PPO>",

@@ -192,7 +192,7 @@ int rlpyt_ppo_trunk_head_loss_fwd_bwd_f32(const float* z, const float* trunk_bia
 /* c[M,N] = a[M,K] * b[N,K]^T, all f32 row-major -- the trunk Linear of the update
  * (rlpyt/models/mlp.py:24-31 via torch.nn.functional.linear: forward x W^T; with b = W^T the input
  * gradient g W).  Computed on the bf16 matrix pipe from exact three-piece bf16 splits of both
- * operands (six products of order <= 2, f32 accumulation; dropped terms <= 2^-26 |ab|): f32 in,
+ * operands (six products of order <= 2, f32 accumulation; dropped terms <= 2^-24 |ab|, 2^-27 rms): f32 in,
  * f32 out, f32-level error.  K must be a multiple of 32; a, b 16-byte aligned. */
 int rlpyt_gemm_nt_f32(const float* a, const float* b, float* c, int64_t M, int64_t N, int64_t K,
                       rlpyt_stream_t stream);

@@ -17,7 +17,7 @@
 // FMA chains on v_mfma_f32_16x16x4_f32 (64 FLOP/clk/SIMD, the chip's f32 peak).  conv1 forward,
 // conv1 weight gradient (bf16x3: the uint8 operand is exact in bf16, the f32 operand is split into
 // three bf16 pieces whose sum is exact) and conv2 forward at update sizes (bf16x6: both operands
-// split, six products, dropped terms <= 2^-26) run on v_mfma_f32_*_bf16 with f32 accumulation --
+// split, six products, dropped terms <= 2^-24, 2^-27 rms) run on v_mfma_f32_*_bf16 with f32 accumulation --
 // f32 in, f32 out, f32-level error, 2.7-5.3x less matrix-pipe time.
 //
 // MFMA 16x16x4 f32 operand map (cdna_hip_programming.md section 3): lane l supplies
@@ -382,9 +382,9 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(
 // ======================================================================================
 // conv2 forward, large batches, on the bf16 matrix pipe ("bf16x6").  Both operands are f32 here, so
 // BOTH are split into three bf16 pieces (round-to-nearest: x == x0 + x1 + x2 exactly, |x1| <=
-// 2^-9 |x|, |x2| <= 2^-18 |x|) and the six products of order <= 2 are accumulated in f32, smallest
+// 2^-8 |x|, |x2| <= 2^-17 |x|) and the six products of order <= 2 are accumulated in f32, smallest
 // first: a2b0, a0b2, a1b1, a1b0, a0b1, a0b0.  Each is exact in the accumulator; the three dropped
-// products (a1b2, a2b1, a2b2) are together <= 2^-26 |ab| -- a quarter of ONE f32 rounding -- so
+// products (a1b2, a2b1, a2b2) are together <= 2^-24 |ab| (one f32 rounding; 2^-27 rms, unbiased: tests/test_split_arith.py) -- so
 // the result is an f32 contraction to within its own accumulation-order noise, at 6 x 32 cycles
 // per 32x32x16 block instead of the 16 x 32 ... of the f32 MFMA (2.7x less matrix-pipe time).
 //   y2[m, co, pos] = relu(sum_{ky,kx,c} w2[co,c,ky,kx] * y1pad[2oy+ky, 2ox+kx, c] + b2[co])

@@ -4,7 +4,7 @@
 // is no faster f32 instruction on gfx950.  Here both operands are split into three bf16 pieces
 // (round to nearest: x == x0 + x1 + x2 exactly) while they pass from HBM to LDS and the six
 // products of order <= 2 are accumulated in f32, smallest first; the three dropped products are
-// together <= 2^-26 |ab|, a quarter of one f32 rounding (same scheme and the same accuracy test as
+// together <= 2^-24 |ab| (one f32 rounding; 2^-27 rms, unbiased) (same scheme and the same accuracy test as
 // conv2_fwd_x6_kernel, csrc/conv.hip).  6 x v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace
 // 8 x v_mfma_f32_32x32x2_f32 (64 cycles, K = 2): 2.7x less matrix-pipe time per K.
 //
