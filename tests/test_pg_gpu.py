@@ -92,3 +92,26 @@ def test_recurrent_pg_runner_end_to_end(algo_name):
         infos = _run(algo, T=6, B=8, n_itr=3, AgentCls=AtariLstmAgent, mid_batch_reset=False)
         assert algo.update_counter == 3
         assert all(np.isfinite(i.loss) and np.isfinite(i.gradNorm) for i in infos)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second GPU")
+def test_runner_on_second_device():
+    """affinity['cuda_idx'] = 1 with the process's current device left at 0: the runner
+    itself must make device 1 current before the sampler, the workspaces and every kernel launch --
+    parameters, batch and update all on cuda:1, finite losses."""
+    torch.cuda.set_device(0)
+    sampler = GpuSampler(SyntheticPong, dict(points_to_end=2, max_steps=60), batch_T=16, batch_B=8,
+                         n_workers=2, TrajInfoCls=AtariTrajInfo, max_decorrelation_steps=5)
+    agent = AtariFfAgent()
+    algo = PPO(learning_rate=3e-4, gae_lambda=0.95, minibatches=2, epochs=2)
+    runner = MinibatchRl(algo=algo, agent=agent, sampler=sampler, n_steps=16 * 8 * 3, seed=0,
+                         affinity=dict(cuda_idx=1), log_interval_steps=16 * 8 * 3)
+    try:
+        runner.train()
+        assert torch.cuda.current_device() == 1
+        assert all(p.device == torch.device("cuda", 1) for p in agent.parameters())
+        assert sampler.samples.env.observation.device == torch.device("cuda", 1)
+        assert all(torch.isfinite(p).all().item() for p in agent.parameters())
+        assert algo.update_counter == 3 * 4
+    finally:
+        torch.cuda.set_device(0)
