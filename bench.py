@@ -409,7 +409,7 @@ def pmc_traffic(name, g):
     scale = g["alg_bytes_per_launch"] / k["alg_bytes"] if k.get("alg_bytes") else 1.
     return {"bytes_per_launch": k["hbm_bytes_corrected"] * scale,
             "source": "profiles/r2_conv_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / "
-                      "WRITE_SIZE passes over scripts/conv_bench.py, M=8192)"}
+                      "WRITE_SIZE passes over scripts/conv_bench.py / scripts/gemm_bench.py, M=8192)"}
 
 
 def gae_scaled_roofline(T=128, log2n=20, iters=20):
