@@ -230,9 +230,16 @@ def variant_reset():
 
 def variant_counts():
     """{kernel instantiation: launches since the last ``variant_reset``}."""
-    need = lib.rlpyt_hip_variant_dump(None, 0)
-    buf = ctypes.create_string_buffer(int(need) + 1)
-    lib.rlpyt_hip_variant_dump(buf, need + 1)
+    # one pass into a buffer that is known to be large enough: sizing it with a first pass races
+    # with launches from other threads (sampler serve threads), and a short buffer silently drops
+    # the last-registered kernels
+    cap = 1 << 16
+    while True:
+        buf = ctypes.create_string_buffer(cap)
+        used = int(lib.rlpyt_hip_variant_dump(buf, cap))
+        if used < cap:
+            break
+        cap = used + 4096
     out = {}
     for line in buf.value.decode().splitlines():
         name, _, cnt = line.rpartition("\t")
