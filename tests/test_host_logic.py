@@ -511,3 +511,28 @@ def test_runner_diagnostics_match_reference(which):
     finally:
         logger.dump_tabular = orig
     assert rows and rows[-1] == ref, (sorted(set(ref) ^ set(rows[-1])), rows[-1][:14], ref[:14])
+
+
+def test_trunk_pre_activation_contract_on_cpu():
+    """``AtariFfModel.forward(features_only="pre")`` / ``CategoricalPgAgent.trunk_pre`` /
+    ``ops.linear_nobias`` off the device: where the fused path does not apply (CPU tensors) the
+    model hands out its ordinary trunk output and ``None`` for the bias (the caller then adds
+    nothing), and ``linear_nobias`` is ``F.linear`` -- the same statements as the reference's
+    Linear + ReLU (rlpyt/models/mlp.py:24-31)."""
+    import torch.nn.functional as F
+
+    from rlpyt_amd import ops
+    from rlpyt_amd.models.pg.atari_ff_model import AtariFfModel
+    torch.manual_seed(0)
+    m = AtariFfModel(image_shape=(4, 104, 80), output_size=6)
+    img = torch.randint(0, 256, (3, 4, 104, 80), dtype=torch.uint8)
+    z, tb = m(img, None, None, features_only="pre")
+    assert tb is None                                   # CPU: bias + ReLU already applied
+    h = m(img, None, None, features_only=True)
+    assert torch.equal(z, h)
+    pi, v = m(img, None, None)
+    assert torch.allclose(pi, torch.softmax(m.pi(h), -1)) and torch.allclose(v, m.value(h).squeeze(-1))
+    lin = m._single_fc()
+    assert lin is not None and lin.in_features == 3456 and lin.out_features == 512
+    x, w = torch.randn(5, 64), torch.randn(32, 64)
+    assert torch.equal(ops.linear_nobias(x, w), F.linear(x, w))   # CPU tensors: library path
