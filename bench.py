@@ -104,17 +104,57 @@ def parse():
                          "N>1 code path on a single-GPU box")
     ap.add_argument("--check-params", action="store_true",
                     help="debug: assert that all ranks hold identical parameters at the end")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch contract only: every rank joins the process group, reports what "
+                         "it would use (device, CPUs, env workers) and exits without touching a GPU")
+    ap.add_argument("--master-port", type=int, default=0,
+                    help="rendezvous port of the self-launched ranks (0: a free one)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` without a launcher: re-exec this command line under
+    ``python -m torch.distributed.run`` with N ranks on 127.0.0.1 (rank r <-> GPU r, one process
+    per GPU -- rlpyt/runners/sync_rl.py:60-101), stream the ranks' output through, and return
+    the launcher's exit code.  Refuses to run when the box has fewer than N devices (unless
+    --same-gpu / --dry-run), instead of silently measuring fewer ranks."""
+    import subprocess
+    if not (args.same_gpu or args.dry_run):
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this box shows {n_dev} device(s); "
+                  "refusing to run fewer ranks than asked (use --same-gpu --backend gloo to "
+                  "exercise the N>1 code path on one GPU)", file=sys.stderr)
+            return 2
+    port = args.master_port or _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
     if args.config != "ppo":
         return replay_config_main(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: the launcher and "
+                         "the flag disagree (python bench.py --gpus N launches its own N ranks)")
     import torch.distributed as dist
 
     from rlpyt_amd.agents.pg.atari import AtariFfAgent
@@ -147,10 +187,19 @@ def main():
     # worker processes and their CPUs the reference's way: one worker per entry of
     # affinity["workers_cpus"] (rlpyt/samplers/parallel/base.py:157-172); rank r takes the r-th
     # block of the hardware threads
-    per_rank = max(ncpu // max(world, 1), 1)
-    workers_cpus = [rank * per_rank + (w % per_rank) for w in range(workers)]
+    # block of the CPUs this process tree may be scheduled on (the affinity mask, not the raw
+    # hardware thread count); the POOL SIZE above comes from the cgroup quota share cpus / world
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = list(range(ncpu))
+    per_rank = max(len(allowed) // max(world, 1), 1)
+    block = allowed[rank * per_rank:(rank + 1) * per_rank] or allowed
+    workers_cpus = [block[w % len(block)] for w in range(workers)]
     affinity = dict(cuda_idx=local_rank, workers_cpus=workers_cpus,
                     set_affinity=bool(args.pin_workers))
+    if args.dry_run:
+        return dry_run(args, rank, world, local_rank, cpus, workers, block)
 
     # --- build the stack in the reference's order: sampler (forks workers) BEFORE any HIP
     #     call, then device placement, then DDP, then the algorithm ------------------------
@@ -255,9 +304,13 @@ def main():
         torch.cuda.synchronize()
         ar_us = (time.perf_counter() - ta) / n_ar * 1e6
         cpu_list = [None] * world
-        dist.all_gather_object(cpu_list, dict(rank=rank, usable_cpus=cpus, device=torch.cuda.current_device(),
-                                              env_workers=sampler.n_workers))
+        dist.all_gather_object(cpu_list, dict(
+            rank=rank, device=torch.cuda.current_device(),
+            device_name=torch.cuda.get_device_name(torch.cuda.current_device()),
+            cpu_quota_share=round(cpus / world, 2), env_workers=sampler.n_workers,
+            cpu_block=[block[0], block[-1]]))
         multi = dict(dist_world_size=dist.get_world_size(), backend=dist.get_backend(),
+                     rccl_version=_rccl_version(), host_cpu_quota=cpus,
                      ranks=cpu_list, grad_bytes=nparam * 4,
                      allreduce_us_per_minibatch=ar_us,
                      allreduce_ms_per_iteration=ar_us * algo.epochs * algo.minibatches / 1e3,
@@ -290,7 +343,8 @@ def main():
         steps_total = T * B * world * args.steps
         out = {
             "metric": "env-steps/sec (SPS) whole node, PPO Atari [T=128,B=256]",
-            "value": steps_total / elapsed, "unit": "env-steps/s", "n_gpus": world,
+            "value": steps_total / elapsed, "unit": "env-steps/s",
+            "n_gpus": dist.get_world_size() if world > 1 else 1,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -394,6 +448,40 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:  # noqa: BLE001  (CPU-only build container)
+        return f"unavailable ({type(e).__name__})"
+
+
+def dry_run(args, rank, world, local_rank, cpus, workers, block):
+    """Launch contract without a GPU: every rank joins the process group and reports the device,
+    CPU block and env-worker count it WOULD use; rank 0 prints one JSON line whose ``n_gpus`` is
+    the world size torch.distributed reports (tests/test_host_logic.py)."""
+    import torch.distributed as dist
+    backend = args.backend if torch.cuda.is_available() and not args.same_gpu else "gloo"
+    info = dict(rank=rank, device=0 if args.same_gpu else local_rank,
+                cpu_quota_share=round(cpus / world, 2), env_workers=workers,
+                cpu_block=[block[0], block[-1]], pid=os.getpid())
+    ranks = [info]
+    if world > 1:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        ranks = [None] * world
+        dist.all_gather_object(ranks, info)
+        n = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        n = 1
+    if rank == 0:
+        print(json.dumps({"metric": "env-steps/sec (SPS) whole node, PPO Atari [T=128,B=256]",
+                          "dry_run": True, "value": None, "n_gpus": n, "backend": backend,
+                          "rccl_version": _rccl_version(), "host_cpu_quota": cpus,
+                          "ranks": ranks}), flush=True)
 
 
 def pmc_traffic(name, g):

@@ -1,0 +1,67 @@
+"""`python bench.py --gpus N` launches its own N ranks (one process per GPU as
+rlpyt/runners/sync_rl.py:60-101): the launch contract on CPU (``--dry-run``: ranks join the
+process group and report, no GPU work) and, on the GPU box, one real step of two ranks sharing
+cuda:0 over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)       # the point: no launcher around bench.py
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus2_launches_two_ranks_without_torchrun():
+    r, line = _run(["--gpus", "2", "--dry-run"], 300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["dry_run"] is True
+    ranks = sorted(line["ranks"], key=lambda x: x["rank"])
+    assert [x["rank"] for x in ranks] == [0, 1]
+    assert [x["device"] for x in ranks] == [0, 1]            # rank r <-> GPU r
+    assert ranks[0]["pid"] != ranks[1]["pid"]                  # one process per rank
+    # env workers are sized from the QUOTA share of each rank, and the ranks' CPU blocks are disjoint
+    for x in ranks:
+        assert x["env_workers"] <= max(int(round(1.6 * x["cpu_quota_share"])) - 1, 1)
+    if ranks[0]["cpu_block"] != ranks[1]["cpu_block"]:
+        assert ranks[0]["cpu_block"][1] < ranks[1]["cpu_block"][0]
+
+
+def test_bench_rejects_mismatched_world_size():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_gpus_than_devices():
+    import torch
+    n = torch.cuda.device_count()
+    r, line = _run(["--gpus", str(n + 1), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], 300)
+    assert r.returncode == 2 and line is None
+    assert "refusing to run fewer ranks" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_same_gpu_runs_two_ranks():
+    """The real bench step with two self-launched ranks on cuda:0 (gloo): the line reports the
+    world size torch.distributed saw, and DDP kept the ranks' parameters identical."""
+    r, line = _run(["--gpus", "2", "--same-gpu", "--backend", "gloo", "--steps", "1", "--warmup", "1",
+                    "--no-cpu-baseline", "--env-cost-leg-us", "0", "--check-params",
+                    "--batch-T", "32", "--batch-B", "128"], 900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["multi_gpu"]["dist_world_size"] == 2
+    assert line["config"]["parallelism"] == "dp2"
+    assert "bit-identical parameters" in r.stderr
+    assert len({x["rank"] for x in line["multi_gpu"]["ranks"]}) == 2
