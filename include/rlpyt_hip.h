@@ -38,7 +38,9 @@ extern "C" {
 typedef void* rlpyt_stream_t; /* hipStream_t */
 
 const char* rlpyt_hip_last_error(void);
-/* ABI version of this header; bumped when a signature changes. */
+/* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
+ * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
+#define RLPYT_HIP_ABI_VERSION 3
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);

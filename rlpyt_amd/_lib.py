@@ -17,7 +17,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 
 class CopyDesc(ctypes.Structure):

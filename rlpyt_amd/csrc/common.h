@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include "../../include/rlpyt_hip.h"
 
-#define RLPYT_ABI_VERSION 1
+#define RLPYT_ABI_VERSION RLPYT_HIP_ABI_VERSION
 
 namespace rlpyt {
 

@@ -57,22 +57,33 @@ class EpsilonGreedy(DiscreteMixin, Distribution):
             return
         e = torch.as_tensor(self._epsilon, dtype=torch.float32).reshape(-1)
         self._scalar_buf.copy_(e[:1])
-        if self._buf is not None and e.numel() in (1, self._buf.numel()):
+        if self._buf is not None:
+            if e.numel() not in (1, self._buf.numel()):
+                raise ValueError(f"vector epsilon has {e.numel()} entries for {self._buf.numel()} "
+                                 "environments")
             self._buf.copy_(e.expand(self._buf.numel()))
 
     def _eps_for(self, n):
         """Epsilon operand for a batch of ``n`` environments."""
+        e = self._epsilon
+        vector = isinstance(e, torch.Tensor) and e.numel() > 1
+        sl = self._env_slice
         if self._scalar_buf is None:                       # host path
-            e = self._epsilon
-            if isinstance(e, torch.Tensor) and e.numel() > 1 and self._env_slice is not None \
-                    and self._env_slice[1] - self._env_slice[0] == n:
-                return e[self._env_slice[0]:self._env_slice[1]]
+            if vector and sl is not None and sl[1] - sl[0] == n:
+                return e[sl[0]:sl[1]]
+            if vector and e.numel() != n:
+                raise ValueError(f"vector epsilon ({e.numel()} envs) cannot serve a batch of {n} "
+                                 f"(selected envs: {sl})")
             return e
         if self._buf is not None:
-            if self._env_slice is not None and self._env_slice[1] - self._env_slice[0] == n:
-                return self._buf[self._env_slice[0]:self._env_slice[1]]
+            if sl is not None and sl[1] - sl[0] == n:
+                return self._buf[sl[0]:sl[1]]
             if self._buf.numel() == n:
                 return self._buf
+        if vector:
+            # never fall back to the first environment's epsilon silently (ADVICE r2)
+            raise ValueError(f"vector epsilon ({e.numel()} envs) cannot serve a batch of {n} "
+                             f"(selected envs: {sl}); call select_envs(lo, hi) first")
         return self._scalar_buf
 
     def sample(self, q, generator=None):

@@ -65,7 +65,30 @@ class ClipAdam(torch.optim.Adam):
         # MAX_TENSORS tensors of one hyper-parameter group
         group = self.param_groups[0]
         rows = []
-        step = None
+        steps = set()
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif st["step"].is_cuda:
+                # a snapshot written by a fused=True Adam holds `step` on the device: bring it
+                # to the host ONCE (reading it there every update would sync the stream)
+                st["step"] = st["step"].detach().to("cpu", torch.float32)
+            steps.add(int(st["step"].item()))
+        if len(steps) > 1:
+            # parameters with different step counts (a gradient that was None in earlier updates,
+            # a merged state dict) need per-tensor bias corrections: the kernel applies ONE, so
+            # this update goes through torch's own Adam
+            params = [p for p in group["params"] if p.grad is not None]
+            norm = (torch.nn.utils.clip_grad_norm_(params, max_norm) if max_norm
+                    else torch.zeros((), device=dev))
+            self.step()
+            return norm
+        step = (steps.pop() + 1) if steps else None
         for p in group["params"]:
             if p.grad is None:
                 continue
@@ -73,12 +96,7 @@ class ClipAdam(torch.optim.Adam):
             if not (g.is_contiguous() and g.dtype == torch.float32):
                 g = g.contiguous().float()
             st = self.state[p]
-            if len(st) == 0:
-                st["step"] = torch.zeros((), dtype=torch.float32)
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["step"] += 1
-            step = int(st["step"].item()) if step is None else step
             rows.append((p, g, st["exp_avg"], st["exp_avg_sq"]))
         if not rows:
             return self._norm.zero_()

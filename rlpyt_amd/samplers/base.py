@@ -35,8 +35,13 @@ class BaseSampler:
         """Env steps per ``obtain_samples`` call on this rank."""
         return self.batch_spec.size
 
-    def initialize(self, agent, affinity=None, seed=None, bootstrap_value=False,
-                   traj_info_kwargs=None, rank=0, world_size=1):
+    # The reference's own samplers disagree on the tail of this signature: SerialSampler has
+    # (..., rank=0, world_size=1) (rlpyt/samplers/serial/sampler.py:24-33), ParallelSamplerBase
+    # has (..., world_size=1, rank=0, worker_process=None) (rlpyt/samplers/parallel/base.py:28-38)
+    # and BaseSampler takes (*args, **kwargs) (rlpyt/samplers/base.py:49).  The base class here
+    # takes the same open signature, and subclasses make everything after ``seed`` keyword-only
+    # in effect by following THEIR reference class (tests/golden/protocol.json pins both).
+    def initialize(self, *args, **kwargs):
         raise NotImplementedError(f"{type(self).__name__}.initialize")
 
     def obtain_samples(self, itr):

@@ -834,6 +834,12 @@ class GpuSampler(BaseSampler):
         lo, hi = G.lo, G.hi
         self._all_reward[T, lo:hi] = G.reward_stage
         self._all_done[T, lo:hi] = G.done_stage
+        # THIS group's envs / recurrent state before any agent call: value() of a recurrent
+        # agent reads the selected slot's LSTM state (with several pipeline groups the slot
+        # still selected is the group stepped last)
+        self.agent.select_envs(lo, hi)
+        if self.agent.recurrent:
+            self.agent.select_slot(G.idx)
         if "bootstrap_value" in s.agent:
             # as the reference: the value call sees the last action / reward as they are -- the
             # null-after-reset of prev inputs happens AFTER it (action_server.py:60-68); for an
@@ -843,8 +849,7 @@ class GpuSampler(BaseSampler):
             s.agent.bootstrap_value[0, lo:hi] = self.agent.value(G.obs_stage, prev_action,
                                                                  prev_reward)
         if self.agent.recurrent:     # end of batch: finished envs restart from a zero state
-            self.agent.select_slot(G.idx)   # (action_server.py:63-68)
-            self.agent.reset_where(G.done_stage)
+            self.agent.reset_where(G.done_stage)   # (action_server.py:63-68)
 
     def _upload_special(self, G, nb, first):
         """Host-dependent part of the upload (frame-stacked envs only): full stacks for the

@@ -298,6 +298,40 @@ def test_sampler_recurrent_agent_state_bookkeeping():
     s.shutdown()
 
 
+@pytest.mark.parametrize("B,n_groups", [(4, 2), (5, 2)])
+def test_recurrent_pg_bootstrap_value_uses_its_own_groups_state(B, n_groups):
+    """with several pipeline groups the bootstrap value of a recurrent PG agent
+    must come from the LSTM state of THAT group (action_server.py:60-62 has one state for all
+    envs).  No env finishes here, so row 0 of the next batch holds obs_T and the state after T
+    steps: re-running the model on them must reproduce the recorded bootstrap value."""
+    from rlpyt_amd.agents.pg.atari import AtariLstmAgent
+    T = 5
+    s = GpuSampler(SyntheticPong, dict(points_to_end=10 ** 6, max_steps=10 ** 6), batch_T=T,
+                   batch_B=B, n_workers=0, n_groups=n_groups, max_decorrelation_steps=0)
+    a = AtariLstmAgent(model_kwargs=dict(fc_sizes=32, lstm_size=8))
+    torch.manual_seed(0)
+    s.initialize(a, seed=3, bootstrap_value=True)
+    assert s.n_groups == n_groups
+    prev = None
+    for itr in range(3):
+        a.sample_mode(itr)
+        smp, _ = s.obtain_samples(itr)
+        assert not bool(smp.env.done.any())
+        info = smp.agent.agent_info
+        if prev is not None:
+            bv, last_action, last_reward = prev
+            with torch.no_grad():
+                onehot = torch.nn.functional.one_hot(last_action, 6).float()
+                state = tuple(x[0].transpose(0, 1).contiguous() for x in info.prev_rnn_state)
+                _pi, v, _st = a.model(smp.env.observation[0], onehot, last_reward, state)
+            np.testing.assert_allclose(bv.numpy(), v.numpy(), rtol=1e-5, atol=1e-6)
+            # and it is NOT what another group's state would give (the states differ)
+            assert float((state[0][:, 0] - state[0][:, -1]).abs().max()) > 0
+        prev = (smp.agent.bootstrap_value[0].clone(), smp.agent.action[-1].clone(),
+                smp.env.reward[-1].clone())
+    s.shutdown()
+
+
 # ---------------------------------------------------------------------- offline evaluation
 @pytest.mark.parametrize("n_workers", [0, 2])
 def test_sampler_evaluate_agent(n_workers):
