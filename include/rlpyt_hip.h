@@ -198,6 +198,27 @@ int rlpyt_ppo_trunk_head_loss_fwd_bwd_f32(const float* z, const float* trunk_bia
  * f32 out, f32-level error.  K must be a multiple of 32; a, b 16-byte aligned. */
 int rlpyt_gemm_nt_f32(const float* a, const float* b, float* c, int64_t M, int64_t N, int64_t K,
                       rlpyt_stream_t stream);
+/* The same contraction scheme for the trunk's BACKWARD (rlpyt/models/mlp.py:24-31 under autograd),
+ * all f32 row-major, K a multiple of 32, pointers 16-byte aligned:
+ *   rlpyt_gemm_nn_f32: c[M,N] = a[M,K] * b[K,N]    -- input gradient g W (W as stored, no transpose
+ *                                                     copy); N a multiple of 4;
+ *   rlpyt_gemm_tn_f32: c[M,N] = a[K,M]^T * b[K,N]  -- weight gradient g^T x, a contraction over the
+ *                                                     batch axis; M, N multiples of 4.  For K >= 2048
+ *                                                     K is cut into 8 chunks (one per XCD) whose
+ *                                                     partial tiles go to `workspace`
+ *                                                     (rlpyt_gemm_tn_workspace_bytes; 0 = none needed)
+ *                                                     and are summed in a fixed order: results are
+ *                                                     run-to-run identical;
+ *   rlpyt_gemm_nt_pp_f32: rlpyt_gemm_nt_f32 on the same "ping-pong" kernel body as the two above
+ *                         (wave halves alternate between a pure-MFMA segment and a load / split /
+ *                         LDS segment; csrc/gemm_pp.hip). */
+int rlpyt_gemm_nt_pp_f32(const float* a, const float* b, float* c, int64_t M, int64_t N, int64_t K,
+                         rlpyt_stream_t stream);
+int rlpyt_gemm_nn_f32(const float* a, const float* b, float* c, int64_t M, int64_t N, int64_t K,
+                      rlpyt_stream_t stream);
+int64_t rlpyt_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int rlpyt_gemm_tn_f32(const float* a, const float* b, float* c, int64_t M, int64_t N, int64_t K,
+                      void* workspace, rlpyt_stream_t stream);
 
 /* A2C.loss -- rlpyt/algos/pg/a2c.py:63-103: pi_loss = -valid_mean(log(p[a]+eps) * A). */
 int rlpyt_a2c_loss_fwd_bwd_f32(const float* prob /*[M,A]*/, const float* value /*[M]*/,

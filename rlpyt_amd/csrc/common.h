@@ -59,6 +59,8 @@ void variant_hit(VariantSlot* slot);
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                      \
   } while (0)
 
+#define RL_ALIGNED16(p) ((reinterpret_cast<uintptr_t>(p) & 15) == 0)
+
 __host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr int kWave = 64;  // CDNA wavefront width

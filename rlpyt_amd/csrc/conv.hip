@@ -1688,7 +1688,6 @@ constexpr int kPartialRows = kWgradGrid;  // one partial row per persistent work
 
 using namespace rlpyt;
 
-#define RL_ALIGNED16(p) ((reinterpret_cast<uintptr_t>(p) & 15) == 0)
 
 extern "C" int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat_idx, int T,
                                          int64_t B, int64_t M, const float* w1, const float* b1,

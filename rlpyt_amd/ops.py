@@ -5,6 +5,7 @@ torch's current HIP stream.  Shapes follow the reference's ``[Time, Batch, ...]`
 No function in this module computes anything itself: arithmetic lives in the HIP kernels.
 """
 import ctypes
+import os
 
 import torch
 
@@ -628,27 +629,68 @@ def fc_small(x, weight, bias=None, relu=True):
     return y
 
 
-def gemm_nt(a, b):
+# RLPYT_GEMM_PP=0 selects the round-2 lock-step kernel for a @ b.T (A/B timing); default: the
+# ping-pong kernel body shared with the two backward GEMMs (csrc/gemm_pp.hip)
+GEMM_NT_PINGPONG = os.environ.get("RLPYT_GEMM_PP", "1") != "0"
+
+
+def gemm_nt(a, b, pingpong=None):
     """``a @ b.T`` for f32 ``a [M, K]``, ``b [N, K]`` (K a multiple of 32) on the bf16 matrix pipe
-    from exact three-piece bf16 splits of both operands (``rlpyt_gemm_nt_f32``: six products, f32
-    accumulation, dropped terms <= 2^-24 |ab|, 2^-27 rms -- f32-level error, 2.7x less matrix-pipe time than
-    an f32-MFMA GEMM)."""
+    from exact three-piece bf16 splits of both operands (six products, f32 accumulation, dropped
+    terms <= 2^-24 |ab|, 2^-27 rms -- f32-level error, 2.7x less matrix-pipe time than an f32-MFMA
+    GEMM).  ``rlpyt_gemm_nt_pp_f32`` (ping-pong schedule) or ``rlpyt_gemm_nt_f32`` (lock-step)."""
     _lib.require_gpu()
     a, b = _f32(a), _f32(b)
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    pp = GEMM_NT_PINGPONG if pingpong is None else pingpong
+    fn = lib.rlpyt_gemm_nt_pp_f32 if pp else lib.rlpyt_gemm_nt_f32
     with ktimer.region("gemm_nt", 4 * (M * K + N * K + M * N), 2 * M * N * K):
-        check(lib.rlpyt_gemm_nt_f32(ptr(a), ptr(b), ptr(c), M, N, K, stream()), "rlpyt_gemm_nt_f32")
+        check(fn(ptr(a), ptr(b), ptr(c), M, N, K, stream()), "rlpyt_gemm_nt_f32")
+    return c
+
+
+def gemm_nn(a, b):
+    """``a @ b`` for f32 ``a [M, K]``, ``b [K, N]`` (K a multiple of 32, N of 4), same arithmetic as
+    ``gemm_nt``; ``b`` is read as stored (the kernel transposes while staging): the input gradient
+    ``g W`` of a Linear without a transposed copy of ``W`` (``rlpyt_gemm_nn_f32``)."""
+    _lib.require_gpu()
+    a, b = _f32(a), _f32(b)
+    M, K = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with ktimer.region("gemm_nn", 4 * (M * K + N * K + M * N), 2 * M * N * K):
+        check(lib.rlpyt_gemm_nn_f32(ptr(a), ptr(b), ptr(c), M, N, K, stream()), "rlpyt_gemm_nn_f32")
+    return c
+
+
+def gemm_tn(a, b):
+    """``a.T @ b`` for f32 ``a [K, M]``, ``b [K, N]`` (K a multiple of 32; M, N of 4), same
+    arithmetic as ``gemm_nt``: the weight gradient ``g^T x`` of a Linear -- a contraction over the
+    batch axis.  Long contractions are cut into 8 K chunks whose partial tiles are summed in a
+    fixed order (``rlpyt_gemm_tn_f32``; run-to-run identical results)."""
+    _lib.require_gpu()
+    a, b = _f32(a), _f32(b)
+    K, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    nbytes = int(lib.rlpyt_gemm_tn_workspace_bytes(M, N, K))
+    ws = _workspace("gemm_tn", nbytes, a.device) if nbytes else None
+    with ktimer.region("gemm_tn", 4 * (M * K + N * K + M * N), 2 * M * N * K):
+        check(lib.rlpyt_gemm_tn_f32(ptr(a), ptr(b), ptr(c), M, N, K, ptr(ws), stream()),
+              "rlpyt_gemm_tn_f32")
     return c
 
 
 class _LinearNoBias(torch.autograd.Function):
-    """``x @ W.T`` (torch.nn.functional.linear without bias) for the update-size trunk: forward
-    and the input gradient on ``gemm_nt`` (the latter on a transposed copy of W, 7 MB), the weight
-    gradient -- a contraction over the batch axis, where neither operand is K-contiguous --
-    through the library GEMM."""
+    """``x @ W.T`` (torch.nn.functional.linear without bias) for the update-size trunk, all three
+    GEMMs of forward + backward on the bf16 matrix pipe: forward ``gemm_nt(x, W)``, input gradient
+    ``gemm_nn(g, W)``, weight gradient ``gemm_tn(g, x)`` (rlpyt/models/mlp.py:24-31 under
+    autograd).  No vendor GEMM, no transposed copy of W."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -661,9 +703,9 @@ class _LinearNoBias(torch.autograd.Function):
         g = g.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = gemm_nt(g, weight.detach().t().contiguous())
+            gx = gemm_nn(g, weight.detach())
         if ctx.needs_input_grad[1]:
-            gw = torch.mm(g.t(), x)
+            gw = gemm_tn(g, x)
         return gx, gw
 
 
@@ -671,7 +713,7 @@ def linear_nobias(x, weight):
     """``F.linear(x, weight)`` with ``gemm_nt`` forward / input-gradient (see ``_LinearNoBias``);
     shapes it does not cover (K or N not a multiple of 32, non-f32, CPU) take ``F.linear``."""
     if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
-            and x.shape[1] % 32 == 0 and weight.shape[0] % 32 == 0):
+            and x.shape[1] % 32 == 0 and weight.shape[0] % 32 == 0 and x.shape[0] % 32 == 0):
         return _LinearNoBias.apply(x, weight)
     return torch.nn.functional.linear(x, weight)
 

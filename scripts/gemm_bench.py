@@ -1,4 +1,6 @@
-"""rlpyt_gemm_nt_f32 (bf16x6) beside torch / hipBLASLt f32 at the two trunk shapes of the update."""
+"""The three trunk GEMMs of the PPO update at M = 8192 (forward x W^T, input gradient g W, weight
+gradient g^T x) on the bf16x6 kernels, beside torch / hipBLASLt f32 on the same operands.
+Ceiling of a bf16x6 GEMM: 6 bf16 MFMAs per MAC -> 2.5 PFLOP/s / 6 = 417 TFLOP/s algorithmic."""
 import json
 import os
 import sys
@@ -22,13 +24,24 @@ def timeit(fn, iters=20, warmup=3):
     return s.elapsed_time(e) / iters * 1e3
 
 
-res = {}
-for name, (M, N, K) in {"fwd": (8192, 512, 3456), "dgrad": (8192, 3456, 512)}.items():
-    a = torch.randn(M, K, device="cuda")
-    b = torch.randn(N, K, device="cuda")
-    us = timeit(lambda: ops.gemm_nt(a, b))
-    ut = timeit(lambda: torch.mm(a, b.t()))
-    fl = 2 * M * N * K
-    res[name] = {"x6_us": round(us, 1), "torch_f32_us": round(ut, 1),
-                 "x6_alg_TFLOPs": round(fl / us / 1e6, 1), "x6_issued_frac_bf16_peak": round(6 * fl / us / 1e6 / 2500, 3)}
+def entry(us, fl):
+    return {"us": round(us, 1), "alg_TFLOPs": round(fl / us / 1e6, 1),
+            "frac_of_bf16x6_ceiling": round(6 * fl / us / 1e6 / 2500, 3)}
+
+
+M, N, K = 8192, 512, 3456          # batch, trunk width, conv features
+x = torch.randn(M, K, device="cuda")
+w = torch.randn(N, K, device="cuda") * 0.02
+g = torch.randn(M, N, device="cuda")
+fl = 2 * M * N * K
+res = {"shape": {"M": M, "N": N, "K": K, "GFLOP": fl / 1e9}}
+res["fwd_nt_pingpong"] = entry(timeit(lambda: ops.gemm_nt(x, w, pingpong=True)), fl)
+res["fwd_nt_lockstep"] = entry(timeit(lambda: ops.gemm_nt(x, w, pingpong=False)), fl)
+res["fwd_torch_f32"] = entry(timeit(lambda: torch.mm(x, w.t())), fl)
+res["dgrad_nn_pingpong"] = entry(timeit(lambda: ops.gemm_nn(g, w)), fl)
+wt = w.t().contiguous()
+res["dgrad_nt_lockstep_on_transposed_w"] = entry(timeit(lambda: ops.gemm_nt(g, wt, pingpong=False)), fl)
+res["dgrad_torch_f32"] = entry(timeit(lambda: torch.mm(g, w)), fl)
+res["wgrad_tn_pingpong"] = entry(timeit(lambda: ops.gemm_tn(g, x)), fl)
+res["wgrad_torch_f32"] = entry(timeit(lambda: torch.mm(g.t(), x)), fl)
 print(json.dumps(res))

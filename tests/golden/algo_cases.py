@@ -48,10 +48,23 @@ def lstm_init_state(lstm=512):
     return (0.1 * torch.randn(B, 1, lstm, generator=g), 0.1 * torch.randn(B, 1, lstm, generator=g))
 
 
-def batch_inputs():
+# The same iteration at a shape that SELECTS the bench-path kernels: M =
+# T*B / minibatches = 1024 rows per minibatch -> bf16x6 trunk GEMMs (forward, input and weight
+# gradient), conv2_fwd_x6, several images per persistent conv workgroup.  SGD, so every update of
+# both reference iterations is held to fp32 tolerance.  (The observations are regenerated from
+# the seed on both sides; the fixture holds only the reference's outputs.)
+BIG_T, BIG_B = 64, 64
+BIG_CASE = ("ppo_sgd_big", "PPO", dict(discount=0.99, learning_rate=2e-2, value_loss_coeff=1.,
+                                       entropy_loss_coeff=0.01, clip_grad_norm=1., gae_lambda=0.98,
+                                       minibatches=4, epochs=2, ratio_clip=0.1,
+                                       linear_lr_schedule=True, normalize_advantage=False,
+                                       OptimCls=torch.optim.SGD), True)
+
+
+def batch_inputs(T=T, B=B, seed=77):
     """Env-side fields of the sample batch (the agent-side fields -- old probabilities, values,
     bootstrap value -- come from the reference agent's own forward and live in the fixture)."""
-    g = torch.Generator().manual_seed(77)
+    g = torch.Generator().manual_seed(seed)
     obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, generator=g)
     keep = torch.rand((T, B, 4, 104, 80), generator=g) < 0.15
     obs = obs * keep.to(torch.uint8)

@@ -832,6 +832,61 @@ def gen_algos():
     save("algos", **out)
 
 
+def gen_algos_big():
+    """The reference PPO.optimize_agent + AtariFfAgent on CPU at [T=64, B=64] (M = 1024 per
+    minibatch: the size from which this repo's update takes its split-GEMM / bf16-split conv
+    kernels), SGD, two iterations -- algo_cases.BIG_CASE."""
+    import algo_cases as C
+    from rlpyt.agents.pg.atari import AtariFfAgent
+    from rlpyt.agents.pg.base import AgentInfo
+    from rlpyt.algos.pg.ppo import PPO
+    from rlpyt.envs.base import EnvSpaces
+    from rlpyt.samplers.collections import AgentSamplesBsv, BatchSpec, EnvSamples, Samples
+    from rlpyt.spaces.int_box import IntBox
+    spaces = EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
+                       action=IntBox(0, C.A))
+    name, _algo, kwargs, mbr = C.BIG_CASE
+    T, B = C.BIG_T, C.BIG_B
+    inp = C.batch_inputs(T, B, seed=78)
+    torch.manual_seed(C.INIT_SEED)
+    agent = AtariFfAgent()
+    agent.initialize(spaces)
+    obs = inp["observation"]
+    prev_action, action = inp["all_action"][:-1], inp["all_action"][1:]
+    prev_reward, reward = inp["all_reward"][:-1], inp["all_reward"][1:]
+    with torch.no_grad():
+        dist_info, value = agent(obs, prev_action, prev_reward)
+        _, bv = agent(obs[-1], action[-1], reward[-1])
+        bv = (bv + 0.25).unsqueeze(0)
+    samples = Samples(
+        agent=AgentSamplesBsv(action=action, prev_action=prev_action,
+                              agent_info=AgentInfo(dist_info=dist_info, value=value),
+                              bootstrap_value=bv),
+        env=EnvSamples(observation=obs, reward=reward, prev_reward=prev_reward,
+                       done=inp["done"], env_info=()))
+    algo = PPO(**kwargs)
+    algo.initialize(agent=agent, n_itr=C.N_ITR, batch_spec=BatchSpec(T, B), mid_batch_reset=mbr,
+                    examples=None, world_size=1, rank=0)
+    out = {f"{name}_old_prob": dist_info.prob.numpy().copy(),
+           f"{name}_old_value": value.numpy().copy(), f"{name}_bootstrap_value": bv.numpy().copy(),
+           f"{name}_obs_crc": np.int64(int(obs.to(torch.int64).sum()))}
+    np.random.seed(C.SHUFFLE_SEED)
+    for itr in range(C.N_RUN):
+        agent.train_mode(itr)
+        info = algo.optimize_agent(itr, samples)
+        for f in ("loss", "gradNorm", "entropy", "perplexity"):
+            out[f"{name}_itr{itr}_{f}"] = np.atleast_1d(np.array(getattr(info, f), dtype=np.float64))
+        sums, abs_sums = C.param_stats(list(agent.parameters()))
+        out[f"{name}_itr{itr}_param_sums"] = sums
+        out[f"{name}_itr{itr}_param_abs_sums"] = abs_sums
+        for n, p in agent.model.named_parameters():
+            if p.numel() <= 8192:
+                out[f"{name}_itr{itr}_param__{n}"] = p.detach().numpy().copy()
+            else:       # a strided sample of the big tensors (trunk weight: every 433rd element)
+                out[f"{name}_itr{itr}_paramsample__{n}"] = p.detach().reshape(-1)[::433].numpy().copy()
+    save("algos_big", **out)
+
+
 def gen_dqn_iterations():
     """The reference DQN.optimize_agent (rlpyt/algos/dqn/dqn.py:158-190) with its AtariDqnAgent
     and frame replay buffers on CPU: append, sample, loss, clip, Adam, priority and target
@@ -1111,7 +1166,8 @@ if __name__ == "__main__":
     gens = dict(scans=gen_scans, nstep=gen_nstep, normalize=gen_normalize, losses=gen_losses,
                 sumtree=gen_sumtree, frames=gen_frames, replay=gen_replay,
                 seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
-                models=gen_models, sampler=gen_sampler, algos=gen_algos, dqn_iterations=gen_dqn_iterations,
+                models=gen_models, sampler=gen_sampler, algos=gen_algos, algos_big=gen_algos_big,
+                dqn_iterations=gen_dqn_iterations,
                 r2d1_iterations=gen_r2d1_iterations, agents=gen_agents,
                 runner_keys=gen_runner_keys, protocol=gen_protocol)
     for name in (sys.argv[1:] or list(gens)):      # python make_golden.py [subset ...]

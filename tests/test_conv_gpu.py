@@ -379,25 +379,86 @@ def test_bf16_split_kernels_are_f32_accurate(ops):
     assert (db1.double() - db_ref).abs().max().item() <= 1e-5 * dy1_64.abs().sum(dim=(0, 2, 3)).max().item()
 
 
-# (8192, 3456, 512) and (8000, 2100, 64): >= 512 tiles of 256 x 128 -> the 256-row-tile variant
-@pytest.mark.parametrize("M,N,K", [(8192, 512, 3456), (8192, 3456, 512), (8000, 2100, 64),
-                                   (1000, 3456, 512), (130, 200, 96), (1, 1, 32)])
-def test_gemm_nt_bf16x6_is_f32_accurate(ops, M, N, K):
-    """ops.gemm_nt (rlpyt_gemm_nt_f32: a b^T from three-piece bf16 splits, six products) against
-    float64 beside torch's own f32 GEMM on wide-range operands: error <= 2x torch-f32's (+ 2^-22 of
-    the output scale), including ragged tile edges."""
+def _gemm_case(ops, layout, M, N, K, **kw):
+    """C[M,N] in layout NT (a[M,K] b[N,K]^T) / NN (a[M,K] b[K,N]) / TN (a[K,M]^T b[K,N]) against
+    float64, beside torch's own f32 GEMM of the same operands: (ours, theirs, scale)."""
     g = torch.Generator().manual_seed(M + N + K)
-    a64 = _wide((M, K), g, 2.0).float().double().cuda()
-    b64 = _wide((N, K), g, 2.0).float().double().cuda()
+    a64 = _wide((M, K), g, 2.0).float().double().cuda()          # logical A [M, K]
+    b64 = _wide((N, K), g, 2.0).float().double().cuda()          # logical B [N, K]
     ref = a64 @ b64.t()
     theirs = ((a64.float() @ b64.float().t()).double() - ref).abs().max().item()
-    c = ops.gemm_nt(a64.float(), b64.float())
-    ours = (c.double() - ref).abs().max().item()
-    assert ours <= 2 * theirs + ref.abs().max().item() * 2.0 ** -22, (ours, theirs)
+    a, b = a64.float(), b64.float()
+    if layout == "NT":
+        c = ops.gemm_nt(a, b, **kw)
+    elif layout == "NN":
+        c = ops.gemm_nn(a, b.t().contiguous())
+    else:
+        c = ops.gemm_tn(a.t().contiguous(), b.t().contiguous())
+    assert c.shape == ref.shape
+    return (c.double() - ref).abs().max().item(), theirs, ref.abs().max().item()
+
+
+# (8192, 3456, 512) and (8000, 2100, 64): >= 512 tiles of 256 x 128 -> the 256-row-tile variant of
+# the lock-step kernel; (8192, 512, 3456) / (8192, 3456, 512) / (512, 3456, 8192): the three trunk
+# GEMMs of the update at M = 8192 (forward, input gradient, weight gradient)
+@pytest.mark.parametrize("pingpong", [True, False])
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 3456), (8192, 3456, 512), (8000, 2100, 64),
+                                   (1000, 3456, 512), (130, 200, 96), (1, 1, 32)])
+def test_gemm_nt_bf16x6_is_f32_accurate(ops, M, N, K, pingpong):
+    """ops.gemm_nt (a b^T from three-piece bf16 splits, six products; ping-pong kernel
+    rlpyt_gemm_nt_pp_f32 and lock-step kernel rlpyt_gemm_nt_f32) against float64 beside torch's own
+    f32 GEMM on wide-range operands: error <= 2x torch-f32's (+ 2^-22 of the output scale),
+    including ragged tile edges."""
+    ours, theirs, scale = _gemm_case(ops, "NT", M, N, K, pingpong=pingpong)
+    assert ours <= 2 * theirs + scale * 2.0 ** -22, (ours, theirs)
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 3456, 512), (1024, 3456, 512), (130, 200, 96),
+                                   (1, 4, 32), (257, 132, 160)])
+def test_gemm_nn_bf16x6_is_f32_accurate(ops, M, N, K):
+    """ops.gemm_nn (a b with b [K, N] read as stored: the trunk's input gradient g W), same bound."""
+    ours, theirs, scale = _gemm_case(ops, "NN", M, N, K)
+    assert ours <= 2 * theirs + scale * 2.0 ** -22, (ours, theirs)
+
+
+# K >= 2048: the 8-chunk split with partial tiles (K = 8192 with 108 tiles: 96 whole-chunk units +
+# 12 tiles in two K parts per XCD; K = 2080: ragged chunks of 8 / 9 steps); below: one unit per tile
+@pytest.mark.parametrize("M,N,K", [(512, 3456, 8192), (512, 3456, 1024), (132, 200, 2080),
+                                   (4, 4, 32), (260, 136, 4096), (128, 4096, 2048)])
+def test_gemm_tn_bf16x6_is_f32_accurate(ops, M, N, K):
+    """ops.gemm_tn (a^T b, contraction over the leading axis of both operands: the trunk's weight
+    gradient g^T x), same bound; and run-to-run identical (fixed-order partial sums)."""
+    ours, theirs, scale = _gemm_case(ops, "TN", M, N, K)
+    assert ours <= 2 * theirs + scale * 2.0 ** -22, (ours, theirs)
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(K, M, generator=g).cuda()
+    b = torch.randn(K, N, generator=g).cuda()
+    c0 = ops.gemm_tn(a, b)
+    for _ in range(3):
+        assert torch.equal(ops.gemm_tn(a, b), c0)
+
+
+def test_gemm_layouts_agree_on_asymmetric_data(ops):
+    """Index-map check on data where a transposed / permuted operand would show: every layout
+    reproduces the float64 product of the SAME logical matrices element by element (an error in a
+    staging map moves whole rows, i.e. O(1) relative errors, far above this 1e-5 bound)."""
+    M, N, K = 200, 264, 96
+    g = torch.Generator().manual_seed(4)
+    a = (torch.arange(M * K, dtype=torch.float64).reshape(M, K) % 17 - 8) / 8 + \
+        torch.rand(M, K, generator=g, dtype=torch.float64)
+    b = (torch.arange(N * K, dtype=torch.float64).reshape(N, K) % 13 - 6) / 6 + \
+        torch.rand(N, K, generator=g, dtype=torch.float64)
+    ref = (a @ b.t()).cuda()
+    a32, b32 = a.float().cuda(), b.float().cuda()
+    for name, c in (("nt_pp", ops.gemm_nt(a32, b32, pingpong=True)),
+                    ("nt", ops.gemm_nt(a32, b32, pingpong=False)),
+                    ("nn", ops.gemm_nn(a32, b32.t().contiguous())),
+                    ("tn", ops.gemm_tn(a32.t().contiguous(), b32.t().contiguous()))):
+        _close(c, ref, rel=1e-5, what=name)
 
 
 def test_linear_nobias_autograd(ops):
-    """ops.linear_nobias (gemm_nt forward / input gradient, library weight gradient) against
+    """ops.linear_nobias (gemm_nt forward, gemm_nn input gradient, gemm_tn weight gradient) against
     F.linear in float64."""
     g = torch.Generator().manual_seed(3)
     x64 = torch.randn(1024, 3456, generator=g, dtype=torch.float64).cuda().requires_grad_(True)
@@ -410,7 +471,7 @@ def test_linear_nobias_autograd(ops):
     (y * gy.float()).sum().backward()
     _close(y, F.linear(x64, w64), rel=3e-6, what="linear_nobias fwd")
     _close(x.grad, x64.grad, rel=3e-6, what="linear_nobias dx")
-    _close(w.grad, w64.grad, rel=2e-5, what="linear_nobias dw")
+    _close(w.grad, w64.grad, rel=3e-6, what="linear_nobias dw")
 
 
 def test_conv_kernels_run_to_run_identical_at_update_size(ops):
@@ -428,6 +489,7 @@ def test_conv_kernels_run_to_run_identical_at_update_size(ops):
     g2 = torch.randn(M, 3456, generator=g).cuda()
     a = torch.randn(M, 3456, generator=g).cuda()
     wt = (torch.randn(512, 3456, generator=g) * 0.02).cuda()
+    g512 = torch.randn(M, 512, generator=g).cuda()
     ws = torch.empty(lib.rlpyt_atari_conv_wgrad_workspace_bytes(), dtype=torch.uint8, device="cuda")
     ref = None
     for it in range(10):
@@ -442,7 +504,8 @@ def test_conv_kernels_run_to_run_identical_at_update_size(ops):
                                             ptr(dw2), ptr(db2), stream()))
         check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs), ptr(idx), T, B, M, ptr(dy1), 1. / 255, ptr(ws),
                                               ptr(dw1), ptr(db1), stream()))
-        cur = dict(y1=y1, y2=y2, dy1=dy1, dw2=dw2, db2=db2, dw1=dw1, db1=db1, gemm=ops.gemm_nt(a, wt))
+        cur = dict(y1=y1, y2=y2, dy1=dy1, dw2=dw2, db2=db2, dw1=dw1, db1=db1, gemm=ops.gemm_nt(a, wt),
+                   gemm_nn=ops.gemm_nn(g512, wt), gemm_tn=ops.gemm_tn(g512, a))
         torch.cuda.synchronize()
         if ref is None:
             ref = {k: v.clone() for k, v in cur.items()}

@@ -1,8 +1,10 @@
 """N > 1 on the PRODUCT path: two ranks, each its own process, both on
 cuda:0 (a 1-GPU test box), process group over gloo, running the real ``PPO`` + ``AtariFfAgent``:
-MFMA conv stack in index mode, hipBLASLt trunk, fused head + loss kernel whose head-parameter
-gradients reach autograd only through a custom Function -- the piece that could silently bypass
-DistributedDataParallel's gradient hooks (rlpyt/agents/base.py:118-136, runners/sync_rl.py:60-101).
+MFMA conv stack in index mode, the trunk (at M >= 1024: the bf16x6 GEMMs of ``_LinearNoBias``, a
+custom autograd Function that produces the trunk-weight gradient DDP all-reduces; below: F.linear),
+fused head + loss kernel whose head-parameter gradients reach autograd only through a custom
+Function -- the pieces that could silently bypass DistributedDataParallel's gradient hooks
+(rlpyt/agents/base.py:118-136, runners/sync_rl.py:60-101).  Run at M = 16 and at M = 1024.
 
 Checks
 * parameters are bit-identical across the ranks after every iteration (ranks hold different data);
@@ -20,7 +22,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-T, B, A = 8, 4, 6
+A = 6
+SHAPES = [(8, 4), (64, 32)]      # M = T*B/2 = 16 (F.linear trunk) and 1024 (split-GEMM trunk)
 INIT_SEED, SHUFFLE_SEED = 11, 5
 PPO_KW = dict(discount=0.99, learning_rate=0.05, value_loss_coeff=1., entropy_loss_coeff=0.01,
               OptimCls=torch.optim.SGD, clip_grad_norm=1., gae_lambda=0.95, minibatches=2,
@@ -44,7 +47,7 @@ def _agent():
     return agent
 
 
-def _samples(agent, rank):
+def _samples(agent, rank, T, B):
     """A fixed [T, B] sample batch per rank; the behaviour policy is the agent's initial one."""
     from rlpyt_amd.agents.pg.categorical import AgentInfo
     from rlpyt_amd.distributions.categorical import DistInfo
@@ -70,7 +73,7 @@ def _flat(agent):
     return torch.cat([p.detach().reshape(-1) for p in agent.parameters()]).cpu()
 
 
-def _rank_main(rank, world_size, port, outdir):
+def _rank_main(rank, world_size, port, outdir, T, B):
     import torch.distributed as dist
     from rlpyt_amd import _lib
     from rlpyt_amd.algos.pg.ppo import PPO
@@ -81,7 +84,7 @@ def _rank_main(rank, world_size, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world_size,
                             init_method=f"tcp://127.0.0.1:{port}")
     agent = _agent()
-    samples = _samples(agent, rank)          # BEFORE the DDP wrap: same forward on every rank
+    samples = _samples(agent, rank, T, B)    # BEFORE the DDP wrap: same forward on every rank
     agent.data_parallel()
     algo = PPO(**PPO_KW)
     algo.initialize(agent=agent, n_itr=N_ITR, batch_spec=BatchSpec(T, B), mid_batch_reset=True,
@@ -103,7 +106,7 @@ def _rank_main(rank, world_size, port, outdir):
     dist.destroy_process_group()
 
 
-def _one_process_mean_gradient_run():
+def _one_process_mean_gradient_run(T, B):
     """The same updates in one process: per minibatch, the two ranks' losses are averaged before
     backward (== DDP's gradient mean), then the same clip + SGD step."""
     from rlpyt_amd.agents.base import AgentInputs
@@ -111,7 +114,7 @@ def _one_process_mean_gradient_run():
     from rlpyt_amd.samplers.collections import BatchSpec
     from rlpyt_amd.utils.misc import iterate_mb_idxs
     agent = _agent()
-    samples = [_samples(agent, r) for r in range(2)]
+    samples = [_samples(agent, r, T, B) for r in range(2)]
     algo = PPO(**PPO_KW)
     algo.initialize(agent=agent, n_itr=N_ITR, batch_spec=BatchSpec(T, B), mid_batch_reset=True,
                     examples=None, world_size=1, rank=0)
@@ -144,9 +147,10 @@ def _one_process_mean_gradient_run():
     return params, np.array(losses)
 
 
-def test_two_ranks_product_ppo_matches_mean_gradient_run(tmp_path):
+@pytest.mark.parametrize("T,B", SHAPES)
+def test_two_ranks_product_ppo_matches_mean_gradient_run(tmp_path, T, B):
     import torch.multiprocessing as tmp
-    tmp.spawn(_rank_main, args=(2, 29541, str(tmp_path)), nprocs=2, join=True)
+    tmp.spawn(_rank_main, args=(2, 29541 + T, str(tmp_path), T, B), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
     for res in (r0, r1):       # the product path ran in the rank processes, under DDP
@@ -154,12 +158,15 @@ def test_two_ranks_product_ppo_matches_mean_gradient_run(tmp_path):
         for k in ("ppo_head_loss_kernel<8, 6, true>", "conv2_bwd_kernel", "conv1_wgrad_kernel",
                   "conv1_fwd_kernel", "scan_exact_kernel<0, 1, 32, false>"):
             assert res["variants"].get(k, 0) > 0, (k, sorted(res["variants"]))
+        big = T * B // PPO_KW["minibatches"] >= 1024      # _LinearNoBias under DDP's hooks
+        for k in ("gemm_nn_pp_kernel", "gemm_tn_pp_kernel", "conv2_fwd_x6_kernel"):
+            assert (res["variants"].get(k, 0) > 0) == big, (k, big, sorted(res["variants"]))
     # ranks saw different data ...
     assert r0["info"][0]["loss"] != r1["info"][0]["loss"]
     # ... and hold bit-identical parameters after every iteration
     for p0, p1 in zip(r0["params"], r1["params"]):
         assert torch.equal(p0, p1)
-    ref_params, ref_losses = _one_process_mean_gradient_run()
+    ref_params, ref_losses = _one_process_mean_gradient_run(T, B)
     n_upd = PPO_KW["minibatches"] * PPO_KW["epochs"]
     got_losses = np.array([[a, b] for a, b in zip(sum((i["loss"] for i in r0["info"]), []),
                                                   sum((i["loss"] for i in r1["info"]), []))])

@@ -512,13 +512,31 @@ def _conv_bwd():
 @case("gemm_nt_x6_kernel<128>")
 def _gemm_nt():
     import test_conv_gpu as Cv
-    Cv.test_gemm_nt_bf16x6_is_f32_accurate(_ops(), 130, 200, 96)
+    Cv.test_gemm_nt_bf16x6_is_f32_accurate(_ops(), 130, 200, 96, False)
 
 
 @case("gemm_nt_x6_kernel<256>")
 def _gemm_nt_tall():
     import test_conv_gpu as Cv
-    Cv.test_gemm_nt_bf16x6_is_f32_accurate(_ops(), 8000, 2100, 64)     # 32 x 17 tiles of 256 x 128
+    Cv.test_gemm_nt_bf16x6_is_f32_accurate(_ops(), 8000, 2100, 64, False)     # 32 x 17 tiles of 256 x 128
+
+
+@case("gemm_nt_pp_kernel")
+def _gemm_nt_pp():
+    import test_conv_gpu as Cv
+    Cv.test_gemm_nt_bf16x6_is_f32_accurate(_ops(), 130, 200, 96, True)
+
+
+@case("gemm_nn_pp_kernel")
+def _gemm_nn_pp():
+    import test_conv_gpu as Cv
+    Cv.test_gemm_nn_bf16x6_is_f32_accurate(_ops(), 257, 132, 160)
+
+
+@case("gemm_tn_pp_kernel", "gemm_reduce_slots_kernel")
+def _gemm_tn_pp():
+    import test_conv_gpu as Cv
+    Cv.test_gemm_tn_bf16x6_is_f32_accurate(_ops(), 132, 200, 2080)    # ragged K chunks + partials
 
 
 @case("sample_convs_kernel")
