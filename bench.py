@@ -4,8 +4,11 @@
 A "step" = one full PPO iteration of the hot path on one synthetic batch:
   rollout of T x B env steps (host envs, batched action selection on the device, sample
   batch resident in HBM) -> fused GAE scan -> epochs x minibatches of {index-mode MFMA conv
-  stack, hipBLASLt trunk, fused heads + PPO loss kernel, backward, clip + Adam in two launches}
+  stack, trunk GEMM x W^T (bf16x6), fused trunk bias/ReLU + heads + PPO loss kernel, backward
+  (trunk g W and g^T x on the same bf16x6 kernel body, conv2_bwd, conv1_wgrad), clip + Adam in two
+  launches} -- no vendor GEMM / convolution in the update
   (under N>1: DistributedDataParallel all-reduces the 7.14 MB of gradients per minibatch).
+`python bench.py --gpus N` launches its own N ranks (one process per GPU, RCCL).
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      -- the dominant own kernel of the timed region by total HIP-event time, timed live
@@ -47,7 +50,8 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, den
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 # bf16-split kernels (DESIGN.md "fp32 contractions on the bf16 pipe"): issued bf16 MFMA flops per
 # algorithmic fp32 flop (3 exact pieces of one operand; 6 products of two 3-piece operands)
-BF16_SPLIT = {"conv1_fwd": 3, "conv1_wgrad": 3, "conv2_fwd": 6, "gemm_nt": 6}
+BF16_SPLIT = {"conv1_fwd": 3, "conv1_wgrad": 3, "conv2_fwd": 6, "gemm_nt": 6, "gemm_nn": 6,
+              "gemm_tn": 6}
 KERNEL_NAMES = {
     "conv1_fwd": "conv1_fwd_kernel (gather + u8->bf16 + conv 4->16 k8 s4 + bias + ReLU; exact "
                  "bf16x3 split of w1, f32 accumulate)",
@@ -58,8 +62,14 @@ KERNEL_NAMES = {
     "conv2_wgrad": "conv2_wgrad_kernel (+ bias grad, fp32 MFMA)",
     "conv1_wgrad": "conv1_wgrad_kernel (gather + u8->bf16 + weight/bias grad; exact bf16x3 split "
                    "of dy1, f32 accumulate)",
-    "gemm_nt": "gemm_nt_x6_kernel (update trunk x W^T and g W: f32 GEMM from three-piece bf16 splits of "
-               "both operands, six products, f32 accumulate, dropped terms <= 2^-24, 2^-27 rms)",
+    "gemm_nt": "gemm_nt_pp_kernel (update trunk forward x W^T [8192,3456]x[512,3456]^T: f32 GEMM from "
+               "three-piece bf16 splits of both operands, six products, f32 accumulate, dropped terms "
+               "<= 2^-24, 2^-27 rms; ping-pong wave halves)",
+    "gemm_nn": "gemm_nn_pp_kernel (update trunk input gradient g W [8192,512]x[512,3456], W read as "
+               "stored; same bf16x6 arithmetic and kernel body)",
+    "gemm_tn": "gemm_tn_pp_kernel + gemm_reduce_slots_kernel (update trunk weight gradient g^T x "
+               "[8192,512]^T x [8192,3456]: 8 K chunks <-> XCDs, partial tiles, fixed-order sum; same "
+               "bf16x6 arithmetic and kernel body)",
     "obs_to_nhwc": "obs_to_nhwc_f32_kernel (minibatch gather + u8->f32 + CHW->HWC)",
     "gather_tb": "gather_wide_kernel (minibatch observation gather)",
     "gae": "scan_exact_kernel<GAE>", "ppo_loss": "pg_loss_kernel<PPO>",
@@ -393,13 +403,19 @@ def main():
                 issued = g["TFLOPs"] * BF16_SPLIT[name]
                 f_hbm, f_mfma = g["GBps"] / HBM_PEAK_GBPS, issued / BF16_MFMA_PEAK_TFLOPS
                 hbm = f_hbm >= f_mfma
+                nx = BF16_SPLIT[name]
                 out["roofline"] = {"kernel": KERNEL_NAMES.get(name, name),
                                    "bound": "hbm" if hbm else "mfma",
                                    "achieved": g["GBps"] if hbm else issued,
                                    "peak": HBM_PEAK_GBPS if hbm else BF16_MFMA_PEAK_TFLOPS,
                                    "unit": "GB/s" if hbm else "TFLOP/s",
                                    "frac": max(f_hbm, f_mfma), "traffic": None,
-                                   "frac_hbm": f_hbm, "frac_bf16_mfma_issued": f_mfma,
+                                   "frac_note": f"mfma bound: ISSUED bf16 flops ({nx} MFMAs per "
+                                                f"algorithmic MAC) over the dense bf16 peak = the "
+                                                f"fraction of the bf16x{nx} emulation ceiling "
+                                                f"({BF16_MFMA_PEAK_TFLOPS / nx:.0f} TFLOP/s algorithmic)",
+                                   "frac_hbm": f_hbm, f"frac_of_bf16x{nx}_ceiling": f_mfma,
+                                   "frac_alg_vs_bf16_peak": g["TFLOPs"] / BF16_MFMA_PEAK_TFLOPS,
                                    "alg_fp32_TFLOPs": g["TFLOPs"],
                                    "alg_over_f32_mfma_peak": g["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
                                    "avg_us": g["avg_us"], "launches": g["launches"],
@@ -665,6 +681,10 @@ def cpu_baseline(T, B_cpu, env_kwargs):
                             iters=1, threads=None, max_threads=usable_cpus())
     B_cpu = res["B"]
     return {"value": res["value"], "unit": "env-steps/s", "cores": res["cores"], "kind": "port",
+            "functions_kind": "numpy / torch-CPU oracle restatements (oracle/np_oracle.py) -- FASTER "
+                              "than the reference's own torch loops (GAE: 0.3 ms here vs 7.2 ms for "
+                              "rlpyt/algos/utils.py:24-40 on CPU tensors, SURVEY 8a), so the per-"
+                              "function ratios understate the gain over the reference",
             "kind_note": "CPU port of the reference iteration (rlpyt SerialSampler + PPO + AtariFfAgent "
                          "semantics); /root/reference is not on the bench box.  The port's update is "
                          "pinned to the reference's own PPO.optimize_agent run at 1e-5 "

@@ -49,6 +49,37 @@ constexpr int P_SB = 2 * P_OB;             // bytes per stage
 constexpr int P_LDS = 2 * P_SB;            // 122,880
 constexpr int KC = 0, KS = 1;              // operand layouts: K contiguous / K strided
 
+// Debug build (-DRLPYT_TIMING): per-wave cycle totals of the loop phases (scripts/debug/
+// gemm_pp_timing.py); compiled out of the product.  slots: 0 load segment, 1 barrier after load,
+// 2 compute segment, 3 barrier after compute
+// PP_SKIP (debug builds only; results are then wrong): bit 0 no fragment reads, 1 no split / LDS
+// writes, 2 no global loads in the loop, 3 no MFMAs -- what a phase costs is what leaving it out saves
+#ifndef PP_SKIP
+#define PP_SKIP 0
+#endif
+#define PP_SETS 4      // fetch register sets = load segments between request and use
+#ifdef RLPYT_TIMING
+__device__ float g_timing_gemm_pp[1024 * 8 * 4];
+#define PP_T0() long long t_prev_ = clock64(), t_acc_[4] = {0, 0, 0, 0};
+#define PP_T(k)                                  \
+  {                                              \
+    const long long t_now_ = clock64();          \
+    t_acc_[k] += t_now_ - t_prev_;               \
+    t_prev_ = t_now_;                            \
+  }
+#define PP_TOUT()                                                                         \
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) {                                     \
+    float* dbg_ = g_timing_gemm_pp + ((int64_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 4;  \
+    for (int k = 0; k < 4; ++k) dbg_[k] = (float)t_acc_[k];                               \
+  }
+#else
+#define PP_T0()
+#define PP_T(k)
+#define PP_TOUT()
+#endif
+
+typedef int i32x4_ __attribute__((ext_vector_type(4)));
+
 struct PpShape {
   int M, N;                  // C is [M, N]
   int lda, ldb;              // leading dimensions of A and B (elements)
@@ -119,7 +150,12 @@ __device__ __forceinline__ void pp_half(const float* __restrict__ X, int ld, int
     kstride = ld;
   }
   uint4 fa[2][2][3], fb[2][3];        // [slice][row tile][piece], [slice][piece]
-  f32x4 R[2][4];                      // two fetch register sets (steps u + 1 and u + 2)
+  // Fetch register sets: HBM latency under load is ~2 us (~3600 shader cycles) and a K-32 step
+  // should take ~1700, so the rows of a step are requested FOUR load segments before they are
+  // split (measured with two sets, requested at the end of a segment: every load segment waited
+  // ~900 cycles for its data and the step took 3560 cycles -- a closed latency loop, 2 steps -
+  // segment = latency; profiles/r3_gemm_pp_sweep1.log)
+  f32x4 R[PP_SETS][4];
   const int last = nk - 1;
 #define PP_FETCH(set_, step_)                                                     \
   {                                                                               \
@@ -136,19 +172,37 @@ __device__ __forceinline__ void pp_half(const float* __restrict__ X, int ld, int
     fa[sl][0][s] = *reinterpret_cast<const uint4*>(b_ + a_off);                   \
     fa[sl][1][s] = *reinterpret_cast<const uint4*>(b_ + a_off + 32 * P_ROWB);     \
   }
-  // LOAD segment for step u (parity p = u & 1): fragments of step u from stage p; the rows of step
-  // u + 1 (register set p ^ 1) -> pieces -> stage p ^ 1; then request step u + 3 into that set
-#define PP_LOAD(p_, u_)                                                           \
+  // LOAD segment for step u (parity p = u & 1): request step u + PP_SETS into the register set that
+  // the previous segment emptied (free = u % PP_SETS); fragments of step u from stage p; the rows
+  // of step u + 1 (set use = (u + 1) % PP_SETS) -> pieces -> stage p ^ 1
+  // (debug) keep values alive / opaque when a phase is left out, so that the others survive DCE
+#define PP_SINK4(x_) asm volatile("" ::"v"(__builtin_bit_cast(i32x4_, x_)));
+#define PP_OPAQUE4(x_)                            \
+  {                                               \
+    i32x4_ t_;                                    \
+    asm volatile("" : "=v"(t_));                  \
+    x_ = __builtin_bit_cast(uint4, t_);           \
+  }
+#define PP_ALL_FRAGS(OP_)                                                         \
+  _Pragma("unroll") for (int sl = 0; sl < 2; ++sl)                                \
+  _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                 \
+    OP_(fb[sl][s]) OP_(fa[sl][0][s]) OP_(fa[sl][1][s])                            \
+  }
+#define PP_LOAD(p_, free_, use_, u_)                                              \
   {                                                                               \
-    PP_FRAGS(p_)                                                                  \
-    PP_STAGE((p_) ^ 1, (p_) ^ 1)                                                  \
-    PP_FETCH((p_) ^ 1, (u_) + 3)                                                  \
+    if (!(PP_SKIP & 4)) PP_FETCH(free_, (u_) + PP_SETS)                           \
+    if (!(PP_SKIP & 1)) PP_FRAGS(p_)                                              \
+    else fb[0][0] = *reinterpret_cast<const uint4*>(lds + (p_) * P_SB + b_off);   \
+    __builtin_amdgcn_sched_barrier(0);   /* requests and LDS reads before any vmcnt wait */ \
+    if (!(PP_SKIP & 2)) PP_STAGE(use_, (p_) ^ 1)                                  \
+    else { _Pragma("unroll") for (int i = 0; i < 4; ++i) PP_SINK4(R[use_][i]) }   \
   }
   // COMPUTE segment: 2 slices x six products (smallest first) x 2 row tiles, nothing else
 #define PP_TERM(sl_, sa_, sb_)                                                    \
   acc[0] = mfma32_bf16(fa[sl_][0][sa_], fb[sl_][sb_], acc[0]);                    \
   acc[1] = mfma32_bf16(fa[sl_][1][sa_], fb[sl_][sb_], acc[1]);
 #define PP_COMPUTE()                                                              \
+  if (PP_SKIP & 8) { PP_ALL_FRAGS(PP_SINK4) } else                                \
   _Pragma("unroll") for (int sl = 0; sl < 2; ++sl) {                              \
     PP_TERM(sl, 2, 0) PP_TERM(sl, 0, 2) PP_TERM(sl, 1, 1)                         \
     PP_TERM(sl, 1, 0) PP_TERM(sl, 0, 1) PP_TERM(sl, 0, 0)                         \
@@ -161,52 +215,71 @@ __device__ __forceinline__ void pp_half(const float* __restrict__ X, int ld, int
     __syncthreads();                        \
     __builtin_amdgcn_sched_barrier(0);      \
   }
-  // ---- prologue: stage 0 <- step 0; sets: R[1] <- step 1, R[0] <- step 2 ----------------------
+  if (PP_SKIP & 1) { PP_ALL_FRAGS(PP_OPAQUE4) }
+  // ---- prologue: sets k <- step k; stage 0 <- step 0 -------------------------------------------
+  static_assert(PP_SETS == 4, "the loops below are unrolled for four fetch sets");
   PP_FETCH(0, 0)
   PP_FETCH(1, 1)
+  PP_FETCH(2, 2)
+  PP_FETCH(3, 3)
   PP_STAGE(0, 0)
-  PP_FETCH(0, 2)
   PP_BAR()
+  // one K-32 step of each half, i = step index mod 4 (static): half 0 computes step s + i while
+  // half 1 runs the load segment of step s + i, then half 0 runs the load segment of s + i + 1
+  // while half 1 computes s + i
+#define PP_H0(i_)                                                                 \
+  {                                                                               \
+    PP_COMPUTE()                                                                  \
+    PP_T(2)                                                                       \
+    PP_BAR()                                                                      \
+    PP_T(3)                                                                       \
+    PP_LOAD(((i_) + 1) & 1, ((i_) + 1) & 3, ((i_) + 2) & 3, s + (i_) + 1)         \
+    PP_T(0)                                                                       \
+    PP_BAR()                                                                      \
+    PP_T(1)                                                                       \
+  }
+#define PP_H1(i_)                                                                 \
+  {                                                                               \
+    PP_LOAD((i_) & 1, (i_) & 3, ((i_) + 1) & 3, s + (i_))                         \
+    PP_T(0)                                                                       \
+    PP_BAR()                                                                      \
+    PP_T(1)                                                                       \
+    PP_COMPUTE()                                                                  \
+    PP_T(2)                                                                       \
+    PP_BAR()                                                                      \
+    PP_T(3)                                                                       \
+  }
   int s = 0;
   if constexpr (HALF == 0) {
-    PP_LOAD(0, 0)                     // enters the loop with the fragments of step 0
+    PP_LOAD(0, 0, 1, 0)               // enters the loop with the fragments of step 0
     PP_BAR()
-    // P0(s): compute | P1(s): load for s + 1 | P0(s + 1): compute | P1(s + 1): load for s + 2
+    PP_T0()
 #pragma unroll 1
-    for (; s + 1 < nk; s += 2) {
-      PP_COMPUTE()
-      PP_BAR()
-      PP_LOAD(1, s + 1)
-      PP_BAR()
-      PP_COMPUTE()
-      PP_BAR()
-      PP_LOAD(0, s + 2)
-      PP_BAR()
+    for (; s + 3 < nk; s += 4) {
+      PP_H0(0) PP_H0(1) PP_H0(2) PP_H0(3)
     }
-    if (s < nk) {
-      PP_COMPUTE()
-      PP_BAR()
-    }
+    PP_TOUT()
+    if (s < nk) PP_H0(0)
+    if (s + 1 < nk) PP_H0(1)
+    if (s + 2 < nk) PP_H0(2)
   } else {
     PP_BAR()
+    PP_T0()
 #pragma unroll 1
-    for (; s + 1 < nk; s += 2) {
-      PP_LOAD(0, s)
-      PP_BAR()
-      PP_COMPUTE()
-      PP_BAR()
-      PP_LOAD(1, s + 1)
-      PP_BAR()
-      PP_COMPUTE()
-      PP_BAR()
+    for (; s + 3 < nk; s += 4) {
+      PP_H1(0) PP_H1(1) PP_H1(2) PP_H1(3)
     }
-    if (s < nk) {
-      PP_LOAD(0, s)
-      PP_BAR()
-      PP_COMPUTE()
-    }
+    PP_TOUT()
+    if (s < nk) PP_H1(0)
+    if (s + 1 < nk) PP_H1(1)
+    if (s + 2 < nk) PP_H1(2)
   }
+#undef PP_H1
+#undef PP_H0
 #undef PP_BAR
+#undef PP_ALL_FRAGS
+#undef PP_OPAQUE4
+#undef PP_SINK4
 #undef PP_COMPUTE
 #undef PP_TERM
 #undef PP_LOAD
@@ -356,6 +429,12 @@ void tn_plan(PpShape& sh) {
 }  // namespace rlpyt
 
 using namespace rlpyt;
+
+#ifdef RLPYT_TIMING
+extern "C" int rlpyt_debug_timing_read_gemm_pp(float* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timing_gemm_pp), (size_t)n * sizeof(float));
+}
+#endif
 
 static int pp_check(const char* fn, const float* a, const float* b, const float* c, int64_t M,
                     int64_t N, int64_t K) {
