@@ -57,7 +57,13 @@ constexpr int KC = 0, KS = 1;              // operand layouts: K contiguous / K 
 #ifndef PP_SKIP
 #define PP_SKIP 0
 #endif
-#define PP_SETS 4      // fetch register sets = load segments between request and use
+// Fetch register sets (debug builds may pass -DPP_SETS=4): 2 = the rows of step u + 1 are split in
+// load segment u and the set is refilled at once with step u + 3; 4 = four sets, refilled at the
+// START of a segment, four segments ahead (measured: 4-7 % SLOWER than 2 -- more loads in flight
+// lower the CU's vector-memory throughput; profiles/r3_gemm_pp_sweep2.log)
+#ifndef PP_SETS
+#define PP_SETS 2
+#endif
 #ifdef RLPYT_TIMING
 __device__ float g_timing_gemm_pp[1024 * 8 * 4];
 #define PP_T0() long long t_prev_ = clock64(), t_acc_[4] = {0, 0, 0, 0};
@@ -150,11 +156,6 @@ __device__ __forceinline__ void pp_half(const float* __restrict__ X, int ld, int
     kstride = ld;
   }
   uint4 fa[2][2][3], fb[2][3];        // [slice][row tile][piece], [slice][piece]
-  // Fetch register sets: HBM latency under load is ~2 us (~3600 shader cycles) and a K-32 step
-  // should take ~1700, so the rows of a step are requested FOUR load segments before they are
-  // split (measured with two sets, requested at the end of a segment: every load segment waited
-  // ~900 cycles for its data and the step took 3560 cycles -- a closed latency loop, 2 steps -
-  // segment = latency; profiles/r3_gemm_pp_sweep1.log)
   f32x4 R[PP_SETS][4];
   const int last = nk - 1;
 #define PP_FETCH(set_, step_)                                                     \
@@ -172,9 +173,10 @@ __device__ __forceinline__ void pp_half(const float* __restrict__ X, int ld, int
     fa[sl][0][s] = *reinterpret_cast<const uint4*>(b_ + a_off);                   \
     fa[sl][1][s] = *reinterpret_cast<const uint4*>(b_ + a_off + 32 * P_ROWB);     \
   }
-  // LOAD segment for step u (parity p = u & 1): request step u + PP_SETS into the register set that
-  // the previous segment emptied (free = u % PP_SETS); fragments of step u from stage p; the rows
-  // of step u + 1 (set use = (u + 1) % PP_SETS) -> pieces -> stage p ^ 1
+  // LOAD segment for step u (parity p = u & 1): fragments of step u from stage p; the rows of step
+  // u + 1 (register set (u + 1) % PP_SETS) -> pieces -> stage p ^ 1; that set is then refilled with
+  // step u + 3 (PP_SETS == 4: instead, step u + 4 is requested first, into the set u % 4 that the
+  // previous segment emptied)
   // (debug) keep values alive / opaque when a phase is left out, so that the others survive DCE
 #define PP_SINK4(x_) asm volatile("" ::"v"(__builtin_bit_cast(i32x4_, x_)));
 #define PP_OPAQUE4(x_)                            \
@@ -190,12 +192,13 @@ __device__ __forceinline__ void pp_half(const float* __restrict__ X, int ld, int
   }
 #define PP_LOAD(p_, free_, use_, u_)                                              \
   {                                                                               \
-    if (!(PP_SKIP & 4)) PP_FETCH(free_, (u_) + PP_SETS)                           \
+    if (PP_SETS == 4 && !(PP_SKIP & 4)) PP_FETCH((free_) % PP_SETS, (u_) + 4)                 \
     if (!(PP_SKIP & 1)) PP_FRAGS(p_)                                              \
     else fb[0][0] = *reinterpret_cast<const uint4*>(lds + (p_) * P_SB + b_off);   \
     __builtin_amdgcn_sched_barrier(0);   /* requests and LDS reads before any vmcnt wait */ \
-    if (!(PP_SKIP & 2)) PP_STAGE(use_, (p_) ^ 1)                                  \
-    else { _Pragma("unroll") for (int i = 0; i < 4; ++i) PP_SINK4(R[use_][i]) }   \
+    if (!(PP_SKIP & 2)) PP_STAGE((use_) % PP_SETS, (p_) ^ 1)                      \
+    else { _Pragma("unroll") for (int i = 0; i < 4; ++i) PP_SINK4(R[(use_) % PP_SETS][i]) } \
+    if (PP_SETS == 2 && !(PP_SKIP & 4)) PP_FETCH((use_) % PP_SETS, (u_) + 3)      \
   }
   // COMPUTE segment: 2 slices x six products (smallest first) x 2 row tiles, nothing else
 #define PP_TERM(sl_, sa_, sb_)                                                    \
@@ -216,13 +219,16 @@ __device__ __forceinline__ void pp_half(const float* __restrict__ X, int ld, int
     __builtin_amdgcn_sched_barrier(0);      \
   }
   if (PP_SKIP & 1) { PP_ALL_FRAGS(PP_OPAQUE4) }
-  // ---- prologue: sets k <- step k; stage 0 <- step 0 -------------------------------------------
-  static_assert(PP_SETS == 4, "the loops below are unrolled for four fetch sets");
+  // ---- prologue: stage 0 <- step 0; the sets hold the next steps -----------------------------------
+  static_assert(PP_SETS == 2 || PP_SETS == 4, "the loops below index the sets modulo 2 or 4");
   PP_FETCH(0, 0)
   PP_FETCH(1, 1)
-  PP_FETCH(2, 2)
-  PP_FETCH(3, 3)
+  if (PP_SETS == 4) {
+    PP_FETCH(2 % PP_SETS, 2)
+    PP_FETCH(3 % PP_SETS, 3)
+  }
   PP_STAGE(0, 0)
+  if (PP_SETS == 2) PP_FETCH(0, 2)
   PP_BAR()
   // one K-32 step of each half, i = step index mod 4 (static): half 0 computes step s + i while
   // half 1 runs the load segment of step s + i, then half 0 runs the load segment of s + i + 1

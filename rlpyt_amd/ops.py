@@ -629,9 +629,10 @@ def fc_small(x, weight, bias=None, relu=True):
     return y
 
 
-# RLPYT_GEMM_PP=0 selects the round-2 lock-step kernel for a @ b.T (A/B timing); default: the
-# ping-pong kernel body shared with the two backward GEMMs (csrc/gemm_pp.hip)
-GEMM_NT_PINGPONG = os.environ.get("RLPYT_GEMM_PP", "1") != "0"
+# a @ b.T runs on the lock-step kernel (csrc/gemm.hip: 156-163 us at the trunk's forward shape);
+# RLPYT_GEMM_PP=1 selects the ping-pong kernel body of the two backward GEMMs instead
+# (csrc/gemm_pp.hip: 221-233 us there -- kept for A/B timing, profiles/r3_gemm_pp_sweep*.log)
+GEMM_NT_PINGPONG = os.environ.get("RLPYT_GEMM_PP", "0") != "0"
 
 
 def gemm_nt(a, b, pingpong=None):
