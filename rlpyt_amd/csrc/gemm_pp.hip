@@ -64,6 +64,10 @@ constexpr int KC = 0, KS = 1;              // operand layouts: K contiguous / K 
 #ifndef PP_SETS
 #define PP_SETS 2
 #endif
+// 1: warp-specialised producer / consumer waves (below); 0: the ping-pong halves
+#ifndef PP_WS
+#define PP_WS 1
+#endif
 #ifdef RLPYT_TIMING
 __device__ float g_timing_gemm_pp[1024 * 8 * 4];
 #define PP_T0() long long t_prev_ = clock64(), t_acc_[4] = {0, 0, 0, 0};
@@ -294,6 +298,170 @@ __device__ __forceinline__ void pp_half(const float* __restrict__ X, int ld, int
 #undef PP_FETCH
 }
 
+// ---------------------------------------------------------------------------------------------
+// Warp-specialised variant (PP_WS, the default): waves 4-7 are PRODUCERS (fetch both operands, split,
+// write the LDS stage: 8 float4 per thread and K-32 step), waves 0-3 are CONSUMERS (one per SIMD,
+// wave tile 64 x 64: 24 fragment reads and 48 MFMAs per step), ONE barrier per step.  What the
+// ping-pong halves above measured (profiles/r3_gemm_pp_sweep*.log): MFMA issue is asynchronous on
+// gfx950 (24 MFMAs issue in ~80 cycles and drain from a queue), so a single wave per SIMD keeps the
+// matrix pipe busy while it waits at the barrier and reads the next fragments -- the two phases of a
+// ping-pong step only added barrier waits (3300-3800 cycles per step against 1540 of matrix-pipe
+// time, although every pair of its phases overlapped fine).  64 x 64 wave tiles also halve the LDS
+// fragment traffic per MFMA (0.5 KB instead of 0.75 KB).
+// ---------------------------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ void pp_operand_map(const float* __restrict__ X, int ld, int dim, int r0,
+                                               int ks0, int ht, const float* (&gp)[4], int (&soff)[4],
+                                               int64_t& kstride) {
+  if constexpr (L == KC) {
+    const int row = ht >> 3, kq = ht & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gp[i] = X + (int64_t)min(r0 + row + 32 * i, dim - 1) * ld + (int64_t)ks0 * P_BK + 4 * kq;
+      soff[i] = (row + 32 * i) * P_ROWB + kq * 8;
+    }
+    kstride = 1;
+  } else {
+    const int mg = ht & 7, ng = 8 * (ht >> 6) + ((ht >> 3) & 7);
+    const int col = min(r0 + 4 * ng, dim - 4);   // dim % 4 == 0: blocks are all in or all out
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gp[i] = X + ((int64_t)ks0 * P_BK + 4 * mg + i) * ld + col;
+      soff[i] = (4 * ng + i) * P_ROWB + mg * 8;
+    }
+    kstride = ld;
+  }
+}
+
+#define WS_BAR()                            \
+  {                                         \
+    __builtin_amdgcn_sched_barrier(0);      \
+    __syncthreads();                        \
+    __builtin_amdgcn_sched_barrier(0);      \
+  }
+
+template <int LA, int LB>
+__device__ __forceinline__ void ws_producer(const float* __restrict__ A, const float* __restrict__ B,
+                                            const PpShape& sh, int tm, int tn, int ks0, int nk,
+                                            uint8_t* lds) {
+  const int ht = threadIdx.x & 255;
+  const float *gpa[4], *gpb[4];
+  int soa[4], sob[4];
+  int64_t ksa, ksb;
+  pp_operand_map<LA>(A, sh.lda, sh.M, tm * PT, ks0, ht, gpa, soa, ksa);
+  pp_operand_map<LB>(B, sh.ldb, sh.N, tn * PT, ks0, ht, gpb, sob, ksb);
+  f32x4 Ra[2][4], Rb[2][4];            // two fetch sets: steps u + 1 and u + 2
+  const int last = nk - 1;
+#define WS_FETCH(set_, step_)                                                     \
+  if (!(PP_SKIP & 4)) {                                                           \
+    const int64_t ko_ = (int64_t)min((step_), last) * P_BK;                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                               \
+      Ra[set_][i] = *reinterpret_cast<const f32x4*>(gpa[i] + ko_ * ksa);          \
+      Rb[set_][i] = *reinterpret_cast<const f32x4*>(gpb[i] + ko_ * ksb);          \
+    }                                                                             \
+  }
+#define WS_STAGE(set_, stage_)                                                    \
+  if (!(PP_SKIP & 2)) {                                                           \
+    pp_stage<LA>(Ra[set_], lds + (stage_) * P_SB, soa);                           \
+    pp_stage<LB>(Rb[set_], lds + (stage_) * P_SB + P_OB, sob);                    \
+  } else {                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                               \
+      asm volatile("" ::"v"(Ra[set_][i]), "v"(Rb[set_][i]));                      \
+    }                                                                             \
+  }
+  // step u of the producer: the rows of step u + 1 -> pieces -> stage (u + 1) & 1, refill the set
+#define WS_PSTEP(p_, u_)                                                          \
+  {                                                                               \
+    WS_STAGE((p_) ^ 1, (p_) ^ 1)                                                  \
+    WS_FETCH((p_) ^ 1, (u_) + 3)                                                  \
+    PP_T(0)                                                                       \
+    WS_BAR()                                                                      \
+    PP_T(1)                                                                       \
+  }
+  {
+    const int64_t k0 = 0, k1 = (int64_t)min(1, last) * P_BK, k2 = (int64_t)min(2, last) * P_BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Ra[0][i] = *reinterpret_cast<const f32x4*>(gpa[i] + k0 * ksa);
+      Rb[0][i] = *reinterpret_cast<const f32x4*>(gpb[i] + k0 * ksb);
+      Ra[1][i] = *reinterpret_cast<const f32x4*>(gpa[i] + k1 * ksa);
+      Rb[1][i] = *reinterpret_cast<const f32x4*>(gpb[i] + k1 * ksb);
+    }
+    pp_stage<LA>(Ra[0], lds, soa);
+    pp_stage<LB>(Rb[0], lds + P_OB, sob);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Ra[0][i] = *reinterpret_cast<const f32x4*>(gpa[i] + k2 * ksa);
+      Rb[0][i] = *reinterpret_cast<const f32x4*>(gpb[i] + k2 * ksb);
+    }
+  }
+  WS_BAR()                              // stage 0 ready
+  PP_T0()
+  int s = 0;
+#pragma unroll 1
+  for (; s + 1 < nk; s += 2) {
+    WS_PSTEP(0, s)
+    WS_PSTEP(1, s + 1)
+  }
+  PP_TOUT()
+  if (s < nk) WS_PSTEP(0, s)
+#undef WS_PSTEP
+#undef WS_STAGE
+#undef WS_FETCH
+}
+
+__device__ __forceinline__ void ws_consumer(const uint8_t* lds, int nk, int a_off, int b_off,
+                                            f32x16 (&acc)[2][2]) {
+  uint4 fa[2][2][3], fb[2][2][3];      // [slice][tile][piece]
+#define WS_FRAGS(stage_)                                                          \
+  _Pragma("unroll") for (int sl = 0; sl < 2; ++sl)                                \
+  _Pragma("unroll") for (int p = 0; p < 3; ++p)                                   \
+  _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                 \
+    const uint8_t* b_ = lds + (stage_) * P_SB + sl * 32 + p * P_PB + t * 32 * P_ROWB; \
+    fa[sl][t][p] = *reinterpret_cast<const uint4*>(b_ + a_off);                   \
+    fb[sl][t][p] = *reinterpret_cast<const uint4*>(b_ + b_off);                   \
+  }
+#define WS_TERM(sl_, sa_, sb_)                                                    \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                   \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                   \
+    acc[i][j] = mfma32_bf16(fa[sl_][i][sa_], fb[sl_][j][sb_], acc[i][j]);
+  // six products per tile, smallest first; the fragment reads of slice 1 land under slice 0's MFMAs
+#define WS_CSTEP(p_)                                                              \
+  {                                                                               \
+    WS_FRAGS(p_)                                                                  \
+    if (!(PP_SKIP & 8)) {                                                         \
+      _Pragma("unroll") for (int sl = 0; sl < 2; ++sl) {                          \
+        WS_TERM(sl, 2, 0) WS_TERM(sl, 0, 2) WS_TERM(sl, 1, 1)                     \
+        WS_TERM(sl, 1, 0) WS_TERM(sl, 0, 1) WS_TERM(sl, 0, 0)                     \
+      }                                                                           \
+    } else {                                                                      \
+      _Pragma("unroll") for (int sl = 0; sl < 2; ++sl)                            \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p)                               \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                             \
+        asm volatile("" ::"v"(__builtin_bit_cast(i32x4_, fa[sl][t][p])),          \
+                     "v"(__builtin_bit_cast(i32x4_, fb[sl][t][p])));              \
+      }                                                                           \
+    }                                                                             \
+    PP_T(2)                                                                       \
+    WS_BAR()                                                                      \
+    PP_T(3)                                                                       \
+  }
+  WS_BAR()                              // stage 0 ready
+  PP_T0()
+  int s = 0;
+#pragma unroll 1
+  for (; s + 1 < nk; s += 2) {
+    WS_CSTEP(0)
+    WS_CSTEP(1)
+  }
+  PP_TOUT()
+  if (s < nk) WS_CSTEP(0)
+#undef WS_CSTEP
+#undef WS_TERM
+#undef WS_FRAGS
+}
+#undef WS_BAR
+
 template <int LA, int LB>
 __device__ __forceinline__ void gemm_pp_body(const float* __restrict__ A, const float* __restrict__ B,
                                              float* __restrict__ C, const PpShape sh) {
@@ -346,6 +514,39 @@ __device__ __forceinline__ void gemm_pp_body(const float* __restrict__ A, const 
   const int nk = ks1 - ks0;
   float* Cout = C + (int64_t)slot * sh.M * sh.N;
 
+#if PP_WS
+  if (half != 0) {
+    ws_producer<LA, LB>(A, B, sh, tm, tn, ks0, nk, lds);
+    return;
+  }
+  {
+    // consumers: 2 x 2 waves of 64 x 64; fragment addresses: row (column) lane & 31, K half lane >> 5
+    const int cm = wave & 1, cn = wave >> 1;
+    const int a_off = (cm * 64 + (lane & 31)) * P_ROWB + (lane >> 5) * 16;
+    const int b_off = P_OB + (cn * 64 + (lane & 31)) * P_ROWB + (lane >> 5) * 16;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    ws_consumer(lds, nk, a_off, b_off, acc);
+    // D[row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31] of tile (i, j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = tn * PT + cn * 64 + 32 * j + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = tm * PT + cm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < sh.M && col < sh.N) Cout[(int64_t)row * sh.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+#endif
   // fragment addresses of this lane: row (column) lane & 31 of an MFMA tile, K half lane >> 5
   const int a_off = (wm * 64 + (lane & 31)) * P_ROWB + (lane >> 5) * 16;
   const int b_off = P_OB + (wn * 32 + (lane & 31)) * P_ROWB + (lane >> 5) * 16;

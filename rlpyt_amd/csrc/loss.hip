@@ -593,13 +593,41 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock, 2) void ppo_head_loss_kern
   }
 }
 
-// out[e] = sum over the per-workgroup partial rows (fixed order -> deterministic).
+// Weight-gradient partial rows: out[e] = sum over the per-workgroup partial rows (fixed order -> deterministic).
 // 64 elements per workgroup, the rows split over 16 waves with 4 independent loads in flight each:
 // the reduction is a chain of dependent 256-byte loads per wave (round 2 start: 4 waves x 2 in
 // flight = 64 dependent rounds, 21 us for 7 MB); now 8 rounds.
-__global__ __launch_bounds__(1024) void head_reduce_kernel(const float* __restrict__ wpart, int n_rows,
-                                                           int part, float* __restrict__ out) {
+// ... and the loss scalars in the SAME launch (round 2: head_reduce_kernel + pg_loss_finalize_kernel):
+// workgroups [0, nb) reduce the partial rows, the LAST workgroup sums the per-wave loss partials
+// (f64, fixed order) and writes the five scalars -- the arithmetic of pg_loss_finalize_kernel, one
+// launch (~6 us on a 97 %-busy update) less.
+__global__ __launch_bounds__(1024) void head_reduce_finalize_kernel(
+    const float* __restrict__ wpart, int n_rows, int part, float* __restrict__ out_w,
+    const LossWs* __restrict__ ws, int n_part, int64_t M, int has_valid, float c_v, float c_e,
+    float* __restrict__ out_scalars) {
   __shared__ float red[16][64];
+  __shared__ double scratch[6 * 16];
+  if (blockIdx.x == gridDim.x - 1) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] += ws->part[i][k];
+    }
+    block_sum<6>(acc, scratch);
+    if (threadIdx.x == 0) {
+      const double denom = has_valid ? acc[4] : (double)M;
+      const float pi_loss = -(float)(acc[0] / denom);
+      const float value_loss = c_v * (float)(acc[1] / denom);
+      const float entropy = (float)(acc[2] / denom);
+      const float perplexity = (float)(acc[3] / denom);
+      out_scalars[0] = pi_loss + value_loss - c_e * entropy;  // ppo.py:151
+      out_scalars[1] = pi_loss;
+      out_scalars[2] = value_loss;
+      out_scalars[3] = entropy;
+      out_scalars[4] = perplexity;
+    }
+    return;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -619,7 +647,7 @@ __global__ __launch_bounds__(1024) void head_reduce_kernel(const float* __restri
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) v += red[w][lane];
-    out[e] = v;
+    out_w[e] = v;
   }
 }
 
@@ -803,12 +831,9 @@ extern "C" int rlpyt_ppo_trunk_head_loss_fwd_bwd_f32(
 #undef RL_HEAD
 #undef RL_HEAD_TB
   RL_LAUNCH_CHECK();
-  RL_LAUNCH(head_reduce_kernel, dim3((part + 63) / 64), dim3(1024), 0, s, wpart, grid,
-                     part, grad_params);
-  RL_LAUNCH_CHECK();
-  RL_LAUNCH(pg_loss_finalize_kernel, dim3(1), dim3(kLossBlock), 0, s, ws, n_waves, M,
-                     valid != nullptr ? 1 : 0, 0, value_loss_coeff, entropy_loss_coeff,
-                     out_scalars);
+  RL_LAUNCH(head_reduce_finalize_kernel, dim3((part + 63) / 64 + 1), dim3(1024), 0, s, wpart, grid,
+            part, grad_params, ws, n_waves, M, valid != nullptr ? 1 : 0, value_loss_coeff,
+            entropy_loss_coeff, out_scalars);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

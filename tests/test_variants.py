@@ -264,7 +264,7 @@ for _ki, _K in ((8, 512), (4, 256)):
     for _am, _A in ((4, 3), (6, 6), (8, 8)):      # action slots held in registers: A <= 4, <= 6, <= 8
         CASES[f"ppo_head_loss_kernel<{_ki}, {_am}, false>"] = _head_loss_case(_K, _A)
         CASES[f"ppo_head_loss_kernel<{_ki}, {_am}, true>"] = _trunk_head_loss_case(_K, _A)
-CASES["head_reduce_kernel"] = _head_loss_case(512)
+CASES["head_reduce_finalize_kernel"] = _head_loss_case(512)
 
 
 # ---------------------------------------------------------------------------------- gathers
