@@ -5,27 +5,34 @@
 //   NT  C[M,N] = A[M,K]  B[N,K]^T   forward            x W^T
 //   NN  C[M,N] = A[M,K]  B[K,N]     input gradient     g W           (no transposed copy of W)
 //   TN  C[M,N] = A[K,M]^T B[K,N]    weight gradient    g^T x         (contraction over the batch)
-// and a "ping-pong" schedule: the 8 waves of a workgroup are two halves (waves 0-3 / 4-7: one wave
-// of each half per SIMD).  While one half issues the 24 MFMAs of a K-32 step back to back (pure
-// matrix-pipe segment, 768 cycles), the other half runs its LOAD segment: ds_read the fragments
-// of its next step, split the f32 rows it fetched two steps ago into bf16 pieces, ds_write them
-// into the other LDS stage, issue the global loads of three steps ahead; then the halves swap
-// (two barriers per step).  A SIMD's matrix pipe always has one wave feeding it, and neither LDS
-// traffic nor split VALU sits between MFMAs (MI355X_MICROARCH.md "Two waves per SIMD").  Half 0
-// stages the A operand, half 1 the B operand.
+// with SPECIALISED waves: of the 8 waves of a workgroup (tile 128 x 128 of C), waves 4-7 are
+// PRODUCERS -- fetch both operands (8 float4 per thread and K-32 step, requested two steps ahead),
+// split them into bf16 pieces, write an LDS stage -- and waves 0-3 are CONSUMERS, one per SIMD, wave
+// tile 64 x 64: 24 fragment reads and 48 MFMAs per step.  One barrier per K-32 step.
 //
-// Tile 128 x 128 of C per workgroup, wave tile 64 x 32 (2 MFMA 32x32x16 tiles), K-step 32 = two
-// MFMA K-slices.  LDS: 2 stages x {A, B} x 3 pieces x 128 rows x 80 B (64 B = 32 bf16 along K +
-// 16 B pad: ds_read_b128 of 32 rows x 2 K-halves is conflict-free at a pitch of 20 dwords) =
-// 122,880 B, one workgroup per CU.
+// What shaped it (per-phase cycle counters and phase-elimination builds, profiles/r3_gemm_*.log):
+//  * v_mfma issue is asynchronous on gfx950: 24 dependent MFMAs issue in ~80 cycles and drain from a
+//    queue at 32 cycles each, so ONE wave per SIMD keeps the matrix pipe busy as long as its next
+//    fragments are in registers before the queue runs dry.  A ping-pong version (wave halves
+//    alternating between an MFMA segment and a load segment, two barriers per step) overlapped
+//    every PAIR of its phases and still took 3300-3800 cycles per step against 1540 of matrix-pipe
+//    time: whatever the loading half waited for held the computing half at the barrier.
+//  * the consumer therefore never reads fragments right behind a barrier: the LDS ring has THREE
+//    stages, and the fragments of step v + 1 are read slice by slice BEHIND the MFMAs of step v
+//    (slice 0 of v + 1 into the registers slice 0 of v just left, while slice 1 of v runs).  With
+//    two stages the reads sat between the barrier and the first MFMA: 2090 cycles per step.
+//  * three stages fit the 160 KB of LDS only unpadded: rows are 64 B (32 bf16 along K), and the
+//    16-byte chunk c of row r lives at chunk c ^ ((r >> 2) & 3): the 16-lane groups of a
+//    ds_read_b128 (rows r, K half h) then cover all 64 banks, the 8-byte staging writes of two
+//    adjacent rows all 32.  3 x {A, B} x 3 pieces x 128 rows x 64 B = 147,456 B.
+//  * 64 x 64 wave tiles halve the fragment traffic per MFMA (0.5 KB instead of 0.75 KB).
 //
 // Staging of an operand X whose K axis is contiguous ("KC": X[r][k]): a thread moves 4 float4 =
 // 4 k of rows r, r+32, r+64, r+96 (8 lanes cover 128 contiguous bytes of a row) and writes
 // 3 x 4 ds_write_b64.  K strided ("KS": X[k][r], the transposing layouts of NN / TN): a thread
 // owns a 4 (k) x 4 (r) block -- four float4 loads along r from four consecutive k rows -- packs
 // (k, k+1) pairs per r and writes, per piece, one ds_write_b64 (4 k of one r) to each of its four
-// LDS rows; lanes are mapped (k group = lane & 7, r group = lane >> 3) so that the 16-lane groups
-// of a ds_write_b64 cover all 32 banks.
+// LDS rows (lanes: k group = lane & 7, r group = lane >> 3).
 //
 // TN contracts over the batch (K = 8192) and has only 4 x 27 output tiles: K is cut into 8 chunks,
 // chunk c <-> XCD c (each XCD streams ITS rows of x and g once through its own L2; the 4 row tiles
@@ -42,32 +49,27 @@ namespace {
 constexpr int PT = 128;                    // tile edge of C
 constexpr int P_THREADS = 512;
 constexpr int P_BK = 32;                   // K per step (two MFMA slices of 16)
-constexpr int P_ROWB = 2 * P_BK + 16;      // 80 B per (piece, row): data + pad
+constexpr int P_ROWB = 2 * P_BK;           // 64 B per (piece, row), chunks swizzled (no pad)
 constexpr int P_PB = PT * P_ROWB;          // bytes per piece of one operand
 constexpr int P_OB = 3 * P_PB;             // bytes per operand of one stage
-constexpr int P_SB = 2 * P_OB;             // bytes per stage
-constexpr int P_LDS = 2 * P_SB;            // 122,880
+constexpr int P_SB = 2 * P_OB;             // bytes per stage: 49,152
+constexpr int P_NST = 3;                   // stages of the LDS ring
+constexpr int P_LDS = P_NST * P_SB;        // 147,456
 constexpr int KC = 0, KS = 1;              // operand layouts: K contiguous / K strided
 
-// Debug build (-DRLPYT_TIMING): per-wave cycle totals of the loop phases (scripts/debug/
-// gemm_pp_timing.py); compiled out of the product.  slots: 0 load segment, 1 barrier after load,
-// 2 compute segment, 3 barrier after compute
-// PP_SKIP (debug builds only; results are then wrong): bit 0 no fragment reads, 1 no split / LDS
-// writes, 2 no global loads in the loop, 3 no MFMAs -- what a phase costs is what leaving it out saves
+// byte offset of (row, 8-byte slot q = k / 4) inside a piece: chunk q >> 1 swizzled by the row
+__device__ __forceinline__ int pp_slot(int row, int q) {
+  return row * P_ROWB + ((((q >> 1) ^ (row >> 2)) & 3) << 4) + ((q & 1) << 3);
+}
+
+// PP_SKIP (debug builds only; results are then wrong): bit 1 no split / LDS writes, 2 no global loads
+// in the loop, 3 no MFMAs -- what a phase costs is what leaving it out saves
 #ifndef PP_SKIP
 #define PP_SKIP 0
 #endif
-// Fetch register sets (debug builds may pass -DPP_SETS=4): 2 = the rows of step u + 1 are split in
-// load segment u and the set is refilled at once with step u + 3; 4 = four sets, refilled at the
-// START of a segment, four segments ahead (measured: 4-7 % SLOWER than 2 -- more loads in flight
-// lower the CU's vector-memory throughput; profiles/r3_gemm_pp_sweep2.log)
-#ifndef PP_SETS
-#define PP_SETS 2
-#endif
-// 1: warp-specialised producer / consumer waves (below); 0: the ping-pong halves
-#ifndef PP_WS
-#define PP_WS 1
-#endif
+// Debug build (-DRLPYT_TIMING): per-wave cycle totals of the loop phases (scripts/debug/
+// gemm_pp_timing.py); compiled out of the product.  slots: 0 producer stage + fetch, 1 its barrier
+// wait, 2 consumer MFMA issue + fragment reads, 3 its barrier wait
 #ifdef RLPYT_TIMING
 __device__ float g_timing_gemm_pp[1024 * 8 * 4];
 #define PP_T0() long long t_prev_ = clock64(), t_acc_[4] = {0, 0, 0, 0};
@@ -128,187 +130,7 @@ __device__ __forceinline__ void pp_stage(const f32x4 (&r)[4], uint8_t* dst, cons
   }
 }
 
-// One half of the workgroup (HALF 0: waves 0-3, stages operand A, computes first; HALF 1: waves
-// 4-7, stages B).  X: this half's operand (layout L, leading dimension ld, `dim` rows / columns of
-// C on its output axis, tile origin r0), K steps [ks0, ks0 + nk).
-template <int L, int HALF>
-__device__ __forceinline__ void pp_half(const float* __restrict__ X, int ld, int dim, int r0, int ks0,
-                                        int nk, uint8_t* lds, int a_off, int b_off,
-                                        f32x16 (&acc)[2]) {
-  const int ht = threadIdx.x & 255;
-  // ---- this thread's share of the operand: 4 global float4 per step, 4 LDS rows ----------------
-  const float* gp[4];
-  int soff[4];
-  int64_t kstride;
-  uint8_t* const lds_op = lds + HALF * P_OB;      // operand base inside a stage
-  if constexpr (L == KC) {
-    const int row = ht >> 3, kq = ht & 7;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      gp[i] = X + (int64_t)min(r0 + row + 32 * i, dim - 1) * ld + (int64_t)ks0 * P_BK + 4 * kq;
-      soff[i] = (row + 32 * i) * P_ROWB + kq * 8;
-    }
-    kstride = 1;
-  } else {
-    const int mg = ht & 7, ng = 8 * (ht >> 6) + ((ht >> 3) & 7);
-    const int col = min(r0 + 4 * ng, dim - 4);   // dim % 4 == 0: blocks are all in or all out
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      gp[i] = X + ((int64_t)ks0 * P_BK + 4 * mg + i) * ld + col;
-      soff[i] = (4 * ng + i) * P_ROWB + mg * 8;
-    }
-    kstride = ld;
-  }
-  uint4 fa[2][2][3], fb[2][3];        // [slice][row tile][piece], [slice][piece]
-  f32x4 R[PP_SETS][4];
-  const int last = nk - 1;
-#define PP_FETCH(set_, step_)                                                     \
-  {                                                                               \
-    const int64_t ko_ = (int64_t)min((step_), last) * P_BK * kstride;             \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                 \
-      R[set_][i] = *reinterpret_cast<const f32x4*>(gp[i] + ko_);                  \
-  }
-#define PP_STAGE(set_, stage_) pp_stage<L>(R[set_], lds_op + (stage_) * P_SB, soff);
-#define PP_FRAGS(stage_)                                                          \
-  _Pragma("unroll") for (int sl = 0; sl < 2; ++sl)                                \
-  _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                 \
-    const uint8_t* b_ = lds + (stage_) * P_SB + sl * 32 + s * P_PB;               \
-    fb[sl][s] = *reinterpret_cast<const uint4*>(b_ + b_off);                      \
-    fa[sl][0][s] = *reinterpret_cast<const uint4*>(b_ + a_off);                   \
-    fa[sl][1][s] = *reinterpret_cast<const uint4*>(b_ + a_off + 32 * P_ROWB);     \
-  }
-  // LOAD segment for step u (parity p = u & 1): fragments of step u from stage p; the rows of step
-  // u + 1 (register set (u + 1) % PP_SETS) -> pieces -> stage p ^ 1; that set is then refilled with
-  // step u + 3 (PP_SETS == 4: instead, step u + 4 is requested first, into the set u % 4 that the
-  // previous segment emptied)
-  // (debug) keep values alive / opaque when a phase is left out, so that the others survive DCE
-#define PP_SINK4(x_) asm volatile("" ::"v"(__builtin_bit_cast(i32x4_, x_)));
-#define PP_OPAQUE4(x_)                            \
-  {                                               \
-    i32x4_ t_;                                    \
-    asm volatile("" : "=v"(t_));                  \
-    x_ = __builtin_bit_cast(uint4, t_);           \
-  }
-#define PP_ALL_FRAGS(OP_)                                                         \
-  _Pragma("unroll") for (int sl = 0; sl < 2; ++sl)                                \
-  _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                 \
-    OP_(fb[sl][s]) OP_(fa[sl][0][s]) OP_(fa[sl][1][s])                            \
-  }
-#define PP_LOAD(p_, free_, use_, u_)                                              \
-  {                                                                               \
-    if (PP_SETS == 4 && !(PP_SKIP & 4)) PP_FETCH((free_) % PP_SETS, (u_) + 4)                 \
-    if (!(PP_SKIP & 1)) PP_FRAGS(p_)                                              \
-    else fb[0][0] = *reinterpret_cast<const uint4*>(lds + (p_) * P_SB + b_off);   \
-    __builtin_amdgcn_sched_barrier(0);   /* requests and LDS reads before any vmcnt wait */ \
-    if (!(PP_SKIP & 2)) PP_STAGE((use_) % PP_SETS, (p_) ^ 1)                      \
-    else { _Pragma("unroll") for (int i = 0; i < 4; ++i) PP_SINK4(R[(use_) % PP_SETS][i]) } \
-    if (PP_SETS == 2 && !(PP_SKIP & 4)) PP_FETCH((use_) % PP_SETS, (u_) + 3)      \
-  }
-  // COMPUTE segment: 2 slices x six products (smallest first) x 2 row tiles, nothing else
-#define PP_TERM(sl_, sa_, sb_)                                                    \
-  acc[0] = mfma32_bf16(fa[sl_][0][sa_], fb[sl_][sb_], acc[0]);                    \
-  acc[1] = mfma32_bf16(fa[sl_][1][sa_], fb[sl_][sb_], acc[1]);
-#define PP_COMPUTE()                                                              \
-  if (PP_SKIP & 8) { PP_ALL_FRAGS(PP_SINK4) } else                                \
-  _Pragma("unroll") for (int sl = 0; sl < 2; ++sl) {                              \
-    PP_TERM(sl, 2, 0) PP_TERM(sl, 0, 2) PP_TERM(sl, 1, 1)                         \
-    PP_TERM(sl, 1, 0) PP_TERM(sl, 0, 1) PP_TERM(sl, 0, 0)                         \
-  }
-
-  // the machine scheduler must not move MFMAs (register-only) across the phase boundaries
-#define PP_BAR()                            \
-  {                                         \
-    __builtin_amdgcn_sched_barrier(0);      \
-    __syncthreads();                        \
-    __builtin_amdgcn_sched_barrier(0);      \
-  }
-  if (PP_SKIP & 1) { PP_ALL_FRAGS(PP_OPAQUE4) }
-  // ---- prologue: stage 0 <- step 0; the sets hold the next steps -----------------------------------
-  static_assert(PP_SETS == 2 || PP_SETS == 4, "the loops below index the sets modulo 2 or 4");
-  PP_FETCH(0, 0)
-  PP_FETCH(1, 1)
-  if (PP_SETS == 4) {
-    PP_FETCH(2 % PP_SETS, 2)
-    PP_FETCH(3 % PP_SETS, 3)
-  }
-  PP_STAGE(0, 0)
-  if (PP_SETS == 2) PP_FETCH(0, 2)
-  PP_BAR()
-  // one K-32 step of each half, i = step index mod 4 (static): half 0 computes step s + i while
-  // half 1 runs the load segment of step s + i, then half 0 runs the load segment of s + i + 1
-  // while half 1 computes s + i
-#define PP_H0(i_)                                                                 \
-  {                                                                               \
-    PP_COMPUTE()                                                                  \
-    PP_T(2)                                                                       \
-    PP_BAR()                                                                      \
-    PP_T(3)                                                                       \
-    PP_LOAD(((i_) + 1) & 1, ((i_) + 1) & 3, ((i_) + 2) & 3, s + (i_) + 1)         \
-    PP_T(0)                                                                       \
-    PP_BAR()                                                                      \
-    PP_T(1)                                                                       \
-  }
-#define PP_H1(i_)                                                                 \
-  {                                                                               \
-    PP_LOAD((i_) & 1, (i_) & 3, ((i_) + 1) & 3, s + (i_))                         \
-    PP_T(0)                                                                       \
-    PP_BAR()                                                                      \
-    PP_T(1)                                                                       \
-    PP_COMPUTE()                                                                  \
-    PP_T(2)                                                                       \
-    PP_BAR()                                                                      \
-    PP_T(3)                                                                       \
-  }
-  int s = 0;
-  if constexpr (HALF == 0) {
-    PP_LOAD(0, 0, 1, 0)               // enters the loop with the fragments of step 0
-    PP_BAR()
-    PP_T0()
-#pragma unroll 1
-    for (; s + 3 < nk; s += 4) {
-      PP_H0(0) PP_H0(1) PP_H0(2) PP_H0(3)
-    }
-    PP_TOUT()
-    if (s < nk) PP_H0(0)
-    if (s + 1 < nk) PP_H0(1)
-    if (s + 2 < nk) PP_H0(2)
-  } else {
-    PP_BAR()
-    PP_T0()
-#pragma unroll 1
-    for (; s + 3 < nk; s += 4) {
-      PP_H1(0) PP_H1(1) PP_H1(2) PP_H1(3)
-    }
-    PP_TOUT()
-    if (s < nk) PP_H1(0)
-    if (s + 1 < nk) PP_H1(1)
-    if (s + 2 < nk) PP_H1(2)
-  }
-#undef PP_H1
-#undef PP_H0
-#undef PP_BAR
-#undef PP_ALL_FRAGS
-#undef PP_OPAQUE4
-#undef PP_SINK4
-#undef PP_COMPUTE
-#undef PP_TERM
-#undef PP_LOAD
-#undef PP_FRAGS
-#undef PP_STAGE
-#undef PP_FETCH
-}
-
-// ---------------------------------------------------------------------------------------------
-// Warp-specialised variant (PP_WS, the default): waves 4-7 are PRODUCERS (fetch both operands, split,
-// write the LDS stage: 8 float4 per thread and K-32 step), waves 0-3 are CONSUMERS (one per SIMD,
-// wave tile 64 x 64: 24 fragment reads and 48 MFMAs per step), ONE barrier per step.  What the
-// ping-pong halves above measured (profiles/r3_gemm_pp_sweep*.log): MFMA issue is asynchronous on
-// gfx950 (24 MFMAs issue in ~80 cycles and drain from a queue), so a single wave per SIMD keeps the
-// matrix pipe busy while it waits at the barrier and reads the next fragments -- the two phases of a
-// ping-pong step only added barrier waits (3300-3800 cycles per step against 1540 of matrix-pipe
-// time, although every pair of its phases overlapped fine).  64 x 64 wave tiles also halve the LDS
-// fragment traffic per MFMA (0.5 KB instead of 0.75 KB).
-// ---------------------------------------------------------------------------------------------
+// this producer thread's share of an operand: 4 global float4 per K-32 step, 4 LDS slots
 template <int L>
 __device__ __forceinline__ void pp_operand_map(const float* __restrict__ X, int ld, int dim, int r0,
                                                int ks0, int ht, const float* (&gp)[4], int (&soff)[4],
@@ -318,7 +140,7 @@ __device__ __forceinline__ void pp_operand_map(const float* __restrict__ X, int 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       gp[i] = X + (int64_t)min(r0 + row + 32 * i, dim - 1) * ld + (int64_t)ks0 * P_BK + 4 * kq;
-      soff[i] = (row + 32 * i) * P_ROWB + kq * 8;
+      soff[i] = pp_slot(row + 32 * i, kq);
     }
     kstride = 1;
   } else {
@@ -327,7 +149,7 @@ __device__ __forceinline__ void pp_operand_map(const float* __restrict__ X, int 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       gp[i] = X + ((int64_t)ks0 * P_BK + 4 * mg + i) * ld + col;
-      soff[i] = (4 * ng + i) * P_ROWB + mg * 8;
+      soff[i] = pp_slot(4 * ng + i, mg);
     }
     kstride = ld;
   }
@@ -340,6 +162,8 @@ __device__ __forceinline__ void pp_operand_map(const float* __restrict__ X, int 
     __builtin_amdgcn_sched_barrier(0);      \
   }
 
+// Producer waves (4-7).  Ring protocol: at the barrier that ends step v, stage (v + 2) % 3 holds
+// step v + 2; during step v the producers write it while the consumers read stage (v + 1) % 3.
 template <int LA, int LB>
 __device__ __forceinline__ void ws_producer(const float* __restrict__ A, const float* __restrict__ B,
                                             const PpShape& sh, int tm, int tn, int ks0, int nk,
@@ -350,113 +174,104 @@ __device__ __forceinline__ void ws_producer(const float* __restrict__ A, const f
   int64_t ksa, ksb;
   pp_operand_map<LA>(A, sh.lda, sh.M, tm * PT, ks0, ht, gpa, soa, ksa);
   pp_operand_map<LB>(B, sh.ldb, sh.N, tn * PT, ks0, ht, gpb, sob, ksb);
-  f32x4 Ra[2][4], Rb[2][4];            // two fetch sets: steps u + 1 and u + 2
+  f32x4 Ra[2][4], Rb[2][4];            // two fetch sets
   const int last = nk - 1;
 #define WS_FETCH(set_, step_)                                                     \
-  if (!(PP_SKIP & 4)) {                                                           \
+  {                                                                               \
     const int64_t ko_ = (int64_t)min((step_), last) * P_BK;                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                               \
       Ra[set_][i] = *reinterpret_cast<const f32x4*>(gpa[i] + ko_ * ksa);          \
       Rb[set_][i] = *reinterpret_cast<const f32x4*>(gpb[i] + ko_ * ksb);          \
     }                                                                             \
   }
-#define WS_STAGE(set_, stage_)                                                    \
-  if (!(PP_SKIP & 2)) {                                                           \
-    pp_stage<LA>(Ra[set_], lds + (stage_) * P_SB, soa);                           \
-    pp_stage<LB>(Rb[set_], lds + (stage_) * P_SB + P_OB, sob);                    \
-  } else {                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                               \
-      asm volatile("" ::"v"(Ra[set_][i]), "v"(Rb[set_][i]));                      \
-    }                                                                             \
-  }
-  // step u of the producer: the rows of step u + 1 -> pieces -> stage (u + 1) & 1, refill the set
-#define WS_PSTEP(p_, u_)                                                          \
+#define WS_STAGE(set_, st_)                                                       \
   {                                                                               \
-    WS_STAGE((p_) ^ 1, (p_) ^ 1)                                                  \
-    WS_FETCH((p_) ^ 1, (u_) + 3)                                                  \
+    pp_stage<LA>(Ra[set_], lds + (st_) * P_SB, soa);                              \
+    pp_stage<LB>(Rb[set_], lds + (st_) * P_SB + P_OB, sob);                       \
+  }
+  // prologue: stages 0 and 1 <- steps 0 and 1; the sets then hold steps 2 and 3
+  WS_FETCH(0, 0)
+  WS_FETCH(1, 1)
+  WS_STAGE(0, 0)
+  WS_FETCH(0, 2)
+  WS_STAGE(1, 1)
+  WS_FETCH(1, 3)
+  WS_BAR()
+  // step v: set v & 1 (step v + 2) -> stage (v + 2) % 3, refilled with step v + 4
+#define WS_PSTEP(p_, v_)                                                          \
+  {                                                                               \
+    if (!(PP_SKIP & 2)) WS_STAGE(p_, st)                                          \
+    else { _Pragma("unroll") for (int i = 0; i < 4; ++i)                          \
+             asm volatile("" ::"v"(Ra[p_][i]), "v"(Rb[p_][i])); }                 \
+    if (!(PP_SKIP & 4)) WS_FETCH(p_, (v_) + 4)                                    \
+    st = st == P_NST - 1 ? 0 : st + 1;                                            \
     PP_T(0)                                                                       \
     WS_BAR()                                                                      \
     PP_T(1)                                                                       \
   }
-  {
-    const int64_t k0 = 0, k1 = (int64_t)min(1, last) * P_BK, k2 = (int64_t)min(2, last) * P_BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      Ra[0][i] = *reinterpret_cast<const f32x4*>(gpa[i] + k0 * ksa);
-      Rb[0][i] = *reinterpret_cast<const f32x4*>(gpb[i] + k0 * ksb);
-      Ra[1][i] = *reinterpret_cast<const f32x4*>(gpa[i] + k1 * ksa);
-      Rb[1][i] = *reinterpret_cast<const f32x4*>(gpb[i] + k1 * ksb);
-    }
-    pp_stage<LA>(Ra[0], lds, soa);
-    pp_stage<LB>(Rb[0], lds + P_OB, sob);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      Ra[0][i] = *reinterpret_cast<const f32x4*>(gpa[i] + k2 * ksa);
-      Rb[0][i] = *reinterpret_cast<const f32x4*>(gpb[i] + k2 * ksb);
-    }
-  }
-  WS_BAR()                              // stage 0 ready
+  int st = 2, v = 0;
   PP_T0()
-  int s = 0;
 #pragma unroll 1
-  for (; s + 1 < nk; s += 2) {
-    WS_PSTEP(0, s)
-    WS_PSTEP(1, s + 1)
+  for (; v + 1 < nk; v += 2) {
+    WS_PSTEP(0, v)
+    WS_PSTEP(1, v + 1)
   }
   PP_TOUT()
-  if (s < nk) WS_PSTEP(0, s)
+  if (v < nk) WS_PSTEP(0, v)
 #undef WS_PSTEP
 #undef WS_STAGE
 #undef WS_FETCH
 }
 
-__device__ __forceinline__ void ws_consumer(const uint8_t* lds, int nk, int a_off, int b_off,
-                                            f32x16 (&acc)[2][2]) {
+// Consumer waves (0-3): wave tile 64 x 64 = 2 x 2 MFMA tiles.  a_off / b_off: this lane's row /
+// column (lane & 31) of tile 0 and its swizzled 16-byte chunk for K slice 0 / 1 (K half lane >> 5).
+__device__ __forceinline__ void ws_consumer(const uint8_t* lds, int nk, const int (&a_off)[2],
+                                            const int (&b_off)[2], f32x16 (&acc)[2][2]) {
   uint4 fa[2][2][3], fb[2][2][3];      // [slice][tile][piece]
-#define WS_FRAGS(stage_)                                                          \
-  _Pragma("unroll") for (int sl = 0; sl < 2; ++sl)                                \
+#define WS_FRAGS(sl_, base_)                                                      \
   _Pragma("unroll") for (int p = 0; p < 3; ++p)                                   \
   _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                 \
-    const uint8_t* b_ = lds + (stage_) * P_SB + sl * 32 + p * P_PB + t * 32 * P_ROWB; \
-    fa[sl][t][p] = *reinterpret_cast<const uint4*>(b_ + a_off);                   \
-    fb[sl][t][p] = *reinterpret_cast<const uint4*>(b_ + b_off);                   \
+    const uint8_t* b_ = (base_) + p * P_PB + t * 32 * P_ROWB;                     \
+    fa[sl_][t][p] = *reinterpret_cast<const uint4*>(b_ + a_off[sl_]);             \
+    fb[sl_][t][p] = *reinterpret_cast<const uint4*>(b_ + b_off[sl_]);             \
   }
 #define WS_TERM(sl_, sa_, sb_)                                                    \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                                   \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                   \
     acc[i][j] = mfma32_bf16(fa[sl_][i][sa_], fb[sl_][j][sb_], acc[i][j]);
-  // six products per tile, smallest first; the fragment reads of slice 1 land under slice 0's MFMAs
-#define WS_CSTEP(p_)                                                              \
-  {                                                                               \
-    WS_FRAGS(p_)                                                                  \
-    if (!(PP_SKIP & 8)) {                                                         \
-      _Pragma("unroll") for (int sl = 0; sl < 2; ++sl) {                          \
-        WS_TERM(sl, 2, 0) WS_TERM(sl, 0, 2) WS_TERM(sl, 1, 1)                     \
-        WS_TERM(sl, 1, 0) WS_TERM(sl, 0, 1) WS_TERM(sl, 0, 0)                     \
-      }                                                                           \
-    } else {                                                                      \
-      _Pragma("unroll") for (int sl = 0; sl < 2; ++sl)                            \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p)                               \
-      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                             \
-        asm volatile("" ::"v"(__builtin_bit_cast(i32x4_, fa[sl][t][p])),          \
-                     "v"(__builtin_bit_cast(i32x4_, fb[sl][t][p])));              \
-      }                                                                           \
-    }                                                                             \
-    PP_T(2)                                                                       \
-    WS_BAR()                                                                      \
-    PP_T(3)                                                                       \
+  // six products per tile, smallest first
+#define WS_MMA(sl_)                                                               \
+  if (!(PP_SKIP & 8)) {                                                           \
+    WS_TERM(sl_, 2, 0) WS_TERM(sl_, 0, 2) WS_TERM(sl_, 1, 1)                      \
+    WS_TERM(sl_, 1, 0) WS_TERM(sl_, 0, 1) WS_TERM(sl_, 0, 0)                      \
+  } else {                                                                        \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p)                                 \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                 \
+      asm volatile("" ::"v"(__builtin_bit_cast(i32x4_, fa[sl_][t][p])),           \
+                   "v"(__builtin_bit_cast(i32x4_, fb[sl_][t][p])));               \
   }
-  WS_BAR()                              // stage 0 ready
+  WS_BAR()                              // stages 0 and 1 ready
+  WS_FRAGS(0, lds)
+  WS_FRAGS(1, lds)
+  int st = 1;                           // stage of step v + 1
   PP_T0()
-  int s = 0;
 #pragma unroll 1
-  for (; s + 1 < nk; s += 2) {
-    WS_CSTEP(0)
-    WS_CSTEP(1)
+  for (int v = 0; v < nk; ++v) {
+    const uint8_t* nxt = lds + st * P_SB;
+    WS_MMA(0)
+    __builtin_amdgcn_sched_barrier(0);  // the reads of slice 0 go BEHIND its MFMAs, not before
+    WS_FRAGS(0, nxt)                    // (past the last step: a stage nobody needs)
+    __builtin_amdgcn_sched_barrier(0);
+    WS_MMA(1)
+    __builtin_amdgcn_sched_barrier(0);
+    WS_FRAGS(1, nxt)
+    st = st == P_NST - 1 ? 0 : st + 1;
+    PP_T(2)
+    WS_BAR()
+    PP_T(3)
   }
   PP_TOUT()
-  if (s < nk) WS_CSTEP(0)
-#undef WS_CSTEP
+#undef WS_MMA
 #undef WS_TERM
 #undef WS_FRAGS
 }
@@ -468,9 +283,6 @@ __device__ __forceinline__ void gemm_pp_body(const float* __restrict__ A, const 
   __shared__ __attribute__((aligned(16))) uint8_t lds[P_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = wave >> 2;                 // 0: stages A, computes first; 1: stages B
-  const int wm = wave & 1, wn = (wave >> 1) & 3;   // wave tile: rows 64 wm.., columns 32 wn..
-  // (waves w and w + 4 share a SIMD and a row half; their column quarters differ)
 
   // ---- work unit -> (tile, K range, output slot) -------------------------------------------
   int tm, tn, ks0, ks1, slot = 0;
@@ -514,61 +326,38 @@ __device__ __forceinline__ void gemm_pp_body(const float* __restrict__ A, const 
   const int nk = ks1 - ks0;
   float* Cout = C + (int64_t)slot * sh.M * sh.N;
 
-#if PP_WS
-  if (half != 0) {
+  if (wave >= 4) {       // (the branch is wave-uniform; both roles execute 1 + nk barriers)
     ws_producer<LA, LB>(A, B, sh, tm, tn, ks0, nk, lds);
     return;
   }
-  {
-    // consumers: 2 x 2 waves of 64 x 64; fragment addresses: row (column) lane & 31, K half lane >> 5
-    const int cm = wave & 1, cn = wave >> 1;
-    const int a_off = (cm * 64 + (lane & 31)) * P_ROWB + (lane >> 5) * 16;
-    const int b_off = P_OB + (cn * 64 + (lane & 31)) * P_ROWB + (lane >> 5) * 16;
-    f32x16 acc[2][2];
+  // consumers: 2 x 2 waves of 64 x 64
+  const int cm = wave & 1, cn = wave >> 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  int a_off[2], b_off[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    ws_consumer(lds, nk, a_off, b_off, acc);
-    // D[row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31] of tile (i, j)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = tn * PT + cn * 64 + 32 * j + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = tm * PT + cm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (row < sh.M && col < sh.N) Cout[(int64_t)row * sh.N + col] = acc[i][j][r];
-        }
-      }
-    return;
+  for (int sl = 0; sl < 2; ++sl) {
+    a_off[sl] = pp_slot(cm * 64 + fr, 2 * (2 * sl + fh));
+    b_off[sl] = P_OB + pp_slot(cn * 64 + fr, 2 * (2 * sl + fh));
   }
-#endif
-  // fragment addresses of this lane: row (column) lane & 31 of an MFMA tile, K half lane >> 5
-  const int a_off = (wm * 64 + (lane & 31)) * P_ROWB + (lane >> 5) * 16;
-  const int b_off = P_OB + (wn * 32 + (lane & 31)) * P_ROWB + (lane >> 5) * 16;
-  f32x16 acc[2];
+  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  // The two halves run DIFFERENT instruction streams with the same number of barriers (the branch
-  // is wave-uniform): each gets its own register allocation and a straight-line loop body.
-  if (half == 0)
-    pp_half<LA, 0>(A, sh.lda, sh.M, tm * PT, ks0, nk, lds, a_off, b_off, acc);
-  else
-    pp_half<LB, 1>(B, sh.ldb, sh.N, tn * PT, ks0, nk, lds, a_off, b_off, acc);
-  // D[row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31] of row tile i
-  const int col = tn * PT + wn * 32 + (lane & 31);
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  ws_consumer(lds, nk, a_off, b_off, acc);
+  // D[row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31] of tile (i, j)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = tm * PT + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < sh.M && col < sh.N) Cout[(int64_t)row * sh.N + col] = acc[i][r];
+    for (int j = 0; j < 2; ++j) {
+      const int col = tn * PT + cn * 64 + 32 * j + fr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tm * PT + cm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (row < sh.M && col < sh.N) Cout[(int64_t)row * sh.N + col] = acc[i][j][r];
+      }
     }
 }
 
