@@ -40,7 +40,10 @@
 // gemm_reduce_slots_kernel sums the slots in a fixed order (deterministic, no atomics).  The
 // tiles left over after whole rounds of 32 CUs are cut into `sub` K-parts so that the last round
 // is short instead of sparse.
+#include <stdlib.h>
+
 #include <algorithm>
+
 #include "split_bf16.h"
 
 namespace rlpyt {
@@ -100,6 +103,10 @@ struct PpShape {
   int S;                     // K chunks: 1, or 8 (chunk <-> XCD, partial tiles)
   int full, sub;             // S == 8: units [0, full) of an XCD are whole chunks, the tiles behind
                              // them are cut into `sub` K-parts
+  int rot;                   // > 0: unit li starts its K loop at step (li * rot) % nk and wraps
+                             // (operands whose rows are a power of two apart -- g: 2 KB -- put the
+                             // same K offset of every row on the same 2 of 16 L2 channels; units
+                             // that walk K in step all camp on them)
 };
 
 // split the fetched rows into bf16 pieces and write them into LDS (operand base `dst`)
@@ -167,7 +174,7 @@ __device__ __forceinline__ void pp_operand_map(const float* __restrict__ X, int 
 template <int LA, int LB>
 __device__ __forceinline__ void ws_producer(const float* __restrict__ A, const float* __restrict__ B,
                                             const PpShape& sh, int tm, int tn, int ks0, int nk,
-                                            uint8_t* lds) {
+                                            int rot, uint8_t* lds) {
   const int ht = threadIdx.x & 255;
   const float *gpa[4], *gpb[4];
   int soa[4], sob[4];
@@ -178,7 +185,9 @@ __device__ __forceinline__ void ws_producer(const float* __restrict__ A, const f
   const int last = nk - 1;
 #define WS_FETCH(set_, step_)                                                     \
   {                                                                               \
-    const int64_t ko_ = (int64_t)min((step_), last) * P_BK;                       \
+    int kk_ = min((step_), last) + rot;                                           \
+    kk_ = kk_ >= nk ? kk_ - nk : kk_;                                             \
+    const int64_t ko_ = (int64_t)kk_ * P_BK;                                      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                               \
       Ra[set_][i] = *reinterpret_cast<const f32x4*>(gpa[i] + ko_ * ksa);          \
       Rb[set_][i] = *reinterpret_cast<const f32x4*>(gpb[i] + ko_ * ksb);          \
@@ -325,9 +334,10 @@ __device__ __forceinline__ void gemm_pp_body(const float* __restrict__ A, const 
   }
   const int nk = ks1 - ks0;
   float* Cout = C + (int64_t)slot * sh.M * sh.N;
+  const int rot = sh.rot > 0 ? (int)(((int64_t)(blockIdx.x >> 3) * sh.rot) % nk) : 0;
 
   if (wave >= 4) {       // (the branch is wave-uniform; both roles execute 1 + nk barriers)
-    ws_producer<LA, LB>(A, B, sh, tm, tn, ks0, nk, lds);
+    ws_producer<LA, LB>(A, B, sh, tm, tn, ks0, nk, rot, lds);
     return;
   }
   // consumers: 2 x 2 waves of 64 x 64
@@ -449,7 +459,7 @@ static PpShape pp_shape(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ld
   sh.M = (int)M; sh.N = (int)N; sh.lda = (int)lda; sh.ldb = (int)ldb;
   sh.tiles_m = (int)ceil_div(M, PT); sh.tiles_n = (int)ceil_div(N, PT);
   sh.nk = (int)(K / P_BK);
-  sh.S = 1; sh.full = sh.tiles_m * sh.tiles_n; sh.sub = 1;
+  sh.S = 1; sh.full = sh.tiles_m * sh.tiles_n; sh.sub = 1; sh.rot = 0;
   return sh;
 }
 
@@ -470,7 +480,8 @@ extern "C" int rlpyt_gemm_nn_f32(const float* a, const float* b, float* c, int64
   if (int e = pp_check("rlpyt_gemm_nn_f32", a, b, c, M, N, K)) return e;
   RL_CHECK_ARG(N % 4 == 0, RLPYT_ESHAPE, "rlpyt_gemm_nn_f32: N must be a multiple of 4 (N=%ld)",
                (long)N);
-  const PpShape sh = pp_shape(M, N, K, K, N);
+  PpShape sh = pp_shape(M, N, K, K, N);
+  if (const char* e = getenv("RLPYT_GEMM_ROT")) sh.rot = atoi(e);
   RL_LAUNCH(gemm_nn_pp_kernel, dim3(pp_grid(sh)), dim3(P_THREADS), 0, (hipStream_t)stream, a, b,
             c, sh);
   RL_LAUNCH_CHECK();

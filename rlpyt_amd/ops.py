@@ -629,10 +629,17 @@ def fc_small(x, weight, bias=None, relu=True):
     return y
 
 
-# a @ b.T runs on the lock-step kernel (csrc/gemm.hip: 156-163 us at the trunk's forward shape);
-# RLPYT_GEMM_PP=1 selects the ping-pong kernel body of the two backward GEMMs instead
-# (csrc/gemm_pp.hip: 221-233 us there -- kept for A/B timing, profiles/r3_gemm_pp_sweep*.log)
+# Which kernel serves which trunk GEMM (M = 8192, gemm_bench on the MI355X, profiles/r3_gemm_*):
+#   forward   x W^T : lock-step NT kernel (csrc/gemm.hip) 156-163 us; the producer / consumer
+#                     kernel body of csrc/gemm_pp.hip 196-233 us (RLPYT_GEMM_PP=1 selects it: A/B);
+#   dgrad     g W   : lock-step NT kernel on a transposed copy of W, 195-200 (+12 for the copy)
+#                     against 228-240 for gemm_nn reading W as stored (RLPYT_GEMM_NN=1 selects it);
+#   wgrad     g^T x : gemm_tn 223-240 against 265-274 for the library GEMM it replaces.
+# (On gfx950 VALU and MFMA instructions of one SIMD do not overlap, whichever wave issues them, so a
+# bf16x6 GEMM that splits its operands in-kernel is bounded by matrix-pipe + split-VALU time, ~2200
+# cycles per 128 x 128 x 32 step; the lock-step kernel sits within 10 % of that.)
 GEMM_NT_PINGPONG = os.environ.get("RLPYT_GEMM_PP", "0") != "0"
+GEMM_DGRAD_NN = os.environ.get("RLPYT_GEMM_NN", "0") != "0"
 
 
 def gemm_nt(a, b, pingpong=None):
@@ -689,9 +696,9 @@ def gemm_tn(a, b):
 
 class _LinearNoBias(torch.autograd.Function):
     """``x @ W.T`` (torch.nn.functional.linear without bias) for the update-size trunk, all three
-    GEMMs of forward + backward on the bf16 matrix pipe: forward ``gemm_nt(x, W)``, input gradient
-    ``gemm_nn(g, W)``, weight gradient ``gemm_tn(g, x)`` (rlpyt/models/mlp.py:24-31 under
-    autograd).  No vendor GEMM, no transposed copy of W."""
+    GEMMs of forward + backward on the bf16 matrix pipe (rlpyt/models/mlp.py:24-31 under
+    autograd): forward ``gemm_nt(x, W)``, input gradient ``gemm_nt(g, W^T copy)`` (or
+    ``gemm_nn(g, W)``, see the table above), weight gradient ``gemm_tn(g, x)``.  No vendor GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -704,7 +711,10 @@ class _LinearNoBias(torch.autograd.Function):
         g = g.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = gemm_nn(g, weight.detach())
+            if GEMM_DGRAD_NN:
+                gx = gemm_nn(g, weight.detach())
+            else:       # g W as g (W^T)^T on the faster lock-step kernel; 7 MB transposed copy
+                gx = gemm_nt(g, weight.detach().t().contiguous(), pingpong=False)
         if ctx.needs_input_grad[1]:
             gw = gemm_tn(g, x)
         return gx, gw
