@@ -50,8 +50,8 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, den
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 # bf16-split kernels (DESIGN.md "fp32 contractions on the bf16 pipe"): issued bf16 MFMA flops per
 # algorithmic fp32 flop (3 exact pieces of one operand; 6 products of two 3-piece operands)
-BF16_SPLIT = {"conv1_fwd": 3, "conv1_wgrad": 3, "conv2_fwd": 6, "gemm_nt": 6, "gemm_nn": 6,
-              "gemm_tn": 6}
+BF16_SPLIT = {"conv1_fwd": 3, "conv1_wgrad": 3, "conv2_fwd": 6, "gemm_nt": 6, "gemm_nt_dgrad": 6,
+              "gemm_nn": 6, "gemm_tn": 6}
 KERNEL_NAMES = {
     "conv1_fwd": "conv1_fwd_kernel (gather + u8->bf16 + conv 4->16 k8 s4 + bias + ReLU; exact "
                  "bf16x3 split of w1, f32 accumulate)",
@@ -62,14 +62,16 @@ KERNEL_NAMES = {
     "conv2_wgrad": "conv2_wgrad_kernel (+ bias grad, fp32 MFMA)",
     "conv1_wgrad": "conv1_wgrad_kernel (gather + u8->bf16 + weight/bias grad; exact bf16x3 split "
                    "of dy1, f32 accumulate)",
-    "gemm_nt": "gemm_nt_pp_kernel (update trunk forward x W^T [8192,3456]x[512,3456]^T: f32 GEMM from "
-               "three-piece bf16 splits of both operands, six products, f32 accumulate, dropped terms "
-               "<= 2^-24, 2^-27 rms; ping-pong wave halves)",
+    "gemm_nt": "gemm_nt_x6_kernel<128> (update trunk forward x W^T [8192,3456]x[512,3456]^T: f32 GEMM "
+               "from three-piece bf16 splits of both operands, six products, f32 accumulate, dropped "
+               "terms <= 2^-24, 2^-27 rms)",
+    "gemm_nt_dgrad": "gemm_nt_x6_kernel<256> (update trunk input gradient g W [8192,512]x[512,3456] as "
+                     "g (W^T)^T on a transposed copy of W; same bf16x6 arithmetic)",
     "gemm_nn": "gemm_nn_pp_kernel (update trunk input gradient g W [8192,512]x[512,3456], W read as "
-               "stored; same bf16x6 arithmetic and kernel body)",
+               "stored; bf16x6, producer / consumer waves)",
     "gemm_tn": "gemm_tn_pp_kernel + gemm_reduce_slots_kernel (update trunk weight gradient g^T x "
-               "[8192,512]^T x [8192,3456]: 8 K chunks <-> XCDs, partial tiles, fixed-order sum; same "
-               "bf16x6 arithmetic and kernel body)",
+               "[8192,512]^T x [8192,3456]: 8 K chunks <-> XCDs, partial tiles, fixed-order sum; "
+               "bf16x6, producer / consumer waves)",
     "obs_to_nhwc": "obs_to_nhwc_f32_kernel (minibatch gather + u8->f32 + CHW->HWC)",
     "gather_tb": "gather_wide_kernel (minibatch observation gather)",
     "gae": "scan_exact_kernel<GAE>", "ppo_loss": "pg_loss_kernel<PPO>",
@@ -271,6 +273,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     ktimer.enable(False)
+    timing = dict(sampler.timing)         # (the env-cost leg below keeps adding to sampler.timing)
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -370,11 +373,11 @@ def main():
             "sampling_frac_of_step": t_sample / (elapsed if elapsed > 0 else 1.),
             "sampler": {"pipeline_groups": sampler.n_groups, "hip_graph": not args.no_graph,
                         "ms_per_time_step": t_sample / args.steps / T * 1e3,
-                        "master_wait_env_ms": sampler.timing["wait_env_s"] / args.steps / T * 1e3,
-                        "master_issue_ms": sampler.timing["device_issue_s"] / args.steps / T * 1e3,
+                        "master_wait_env_ms": timing["wait_env_s"] / args.steps / T * 1e3,
+                        "master_issue_ms": timing["device_issue_s"] / args.steps / T * 1e3,
                         "master_wait_device_ms":
-                            sampler.timing["device_wait_s"] / args.steps / T * 1e3,
-                        "per_batch_ms": {k[:-2]: sampler.timing[k] / args.steps * 1e3
+                            timing["device_wait_s"] / args.steps / T * 1e3,
+                        "per_batch_ms": {k[:-2]: timing[k] / args.steps * 1e3
                                          for k in ("pre_s", "loop_s", "tail_s", "post_s")}},
             "last_loss": opt_info.loss[-1] if opt_info.loss else None,
             "losses_finite": all(x == x and abs(x) != float("inf") for x in opt_info.loss),

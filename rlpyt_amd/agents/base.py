@@ -67,14 +67,28 @@ class BaseAgent:
         self.model.to(self.device)
         logger.log(f"Initialized agent model on device: {self.device}.")
 
-    def data_parallel(self):
+    def data_parallel(self, bucket_cap_mb=None):
         """Wrap the model in DistributedDataParallel: gradient all-reduce rides RCCL over
-        xGMI when the process group backend is "nccl" (gloo on CPU)."""
+        xGMI when the process group backend is "nccl" (gloo on CPU)
+        (rlpyt/agents/base.py:118-136).
+
+        Bucketing: the models of this path are a few small tensors around ONE large one (the trunk
+        weight: 7.1 MB of AtariFfModel's 7.14 MB) whose gradient is ready half a millisecond before
+        the conv gradients.  With DDP's default 25 MB cap everything but the head shares one bucket,
+        so the only sizeable all-reduce of a minibatch starts when backward has finished and is
+        fully exposed.  A cap just below the largest tensor gives that tensor a bucket of its own:
+        its all-reduce (xGMI ring, latency-class at this size) then runs under conv2_bwd /
+        conv1_wgrad, and only the small tail bucket is exposed.  Same mean gradient either way."""
         from torch.nn.parallel import DistributedDataParallel as DDP
         device_id = self.device.index
+        if bucket_cap_mb is None:
+            sizes = [p.numel() * p.element_size() for p in self.model.parameters() if p.requires_grad]
+            largest = max(sizes) / 2 ** 20 if sizes else 0.
+            bucket_cap_mb = 25 if largest < 2 else max(1, min(25, int(0.6 * largest)))
         self.model = DDP(self.model, device_ids=None if device_id is None else [device_id],
-                         output_device=device_id)
-        logger.log(f"Initialized DistributedDataParallel agent model on device {self.device}.")
+                         output_device=device_id, bucket_cap_mb=bucket_cap_mb)
+        logger.log(f"Initialized DistributedDataParallel agent model on device {self.device} "
+                   f"(bucket cap {bucket_cap_mb} MB).")
         return device_id
 
     @property

@@ -642,7 +642,7 @@ GEMM_NT_PINGPONG = os.environ.get("RLPYT_GEMM_PP", "0") != "0"
 GEMM_DGRAD_NN = os.environ.get("RLPYT_GEMM_NN", "0") != "0"
 
 
-def gemm_nt(a, b, pingpong=None):
+def gemm_nt(a, b, pingpong=None, region="gemm_nt"):
     """``a @ b.T`` for f32 ``a [M, K]``, ``b [N, K]`` (K a multiple of 32) on the bf16 matrix pipe
     from exact three-piece bf16 splits of both operands (six products, f32 accumulation, dropped
     terms <= 2^-24 |ab|, 2^-27 rms -- f32-level error, 2.7x less matrix-pipe time than an f32-MFMA
@@ -655,7 +655,7 @@ def gemm_nt(a, b, pingpong=None):
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
     pp = GEMM_NT_PINGPONG if pingpong is None else pingpong
     fn = lib.rlpyt_gemm_nt_pp_f32 if pp else lib.rlpyt_gemm_nt_f32
-    with ktimer.region("gemm_nt", 4 * (M * K + N * K + M * N), 2 * M * N * K):
+    with ktimer.region(region, 4 * (M * K + N * K + M * N), 2 * M * N * K):
         check(fn(ptr(a), ptr(b), ptr(c), M, N, K, stream()), "rlpyt_gemm_nt_f32")
     return c
 
@@ -714,7 +714,8 @@ class _LinearNoBias(torch.autograd.Function):
             if GEMM_DGRAD_NN:
                 gx = gemm_nn(g, weight.detach())
             else:       # g W as g (W^T)^T on the faster lock-step kernel; 7 MB transposed copy
-                gx = gemm_nt(g, weight.detach().t().contiguous(), pingpong=False)
+                gx = gemm_nt(g, weight.detach().t().contiguous(), pingpong=False,
+                             region="gemm_nt_dgrad")
         if ctx.needs_input_grad[1]:
             gw = gemm_tn(g, x)
         return gx, gw

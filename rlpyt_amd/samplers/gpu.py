@@ -78,6 +78,8 @@ class EnvRunner:
         # flat namedtuple env_info (the usual case): one array per field, written directly
         self._info_arrays = info_leaves if (
             info_leaves and not any(isinstance(v, tuple) for v in env_info_np)) else None
+        self._native = None            # rlpyt_amd._envloop.EnvLoop once start() has armed it
+        self.use_native = True         # False: always the Python loop body (A/B, tests)
 
     def start(self, max_decorrelation_steps=0):
         """Reset (and optionally decorrelate with random actions,
@@ -103,6 +105,8 @@ class EnvRunner:
             step.reward[b] = r
             step.done[b] = False
             self.last_obs[b] = o
+        if self.envs and self._native_ok(self.last_obs[0]):
+            self._native_begin()
 
     def begin_batch(self):
         """Between batches under wait-reset: reset finished envs, reinstate held observations,
@@ -130,8 +134,91 @@ class EnvRunner:
         self.need_reset[:] = False
         step.done[:] = False
 
+    # ------------------------------------------------------------------ native loop body
+    # With the device side of a time step at ~100 us the rollout is priced in host CPU-seconds per
+    # env step under the box's CPU quota, and ~1/3 of them were the interpreter overhead of the loop
+    # body below (TrajInfo dict updates, numpy scalar stores, attribute probing).  For the
+    # mid-batch-reset collector with the stock trajectory statistics that body runs in C
+    # (rlpyt_amd/_envloop, csrc/envloop.c); ``env.step`` stays the Python call it is.  The running
+    # statistics live in numpy arrays typed as the reference's per-step updates leave them
+    # (np.float32 rewards: float32 sums, float64 discount); a finished trajectory is turned back
+    # into a ``TrajInfoCls`` record in ``_native_on_done``.
+    def _native_ok(self, first_obs):
+        from .collections import AtariTrajInfo, TrajInfo
+        if not (self.use_native and self.mid_batch_reset
+                and self.TrajInfoCls in (TrajInfo, AtariTrajInfo)
+                and (self.env_info is None or self._info_arrays is not None)):
+            return False
+        step = self.step
+        o = np.asarray(first_obs)
+        return (step.reward.dtype == np.float32 and step.action.dtype == np.int64
+                and step.action.ndim == 1 and step.done.dtype == np.bool_
+                and o.dtype == step.observation.dtype and o.flags.c_contiguous
+                and o.shape == step.observation.shape[1:]
+                and all(a.ndim == 2 and a.dtype.kind in "fbiu" for a in (self._info_arrays or ())))
+
+    def _native_begin(self):
+        try:
+            from .. import _envloop
+        except ImportError:       # extension not built: the Python loop body does the same work
+            return
+        n = len(self.envs)
+        ti = self.traj_infos
+        st = self._nstats = AttrDict(
+            length=np.array([int(x["Length"]) for x in ti], dtype=np.int64),
+            nonzero=np.array([int(x["NonzeroRewards"]) for x in ti], dtype=np.int64),
+            g=np.array([float(x["_cur_discount"]) for x in ti], dtype=np.float64),
+            ret32=np.zeros(n, np.float32), disc32=np.zeros(n, np.float32),
+            ret64=np.zeros(n, np.float64), disc64=np.zeros(n, np.float64),
+            score=(np.array([float(x["GameScore"]) for x in ti], dtype=np.float64)
+                   if "GameScore" in ti[0] else None))
+        # sums so far (decorrelation steps of start()): float32 unless some reward was not np.float32
+        vals = [x["Return"] for x in ti] + [x["DiscountedReturn"] for x in ti]
+        f64 = any(isinstance(v, (float, np.float64)) for v in vals)
+        for b, x in enumerate(ti):
+            (st.ret64 if f64 else st.ret32)[b] = x["Return"]
+            (st.disc64 if f64 else st.disc32)[b] = x["DiscountedReturn"]
+        step = self.step
+        self._native = _envloop.EnvLoop(
+            envs=list(self.envs), action=step.action, reward=step.reward, done=step.done,
+            frame=step.frame if self.frames else None, reset=step.reset if self.frames else None,
+            observation=step.observation, info_arrays=self._info_arrays, length=st.length,
+            ret32=st.ret32, nonzero=st.nonzero, disc32=st.disc32, ret64=st.ret64, disc64=st.disc64,
+            cur_discount=st.g, score=st.score, discount=float(self.TrajInfoCls._discount),
+            f64_mode=int(f64), on_done=self._native_on_done, float32_type=np.float32)
+        self._completed = None
+
+    def _native_on_done(self, b, final_obs):
+        """Env ``b`` finished a trajectory: record it (fields typed as the reference's updates leave
+        them), restart the statistics, reset the env; returns the first observation."""
+        st = self._nstats
+        f64 = self._native.f64_mode()
+        info = self.TrajInfoCls()
+        info["Length"] = int(st.length[b])
+        info["Return"] = (st.ret64 if f64 else st.ret32)[b]
+        info["NonzeroRewards"] = st.nonzero[b]
+        info["DiscountedReturn"] = (st.disc64 if f64 else st.disc32)[b]
+        info["_cur_discount"] = float(st.g[b])
+        if st.score is not None:
+            info["GameScore"] = float(st.score[b])
+            st.score[b] = 0.
+        self._completed.append(info.terminate(final_obs))
+        st.length[b] = st.nonzero[b] = 0
+        st.ret32[b] = st.disc32[b] = 0
+        st.ret64[b] = st.disc64[b] = 0
+        st.g[b] = 1
+        o = self.envs[b].reset()
+        self.last_obs[b] = o
+        return o
+
     def step_all(self, t, completed):
         """Apply ``step.action`` to every env; write obs/reward/done for the next step."""
+        if self._native is not None:
+            lazy = (self.frames and self.lazy_obs is not None and self.lazy_obs.value
+                    and self.batch_T is not None and t != self.batch_T - 1)
+            self._completed = completed
+            self._native.step(t, bool(lazy))
+            return
         step = self.step
         mbr = self.mid_batch_reset
         obs_buf, act_buf, rew_buf, done_buf = step.observation, step.action, step.reward, step.done
@@ -983,9 +1070,12 @@ class GpuSampler(BaseSampler):
         two spare cores per rank on top of the env workers; under a tight CPU quota (several
         ranks in one quota-limited container) the threads sleep between hand-offs instead."""
         if getattr(self, "_spin", None) is None:
+            import os
             from ..utils.misc import usable_cpus
             per_rank = usable_cpus() / max(self.world_size, 1)
             self._spin = 20000 if per_rank >= 6 else 0
+            if os.environ.get("RLPYT_SERVE_SPIN"):          # A/B experiments (rollout sweep)
+                self._spin = int(os.environ["RLPYT_SERVE_SPIN"])
         return self._spin
 
     def _serve_native(self, T):

@@ -1,0 +1,98 @@
+"""rlpyt_amd._envloop (csrc/envloop.c): the sampler workers' per-env loop body in C against the Python
+loop body of ``EnvRunner.step_all`` -- the worker side of rlpyt/samplers/parallel/gpu/collectors.py:18-50
+plus the stock trajectory statistics (rlpyt/samplers/collections.py:30-56).  Same step-buffer bytes,
+same env_info rows, same completed-trajectory records, field for field and TYPE for type (the types are
+what numpy's promotion rules make of the reference's per-step updates)."""
+import numpy as np
+import pytest
+
+from rlpyt_amd.envs import EnvStep
+from rlpyt_amd.envs.synthetic import SyntheticPong, TinyDiscreteEnv
+from rlpyt_amd.samplers.collections import AtariTrajInfo, StepBuffer, StepBufferFs, TrajInfo
+from rlpyt_amd.samplers.gpu import EnvRunner
+from rlpyt_amd.utils.collections import namedarraytuple
+
+EnvInfo = namedarraytuple("EnvInfo", ["game_score", "traj_done"])
+
+
+class Float64RewardPong(SyntheticPong):
+    """Rewards as np.float64 (what rlpyt's own AtariEnv hands out: np.sign(game_score))."""
+
+    def step(self, action):
+        o, r, d, info = super().step(action)
+        return EnvStep(o, np.float64(r), d, info)
+
+
+def _runner(EnvCls, n, T, native, TrajInfoCls, lazy, frames=True, **env_kw):
+    envs = [EnvCls(seed=100 + i, **env_kw) for i in range(n)]
+    o = envs[0].reset()
+    fields = dict(observation=np.zeros((n,) + o.shape, o.dtype), action=np.zeros(n, np.int64),
+                  reward=np.zeros(n, np.float32), done=np.zeros(n, bool))
+    if frames:
+        step = StepBufferFs(frame=np.zeros((n,) + o.shape[1:], o.dtype), reset=np.zeros(n, bool), **fields)
+    else:
+        step = StepBuffer(**fields)
+    # env_info as the sampler hands it to a worker: COLUMN slices of the [T, B] arrays
+    big = EnvInfo(game_score=np.zeros((T, n + 3), np.float32), traj_done=np.zeros((T, n + 3), bool))
+    info = EnvInfo(game_score=big.game_score[:, 2:2 + n], traj_done=big.traj_done[:, 2:2 + n]) \
+        if EnvCls is not TinyDiscreteEnv else None
+    r = EnvRunner(envs, step, info, TrajInfoCls, True)
+    r.use_native = native
+    if lazy:
+        class L:
+            value = True
+        r.lazy_obs, r.batch_T = L(), T
+    np.random.seed(5)
+    r.start(7)
+    return r, step, big
+
+
+@pytest.mark.parametrize("EnvCls,TI,env_kw,frames,lazy", [
+    (SyntheticPong, AtariTrajInfo, dict(points_to_end=1, max_steps=40), True, True),
+    (SyntheticPong, TrajInfo, dict(points_to_end=2, max_steps=25), True, False),
+    (Float64RewardPong, AtariTrajInfo, dict(points_to_end=1, max_steps=30), True, True),
+    (TinyDiscreteEnv, TrajInfo, dict(horizon=9), False, False),
+])
+def test_native_loop_body_equals_python_loop_body(EnvCls, TI, env_kw, frames, lazy):
+    n, T, n_batches = 5, 16, 6
+    TI._discount = 0.97
+    try:
+        runs = []
+        for native in (True, False):
+            r, step, big = _runner(EnvCls, n, T, native, TI, lazy, frames, **env_kw)
+            assert (r._native is not None) == native
+            rng = np.random.RandomState(3)
+            rows, completed = [], []
+            for _ in range(n_batches):
+                for t in range(T):
+                    step.action[:] = rng.randint(0, 2 if EnvCls is TinyDiscreteEnv else 6, n)
+                    r.step_all(t, completed)
+                    rows.append([np.array(x).copy() for x in step])
+                rows.append([big.game_score.copy(), big.traj_done.copy()])
+            runs.append((rows, completed))
+        (rows_n, comp_n), (rows_p, comp_p) = runs
+        for a, b in zip(rows_n, rows_p):
+            for x, y in zip(a, b):
+                assert x.dtype == y.dtype and np.array_equal(x, y)
+        assert len(comp_n) == len(comp_p) > 5
+        for a, b in zip(comp_n, comp_p):
+            assert list(a.keys()) == list(b.keys())
+            for k in a:
+                assert type(a[k]) is type(b[k]), (k, type(a[k]), type(b[k]))
+                assert a[k] == b[k], (k, a[k], b[k])
+    finally:
+        TI._discount = 1
+
+
+def test_native_loop_declines_what_it_does_not_cover():
+    class MyTrajInfo(TrajInfo):        # a user's own statistics: their step() must be called
+        pass
+    r, _, _ = _runner(SyntheticPong, 3, 4, True, MyTrajInfo, False)
+    assert r._native is None
+    envs = [SyntheticPong(seed=i) for i in range(2)]
+    o = envs[0].reset()
+    step = StepBuffer(observation=np.zeros((2,) + o.shape, o.dtype), action=np.zeros(2, np.int64),
+                      reward=np.zeros(2, np.float32), done=np.zeros(2, bool))
+    r = EnvRunner(envs, step, None, TrajInfo, False)     # wait-reset collector
+    r.start(0)
+    assert r._native is None
