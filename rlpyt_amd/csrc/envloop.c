@@ -19,8 +19,33 @@
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#include <limits.h>
+#include <linux/futex.h>
 #include <stdint.h>
 #include <string.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
+
+/* The step hand-off words of csrc/hostsync.cpp (rlpyt_seq_wait / rlpyt_seq_arrive), restated here so
+ * that a worker's wait -> step -> arrive of one pipeline group is ONE call from Python. */
+static inline int seq_reached(uint32_t cur, uint32_t target) { return (int32_t)(cur - target) >= 0; }
+static void seq_wait(uint32_t* word, uint32_t target, int spin_iters) {
+  for (int i = 0; i < spin_iters; ++i) {
+    if (seq_reached(__atomic_load_n(word, __ATOMIC_ACQUIRE), target)) return;
+    __builtin_ia32_pause();
+  }
+  for (;;) {
+    const uint32_t cur = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+    if (seq_reached(cur, target)) return;
+    struct timespec ts = {0, 50 * 1000 * 1000};   /* re-check at least every 50 ms */
+    syscall(SYS_futex, word, FUTEX_WAIT, cur, &ts, NULL, 0);
+  }
+}
+static void seq_arrive(uint32_t* word, uint32_t wake_at) {
+  const uint32_t now = __atomic_add_fetch(word, 1u, __ATOMIC_ACQ_REL);
+  if (seq_reached(now, wake_at)) syscall(SYS_futex, word, FUTEX_WAKE, INT_MAX, NULL, NULL, 0);
+}
 
 typedef struct {
   Py_buffer view;
@@ -348,12 +373,34 @@ static PyObject* EnvLoop_step(EnvLoop* self, PyObject* args) {
   Py_RETURN_NONE;
 }
 
+/* step_synced(t, lazy, act_word, act_target, spin, obs_word, wake_at): wait until the master has
+ * published action set `act_target`, step, report the arrival (the last arriver wakes the master). */
+static PyObject* EnvLoop_step_synced(EnvLoop* self, PyObject* args) {
+  Py_ssize_t t;
+  int lazy, spin;
+  unsigned long long act_word, obs_word;
+  unsigned long act_target, wake_at;
+  if (!PyArg_ParseTuple(args, "npKkiKk", &t, &lazy, &act_word, &act_target, &spin, &obs_word, &wake_at))
+    return NULL;
+  seq_wait((uint32_t*)(uintptr_t)act_word, (uint32_t)act_target, spin);
+  PyObject* a2 = Py_BuildValue("(ni)", t, lazy);
+  if (!a2) return NULL;
+  PyObject* r = EnvLoop_step(self, a2);
+  Py_DECREF(a2);
+  if (!r) return NULL;
+  Py_DECREF(r);
+  seq_arrive((uint32_t*)(uintptr_t)obs_word, (uint32_t)wake_at);
+  Py_RETURN_NONE;
+}
+
 static PyObject* EnvLoop_f64_mode(EnvLoop* self, PyObject* Py_UNUSED(ignored)) {
   return PyBool_FromLong(self->f64_mode);
 }
 
 static PyMethodDef EnvLoop_methods[] = {
     {"step", (PyCFunction)EnvLoop_step, METH_VARARGS, "step(t, lazy): one time step of every env"},
+    {"step_synced", (PyCFunction)EnvLoop_step_synced, METH_VARARGS,
+     "step_synced(t, lazy, act_word, act_target, spin, obs_word, wake_at): wait, step, arrive"},
     {"f64_mode", (PyCFunction)EnvLoop_f64_mode, METH_NOARGS, "True once the float64 sums are live"},
     {NULL, NULL, 0, NULL}};
 

@@ -211,6 +211,17 @@ class EnvRunner:
         self.last_obs[b] = o
         return o
 
+    def step_synced(self, seq, g, t, completed):
+        """``seq.worker_wait_act(g)`` + ``step_all`` + ``seq.worker_arrive(g)`` as one native call."""
+        lazy = (self.frames and self.lazy_obs is not None and self.lazy_obs.value
+                and self.batch_T is not None and t != self.batch_T - 1)
+        self._completed = completed
+        seq.acts[g] += 1
+        seq.rounds[g] += 1
+        self._native.step_synced(t, bool(lazy), seq.act[g].value, seq.acts[g] & 0xffffffff,
+                                 seq.WORKER_SPIN, seq.obs[g].value,
+                                 (seq.rounds[g] * seq.group_workers[g]) & 0xffffffff)
+
     def step_all(self, t, completed):
         """Apply ``step.action`` to every env; write obs/reward/done for the next step."""
         if self._native is not None:
@@ -350,9 +361,12 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus, eval_runner=None):
             seq.worker_arrive(g)
         for t in range(batch_T):
             for g, rn in runners:
-                seq.worker_wait_act(g)
-                rn.step_all(t, completed)
-                seq.worker_arrive(g)
+                if rn._native is not None:     # wait -> step -> arrive in one C call
+                    rn.step_synced(seq, g, t, completed)
+                else:
+                    seq.worker_wait_act(g)
+                    rn.step_all(t, completed)
+                    seq.worker_arrive(g)
         # completed-trajectory statistics -> this worker's rows of the shared table (numeric
         # TrajInfo fields); anything that does not fit goes through the queue instead
         n = len(completed)
