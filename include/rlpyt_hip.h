@@ -475,6 +475,12 @@ int rlpyt_atari_conv2_wgrad_f32(const float* g2, const float* y2, const float* y
 int rlpyt_atari_conv2_bwd_f32(const float* g2, const float* y2, const float* y1, int64_t M,
                               const float* w2, float* dy1, float* workspace, float* dw2,
                               float* db2, rlpyt_stream_t stream);
+/* The same operation with both contractions on the bf16 matrix pipe (three-piece bf16 splits of
+ * both operands, six products, f32 accumulate: f32-level error, like rlpyt_gemm_nt_f32); same
+ * arguments, same workspace. */
+int rlpyt_atari_conv2_bwd_x6_f32(const float* g2, const float* y2, const float* y1, int64_t M,
+                              const float* w2, float* dy1, float* workspace, float* dw2,
+                              float* db2, rlpyt_stream_t stream);
 int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* flat_idx /*nullable*/, int T,
                                 int64_t B, int64_t M, const float* dy1, float scale,
                                 float* workspace, float* dw1, float* db1, rlpyt_stream_t stream);

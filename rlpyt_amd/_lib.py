@@ -139,6 +139,7 @@ _SIGNATURES = {
     "rlpyt_atari_conv_wgrad_workspace_bytes": (c_int64, []),
     "rlpyt_atari_conv2_wgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p, _p]),
     "rlpyt_atari_conv2_bwd_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p, _p, _p, _p]),
+    "rlpyt_atari_conv2_bwd_x6_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p, _p, _p, _p]),
     "rlpyt_atari_conv1_wgrad_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, c_float, _p, _p,
                                             _p, _p]),
     "rlpyt_gather_rows": (c_int, [_p, _p, _p, _p, c_int, c_int64, c_int64, c_int64, _p]),

@@ -1472,6 +1472,303 @@ __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
   }
 }
 
+// ======================================================================================
+// conv2 backward on the bf16 matrix pipe ("bf16x6"), fused like conv2_bwd_kernel: dgrad (+ ReLU mask
+// of conv1) and wgrad (+ bias gradient) in ONE pass over the images.  The f32-MFMA kernel above is
+// matrix-pipe bound (1920 f32 MFMAs = 15 360 cycles per SIMD and image: 0.62-0.68 of the f32 peak
+// at the clock the chip sustains, ~305 us at M = 8192); with both operands of both contractions
+// split into three bf16 pieces (six products of order <= 2, f32 accumulate, dropped terms
+// <= 2^-24: the scheme of conv2_fwd_x6_kernel / gemm.hip) the same work is 23 040 bf16-MFMA cycles
+// per image on the CU = 6 144 on the busiest SIMD.
+//
+// What makes it simple: ds_read_b64_tr_b16, the LDS transpose read of gfx950.  Within a group of 16
+// lanes, lane s supplies the address of four contiguous 16-bit elements = "key s >> 2, columns
+// 4 (s & 3) .. + 3" of a 4 x 16 block, and lane i receives column i of the block, keys 0..3
+// (scripts/debug/tr_probe.hip prints the map).  The addresses are per lane, i.e. a free gather of
+// 8-byte chunks -- so
+//   * y1 stays in LDS in its natural [pixel][16 channels] order (bf16 pieces, zero-bordered plane
+//     26 x 20): staging is three 8-byte writes per float4, and the weight gradient's B operand
+//     B[k = position][n = (tap, channel)] -- eight consecutive positions per lane, i.e. pixels two
+//     apart with row wraps -- is two transpose reads per piece whose lanes point at the right pixels;
+//   * gm2 = g2 * (y2 > 0) is staged once as [co][position] (three 8-byte writes per float4; the A
+//     operand of the weight gradient reads it directly, K = position contiguous) and transposed
+//     LDS -> LDS into [position][co] for the data gradient (K = co contiguous) by 42 wave-level
+//     transpose reads + 8-byte writes per image.
+// Roles (waves w and w + 4 share a SIMD): waves 0-3 = dgrad of parity class q = w of the stride-2
+// transposed convolution (9 / 8 / 8 / 7 tiles of 16 pixels, 4 taps x 6 v_mfma_f32_16x16x32_bf16
+// each, the class's weights as 48 VGPRs of pieces, tile addressing from an LDS table, ReLU mask
+// from the y1 pieces, 16-byte stores); waves 4-7 = wgrad of two of the eight 32-column tiles
+// (32 co x (2 taps x 16 channels)), 7 K-slices of 16 positions x 6 v_mfma_f32_32x32x16_bf16 per tile,
+// accumulators in VGPRs across all images of the workgroup.  One persistent workgroup per CU;
+// LDS single-buffered (106 KB): stage -> barrier -> transpose -> barrier -> compute -> barrier,
+// the next image's rows in flight (registers) meanwhile.
+// ======================================================================================
+constexpr int X6_THREADS = 512;
+constexpr int X6_YPB = (PPIX + 1) * 32;      // bytes per piece of the y1 plane (+ 1 spare pixel)
+constexpr int X6_GP = 112;                   // positions padded to 7 K-slices of 16
+constexpr int X6_G0_ROWB = X6_GP * 2, X6_G0_PB = C2 * X6_G0_ROWB;     // [co][pos]: 224 B rows
+constexpr int X6_GT_ROWB = C2 * 2, X6_GT_PB = X6_GP * X6_GT_ROWB;     // [pos][co]: 64 B rows
+constexpr int X6_TABP = 144;                 // pixel slots per class in the dgrad tile table
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr16(const uint8_t* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(p));
+  return __builtin_bit_cast(uint2, v);
+}
+
+__global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
+    const float* __restrict__ g2, const float* __restrict__ y2, const float* __restrict__ y1,
+    const float* __restrict__ w2, float* __restrict__ dy1, float* __restrict__ partial, int64_t M) {
+  __shared__ __attribute__((aligned(16))) uint8_t y1p[3 * X6_YPB];       // 50,016 B
+  __shared__ __attribute__((aligned(16))) uint8_t g0[3 * X6_G0_PB];      // 21,504 B
+  __shared__ __attribute__((aligned(16))) uint8_t gt[3 * X6_GT_PB];      // 21,504 B
+  __shared__ __attribute__((aligned(16))) int dtab[4 * X6_TABP * 4];     //  9,216 B
+  __shared__ float bred[2 * X6_THREADS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  for (int i = tid; i < 3 * X6_YPB / 16; i += X6_THREADS)
+    reinterpret_cast<uint4*>(y1p)[i] = uint4{0u, 0u, 0u, 0u};          // border stays zero
+  for (int i = tid; i < 3 * X6_G0_PB / 16; i += X6_THREADS)
+    reinterpret_cast<uint4*>(g0)[i] = uint4{0u, 0u, 0u, 0u};           // positions 108..111 stay zero
+  // dgrad tile table: entry (class q, pixel slot p) = {GT byte offsets of taps 0 | 1 << 16,
+  // taps 2 | 3 << 16 (position 108 = a zero row where a tap falls outside), byte offset of the pixel
+  // in a y1 piece plane, float offset of the pixel in dy1}; slots past the last pixel repeat it
+  for (int i = tid; i < 4 * X6_TABP; i += X6_THREADS) {
+    const int cq = i / X6_TABP, p = i - cq * X6_TABP;
+    const int py = cq >> 1, px = cq & 1;
+    const int nb = px ? 9 : 10, npx = (py ? 12 : 13) * nb;
+    const int pc = min(p, npx - 1);
+    const int a = pc / nb, b = pc - a * nb;
+    const int iy = 2 * a + py, ix = 2 * b + px;
+    int off[4];
+    for (int dd = 0; dd < 4; ++dd) {
+      const int oy = a + py - (dd >> 1), ox = b + px - (dd & 1);
+      const bool v = (oy >= 0) && (oy < H2) && (ox >= 0) && (ox < W2);
+      off[dd] = (v ? oy * W2 + ox : P2) * X6_GT_ROWB;
+    }
+    int* e = dtab + i * 4;
+    e[0] = off[0] | (off[1] << 16);
+    e[1] = off[2] | (off[3] << 16);
+    e[2] = ((iy + 1) * PW + ix + 1) * 32;
+    e[3] = (iy * W1 + ix) * C1;
+  }
+
+  // ---- staging maps (fixed per thread) and the registers the next image travels in -------------
+  // gm2: float4 i = tid + 512 k of [32 co][27 quads]; y1: float4 i = tid + 512 k of [475 pixels][4]
+  int gdst[2], ydst[4];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = min(tid + k * X6_THREADS, F2 / 4 - 1);
+    const int co = i / (P2 / 4), q4 = i - co * (P2 / 4);
+    gdst[k] = co * X6_G0_ROWB + q4 * 8;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = min(tid + k * X6_THREADS, Y1 / 4 - 1);
+    const int p = i >> 2, q = i & 3, iy = p / W1, ix = p - iy * W1;
+    ydst[k] = ((iy + 1) * PW + ix + 1) * 32 + q * 8;
+  }
+  f32x4 pg[2], py2[2], py1[4];
+  float bsum[2] = {0.f, 0.f};
+#define RLPYT_X6_PREFETCH(mi)                                                                  \
+  {                                                                                            \
+    const f32x4* __restrict__ gs_ = reinterpret_cast<const f32x4*>(g2 + (mi) * F2);            \
+    const f32x4* __restrict__ ys_ = reinterpret_cast<const f32x4*>(y2 + (mi) * F2);            \
+    const f32x4* __restrict__ y1s_ = reinterpret_cast<const f32x4*>(y1 + (mi) * Y1);          \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                            \
+      const int i = min(tid + k * X6_THREADS, F2 / 4 - 1);                                     \
+      pg[k] = gs_[i];                                                                          \
+      py2[k] = ys_[i];                                                                         \
+    }                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                              \
+      py1[k] = y1s_[min(tid + k * X6_THREADS, Y1 / 4 - 1)];                                    \
+  }
+#define RLPYT_X6_STAGE()                                                                       \
+  {                                                                                            \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                            \
+      if (tid + k * X6_THREADS < F2 / 4) {                                                     \
+        float v_[4];                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = py2[k][e] > 0.f ? pg[k][e] : 0.f; \
+        bsum[k] += (v_[0] + v_[1]) + (v_[2] + v_[3]);                                          \
+        uint32_t p_[3][2];                                                                     \
+        split3_rn(v_[0], v_[1], p_[0][0], p_[1][0], p_[2][0]);                                 \
+        split3_rn(v_[2], v_[3], p_[0][1], p_[1][1], p_[2][1]);                                 \
+        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                       \
+          *reinterpret_cast<uint2*>(g0 + s_ * X6_G0_PB + gdst[k]) = uint2{p_[s_][0], p_[s_][1]}; \
+      }                                                                                        \
+    }                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
+      if (tid + k * X6_THREADS < Y1 / 4) {                                                     \
+        uint32_t p_[3][2];                                                                     \
+        split3_rn(py1[k][0], py1[k][1], p_[0][0], p_[1][0], p_[2][0]);                         \
+        split3_rn(py1[k][2], py1[k][3], p_[0][1], p_[1][1], p_[2][1]);                         \
+        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                       \
+          *reinterpret_cast<uint2*>(y1p + s_ * X6_YPB + ydst[k]) = uint2{p_[s_][0], p_[s_][1]}; \
+      }                                                                                        \
+    }                                                                                          \
+  }
+  // gm2 [co][pos] -> [pos][co]: group-blocks of 4 co x 16 positions, 3 pieces x 7 x 8 = 168 of them
+#define RLPYT_X6_TRANSPOSE()                                                                   \
+  for (int blk = wave * 4 + (lane >> 4); blk < 168; blk += 32) {                               \
+    const int pc_ = blk / 56, rem_ = blk - pc_ * 56, pb_ = rem_ >> 3, cq_ = rem_ & 7;          \
+    const int s_ = lane & 15;                                                                  \
+    const uint2 v_ = lds_tr16(g0 + pc_ * X6_G0_PB + (4 * cq_ + (s_ >> 2)) * X6_G0_ROWB +       \
+                              (16 * pb_ + 4 * (s_ & 3)) * 2);                                  \
+    *reinterpret_cast<uint2*>(gt + pc_ * X6_GT_PB + (16 * pb_ + s_) * X6_GT_ROWB + cq_ * 8) = v_; \
+  }
+  // six products, smallest first (a2 b0, a0 b2, a1 b1, a1 b0, a0 b1, a0 b0)
+#define RLPYT_X6_SIX(MF_, acc_, a_, b_)                                                        \
+  acc_ = MF_(a_[2], b_[0], acc_);                                                              \
+  acc_ = MF_(a_[0], b_[2], acc_);                                                              \
+  acc_ = MF_(a_[1], b_[1], acc_);                                                              \
+  acc_ = MF_(a_[1], b_[0], acc_);                                                              \
+  acc_ = MF_(a_[0], b_[1], acc_);                                                              \
+  acc_ = MF_(a_[0], b_[0], acc_);
+
+  if ((int64_t)blockIdx.x < M) RLPYT_X6_PREFETCH((int64_t)blockIdx.x)
+  __syncthreads();                                   // zero fill + table done
+
+  if (wave < 4) {
+    // =========================== dgrad role: parity class q ================================
+    const int q = wave, py = q >> 1, px = q & 1;
+    const int nb = px ? 9 : 10, ntile = ((py ? 12 : 13) * nb + 15) >> 4;
+    const int n = lane & 15, kq = lane >> 4;
+    // A = w2 of the class's four taps: lane (row c = n, k = co 8 kq .. + 7), three pieces each
+    uint4 wa[4][3];
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+      const int ky = 1 - py + 2 * (dd >> 1), kx = 1 - px + 2 * (dd & 1);
+      uint32_t p[3][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = 8 * kq + 2 * e;
+        split3_rn(w2[co * 256 + n * 16 + ky * 4 + kx], w2[(co + 1) * 256 + n * 16 + ky * 4 + kx],
+                  p[0][e], p[1][e], p[2][e]);
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s) wa[dd][s] = uint4{p[s][0], p[s][1], p[s][2], p[s][3]};
+    }
+    const int4* tab = reinterpret_cast<const int4*>(dtab) + q * X6_TABP + n;
+    const uint8_t* gtb = gt + 16 * kq;
+    const uint8_t* ymk = y1p + 8 * kq;
+    for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+      RLPYT_X6_STAGE()
+      const bool more = m + gridDim.x < M;
+      if (more) RLPYT_X6_PREFETCH(m + gridDim.x)
+      __syncthreads();                               // G0 / y1 pieces complete
+      RLPYT_X6_TRANSPOSE()
+      __syncthreads();                               // GT complete
+      float* dyimg = dy1 + m * Y1 + 4 * kq;
+      for (int t = 0; t < ntile; ++t) {
+        const int4 e = tab[16 * t];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          const int off = dd == 0 ? (e.x & 0xffff) : dd == 1 ? ((unsigned)e.x >> 16)
+                          : dd == 2 ? (e.y & 0xffff) : ((unsigned)e.y >> 16);
+          uint4 b[3];
+#pragma unroll
+          for (int s = 0; s < 3; ++s)
+            b[s] = *reinterpret_cast<const uint4*>(gtb + s * X6_GT_PB + off);
+          RLPYT_X6_SIX(mfma_bf16, acc, wa[dd], b)
+        }
+        // ReLU mask of conv1: y1 > 0 <=> some piece of it is non-zero (y1 >= 0, the pieces sum to it)
+        uint2 mk = *reinterpret_cast<const uint2*>(ymk + e.z);
+#pragma unroll
+        for (int s = 1; s < 3; ++s) {
+          const uint2 o = *reinterpret_cast<const uint2*>(ymk + s * X6_YPB + e.z);
+          mk.x |= o.x;
+          mk.y |= o.y;
+        }
+        f32x4 o;
+        o[0] = (mk.x & 0xffffu) ? acc[0] : 0.f;
+        o[1] = (mk.x >> 16) ? acc[1] : 0.f;
+        o[2] = (mk.y & 0xffffu) ? acc[2] : 0.f;
+        o[3] = (mk.y >> 16) ? acc[3] : 0.f;
+        *reinterpret_cast<f32x4*>(dyimg + e.w) = o;
+      }
+      __syncthreads();                               // LDS free for the next image
+    }
+  } else {
+    // =========================== wgrad role: column tiles 2 ww, 2 ww + 1 ===================
+    const int ww = wave - 4;
+    const int s = lane & 15, tsel = (lane >> 4) & 1, h = lane >> 5;
+    // per-lane source addresses of the transpose reads: (K-slice, 4-position half r) -> pixel base
+    // (2 oy, 2 ox) of position 16 sl + 8 h + 4 r + (s >> 2) [positions >= 108: any valid pixel, the
+    // A operand is zero there], this lane's tap of the tile's two (+ 32 B) and its channel quad
+    int wb[7][2];
+#pragma unroll
+    for (int sl = 0; sl < 7; ++sl)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int pos = 16 * sl + 8 * h + 4 * r + (s >> 2);
+        const int oy = pos / W2, ox = pos - oy * W2;
+        wb[sl][r] = (pos < P2 ? (2 * oy * PW + 2 * ox) * 32 : 0) + tsel * 32 + (s & 3) * 8;
+      }
+    const uint8_t* ga = g0 + (lane & 31) * X6_G0_ROWB + 16 * h;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+      RLPYT_X6_STAGE()
+      const bool more = m + gridDim.x < M;
+      if (more) RLPYT_X6_PREFETCH(m + gridDim.x)
+      __syncthreads();
+      RLPYT_X6_TRANSPOSE()
+      __syncthreads();
+#pragma unroll
+      for (int sl = 0; sl < 7; ++sl) {
+        uint4 a[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[p] = *reinterpret_cast<const uint4*>(ga + p * X6_G0_PB + 32 * sl);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int t = 2 * ww + i;                                  // tile: ky = t >> 1, kx = 2 (t & 1) + tsel
+          const uint8_t* yb = y1p + ((t >> 1) * PW + 2 * (t & 1)) * 32;
+          uint4 b[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const uint2 r0 = lds_tr16(yb + p * X6_YPB + wb[sl][0]);
+            const uint2 r1 = lds_tr16(yb + p * X6_YPB + wb[sl][1]);
+            b[p] = uint4{r0.x, r0.y, r1.x, r1.y};
+          }
+          RLPYT_X6_SIX(mfma32_bf16, acc[i], a, b)
+        }
+      }
+      __syncthreads();
+    }
+    // partial weight gradient of this workgroup: dw2[co][c][ky][kx], co = row, (tap, c) = column
+    float* prow = partial + (int64_t)blockIdx.x * PART2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = 2 * ww + i, ky = t >> 1, kx = 2 * (t & 1) + tsel, c = lane & 15;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+        prow[co * 256 + c * 16 + ky * 4 + kx] = acc[i][r];
+      }
+    }
+  }
+  // bias gradient: this thread's masked g2 sums (fixed co per thread and k) -> per-co sums
+  bred[tid] = bsum[0];
+  bred[X6_THREADS + tid] = tid + X6_THREADS < F2 / 4 ? bsum[1] : 0.f;
+  __syncthreads();
+  if (tid < C2) {
+    float v = 0.f;
+    for (int q4 = 0; q4 < P2 / 4; ++q4) v += bred[tid * (P2 / 4) + q4];
+    partial[(int64_t)blockIdx.x * PART2 + DW2_N + tid] = v;
+  }
+#undef RLPYT_X6_SIX
+#undef RLPYT_X6_TRANSPOSE
+#undef RLPYT_X6_STAGE
+#undef RLPYT_X6_PREFETCH
+}
+
 // out[e] = sum_g partial[g][e]; e < n.  Fixed order -> run-to-run deterministic.
 // 64 elements per workgroup, the G partials split over 16 waves with 4 independent 256-byte row
 // loads in flight each (4 waves x 2 in flight measured 11.5 us for 256 rows: a chain of 32
@@ -1802,6 +2099,27 @@ extern "C" int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* fl
   RL_LAUNCH_CHECK();
   RL_LAUNCH(reduce_partials_kernel, dim3((PART1 + 63) / 64), dim3(1024), 0, s, workspace,
                      g, PART1, dw1, DW1_N, db1);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_atari_conv2_bwd_x6_f32(const float* g2, const float* y2, const float* y1,
+                                            int64_t M, const float* w2, float* dy1,
+                                            float* workspace, float* dw2, float* db2,
+                                            rlpyt_stream_t stream) {
+  RL_CHECK_ARG(M > 0, RLPYT_EINVAL, "rlpyt_atari_conv2_bwd_x6_f32: bad sizes");
+  RL_CHECK_ARG(g2 && y2 && y1 && w2 && dy1 && workspace && dw2 && db2, RLPYT_EINVAL,
+               "rlpyt_atari_conv2_bwd_x6_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(dy1) && RL_ALIGNED16(g2) && RL_ALIGNED16(y2) &&
+                   RL_ALIGNED16(workspace),
+               RLPYT_ESHAPE, "rlpyt_atari_conv2_bwd_x6_f32: g2 / y2 / y1 / dy1 / workspace must be "
+                             "16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int g = std::min(grid_for(M, 1), kPartialRows);   // one persistent workgroup per CU
+  RL_LAUNCH(conv2_bwd_x6_kernel, dim3(g), dim3(X6_THREADS), 0, s, g2, y2, y1, w2, dy1, workspace, M);
+  RL_LAUNCH_CHECK();
+  RL_LAUNCH(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(1024), 0, s, workspace,
+                     g, PART2, dw2, DW2_N, db2);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

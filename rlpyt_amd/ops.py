@@ -483,6 +483,9 @@ def obs_normalize(x, mean, var, var_clip=1e-6, obs_clip=10.):
 ATARI_IMG = (4, 104, 80)
 ATARI_P1, ATARI_C1, ATARI_F2 = 25 * 19, 16, 32 * 12 * 9
 # algorithmic flops per image (2 * MACs): conv1 475x256x16, conv2 108x256x32
+# conv2 backward: bf16x6 kernel (csrc/conv.hip conv2_bwd_x6_kernel) or, RLPYT_CONV2_BWD_X6=0, the
+# f32-MFMA kernel of rounds 1-2 (A/B timing)
+CONV2_BWD_X6 = os.environ.get("RLPYT_CONV2_BWD_X6", "1") != "0"
 _FL_C1, _FL_C2 = 2 * 475 * 256 * 16, 2 * 108 * 256 * 32
 _FL_C2D = 2 * 475 * 128 * 16      # transposed conv: 2x2 taps x 32 channels per input pixel
 
@@ -532,10 +535,10 @@ class _AtariConvStack(torch.autograd.Function):
         db1 = torch.empty(16, dtype=torch.float32, device=dev)
         dw2 = torch.empty((32, 16, 4, 4), dtype=torch.float32, device=dev)
         db2 = torch.empty(32, dtype=torch.float32, device=dev)
+        bwd = lib.rlpyt_atari_conv2_bwd_x6_f32 if CONV2_BWD_X6 else lib.rlpyt_atari_conv2_bwd_f32
         with ktimer.region("conv2_bwd", M * 4 * (2 * 3456 + 2 * 7600), M * (_FL_C2D + _FL_C2)):
-            check(lib.rlpyt_atari_conv2_bwd_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2c), ptr(dy1),
-                                                ptr(ws), ptr(dw2), ptr(db2), stream()),
-                  "rlpyt_atari_conv2_bwd_f32")
+            check(bwd(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2c), ptr(dy1), ptr(ws), ptr(dw2), ptr(db2),
+                      stream()), "rlpyt_atari_conv2_bwd_f32")
         with ktimer.region("conv1_wgrad", M * (33280 + 4 * 7600), M * _FL_C1):
             check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs), ptr(idx), T, B, M, ptr(dy1), scale,
                                                   ptr(ws), ptr(dw1), ptr(db1), stream()),

@@ -55,6 +55,9 @@ def main():
         "conv2_bwd_fused": (lambda: check(lib.rlpyt_atari_conv2_bwd_f32(
             ptr(g2), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1), ptr(ws), ptr(dw2), ptr(db2), st)),
             ops._FL_C2D + ops._FL_C2),
+        "conv2_bwd_x6": (lambda: check(lib.rlpyt_atari_conv2_bwd_x6_f32(
+            ptr(g2), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1), ptr(ws), ptr(dw2), ptr(db2), st)),
+            ops._FL_C2D + ops._FL_C2),
         "conv1_wgrad": (lambda: check(lib.rlpyt_atari_conv1_wgrad_f32(
             ptr(obs), ptr(idx), T, B, M, ptr(dy1), 1. / 255, ptr(ws), ptr(dw1), ptr(db1), st)),
             ops._FL_C1),

@@ -134,6 +134,16 @@ def test_conv_backward_kernels(ops, M):
     _close(dw2f, p64[2].grad, what="fused conv2 wgrad")
     _close(db2f, p64[3].grad, what="fused conv2 bias grad")
     assert not torch.isnan(dy1f).any()
+    # ... and so does the bf16x6 version of the fused kernel (both contractions on the bf16 pipe)
+    dy1x = torch.full((M, 475, 16), float("nan"), device="cuda")
+    dw2x = torch.full((32, 16, 4, 4), float("nan"), device="cuda")
+    db2x = torch.full((32,), float("nan"), device="cuda")
+    check(lib.rlpyt_atari_conv2_bwd_x6_f32(ptr(g2d), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1x), ptr(ws),
+                                           ptr(dw2x), ptr(db2x), stream()), "conv2 bwd x6")
+    _close(dy1x, dy1_ref, what="bf16x6 conv2 dgrad")
+    _close(dw2x, p64[2].grad, what="bf16x6 conv2 wgrad")
+    _close(db2x, p64[3].grad, what="bf16x6 conv2 bias grad")
+    assert not torch.isnan(dy1x).any()
     dw1 = torch.full((16, 4, 8, 8), float("nan"), device="cuda")
     db1 = torch.full((16,), float("nan"), device="cuda")
     dy1_in = dy1_ref.float().cuda().contiguous()

@@ -501,7 +501,7 @@ def _conv_fwd_large():
     Cv.test_conv_identity_weights_asymmetric(_ops())
 
 
-@case("conv2_bwd_kernel", "conv1_wgrad_kernel", "reduce_partials_kernel", "conv2_dgrad_kernel",
+@case("conv2_bwd_kernel", "conv2_bwd_x6_kernel", "conv1_wgrad_kernel", "reduce_partials_kernel", "conv2_dgrad_kernel",
       "conv2_wgrad_kernel")
 def _conv_bwd():
     import test_conv_gpu as Cv
