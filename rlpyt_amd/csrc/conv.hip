@@ -1619,13 +1619,22 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     *reinterpret_cast<uint2*>(gt + pc_ * X6_GT_PB + (16 * pb_ + s_) * X6_GT_ROWB + cq_ * 8) = v_; \
   }
   // six products, smallest first (a2 b0, a0 b2, a1 b1, a1 b0, a0 b1, a0 b0)
-#define RLPYT_X6_SIX(MF_, acc_, a_, b_)                                                        \
-  acc_ = MF_(a_[2], b_[0], acc_);                                                              \
-  acc_ = MF_(a_[0], b_[2], acc_);                                                              \
-  acc_ = MF_(a_[1], b_[1], acc_);                                                              \
-  acc_ = MF_(a_[1], b_[0], acc_);                                                              \
-  acc_ = MF_(a_[0], b_[1], acc_);                                                              \
-  acc_ = MF_(a_[0], b_[0], acc_);
+// ... for TWO output tiles that share the A operand, interleaved: two independent accumulator
+// chains (a dependent v_mfma waits for its predecessor's result; one chain alone ran the data
+// gradient at about half the matrix-pipe rate)
+#define RLPYT_X6_PAIR(MF_, acc0_, acc1_, a_, b0_, b1_, sa_, sb_)                                \
+  acc0_ = MF_(a_[sa_], b0_[sb_], acc0_);                                                       \
+  acc1_ = MF_(a_[sa_], b1_[sb_], acc1_);                                                       \
+  /* pin the pair: the optimizer otherwise moves the second chain's MFMAs (pure intrinsics) */ \
+  /* behind the first chain's -- across sched_barrier too -- and the chains run serially    */ \
+  asm volatile("" : "+v"(acc0_), "+v"(acc1_));
+#define RLPYT_X6_SIX2(MF_, acc0_, acc1_, a_, b0_, b1_)                                         \
+  RLPYT_X6_PAIR(MF_, acc0_, acc1_, a_, b0_, b1_, 2, 0)                                         \
+  RLPYT_X6_PAIR(MF_, acc0_, acc1_, a_, b0_, b1_, 0, 2)                                         \
+  RLPYT_X6_PAIR(MF_, acc0_, acc1_, a_, b0_, b1_, 1, 1)                                         \
+  RLPYT_X6_PAIR(MF_, acc0_, acc1_, a_, b0_, b1_, 1, 0)                                         \
+  RLPYT_X6_PAIR(MF_, acc0_, acc1_, a_, b0_, b1_, 0, 1)                                         \
+  RLPYT_X6_PAIR(MF_, acc0_, acc1_, a_, b0_, b1_, 0, 0)
 
   if ((int64_t)blockIdx.x < M) RLPYT_X6_PREFETCH((int64_t)blockIdx.x)
   __syncthreads();                                   // zero fill + table done
@@ -1633,7 +1642,7 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
   if (wave < 4) {
     // =========================== dgrad role: parity class q ================================
     const int q = wave, py = q >> 1, px = q & 1;
-    const int nb = px ? 9 : 10, ntile = ((py ? 12 : 13) * nb + 15) >> 4;
+    const int nb = px ? 9 : 10, ntile = ((py ? 12 : 13) * nb + 15) >> 4, npair = (ntile + 1) >> 1;
     const int n = lane & 15, kq = lane >> 4;
     // A = w2 of the class's four taps: lane (row c = n, k = co 8 kq .. + 7), three pieces each
     uint4 wa[4][3];
@@ -1661,34 +1670,57 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
       RLPYT_X6_TRANSPOSE()
       __syncthreads();                               // GT complete
       float* dyimg = dy1 + m * Y1 + 4 * kq;
-      for (int t = 0; t < ntile; ++t) {
-        const int4 e = tab[16 * t];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      // two tiles per trip (an odd last tile is done twice: same values to the same addresses);
+      // the B operands of the next tap -- after the last tap: of the next pair's first tap -- and
+      // the mask words are requested BEFORE the 12 MFMAs that hide them
+#define RLPYT_X6_DOFF(e_, dd_)                                                                 \
+  ((dd_) == 0 ? ((e_).x & 0xffff) : (dd_) == 1 ? (int)((unsigned)(e_).x >> 16)                 \
+   : (dd_) == 2 ? ((e_).y & 0xffff) : (int)((unsigned)(e_).y >> 16))
+#define RLPYT_X6_DREAD(dst_, e0_, e1_, dd_)                                                    \
+  _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                           \
+    dst_[0][s_] = *reinterpret_cast<const uint4*>(gtb + s_ * X6_GT_PB + RLPYT_X6_DOFF(e0_, dd_)); \
+    dst_[1][s_] = *reinterpret_cast<const uint4*>(gtb + s_ * X6_GT_PB + RLPYT_X6_DOFF(e1_, dd_)); \
+  }
+      int4 e0 = tab[0], e1 = tab[16 * min(1, ntile - 1)];
+      uint4 bc[2][3], bn[2][3];
+      RLPYT_X6_DREAD(bc, e0, e1, 0)
+      for (int u = 0; u < npair; ++u) {
+        const int4 n0 = tab[16 * min(2 * u + 2, ntile - 1)], n1 = tab[16 * min(2 * u + 3, ntile - 1)];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        uint2 mk0[3], mk1[3];
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) {
-          const int off = dd == 0 ? (e.x & 0xffff) : dd == 1 ? ((unsigned)e.x >> 16)
-                          : dd == 2 ? (e.y & 0xffff) : ((unsigned)e.y >> 16);
-          uint4 b[3];
+          if (dd < 3) {
+            RLPYT_X6_DREAD(bn, e0, e1, dd + 1)
+          } else {
+            RLPYT_X6_DREAD(bn, n0, n1, 0)
 #pragma unroll
-          for (int s = 0; s < 3; ++s)
-            b[s] = *reinterpret_cast<const uint4*>(gtb + s * X6_GT_PB + off);
-          RLPYT_X6_SIX(mfma_bf16, acc, wa[dd], b)
+            for (int s = 0; s < 3; ++s) {
+              mk0[s] = *reinterpret_cast<const uint2*>(ymk + s * X6_YPB + e0.z);
+              mk1[s] = *reinterpret_cast<const uint2*>(ymk + s * X6_YPB + e1.z);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          RLPYT_X6_SIX2(mfma_bf16, acc0, acc1, wa[dd], bc[0], bc[1])
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) { bc[0][s] = bn[0][s]; bc[1][s] = bn[1][s]; }
         }
         // ReLU mask of conv1: y1 > 0 <=> some piece of it is non-zero (y1 >= 0, the pieces sum to it)
-        uint2 mk = *reinterpret_cast<const uint2*>(ymk + e.z);
-#pragma unroll
-        for (int s = 1; s < 3; ++s) {
-          const uint2 o = *reinterpret_cast<const uint2*>(ymk + s * X6_YPB + e.z);
-          mk.x |= o.x;
-          mk.y |= o.y;
-        }
-        f32x4 o;
-        o[0] = (mk.x & 0xffffu) ? acc[0] : 0.f;
-        o[1] = (mk.x >> 16) ? acc[1] : 0.f;
-        o[2] = (mk.y & 0xffffu) ? acc[2] : 0.f;
-        o[3] = (mk.y >> 16) ? acc[3] : 0.f;
-        *reinterpret_cast<f32x4*>(dyimg + e.w) = o;
+        const uint32_t ma = mk0[0].x | mk0[1].x | mk0[2].x, mb = mk0[0].y | mk0[1].y | mk0[2].y;
+        const uint32_t mc = mk1[0].x | mk1[1].x | mk1[2].x, md = mk1[0].y | mk1[1].y | mk1[2].y;
+        f32x4 o0, o1;
+        o0[0] = (ma & 0xffffu) ? acc0[0] : 0.f;  o0[1] = (ma >> 16) ? acc0[1] : 0.f;
+        o0[2] = (mb & 0xffffu) ? acc0[2] : 0.f;  o0[3] = (mb >> 16) ? acc0[3] : 0.f;
+        o1[0] = (mc & 0xffffu) ? acc1[0] : 0.f;  o1[1] = (mc >> 16) ? acc1[1] : 0.f;
+        o1[2] = (md & 0xffffu) ? acc1[2] : 0.f;  o1[3] = (md >> 16) ? acc1[3] : 0.f;
+        *reinterpret_cast<f32x4*>(dyimg + e0.w) = o0;
+        *reinterpret_cast<f32x4*>(dyimg + e1.w) = o1;
+        e0 = n0;
+        e1 = n1;
       }
+#undef RLPYT_X6_DREAD
+#undef RLPYT_X6_DOFF
       __syncthreads();                               // LDS free for the next image
     }
   } else {
@@ -1708,6 +1740,9 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
         wb[sl][r] = (pos < P2 ? (2 * oy * PW + 2 * ox) * 32 : 0) + tsel * 32 + (s & 3) * 8;
       }
     const uint8_t* ga = g0 + (lane & 31) * X6_G0_ROWB + 16 * h;
+    // tile t: ky = t >> 1, kx = 2 (t & 1) + tsel
+    const uint8_t* yb0 = y1p + (((2 * ww) >> 1) * PW + 2 * ((2 * ww) & 1)) * 32;
+    const uint8_t* yb1 = y1p + (((2 * ww + 1) >> 1) * PW + 2 * ((2 * ww + 1) & 1)) * 32;
     f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1720,26 +1755,29 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
       __syncthreads();
       RLPYT_X6_TRANSPOSE()
       __syncthreads();
+      // the 15 operand reads of slice sl + 1 are requested before the 12 MFMAs of slice sl
+#define RLPYT_X6_WREAD(a_, b0_, b1_, sl_)                                                      \
+  _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) {                                           \
+    a_[p_] = *reinterpret_cast<const uint4*>(ga + p_ * X6_G0_PB + 32 * (sl_));                 \
+    const uint2 r0_ = lds_tr16(yb0 + p_ * X6_YPB + wb[sl_][0]);                                \
+    const uint2 r1_ = lds_tr16(yb0 + p_ * X6_YPB + wb[sl_][1]);                                \
+    const uint2 r2_ = lds_tr16(yb1 + p_ * X6_YPB + wb[sl_][0]);                                \
+    const uint2 r3_ = lds_tr16(yb1 + p_ * X6_YPB + wb[sl_][1]);                                \
+    b0_[p_] = uint4{r0_.x, r0_.y, r1_.x, r1_.y};                                               \
+    b1_[p_] = uint4{r2_.x, r2_.y, r3_.x, r3_.y};                                               \
+  }
+      uint4 ac[3], bc0[3], bc1[3], an[3], bn0[3], bn1[3];
+      RLPYT_X6_WREAD(ac, bc0, bc1, 0)
 #pragma unroll
       for (int sl = 0; sl < 7; ++sl) {
-        uint4 a[3];
+        if (sl < 6) RLPYT_X6_WREAD(an, bn0, bn1, sl + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        RLPYT_X6_SIX2(mfma32_bf16, acc[0], acc[1], ac, bc0, bc1)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          a[p] = *reinterpret_cast<const uint4*>(ga + p * X6_G0_PB + 32 * sl);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int t = 2 * ww + i;                                  // tile: ky = t >> 1, kx = 2 (t & 1) + tsel
-          const uint8_t* yb = y1p + ((t >> 1) * PW + 2 * (t & 1)) * 32;
-          uint4 b[3];
-#pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            const uint2 r0 = lds_tr16(yb + p * X6_YPB + wb[sl][0]);
-            const uint2 r1 = lds_tr16(yb + p * X6_YPB + wb[sl][1]);
-            b[p] = uint4{r0.x, r0.y, r1.x, r1.y};
-          }
-          RLPYT_X6_SIX(mfma32_bf16, acc[i], a, b)
-        }
+        for (int p = 0; p < 3; ++p) { ac[p] = an[p]; bc0[p] = bn0[p]; bc1[p] = bn1[p]; }
       }
+#undef RLPYT_X6_WREAD
       __syncthreads();
     }
     // partial weight gradient of this workgroup: dw2[co][c][ky][kx], co = row, (tap, c) = column
@@ -1763,7 +1801,8 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     for (int q4 = 0; q4 < P2 / 4; ++q4) v += bred[tid * (P2 / 4) + q4];
     partial[(int64_t)blockIdx.x * PART2 + DW2_N + tid] = v;
   }
-#undef RLPYT_X6_SIX
+#undef RLPYT_X6_SIX2
+#undef RLPYT_X6_PAIR
 #undef RLPYT_X6_TRANSPOSE
 #undef RLPYT_X6_STAGE
 #undef RLPYT_X6_PREFETCH
