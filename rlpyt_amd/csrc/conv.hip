@@ -1500,8 +1500,8 @@ __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
 // from the y1 pieces, 16-byte stores); waves 4-7 = wgrad of two of the eight 32-column tiles
 // (32 co x (2 taps x 16 channels)), 7 K-slices of 16 positions x 6 v_mfma_f32_32x32x16_bf16 per tile,
 // accumulators in VGPRs across all images of the workgroup.  One persistent workgroup per CU;
-// LDS single-buffered (106 KB): stage -> barrier -> transpose -> barrier -> compute -> barrier,
-// the next image's rows in flight (registers) meanwhile.
+// y1 planes double-buffered (156 KB of LDS in all): gm2 stage -> barrier -> transpose -> barrier ->
+// compute + y1 staging of the next image -> barrier, rows in flight (registers) one / two images ahead.
 // ======================================================================================
 constexpr int X6_THREADS = 512;
 constexpr int X6_YPB = (PPIX + 1) * 32;      // bytes per piece of the y1 plane (+ 1 spare pixel)
@@ -1520,7 +1520,7 @@ __device__ __forceinline__ uint2 lds_tr16(const uint8_t* p) {
 __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     const float* __restrict__ g2, const float* __restrict__ y2, const float* __restrict__ y1,
     const float* __restrict__ w2, float* __restrict__ dy1, float* __restrict__ partial, int64_t M) {
-  __shared__ __attribute__((aligned(16))) uint8_t y1p[3 * X6_YPB];       // 50,016 B
+  __shared__ __attribute__((aligned(16))) uint8_t y1p[2 * 3 * X6_YPB];   // 2 x 50,016 B
   __shared__ __attribute__((aligned(16))) uint8_t g0[3 * X6_G0_PB];      // 21,504 B
   __shared__ __attribute__((aligned(16))) uint8_t gt[3 * X6_GT_PB];      // 21,504 B
   __shared__ __attribute__((aligned(16))) int dtab[4 * X6_TABP * 4];     //  9,216 B
@@ -1528,8 +1528,8 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  for (int i = tid; i < 3 * X6_YPB / 16; i += X6_THREADS)
-    reinterpret_cast<uint4*>(y1p)[i] = uint4{0u, 0u, 0u, 0u};          // border stays zero
+  for (int i = tid; i < 2 * 3 * X6_YPB / 16; i += X6_THREADS)
+    reinterpret_cast<uint4*>(y1p)[i] = uint4{0u, 0u, 0u, 0u};          // borders stay zero
   for (int i = tid; i < 3 * X6_G0_PB / 16; i += X6_THREADS)
     reinterpret_cast<uint4*>(g0)[i] = uint4{0u, 0u, 0u, 0u};           // positions 108..111 stay zero
   // dgrad tile table: entry (class q, pixel slot p) = {GT byte offsets of taps 0 | 1 << 16,
@@ -1572,51 +1572,67 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
   }
   f32x4 pg[2], py2[2], py1[4];
   float bsum[2] = {0.f, 0.f};
-#define RLPYT_X6_PREFETCH(mi)                                                                  \
+#define RLPYT_X6_FETCH_G(mi)                                                                   \
   {                                                                                            \
     const f32x4* __restrict__ gs_ = reinterpret_cast<const f32x4*>(g2 + (mi) * F2);            \
     const f32x4* __restrict__ ys_ = reinterpret_cast<const f32x4*>(y2 + (mi) * F2);            \
-    const f32x4* __restrict__ y1s_ = reinterpret_cast<const f32x4*>(y1 + (mi) * Y1);          \
     _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                            \
       const int i = min(tid + k * X6_THREADS, F2 / 4 - 1);                                     \
       pg[k] = gs_[i];                                                                          \
       py2[k] = ys_[i];                                                                         \
     }                                                                                          \
+  }
+#define RLPYT_X6_FETCH_Y(mi)                                                                   \
+  {                                                                                            \
+    const f32x4* __restrict__ y1s_ = reinterpret_cast<const f32x4*>(y1 + (mi) * Y1);          \
     _Pragma("unroll") for (int k = 0; k < 4; ++k)                                              \
       py1[k] = y1s_[min(tid + k * X6_THREADS, Y1 / 4 - 1)];                                    \
   }
-#define RLPYT_X6_STAGE()                                                                       \
-  {                                                                                            \
-    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                            \
-      if (tid + k * X6_THREADS < F2 / 4) {                                                     \
-        float v_[4];                                                                           \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = py2[k][e] > 0.f ? pg[k][e] : 0.f; \
-        bsum[k] += (v_[0] + v_[1]) + (v_[2] + v_[3]);                                          \
-        uint32_t p_[3][2];                                                                     \
-        split3_rn(v_[0], v_[1], p_[0][0], p_[1][0], p_[2][0]);                                 \
-        split3_rn(v_[2], v_[3], p_[0][1], p_[1][1], p_[2][1]);                                 \
-        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                       \
-          *reinterpret_cast<uint2*>(g0 + s_ * X6_G0_PB + gdst[k]) = uint2{p_[s_][0], p_[s_][1]}; \
-      }                                                                                        \
-    }                                                                                          \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
-      if (tid + k * X6_THREADS < Y1 / 4) {                                                     \
-        uint32_t p_[3][2];                                                                     \
-        split3_rn(py1[k][0], py1[k][1], p_[0][0], p_[1][0], p_[2][0]);                         \
-        split3_rn(py1[k][2], py1[k][3], p_[0][1], p_[1][1], p_[2][1]);                         \
-        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                       \
-          *reinterpret_cast<uint2*>(y1p + s_ * X6_YPB + ydst[k]) = uint2{p_[s_][0], p_[s_][1]}; \
-      }                                                                                        \
+#define RLPYT_X6_STAGE_G()                                                                     \
+  _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                              \
+    if (tid + k * X6_THREADS < F2 / 4) {                                                       \
+      float v_[4];                                                                             \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = py2[k][e] > 0.f ? pg[k][e] : 0.f;  \
+      bsum[k] += (v_[0] + v_[1]) + (v_[2] + v_[3]);                                            \
+      uint32_t p_[3][2];                                                                       \
+      split3_rn(v_[0], v_[1], p_[0][0], p_[1][0], p_[2][0]);                                   \
+      split3_rn(v_[2], v_[3], p_[0][1], p_[1][1], p_[2][1]);                                   \
+      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
+        *reinterpret_cast<uint2*>(g0 + s_ * X6_G0_PB + gdst[k]) = uint2{p_[s_][0], p_[s_][1]}; \
     }                                                                                          \
   }
-  // gm2 [co][pos] -> [pos][co]: group-blocks of 4 co x 16 positions, 3 pieces x 7 x 8 = 168 of them
+#define RLPYT_X6_STAGE_Y(buf_)                                                                 \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                              \
+    if (tid + k * X6_THREADS < Y1 / 4) {                                                       \
+      uint32_t p_[3][2];                                                                       \
+      split3_rn(py1[k][0], py1[k][1], p_[0][0], p_[1][0], p_[2][0]);                           \
+      split3_rn(py1[k][2], py1[k][3], p_[0][1], p_[1][1], p_[2][1]);                           \
+      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
+        *reinterpret_cast<uint2*>(y1p + (buf_) * (3 * X6_YPB) + s_ * X6_YPB + ydst[k]) =       \
+            uint2{p_[s_][0], p_[s_][1]};                                                       \
+    }                                                                                          \
+  }
+  // gm2 [co][pos] -> [pos][co]: group-blocks of 4 co x 16 positions, 3 pieces x 7 x 8 = 168 of them,
+  // 4 per wave-level transpose read: blocks wave * 4 + (lane >> 4) + 32 it.  The addresses do not
+  // depend on the image (hoisted), and all reads of a wave are in flight before its first write
+  // (one read -> wait -> write chain per block measured 1400-1900 cycles per image).
+  int tsrc[6], tdst[6];
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int blk = min(wave * 4 + (lane >> 4) + 32 * it, 167);
+    const int pc = blk / 56, rem = blk - pc * 56, pb = rem >> 3, cq = rem & 7, s_ = lane & 15;
+    tsrc[it] = pc * X6_G0_PB + (4 * cq + (s_ >> 2)) * X6_G0_ROWB + (16 * pb + 4 * (s_ & 3)) * 2;
+    tdst[it] = pc * X6_GT_PB + (16 * pb + s_) * X6_GT_ROWB + cq * 8;
+  }
+  const bool t5 = wave * 4 + (lane >> 4) + 160 < 168;      // the sixth round: 8 blocks only
 #define RLPYT_X6_TRANSPOSE()                                                                   \
-  for (int blk = wave * 4 + (lane >> 4); blk < 168; blk += 32) {                               \
-    const int pc_ = blk / 56, rem_ = blk - pc_ * 56, pb_ = rem_ >> 3, cq_ = rem_ & 7;          \
-    const int s_ = lane & 15;                                                                  \
-    const uint2 v_ = lds_tr16(g0 + pc_ * X6_G0_PB + (4 * cq_ + (s_ >> 2)) * X6_G0_ROWB +       \
-                              (16 * pb_ + 4 * (s_ & 3)) * 2);                                  \
-    *reinterpret_cast<uint2*>(gt + pc_ * X6_GT_PB + (16 * pb_ + s_) * X6_GT_ROWB + cq_ * 8) = v_; \
+  {                                                                                            \
+    uint2 v_[6];                                                                               \
+    _Pragma("unroll") for (int it = 0; it < 5; ++it) v_[it] = lds_tr16(g0 + tsrc[it]);         \
+    if (t5) v_[5] = lds_tr16(g0 + tsrc[5]);                                                    \
+    _Pragma("unroll") for (int it = 0; it < 5; ++it)                                           \
+      *reinterpret_cast<uint2*>(gt + tdst[it]) = v_[it];                                       \
+    if (t5) *reinterpret_cast<uint2*>(gt + tdst[5]) = v_[5];                                   \
   }
   // six products, smallest first (a2 b0, a0 b2, a1 b1, a1 b0, a0 b1, a0 b0)
 // ... for TWO output tiles that share the A operand, interleaved: two independent accumulator
@@ -1636,8 +1652,20 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
   RLPYT_X6_PAIR(MF_, acc0_, acc1_, a_, b0_, b1_, 0, 1)                                         \
   RLPYT_X6_PAIR(MF_, acc0_, acc1_, a_, b0_, b1_, 0, 0)
 
-  if ((int64_t)blockIdx.x < M) RLPYT_X6_PREFETCH((int64_t)blockIdx.x)
+  // pipeline: gm2 of image m is staged (and transposed) at the top of iteration m; y1 of image m + 1
+  // is staged INTO THE OTHER PLANE BUFFER during the compute phase of image m -- by the wgrad waves
+  // before their MFMAs and by the dgrad waves after theirs, so that on every SIMD one wave's split /
+  // LDS-write work runs under its partner's MFMAs.  Rows travel in registers one image (gm2) / two
+  // images (y1) ahead of their use.
+  if ((int64_t)blockIdx.x < M) {
+    RLPYT_X6_FETCH_G((int64_t)blockIdx.x)
+    RLPYT_X6_FETCH_Y((int64_t)blockIdx.x)
+  }
   __syncthreads();                                   // zero fill + table done
+  if ((int64_t)blockIdx.x < M) {
+    RLPYT_X6_STAGE_Y(0)
+    if ((int64_t)blockIdx.x + gridDim.x < M) RLPYT_X6_FETCH_Y((int64_t)blockIdx.x + gridDim.x)
+  }
 
   if (wave < 4) {
     // =========================== dgrad role: parity class q ================================
@@ -1661,16 +1689,22 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     }
     const int4* tab = reinterpret_cast<const int4*>(dtab) + q * X6_TABP + n;
     const uint8_t* gtb = gt + 16 * kq;
-    const uint8_t* ymk = y1p + 8 * kq;
-    for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
-      RLPYT_X6_STAGE()
+    int cur = 0;
+    RL_T0()
+    for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
+      RLPYT_X6_STAGE_G()
       const bool more = m + gridDim.x < M;
-      if (more) RLPYT_X6_PREFETCH(m + gridDim.x)
-      __syncthreads();                               // G0 / y1 pieces complete
+      if (more) RLPYT_X6_FETCH_G(m + gridDim.x)
+      RL_T(0)
+      __syncthreads();                               // G0 (and the y1 planes of image m) complete
+      RL_T(1)
       RLPYT_X6_TRANSPOSE()
+      RL_T(2)
       __syncthreads();                               // GT complete
+      RL_T(3)
+      const uint8_t* ymk = y1p + cur * (3 * X6_YPB) + 8 * kq;
       float* dyimg = dy1 + m * Y1 + 4 * kq;
-      // two tiles per trip (an odd last tile is done twice: same values to the same addresses);
+      // two tiles per trip (an odd last tile alone, its products split over the two chains);
       // the B operands of the next tap -- after the last tap: of the next pair's first tap -- and
       // the mask words are requested BEFORE the 12 MFMAs that hide them
 #define RLPYT_X6_DOFF(e_, dd_)                                                                 \
@@ -1688,6 +1722,7 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
         const int4 n0 = tab[16 * min(2 * u + 2, ntile - 1)], n1 = tab[16 * min(2 * u + 3, ntile - 1)];
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         uint2 mk0[3], mk1[3];
+        const bool pair = 2 * u + 1 < ntile;     // (wave-uniform) the odd last tile of classes 0 / 3
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) {
           if (dd < 3) {
@@ -1701,28 +1736,49 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
             }
           }
           __builtin_amdgcn_sched_barrier(0);
-          RLPYT_X6_SIX2(mfma_bf16, acc0, acc1, wa[dd], bc[0], bc[1])
+          if (pair) {
+            RLPYT_X6_SIX2(mfma_bf16, acc0, acc1, wa[dd], bc[0], bc[1])
+          } else {
+            // a single tile: its six products alternate between the two accumulators (summed below)
+            acc0 = mfma_bf16(wa[dd][2], bc[0][0], acc0);  acc1 = mfma_bf16(wa[dd][0], bc[0][2], acc1);
+            asm volatile("" : "+v"(acc0), "+v"(acc1));
+            acc0 = mfma_bf16(wa[dd][1], bc[0][1], acc0);  acc1 = mfma_bf16(wa[dd][1], bc[0][0], acc1);
+            asm volatile("" : "+v"(acc0), "+v"(acc1));
+            acc0 = mfma_bf16(wa[dd][0], bc[0][1], acc0);  acc1 = mfma_bf16(wa[dd][0], bc[0][0], acc1);
+            asm volatile("" : "+v"(acc0), "+v"(acc1));
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int s = 0; s < 3; ++s) { bc[0][s] = bn[0][s]; bc[1][s] = bn[1][s]; }
         }
+        if (!pair) acc0 += acc1;
         // ReLU mask of conv1: y1 > 0 <=> some piece of it is non-zero (y1 >= 0, the pieces sum to it)
         const uint32_t ma = mk0[0].x | mk0[1].x | mk0[2].x, mb = mk0[0].y | mk0[1].y | mk0[2].y;
         const uint32_t mc = mk1[0].x | mk1[1].x | mk1[2].x, md = mk1[0].y | mk1[1].y | mk1[2].y;
         f32x4 o0, o1;
         o0[0] = (ma & 0xffffu) ? acc0[0] : 0.f;  o0[1] = (ma >> 16) ? acc0[1] : 0.f;
         o0[2] = (mb & 0xffffu) ? acc0[2] : 0.f;  o0[3] = (mb >> 16) ? acc0[3] : 0.f;
-        o1[0] = (mc & 0xffffu) ? acc1[0] : 0.f;  o1[1] = (mc >> 16) ? acc1[1] : 0.f;
-        o1[2] = (md & 0xffffu) ? acc1[2] : 0.f;  o1[3] = (md >> 16) ? acc1[3] : 0.f;
         *reinterpret_cast<f32x4*>(dyimg + e0.w) = o0;
-        *reinterpret_cast<f32x4*>(dyimg + e1.w) = o1;
+        if (pair) {
+          o1[0] = (mc & 0xffffu) ? acc1[0] : 0.f;  o1[1] = (mc >> 16) ? acc1[1] : 0.f;
+          o1[2] = (md & 0xffffu) ? acc1[2] : 0.f;  o1[3] = (md >> 16) ? acc1[3] : 0.f;
+          *reinterpret_cast<f32x4*>(dyimg + e1.w) = o1;
+        }
         e0 = n0;
         e1 = n1;
       }
 #undef RLPYT_X6_DREAD
 #undef RLPYT_X6_DOFF
+      RL_T(4)
+      if (more) {                                    // y1 of the next image -> the other plane buffer
+        RLPYT_X6_STAGE_Y(cur ^ 1)
+        if (m + 2 * (int64_t)gridDim.x < M) RLPYT_X6_FETCH_Y(m + 2 * (int64_t)gridDim.x)
+      }
+      RL_T(6)
       __syncthreads();                               // LDS free for the next image
+      RL_T(5)
     }
+    RL_TOUT()
   } else {
     // =========================== wgrad role: column tiles 2 ww, 2 ww + 1 ===================
     const int ww = wave - 4;
@@ -1741,20 +1797,33 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
       }
     const uint8_t* ga = g0 + (lane & 31) * X6_G0_ROWB + 16 * h;
     // tile t: ky = t >> 1, kx = 2 (t & 1) + tsel
-    const uint8_t* yb0 = y1p + (((2 * ww) >> 1) * PW + 2 * ((2 * ww) & 1)) * 32;
-    const uint8_t* yb1 = y1p + (((2 * ww + 1) >> 1) * PW + 2 * ((2 * ww + 1) & 1)) * 32;
+    const uint8_t* yb0_ = y1p + (((2 * ww) >> 1) * PW + 2 * ((2 * ww) & 1)) * 32;
+    const uint8_t* yb1_ = y1p + (((2 * ww + 1) >> 1) * PW + 2 * ((2 * ww + 1) & 1)) * 32;
     f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
-      RLPYT_X6_STAGE()
+    int cur = 0;
+    RL_T0()
+    for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
+      RLPYT_X6_STAGE_G()
       const bool more = m + gridDim.x < M;
-      if (more) RLPYT_X6_PREFETCH(m + gridDim.x)
+      if (more) RLPYT_X6_FETCH_G(m + gridDim.x)
+      RL_T(0)
       __syncthreads();
+      RL_T(1)
       RLPYT_X6_TRANSPOSE()
+      RL_T(2)
       __syncthreads();
+      RL_T(3)
+      if (more) {                                    // y1 of the next image -> the other plane buffer
+        RLPYT_X6_STAGE_Y(cur ^ 1)
+        if (m + 2 * (int64_t)gridDim.x < M) RLPYT_X6_FETCH_Y(m + 2 * (int64_t)gridDim.x)
+      }
+      RL_T(6)
+      const uint8_t* yb0 = yb0_ + cur * (3 * X6_YPB);
+      const uint8_t* yb1 = yb1_ + cur * (3 * X6_YPB);
       // the 15 operand reads of slice sl + 1 are requested before the 12 MFMAs of slice sl
 #define RLPYT_X6_WREAD(a_, b0_, b1_, sl_)                                                      \
   _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) {                                           \
@@ -1778,8 +1847,11 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
         for (int p = 0; p < 3; ++p) { ac[p] = an[p]; bc0[p] = bn0[p]; bc1[p] = bn1[p]; }
       }
 #undef RLPYT_X6_WREAD
+      RL_T(4)
       __syncthreads();
+      RL_T(5)
     }
+    RL_TOUT()
     // partial weight gradient of this workgroup: dw2[co][c][ky][kx], co = row, (tap, c) = column
     float* prow = partial + (int64_t)blockIdx.x * PART2;
 #pragma unroll
@@ -1804,8 +1876,10 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
 #undef RLPYT_X6_SIX2
 #undef RLPYT_X6_PAIR
 #undef RLPYT_X6_TRANSPOSE
-#undef RLPYT_X6_STAGE
-#undef RLPYT_X6_PREFETCH
+#undef RLPYT_X6_STAGE_Y
+#undef RLPYT_X6_STAGE_G
+#undef RLPYT_X6_FETCH_Y
+#undef RLPYT_X6_FETCH_G
 }
 
 // out[e] = sum_g partial[g][e]; e < n.  Fixed order -> run-to-run deterministic.

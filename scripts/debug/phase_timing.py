@@ -1,5 +1,6 @@
 """Per-wave phase cycles of a persistent conv kernel (needs a -DRLPYT_TIMING build of conv.hip).
-usage: phase_timing.py conv1_wgrad|conv1_fwd|conv2_fwd|conv2_bwd  [n_waves]"""
+usage: phase_timing.py conv1_wgrad|conv1_fwd|conv2_fwd|conv2_bwd|conv2_bwd_x6  [n_waves]
+(conv2_bwd_x6 phases: 0 stage + prefetch issue, 1 barrier, 2 gm2 transpose, 3 barrier, 4 compute, 5 barrier)"""
 import ctypes
 import os
 import sys
@@ -33,6 +34,8 @@ calls = {
     "conv2_fwd": lambda: lib.rlpyt_atari_conv2_fwd_f32(ptr(y1), M, ptr(w2), ptr(b2), ptr(y2), stream()),
     "conv2_bwd": lambda: lib.rlpyt_atari_conv2_bwd_f32(ptr(g2), ptr(y2b), ptr(y1), M, ptr(w2), ptr(dy1o), ptr(ws),
                                                        ptr(dw2), ptr(db2), stream()),
+    "conv2_bwd_x6": lambda: lib.rlpyt_atari_conv2_bwd_x6_f32(ptr(g2), ptr(y2b), ptr(y1), M, ptr(w2), ptr(dy1o),
+                                                             ptr(ws), ptr(dw2), ptr(db2), stream()),
 }
 for _ in range(3):
     check(calls[which]())
