@@ -1555,29 +1555,34 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     e[3] = (iy * W1 + ix) * C1;
   }
 
-  // ---- staging maps (fixed per thread) and the registers the next image travels in -------------
-  // gm2: float4 i = tid + 512 k of [32 co][27 quads]; y1: float4 i = tid + 512 k of [475 pixels][4]
-  int gdst[2], ydst[4];
+  // ---- staging maps and the registers the next images travel in: the WGRAD waves do all of it ----
+  // (the dgrad waves carry 2.3-2.6x the matrix-pipe time: v_mfma_f32_16x16x32_bf16 runs at half the
+  // rate of the 32x32x16 form -- measured 37 cycles per MFMA on two chains -- so every cycle of
+  // staging they did was on the critical path while the wgrad waves waited ~3500 cycles per image).
+  // gm2: float4 i = wt + 256 k of [32 co][27 quads]; y1: float4 i = wt + 256 k of [475 pixels][4]
+  constexpr int X6_WT = X6_THREADS / 2, X6_NG = 4, X6_NY = 8;
+  const int wt = tid - X6_WT;                       // (negative in the dgrad waves: unused there)
+  int gdst[X6_NG], ydst[X6_NY];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int i = min(tid + k * X6_THREADS, F2 / 4 - 1);
+  for (int k = 0; k < X6_NG; ++k) {
+    const int i = min(max(wt, 0) + k * X6_WT, F2 / 4 - 1);
     const int co = i / (P2 / 4), q4 = i - co * (P2 / 4);
     gdst[k] = co * X6_G0_ROWB + q4 * 8;
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = min(tid + k * X6_THREADS, Y1 / 4 - 1);
+  for (int k = 0; k < X6_NY; ++k) {
+    const int i = min(max(wt, 0) + k * X6_WT, Y1 / 4 - 1);
     const int p = i >> 2, q = i & 3, iy = p / W1, ix = p - iy * W1;
     ydst[k] = ((iy + 1) * PW + ix + 1) * 32 + q * 8;
   }
-  f32x4 pg[2], py2[2], py1[4];
-  float bsum[2] = {0.f, 0.f};
+  f32x4 pg[X6_NG], py2[X6_NG], py1[X6_NY];
+  float bsum[X6_NG] = {0.f, 0.f, 0.f, 0.f};
 #define RLPYT_X6_FETCH_G(mi)                                                                   \
   {                                                                                            \
     const f32x4* __restrict__ gs_ = reinterpret_cast<const f32x4*>(g2 + (mi) * F2);            \
     const f32x4* __restrict__ ys_ = reinterpret_cast<const f32x4*>(y2 + (mi) * F2);            \
-    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                            \
-      const int i = min(tid + k * X6_THREADS, F2 / 4 - 1);                                     \
+    _Pragma("unroll") for (int k = 0; k < X6_NG; ++k) {                                        \
+      const int i = min(wt + k * X6_WT, F2 / 4 - 1);                                           \
       pg[k] = gs_[i];                                                                          \
       py2[k] = ys_[i];                                                                         \
     }                                                                                          \
@@ -1585,12 +1590,12 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
 #define RLPYT_X6_FETCH_Y(mi)                                                                   \
   {                                                                                            \
     const f32x4* __restrict__ y1s_ = reinterpret_cast<const f32x4*>(y1 + (mi) * Y1);          \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                              \
-      py1[k] = y1s_[min(tid + k * X6_THREADS, Y1 / 4 - 1)];                                    \
+    _Pragma("unroll") for (int k = 0; k < X6_NY; ++k)                                          \
+      py1[k] = y1s_[min(wt + k * X6_WT, Y1 / 4 - 1)];                                          \
   }
 #define RLPYT_X6_STAGE_G()                                                                     \
-  _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                              \
-    if (tid + k * X6_THREADS < F2 / 4) {                                                       \
+  _Pragma("unroll") for (int k = 0; k < X6_NG; ++k) {                                          \
+    if (wt + k * X6_WT < F2 / 4) {                                                             \
       float v_[4];                                                                             \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = py2[k][e] > 0.f ? pg[k][e] : 0.f;  \
       bsum[k] += (v_[0] + v_[1]) + (v_[2] + v_[3]);                                            \
@@ -1602,8 +1607,8 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     }                                                                                          \
   }
 #define RLPYT_X6_STAGE_Y(buf_)                                                                 \
-  _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                              \
-    if (tid + k * X6_THREADS < Y1 / 4) {                                                       \
+  _Pragma("unroll") for (int k = 0; k < X6_NY; ++k) {                                          \
+    if (wt + k * X6_WT < Y1 / 4) {                                                             \
       uint32_t p_[3][2];                                                                       \
       split3_rn(py1[k][0], py1[k][1], p_[0][0], p_[1][0], p_[2][0]);                           \
       split3_rn(py1[k][2], py1[k][3], p_[0][1], p_[1][1], p_[2][1]);                           \
@@ -1653,19 +1658,10 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
   RLPYT_X6_PAIR(MF_, acc0_, acc1_, a_, b0_, b1_, 0, 0)
 
   // pipeline: gm2 of image m is staged (and transposed) at the top of iteration m; y1 of image m + 1
-  // is staged INTO THE OTHER PLANE BUFFER during the compute phase of image m -- by the wgrad waves
-  // before their MFMAs and by the dgrad waves after theirs, so that on every SIMD one wave's split /
-  // LDS-write work runs under its partner's MFMAs.  Rows travel in registers one image (gm2) / two
-  // images (y1) ahead of their use.
-  if ((int64_t)blockIdx.x < M) {
-    RLPYT_X6_FETCH_G((int64_t)blockIdx.x)
-    RLPYT_X6_FETCH_Y((int64_t)blockIdx.x)
-  }
+  // is staged INTO THE OTHER PLANE BUFFER during the compute phase of image m, before the wgrad
+  // waves' own MFMAs -- i.e. under their SIMD partners' (the dgrad waves') MFMAs.  Rows travel in
+  // registers one image (gm2) / two images (y1) ahead of their use.
   __syncthreads();                                   // zero fill + table done
-  if ((int64_t)blockIdx.x < M) {
-    RLPYT_X6_STAGE_Y(0)
-    if ((int64_t)blockIdx.x + gridDim.x < M) RLPYT_X6_FETCH_Y((int64_t)blockIdx.x + gridDim.x)
-  }
 
   if (wave < 4) {
     // =========================== dgrad role: parity class q ================================
@@ -1692,9 +1688,6 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     int cur = 0;
     RL_T0()
     for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
-      RLPYT_X6_STAGE_G()
-      const bool more = m + gridDim.x < M;
-      if (more) RLPYT_X6_FETCH_G(m + gridDim.x)
       RL_T(0)
       __syncthreads();                               // G0 (and the y1 planes of image m) complete
       RL_T(1)
@@ -1718,7 +1711,11 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
       int4 e0 = tab[0], e1 = tab[16 * min(1, ntile - 1)];
       uint4 bc[2][3], bn[2][3];
       RLPYT_X6_DREAD(bc, e0, e1, 0)
+#ifdef X6_NO_DGRAD          // (debug builds: what the other role costs alone; results are then wrong)
+      for (int u = 0; u < 0; ++u) {
+#else
       for (int u = 0; u < npair; ++u) {
+#endif
         const int4 n0 = tab[16 * min(2 * u + 2, ntile - 1)], n1 = tab[16 * min(2 * u + 3, ntile - 1)];
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         uint2 mk0[3], mk1[3];
@@ -1770,11 +1767,6 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
 #undef RLPYT_X6_DREAD
 #undef RLPYT_X6_DOFF
       RL_T(4)
-      if (more) {                                    // y1 of the next image -> the other plane buffer
-        RLPYT_X6_STAGE_Y(cur ^ 1)
-        if (m + 2 * (int64_t)gridDim.x < M) RLPYT_X6_FETCH_Y(m + 2 * (int64_t)gridDim.x)
-      }
-      RL_T(6)
       __syncthreads();                               // LDS free for the next image
       RL_T(5)
     }
@@ -1804,6 +1796,12 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    if ((int64_t)blockIdx.x < M) {
+      RLPYT_X6_FETCH_G((int64_t)blockIdx.x)
+      RLPYT_X6_FETCH_Y((int64_t)blockIdx.x)
+      RLPYT_X6_STAGE_Y(0)
+      if ((int64_t)blockIdx.x + gridDim.x < M) RLPYT_X6_FETCH_Y((int64_t)blockIdx.x + gridDim.x)
+    }
     int cur = 0;
     RL_T0()
     for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
@@ -1837,8 +1835,13 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
   }
       uint4 ac[3], bc0[3], bc1[3], an[3], bn0[3], bn1[3];
       RLPYT_X6_WREAD(ac, bc0, bc1, 0)
+#ifdef X6_NO_WGRAD
+#pragma unroll
+      for (int sl = 0; sl < 0; ++sl) {
+#else
 #pragma unroll
       for (int sl = 0; sl < 7; ++sl) {
+#endif
         if (sl < 6) RLPYT_X6_WREAD(an, bn0, bn1, sl + 1)
         __builtin_amdgcn_sched_barrier(0);
         RLPYT_X6_SIX2(mfma32_bf16, acc[0], acc[1], ac, bc0, bc1)
@@ -1865,8 +1868,10 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     }
   }
   // bias gradient: this thread's masked g2 sums (fixed co per thread and k) -> per-co sums
-  bred[tid] = bsum[0];
-  bred[X6_THREADS + tid] = tid + X6_THREADS < F2 / 4 ? bsum[1] : 0.f;
+  if (wt >= 0) {
+#pragma unroll
+    for (int k = 0; k < X6_NG; ++k) bred[wt + k * X6_WT] = wt + k * X6_WT < F2 / 4 ? bsum[k] : 0.f;
+  }
   __syncthreads();
   if (tid < C2) {
     float v = 0.f;

@@ -514,7 +514,18 @@ def test_conv_kernels_run_to_run_identical_at_update_size(ops):
                                             ptr(dw2), ptr(db2), stream()))
         check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs), ptr(idx), T, B, M, ptr(dy1), 1. / 255, ptr(ws),
                                               ptr(dw1), ptr(db1), stream()))
+        # the bf16x6 conv2 backward on the same inputs (32 images per persistent workgroup: its
+        # double-buffered planes and register pipelines in steady state)
+        dy1x = torch.empty_like(y1)
+        dw2x, db2x = torch.empty_like(w2), torch.empty_like(b2)
+        check(lib.rlpyt_atari_conv2_bwd_x6_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1x), ptr(ws),
+                                               ptr(dw2x), ptr(db2x), stream()))
+        if it == 0:      # the two conv2 backward kernels agree (f32 kernel = reference here)
+            _close(dy1x, dy1, rel=2e-5, what="conv2_bwd_x6 dy1 vs f32 kernel at M = 8192")
+            _close(dw2x, dw2, rel=2e-5, what="conv2_bwd_x6 dw2 vs f32 kernel at M = 8192")
+            _close(db2x, db2, rel=2e-5, what="conv2_bwd_x6 db2 vs f32 kernel at M = 8192")
         cur = dict(y1=y1, y2=y2, dy1=dy1, dw2=dw2, db2=db2, dw1=dw1, db1=db1, gemm=ops.gemm_nt(a, wt),
+                   dy1x=dy1x, dw2x=dw2x, db2x=db2x,
                    gemm_nn=ops.gemm_nn(g512, wt), gemm_tn=ops.gemm_tn(g512, a))
         torch.cuda.synchronize()
         if ref is None:
