@@ -1490,18 +1490,17 @@ __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
 //     26 x 20): staging is three 8-byte writes per float4, and the weight gradient's B operand
 //     B[k = position][n = (tap, channel)] -- eight consecutive positions per lane, i.e. pixels two
 //     apart with row wraps -- is two transpose reads per piece whose lanes point at the right pixels;
-//   * gm2 = g2 * (y2 > 0) is staged once as [co][position] (three 8-byte writes per float4; the A
-//     operand of the weight gradient reads it directly, K = position contiguous) and transposed
-//     LDS -> LDS into [position][co] for the data gradient (K = co contiguous) by 42 wave-level
-//     transpose reads + 8-byte writes per image.
+//   * gm2 = g2 * (y2 > 0) is staged in both orders by the thread that owns a 4 co x 4 position block
+//     of it: [co][position] (the A operand of the weight gradient, K = position contiguous) and,
+//     re-paired with v_perm, [position][co] (the data gradient's B operand, K = co contiguous).
 // Roles (waves w and w + 4 share a SIMD): waves 0-3 = dgrad of parity class q = w of the stride-2
 // transposed convolution (9 / 8 / 8 / 7 tiles of 16 pixels, 4 taps x 6 v_mfma_f32_16x16x32_bf16
 // each, the class's weights as 48 VGPRs of pieces, tile addressing from an LDS table, ReLU mask
 // from the y1 pieces, 16-byte stores); waves 4-7 = wgrad of two of the eight 32-column tiles
 // (32 co x (2 taps x 16 channels)), 7 K-slices of 16 positions x 6 v_mfma_f32_32x32x16_bf16 per tile,
 // accumulators in VGPRs across all images of the workgroup.  One persistent workgroup per CU;
-// y1 planes double-buffered (156 KB of LDS in all): gm2 stage -> barrier -> transpose -> barrier ->
-// compute + y1 staging of the next image -> barrier, rows in flight (registers) one / two images ahead.
+// y1 planes double-buffered (156 KB of LDS in all): gm2 stage -> barrier -> compute + y1 staging of
+// the next image -> barrier, rows in flight (registers) one / two images ahead.
 // ======================================================================================
 constexpr int X6_THREADS = 512;
 constexpr int X6_YPB = (PPIX + 1) * 32;      // bytes per piece of the y1 plane (+ 1 spare pixel)
@@ -1530,8 +1529,10 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
 
   for (int i = tid; i < 2 * 3 * X6_YPB / 16; i += X6_THREADS)
     reinterpret_cast<uint4*>(y1p)[i] = uint4{0u, 0u, 0u, 0u};          // borders stay zero
-  for (int i = tid; i < 3 * X6_G0_PB / 16; i += X6_THREADS)
+  for (int i = tid; i < 3 * X6_G0_PB / 16; i += X6_THREADS) {
     reinterpret_cast<uint4*>(g0)[i] = uint4{0u, 0u, 0u, 0u};           // positions 108..111 stay zero
+    reinterpret_cast<uint4*>(gt)[i] = uint4{0u, 0u, 0u, 0u};           // (same size: 112 x 32 x 2 B)
+  }
   // dgrad tile table: entry (class q, pixel slot p) = {GT byte offsets of taps 0 | 1 << 16,
   // taps 2 | 3 << 16 (position 108 = a zero row where a tap falls outside), byte offset of the pixel
   // in a y1 piece plane, float offset of the pixel in dy1}; slots past the last pixel repeat it
@@ -1559,16 +1560,15 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
   // (the dgrad waves carry 2.3-2.6x the matrix-pipe time: v_mfma_f32_16x16x32_bf16 runs at half the
   // rate of the 32x32x16 form -- measured 37 cycles per MFMA on two chains -- so every cycle of
   // staging they did was on the critical path while the wgrad waves waited ~3500 cycles per image).
-  // gm2: float4 i = wt + 256 k of [32 co][27 quads]; y1: float4 i = wt + 256 k of [475 pixels][4]
+  // y1: float4 i = wt + 256 k of [475 pixels][4]
   constexpr int X6_WT = X6_THREADS / 2, X6_NG = 4, X6_NY = 8;
   const int wt = tid - X6_WT;                       // (negative in the dgrad waves: unused there)
-  int gdst[X6_NG], ydst[X6_NY];
-#pragma unroll
-  for (int k = 0; k < X6_NG; ++k) {
-    const int i = min(max(wt, 0) + k * X6_WT, F2 / 4 - 1);
-    const int co = i / (P2 / 4), q4 = i - co * (P2 / 4);
-    gdst[k] = co * X6_G0_ROWB + q4 * 8;
-  }
+  // gm2: thread wt < 216 owns the block (4 co: 4 cq .. + 3) x (4 positions: 4 pq .. + 3) -- four
+  // float4 of g2 and of y2 -- and writes it in BOTH orders: [co][pos] (rows of 4 positions) and
+  // [pos][co] (rows of 4 co, re-paired with v_perm), so no LDS -> LDS transpose pass is needed
+  const int gtask = min(max(wt, 0), 215), gcq = gtask / (P2 / 4), gpq = gtask - gcq * (P2 / 4);
+  const int g0dst = 4 * gcq * X6_G0_ROWB + gpq * 8, gtdst = 4 * gpq * X6_GT_ROWB + gcq * 8;
+  int ydst[X6_NY];
 #pragma unroll
   for (int k = 0; k < X6_NY; ++k) {
     const int i = min(max(wt, 0) + k * X6_WT, Y1 / 4 - 1);
@@ -1581,10 +1581,10 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
   {                                                                                            \
     const f32x4* __restrict__ gs_ = reinterpret_cast<const f32x4*>(g2 + (mi) * F2);            \
     const f32x4* __restrict__ ys_ = reinterpret_cast<const f32x4*>(y2 + (mi) * F2);            \
-    _Pragma("unroll") for (int k = 0; k < X6_NG; ++k) {                                        \
-      const int i = min(wt + k * X6_WT, F2 / 4 - 1);                                           \
-      pg[k] = gs_[i];                                                                          \
-      py2[k] = ys_[i];                                                                         \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                            \
+      const int i = (4 * gcq + c) * (P2 / 4) + gpq;                                            \
+      pg[c] = gs_[i];                                                                          \
+      py2[c] = ys_[i];                                                                         \
     }                                                                                          \
   }
 #define RLPYT_X6_FETCH_Y(mi)                                                                   \
@@ -1594,16 +1594,24 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
       py1[k] = y1s_[min(wt + k * X6_WT, Y1 / 4 - 1)];                                          \
   }
 #define RLPYT_X6_STAGE_G()                                                                     \
-  _Pragma("unroll") for (int k = 0; k < X6_NG; ++k) {                                          \
-    if (wt + k * X6_WT < F2 / 4) {                                                             \
+  if (wt < 216) {                                                                              \
+    uint32_t p_[3][4][2];                              /* [piece][co][position pair] */        \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                            \
       float v_[4];                                                                             \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = py2[k][e] > 0.f ? pg[k][e] : 0.f;  \
-      bsum[k] += (v_[0] + v_[1]) + (v_[2] + v_[3]);                                            \
-      uint32_t p_[3][2];                                                                       \
-      split3_rn(v_[0], v_[1], p_[0][0], p_[1][0], p_[2][0]);                                   \
-      split3_rn(v_[2], v_[3], p_[0][1], p_[1][1], p_[2][1]);                                   \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = py2[c][e] > 0.f ? pg[c][e] : 0.f;  \
+      bsum[c] += (v_[0] + v_[1]) + (v_[2] + v_[3]);                                            \
+      split3_rn(v_[0], v_[1], p_[0][c][0], p_[1][c][0], p_[2][c][0]);                          \
+      split3_rn(v_[2], v_[3], p_[0][c][1], p_[1][c][1], p_[2][c][1]);                          \
       _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
-        *reinterpret_cast<uint2*>(g0 + s_ * X6_G0_PB + gdst[k]) = uint2{p_[s_][0], p_[s_][1]}; \
+        *reinterpret_cast<uint2*>(g0 + s_ * X6_G0_PB + g0dst + c * X6_G0_ROWB) =               \
+            uint2{p_[s_][c][0], p_[s_][c][1]};                                                 \
+    }                                                                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                           \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+      const uint32_t sel_ = (e & 1) ? 0x07060302u : 0x05040100u;   /* high / low halves */     \
+      *reinterpret_cast<uint2*>(gt + s_ * X6_GT_PB + gtdst + e * X6_GT_ROWB) =                 \
+          uint2{__builtin_amdgcn_perm(p_[s_][1][e >> 1], p_[s_][0][e >> 1], sel_),             \
+                __builtin_amdgcn_perm(p_[s_][3][e >> 1], p_[s_][2][e >> 1], sel_)};            \
     }                                                                                          \
   }
 #define RLPYT_X6_STAGE_Y(buf_)                                                                 \
@@ -1616,28 +1624,6 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
         *reinterpret_cast<uint2*>(y1p + (buf_) * (3 * X6_YPB) + s_ * X6_YPB + ydst[k]) =       \
             uint2{p_[s_][0], p_[s_][1]};                                                       \
     }                                                                                          \
-  }
-  // gm2 [co][pos] -> [pos][co]: group-blocks of 4 co x 16 positions, 3 pieces x 7 x 8 = 168 of them,
-  // 4 per wave-level transpose read: blocks wave * 4 + (lane >> 4) + 32 it.  The addresses do not
-  // depend on the image (hoisted), and all reads of a wave are in flight before its first write
-  // (one read -> wait -> write chain per block measured 1400-1900 cycles per image).
-  int tsrc[6], tdst[6];
-#pragma unroll
-  for (int it = 0; it < 6; ++it) {
-    const int blk = min(wave * 4 + (lane >> 4) + 32 * it, 167);
-    const int pc = blk / 56, rem = blk - pc * 56, pb = rem >> 3, cq = rem & 7, s_ = lane & 15;
-    tsrc[it] = pc * X6_G0_PB + (4 * cq + (s_ >> 2)) * X6_G0_ROWB + (16 * pb + 4 * (s_ & 3)) * 2;
-    tdst[it] = pc * X6_GT_PB + (16 * pb + s_) * X6_GT_ROWB + cq * 8;
-  }
-  const bool t5 = wave * 4 + (lane >> 4) + 160 < 168;      // the sixth round: 8 blocks only
-#define RLPYT_X6_TRANSPOSE()                                                                   \
-  {                                                                                            \
-    uint2 v_[6];                                                                               \
-    _Pragma("unroll") for (int it = 0; it < 5; ++it) v_[it] = lds_tr16(g0 + tsrc[it]);         \
-    if (t5) v_[5] = lds_tr16(g0 + tsrc[5]);                                                    \
-    _Pragma("unroll") for (int it = 0; it < 5; ++it)                                           \
-      *reinterpret_cast<uint2*>(gt + tdst[it]) = v_[it];                                       \
-    if (t5) *reinterpret_cast<uint2*>(gt + tdst[5]) = v_[5];                                   \
   }
   // six products, smallest first (a2 b0, a0 b2, a1 b1, a1 b0, a0 b1, a0 b0)
 // ... for TWO output tiles that share the A operand, interleaved: two independent accumulator
@@ -1689,12 +1675,8 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     RL_T0()
     for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
       RL_T(0)
-      __syncthreads();                               // G0 (and the y1 planes of image m) complete
+      __syncthreads();                               // gm2 in both orders (and the y1 planes of image m) complete
       RL_T(1)
-      RLPYT_X6_TRANSPOSE()
-      RL_T(2)
-      __syncthreads();                               // GT complete
-      RL_T(3)
       const uint8_t* ymk = y1p + cur * (3 * X6_YPB) + 8 * kq;
       float* dyimg = dy1 + m * Y1 + 4 * kq;
       // two tiles per trip (an odd last tile alone, its products split over the two chains);
@@ -1811,10 +1793,6 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
       RL_T(0)
       __syncthreads();
       RL_T(1)
-      RLPYT_X6_TRANSPOSE()
-      RL_T(2)
-      __syncthreads();
-      RL_T(3)
       if (more) {                                    // y1 of the next image -> the other plane buffer
         RLPYT_X6_STAGE_Y(cur ^ 1)
         if (m + 2 * (int64_t)gridDim.x < M) RLPYT_X6_FETCH_Y(m + 2 * (int64_t)gridDim.x)
@@ -1868,9 +1846,9 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     }
   }
   // bias gradient: this thread's masked g2 sums (fixed co per thread and k) -> per-co sums
-  if (wt >= 0) {
+  if (wt >= 0 && wt < 216) {
 #pragma unroll
-    for (int k = 0; k < X6_NG; ++k) bred[wt + k * X6_WT] = wt + k * X6_WT < F2 / 4 ? bsum[k] : 0.f;
+    for (int c = 0; c < 4; ++c) bred[(4 * gcq + c) * (P2 / 4) + gpq] = bsum[c];
   }
   __syncthreads();
   if (tid < C2) {
@@ -1880,7 +1858,6 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
   }
 #undef RLPYT_X6_SIX2
 #undef RLPYT_X6_PAIR
-#undef RLPYT_X6_TRANSPOSE
 #undef RLPYT_X6_STAGE_Y
 #undef RLPYT_X6_STAGE_G
 #undef RLPYT_X6_FETCH_Y
