@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
 //     26 x 20): staging is three 8-byte writes per float4, and the weight gradient's B operand
 //     B[k = position][n = (tap, channel)] -- eight consecutive positions per lane, i.e. pixels two
 //     apart with row wraps -- is two transpose reads per piece whose lanes point at the right pixels;
-//   * gm2 = g2 * (y2 > 0) is staged in both orders by the thread that owns a 4 co x 4 position block
+//   * gm2 = g2 * (y2 > 0) is staged in both orders by the thread that owns a 2 co x 4 position block
 //     of it: [co][position] (the A operand of the weight gradient, K = position contiguous) and,
 //     re-paired with v_perm, [position][co] (the data gradient's B operand, K = co contiguous).
 // Roles (waves w and w + 4 share a SIMD): waves 0-3 = dgrad of parity class q = w of the stride-2
@@ -1556,18 +1556,24 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     e[3] = (iy * W1 + ix) * C1;
   }
 
-  // ---- staging maps and the registers the next images travel in: the WGRAD waves do all of it ----
+  // ---- staging maps and the registers the next images travel in: the WGRAD waves stage y1 --------
   // (the dgrad waves carry 2.3-2.6x the matrix-pipe time: v_mfma_f32_16x16x32_bf16 runs at half the
   // rate of the 32x32x16 form -- measured 37 cycles per MFMA on two chains -- so every cycle of
   // staging they did was on the critical path while the wgrad waves waited ~3500 cycles per image).
   // y1: float4 i = wt + 256 k of [475 pixels][4]
-  constexpr int X6_WT = X6_THREADS / 2, X6_NG = 4, X6_NY = 8;
+  constexpr int X6_WT = X6_THREADS / 2, X6_NY = 8;
   const int wt = tid - X6_WT;                       // (negative in the dgrad waves: unused there)
-  // gm2: thread wt < 216 owns the block (4 co: 4 cq .. + 3) x (4 positions: 4 pq .. + 3) -- four
-  // float4 of g2 and of y2 -- and writes it in BOTH orders: [co][pos] (rows of 4 positions) and
-  // [pos][co] (rows of 4 co, re-paired with v_perm), so no LDS -> LDS transpose pass is needed
-  const int gtask = min(max(wt, 0), 215), gcq = gtask / (P2 / 4), gpq = gtask - gcq * (P2 / 4);
-  const int g0dst = 4 * gcq * X6_G0_ROWB + gpq * 8, gtdst = 4 * gpq * X6_GT_ROWB + gcq * 8;
+  // gm2: EVERY thread (448 of the 512) owns a block (2 co: 2 gcp, + 1) x (4 positions: 4 gpq .. + 3)
+  // -- two float4 of g2 and of y2 -- and writes it in BOTH orders: [co][pos] (rows of 4 positions,
+  // 8 bytes) and [pos][co] (2 co re-paired with v_perm, 4 bytes), so no LDS -> LDS transpose pass
+  // is needed.  Task -> lane map: a 16-lane group = 4 co-pairs x 4 position-quads (with consecutive
+  // lanes on consecutive position quads the [pos][co] writes were 256 B apart: 16-way bank
+  // conflicts, 3000 cycles per image).  All eight waves share this part: the data gradient cannot
+  // start before it is done.
+  const int gl = tid & 15, gg = tid >> 4;
+  const int gcp = (gl & 3) + 4 * (gg & 3), gpq = min(((gl >> 2) & 3) + 4 * (gg >> 2), P2 / 4 - 1);
+  const bool gok = ((gl >> 2) & 3) + 4 * (gg >> 2) < P2 / 4;
+  const int g0dst = 2 * gcp * X6_G0_ROWB + gpq * 8, gtdst = 4 * gpq * X6_GT_ROWB + gcp * 4;
   int ydst[X6_NY];
 #pragma unroll
   for (int k = 0; k < X6_NY; ++k) {
@@ -1575,14 +1581,14 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     const int p = i >> 2, q = i & 3, iy = p / W1, ix = p - iy * W1;
     ydst[k] = ((iy + 1) * PW + ix + 1) * 32 + q * 8;
   }
-  f32x4 pg[X6_NG], py2[X6_NG], py1[X6_NY];
-  float bsum[X6_NG] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 pg[2], py2[2], py1[X6_NY];
+  float bsum[2] = {0.f, 0.f};
 #define RLPYT_X6_FETCH_G(mi)                                                                   \
   {                                                                                            \
     const f32x4* __restrict__ gs_ = reinterpret_cast<const f32x4*>(g2 + (mi) * F2);            \
     const f32x4* __restrict__ ys_ = reinterpret_cast<const f32x4*>(y2 + (mi) * F2);            \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                            \
-      const int i = (4 * gcq + c) * (P2 / 4) + gpq;                                            \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                            \
+      const int i = (2 * gcp + c) * (P2 / 4) + gpq;                                            \
       pg[c] = gs_[i];                                                                          \
       py2[c] = ys_[i];                                                                         \
     }                                                                                          \
@@ -1594,9 +1600,9 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
       py1[k] = y1s_[min(wt + k * X6_WT, Y1 / 4 - 1)];                                          \
   }
 #define RLPYT_X6_STAGE_G()                                                                     \
-  if (wt < 216) {                                                                              \
-    uint32_t p_[3][4][2];                              /* [piece][co][position pair] */        \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                            \
+  if (gok) {                                                                                   \
+    uint32_t p_[3][2][2];                              /* [piece][co][position pair] */        \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                            \
       float v_[4];                                                                             \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = py2[c][e] > 0.f ? pg[c][e] : 0.f;  \
       bsum[c] += (v_[0] + v_[1]) + (v_[2] + v_[3]);                                            \
@@ -1607,12 +1613,10 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
             uint2{p_[s_][c][0], p_[s_][c][1]};                                                 \
     }                                                                                          \
     _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                           \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
-      const uint32_t sel_ = (e & 1) ? 0x07060302u : 0x05040100u;   /* high / low halves */     \
-      *reinterpret_cast<uint2*>(gt + s_ * X6_GT_PB + gtdst + e * X6_GT_ROWB) =                 \
-          uint2{__builtin_amdgcn_perm(p_[s_][1][e >> 1], p_[s_][0][e >> 1], sel_),             \
-                __builtin_amdgcn_perm(p_[s_][3][e >> 1], p_[s_][2][e >> 1], sel_)};            \
-    }                                                                                          \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                              \
+      *reinterpret_cast<uint32_t*>(gt + s_ * X6_GT_PB + gtdst + e * X6_GT_ROWB) =              \
+          __builtin_amdgcn_perm(p_[s_][1][e >> 1], p_[s_][0][e >> 1],                          \
+                                (e & 1) ? 0x07060302u : 0x05040100u);    /* high / low halves */ \
   }
 #define RLPYT_X6_STAGE_Y(buf_)                                                                 \
   _Pragma("unroll") for (int k = 0; k < X6_NY; ++k) {                                          \
@@ -1647,6 +1651,7 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
   // is staged INTO THE OTHER PLANE BUFFER during the compute phase of image m, before the wgrad
   // waves' own MFMAs -- i.e. under their SIMD partners' (the dgrad waves') MFMAs.  Rows travel in
   // registers one image (gm2) / two images (y1) ahead of their use.
+  if ((int64_t)blockIdx.x < M) RLPYT_X6_FETCH_G((int64_t)blockIdx.x)
   __syncthreads();                                   // zero fill + table done
 
   if (wave < 4) {
@@ -1674,6 +1679,9 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     int cur = 0;
     RL_T0()
     for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
+      RLPYT_X6_STAGE_G()
+      const bool more = m + gridDim.x < M;
+      if (more) RLPYT_X6_FETCH_G(m + gridDim.x)
       RL_T(0)
       __syncthreads();                               // gm2 in both orders (and the y1 planes of image m) complete
       RL_T(1)
@@ -1779,7 +1787,6 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     if ((int64_t)blockIdx.x < M) {
-      RLPYT_X6_FETCH_G((int64_t)blockIdx.x)
       RLPYT_X6_FETCH_Y((int64_t)blockIdx.x)
       RLPYT_X6_STAGE_Y(0)
       if ((int64_t)blockIdx.x + gridDim.x < M) RLPYT_X6_FETCH_Y((int64_t)blockIdx.x + gridDim.x)
@@ -1846,9 +1853,9 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     }
   }
   // bias gradient: this thread's masked g2 sums (fixed co per thread and k) -> per-co sums
-  if (wt >= 0 && wt < 216) {
+  if (gok) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bred[(4 * gcq + c) * (P2 / 4) + gpq] = bsum[c];
+    for (int c = 0; c < 2; ++c) bred[(2 * gcp + c) * (P2 / 4) + gpq] = bsum[c];
   }
   __syncthreads();
   if (tid < C2) {
