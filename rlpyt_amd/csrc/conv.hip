@@ -1493,21 +1493,25 @@ __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
 //   * gm2 = g2 * (y2 > 0) is staged in both orders by the thread that owns a 2 co x 4 position block
 //     of it: [co][position] (the A operand of the weight gradient, K = position contiguous) and,
 //     re-paired with v_perm, [position][co] (the data gradient's B operand, K = co contiguous).
-// Roles (waves w and w + 4 share a SIMD): waves 0-3 = dgrad of parity class q = w of the stride-2
-// transposed convolution (9 / 8 / 8 / 7 tiles of 16 pixels, 4 taps x 6 v_mfma_f32_16x16x32_bf16
-// each, the class's weights as 48 VGPRs of pieces, tile addressing from an LDS table, ReLU mask
-// from the y1 pieces, 16-byte stores); waves 4-7 = wgrad of two of the eight 32-column tiles
+// Roles (waves w and w + 4 share a SIMD): waves 0-3 = dgrad.  The four parity classes of the stride-2
+// transposed convolution read the SAME gm2 rows (positions (i' - dy, j' - dx) of the 2 x 2 taps), so
+// two classes are the 32 rows of a v_mfma_f32_32x32x16_bf16 against tiles of 32 positions: 9 tiles of
+// 8 K-steps x 6 MFMAs per image, 2.5 / 2.5 / 2 / 2 per wave (one class per v_mfma_f32_16x16x32_bf16 -- the
+// first version -- ran at half the matrix-pipe rate: 37 cycles per 8 K MACs), the pair's weights as
+// 96 VGPRs of pieces, tile addressing in registers, ReLU mask from the first y1 piece, 16-byte
+// stores; waves 4-7 = wgrad of two of the eight 32-column tiles
 // (32 co x (2 taps x 16 channels)), 7 K-slices of 16 positions x 6 v_mfma_f32_32x32x16_bf16 per tile,
 // accumulators in VGPRs across all images of the workgroup.  One persistent workgroup per CU;
-// y1 planes double-buffered (156 KB of LDS in all): gm2 stage -> barrier -> compute + y1 staging of
+// y1 planes double-buffered (149 KB of LDS in all): gm2 stage -> barrier -> compute + y1 staging of
 // the next image -> barrier, rows in flight (registers) one / two images ahead.
 // ======================================================================================
 constexpr int X6_THREADS = 512;
 constexpr int X6_YPB = (PPIX + 1) * 32;      // bytes per piece of the y1 plane (+ 1 spare pixel)
 constexpr int X6_GP = 112;                   // positions padded to 7 K-slices of 16
 constexpr int X6_G0_ROWB = X6_GP * 2, X6_G0_PB = C2 * X6_G0_ROWB;     // [co][pos]: 224 B rows
-constexpr int X6_GT_ROWB = C2 * 2, X6_GT_PB = X6_GP * X6_GT_ROWB;     // [pos][co]: 64 B rows
-constexpr int X6_TABP = 144;                 // pixel slots per class in the dgrad tile table
+constexpr int X6_GT_ROWB = C2 * 2 + 16, X6_GT_PB = X6_GP * X6_GT_ROWB;  // [pos][co]: 64 B rows + 16 B pad
+// (rows 80 B apart: the 16 rows a ds_read_b128 group touches, and the 4 + 4 rows of a staging write, fall on
+// all 32 banks twice -- 64 B rows put them on 8 / 16 banks)
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 lds_tr16(const uint8_t* p) {
@@ -1521,41 +1525,20 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     const float* __restrict__ w2, float* __restrict__ dy1, float* __restrict__ partial, int64_t M) {
   __shared__ __attribute__((aligned(16))) uint8_t y1p[2 * 3 * X6_YPB];   // 2 x 50,016 B
   __shared__ __attribute__((aligned(16))) uint8_t g0[3 * X6_G0_PB];      // 21,504 B
-  __shared__ __attribute__((aligned(16))) uint8_t gt[3 * X6_GT_PB];      // 21,504 B
-  __shared__ __attribute__((aligned(16))) int dtab[4 * X6_TABP * 4];     //  9,216 B
+  __shared__ __attribute__((aligned(16))) uint8_t gt[3 * X6_GT_PB];      // 26,880 B
   __shared__ float bred[2 * X6_THREADS];
+  __shared__ __attribute__((aligned(16))) float xch[4 * 16];   // wave 1 -> wave 0: half sums of the fifth tile
+  __shared__ int xflag;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+  if (tid == 0) xflag = -1;
   for (int i = tid; i < 2 * 3 * X6_YPB / 16; i += X6_THREADS)
     reinterpret_cast<uint4*>(y1p)[i] = uint4{0u, 0u, 0u, 0u};          // borders stay zero
-  for (int i = tid; i < 3 * X6_G0_PB / 16; i += X6_THREADS) {
+  for (int i = tid; i < 3 * X6_G0_PB / 16; i += X6_THREADS)
     reinterpret_cast<uint4*>(g0)[i] = uint4{0u, 0u, 0u, 0u};           // positions 108..111 stay zero
-    reinterpret_cast<uint4*>(gt)[i] = uint4{0u, 0u, 0u, 0u};           // (same size: 112 x 32 x 2 B)
-  }
-  // dgrad tile table: entry (class q, pixel slot p) = {GT byte offsets of taps 0 | 1 << 16,
-  // taps 2 | 3 << 16 (position 108 = a zero row where a tap falls outside), byte offset of the pixel
-  // in a y1 piece plane, float offset of the pixel in dy1}; slots past the last pixel repeat it
-  for (int i = tid; i < 4 * X6_TABP; i += X6_THREADS) {
-    const int cq = i / X6_TABP, p = i - cq * X6_TABP;
-    const int py = cq >> 1, px = cq & 1;
-    const int nb = px ? 9 : 10, npx = (py ? 12 : 13) * nb;
-    const int pc = min(p, npx - 1);
-    const int a = pc / nb, b = pc - a * nb;
-    const int iy = 2 * a + py, ix = 2 * b + px;
-    int off[4];
-    for (int dd = 0; dd < 4; ++dd) {
-      const int oy = a + py - (dd >> 1), ox = b + px - (dd & 1);
-      const bool v = (oy >= 0) && (oy < H2) && (ox >= 0) && (ox < W2);
-      off[dd] = (v ? oy * W2 + ox : P2) * X6_GT_ROWB;
-    }
-    int* e = dtab + i * 4;
-    e[0] = off[0] | (off[1] << 16);
-    e[1] = off[2] | (off[3] << 16);
-    e[2] = ((iy + 1) * PW + ix + 1) * 32;
-    e[3] = (iy * W1 + ix) * C1;
-  }
-
+  for (int i = tid; i < 3 * X6_GT_PB / 16; i += X6_THREADS)
+    reinterpret_cast<uint4*>(gt)[i] = uint4{0u, 0u, 0u, 0u};
   // ---- staging maps and the registers the next images travel in: the WGRAD waves stage y1 --------
   // (the dgrad waves carry 2.3-2.6x the matrix-pipe time: v_mfma_f32_16x16x32_bf16 runs at half the
   // rate of the 32x32x16 form -- measured 37 cycles per MFMA on two chains -- so every cycle of
@@ -1593,6 +1576,18 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
       py2[c] = ys_[i];                                                                         \
     }                                                                                          \
   }
+// ... one request at a time: in the main loops the rows of the next images are requested BETWEEN the
+// MFMA groups.  A wave issues in order, and the CU's vector-memory queue takes the 58 KB an image
+// needs only at the rate HBM delivers them (~10 B per cycle and CU: 5-6 K cycles) -- a burst of 12
+// load instructions in front of a wave's MFMAs held those MFMAs back for that long.
+#define RLPYT_X6_LOAD_G(mi, j_)                                                                \
+  {                                                                                            \
+    const int i_ = (2 * gcp + ((j_) >> 1)) * (P2 / 4) + gpq;                                   \
+    if ((j_) & 1) py2[(j_) >> 1] = reinterpret_cast<const f32x4*>(y2 + (mi) * F2)[i_];         \
+    else          pg[(j_) >> 1] = reinterpret_cast<const f32x4*>(g2 + (mi) * F2)[i_];          \
+  }
+#define RLPYT_X6_LOAD_Y(mi, k_)                                                                \
+  py1[k_] = reinterpret_cast<const f32x4*>(y1 + (mi) * Y1)[min(wt + (k_) * X6_WT, Y1 / 4 - 1)];
 #define RLPYT_X6_FETCH_Y(mi)                                                                   \
   {                                                                                            \
     const f32x4* __restrict__ y1s_ = reinterpret_cast<const f32x4*>(y1 + (mi) * Y1);          \
@@ -1655,115 +1650,205 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
   __syncthreads();                                   // zero fill + table done
 
   if (wave < 4) {
-    // =========================== dgrad role: parity class q ================================
-    const int q = wave, py = q >> 1, px = q & 1;
-    const int nb = px ? 9 : 10, ntile = ((py ? 12 : 13) * nb + 15) >> 4, npair = (ntile + 1) >> 1;
-    const int n = lane & 15, kq = lane >> 4;
-    // A = w2 of the class's four taps: lane (row c = n, k = co 8 kq .. + 7), three pieces each
-    uint4 wa[4][3];
+    // ============ dgrad role: class pair py = wave >> 1, pixel tiles of its half ==============
+    // dy1[(2 i' - py, 2 j' - px)][c] = sum over taps (dy, dx) and co of
+    //     gm2[(i' - dy, j' - dx)][co] * w2[co][c][1 - py + 2 dy][1 - px + 2 dx]:
+    // the B operand (positions i' 0..12 [from 1 for py = 1], j' 0..9 -> columns, K = (tap, co)) is
+    // the SAME for the two classes px = 0 | 1, so the two classes are the 32 rows of a
+    // v_mfma_f32_32x32x16_bf16 (16 channels each) -- the 16x16x32 form a single class fills runs at
+    // half the rate (measured 37 cycles for 8 K MACs against 32 for 16 K).  Tiles of 32 positions:
+    // 130 -> 5 for py = 0 (the fifth holds 2 positions), 120 -> 4 for py = 1; waves 0 | 1 take tiles
+    // {0, 1} | {2, 3} of py = 0 and each half of the K-steps of the fifth, waves 2 | 3 tiles {0, 1} |
+    // {2, 3} of py = 1.  8 K-steps (4 taps x
+    // 2 halves of co) x 6 products per tile, two tiles (two accumulator chains) per trip.
+    const int py = wave >> 1, part = wave & 1;
+#ifdef X6_DPRIO
+    __builtin_amdgcn_s_setprio(X6_DPRIO);
+#endif
+    const int n = lane & 31, hh = lane >> 5;
+    const int npos = py ? 120 : 130;
+    // A = w2: row n = (px = n >> 4, c = n & 15), k = co 16 ks + 8 hh .. + 7; three pieces each
+    uint4 wa[4][2][3];
 #pragma unroll
-    for (int dd = 0; dd < 4; ++dd) {
-      const int ky = 1 - py + 2 * (dd >> 1), kx = 1 - px + 2 * (dd & 1);
-      uint32_t p[3][4];
+    for (int dd = 0; dd < 4; ++dd)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int co = 8 * kq + 2 * e;
-        split3_rn(w2[co * 256 + n * 16 + ky * 4 + kx], w2[(co + 1) * 256 + n * 16 + ky * 4 + kx],
-                  p[0][e], p[1][e], p[2][e]);
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ky = 1 - py + 2 * (dd >> 1), kx = 1 - (n >> 4) + 2 * (dd & 1);
+        uint32_t p[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = 16 * ks + 8 * hh + 2 * e;
+          split3_rn(w2[co * 256 + (n & 15) * 16 + ky * 4 + kx],
+                    w2[(co + 1) * 256 + (n & 15) * 16 + ky * 4 + kx], p[0][e], p[1][e], p[2][e]);
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) wa[dd][ks][s] = uint4{p[s][0], p[s][1], p[s][2], p[s][3]};
       }
+    // per tile k (0, 1: the pair; 2: wave 0's third): GT byte offset of each tap's position (108 = a
+    // zero row where the tap falls outside), the px = 0 pixel's offsets in a y1 piece plane / in dy1
+    int boff[3][4], yo[3], dof[3];
+    bool va[3], vb[3];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) wa[dd][s] = uint4{p[s][0], p[s][1], p[s][2], p[s][3]};
+    for (int k = 0; k < 3; ++k) {
+      const int p = 32 * (k < 2 ? 2 * part + k : 4) + n;
+      const bool ok = p < npos;
+      const int pc = min(p, npos - 1), ii = pc / 10 + py, jj = pc - (pc / 10) * 10;
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {
+        const int oy = ii - (dd >> 1), ox = jj - (dd & 1);
+        const bool v = ok && (oy >= 0) && (oy < H2) && (ox >= 0) && (ox < W2);
+        boff[k][dd] = (v ? oy * W2 + ox : P2) * X6_GT_ROWB + 16 * hh;
+      }
+      const int iy = 2 * ii - py, ix = 2 * jj;
+      va[k] = ok;
+      vb[k] = ok && (jj >= 1);                       // px = 1: pixel (iy, ix - 1)
+      yo[k] = ((iy + 1) * PW + ix + 1) * 32 + 8 * hh;
+      dof[k] = (iy * W1 + ix) * C1 + 4 * hh;
     }
-    const int4* tab = reinterpret_cast<const int4*>(dtab) + q * X6_TABP + n;
-    const uint8_t* gtb = gt + 16 * kq;
-    int cur = 0;
+    int cur = 0, it = 0;
+    uint32_t dsink = 0;
     RL_T0()
-    for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
+    for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1, ++it) {
       RLPYT_X6_STAGE_G()
-      const bool more = m + gridDim.x < M;
-      if (more) RLPYT_X6_FETCH_G(m + gridDim.x)
+      // (past the last image: this one again -- no branches around the requests, so the compiler's
+      // vmcnt bookkeeping stays exact)
+      const int64_t mg = m + gridDim.x < M ? m + gridDim.x : m;
       RL_T(0)
       __syncthreads();                               // gm2 in both orders (and the y1 planes of image m) complete
       RL_T(1)
-      const uint8_t* ymk = y1p + cur * (3 * X6_YPB) + 8 * kq;
-      float* dyimg = dy1 + m * Y1 + 4 * kq;
-      // two tiles per trip (an odd last tile alone, its products split over the two chains);
-      // the B operands of the next tap -- after the last tap: of the next pair's first tap -- and
-      // the mask words are requested BEFORE the 12 MFMAs that hide them
-#define RLPYT_X6_DOFF(e_, dd_)                                                                 \
-  ((dd_) == 0 ? ((e_).x & 0xffff) : (dd_) == 1 ? (int)((unsigned)(e_).x >> 16)                 \
-   : (dd_) == 2 ? ((e_).y & 0xffff) : (int)((unsigned)(e_).y >> 16))
-#define RLPYT_X6_DREAD(dst_, e0_, e1_, dd_)                                                    \
-  _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                           \
-    dst_[0][s_] = *reinterpret_cast<const uint4*>(gtb + s_ * X6_GT_PB + RLPYT_X6_DOFF(e0_, dd_)); \
-    dst_[1][s_] = *reinterpret_cast<const uint4*>(gtb + s_ * X6_GT_PB + RLPYT_X6_DOFF(e1_, dd_)); \
-  }
-      int4 e0 = tab[0], e1 = tab[16 * min(1, ntile - 1)];
-      uint4 bc[2][3], bn[2][3];
-      RLPYT_X6_DREAD(bc, e0, e1, 0)
-#ifdef X6_NO_DGRAD          // (debug builds: what the other role costs alone; results are then wrong)
-      for (int u = 0; u < 0; ++u) {
+      // (tried and dropped: an L2 prefetch from these waves -- one dword of every 128-byte line of the rows
+      // of images m + 2 / m + 3.  It took the y1 staging wait from 5.7 K to 1.8 K cycles per image, but
+      // the compute phases of BOTH roles grew by more, 11.3 K -> 13.1 K per image in all: the CU's
+      // memory pipe is busy, not merely late.)
+      const uint8_t* ymk = y1p + cur * (3 * X6_YPB);   // piece 0 alone decides y1 > 0 (it is the
+      float* dyimg = dy1 + m * Y1;                     // nearest bf16: zero only if y1 rounds to zero)
+#define RLPYT_X6_DREAD(dst_, k_, st_)                                                          \
+  _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                             \
+    dst_[s_] = *reinterpret_cast<const uint4*>(gt + s_ * X6_GT_PB + boff[k_][(st_) >> 1] +     \
+                                               32 * ((st_) & 1));
+#define RLPYT_X6_DMASK(mk_, k_)                                                                \
+  mk_[0] = *reinterpret_cast<const uint2*>(ymk + yo[k_]);                                      \
+  mk_[1] = *reinterpret_cast<const uint2*>(ymk + yo[k_] + 16);                                 \
+  mk_[2] = *reinterpret_cast<const uint2*>(ymk + yo[k_] - 32);                                 \
+  mk_[3] = *reinterpret_cast<const uint2*>(ymk + yo[k_] - 16);
+      // D rows r -> (px = r >> 3, c = (r & 3) + 8 ((r >> 2) & 1) + 4 hh): four 16-byte stores
+#ifdef X6_NO_STORE         // (debug builds: the data gradient computed but not written)
+#define X6_STORE_OK(v_) ((v_) == 1.2345e33f)
 #else
-      for (int u = 0; u < npair; ++u) {
+#define X6_STORE_OK(v_) true
 #endif
-        const int4 n0 = tab[16 * min(2 * u + 2, ntile - 1)], n1 = tab[16 * min(2 * u + 3, ntile - 1)];
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        uint2 mk0[3], mk1[3];
-        const bool pair = 2 * u + 1 < ntile;     // (wave-uniform) the odd last tile of classes 0 / 3
+#define RLPYT_X6_DSTORE(acc_, mk_, k_)                                                         \
+  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                           \
+    if (X6_STORE_OK(acc_[4 * j_]) && (j_ < 2 ? va[k_] : vb[k_])) {                             \
+      f32x4 o_;                                                                                \
+      o_[0] = (mk_[j_].x & 0xffffu) ? acc_[4 * j_ + 0] : 0.f;                                  \
+      o_[1] = (mk_[j_].x >> 16) ? acc_[4 * j_ + 1] : 0.f;                                      \
+      o_[2] = (mk_[j_].y & 0xffffu) ? acc_[4 * j_ + 2] : 0.f;                                  \
+      o_[3] = (mk_[j_].y >> 16) ? acc_[4 * j_ + 3] : 0.f;                                      \
+      *reinterpret_cast<f32x4*>(dyimg + dof[k_] + (j_ & 1) * 8 - (j_ >> 1) * C1) = o_;         \
+    }                                                                                          \
+  }
+      uint4 bc[2][3], bn[2][3];
+      uint2 mk0[4], mk1[4];
+      f32x16 acc0, acc1;
+      // half of the fifth tile of py = 0 (2 positions; K-steps ST0_ .. + 3 = two taps): the six
+      // products alternate between the two accumulators (one chain alone runs at half rate)
+#define RLPYT_X6_HALF(ST0_)                                                                    \
+  {                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }           \
+    RLPYT_X6_DREAD(bc[0], 2, ST0_)                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                         \
+      if (i_ < 3) RLPYT_X6_DREAD(bn[0], 2, (ST0_) + i_ + 1)                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+      const uint4* w_ = wa[((ST0_) + i_) >> 1][((ST0_) + i_) & 1];                             \
+      acc0 = mfma32_bf16(w_[2], bc[0][0], acc0);  acc1 = mfma32_bf16(w_[0], bc[0][2], acc1);   \
+      asm volatile("" : "+v"(acc0), "+v"(acc1));                                               \
+      acc0 = mfma32_bf16(w_[1], bc[0][1], acc0);  acc1 = mfma32_bf16(w_[1], bc[0][0], acc1);   \
+      asm volatile("" : "+v"(acc0), "+v"(acc1));                                               \
+      acc0 = mfma32_bf16(w_[0], bc[0][1], acc0);  acc1 = mfma32_bf16(w_[0], bc[0][0], acc1);   \
+      asm volatile("" : "+v"(acc0), "+v"(acc1));                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) bc[0][s_] = bn[0][s_];                  \
+    }                                                                                          \
+    acc0 += acc1;                                                                              \
+  }
+#ifndef X6_NO_DGRAD         // (debug builds: what the other role costs alone; results are then wrong)
+      if (wave == 1) {
+        // taps 2, 3 of the fifth tile FIRST; the sum goes to wave 0 through LDS
+        RLPYT_X6_HALF(4)
+        if (va[2]) {
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-          if (dd < 3) {
-            RLPYT_X6_DREAD(bn, e0, e1, dd + 1)
-          } else {
-            RLPYT_X6_DREAD(bn, n0, n1, 0)
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-              mk0[s] = *reinterpret_cast<const uint2*>(ymk + s * X6_YPB + e0.z);
-              mk1[s] = *reinterpret_cast<const uint2*>(ymk + s * X6_YPB + e1.z);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (pair) {
-            RLPYT_X6_SIX2(mfma_bf16, acc0, acc1, wa[dd], bc[0], bc[1])
-          } else {
-            // a single tile: its six products alternate between the two accumulators (summed below)
-            acc0 = mfma_bf16(wa[dd][2], bc[0][0], acc0);  acc1 = mfma_bf16(wa[dd][0], bc[0][2], acc1);
-            asm volatile("" : "+v"(acc0), "+v"(acc1));
-            acc0 = mfma_bf16(wa[dd][1], bc[0][1], acc0);  acc1 = mfma_bf16(wa[dd][1], bc[0][0], acc1);
-            asm volatile("" : "+v"(acc0), "+v"(acc1));
-            acc0 = mfma_bf16(wa[dd][0], bc[0][1], acc0);  acc1 = mfma_bf16(wa[dd][0], bc[0][0], acc1);
-            asm volatile("" : "+v"(acc0), "+v"(acc1));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int s = 0; s < 3; ++s) { bc[0][s] = bn[0][s]; bc[1][s] = bn[1][s]; }
+          for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(xch + (n + 2 * hh) * 16 + 4 * j) =
+                f32x4{acc0[4 * j], acc0[4 * j + 1], acc0[4 * j + 2], acc0[4 * j + 3]};
         }
-        if (!pair) acc0 += acc1;
-        // ReLU mask of conv1: y1 > 0 <=> some piece of it is non-zero (y1 >= 0, the pieces sum to it)
-        const uint32_t ma = mk0[0].x | mk0[1].x | mk0[2].x, mb = mk0[0].y | mk0[1].y | mk0[2].y;
-        const uint32_t mc = mk1[0].x | mk1[1].x | mk1[2].x, md = mk1[0].y | mk1[1].y | mk1[2].y;
-        f32x4 o0, o1;
-        o0[0] = (ma & 0xffffu) ? acc0[0] : 0.f;  o0[1] = (ma >> 16) ? acc0[1] : 0.f;
-        o0[2] = (mb & 0xffffu) ? acc0[2] : 0.f;  o0[3] = (mb >> 16) ? acc0[3] : 0.f;
-        *reinterpret_cast<f32x4*>(dyimg + e0.w) = o0;
-        if (pair) {
-          o1[0] = (mc & 0xffffu) ? acc1[0] : 0.f;  o1[1] = (mc >> 16) ? acc1[1] : 0.f;
-          o1[2] = (md & 0xffffu) ? acc1[2] : 0.f;  o1[3] = (md >> 16) ? acc1[3] : 0.f;
-          *reinterpret_cast<f32x4*>(dyimg + e1.w) = o1;
-        }
-        e0 = n0;
-        e1 = n1;
+        __hip_atomic_store(&xflag, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+#endif
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      RLPYT_X6_DREAD(bc[0], 0, 0)
+      RLPYT_X6_DREAD(bc[1], 1, 0)
+#ifndef X6_NO_DGRAD         // (debug builds: what the other role costs alone; results are then wrong)
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        // the B operands of the next K-step (after the last: the mask words)
+        // are requested BEFORE the 12 MFMAs that hide them
+        if (st < 4) RLPYT_X6_LOAD_G(mg, st)         // gm2 rows of the next image, one request per step
+        if (st < 7) {
+          RLPYT_X6_DREAD(bn[0], 0, st + 1)
+          RLPYT_X6_DREAD(bn[1], 1, st + 1)
+        } else {
+          RLPYT_X6_DMASK(mk0, 0)
+          RLPYT_X6_DMASK(mk1, 1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        RLPYT_X6_SIX2(mfma32_bf16, acc0, acc1, wa[st >> 1][st & 1], bc[0], bc[1])
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { bc[0][s] = bn[0][s]; bc[1][s] = bn[1][s]; }
+      }
+      RLPYT_X6_DSTORE(acc0, mk0, 0)
+      RLPYT_X6_DSTORE(acc1, mk1, 1)
+      if (wave == 0) {
+        // ... and taps 0, 1 of the fifth tile LAST: wave 1 left the other half of its sum in LDS
+        // (flagged, not barrier-ordered: wave 1 wrote it thousands of cycles ago)
+        RLPYT_X6_HALF(0)
+        RLPYT_X6_DMASK(mk0, 2)
+        while (__hip_atomic_load(&xflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != it)
+          __builtin_amdgcn_s_sleep(1);
+        if (va[2]) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(xch + (n + 2 * hh) * 16 + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc0[4 * j + e] += o[e];
+          }
+        }
+        RLPYT_X6_DSTORE(acc0, mk0, 2)
+      }
+#endif
+#undef RLPYT_X6_DSTORE
+#undef X6_STORE_OK
+#ifdef X6_NO_DGRAD         // (keeps the staging alive in the staging-only debug build)
+      RLPYT_X6_FETCH_G(mg)
+      dsink += reinterpret_cast<const uint32_t*>(gt)[tid] + reinterpret_cast<const uint32_t*>(ymk)[tid * 3];
+#endif
+#undef RLPYT_X6_HALF
+#undef RLPYT_X6_DMASK
 #undef RLPYT_X6_DREAD
-#undef RLPYT_X6_DOFF
       RL_T(4)
       __syncthreads();                               // LDS free for the next image
       RL_T(5)
     }
     RL_TOUT()
+    if (dsink == 0x12345u) partial[tid] = 1.f;       // (never; dsink stays 0 in product builds)
   } else {
     // =========================== wgrad role: column tiles 2 ww, 2 ww + 1 ===================
     const int ww = wave - 4;
+#ifdef X6_WPRIO
+    __builtin_amdgcn_s_setprio(X6_WPRIO);
+#endif
     const int s = lane & 15, tsel = (lane >> 4) & 1, h = lane >> 5;
     // per-lane source addresses of the transpose reads: (K-slice, 4-position half r) -> pixel base
     // (2 oy, 2 ox) of position 16 sl + 8 h + 4 r + (s >> 2) [positions >= 108: any valid pixel, the
@@ -1796,14 +1881,12 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
       RLPYT_X6_STAGE_G()
       const bool more = m + gridDim.x < M;
-      if (more) RLPYT_X6_FETCH_G(m + gridDim.x)
       RL_T(0)
       __syncthreads();
       RL_T(1)
-      if (more) {                                    // y1 of the next image -> the other plane buffer
-        RLPYT_X6_STAGE_Y(cur ^ 1)
-        if (m + 2 * (int64_t)gridDim.x < M) RLPYT_X6_FETCH_Y(m + 2 * (int64_t)gridDim.x)
-      }
+      if (more) RLPYT_X6_STAGE_Y(cur ^ 1)            // y1 of the next image -> the other plane buffer
+      const int64_t mg = more ? m + gridDim.x : m;
+      const int64_t my = m + 2 * (int64_t)gridDim.x < M ? m + 2 * (int64_t)gridDim.x : m;
       RL_T(6)
       const uint8_t* yb0 = yb0_ + cur * (3 * X6_YPB);
       const uint8_t* yb1 = yb1_ + cur * (3 * X6_YPB);
@@ -1827,6 +1910,14 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
 #pragma unroll
       for (int sl = 0; sl < 7; ++sl) {
 #endif
+        // rows of the next images: two requests per slice (gm2 of image m + 1, then y1 of m + 2)
+        if (sl < 2) {
+          RLPYT_X6_LOAD_G(mg, 2 * sl)
+          RLPYT_X6_LOAD_G(mg, 2 * sl + 1)
+        } else if (sl < 6) {
+          RLPYT_X6_LOAD_Y(my, 2 * sl - 4)
+          RLPYT_X6_LOAD_Y(my, 2 * sl - 3)
+        }
         if (sl < 6) RLPYT_X6_WREAD(an, bn0, bn1, sl + 1)
         __builtin_amdgcn_sched_barrier(0);
         RLPYT_X6_SIX2(mfma32_bf16, acc[0], acc[1], ac, bc0, bc1)
@@ -1835,6 +1926,13 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
         for (int p = 0; p < 3; ++p) { ac[p] = an[p]; bc0[p] = bn0[p]; bc1[p] = bn1[p]; }
       }
 #undef RLPYT_X6_WREAD
+#ifdef X6_NO_WGRAD
+      RLPYT_X6_FETCH_G(mg)
+      RLPYT_X6_FETCH_Y(my)
+      acc[0][0] += __uint_as_float(reinterpret_cast<const uint32_t*>(g0)[wt] & 0x3fffffffu) +
+                   __uint_as_float(reinterpret_cast<const uint32_t*>(yb0)[wt * 3 + 1000] & 0x3fffffffu) +
+                   __uint_as_float(reinterpret_cast<const uint32_t*>(yb0 + 2 * X6_YPB)[wt * 3 + 1000] & 0x3fffffffu);
+#endif
       RL_T(4)
       __syncthreads();
       RL_T(5)
@@ -1869,6 +1967,8 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
 #undef RLPYT_X6_STAGE_G
 #undef RLPYT_X6_FETCH_Y
 #undef RLPYT_X6_FETCH_G
+#undef RLPYT_X6_LOAD_Y
+#undef RLPYT_X6_LOAD_G
 }
 
 // out[e] = sum_g partial[g][e]; e < n.  Fixed order -> run-to-run deterministic.
