@@ -58,6 +58,8 @@ KERNEL_NAMES = {
     "conv2_fwd": "conv2_fwd_x6_kernel (conv 16->32 k4 s2 p1 + bias + ReLU; bf16x6 split, f32 "
                  "accumulate, dropped terms <= 2^-24, 2^-27 rms)",
     "conv2_bwd": "conv2_bwd_kernel (dgrad + ReLU masks + weight/bias grad in one pass, fp32 MFMA)",
+    "conv2_bwd_x6": "conv2_bwd_x6_kernel (dgrad + ReLU masks + weight/bias grad in one pass over the "
+                    "images; bf16x6 split of both operands of both contractions, f32 accumulate)",
     "conv2_dgrad": "conv2_dgrad_kernel (transposed conv + ReLU masks, fp32 MFMA)",
     "conv2_wgrad": "conv2_wgrad_kernel (+ bias grad, fp32 MFMA)",
     "conv1_wgrad": "conv1_wgrad_kernel (gather + u8->bf16 + weight/bias grad; exact bf16x3 split "
@@ -403,14 +405,19 @@ def main():
         if ksum:
             # dominant own kernel of the timed region = largest total HIP-event time
             name, g = max(ksum.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])
-            if name in BF16_SPLIT:
-                # fp32 contraction issued as BF16_SPLIT[name] bf16 MFMAs per algorithmic MAC: priced
+            from rlpyt_amd import ops as _ops
+            conv2_bwd_x6 = bool(getattr(_ops, "CONV2_BWD_X6", False))
+            split = dict(BF16_SPLIT, **({"conv2_bwd": 6} if conv2_bwd_x6 else {}))
+            names = dict(KERNEL_NAMES, **({"conv2_bwd": KERNEL_NAMES["conv2_bwd_x6"]}
+                                          if conv2_bwd_x6 else {}))
+            if name in split:
+                # fp32 contraction issued as split[name] bf16 MFMAs per algorithmic MAC: priced
                 # against BOTH ceilings, "bound" = the one it sits closer to
-                issued = g["TFLOPs"] * BF16_SPLIT[name]
+                issued = g["TFLOPs"] * split[name]
                 f_hbm, f_mfma = g["GBps"] / HBM_PEAK_GBPS, issued / BF16_MFMA_PEAK_TFLOPS
                 hbm = f_hbm >= f_mfma
-                nx = BF16_SPLIT[name]
-                out["roofline"] = {"kernel": KERNEL_NAMES.get(name, name),
+                nx = split[name]
+                out["roofline"] = {"kernel": names.get(name, name),
                                    "bound": "hbm" if hbm else "mfma",
                                    "achieved": g["GBps"] if hbm else issued,
                                    "peak": HBM_PEAK_GBPS if hbm else BF16_MFMA_PEAK_TFLOPS,
@@ -428,7 +435,7 @@ def main():
                                    "alg_flops_per_launch": g["alg_flops_per_launch"],
                                    "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
             elif "TFLOPs" in g:   # dense f32 contraction: priced against the fp32 MFMA peak
-                out["roofline"] = {"kernel": KERNEL_NAMES.get(name, name), "bound": "mfma",
+                out["roofline"] = {"kernel": names.get(name, name), "bound": "mfma",
                                    "achieved": g["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": g["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
                                    "traffic": None, "avg_us": g["avg_us"],
@@ -436,20 +443,37 @@ def main():
                                    "alg_flops_per_launch": g["alg_flops_per_launch"],
                                    "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
             else:
-                out["roofline"] = {"kernel": KERNEL_NAMES.get(name, name),
+                out["roofline"] = {"kernel": names.get(name, name),
                                    "bound": "hbm", "achieved": g["GBps"],
                                    "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                    "frac": g["GBps"] / HBM_PEAK_GBPS, "traffic": None,
                                    "avg_us": g["avg_us"], "launches": g["launches"],
                                    "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
             if name != "conv2_bwd" and "conv2_bwd" in ksum:
-                # the remaining f32-MFMA kernel, kept beside the dominant one
+                # the conv2 backward pass, kept beside the dominant
+                # kernel: bf16x6 since round 3 -- 88 KB of rows per image against 23 K bf16-MFMA
+                # cycles per CU, the HBM side is the nearer ceiling
                 gb = ksum["conv2_bwd"]
-                out["roofline_conv2_bwd"] = {
-                    "kernel": KERNEL_NAMES["conv2_bwd"], "bound": "mfma", "achieved": gb["TFLOPs"],
-                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": gb["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, "avg_us": gb["avg_us"],
-                    "launches": gb["launches"]}
+                if conv2_bwd_x6:
+                    f_hbm = gb["GBps"] / HBM_PEAK_GBPS
+                    f_mfma = gb["TFLOPs"] * 6 / BF16_MFMA_PEAK_TFLOPS
+                    out["roofline_conv2_bwd"] = {
+                        "kernel": KERNEL_NAMES["conv2_bwd_x6"],
+                        "bound": "hbm" if f_hbm >= f_mfma else "mfma",
+                        "achieved": gb["GBps"] if f_hbm >= f_mfma else gb["TFLOPs"] * 6,
+                        "peak": HBM_PEAK_GBPS if f_hbm >= f_mfma else BF16_MFMA_PEAK_TFLOPS,
+                        "unit": "GB/s" if f_hbm >= f_mfma else "TFLOP/s",
+                        "frac": max(f_hbm, f_mfma), "frac_hbm": f_hbm,
+                        "frac_of_bf16x6_ceiling": f_mfma, "alg_fp32_TFLOPs": gb["TFLOPs"],
+                        "alg_over_f32_mfma_peak": gb["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
+                        "avg_us": gb["avg_us"], "launches": gb["launches"],
+                        "alg_bytes_per_launch": gb["alg_bytes_per_launch"]}
+                else:
+                    out["roofline_conv2_bwd"] = {
+                        "kernel": KERNEL_NAMES["conv2_bwd"], "bound": "mfma",
+                        "achieved": gb["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": gb["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, "avg_us": gb["avg_us"],
+                        "launches": gb["launches"]}
             # HBM traffic of that kernel from the separate rocprofv3 --pmc passes (a PMC pass
             # cannot run inside this timed process); committed under profiles/
             traffic = pmc_traffic(name, g)

@@ -30,6 +30,7 @@ Buffer layout contract: ``action`` / ``prev_action`` are the 
 ``bootstrap_value`` is ``[1, B]``; ``done`` is bool; ``observation`` keeps the env dtype.
 ``env_info`` stays a host numpy buffer (only loggers read it).
 """
+import os
 import ctypes
 import multiprocessing as mp
 from collections import namedtuple
@@ -330,10 +331,26 @@ class EvalRunner:
         q.put(None)    # end sentinel of this worker
 
 
+def _die_with_parent():
+    """A worker waits for its next action set without a timeout; if the master is killed (a GPU
+    fault aborts the process, an OOM kill) nobody would ever wake it -- under rocprofv3, which waits
+    for every child, that hung the whole command.  Linux: have the kernel send SIGTERM to the
+    worker when its parent dies."""
+    try:
+        import signal
+        ppid = os.getppid()
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)   # PR_SET_PDEATHSIG
+        if os.getppid() != ppid:      # the parent died between fork and prctl
+            os._exit(1)
+    except Exception:  # noqa: BLE001  (not Linux: keep the reference's behaviour)
+        pass
+
+
 def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus, eval_runner=None):
     """Forked sampler worker (rlpyt/samplers/parallel/worker.py:37-101).  ``runners`` =
     [(group index, EnvRunner)]: this worker's environments, served in group order (with
     dedicated workers per pipeline group there is exactly one entry)."""
+    _die_with_parent()
     try:
         if cpus is not None:
             import psutil

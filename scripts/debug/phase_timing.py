@@ -1,6 +1,7 @@
 """Per-wave phase cycles of a persistent conv kernel (needs a -DRLPYT_TIMING build of conv.hip).
 usage: phase_timing.py conv1_wgrad|conv1_fwd|conv2_fwd|conv2_bwd|conv2_bwd_x6  [n_waves]
-(conv2_bwd_x6 phases: 0 stage + prefetch issue, 1 barrier, 2 gm2 transpose, 3 barrier, 4 compute, 5 barrier)"""
+(conv2_bwd_x6 phases: 0 gm2 staging, 1 barrier, 4 compute, 5 barrier, 6 y1 staging of the next image --
+ wgrad waves 4-7 only)"""
 import ctypes
 import os
 import sys

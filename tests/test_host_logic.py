@@ -5,6 +5,7 @@ driven on CPU tensors (serial and forked workers), and the runner loop.
 The product algorithms have no CPU path (their arithmetic is HIP-only), so the runner tests
 drive the loop with ``OraclePPO`` -- a TEST-ONLY subclass that swaps the two HIP touch
 points for the CPU oracle."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -570,3 +571,38 @@ def test_trunk_pre_activation_contract_on_cpu():
     assert lin is not None and lin.in_features == 3456 and lin.out_features == 512
     x, w = torch.randn(5, 64), torch.randn(32, 64)
     assert torch.equal(ops.linear_nobias(x, w), F.linear(x, w))   # CPU tensors: library path
+
+
+def test_sampler_worker_dies_with_its_parent():
+    """A forked worker waits for actions without a timeout; when the master process is killed the
+    kernel must take the worker down (``_die_with_parent``), or a crashed run leaves hung workers
+    behind (and hangs any launcher that waits for all children)."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    code = (
+        "import multiprocessing as mp, sys, time\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from rlpyt_amd.samplers.gpu import _die_with_parent\n"
+        "def child():\n"
+        "    _die_with_parent()\n"
+        "    time.sleep(120)\n"
+        "if __name__ == '__main__':\n"
+        "    p = mp.get_context('fork').Process(target=child); p.start()\n"
+        "    print(p.pid, flush=True)\n"
+        "    time.sleep(120)\n")
+    pr = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True)
+    pid = int(pr.stdout.readline())
+    os.kill(pr.pid, signal.SIGKILL)
+    pr.wait()
+    for _ in range(50):
+        try:
+            with open(f"/proc/{pid}/status") as f:
+                state = f.read().split("State:")[1].split()[0]
+        except (FileNotFoundError, ProcessLookupError):
+            state = "gone"
+        if state in ("gone", "Z", "X"):
+            break
+        time.sleep(0.1)
+    assert state in ("gone", "Z", "X"), f"worker {pid} still {state} after its parent was killed"
