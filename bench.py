@@ -479,7 +479,13 @@ def main():
             traffic = pmc_traffic(name, g)
             if traffic is not None:
                 out["roofline"]["traffic"] = traffic["bytes_per_launch"]
+                out["roofline"]["traffic_over_alg"] = traffic["traffic_over_alg"]
                 out["roofline"]["traffic_source"] = traffic["source"]
+            tb = pmc_traffic("conv2_bwd", ksum["conv2_bwd"]) if "roofline_conv2_bwd" in out else None
+            if tb is not None and conv2_bwd_x6:
+                out["roofline_conv2_bwd"]["traffic"] = tb["bytes_per_launch"]
+                out["roofline_conv2_bwd"]["traffic_over_alg"] = tb["traffic_over_alg"]
+                out["roofline_conv2_bwd"]["traffic_source"] = tb["source"]
             out["kernels"] = {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv)
                                   for kk, vv in v.items()} for k, v in ksum.items()}
         out["roofline_gae_scaled"] = gae_scaled_roofline()
@@ -531,19 +537,26 @@ def dry_run(args, rank, world, local_rank, cpus, workers, block):
 
 
 def pmc_traffic(name, g):
-    """HBM bytes per launch of kernel ``name`` from profiles/r2_conv_pmc_counters.json
-    ((2 * FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md), rescaled by algorithmic
-    bytes when the bench launch is not the profiled M = 8192 one."""
-    path = os.path.join(ROOT, "profiles", "r2_conv_pmc_counters.json")
-    try:
-        with open(path) as f:
-            k = json.load(f)["kernels"][name]
-    except (OSError, KeyError, ValueError):
-        return None
-    scale = g["alg_bytes_per_launch"] / k["alg_bytes"] if k.get("alg_bytes") else 1.
-    return {"bytes_per_launch": k["hbm_bytes_corrected"] * scale,
-            "source": "profiles/r2_conv_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / "
-                      "WRITE_SIZE passes over scripts/conv_bench.py / scripts/gemm_bench.py, M=8192)"}
+    """HBM bytes per launch of the kernel(s) of bench region ``name`` from the newest
+    profiles/r*pmc_counters.json that holds it ((2 * FETCH_SIZE + WRITE_SIZE) * 1024 per
+    MI355X_MICROARCH.md; scripts/pmc_update.sh), rescaled by algorithmic bytes when the bench
+    launch is not the profiled M = 8192 one."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_counters.json")), reverse=True):
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+            k = doc["kernels"][name]
+        except (OSError, KeyError, ValueError):
+            continue
+        scale = g["alg_bytes_per_launch"] / k["alg_bytes"] if k.get("alg_bytes") else 1.
+        rel = os.path.relpath(path, ROOT)
+        return {"bytes_per_launch": k["hbm_bytes_corrected"] * scale,
+                "traffic_over_alg": k.get("traffic_over_alg"),
+                "source": f"{rel} @ {doc.get('commit') or 'unstamped'} (rocprofv3 --pmc FETCH_SIZE / "
+                          "WRITE_SIZE passes over scripts/conv_bench.py / scripts/gemm_bench.py, "
+                          "M=8192; scripts/pmc_update.sh)"}
+    return None
 
 
 def gae_scaled_roofline(T=128, log2n=20, iters=20):
@@ -621,6 +634,13 @@ def isolated_functions(T, B):
     both("gae", lambda: ops.gae(r_d, v_d, d_d, bv_d, 0.99, 0.98),
          lambda: O.generalized_advantage_estimation(r_n, v_n, d_n, bv_n, 0.99, 0.98),
          shape=[T, B])
+    # the segmented variant (time axis split over lanes, affine-map composition: re-associated,
+    # within f32 rounding of the exact one) beside the exact scan the algorithms use
+    res["gae"]["hip_us_segmented"] = round(_hip_us(lambda: ops.gae(
+        r_d, v_d, d_d, bv_d, 0.99, 0.98, variant=ops.SCAN_SEGMENTED)), 2)
+    res["gae"]["note"] = ("hip_us = RLPYT_SCAN_EXACT (bit-exact with the reference's association; the "
+                          "product path), hip_us_segmented = RLPYT_SCAN_SEGMENTED; both latency-class "
+                          "at [128, 256] (0.56 MB)")
     both("discount_return", lambda: ops.discount_return(r_d, d_d, bv_d, 0.99),
          lambda: O.discount_return(r_n, d_n, bv_n, 0.99), shape=[T, B])
     both("valid_from_done", lambda: ops.valid_from_done(d_d), lambda: O.valid_from_done(d_n),
@@ -684,6 +704,16 @@ def isolated_functions(T, B):
                                "alg_bytes_per_launch": nb,
                                "achieved": nb / res["frames_gather"]["hip_us"] / 1e3,
                                "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+    # ... and what a DQN batch actually issues: the agent and the target stack in one launch
+    out_p = torch.empty((2, n, C, H, W), dtype=torch.uint8, device="cuda")
+    both("frames_gather_pair", lambda: ops.frames_gather_pair(f_d, fd_d, ti_d, bi_d, C, 1, out=out_p),
+         lambda: (O.frames_gather(f_n, fd_n, ti, bi, C), O.frames_gather(f_n, fd_n, ti + 1, bi, C)),
+         n=n)
+    replay["frames_gather_pair"] = {"bound": "hbm", "avg_us": res["frames_gather_pair"]["hip_us"],
+                                    "alg_bytes_per_launch": 2 * nb,
+                                    "achieved": 2 * nb / res["frames_gather_pair"]["hip_us"] / 1e3,
+                                    "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                    "note": "agent + n-step target observation of one batch"}
     ns, seq_T = 64, 125
     out_s = torch.empty((seq_T, ns, C, H, W), dtype=torch.uint8, device="cuda")
     both("frames_gather_seq",
@@ -695,7 +725,7 @@ def isolated_functions(T, B):
                                    "alg_bytes_per_launch": nb,
                                    "achieved": nb / res["frames_gather_seq"]["hip_us"] / 1e3,
                                    "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
-    for k in ("frames_gather", "frames_gather_seq"):
+    for k in ("frames_gather", "frames_gather_pair", "frames_gather_seq"):
         replay[k]["frac"] = replay[k]["achieved"] / HBM_PEAK_GBPS
     res["roofline_replay"] = replay
     return res

@@ -503,6 +503,14 @@ int rlpyt_frames_gather_seq(const uint8_t* frames, const uint8_t* done, const in
                             const int64_t* b_idx, uint8_t* obs, int64_t n, int seq_T, int T,
                             int64_t B, int C, int64_t HW, rlpyt_stream_t stream);
 
+/* The two observation gathers of NStepReturnBuffer.extract_batch -- agent inputs at t_i and target
+ * inputs at (t_i + n_step) mod T, rlpyt/replays/non_sequence/n_step.py:29-42 with
+ * frame.py:14-30 for each -- in ONE launch: obs [2, n, C, HW], obs[0] = the stack at t_i,
+ * obs[1] = the stack at t_i + n_step (same blanking rule for both). */
+int rlpyt_frames_gather_pair(const uint8_t* frames, const uint8_t* done, const int64_t* t_idx,
+                             const int64_t* b_idx, uint8_t* obs, int64_t n, int n_step, int T,
+                             int64_t B, int C, int64_t HW, rlpyt_stream_t stream);
+
 /* extract_sequences -- rlpyt/utils/misc.py:38-56: dst[s,i,:] = src[(t_i+s) mod T, b_i, :]. */
 int rlpyt_gather_sequences(const void* src, const int64_t* t_idx, const int64_t* b_idx,
                            void* dst, int64_t n, int seq_T, int T, int64_t B,

@@ -147,6 +147,8 @@ _SIGNATURES = {
                                     _p]),
     "rlpyt_frames_gather_seq": (c_int, [_p, _p, _p, _p, _p, c_int64, c_int, c_int, c_int64,
                                         c_int, c_int64, _p]),
+    "rlpyt_frames_gather_pair": (c_int, [_p, _p, _p, _p, _p, c_int64, c_int, c_int, c_int64,
+                                         c_int, c_int64, _p]),
     "rlpyt_gather_sequences": (c_int, [_p, _p, _p, _p, c_int64, c_int, c_int, c_int64, c_int64,
                                        _p]),
     "rlpyt_clip_adam_workspace_bytes": (c_int64, []),

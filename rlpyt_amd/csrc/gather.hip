@@ -117,14 +117,15 @@ template <typename V>
 __global__ __launch_bounds__(256) void frames_gather_kernel(
     const V* __restrict__ frames, const uint8_t* __restrict__ done,
     const int64_t* __restrict__ t_idx, const int64_t* __restrict__ b_idx, V* __restrict__ obs,
-    int64_t n, int seq_T, int T, int64_t B, int C, int64_t nvec) {
+    int64_t n, int seq_T, int s_stride, int T, int64_t B, int C, int64_t nvec) {
   const int c = blockIdx.y;
   const int64_t items = n * (int64_t)seq_T;
   for (int64_t item = blockIdx.z; item < items; item += gridDim.z) {
-    // obs layout [seq_T, n, C, HW]: item = s * n + i
+    // obs layout [seq_T, n, C, HW]: item = s * n + i; step s is ring time t_idx[i] + s * s_stride
+    // (stride 1: a sequence; seq_T = 2, stride n: the agent and the n-step target observation)
     const int64_t s = item / n, i = item - s * n;
     const int64_t b = b_idx[i];
-    int64_t tt = (t_idx[i] + s) % T;
+    int64_t tt = (t_idx[i] + s * s_stride) % T;
     if (tt < 0) tt += T;
     const bool blank = channel_blank(done, tt, b, c, C, T, B);  // workgroup-uniform
     const V* __restrict__ src = frames + ((tt + c) * B + b) * nvec;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void frames_gather_kernel(
 __global__ __launch_bounds__(256) void frames_gather_wide_kernel(
     const B16* __restrict__ frames, const uint8_t* __restrict__ done,
     const int64_t* __restrict__ t_idx, const int64_t* __restrict__ b_idx, B16* __restrict__ obs,
-    int64_t n, int seq_T, int T, int64_t B, int C, int64_t nvec) {
+    int64_t n, int seq_T, int s_stride, int T, int64_t B, int C, int64_t nvec) {
   const int64_t items = n * (int64_t)seq_T;
   const int64_t total = (int64_t)C * nvec;
   B16 zero;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void frames_gather_wide_kernel(
   for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
     const int64_t s = item / n, i = item - s * n;
     const int64_t b = b_idx[i];
-    int64_t tt = (t_idx[i] + s) % T;
+    int64_t tt = (t_idx[i] + s * s_stride) % T;
     if (tt < 0) tt += T;
     // blank flags of the C channels (bit c), workgroup-uniform
     unsigned blank_mask = 0;
@@ -180,20 +181,20 @@ __global__ __launch_bounds__(256) void frames_gather_wide_kernel(
 
 template <typename V>
 int launch_frames_v(const uint8_t* frames, const uint8_t* done, const int64_t* t_idx,
-                    const int64_t* b_idx, uint8_t* obs, int64_t n, int seq_T, int T, int64_t B,
-                    int C, int64_t HW, hipStream_t s) {
+                    const int64_t* b_idx, uint8_t* obs, int64_t n, int seq_T, int s_stride, int T,
+                    int64_t B, int C, int64_t HW, hipStream_t s) {
   const int64_t nvec = HW / (int64_t)sizeof(V);
   const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(nvec, 256), 16);
   const unsigned gz = (unsigned)std::min<int64_t>(n * seq_T, 65535);
   RL_LAUNCH((frames_gather_kernel<V>), dim3(gx, C, gz), dim3(256), 0, s,
-                     (const V*)frames, done, t_idx, b_idx, (V*)obs, n, seq_T, T, B, C, nvec);
+                     (const V*)frames, done, t_idx, b_idx, (V*)obs, n, seq_T, s_stride, T, B, C, nvec);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
 
 int launch_frames(const uint8_t* frames, const uint8_t* done, const int64_t* t_idx,
-                  const int64_t* b_idx, uint8_t* obs, int64_t n, int seq_T, int T, int64_t B,
-                  int C, int64_t HW, hipStream_t s) {
+                  const int64_t* b_idx, uint8_t* obs, int64_t n, int seq_T, int s_stride, int T,
+                  int64_t B, int C, int64_t HW, hipStream_t s) {
   const uintptr_t a = reinterpret_cast<uintptr_t>(frames) | reinterpret_cast<uintptr_t>(obs) |
                       (uintptr_t)HW;
   // (a frame-reuse variant -- SB consecutive steps of a sample per workgroup, each lane loading
@@ -203,15 +204,15 @@ int launch_frames(const uint8_t* frames, const uint8_t* done, const int64_t* t_i
     const int64_t nvec = HW / 16;
     const unsigned g = (unsigned)std::min<int64_t>(n * seq_T, 256 * 32);
     RL_LAUNCH(frames_gather_wide_kernel, dim3(g), dim3(256), 0, s, (const B16*)frames, done,
-                       t_idx, b_idx, (B16*)obs, n, seq_T, T, B, C, nvec);
+                       t_idx, b_idx, (B16*)obs, n, seq_T, s_stride, T, B, C, nvec);
     RL_LAUNCH_CHECK();
     return RLPYT_OK;
   }
   if ((a & 15) == 0)
-    return launch_frames_v<B16>(frames, done, t_idx, b_idx, obs, n, seq_T, T, B, C, HW, s);
+    return launch_frames_v<B16>(frames, done, t_idx, b_idx, obs, n, seq_T, s_stride, T, B, C, HW, s);
   if ((a & 3) == 0)
-    return launch_frames_v<uint32_t>(frames, done, t_idx, b_idx, obs, n, seq_T, T, B, C, HW, s);
-  return launch_frames_v<uint8_t>(frames, done, t_idx, b_idx, obs, n, seq_T, T, B, C, HW, s);
+    return launch_frames_v<uint32_t>(frames, done, t_idx, b_idx, obs, n, seq_T, s_stride, T, B, C, HW, s);
+  return launch_frames_v<uint8_t>(frames, done, t_idx, b_idx, obs, n, seq_T, s_stride, T, B, C, HW, s);
 }
 
 // ---- extract_sequences (utils/misc.py:38-56) --------------------------------------------
@@ -279,7 +280,7 @@ extern "C" int rlpyt_frames_gather(const uint8_t* frames, const uint8_t* done,
   RL_CHECK_ARG(n >= 0 && T > 0 && B > 0 && C > 0 && C <= 65535 && HW > 0, RLPYT_EINVAL,
                "rlpyt_frames_gather: bad sizes");
   if (n == 0) return RLPYT_OK;
-  return launch_frames(frames, done, t_idx, b_idx, obs, n, 1, T, B, C, HW, (hipStream_t)stream);
+  return launch_frames(frames, done, t_idx, b_idx, obs, n, 1, 1, T, B, C, HW, (hipStream_t)stream);
 }
 
 extern "C" int rlpyt_frames_gather_seq(const uint8_t* frames, const uint8_t* done,
@@ -293,7 +294,20 @@ extern "C" int rlpyt_frames_gather_seq(const uint8_t* frames, const uint8_t* don
   RL_CHECK_ARG(seq_T <= T, RLPYT_ESHAPE, "rlpyt_frames_gather_seq: seq_T=%d > ring T=%d", seq_T,
                T);
   if (n == 0) return RLPYT_OK;
-  return launch_frames(frames, done, t_idx, b_idx, obs, n, seq_T, T, B, C, HW,
+  return launch_frames(frames, done, t_idx, b_idx, obs, n, seq_T, 1, T, B, C, HW,
+                       (hipStream_t)stream);
+}
+
+extern "C" int rlpyt_frames_gather_pair(const uint8_t* frames, const uint8_t* done,
+                                        const int64_t* t_idx, const int64_t* b_idx,
+                                        uint8_t* obs, int64_t n, int n_step, int T, int64_t B,
+                                        int C, int64_t HW, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(frames && done && t_idx && b_idx && obs, RLPYT_EINVAL,
+               "rlpyt_frames_gather_pair: null pointer");
+  RL_CHECK_ARG(n >= 0 && n_step > 0 && T > 0 && B > 0 && C > 0 && C <= 65535 && HW > 0,
+               RLPYT_EINVAL, "rlpyt_frames_gather_pair: bad sizes");
+  if (n == 0) return RLPYT_OK;
+  return launch_frames(frames, done, t_idx, b_idx, obs, n, 2, n_step, T, B, C, HW,
                        (hipStream_t)stream);
 }
 

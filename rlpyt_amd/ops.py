@@ -933,6 +933,31 @@ def frames_gather(frames, done, t_idx, b_idx, n_frames, out=None):
     return out
 
 
+def frames_gather_pair(frames, done, t_idx, b_idx, n_frames, n_step, out=None):
+    """Agent observation at ``t_idx`` and target observation at ``t_idx + n_step`` of a replay
+    batch in one launch (the two ``extract_observation`` calls of
+    rlpyt/replays/non_sequence/n_step.py:29-42) -> uint8 [2, n, C, *img]."""
+    _lib.require_gpu()
+    assert frames.dtype == torch.uint8 and frames.is_contiguous()
+    C = int(n_frames)
+    T = frames.shape[0] - (C - 1)
+    B = frames.shape[1]
+    img = tuple(frames.shape[2:])
+    HW = 1
+    for s in img:
+        HW *= s
+    done8 = _as_done_u8(done)
+    assert done8.shape[0] == T and done8.shape[1] == B
+    t_idx, b_idx = t_idx.long().contiguous(), b_idx.long().contiguous()
+    n = t_idx.numel()
+    if out is None:
+        out = torch.empty((2, n, C) + img, dtype=torch.uint8, device=frames.device)
+    check(lib.rlpyt_frames_gather_pair(ptr(frames), ptr(done8), ptr(t_idx), ptr(b_idx), ptr(out), n,
+                                       int(n_step), T, B, C, HW, stream()),
+          "rlpyt_frames_gather_pair")
+    return out
+
+
 def frames_gather_seq(frames, done, t_idx, b_idx, n_frames, seq_T, out=None):
     """SequenceNStepFrameBuffer.extract_observation (replays/sequence/frame.py:17-50)
     -> uint8 [seq_T, n, C, *img]."""

@@ -386,6 +386,23 @@ def test_frames_atari_shape_vs_oracle(ops):
     assert np.array_equal(host(seq), O.frames_gather_seq(frames, done, sT, B_idxs[:8], C, 25))
 
 
+@pytest.mark.parametrize("n_step", [1, 3])
+def test_frames_gather_pair_is_the_two_single_gathers(ops, n_step):
+    """Agent + target observation of a replay batch in one launch == the two extract_observation
+    calls of rlpyt/replays/non_sequence/n_step.py:29-42 (oracle), incl. target rows past the wrap."""
+    rng = np.random.RandomState(5 + n_step)
+    T, B, C, H, W, n = 300, 8, 4, 104, 80, 128
+    frames = rng.randint(0, 256, size=(T + C - 1, B, H, W)).astype(np.uint8)
+    frames[:C - 1] = frames[-(C - 1):]
+    done = rng.rand(T, B) < 0.05
+    T_idxs, B_idxs = rng.randint(0, T, size=n), rng.randint(0, B, size=n)
+    T_idxs[:3] = [T - 1, T - n_step, 0]
+    both = ops.frames_gather_pair(dev(frames), dev(done), dev(T_idxs), dev(B_idxs), C, n_step)
+    assert np.array_equal(host(both[0]), O.frames_gather(frames, done, T_idxs, B_idxs, C))
+    assert np.array_equal(host(both[1]),
+                          O.frames_gather(frames, done, (T_idxs + n_step) % T, B_idxs, C))
+
+
 def test_extract_sequences_golden(ops):
     g = load_golden("frames")
     out = ops.extract_sequences(dev(g["es_arr"]), dev(g["es_T_idxs"]), dev(g["es_B_idxs"]),
