@@ -71,9 +71,9 @@ KERNEL_NAMES = {
                      "g (W^T)^T on a transposed copy of W; same bf16x6 arithmetic)",
     "gemm_nn": "gemm_nn_pp_kernel (update trunk input gradient g W [8192,512]x[512,3456], W read as "
                "stored; bf16x6, producer / consumer waves)",
-    "gemm_tn": "gemm_tn_pp_kernel + gemm_reduce_slots_kernel (update trunk weight gradient g^T x "
+    "gemm_tn": "gemm_tn_x6_kernel + gemm_reduce_slots_kernel (update trunk weight gradient g^T x "
                "[8192,512]^T x [8192,3456]: 8 K chunks <-> XCDs, partial tiles, fixed-order sum; "
-               "bf16x6, producer / consumer waves)",
+               "bf16x6 in lock step, K-major LDS tiles read with ds_read_b64_tr_b16)",
     "obs_to_nhwc": "obs_to_nhwc_f32_kernel (minibatch gather + u8->f32 + CHW->HWC)",
     "gather_tb": "gather_wide_kernel (minibatch observation gather)",
     "gae": "scan_exact_kernel<GAE>", "ppo_loss": "pg_loss_kernel<PPO>",

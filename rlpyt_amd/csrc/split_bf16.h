@@ -30,4 +30,16 @@ __device__ __forceinline__ void split3_rn(float x0, float x1, uint32_t& hi, uint
   lo = cvt_pk_bf16(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
 }
 
+// ds_read_b64_tr_b16, the LDS transpose read of gfx950: within a group of 16 lanes, lane s supplies
+// the address of four contiguous 16-bit elements = "key s >> 2, columns 4 (s & 3) .. + 3" of a
+// 4 x 16 block, and lane i receives column i of the block, keys 0..3 (scripts/debug/tr_probe.hip
+// prints the map).  Two of them give a lane the 8 consecutive K of an MFMA operand from data that is
+// stored K-major.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr16(const uint8_t* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(p));
+  return __builtin_bit_cast(uint2, v);
+}
+
 }  // namespace rlpyt

@@ -17,8 +17,9 @@ x = torch.randn(M, K, device="cuda")
 w = torch.randn(N, K, device="cuda")
 g = torch.randn(M, N, device="cuda")
 for name, fn, steps in (("fwd NT", lambda: ops.gemm_nt(x, w, pingpong=True), K // 32),
-                        ("dgrad NN", lambda: ops.gemm_nn(g, w), N // 32),
-                        ("wgrad TN", lambda: ops.gemm_tn(g, x), M // 32 // 8)):
+                        ("dgrad NN", lambda: ops.gemm_nn(g, w), N // 32)):
+    # (the TN rows of profiles/r3_gemm_*_sweep*.log are of the producer / consumer TN instantiation,
+    #  since replaced by gemm_tn_x6_kernel, which carries no phase counters)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

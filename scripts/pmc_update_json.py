@@ -22,7 +22,7 @@ REGIONS = {
     "conv1_wgrad": (["conv1_wgrad_kernel"], M * (33280 + 4 * 7600)),
     "gemm_nt": (["gemm_nt_x6_kernel<128>"], GEMM_ALG),
     "gemm_nt_dgrad": (["gemm_nt_x6_kernel<256>"], GEMM_ALG),
-    "gemm_tn": (["gemm_tn_pp_kernel", "gemm_reduce_slots_kernel"], GEMM_ALG),
+    "gemm_tn": (["gemm_tn_x6_kernel", "gemm_reduce_slots_kernel"], GEMM_ALG),
 }
 RENAME = {"SQ_VALU_MFMA_BUSY_CYCLES": "mfma_busy_cycles", "SQ_BUSY_CYCLES": "sq_busy_cycles",
           "GRBM_GUI_ACTIVE": "gui_active", "SQ_WAVE_CYCLES": "wave_cycles_quad",

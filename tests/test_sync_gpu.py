@@ -161,7 +161,7 @@ def test_two_ranks_product_ppo_matches_mean_gradient_run(tmp_path, T, B):
                   "conv1_fwd_kernel", "scan_exact_kernel<0, 1, 32, false>"):
             assert res["variants"].get(k, 0) > 0, (k, sorted(res["variants"]))
         big = T * B // PPO_KW["minibatches"] >= 1024      # _LinearNoBias under DDP's hooks
-        for k in ("gemm_nt_x6_kernel<128>", "gemm_tn_pp_kernel", "conv2_fwd_x6_kernel"):
+        for k in ("gemm_nt_x6_kernel<128>", "gemm_tn_x6_kernel", "conv2_fwd_x6_kernel"):
             assert (res["variants"].get(k, 0) > 0) == big, (k, big, sorted(res["variants"]))
     # ranks saw different data ...
     assert r0["info"][0]["loss"] != r1["info"][0]["loss"]

@@ -533,8 +533,8 @@ def _gemm_nn_pp():
     Cv.test_gemm_nn_bf16x6_is_f32_accurate(_ops(), 257, 132, 160)
 
 
-@case("gemm_tn_pp_kernel", "gemm_reduce_slots_kernel")
-def _gemm_tn_pp():
+@case("gemm_tn_x6_kernel", "gemm_reduce_slots_kernel")
+def _gemm_tn_x6():
     import test_conv_gpu as Cv
     Cv.test_gemm_tn_bf16x6_is_f32_accurate(_ops(), 132, 200, 2080)    # ragged K chunks + partials
 
