@@ -790,7 +790,10 @@ def replay_config_main(args):
         algo = DQN(discount=0.99, batch_size=128, learning_rate=1e-4, clip_grad_norm=10.,
                    min_steps_learn=0, double_dqn=False, prioritized_replay=True, n_step_return=1,
                    replay_size=int(1e6))
-        workers, fill = 2, (2000 if args.replay_fill_itrs < 0 else args.replay_fill_itrs)
+        # sampling-only iterations before the timed region: by default until the 62 500-row ring
+        # has WRAPPED (the timed sampling / updates then run on a full ring: every leaf of the
+        # 1M-leaf tree live, frame windows crossing the wrap point)
+        workers, fill = 2, (int(1e6) // B // T + 400 if args.replay_fill_itrs < 0 else args.replay_fill_itrs)
         steps = args.steps if args.steps != 5 else 300
         warmup = args.warmup if args.warmup != 2 else 20
         name = "DQN AtariDqnAgent, PrioritizedReplayFrameBuffer 1e6 frames, sampler [2,16], batch 128"
@@ -805,7 +808,7 @@ def replay_config_main(args):
                     pri_beta_init=0.6, pri_beta_final=0.6, input_priority_shift=2,
                     replay_size=int(4e6))
         workers = max(min(int(round(1.6 * cpus)) - 1, B // 10), 1)
-        fill = 12 if args.replay_fill_itrs < 0 else args.replay_fill_itrs
+        fill = int(4e6) // B // T + 8 if args.replay_fill_itrs < 0 else args.replay_fill_itrs   # wraps
         steps = args.steps if args.steps != 5 else 20
         warmup = args.warmup if args.warmup != 2 else 3
         name = ("R2D1 AtariR2d1Agent (conv + LSTM 512), PrioritizedSequenceReplayFrameBuffer 4e6 "
@@ -876,6 +879,16 @@ def replay_config_main(args):
                                    "achieved": nb / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                    "frac": nb / us / 1e3 / HBM_PEAK_GBPS,
                                    "note": "8.5 MB per launch: latency-class at this batch size"}
+        # what sample_batch issues: agent + target stack in one launch
+        out_p = torch.empty((2, n, C) + tuple(frames.shape[2:]), dtype=torch.uint8, device="cuda")
+        us = _hip_us(lambda: ops.frames_gather_pair(frames, rb.samples.done, ti, bi, C,
+                                                    rb.n_step_return, out=out_p))
+        replay["frames_gather_pair"] = {"bound": "hbm", "avg_us": round(us, 2),
+                                        "alg_bytes_per_launch": 2 * nb,
+                                        "achieved": 2 * nb / us / 1e3, "peak": HBM_PEAK_GBPS,
+                                        "unit": "GB/s", "frac": 2 * nb / us / 1e3 / HBM_PEAK_GBPS,
+                                        "kernel": "frames_gather_kernel<B16> [2, 128, 4, 104, 80] "
+                                                  "(agent + n-step target stacks of one batch)"}
         us = _hip_us(lambda: rb.sample_batch(n), iters=20)
         replay["sample_batch_total_us"] = round(us, 1)
     else:
@@ -900,7 +913,8 @@ def replay_config_main(args):
                                     "levels": int(tree.tree_levels)}
         us = _hip_us(lambda: rb.sample_batch(n), iters=10)
         replay["sample_batch_total_us"] = round(us, 1)
-    key = "frames_gather" if args.config == "dqn" else "frames_gather_seq"
+    key = "frames_gather_pair" if args.config == "dqn" else "frames_gather_seq"
+    traffic = pmc_traffic(key, replay[key])
     out = {
         "metric": f"env-steps/sec (SPS), {args.config.upper()} Atari end to end, 1 GPU "
                   "(BASELINE config #%d)" % (3 if args.config == "dqn" else 5),
@@ -914,12 +928,19 @@ def replay_config_main(args):
                    "frame_store_GB": round(frames.numel() / 1e9, 2),
                    "tree_leaves": int(tree.T * tree.B), "tree_levels": int(tree.tree_levels),
                    "ring_rows_filled": int(filled_T), "fill_iterations": fill,
+                   "ring_wrapped": bool(getattr(rb, "_buffer_full", False)),
                    "updates_per_iteration": algo.updates_per_optimize,
                    "batch_size": int(algo.batch_size)},
         "updates_per_s": updates / elapsed, "updates": updates,
         "sampling_frac_of_step": t_sample / elapsed,
-        "roofline": dict(kernel=replay[key].get("kernel", key), **{k: v for k, v in replay[key].items()
-                                                                   if k != "kernel"}, traffic=None),
+        "roofline": dict(kernel=replay[key].get("kernel", key),
+                         **{k: v for k, v in replay[key].items() if k != "kernel"},
+                         traffic=None if traffic is None else traffic["bytes_per_launch"],
+                         traffic_over_alg=None if traffic is None else traffic["traffic_over_alg"],
+                         traffic_source=None if traffic is None else traffic["source"],
+                         note="the replay kernel of this config (SURVEY 8(d)); the step's time is in "
+                              "the model's MIOpen / hipBLASLt kernels: profiles/r3_" + args.config +
+                              "_kernel_stats.csv"),
         "roofline_replay": replay,
         "last_loss": (info.loss[-1] if info.loss else None),
     }
