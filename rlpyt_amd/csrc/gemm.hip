@@ -16,8 +16,6 @@
 // split / LDS phase idled the matrix pipe: 226 us).  Per K-step a thread moves 1 + 1 float4
 // HBM -> registers (one step ahead), splits them and writes 6 x 8 B to the other LDS stage; one
 // barrier per K-step.  blockIdx -> tile map keeps the column tiles of one row block on one XCD.
-#include <stdlib.h>
-
 #include <algorithm>
 #include "common.h"
 
@@ -265,181 +263,6 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// EXPERIMENT (RLPYT_GEMM_DMA=1): the 128 x 128 kernel above with the operand rows travelling
-// HBM -> LDS by `global_load_lds_dwordx4` (LDS-DMA: no VGPRs, and -- MI355X_MICROARCH.md -- a higher
-// per-CU rate than the ~10-12 B/clk at which register loads arrive here) into a ring of RAW f32
-// K-steps.  The DMA writes lane l's 16 bytes at (wave-uniform base) + 16 l, so with the staging map
-// of the kernel above (float4 tid = row tid >> 2, K quarter tid & 3) every thread later reads back
-// exactly the 16 bytes its own lane requested: the raw ring needs no barrier, only the wave's own
-// counted vmcnt.  From there on the K step is the one above (split in the MFMA gaps, three piece
-// stages, one barrier per step).  Raw barriers / hand-counted waits: hipcc drains LDS-DMA with
-// vmcnt(0) before every __syncthreads otherwise.
-// ---------------------------------------------------------------------------------------------
-constexpr int GD_NRAW = 5;               // raw ring stages (16 KB each: A 8 KB | B 8 KB)
-constexpr int GD_AHEAD = GD_NRAW - 2;    // a K step is requested GD_AHEAD steps before it is split
-
-__global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_dma_kernel(
-    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
-    int K, int tiles_m, int tiles_n) {
-  constexpr int TM = 128;
-  constexpr int ROWB = 2 * G_BK;                               // unpadded, halves swizzled
-  constexpr int PB = TM * ROWB, OB = 3 * PB, SB = 2 * OB;      // piece / operand / stage bytes
-  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * SB];              // 73,728 B
-  __shared__ __attribute__((aligned(16))) uint8_t raw[GD_NRAW * 16384];     // 81,920 B (5 stages)
-  static_assert(3 * SB + GD_NRAW * 16384 <= 160 * 1024, "LDS");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave % 2, wn = wave / 2;
-  int tm, tn;
-  if ((tiles_m & 7) == 0) {
-    const int R = tiles_m >> 3, xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    const int cb = li / (4 * R), rem = li - cb * 4 * R;
-    const int cw = min(4, tiles_n - 4 * cb);
-    tm = xcd * R + rem / cw;
-    tn = 4 * cb + rem % cw;
-  } else {
-    const int n_tiles = tiles_m * tiles_n, per_xcd = (n_tiles + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= n_tiles) return;
-    tm = tile / tiles_n;
-    tn = tile - tm * tiles_n;
-  }
-  const int row = tid >> 2, kq = tid & 3;
-  const float* ga = A + (int64_t)min(tm * TM + row, M - 1) * K + 4 * kq;
-  const float* gb = B + (int64_t)min(tn * GT + row, N - 1) * K + 4 * kq;
-  // piece slot of (row, 8-byte K quarter kq): 16-byte half (kq >> 1) ^ ((row >> 2) & 1)
-  const int sdst = row * ROWB + ((((kq >> 1) ^ ((row >> 2) & 1)) << 4) | ((kq & 1) << 3));
-  const int nk = K / G_BK, last = nk - 1;
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef __attribute__((address_space(1))) const void glb_void;
-  // request K step j (clamped: past the end the last step again, into a slot nobody reads -- the
-  // count of outstanding requests stays uniform, which the counted waits below rely on)
-#define GD_REQ(j_)                                                                             \
-  {                                                                                            \
-    const int jj_ = min((j_), last);                                                           \
-    uint8_t* d_ = raw + ((j_) % GD_NRAW) * 16384 + wave * 1024;                                \
-    __builtin_amdgcn_global_load_lds((glb_void*)(ga + jj_ * G_BK), (lds_void*)d_, 16, 0, 0);   \
-    __builtin_amdgcn_global_load_lds((glb_void*)(gb + jj_ * G_BK), (lds_void*)(d_ + 8192), 16, 0, 0); \
-  }
-  f32x4 ra, rb;
-  // this thread's 16 + 16 bytes of K step j, once all but the NEWER_ most recent requests landed
-#define GD_TAKE(j_, NEWER_)                                                                    \
-  {                                                                                            \
-    /* ONE asm block: counted wait, the two reads, and the wait for them (the fragment reads  */ \
-    /* issued just before are due at the first MFMA anyway).  As plain C++ loads hipcc puts   */ \
-    /* vmcnt(0) in front of them (an LDS read that may alias an LDS-DMA in flight); results   */ \
-    /* of an asm read that are still in flight when the block ends are not safe to hand to    */ \
-    /* the compiler (it may copy the registers before any wait it cannot see).                */ \
-    const uint32_t o_ = (uint32_t)(uintptr_t)(raw + ((j_) % GD_NRAW) * 16384 + tid * 16);      \
-    asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:8192\n\t" \
-                 "s_waitcnt lgkmcnt(0)"                                                        \
-                 : "=&v"(ra), "=&v"(rb) : "n"(NEWER_), "v"(o_) : "memory");                     \
-  }
-#define GD_STAGE(st_)                                                                          \
-  {                                                                                            \
-    uint32_t p_[3][2], q_[3][2];                                                               \
-    split3_rn(ra[0], ra[1], p_[0][0], p_[1][0], p_[2][0]);                                     \
-    split3_rn(ra[2], ra[3], p_[0][1], p_[1][1], p_[2][1]);                                     \
-    split3_rn(rb[0], rb[1], q_[0][0], q_[1][0], q_[2][0]);                                     \
-    split3_rn(rb[2], rb[3], q_[0][1], q_[1][1], q_[2][1]);                                     \
-    uint8_t* d_ = lds + (st_) * SB + sdst;                                                     \
-    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                         \
-      *reinterpret_cast<uint2*>(d_ + s_ * PB) = uint2{p_[s_][0], p_[s_][1]};                   \
-      *reinterpret_cast<uint2*>(d_ + OB + s_ * PB) = uint2{q_[s_][0], q_[s_][1]};              \
-    }                                                                                          \
-  }
-  f32x16 acc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  const int fr = lane & 31, fh = lane >> 5;
-  int a_off[2], b_off;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r_ = wm * 64 + 32 * i + fr;
-    a_off[i] = r_ * ROWB + ((fh ^ ((r_ >> 2) & 1)) << 4);
-  }
-  {
-    const int c_ = wn * 32 + fr;
-    b_off = OB + c_ * ROWB + ((fh ^ ((c_ >> 2) & 1)) << 4);
-  }
-#define GD_FRAGS(af_, bf_, st_)                                                                \
-  _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                              \
-    bf_[s] = *reinterpret_cast<const uint4*>(lds + (st_) * SB + b_off + s * PB);               \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
-      af_[i][s] = *reinterpret_cast<const uint4*>(lds + (st_) * SB + a_off[i] + s * PB);       \
-  }
-#define GD_TERM(af_, bf_, sa_, sb_)                                                            \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[i] = mfma32_bf16(af_[i][sa_], bf_[sb_], acc[i]);
-#define GD_MMA(af_, bf_)                                                                       \
-  GD_TERM(af_, bf_, 2, 0) GD_TERM(af_, bf_, 0, 2) GD_TERM(af_, bf_, 1, 1)                      \
-  GD_TERM(af_, bf_, 1, 0) GD_TERM(af_, bf_, 0, 1) GD_TERM(af_, bf_, 0, 0)
-#define GD_BAR()                                                                               \
-  {                                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
-    __builtin_amdgcn_s_barrier();                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-  }
-  uint4 af0[2][3], bf0[3], af1[2][3], bf1[3];
-  // prologue: steps 0 .. 1 + GD_AHEAD requested; steps 0 and 1 split into stages 0 and 1
-#pragma unroll
-  for (int j = 0; j < 2 + GD_AHEAD; ++j) GD_REQ(j)
-  GD_TAKE(0, 2 * (1 + GD_AHEAD))
-  GD_STAGE(0)
-  GD_TAKE(1, 2 * GD_AHEAD)
-  GD_STAGE(1)
-  GD_BAR()
-  GD_FRAGS(af0, bf0, 0)
-  int st_next = 1, st_write = 2;
-  // step ks: fragments of ks + 1, own raw rows of ks + 2 out of the ring, MFMAs of ks with the split
-  // of ks + 2 in their gaps, request of ks + 2 + GD_AHEAD
-#define GD_STEP(afc_, bfc_, afn_, bfn_, ks_)                                                   \
-  {                                                                                            \
-    GD_BAR()                                                                                   \
-    GD_FRAGS(afn_, bfn_, st_next)                                                              \
-    GD_TAKE((ks_) + 2, 2 * (GD_AHEAD - 1))                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    GD_MMA(afc_, bfc_)                                                                         \
-    GD_STAGE(st_write)                                                                         \
-    _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                        \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                       \
-    }                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    GD_REQ((ks_) + 2 + GD_AHEAD)                                                               \
-    st_next = st_next == 2 ? 0 : st_next + 1;                                                  \
-    st_write = st_write == 2 ? 0 : st_write + 1;                                               \
-  }
-  int ks = 0;
-#pragma unroll 1
-  for (; ks + 1 < nk; ks += 2) {
-    GD_STEP(af0, bf0, af1, bf1, ks)
-    GD_STEP(af1, bf1, af0, bf0, ks + 1)
-  }
-  if (ks < nk) GD_STEP(af0, bf0, af1, bf1, ks)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tail's surplus requests, before the LDS dies
-#undef GD_STEP
-#undef GD_BAR
-#undef GD_MMA
-#undef GD_TERM
-#undef GD_FRAGS
-#undef GD_STAGE
-#undef GD_TAKE
-#undef GD_REQ
-  const int col = tn * GT + wn * 32 + fr;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int orow = tm * TM + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      if (orow < M && col < N) C[(int64_t)orow * N + col] = acc[i][r];
-    }
-}
-
 }  // namespace
 }  // namespace rlpyt
 
@@ -471,14 +294,8 @@ extern "C" int rlpyt_gemm_nt_f32(const float* a, const float* b, float* c, int64
   } else {
     const int tiles_m = (int)ceil_div(M, GT);
     const int grid = 8 * ((tiles_m * tiles_n + 7) / 8);
-    static const bool dma = [] { const char* e = getenv("RLPYT_GEMM_DMA"); return e && atoi(e) != 0; }();
-    if (dma) {
-      RL_LAUNCH(gemm_nt_x6_dma_kernel, dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, (int)N,
-                (int)K, tiles_m, tiles_n);
-    } else {
-      RL_LAUNCH((gemm_nt_x6_kernel<128>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, (int)N,
-                (int)K, tiles_m, tiles_n);
-    }
+    RL_LAUNCH((gemm_nt_x6_kernel<128>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, (int)N,
+              (int)K, tiles_m, tiles_n);
   }
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
