@@ -239,7 +239,10 @@ __global__ __launch_bounds__(256) void fc_small_kernel(const float* __restrict__
   fc_f32x4 acc[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = fc_f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 3;   // K-groups of 16 fetched together: loads of a slab are independent
+  // K-groups of 16 fetched together: the loads of a slab are independent, the slabs are not -- a
+  // workgroup's K chunk (432 at the trunk's 3456 / 8) is a chain of chunk / (16 U) L2 round trips,
+  // and at 64 rows the kernel is nothing but that chain (U = 3: 9 trips, 9.9 us per launch)
+  constexpr int U = MT == 1 ? 9 : (MT == 2 ? 6 : 3);
   int k = k0;
   for (; k + 16 * U <= k1; k += 16 * U) {
     fc_f32x4 a[U], b[U][MT];
