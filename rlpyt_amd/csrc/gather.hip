@@ -130,11 +130,13 @@ __global__ __launch_bounds__(256) void frames_gather_kernel(
     const bool blank = channel_blank(done, tt, b, c, C, T, B);  // workgroup-uniform
     const V* __restrict__ src = frames + ((tt + c) * B + b) * nvec;
     V* __restrict__ dst = obs + (item * C + c) * nvec;
-    V zero;
-    memset(&zero, 0, sizeof(V));
+    const V zero = V{};         // (memset of a local put it in scratch memory)
+    // (as `blank ? zero : src[v]` hipcc selected between the two ADDRESSES, with `zero` in scratch)
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
-         v += (int64_t)gridDim.x * blockDim.x)
-      dst[v] = blank ? zero : src[v];
+         v += (int64_t)gridDim.x * blockDim.x) {
+      if (blank) dst[v] = zero;
+      else dst[v] = src[v];
+    }
   }
 }
 
@@ -147,8 +149,7 @@ __global__ __launch_bounds__(256) void frames_gather_wide_kernel(
     int64_t n, int seq_T, int s_stride, int T, int64_t B, int C, int64_t nvec) {
   const int64_t items = n * (int64_t)seq_T;
   const int64_t total = (int64_t)C * nvec;
-  B16 zero;
-  memset(&zero, 0, sizeof(B16));
+  const B16 zero = B16{};
   for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
     const int64_t s = item / n, i = item - s * n;
     const int64_t b = b_idx[i];
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(256) void frames_gather_wide_kernel(
         vv[u] = v0 + u * 256;
         if (vv[u] < total) {
           const int64_t c = vv[u] / nvec, e = vv[u] - c * nvec;
-          val[u] = ((blank_mask >> c) & 1u) ? zero : src0[c * cstride + e];
+          if ((blank_mask >> c) & 1u) val[u] = zero;
+          else val[u] = src0[c * cstride + e];
         }
       }
 #pragma unroll
