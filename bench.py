@@ -474,6 +474,22 @@ def main():
                         "achieved": gb["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": gb["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, "avg_us": gb["avg_us"],
                         "launches": gb["launches"]}
+            if name != "gemm_tn" and "gemm_tn" in ksum:
+                # the largest matrix-pipe-bound kernel beside the dominant one (the two trade places
+                # from box to box: conv2 backward 195-206 us, weight gradient 187-224 us)
+                gt = ksum["gemm_tn"]
+                tt = pmc_traffic("gemm_tn", gt)
+                out["roofline_gemm_tn"] = {
+                    "kernel": names["gemm_tn"], "bound": "mfma", "achieved": gt["TFLOPs"] * 6,
+                    "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": gt["TFLOPs"] * 6 / BF16_MFMA_PEAK_TFLOPS,
+                    "frac_of_bf16x6_ceiling": gt["TFLOPs"] * 6 / BF16_MFMA_PEAK_TFLOPS,
+                    "frac_hbm": gt["GBps"] / HBM_PEAK_GBPS, "alg_fp32_TFLOPs": gt["TFLOPs"],
+                    "avg_us": gt["avg_us"], "launches": gt["launches"],
+                    "alg_bytes_per_launch": gt["alg_bytes_per_launch"],
+                    "traffic": None if tt is None else tt["bytes_per_launch"],
+                    "traffic_over_alg": None if tt is None else tt["traffic_over_alg"],
+                    "traffic_source": None if tt is None else tt["source"]}
             # HBM traffic of that kernel from the separate rocprofv3 --pmc passes (a PMC pass
             # cannot run inside this timed process); committed under profiles/
             traffic = pmc_traffic(name, g)
