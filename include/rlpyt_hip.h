@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 3
+#define RLPYT_HIP_ABI_VERSION 4
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -406,6 +406,17 @@ int64_t rlpyt_fc_small_workspace_bytes(int M, int N);
 int rlpyt_fc_small_ksplit(int K); /* number of K slices = leading dim of the partials */
 int rlpyt_fc_small_f32(const float* x, const float* w, const float* bias /*nullable*/, float* y,
                        int M, int N, int K, int relu, float* workspace, rlpyt_stream_t stream);
+
+/* One LSTM cell step for the per-time-step sampling forward of the recurrent agents
+ * (torch.nn.LSTM with T = 1 as used by rlpyt/models/dqn/atari_r2d1_model.py:61-63 and
+ * rlpyt/models/pg/atari_lstm_model.py): the gate pre-activations arrive as the split-K partials
+ * [ksplit, B, 4H] of rlpyt_fc_small_f32([x | h], [W_ih | W_hh]) (y == NULL), this adds b_ih + b_hh,
+ * applies the gates in torch's order (i, f, g, o) and writes h' [B,H], c' [B,H]
+ * (c' = sigmoid(f) c + sigmoid(i) tanh(g), h' = sigmoid(o) tanh(c')).  h_out / c_out may alias
+ * c_prev's buffer only if they are the same element-for-element (in-place state update). */
+int rlpyt_lstm_cell_f32(const float* partial, int ksplit, const float* b_ih, const float* b_hh,
+                        const float* c_prev, float* h_out, float* c_out, int64_t B, int H,
+                        rlpyt_stream_t stream);
 
 /* Sampling head of the fused AtariFf step: h = relu(sum_s partial[s] + fc_bias) (the split-K
  * partials of rlpyt_fc_small_f32), policy / value heads + softmax + inverse-CDF draw

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class CopyDesc(ctypes.Structure):
@@ -129,6 +129,7 @@ _SIGNATURES = {
     "rlpyt_frame_push": (c_int, [_p, _p, c_int64, c_int64, c_int64, c_int, c_int64, _p, _p, _p, _p,
                                  _p, _p, _p, _p, _p]),
     "rlpyt_fc_small_ksplit": (c_int, [c_int]),
+    "rlpyt_lstm_cell_f32": (c_int, [_p, c_int, _p, _p, _p, _p, _p, c_int64, c_int, _p]),
     "rlpyt_pg_sample_head_f32": (c_int, [_p, c_int] + [_p] * 7 + [c_int64, c_int, c_int, _p, _p, _p,
                                                               c_int64, c_int64, _p, _p]),
     "rlpyt_atari_conv1_fwd_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, _p, c_float, _p, _p]),

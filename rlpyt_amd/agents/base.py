@@ -149,10 +149,19 @@ class BaseAgent:
     def sample_mode(self, itr):
         self.model.eval()
         self._mode = "sample"
+        self._refresh_step_weights()
 
     def eval_mode(self, itr):
         self.model.eval()
         self._mode = "eval"
+        self._refresh_step_weights()
+
+    def _refresh_step_weights(self):
+        """Models that keep derived weight buffers for their fused sampling step (read by address
+        from captured step graphs) bring them up to date with the parameters once per iteration."""
+        m = getattr(getattr(self.model, "module", self.model), "refresh_step_weights", None)
+        if m is not None:
+            m()
 
     def sync_shared_memory(self):
         if self.shared_model is not None and self.shared_model is not self.model:

@@ -299,8 +299,66 @@ __global__ __launch_bounds__(256) void fc_small_finish_kernel(const float* __res
   }
   *reinterpret_cast<fc_f32x4*>(y + e) = s;
 }
+
+// One LSTM cell step behind the split-K GEMM above (the per-time-step sampling forward of the
+// recurrent agents, rlpyt/models/dqn/atari_r2d1_model.py:61-63 / torch.nn.LSTM with T = 1):
+//   gates[b, :] = sum_s partial[s][b][:] + b_ih + b_hh      (partials of [x | h] [W_ih | W_hh]^T)
+//   i, f, g, o = gates[0:H], [H:2H], [2H:3H], [3H:4H]        (torch gate order)
+//   c' = sigmoid(f) c + sigmoid(i) tanh(g);   h' = sigmoid(o) tanh(c')
+// One thread per (row, 4 hidden units); fixed summation order -> deterministic.
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ partial, int ksplit,
+                                                        const float* __restrict__ b_ih,
+                                                        const float* __restrict__ b_hh,
+                                                        const float* __restrict__ c_prev,
+                                                        float* __restrict__ h_out,
+                                                        float* __restrict__ c_out, int64_t B, int H) {
+  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;     // element of [B, H]
+  if (e >= B * H) return;
+  const int64_t b = e / H;
+  const int j = (int)(e - b * H);
+  const int64_t BN = B * 4 * (int64_t)H;
+  fc_f32x4 g[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t off = b * 4 * (int64_t)H + (int64_t)q * H + j;
+    fc_f32x4 v = *reinterpret_cast<const fc_f32x4*>(partial + off);
+    for (int k = 1; k < ksplit; ++k) v += *reinterpret_cast<const fc_f32x4*>(partial + (int64_t)k * BN + off);
+    const fc_f32x4 bi = *reinterpret_cast<const fc_f32x4*>(b_ih + q * H + j);
+    const fc_f32x4 bh = *reinterpret_cast<const fc_f32x4*>(b_hh + q * H + j);
+    g[q] = (v + bi) + bh;               // (x W_ih^T + h W_hh^T + b_ih) + b_hh
+  }
+  const fc_f32x4 c0 = *reinterpret_cast<const fc_f32x4*>(c_prev + e);
+  fc_f32x4 c1, h1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    c1[r] = sigmoid_f(g[1][r]) * c0[r] + sigmoid_f(g[0][r]) * tanhf(g[2][r]);
+    h1[r] = sigmoid_f(g[3][r]) * tanhf(c1[r]);
+  }
+  *reinterpret_cast<fc_f32x4*>(c_out + e) = c1;
+  *reinterpret_cast<fc_f32x4*>(h_out + e) = h1;
+}
 }  // namespace
 }  // namespace rlpyt
+
+extern "C" int rlpyt_lstm_cell_f32(const float* partial, int ksplit, const float* b_ih,
+                                   const float* b_hh, const float* c_prev, float* h_out,
+                                   float* c_out, int64_t B, int H, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(partial && b_ih && b_hh && c_prev && h_out && c_out, RLPYT_EINVAL,
+               "rlpyt_lstm_cell_f32: null pointer");
+  RL_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && ksplit > 0, RLPYT_ESHAPE,
+               "rlpyt_lstm_cell_f32: need B > 0, H a positive multiple of 4, ksplit > 0 (B=%ld H=%d "
+               "ksplit=%d)", (long)B, H, ksplit);
+  RL_CHECK_ARG(((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(b_ih) |
+                 reinterpret_cast<uintptr_t>(b_hh) | reinterpret_cast<uintptr_t>(c_prev) |
+                 reinterpret_cast<uintptr_t>(h_out) | reinterpret_cast<uintptr_t>(c_out)) & 15) == 0,
+               RLPYT_ESHAPE, "rlpyt_lstm_cell_f32: buffers must be 16-byte aligned");
+  const int64_t n4 = B * H / 4;
+  RL_LAUNCH(rlpyt::lstm_cell_kernel, dim3((unsigned)rlpyt::ceil_div(n4, 256)), dim3(256), 0,
+            (hipStream_t)stream, partial, ksplit, b_ih, b_hh, c_prev, h_out, c_out, B, H);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
 
 extern "C" int64_t rlpyt_fc_small_workspace_bytes(int M, int N) {
   if (M <= 0 || N <= 0) return 0;

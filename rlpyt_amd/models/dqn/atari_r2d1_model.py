@@ -3,8 +3,12 @@
 rlpyt/models/dqn/atari_r2d1_model.py:13-77, so state dicts interchange).
 
 On the device the uint8 frames are converted by ``rlpyt_obs_to_nhwc_f32`` (one kernel, no f32
-NCHW copy); the LSTM runs through torch's ``nn.LSTM`` (MIOpen RNN on ROCm) and always keeps the
-B dimension in the returned state ``RnnState(h, c)`` of shape ``[N, B, H]``."""
+NCHW copy); the LSTM runs through torch's ``nn.LSTM`` (MIOpen RNN on ROCm) for sequences and for
+anything under autograd, and through ``ops.LstmStep`` (split-K gate GEMM + one cell kernel) for the
+one-step sampling forward; the returned state ``RnnState(h, c)`` always keeps the B dimension,
+shape ``[N, B, H]``."""
+import os
+
 import torch
 
 from ...utils.collections import namedarraytuple
@@ -31,10 +35,37 @@ class AtariR2d1Model(torch.nn.Module):
         self.head = (DuelingHeadModel(lstm_size, head_size, output_size) if dueling
                      else MlpModel(lstm_size, head_size, output_size=output_size))
 
+    # set False (or RLPYT_LSTM_STEP=0) for the library RNN in the one-step sampling forward too (A/B tests)
+    use_fused_lstm_step = os.environ.get("RLPYT_LSTM_STEP", "1") != "0"
+    _lstm_step = None
+
+    def _fused_step_ok(self, T, B, conv_out, init_rnn_state):
+        if not (self.use_fused_lstm_step and T == 1 and B <= 256 and init_rnn_state is not None
+                and not torch.is_grad_enabled() and conv_out.is_cuda
+                and conv_out.dtype == torch.float32 and self.lstm.hidden_size % 16 == 0):
+            return False
+        h0, _c0 = tuple(init_rnn_state)     # (a namedarraytuple indexes its leaves: iterate for the fields)
+        return h0.dim() == 3 and h0.shape[0] == 1 and h0.shape[1] == B
+
+    def refresh_step_weights(self):
+        """Bring the fused step's weight buffer up to date (captured step graphs read it by address)."""
+        if self._lstm_step is not None:
+            self._lstm_step.refresh()
+
     def forward(self, observation, prev_action, prev_reward, init_rnn_state):
         """Leading dims [T,B], [B] or []; prev_action one-hot; returns (q, RnnState [N,B,H])."""
         lead_dim, T, B, img_shape = infer_leading_dims(observation, 3)
         conv_out = self.conv(prepare_image(observation, T * B, img_shape))
+        if self._fused_step_ok(T, B, conv_out, init_rnn_state):
+            # sampling forward, one time step: gate GEMM + cell as two launches (ops.LstmStep)
+            if self._lstm_step is None:
+                from ... import ops
+                self._lstm_step = ops.LstmStep(self.lstm)
+            h0, c0 = tuple(init_rnn_state)
+            hn, cn = self._lstm_step.step([conv_out, prev_action, prev_reward], h0[0], c0[0])
+            q = self.head(hn)
+            return restore_leading_dims(q, lead_dim, T, B), RnnState(h=hn.unsqueeze(0),
+                                                                     c=cn.unsqueeze(0))
         lstm_input = torch.cat([conv_out.reshape(T, B, -1),
                                 prev_action.reshape(T, B, -1).to(conv_out.dtype),
                                 prev_reward.reshape(T, B, 1).to(conv_out.dtype)], dim=2)

@@ -6,6 +6,8 @@ On the device the convolution stack is the same hand-written fp32-MFMA path as A
 (``ops.atari_conv_stack``: uint8 in, 3456 features out, forward and backward) when the geometry
 is the default one; the LSTM runs through ``nn.LSTM`` (MIOpen RNN on ROCm) and always keeps the
 B dimension in the returned state ``RnnState(h, c)`` of shape ``[N, B, H]``."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -34,6 +36,23 @@ class AtariLstmModel(torch.nn.Module):
             and list(strides or [4, 2]) == [4, 2] and list(paddings or [0, 1]) == [0, 1])
         self.use_fused_conv = True
 
+    # set False (or RLPYT_LSTM_STEP=0) for the library RNN in the one-step sampling forward too
+    use_fused_lstm_step = os.environ.get("RLPYT_LSTM_STEP", "1") != "0"
+    _lstm_step = None
+
+    def _fused_step_ok(self, T, B, fc_out, init_rnn_state):
+        if not (self.use_fused_lstm_step and T == 1 and B <= 256 and init_rnn_state is not None
+                and not torch.is_grad_enabled() and fc_out.is_cuda
+                and fc_out.dtype == torch.float32 and self.lstm.hidden_size % 16 == 0):
+            return False
+        h0, _c0 = tuple(init_rnn_state)
+        return h0.dim() == 3 and h0.shape[0] == 1 and h0.shape[1] == B
+
+    def refresh_step_weights(self):
+        """Bring the fused step's weight buffer up to date (captured step graphs read it by address)."""
+        if self._lstm_step is not None:
+            self._lstm_step.refresh()
+
     @property
     def fused_conv(self):
         w = self.conv.conv.conv[0].weight
@@ -52,12 +71,22 @@ class AtariLstmModel(torch.nn.Module):
             fc_out = self.conv.head(feat)
         else:
             fc_out = self.conv(prepare_image(image, T * B, img_shape))
-        lstm_input = torch.cat([fc_out.reshape(T, B, -1),
-                                prev_action.reshape(T, B, -1).to(fc_out.dtype),
-                                prev_reward.reshape(T, B, 1).to(fc_out.dtype)], dim=2)
-        state = None if init_rnn_state is None else tuple(x.contiguous() for x in init_rnn_state)
-        lstm_out, (hn, cn) = self.lstm(lstm_input, state)
-        flat = lstm_out.reshape(T * B, -1)
+        if self._fused_step_ok(T, B, fc_out, init_rnn_state):
+            # sampling forward, one time step: gate GEMM + cell as two launches (ops.LstmStep)
+            if self._lstm_step is None:
+                from ... import ops
+                self._lstm_step = ops.LstmStep(self.lstm)
+            h0, c0 = tuple(init_rnn_state)
+            hn, cn = self._lstm_step.step([fc_out, prev_action, prev_reward], h0[0], c0[0])
+            flat, hn, cn = hn, hn.unsqueeze(0), cn.unsqueeze(0)
+        else:
+            lstm_input = torch.cat([fc_out.reshape(T, B, -1),
+                                    prev_action.reshape(T, B, -1).to(fc_out.dtype),
+                                    prev_reward.reshape(T, B, 1).to(fc_out.dtype)], dim=2)
+            state = (None if init_rnn_state is None
+                     else tuple(x.contiguous() for x in init_rnn_state))
+            lstm_out, (hn, cn) = self.lstm(lstm_input, state)
+            flat = lstm_out.reshape(T * B, -1)
         pi = F.softmax(self.pi(flat), dim=-1)
         v = self.value(flat).squeeze(-1)
         pi, v = restore_leading_dims((pi, v), lead_dim, T, B)

@@ -747,6 +747,65 @@ def fc_small_partials(x, weight):
     return ws, lib.rlpyt_fc_small_ksplit(K)
 
 
+class LstmStep:
+    """One step of a single-layer ``torch.nn.LSTM`` (no grad) for the per-time-step sampling forward
+    of the recurrent agents: ``step(parts, h, c) -> (h', c')`` with ``parts`` the pieces of the input
+    row ``x = cat(parts, 1)`` (``[B, *]`` each), ``h, c [B, H]``.
+
+    The gate GEMM ``[x | h] [W_ih | W_hh]^T`` runs as the split-K small-batch kernel
+    (``rlpyt_fc_small_f32`` partials), bias + gates + cell as one more launch
+    (``rlpyt_lstm_cell_f32``): one concatenation and two launches instead of the library RNN's
+    ten-odd kernels per time step.  The concatenated, K-padded weight lives in ONE buffer for the
+    life of the object (captured hipGraphs keep its address); ``refresh()`` copies the module's
+    current parameters into it when their versions changed -- eager calls do that themselves, a
+    captured step graph relies on the agent calling it once per iteration (``BaseAgent.sample_mode``)."""
+
+    def __init__(self, lstm):
+        assert lstm.num_layers == 1 and not lstm.bidirectional and lstm.bias
+        self.lstm = lstm
+        w_ih, w_hh = lstm.weight_ih_l0, lstm.weight_hh_l0
+        self.I, self.H = w_ih.shape[1], w_hh.shape[1]
+        self.K = self.I + self.H
+        self.Kp = (self.K + 15) // 16 * 16
+        self.wc = torch.zeros((4 * self.H, self.Kp), dtype=torch.float32, device=w_ih.device)
+        self._key = None
+        self._pad = {}
+        self.refresh()
+
+    def refresh(self):
+        lstm = self.lstm
+        w_ih, w_hh = lstm.weight_ih_l0, lstm.weight_hh_l0
+        key = (w_ih._version, w_hh._version, w_ih.data_ptr(), w_hh.data_ptr())
+        if key == self._key or torch.cuda.is_current_stream_capturing():
+            return
+        with torch.no_grad():
+            self.wc[:, :self.I].copy_(w_ih)
+            self.wc[:, self.I:self.K].copy_(w_hh)
+        self._key = key
+
+    def step(self, parts, h, c):
+        _lib.require_gpu()
+        self.refresh()
+        B = h.shape[0]
+        parts = [p.reshape(B, -1).float() for p in parts] + [h.reshape(B, self.H)]
+        if self.Kp != self.K:
+            pad = self._pad.get(B)
+            if pad is None:
+                pad = torch.zeros((B, self.Kp - self.K), dtype=torch.float32, device=h.device)
+                self._pad[B] = pad
+            parts.append(pad)
+        xh = torch.cat(parts, dim=1)
+        assert xh.shape[1] == self.Kp, "input pieces do not add up to the LSTM's input size"
+        partial, ksplit = fc_small_partials(xh, self.wc)
+        c = _f32(c.reshape(B, self.H))
+        h1, c1 = torch.empty_like(c), torch.empty_like(c)
+        lstm = self.lstm
+        check(lib.rlpyt_lstm_cell_f32(ptr(partial), ksplit, ptr(lstm.bias_ih_l0), ptr(lstm.bias_hh_l0),
+                                      ptr(c), ptr(h1), ptr(c1), B, self.H, stream()),
+              "rlpyt_lstm_cell_f32")
+        return h1, c1
+
+
 def pg_sample_head(partial, ksplit, fc_bias, w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, prob_rows,
                    value_rows, action_rows, lo, action_out):
     """Trunk finish + heads + softmax + draw + the step's row writes in one launch

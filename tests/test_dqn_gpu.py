@@ -211,3 +211,98 @@ def test_epsilon_schedule_reaches_captured_step_graphs(vector_eps):
     assert greedy_frac[0] < 0.6        # iteration 0 ran with epsilon 1 (uniform over 6 actions)
     assert all(G.graph is not None for G in sampler.groups)
     sampler.shutdown()
+
+
+@pytest.mark.parametrize("B,I,H", [(5, 531, 512), (64, 531, 512), (192, 519, 512), (3, 71, 32)])
+def test_lstm_step_matches_nn_lstm(B, I, H):
+    """``ops.LstmStep`` (split-K gate GEMM + ``rlpyt_lstm_cell_f32``) == one step of
+    ``torch.nn.LSTM`` (rlpyt/models/dqn/atari_r2d1_model.py:61-63 at T = 1): against float64 on the
+    CPU, no further off than 2x the library RNN's own f32 error (or 2e-6 of the output scale)."""
+    from rlpyt_amd import ops
+    g = torch.Generator().manual_seed(B + I)
+    lstm = torch.nn.LSTM(I, H)
+    for p_ in lstm.parameters():
+        p_.data = torch.randn(p_.shape, generator=g) * 0.2
+    x = torch.randn(B, I, generator=g)
+    h = torch.randn(B, H, generator=g) * 0.5
+    c = torch.randn(B, H, generator=g)
+    ref = torch.nn.LSTM(I, H).double()
+    ref.load_state_dict({k: v.double() for k, v in lstm.state_dict().items()})
+    with torch.no_grad():
+        _, (h64, c64) = ref(x.double()[None], (h.double()[None], c.double()[None]))
+        dl = lstm.cuda()
+        _, (hl, cl) = dl(x.cuda()[None], (h.cuda()[None].contiguous(), c.cuda()[None].contiguous()))
+        step = ops.LstmStep(dl)
+        cut = [I - 19, I - 1] if I > 40 else [I - 7, I - 1]
+        parts = [x[:, :cut[0]].cuda(), x[:, cut[0]:cut[1]].cuda(), x[:, cut[1]:].cuda()]
+        h1, c1 = step.step(parts, h.cuda(), c.cuda())
+    for mine, lib_, want in ((h1, hl[0], h64[0]), (c1, cl[0], c64[0])):
+        e_mine = (mine.double().cpu() - want).abs().max().item()
+        e_lib = (lib_.double().cpu() - want).abs().max().item()
+        assert e_mine <= max(2 * e_lib, 2e-6 * want.abs().max().item()), (e_mine, e_lib)
+    from rlpyt_amd import _lib
+    assert _lib.variant_counts().get("lstm_cell_kernel", 0) > 0
+
+
+def test_lstm_step_weight_buffer_follows_the_parameters_through_a_graph():
+    """The fused step reads its concatenated weight by address: after an in-place parameter update
+    ``refresh()`` (what ``BaseAgent.sample_mode`` triggers) must make a CAPTURED step compute with the
+    new weights, without re-capturing."""
+    from rlpyt_amd import ops
+    torch.manual_seed(3)
+    lstm = torch.nn.LSTM(71, 32).cuda()
+    step = ops.LstmStep(lstm)
+    x, h, c = (torch.randn(8, n, device="cuda") for n in (71, 32, 32))
+    with torch.no_grad():
+        for _ in range(3):
+            step.step([x], h, c)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            h1, c1 = step.step([x], h, c)
+        gr.replay()
+        torch.cuda.synchronize()
+        _, (hl, cl) = lstm(x[None], (h[None], c[None]))
+        torch.testing.assert_close(h1, hl[0], rtol=1e-5, atol=1e-6)
+        for p_ in lstm.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))        # an optimizer step
+        gr.replay()
+        torch.cuda.synchronize()
+        stale = h1.clone()
+        step.refresh()
+        gr.replay()
+        torch.cuda.synchronize()
+        _, (hl2, cl2) = lstm(x[None], (h[None], c[None]))
+        torch.testing.assert_close(h1, hl2[0], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(c1, cl2[0], rtol=1e-5, atol=1e-6)
+        assert (stale - h1).abs().max() > 1e-4          # (the replay before refresh() was on the old weights)
+
+
+def test_r2d1_model_one_step_forward_fused_vs_library_rnn():
+    """AtariR2d1Model's one-step no-grad forward through ``ops.LstmStep`` equals the nn.LSTM path;
+    sequences and anything under autograd still take nn.LSTM."""
+    from rlpyt_amd import _lib
+    from rlpyt_amd.models.dqn.atari_r2d1_model import AtariR2d1Model
+    torch.manual_seed(5)
+    m = AtariR2d1Model((4, 104, 80), 6).cuda().eval()
+    B = 12
+    obs = torch.randint(0, 256, (B, 4, 104, 80), dtype=torch.uint8, device="cuda")
+    pa = torch.nn.functional.one_hot(torch.randint(0, 6, (B,), device="cuda"), 6).float()
+    pr = torch.randn(B, device="cuda")
+    st = (torch.randn(1, B, 512, device="cuda") * 0.3, torch.randn(1, B, 512, device="cuda"))
+    with torch.no_grad():
+        _lib.variant_reset()
+        q1, s1 = m(obs, pa, pr, st)
+        assert _lib.variant_counts().get("lstm_cell_kernel", 0) == 1
+        m.use_fused_lstm_step = False
+        _lib.variant_reset()
+        q0, s0 = m(obs, pa, pr, st)
+        assert _lib.variant_counts().get("lstm_cell_kernel", 0) == 0
+    torch.testing.assert_close(q1, q0, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(s1.h, s0.h, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(s1.c, s0.c, rtol=1e-4, atol=1e-5)
+    assert s1.h.shape == (1, B, 512)
+    m.use_fused_lstm_step = True
+    _lib.variant_reset()
+    q, _ = m(obs, pa, pr, st)                      # grad enabled: library path
+    assert q.requires_grad and _lib.variant_counts().get("lstm_cell_kernel", 0) == 0

@@ -539,6 +539,12 @@ def _gemm_tn_x6():
     Cv.test_gemm_tn_bf16x6_is_f32_accurate(_ops(), 132, 200, 2080)    # ragged K chunks + partials
 
 
+@case("lstm_cell_kernel")
+def _lstm_cell():
+    import test_dqn_gpu as D
+    D.test_lstm_step_matches_nn_lstm(64, 531, 512)
+
+
 @case("sample_convs_kernel")
 def _sample_convs():
     import test_sampler_gpu as S
