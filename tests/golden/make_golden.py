@@ -293,6 +293,33 @@ def sumtree_stream(T, B, ob, of, n_ops, n_sample, adv_T, seed, input_pri=False, 
     return res
 
 
+def gen_categorical():
+    """Every tensor-level method of the reference's Categorical distribution
+    (rlpyt/distributions/categorical.py:17-43 + base.py:57-66: kl, mean_kl with and without a valid
+    mask, entropy, perplexity, mean_entropy, mean_perplexity, log_likelihood, likelihood_ratio) on
+    [T, B, A] probabilities that include exact zeros and ones (where EPS matters)."""
+    g = torch.Generator().manual_seed(77)
+    T, B, A = 9, 7, 6
+    p_old = torch.softmax(2.5 * torch.randn(T, B, A, generator=g), -1)
+    p_new = torch.softmax(2.5 * torch.randn(T, B, A, generator=g), -1)
+    p_old[0, 0] = torch.tensor([1., 0., 0., 0., 0., 0.])
+    p_new[0, 1] = torch.tensor([0., 0., 0.5, 0.5, 0., 0.])
+    p_new[1, 0] = p_old[1, 0]
+    idx = torch.randint(0, A, (T, B), generator=g)
+    valid = (torch.rand(T, B, generator=g) < 0.7).float()
+    dist = Categorical(dim=A)
+    o, n = DistInfo(prob=p_old), DistInfo(prob=p_new)
+    save("categorical", p_old=p_old.numpy(), p_new=p_new.numpy(), idx=idx.numpy(), valid=valid.numpy(),
+         kl=dist.kl(o, n).numpy(), mean_kl=np.float32(dist.mean_kl(o, n).item()),
+         mean_kl_valid=np.float32(dist.mean_kl(o, n, valid).item()),
+         entropy=dist.entropy(n).numpy(), perplexity=dist.perplexity(n).numpy(),
+         mean_entropy_valid=np.float32(dist.mean_entropy(n, valid).item()),
+         mean_perplexity_valid=np.float32(dist.mean_perplexity(n, valid).item()),
+         log_likelihood=dist.log_likelihood(idx, n).numpy(),
+         likelihood_ratio=dist.likelihood_ratio(idx, o, n).numpy(),
+         onehot=dist.to_onehot(idx).numpy())     # (the reference's DiscreteMixin.from_onehot raises: keyword typo, discrete.py:25)
+
+
 def gen_sumtree():
     out = {}
     # survey known-answer mini: SumTree(8,2,1,1), advance(4), seed-0 samples (section 8c)
@@ -1164,6 +1191,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     gens = dict(scans=gen_scans, nstep=gen_nstep, normalize=gen_normalize, losses=gen_losses,
+                categorical=gen_categorical,
                 sumtree=gen_sumtree, frames=gen_frames, replay=gen_replay,
                 seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
                 models=gen_models, sampler=gen_sampler, algos=gen_algos, algos_big=gen_algos_big,

@@ -74,6 +74,32 @@ def test_ppo_loss(name):
     np.testing.assert_allclose(v.grad.numpy(), g[f"{name}_grad_value"], rtol=1e-6, atol=1e-9)
 
 
+def test_categorical_methods_match_the_reference():
+    """Every tensor-level method of ``rlpyt_amd.distributions.categorical.Categorical`` against the
+    reference class's outputs (rlpyt/distributions/categorical.py:17-43, base.py:57-66; incl. rows
+    with exact zeros / ones where EPS decides, and the masked means)."""
+    from rlpyt_amd.distributions.categorical import Categorical, DistInfo
+    g = load_golden("categorical")
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    d = Categorical(dim=g["p_old"].shape[-1])
+    o, n, idx, valid = DistInfo(prob=t("p_old")), DistInfo(prob=t("p_new")), t("idx"), t("valid")
+    eq = lambda a, k: np.testing.assert_allclose(  # noqa: E731
+        a.numpy() if isinstance(a, torch.Tensor) else a, g[k], rtol=1e-6, atol=1e-7)
+    eq(d.kl(o, n), "kl")
+    eq(d.mean_kl(o, n).item(), "mean_kl")
+    eq(d.mean_kl(o, n, valid).item(), "mean_kl_valid")
+    eq(d.entropy(n), "entropy")
+    eq(d.perplexity(n), "perplexity")
+    eq(d.mean_entropy(n, valid).item(), "mean_entropy_valid")
+    eq(d.mean_perplexity(n, valid).item(), "mean_perplexity_valid")
+    eq(d.log_likelihood(idx, n), "log_likelihood")
+    eq(d.likelihood_ratio(idx, o, n), "likelihood_ratio")
+    assert np.array_equal(d.to_onehot(idx).numpy(), g["onehot"])
+    # (the reference's from_onehot raises -- keyword typo at rlpyt/distributions/discrete.py:25; here it
+    #  is the inverse of to_onehot)
+    assert torch.equal(d.from_onehot(d.to_onehot(idx)), idx)
+
+
 @pytest.mark.parametrize("name", ["a2c_cfg", "a2c_valid"])
 def test_a2c_loss(name):
     g = load_golden("losses")
