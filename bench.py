@@ -189,11 +189,12 @@ def main():
     cpus = usable_cpus()          # honours the cgroup quota (16 CPUs on the 256-thread bench box)
     workers = args.workers
     if workers < 0:
-        # ~10 envs per worker: waking more workers per step costs the master more than their
-        # extra parallelism returns (measured 12..64 workers at B=256: 20-32 best, flat).
-        # Workers sleep on a futex most of a step (25 of them keep ~10 CPUs busy), so the pool
-        # may exceed this rank's CPU share by ~1.6x but not more, or the quota throttles it.
-        workers = max(min(int(round(1.6 * cpus / world)) - 1, B // 10), 1)
+        # ~1.25 workers per CPU of this rank's quota share, at most one per 10 envs: waking more
+        # workers per step costs the master more than their extra parallelism returns.  With the
+        # worker loop body in C (round 3) fewer workers do: interleaved runs at B=256 on the 16-CPU
+        # box, 16 / 20 / 25 workers = 793 / 799 / 781 K SPS (means of 3; round 2, Python loop body:
+        # 20-32 flat) -- profiles/r3_rollout_sweep.jsonl.
+        workers = max(min(int(round(1.25 * cpus / world)), B // 10), 1)
     import multiprocessing as mp
     # declared host cost per env step, in fork-shared memory so that the second leg can change it
     # under the already forked env workers

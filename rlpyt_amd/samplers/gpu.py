@@ -80,7 +80,8 @@ class EnvRunner:
         self._info_arrays = info_leaves if (
             info_leaves and not any(isinstance(v, tuple) for v in env_info_np)) else None
         self._native = None            # rlpyt_amd._envloop.EnvLoop once start() has armed it
-        self.use_native = True         # False: always the Python loop body (A/B, tests)
+        # False (or RLPYT_ENVLOOP=0): always the Python loop body (A/B, tests)
+        self.use_native = os.environ.get("RLPYT_ENVLOOP", "1") != "0"
 
     def start(self, max_decorrelation_steps=0):
         """Reset (and optionally decorrelate with random actions,

@@ -27,13 +27,15 @@ except Exception as e:
 PY
 }
 run default
+RLPYT_ENVLOOP=0 run python_worker_loop           # the worker's per-step loop body in Python (round 2)
 run default_again
-run split_workers --split-workers
-run pin_workers --pin-workers
+RLPYT_SERVE_SPIN=0 run serve_spin0               # serve threads sleep instead of polling
+RLPYT_SERVE_SPIN=2000 run serve_spin2000
+run zero_copy --zero-copy                        # kernels read frames / write actions in the pinned step buffer
 run groups3 --groups 3
 run groups6 --groups 6
 run workers16 --workers 16
-run workers40 --workers 40
+run workers32 --workers 32
 run env50us --env-cost-us 50
 run env100us --env-cost-us 100
 run env200us --env-cost-us 200
