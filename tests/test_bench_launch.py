@@ -65,3 +65,26 @@ def test_bench_gpus2_same_gpu_runs_two_ranks():
     assert line["config"]["parallelism"] == "dp2"
     assert "bit-identical parameters" in r.stderr
     assert len({x["rank"] for x in line["multi_gpu"]["ranks"]}) == 2
+
+
+def test_pmc_traffic_reads_the_committed_counters():
+    """``bench.pmc_traffic`` (the ``roofline.traffic`` of the driver line) finds every region of the
+    update and both replay gathers in the newest committed ``profiles/r*pmc_counters.json``, rescales
+    by algorithmic bytes and carries the commit of the PMC pass in its source string."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    gemm_alg = 4 * (8192 * 3456 + 512 * 3456 + 8192 * 512)
+    for name, alg in (("conv1_fwd", 8192 * (33280 + 4 * 7600)), ("conv2_fwd", 8192 * 4 * (7600 + 3456)),
+                      ("conv2_bwd", 8192 * 4 * (2 * 3456 + 2 * 7600)), ("conv1_wgrad", 8192 * (33280 + 4 * 7600)),
+                      ("gemm_nt", gemm_alg), ("gemm_nt_dgrad", gemm_alg), ("gemm_tn", gemm_alg),
+                      ("frames_gather_pair", 2 * 128 * 4 * 8320 * 2),
+                      ("frames_gather_seq", 64 * 128 * 8320 + 125 * 64 * 4 * 8320)):
+        t = bench.pmc_traffic(name, {"alg_bytes_per_launch": alg})
+        assert t is not None, name
+        assert 0.9 * alg < t["bytes_per_launch"] < 3.0 * alg, (name, t)
+        assert "profiles/r" in t["source"] and "@" in t["source"], t["source"]
+        half = bench.pmc_traffic(name, {"alg_bytes_per_launch": alg // 2})
+        assert abs(half["bytes_per_launch"] * 2 - t["bytes_per_launch"]) <= 2 + 1e-6 * t["bytes_per_launch"]
+    assert bench.pmc_traffic("no_such_region", {"alg_bytes_per_launch": 1}) is None
