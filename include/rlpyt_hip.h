@@ -407,6 +407,15 @@ int rlpyt_fc_small_ksplit(int K); /* number of K slices = leading dim of the par
 int rlpyt_fc_small_f32(const float* x, const float* w, const float* bias /*nullable*/, float* y,
                        int M, int N, int K, int relu, float* workspace, rlpyt_stream_t stream);
 
+/* Epsilon-greedy selection over Q-values for the DQN-family sampling step --
+ * rlpyt/distributions/epsilon_greedy.py:17-29 (argmax, replaced by a uniformly random action with
+ * probability epsilon) -- from one pre-drawn uniform per environment: action[b] =
+ * u < eps ? floor(u / eps * A) : argmax_a q[b, a], u = uniforms[t_dev[0] * n + b] (t_dev NULL: row 0),
+ * eps = eps[b * eps_stride] (stride 0: one epsilon for all, 1: vector epsilon).  q [n, A]. */
+int rlpyt_eps_greedy_f32(const float* q, int64_t n, int A, const float* eps, int eps_stride,
+                         const float* uniforms /*[T, n]*/, const int64_t* t_dev /*nullable*/,
+                         int64_t* action /*[n]*/, rlpyt_stream_t stream);
+
 /* One LSTM cell step for the per-time-step sampling forward of the recurrent agents
  * (torch.nn.LSTM with T = 1 as used by rlpyt/models/dqn/atari_r2d1_model.py:61-63 and
  * rlpyt/models/pg/atari_lstm_model.py): the gate pre-activations arrive as the split-K partials

@@ -129,6 +129,7 @@ _SIGNATURES = {
     "rlpyt_frame_push": (c_int, [_p, _p, c_int64, c_int64, c_int64, c_int, c_int64, _p, _p, _p, _p,
                                  _p, _p, _p, _p, _p]),
     "rlpyt_fc_small_ksplit": (c_int, [c_int]),
+    "rlpyt_eps_greedy_f32": (c_int, [_p, c_int64, c_int, _p, c_int, _p, _p, _p, _p]),
     "rlpyt_lstm_cell_f32": (c_int, [_p, c_int, _p, _p, _p, _p, _p, c_int64, c_int, _p]),
     "rlpyt_pg_sample_head_f32": (c_int, [_p, c_int] + [_p] * 7 + [c_int64, c_int, c_int, _p, _p, _p,
                                                               c_int64, c_int64, _p, _p]),

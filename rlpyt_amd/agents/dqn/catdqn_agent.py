@@ -34,7 +34,8 @@ class CatDqnAgent(DqnAgent):
         prev_action = self.distribution.to_onehot(prev_action)
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         p = self.model(obs, pa, pr)
-        action = self.distribution.sample(p, generator=self.sample_generator)
+        action = self.distribution.sample(p, generator=self.sample_generator,
+                                          uniforms=self.sample_uniforms)
         return self._out(AgentStep(action=action, agent_info=AgentInfo(p=p)))
 
 

@@ -90,6 +90,12 @@ class DqnAgent(EpsilonGreedyAgentMixin, BaseAgent):
         self.distribution.bind_device(self.device, getattr(self, "_n_local_envs", None))
         self.distribution.set_epsilon(self.eps_sample)
 
+    @property
+    def supports_sample_uniforms(self):
+        """The sampler pre-draws one uniform per environment and step; the epsilon-greedy choice is
+        then one launch (``rlpyt_eps_greedy_f32``) instead of argmax + two draws + compare + where."""
+        return self.device.type == "cuda"
+
     def state_dict(self):
         return dict(model=self.model.state_dict(), target=self.target_model.state_dict())
 
@@ -98,7 +104,8 @@ class DqnAgent(EpsilonGreedyAgentMixin, BaseAgent):
         prev_action = self.distribution.to_onehot(prev_action)
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         q = self.model(obs, pa, pr)
-        action = self.distribution.sample(q, generator=self.sample_generator)
+        action = self.distribution.sample(q, generator=self.sample_generator,
+                                          uniforms=self.sample_uniforms)
         return self._out(AgentStep(action=action, agent_info=AgentInfo(q=q)))
 
     def target(self, observation, prev_action, prev_reward):

@@ -25,7 +25,8 @@ class R2d1AgentBase(DqnAgent):
         prev_action = self.distribution.to_onehot(prev_action)
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         q, rnn_state = self.sampling_model(obs, pa, pr, self.prev_rnn_state)
-        action = self.distribution.sample(q, generator=self.sample_generator)
+        action = self.distribution.sample(q, generator=self.sample_generator,
+                                          uniforms=self.sample_uniforms)
         prev = self.prev_rnn_state
         if prev is None:
             prev = buffer_func(rnn_state, torch.zeros_like)

@@ -341,6 +341,49 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
 }  // namespace
 }  // namespace rlpyt
 
+// Epsilon-greedy action selection of the DQN-family agents' sampling step
+// (rlpyt/distributions/epsilon_greedy.py:17-29: argmax, then with probability epsilon a uniformly
+// random action) from ONE pre-drawn uniform per environment and step: u < eps -> the action
+// floor(u / eps * A) (u / eps is uniform on [0, 1) given u < eps), else the first maximal Q.
+// One thread per environment; replaces argmax + rand + randint + compare + where (5 launches).
+namespace rlpyt {
+namespace {
+__global__ __launch_bounds__(256) void eps_greedy_kernel(const float* __restrict__ q, int A,
+                                                         const float* __restrict__ eps, int eps_stride,
+                                                         const float* __restrict__ uniforms,
+                                                         const int64_t* __restrict__ t_dev, int64_t n,
+                                                         int64_t* __restrict__ action) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const float* row = q + b * A;
+  int best = 0;
+  float vb = row[0];
+  for (int a = 1; a < A; ++a) {
+    const float v = row[a];
+    if (v > vb) { vb = v; best = a; }       // first maximum, as torch.argmax
+  }
+  const int64_t t = t_dev ? t_dev[0] : 0;
+  const float u = uniforms[t * n + b], e = eps[b * eps_stride];
+  int a_rand = (int)(u / e * (float)A);
+  a_rand = a_rand < A ? a_rand : A - 1;
+  action[b] = u < e ? a_rand : best;
+}
+}  // namespace
+}  // namespace rlpyt
+
+extern "C" int rlpyt_eps_greedy_f32(const float* q, int64_t n, int A, const float* eps, int eps_stride,
+                                    const float* uniforms, const int64_t* t_dev, int64_t* action,
+                                    rlpyt_stream_t stream) {
+  RL_CHECK_ARG(q && eps && uniforms && action, RLPYT_EINVAL, "rlpyt_eps_greedy_f32: null pointer");
+  RL_CHECK_ARG(n > 0 && A > 0 && (eps_stride == 0 || eps_stride == 1), RLPYT_ESHAPE,
+               "rlpyt_eps_greedy_f32: need n > 0, A > 0, eps_stride 0 | 1 (n=%ld A=%d stride=%d)",
+               (long)n, A, eps_stride);
+  RL_LAUNCH(rlpyt::eps_greedy_kernel, dim3((unsigned)rlpyt::ceil_div(n, 256)), dim3(256), 0,
+            (hipStream_t)stream, q, A, eps, eps_stride, uniforms, t_dev, n, action);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
 extern "C" int rlpyt_lstm_cell_f32(const float* partial, int ksplit, const float* b_ih,
                                    const float* b_hh, const float* c_prev, float* h_out,
                                    float* c_out, int64_t B, int H, rlpyt_stream_t stream) {

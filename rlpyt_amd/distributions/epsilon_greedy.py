@@ -86,7 +86,19 @@ class EpsilonGreedy(DiscreteMixin, Distribution):
                              f"(selected envs: {sl}); call select_envs(lo, hi) first")
         return self._scalar_buf
 
-    def sample(self, q, generator=None):
+    def _fused(self, q, uniforms):
+        """One-launch selection from the sampler's pre-drawn uniforms ``(u_all [T, n], t_dev)``: only
+        with epsilon in its device buffers (``bind_device``) and 2-D float32 Q-values on that device."""
+        if (uniforms is None or self._scalar_buf is None or q.dim() != 2 or not q.is_cuda
+                or q.dtype != torch.float32 or uniforms[0].shape[-1] != q.shape[0]):
+            return None
+        from .. import ops
+        return ops.eps_greedy(q, self._eps_for(q.shape[0]), uniforms[0], uniforms[1])
+
+    def sample(self, q, generator=None, uniforms=None):
+        fused = self._fused(q, uniforms)
+        if fused is not None:
+            return fused
         greedy = q.argmax(dim=-1)
         return _explore(greedy, q.shape[-1], self._eps_for(greedy.shape[0] if greedy.dim() else 1),
                         generator)
@@ -103,8 +115,11 @@ class CategoricalEpsilonGreedy(EpsilonGreedy):
     def set_z(self, z):
         self.z = z
 
-    def sample(self, p, z=None, generator=None):
+    def sample(self, p, z=None, generator=None, uniforms=None):
         expected = torch.tensordot(p, self.z if z is None else z, dims=1)
+        fused = self._fused(expected, uniforms)
+        if fused is not None:
+            return fused
         greedy = expected.argmax(dim=-1)
         return _explore(greedy, expected.shape[-1],
                         self._eps_for(greedy.shape[0] if greedy.dim() else 1), generator)

@@ -747,6 +747,24 @@ def fc_small_partials(x, weight):
     return ws, lib.rlpyt_fc_small_ksplit(K)
 
 
+def eps_greedy(q, eps, uniforms, t_dev=None):
+    """Epsilon-greedy actions for Q-values ``q [n, A]`` from pre-drawn uniforms ``[T, n]`` (row
+    ``t_dev[0]``, or row 0): ``u < eps ? floor(u / eps * A) : argmax`` in one launch
+    (``rlpyt_eps_greedy_f32``).  ``eps``: f32 device tensor with 1 or n entries."""
+    _lib.require_gpu()
+    q = _f32(q)
+    n, A = q.shape
+    eps = _f32(eps).reshape(-1)
+    assert eps.numel() in (1, n) and eps.device == q.device
+    uniforms = _f32(uniforms)
+    assert uniforms.shape[-1] == n and uniforms.device == q.device
+    action = torch.empty(n, dtype=torch.int64, device=q.device)
+    check(lib.rlpyt_eps_greedy_f32(ptr(q), n, A, ptr(eps), 0 if eps.numel() == 1 else 1,
+                                   ptr(uniforms), ptr(t_dev), ptr(action), stream()),
+          "rlpyt_eps_greedy_f32")
+    return action
+
+
 class LstmStep:
     """One step of a single-layer ``torch.nn.LSTM`` (no grad) for the per-time-step sampling forward
     of the recurrent agents: ``step(parts, h, c) -> (h', c')`` with ``parts`` the pieces of the input

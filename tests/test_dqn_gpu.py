@@ -306,3 +306,41 @@ def test_r2d1_model_one_step_forward_fused_vs_library_rnn():
     _lib.variant_reset()
     q, _ = m(obs, pa, pr, st)                      # grad enabled: library path
     assert q.requires_grad and _lib.variant_counts().get("lstm_cell_kernel", 0) == 0
+
+
+def test_eps_greedy_kernel_semantics():
+    """``rlpyt_eps_greedy_f32``: epsilon 0 -> torch.argmax; epsilon 1 -> floor(u * A) (uniform over
+    the actions); vector epsilon per environment; the uniforms row is picked by the device-side time
+    index; P(random) = epsilon (rlpyt/distributions/epsilon_greedy.py:17-29 in distribution)."""
+    from rlpyt_amd import _lib, ops
+    from rlpyt_amd.distributions.epsilon_greedy import EpsilonGreedy
+    g = torch.Generator().manual_seed(11)
+    n, A, T = 4096, 6, 3
+    q = torch.randn(n, A, generator=g).cuda()
+    u = torch.rand(T, n, generator=g).cuda()
+    t1 = torch.tensor([1], dtype=torch.int64, device="cuda")
+    zero, one = torch.zeros(1, device="cuda"), torch.ones(1, device="cuda")
+    assert torch.equal(ops.eps_greedy(q, zero, u, t1), q.argmax(-1))
+    a = ops.eps_greedy(q, one, u, t1)
+    assert torch.equal(a, (u[1] * A).long().clamp(max=A - 1))
+    assert torch.equal(ops.eps_greedy(q, one, u), (u[0] * A).long().clamp(max=A - 1))      # no t_dev: row 0
+    counts = torch.bincount(a, minlength=A).float() / n
+    assert (counts - 1. / A).abs().max() < 0.03
+    eps = torch.where(torch.arange(n, device="cuda") % 2 == 0, 0.25, 0.).float()
+    a = ops.eps_greedy(q, eps, u, t1)
+    greedy = q.argmax(-1)
+    assert torch.equal(a[1::2], greedy[1::2])
+    took = u[1][0::2] < 0.25
+    assert abs(took.float().mean().item() - 0.25) < 0.03
+    assert torch.equal(a[0::2][~took], greedy[0::2][~took])
+    assert torch.equal(a[0::2][took], (u[1][0::2][took] / 0.25 * A).long().clamp(max=A - 1))
+    # through the distribution object: device-bound epsilon + the sampler's (u_all, t) pair
+    d = EpsilonGreedy(dim=A)
+    d.bind_device("cuda", n_envs=n)
+    d.set_epsilon(0.25)
+    _lib.variant_reset()
+    a2 = d.sample(q, uniforms=(u, t1))
+    assert _lib.variant_counts().get("eps_greedy_kernel", 0) == 1
+    assert abs((a2 != greedy).float().mean().item() - 0.25 * (A - 1) / A) < 0.03
+    a3 = d.sample(q)                                  # no uniforms: the torch path
+    assert a3.shape == a2.shape and _lib.variant_counts().get("eps_greedy_kernel", 0) == 1

@@ -539,6 +539,12 @@ def _gemm_tn_x6():
     Cv.test_gemm_tn_bf16x6_is_f32_accurate(_ops(), 132, 200, 2080)    # ragged K chunks + partials
 
 
+@case("eps_greedy_kernel")
+def _eps_greedy():
+    import test_dqn_gpu as D
+    D.test_eps_greedy_kernel_semantics()
+
+
 @case("lstm_cell_kernel")
 def _lstm_cell():
     import test_dqn_gpu as D
