@@ -788,13 +788,16 @@ class LstmStep:
         self.wc = torch.zeros((4 * self.H, self.Kp), dtype=torch.float32, device=w_ih.device)
         self._key = None
         self._pad = {}
-        self.refresh()
+        self.refresh(force=True)
 
-    def refresh(self):
+    def refresh(self, force=False):
+        """Copy the module's current parameters into the concatenated buffer if they changed.  Not
+        while a graph is being captured (the copies would become graph nodes that re-read the
+        parameters on every replay) -- except for the very first fill, which must never be skipped."""
         lstm = self.lstm
         w_ih, w_hh = lstm.weight_ih_l0, lstm.weight_hh_l0
         key = (w_ih._version, w_hh._version, w_ih.data_ptr(), w_hh.data_ptr())
-        if key == self._key or torch.cuda.is_current_stream_capturing():
+        if not force and (key == self._key or torch.cuda.is_current_stream_capturing()):
             return
         with torch.no_grad():
             self.wc[:, :self.I].copy_(w_ih)
