@@ -30,17 +30,19 @@
 /* The step hand-off words of csrc/hostsync.cpp (rlpyt_seq_wait / rlpyt_seq_arrive), restated here so
  * that a worker's wait -> step -> arrive of one pipeline group is ONE call from Python. */
 static inline int seq_reached(uint32_t cur, uint32_t target) { return (int32_t)(cur - target) >= 0; }
-static void seq_wait(uint32_t* word, uint32_t target, int spin_iters) {
+/* Returns 0 once the word reached `target`, 1 after a futex wait ended without that (timeout of
+ * 50 ms, or EINTR from a signal): the caller -- which holds no GIL while in here -- then lets the
+ * interpreter run its signal handlers before waiting again. */
+static int seq_wait(uint32_t* word, uint32_t target, int spin_iters) {
   for (int i = 0; i < spin_iters; ++i) {
-    if (seq_reached(__atomic_load_n(word, __ATOMIC_ACQUIRE), target)) return;
+    if (seq_reached(__atomic_load_n(word, __ATOMIC_ACQUIRE), target)) return 0;
     __builtin_ia32_pause();
   }
-  for (;;) {
-    const uint32_t cur = __atomic_load_n(word, __ATOMIC_ACQUIRE);
-    if (seq_reached(cur, target)) return;
-    struct timespec ts = {0, 50 * 1000 * 1000};   /* re-check at least every 50 ms */
-    syscall(SYS_futex, word, FUTEX_WAIT, cur, &ts, NULL, 0);
-  }
+  const uint32_t cur = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+  if (seq_reached(cur, target)) return 0;
+  struct timespec ts = {0, 50 * 1000 * 1000};   /* re-check at least every 50 ms */
+  syscall(SYS_futex, word, FUTEX_WAIT, cur, &ts, NULL, 0);
+  return seq_reached(__atomic_load_n(word, __ATOMIC_ACQUIRE), target) ? 0 : 1;
 }
 static void seq_arrive(uint32_t* word, uint32_t wake_at) {
   const uint32_t now = __atomic_add_fetch(word, 1u, __ATOMIC_ACQ_REL);
@@ -85,7 +87,8 @@ typedef struct {
   Buf ret32, disc32, ret64, disc64;
   int f64_mode;                /* 0: float32 accumulators are live, 1: float64 */
   double discount;
-  int has_td, has_score;       /* -1 unknown, 0 no, 1 yes */
+  int has_td, has_score;       /* -1 unknown, 0 no, 1 yes -- for infos of type `info_type` */
+  PyTypeObject* info_type;     /* borrowed: only compared, never dereferenced */
   PyObject *s_step, *s_traj_done, *s_game_score;
   PyObject** small_ints;       /* cached action objects 0..63 */
 } EnvLoop;
@@ -154,6 +157,7 @@ static int EnvLoop_init(EnvLoop* self, PyObject* args, PyObject* kw) {
   self->discount = discount;
   self->f64_mode = f64_mode;
   self->has_td = self->has_score = -1;
+  self->info_type = NULL;
   if (buf_get(act, &self->act, 0) || buf_get(rew, &self->rew, 1) || buf_get(done, &self->done, 1) ||
       buf_get(frame, &self->frame, 1) || buf_get(reset, &self->reset, 1) || buf_get(obs, &self->obs, 1) ||
       buf_get(len_, &self->len_, 1) || buf_get(nz, &self->nz, 1) || buf_get(g, &self->g, 1) ||
@@ -322,7 +326,11 @@ static PyObject* EnvLoop_step(EnvLoop* self, PyObject* args) {
     int td = d;
     const int info_is_tuple = PyTuple_Check(info);
     const Py_ssize_t n_fields = info_is_tuple ? PyTuple_GET_SIZE(info) : 0;
-    if (n_fields > 0) {
+    if (Py_TYPE(info) != self->info_type) {     /* another info class: probe its attributes afresh */
+      self->info_type = Py_TYPE(info);
+      self->has_td = self->has_score = -1;
+    }
+    if (n_fields > 0 || (info != Py_None && !info_is_tuple)) {
       if (self->has_td != 0) {
         PyObject* v = PyObject_GetAttr(info, self->s_traj_done);
         if (v) { td = PyObject_IsTrue(v); Py_DECREF(v); self->has_td = 1; if (td < 0) { Py_DECREF(res); return NULL; } }
@@ -382,7 +390,17 @@ static PyObject* EnvLoop_step_synced(EnvLoop* self, PyObject* args) {
   unsigned long act_target, wake_at;
   if (!PyArg_ParseTuple(args, "npKkiKk", &t, &lazy, &act_word, &act_target, &spin, &obs_word, &wake_at))
     return NULL;
-  seq_wait((uint32_t*)(uintptr_t)act_word, (uint32_t)act_target, spin);
+  /* the wait releases the GIL (as the ctypes call it replaces did) and lets Python-level signal
+   * handlers (SIGINT, a SIGTERM handler) run between futex sleeps */
+  for (;;) {
+    int again;
+    Py_BEGIN_ALLOW_THREADS
+    again = seq_wait((uint32_t*)(uintptr_t)act_word, (uint32_t)act_target, spin);
+    Py_END_ALLOW_THREADS
+    if (!again) break;
+    if (PyErr_CheckSignals() != 0) return NULL;
+    spin = 0;
+  }
   PyObject* a2 = Py_BuildValue("(ni)", t, lazy);
   if (!a2) return NULL;
   PyObject* r = EnvLoop_step(self, a2);

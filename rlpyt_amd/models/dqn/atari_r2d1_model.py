@@ -48,9 +48,11 @@ class AtariR2d1Model(torch.nn.Module):
         return h0.dim() == 3 and h0.shape[0] == 1 and h0.shape[1] == B
 
     def refresh_step_weights(self):
-        """Bring the fused step's weight buffer up to date (captured step graphs read it by address)."""
+        """Bring the fused step's weight buffer up to date (captured step graphs read it by address).
+        Unconditional: two small copies per iteration, independent of how the optimizer wrote the
+        parameters (a raw-pointer kernel does not have to bump ``Tensor._version``)."""
         if self._lstm_step is not None:
-            self._lstm_step.refresh()
+            self._lstm_step.refresh(force=True)
 
     def forward(self, observation, prev_action, prev_reward, init_rnn_state):
         """Leading dims [T,B], [B] or []; prev_action one-hot; returns (q, RnnState [N,B,H])."""

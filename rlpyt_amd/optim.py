@@ -113,5 +113,8 @@ class ClipAdam(torch.optim.Adam):
             ctypes.c_void_p(self._norm.data_ptr()),
             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "rlpyt_clip_adam_step_f32")
         self._keep = rows          # the launch is asynchronous: keep the gradient tensors alive
+        # the kernel wrote the parameters through raw pointers: tell autograd / every cache keyed
+        # on ``Tensor._version`` (ops.LstmStep's concatenated weight buffer) that they changed
+        torch.autograd.graph.increment_version([r[0] for r in rows])
         self._opt_called = True    # (torch's LR schedulers check that a step preceded theirs)
         return self._norm

@@ -157,13 +157,20 @@ class EnvRunner:
                 and step.action.ndim == 1 and step.done.dtype == np.bool_
                 and o.dtype == step.observation.dtype and o.flags.c_contiguous
                 and o.shape == step.observation.shape[1:]
-                and all(a.ndim == 2 and a.dtype.kind in "fbiu" for a in (self._info_arrays or ())))
+                and all(a.ndim == 2 and a.dtype in _ENVLOOP_INFO_DTYPES
+                        for a in (self._info_arrays or ())))
 
     def _native_begin(self):
         try:
             from .. import _envloop
         except ImportError:       # extension not built: the Python loop body does the same work
             return
+        try:
+            self._native_construct(_envloop)
+        except (TypeError, ValueError):   # a buffer the C body does not handle: Python loop body
+            self._native = None
+
+    def _native_construct(self, _envloop):
         n = len(self.envs)
         ti = self.traj_infos
         st = self._nstats = AttrDict(
@@ -280,6 +287,10 @@ class EnvRunner:
                 else:
                     self.env_info[t, b] = info
 
+
+# env_info dtypes csrc/envloop.c:kind_of stores directly (anything else: Python loop body)
+_ENVLOOP_INFO_DTYPES = tuple(np.dtype(x) for x in ("float32", "float64", "bool", "int32", "int64",
+                                                   "uint8"))
 
 EVAL_TRAJ_CHECK = 20    # time steps between checks of the completed-trajectory count
 

@@ -278,6 +278,95 @@ def test_lstm_step_weight_buffer_follows_the_parameters_through_a_graph():
         assert (stale - h1).abs().max() > 1e-4          # (the replay before refresh() was on the old weights)
 
 
+def test_lstm_step_follows_clip_adam_raw_pointer_updates():
+    """``ClipAdam.clip_and_step`` writes the parameters through raw pointers.  The
+    fused step must still see the new weights -- eagerly (the optimizer bumps ``Tensor._version``)
+    and through a captured graph after the per-iteration ``refresh_step_weights()`` (forced copy)."""
+    from rlpyt_amd import ops
+    from rlpyt_amd.optim import ClipAdam
+    torch.manual_seed(11)
+    lstm = torch.nn.LSTM(71, 32).cuda()
+    opt = ClipAdam(lstm.parameters(), lr=5e-2)
+    step = ops.LstmStep(lstm)
+    x, h, c = (torch.randn(8, n, device="cuda") for n in (71, 32, 32))
+    with torch.no_grad():
+        for _ in range(3):
+            step.step([x], h, c)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            h1, c1 = step.step([x], h, c)
+        gr.replay()
+        before = h1.clone()
+    v0 = lstm.weight_ih_l0._version
+    for _ in range(3):                                      # real optimizer updates
+        opt.zero_grad()
+        out, _ = lstm(x[None], (h[None], c[None]))
+        out.square().sum().backward()
+        opt.clip_and_step(1.0)
+    assert lstm.weight_ih_l0._version > v0, "ClipAdam must mark the parameters it wrote as changed"
+    with torch.no_grad():
+        _, (hl, cl) = lstm(x[None], (h[None], c[None]))
+        he, ce = step.step([x], h, c)                       # eager: picks the update up by itself
+        torch.testing.assert_close(he, hl[0], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(ce, cl[0], rtol=1e-5, atol=1e-6)
+        # captured graph + a buffer that an update reached without any version bump
+        lstm.weight_ih_l0.data.view(-1)[:7].copy_(torch.randn(7, device="cuda"))     # .data: no bump
+        step._key = (lstm.weight_ih_l0._version, lstm.weight_hh_l0._version,
+                     lstm.weight_ih_l0.data_ptr(), lstm.weight_hh_l0.data_ptr())
+        step.refresh(force=True)                            # what refresh_step_weights() does
+        gr.replay()
+        torch.cuda.synchronize()
+        _, (hl2, _cl2) = lstm(x[None], (h[None], c[None]))
+        torch.testing.assert_close(h1, hl2[0], rtol=1e-5, atol=1e-6)
+        assert (before - h1).abs().max() > 1e-4
+
+
+@pytest.mark.parametrize("kind", ["r2d1", "lstm_pg"])
+def test_fused_sampling_forward_after_clip_adam_updates_equals_library_path(kind):
+    """after real ClipAdam updates the one-step sampling forward with
+    ``use_fused_lstm_step=True`` (after the agent-level ``refresh_step_weights``) equals the
+    ``nn.LSTM`` path on the SAME trained parameters."""
+    from rlpyt_amd.optim import ClipAdam
+    torch.manual_seed(9)
+    B = 6
+    if kind == "r2d1":
+        from rlpyt_amd.models.dqn.atari_r2d1_model import AtariR2d1Model
+        m = AtariR2d1Model((4, 104, 80), 6).cuda()
+    else:
+        from rlpyt_amd.models.pg.atari_lstm_model import AtariLstmModel
+        m = AtariLstmModel((4, 104, 80), 6).cuda()
+    obs = torch.randint(0, 256, (B, 4, 104, 80), dtype=torch.uint8, device="cuda")
+    pa = torch.nn.functional.one_hot(torch.randint(0, 6, (B,), device="cuda"), 6).float()
+    pr = torch.randn(B, device="cuda")
+    st = (torch.randn(1, B, 512, device="cuda") * 0.3, torch.randn(1, B, 512, device="cuda"))
+
+    def one_step():
+        with torch.no_grad():
+            return m(obs, pa, pr, st)
+
+    m.eval()
+    one_step()                                              # builds the LstmStep buffer (old weights)
+    opt = ClipAdam(m.parameters(), lr=1e-2)
+    for _ in range(3):
+        m.train()
+        opt.zero_grad()
+        out = m(obs[None], pa[None], pr[None], st)          # [T=1, B]: library path under autograd
+        sum(o.square().sum() for o in out[:-1]).backward()
+        opt.clip_and_step(10.0)
+    m.eval()
+    m._lstm_step._key = (m.lstm.weight_ih_l0._version, m.lstm.weight_hh_l0._version,
+                         m.lstm.weight_ih_l0.data_ptr(), m.lstm.weight_hh_l0.data_ptr())
+    m.refresh_step_weights()         # even with a key that claims "unchanged" the copy happens
+    fused = one_step()
+    m.use_fused_lstm_step = False
+    lib_ = one_step()
+    for a, b in zip(fused[:-1], lib_[:-1]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(fused[-1].h, lib_[-1].h, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(fused[-1].c, lib_[-1].c, rtol=1e-4, atol=1e-5)
+
+
 def test_r2d1_model_one_step_forward_fused_vs_library_rnn():
     """AtariR2d1Model's one-step no-grad forward through ``ops.LstmStep`` equals the nn.LSTM path;
     sequences and anything under autograd still take nn.LSTM."""

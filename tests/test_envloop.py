@@ -96,3 +96,65 @@ def test_native_loop_declines_what_it_does_not_cover():
     r = EnvRunner(envs, step, None, TrajInfo, False)     # wait-reset collector
     r.start(0)
     assert r._native is None
+
+
+def test_native_loop_declines_env_info_dtypes_the_c_body_cannot_store():
+    """an env_info field of a dtype csrc/envloop.c does not store (int16 here) must
+    leave the worker on the Python loop body instead of raising in ``start()``."""
+    n, T = 3, 4
+    envs = [SyntheticPong(seed=i) for i in range(n)]
+    o = envs[0].reset()
+    step = StepBufferFs(observation=np.zeros((n,) + o.shape, o.dtype), action=np.zeros(n, np.int64),
+                        reward=np.zeros(n, np.float32), done=np.zeros(n, bool),
+                        frame=np.zeros((n,) + o.shape[1:], o.dtype), reset=np.zeros(n, bool))
+    info = EnvInfo(game_score=np.zeros((T, n), np.int16), traj_done=np.zeros((T, n), bool))
+    r = EnvRunner(envs, step, info, AtariTrajInfo, True)
+    r.start(0)
+    assert r._native is None
+    completed = []
+    step.action[:] = 2
+    r.step_all(0, completed)            # the Python body runs
+    assert step.frame.any()
+
+
+class _InfoA(tuple):
+    traj_done = False
+
+
+def test_native_loop_probes_traj_done_per_info_type():
+    """``traj_done`` / ``game_score`` are looked up per info TYPE, not once for the
+    whole loop -- an env whose first infos lack ``traj_done`` must still end its trajectory when a
+    later info (another type) carries it."""
+    from collections import namedtuple
+    WithTd = namedtuple("WithTd", ["game_score", "traj_done"])
+    Plain = namedtuple("Plain", ["game_score"])
+
+    class TwoInfoEnv(SyntheticPong):
+        k = 0
+
+        def step(self, action):
+            o, r, d, info = super().step(action)
+            self.k += 1
+            if self.k < 3:
+                return EnvStep(o, r, False, Plain(0.0))
+            return EnvStep(o, r, False, WithTd(0.0, self.k == 5))
+
+    n, T = 2, 8
+    outs = []
+    for native in (True, False):
+        envs = [TwoInfoEnv(seed=i) for i in range(n)]
+        o = envs[0].reset()
+        step = StepBufferFs(observation=np.zeros((n,) + o.shape, o.dtype),
+                            action=np.zeros(n, np.int64), reward=np.zeros(n, np.float32),
+                            done=np.zeros(n, bool), frame=np.zeros((n,) + o.shape[1:], o.dtype),
+                            reset=np.zeros(n, bool))
+        r = EnvRunner(envs, step, None, TrajInfo, True)
+        r.use_native = native
+        r.start(0)
+        assert (r._native is not None) == native
+        completed = []
+        for t in range(T):
+            r.step_all(t, completed)
+        outs.append([dict(c) for c in completed])
+    assert len(outs[0]) == len(outs[1]) == n          # one finished trajectory per env (k == 5)
+    assert outs[0] == outs[1]
