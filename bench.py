@@ -110,9 +110,12 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--split-workers", action="store_true",
                     help="each env worker serves one pipeline group only (A/B lead, see DESIGN.md)")
-    ap.add_argument("--zero-copy", action="store_true",
-                    help="A/B: the step kernels read the workers' newest frames and write the actions "
-                         "directly in the page-locked step buffer (no frame H2D / action D2H per step)")
+    ap.add_argument("--no-zero-copy", action="store_true",
+                    help="A/B: hand the sampled actions to the env workers through a D2H copy instead "
+                         "of letting the step's head kernel write them in the page-locked step buffer")
+    ap.add_argument("--zero-copy-frames", action="store_true",
+                    help="A/B: the conv kernel also reads the newest frames in place over PCIe "
+                         "(round 3's --zero-copy; measured slower)")
     ap.add_argument("--no-fused-push", action="store_true",
                     help="debug: separate frame_push / conv1 / conv2 launches in the sampling step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
@@ -227,7 +230,8 @@ def main():
                          TrajInfoCls=AtariTrajInfo, max_decorrelation_steps=100,
                          n_groups=None if args.groups < 0 else args.groups,
                          use_graph=not args.no_graph, fused_push=not args.no_fused_push,
-                         split_workers=args.split_workers, zero_copy=args.zero_copy)
+                         split_workers=args.split_workers, zero_copy=not args.no_zero_copy,
+                         zero_copy_frames=args.zero_copy_frames)
     agent = AtariFfAgent()
     algo = PPO(discount=0.99, learning_rate=1e-3, value_loss_coeff=1., entropy_loss_coeff=0.01,
                clip_grad_norm=1., gae_lambda=0.98, minibatches=4, epochs=4, ratio_clip=0.1,

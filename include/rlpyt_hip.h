@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 4
+#define RLPYT_HIP_ABI_VERSION 5
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -439,6 +439,31 @@ int rlpyt_pg_sample_head_f32(const float* partial, int ksplit, const float* fc_b
                              float* value_rows, int64_t* action_rows, int64_t B, int64_t lo,
                              int64_t* action_out, rlpyt_stream_t stream);
 
+/* Round-4 trunk + head of the rollout step (same roles as rlpyt_fc_small_f32 with y == NULL and
+ * rlpyt_pg_sample_head_f32 -- the FC trunk of rlpyt/models/pg/atari_ff_model.py:52-55 and
+ * rlpyt/agents/pg/categorical.py:34-43 + rlpyt/distributions/categorical.py:28-31 -- re-tiled so
+ * that a CU ingests 64 KB instead of 218 KB per launch):
+ *   rlpyt_rollout_fc_f32: partial[s][m][n] = sum_{k in slice s} x[m,k] w[n,k], slices of 128 along
+ *     K (ksplit = rlpyt_rollout_fc_ksplit(K) <= 32), one workgroup per (64 columns, slice, 64 rows);
+ *     x [M,K], w [N,K], N % 64 == 0, K % 16 == 0, K <= 4096, M <= 1024; partial holds
+ *     rlpyt_rollout_fc_workspace_bytes(M, N, K) bytes.  fp32 MFMA, fixed order: deterministic.
+ *   rlpyt_rollout_head_f32: arguments of rlpyt_pg_sample_head_f32 (ksplit <= 32), one workgroup
+ *     per row; with bootstrap_out != NULL it writes ONLY the value head's output to
+ *     bootstrap_out[row] (the bootstrap value after the last step of a batch,
+ *     rlpyt/samplers/parallel/gpu/action_server.py:60-62) and every row / uniform pointer may be
+ *     NULL. */
+int rlpyt_rollout_fc_ksplit(int K);
+int64_t rlpyt_rollout_fc_workspace_bytes(int M, int N, int K);
+int rlpyt_rollout_fc_f32(const float* x, const float* w, float* partial, int M, int N, int K,
+                         rlpyt_stream_t stream);
+int rlpyt_rollout_head_f32(const float* partial, int ksplit, const float* fc_bias,
+                           const float* w_pi, const float* b_pi, const float* w_v,
+                           const float* b_v, const float* uniforms /*[T', n]*/,
+                           const int64_t* t_dev, int64_t n, int K, int A, float* prob_rows,
+                           float* value_rows, int64_t* action_rows, int64_t B, int64_t lo,
+                           int64_t* action_out, float* bootstrap_out /*nullable: [n]*/,
+                           rlpyt_stream_t stream);
+
 /* Frame-stack push for frame-stacked environments (rlpyt/envs/atari/atari_env.py:115-118:
  * the observation is the last C frames, newest last): the host uploads only the newest
  * frame of each env and row t of the HBM batch is rebuilt on the device,
@@ -486,6 +511,18 @@ int rlpyt_atari_sample_convs_f32(uint8_t* obs, const int64_t* t_dev, int64_t B, 
                                  const uint8_t* done_src, const float* w1, const float* b1,
                                  const float* w2, const float* b2, float scale, float* y2,
                                  rlpyt_stream_t stream);
+/* The same launch with the rebuilt stacks written to dst_stage [Bg, 4, 104, 80] instead of
+ * obs[t, lo + b] (dst_stage NULL: identical to rlpyt_atari_sample_convs_f32): the bootstrap-value
+ * pass on the observation AFTER the last step of a batch (t = T, obs[T-1] is still read, row T of
+ * the batch does not exist). */
+int rlpyt_atari_sample_convs_to_f32(uint8_t* obs, const int64_t* t_dev, int64_t B, int64_t lo,
+                                    int64_t Bg, const uint8_t* new_frame,
+                                    const uint8_t* full_rows, const int32_t* slot,
+                                    float* reward_rows /*nullable*/, const float* reward_src,
+                                    uint8_t* done_rows, const uint8_t* done_src, const float* w1,
+                                    const float* b1, const float* w2, const float* b2, float scale,
+                                    float* y2, uint8_t* dst_stage /*nullable*/,
+                                    rlpyt_stream_t stream);
 int rlpyt_atari_conv2_dgrad_f32(const float* g2, const float* y2, const float* y1, int64_t M,
                                 const float* w2, float* dy1, rlpyt_stream_t stream);
 int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void);

@@ -94,6 +94,19 @@ class CategoricalPgAgent(BaseAgent):
         return bool(m.sample_step_into(observation, out))
 
     @torch.no_grad()
+    def value_into(self, binding, dst_stage, bootstrap_out):
+        """Bootstrap value at ``t = T`` through the step's fused kernels (the sampler's tail):
+        ``binding`` as for ``step_into`` with ``push`` set; the rebuilt observations go to
+        ``dst_stage``, the values to ``bootstrap_out [Bg]``.  False: not supported here."""
+        m = self.sampling_model
+        push = getattr(binding, "push", None)
+        if self.uses_prev_inputs or push is None or not hasattr(m, "sample_value_into"):
+            return False
+        out = _HeadOut(prob_rows=None, value_rows=None, action_rows=None, action_out=None,
+                       uniforms=None, t_dev=binding.t_dev, lo=binding.lo)
+        return bool(m.sample_value_into(out, push, dst_stage, bootstrap_out))
+
+    @torch.no_grad()
     def value(self, observation, prev_action, prev_reward):
         if self.uses_prev_inputs and prev_action is not None:
             prev_action = self.distribution.to_onehot(prev_action)

@@ -2036,7 +2036,9 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
     const float* __restrict__ reward_src, uint8_t* __restrict__ done_rows,
     const uint8_t* __restrict__ done_src, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
-    float scale, float* __restrict__ y2) {
+    float scale, float* __restrict__ y2, uint8_t* __restrict__ dst_stage) {
+  // dst_stage (nullable): the rebuilt stacks go to dst_stage[b] instead of obs[t, lo + b] -- the
+  // bootstrap-value pass after the last step of a batch (t = T: row T of the batch does not exist)
   // obs_w / obs_r are the SAME batch array: row t is only written (through obs_w), row t-1 only
   // read (through obs_r), so the two restrict views never touch the same bytes -- with a single
   // pointer the compiler must order each row-(t-1) load after the previous row-t store
@@ -2085,7 +2087,8 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
     const int i = tid + k * SC_THREADS;
     if (i < PPIX * PS_F / 4) reinterpret_cast<f32x4*>(pad)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(obs_w + (t * B + lo + b) * IMG);
+  u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(
+      dst_stage != nullptr ? dst_stage + b * IMG : obs_w + (t * B + lo + b) * IMG);
   loads_wait();
   if (tid < C0 * LW) {
     reinterpret_cast<u32x4*>(img)[iw] = v;
@@ -2227,6 +2230,17 @@ extern "C" int rlpyt_atari_sample_convs_f32(
     const float* reward_src, uint8_t* done_rows, const uint8_t* done_src, const float* w1,
     const float* b1, const float* w2, const float* b2, float scale, float* y2,
     rlpyt_stream_t stream) {
+  return rlpyt_atari_sample_convs_to_f32(obs, t_dev, B, lo, Bg, new_frame, full_rows, slot,
+                                         reward_rows, reward_src, done_rows, done_src, w1, b1, w2,
+                                         b2, scale, y2, nullptr, stream);
+}
+
+extern "C" int rlpyt_atari_sample_convs_to_f32(
+    uint8_t* obs, const int64_t* t_dev, int64_t B, int64_t lo, int64_t Bg,
+    const uint8_t* new_frame, const uint8_t* full_rows, const int32_t* slot, float* reward_rows,
+    const float* reward_src, uint8_t* done_rows, const uint8_t* done_src, const float* w1,
+    const float* b1, const float* w2, const float* b2, float scale, float* y2,
+    uint8_t* dst_stage, rlpyt_stream_t stream) {
   RL_CHECK_ARG(B > 0 && lo >= 0 && Bg >= 0 && lo + Bg <= B, RLPYT_EINVAL,
                "rlpyt_atari_sample_convs_f32: bad sizes");
   if (Bg == 0) return RLPYT_OK;
@@ -2235,11 +2249,12 @@ extern "C" int rlpyt_atari_sample_convs_f32(
   RL_CHECK_ARG((reward_rows == nullptr) || (reward_src && done_rows && done_src), RLPYT_EINVAL,
                "rlpyt_atari_sample_convs_f32: reward/done rows go together");
   RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(new_frame) && RL_ALIGNED16(full_rows) &&
-                   RL_ALIGNED16(w1) && RL_ALIGNED16(w2),
+                   RL_ALIGNED16(w1) && RL_ALIGNED16(w2) && RL_ALIGNED16(dst_stage),
                RLPYT_ESHAPE, "rlpyt_atari_sample_convs_f32: buffers must be 16-byte aligned");
   RL_LAUNCH(sample_convs_kernel, dim3((unsigned)(Bg * SC_PARTS)), dim3(SC_THREADS), 0,
                      (hipStream_t)stream, obs, obs, t_dev, B, lo, new_frame, full_rows, slot,
-                     reward_rows, reward_src, done_rows, done_src, w1, b1, w2, b2, scale, y2);
+                     reward_rows, reward_src, done_rows, done_src, w1, b1, w2, b2, scale, y2,
+                     dst_stage);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

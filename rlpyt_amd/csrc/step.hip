@@ -570,3 +570,233 @@ extern "C" int rlpyt_pg_sample_head_f32(const float* partial, int ksplit, const 
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
+
+
+// --------------------------------------------------------------------------------------
+// Round-4 rollout chain, trunk + head (replaces fc_small_kernel<1> + pg_sample_head_kernel<8> on the
+// sampler's per-step path; those stay for M > 64 callers, the LSTM gate GEMM and A/B tests).
+//
+// Why: round 3's split (16 columns x K/8 per workgroup) made every CU ingest the x slab of its K
+// slice for ALL rows plus its W rows once per WAVE -- 56 MB of L2 -> L1 traffic per launch for
+// 7 MB of weights, 8.4 us, bound by the ~10..30 B/clk a CU can pull through its L1, not by MFMA
+// (1.4 us) or HBM.  The head then read 8 partials x 512 per row on 16 CUs (139 KB each, 6.2 us).
+// Here a workgroup owns 64 columns x 128 K for a block of 64 rows: W rows are loaded once per
+// workgroup (a wave owns 16 columns, all four 16-row tiles), the x slab is 32 KB (L1-resident, the
+// four waves share it), 64 KB ingest per CU instead of 218 KB, all 40 loads of a wave in flight at
+// once (one latency trip), and the head runs one WORKGROUP per row (4 waves x K/4 each, 64 CUs).
+// Partial layout [ksplit][M][N] as before; fixed summation order -> deterministic.
+namespace rlpyt {
+namespace {
+constexpr int kRfcKc = 128;       // K slice per workgroup
+constexpr int kRfcMaxSplit = 32;  // K <= 4096
+
+__global__ __launch_bounds__(256) void rollout_fc_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         float* __restrict__ partial, int M, int N,
+                                                         int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 64 + wave * 16;
+  const int ks = blockIdx.y;
+  const int k0 = ks * kRfcKc;
+  const int kn = min(kRfcKc, K - k0);                 // multiple of 16, >= 16
+  const int m0 = blockIdx.z * 64;
+  const float* __restrict__ wrow = w + (int64_t)(n0 + j) * K + k0 + 4 * kq;
+  const float* xrow[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int m = min(m0 + 16 * t + j, M - 1);        // clamped: rows >= M are computed, not stored
+    xrow[t] = x + (int64_t)m * K + k0 + 4 * kq;
+  }
+  fc_f32x4 a[8], b[8][4];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int kk = min(16 * g, kn - 16);              // short last slice: re-read, MFMAs skipped
+    a[g] = *reinterpret_cast<const fc_f32x4*>(wrow + kk);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[g][t] = *reinterpret_cast<const fc_f32x4*>(xrow[t] + kk);
+  }
+  fc_f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = fc_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    if (16 * g < kn) {
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][sp], b[g][t][sp], acc[t], 0, 0, 0);
+    }
+  }
+  // D[row = n_local = 4*kq + r][col = m_local = j]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int m = m0 + 16 * t + j;
+    if (m < M)
+      *reinterpret_cast<fc_f32x4*>(partial + ((int64_t)ks * M + m) * N + n0 + 4 * kq) = acc[t];
+  }
+}
+
+// One workgroup per row: wave w finishes the trunk for k in [w K/4, (w+1) K/4) (sum of the ksplit
+// partials in slice order, + bias, ReLU), takes its share of the 7 head dot products, the four
+// shares meet in LDS and thread 0 does softmax + inverse-CDF draw + the step's row writes (as
+// pg_sample_head_kernel).  bootstrap_out != NULL: value only, written to bootstrap_out[row] (the
+// bootstrap-value pass after the last step of a batch).
+template <int KW>   // trunk width = 256 * KW
+__global__ __launch_bounds__(256) void rollout_head_kernel(
+    const float* __restrict__ partial, int ksplit, const float* __restrict__ fc_bias,
+    const float* __restrict__ w_pi, const float* __restrict__ b_pi, const float* __restrict__ w_v,
+    const float* __restrict__ b_v, const float* __restrict__ uniforms,
+    const int64_t* __restrict__ t_dev, int64_t n, int A, float* __restrict__ prob_rows,
+    float* __restrict__ value_rows, int64_t* __restrict__ action_rows, int64_t B, int64_t lo,
+    int64_t* __restrict__ action_out, float* __restrict__ bootstrap_out) {
+  constexpr int K = 256 * KW;
+  constexpr int AMAX = 8;
+  __shared__ float red[4][AMAX + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = blockIdx.x;
+  // unconditional clamped loads, masked sums (see pg_sample_head_kernel)
+  float hv[KW];
+#pragma unroll
+  for (int i = 0; i < KW; ++i) hv[i] = 0.f;
+  const int kb = wave * 64 * KW + lane;
+#pragma unroll
+  for (int s0 = 0; s0 < kRfcMaxSplit; s0 += 8) {
+    if (s0 < ksplit) {                                 // uniform
+      float pv[KW][8];
+#pragma unroll
+      for (int i = 0; i < KW; ++i)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          pv[i][u] = partial[((int64_t)min(s0 + u, ksplit - 1) * n + row) * K + kb + 64 * i];
+#pragma unroll
+      for (int i = 0; i < KW; ++i)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hv[i] += (s0 + u < ksplit ? pv[i][u] : 0.f);
+    }
+  }
+  float wp[AMAX][KW], wvv[KW];
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    const int k = kb + 64 * i;
+    hv[i] = fmaxf(hv[i] + fc_bias[k], 0.f);
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) wp[a][i] = w_pi[min(a, A - 1) * K + k];
+    wvv[i] = w_v[k];
+  }
+  float acc[AMAX + 1];
+#pragma unroll
+  for (int a = 0; a <= AMAX; ++a) acc[a] = 0.f;
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) acc[a] = fmaf(hv[i], wp[a][i], acc[a]);
+    acc[AMAX] = fmaf(hv[i], wvv[i], acc[AMAX]);
+  }
+#pragma unroll
+  for (int a = 0; a <= AMAX; ++a) acc[a] = wave_sum(acc[a]);
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a <= AMAX; ++a) red[wave][a] = acc[a];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+#pragma unroll
+  for (int a = 0; a <= AMAX; ++a) acc[a] = ((red[0][a] + red[1][a]) + red[2][a]) + red[3][a];
+  const float val = acc[AMAX] + b_v[0];
+  if (bootstrap_out != nullptr) {
+    bootstrap_out[row] = val;
+    return;
+  }
+  const int64_t t = *t_dev;
+  const float u = uniforms[t * n + row];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) {
+      acc[a] += b_pi[a];
+      mx = fmaxf(mx, acc[a]);
+    }
+  float den = 0.f;
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) {
+      acc[a] = expf(acc[a] - mx);
+      den += acc[a];
+    }
+  const float inv = 1.f / den;
+  float cum = 0.f;
+  int pick = -1, last_pos = 0;
+  float* __restrict__ pr = prob_rows + (t * B + lo + row) * A;
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) {
+      const float p = acc[a] * inv;
+      pr[a] = p;
+      cum += p;
+      if (p > 0.f) last_pos = a;
+      if (pick < 0 && cum > u) pick = a;
+    }
+  value_rows[t * B + lo + row] = val;
+  const int64_t act = pick >= 0 ? pick : last_pos;
+  action_rows[(t + 1) * B + lo + row] = act;
+  action_out[row] = act;
+}
+}  // namespace
+}  // namespace rlpyt
+
+extern "C" int rlpyt_rollout_fc_ksplit(int K) {
+  return K > 0 ? (int)rlpyt::ceil_div(K, rlpyt::kRfcKc) : 0;
+}
+
+extern "C" int64_t rlpyt_rollout_fc_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (int64_t)rlpyt_rollout_fc_ksplit(K) * M * N * (int64_t)sizeof(float);
+}
+
+extern "C" int rlpyt_rollout_fc_f32(const float* x, const float* w, float* partial, int M, int N,
+                                    int K, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(x && w && partial, RLPYT_EINVAL, "rlpyt_rollout_fc_f32: null pointer");
+  RL_CHECK_ARG(M > 0 && M <= 1024 && N > 0 && N % 64 == 0 && K > 0 && K % 16 == 0 &&
+                   K <= rlpyt::kRfcKc * rlpyt::kRfcMaxSplit,
+               RLPYT_ESHAPE,
+               "rlpyt_rollout_fc_f32: need 0 < M <= 1024, N %% 64 == 0, K %% 16 == 0, K <= 4096 "
+               "(M=%d N=%d K=%d)", M, N, K);
+  RL_CHECK_ARG(RL_ALIGNED16(x) && RL_ALIGNED16(w) && RL_ALIGNED16(partial), RLPYT_ESHAPE,
+               "rlpyt_rollout_fc_f32: buffers must be 16-byte aligned");
+  const dim3 grid((unsigned)(N / 64), (unsigned)rlpyt_rollout_fc_ksplit(K),
+                  (unsigned)rlpyt::ceil_div(M, 64));
+  RL_LAUNCH(rlpyt::rollout_fc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, partial, M, N, K);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_rollout_head_f32(const float* partial, int ksplit, const float* fc_bias,
+                                      const float* w_pi, const float* b_pi, const float* w_v,
+                                      const float* b_v, const float* uniforms,
+                                      const int64_t* t_dev, int64_t n, int K, int A,
+                                      float* prob_rows, float* value_rows, int64_t* action_rows,
+                                      int64_t B, int64_t lo, int64_t* action_out,
+                                      float* bootstrap_out, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(partial && fc_bias && w_pi && b_pi && w_v && b_v, RLPYT_EINVAL,
+               "rlpyt_rollout_head_f32: null pointer");
+  RL_CHECK_ARG(bootstrap_out != nullptr ||
+                   (uniforms && t_dev && prob_rows && value_rows && action_rows && action_out),
+               RLPYT_EINVAL, "rlpyt_rollout_head_f32: null pointer (step mode needs every output)");
+  RL_CHECK_ARG(n > 0 && ksplit > 0 && ksplit <= rlpyt::kRfcMaxSplit && A > 0 && A <= 8 &&
+                   (K == 512 || K == 256) && lo >= 0 && (bootstrap_out != nullptr || lo + n <= B),
+               RLPYT_ESHAPE, "rlpyt_rollout_head_f32: need 0<A<=8, K in {256,512}, ksplit<=32, lo+n<=B");
+  const dim3 grid((unsigned)n), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 512)
+    RL_LAUNCH((rlpyt::rollout_head_kernel<2>), grid, block, 0, s, partial, ksplit, fc_bias, w_pi,
+              b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows, action_rows, B, lo,
+              action_out, bootstrap_out);
+  else
+    RL_LAUNCH((rlpyt::rollout_head_kernel<1>), grid, block, 0, s, partial, ksplit, fc_bias, w_pi,
+              b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows, action_rows, B, lo,
+              action_out, bootstrap_out);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}

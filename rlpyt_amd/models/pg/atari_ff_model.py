@@ -151,11 +151,53 @@ class AtariFfModel(torch.nn.Module):
         else:
             B = image.shape[0]
             feat = self._conv_features(image.contiguous(), None)
+        self._trunk_and_head(feat, lin, out, B)
+        return True
+
+    # False (or RLPYT_ROLLOUT_V1=1): round 3's trunk / head kernels on the rollout step (A/B)
+    use_rollout_v2 = os.environ.get("RLPYT_ROLLOUT_V1", "0") != "1"
+
+    def _trunk_and_head(self, feat, lin, out, B, bootstrap_out=None):
+        """Split-K trunk partials + the head kernel that finishes them (see csrc/step.hip)."""
+        from ... import ops
+        N, K = lin.weight.shape
+        if self.use_rollout_v2 and ops.rollout_fc_ok(B, N, K):
+            partial, ksplit = ops.rollout_fc_partials(feat, lin.weight)
+            ops.rollout_head(partial, ksplit, lin.bias, self.pi.weight, self.pi.bias,
+                             self.value.weight, self.value.bias, out.uniforms, out.t_dev, B,
+                             out.prob_rows, out.value_rows, out.action_rows, out.lo, out.action_out,
+                             bootstrap_out=bootstrap_out)
+            return True
+        if bootstrap_out is not None:
+            return False
         partial, ksplit = ops.fc_small_partials(feat, lin.weight)
         ops.pg_sample_head(partial, ksplit, lin.bias, self.pi.weight, self.pi.bias,
                            self.value.weight, self.value.bias, out.uniforms, out.t_dev, B,
                            out.prob_rows, out.value_rows, out.action_rows, out.lo, out.action_out)
         return True
+
+    @torch.no_grad()
+    def sample_value_into(self, out, push, dst_stage, bootstrap_out):
+        """Bootstrap value of the observation AFTER the last step of a batch (``t = T``) through
+        the step's own kernels: frame push (rebuilt stacks -> ``dst_stage``, reward / done rows
+        ``T`` committed) + conv1 + conv2, split-K trunk, value head only -> ``bootstrap_out [Bg]``.
+        Returns False when this path does not apply (the caller then runs ``agent.value``)."""
+        from ... import ops
+        lin = self._single_fc()
+        obs = push.obs
+        ok = (obs.is_cuda and obs.dtype == torch.uint8 and obs.dim() == 5
+              and tuple(obs.shape[2:]) == (4, 104, 80) and push.new_frame.shape[0] <= 256)
+        if not (ok and self.use_rollout_v2 and self.fused_conv and self.fused_head_loss
+                and lin is not None and lin.in_features % 16 == 0):
+            return False
+        B = push.new_frame.shape[0]
+        if not ops.rollout_fc_ok(B, *lin.weight.shape):
+            return False
+        c1, c2 = self.conv.conv.conv[0], self.conv.conv.conv[2]
+        feat = ops.atari_sample_convs(obs, out.t_dev, out.lo, push.new_frame, push.full_rows,
+                                      push.slot, c1.weight, c1.bias, c2.weight, c2.bias,
+                                      scalar_rows=push.scalar_rows, dst_stage=dst_stage)
+        return self._trunk_and_head(feat, lin, out, B, bootstrap_out=bootstrap_out)
 
     def forward(self, image, prev_action, prev_reward, features_only=False):
         """[T,B,C,H,W] / [B,C,H,W] / [C,H,W] -> (pi, value) with the same lead dims.

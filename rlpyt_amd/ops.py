@@ -124,10 +124,17 @@ def discount_return_n_step(reward, done, n_step, discount, return_dest=None, don
 _ws_cache = {}
 
 
+_ws_retired = []
+
+
 def _workspace(kind, nbytes, device):
     key = (kind, device, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            # a captured hipGraph may hold the old buffer's address: outgrown workspaces are kept
+            # alive instead of going back to the allocator (they are few and small)
+            _ws_retired.append(ws)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
@@ -846,6 +853,49 @@ def pg_sample_head(partial, ksplit, fc_bias, w_pi, b_pi, w_v, b_v, uniforms, t_d
         "rlpyt_pg_sample_head_f32")
 
 
+def rollout_fc_partials(x, weight):
+    """Round-4 trunk of the rollout step: split-K partials ``[ksplit, M, N]`` of ``x @ weight.T``
+    in slices of 128 along K, one workgroup per (64 columns, slice, 64 rows)
+    (``rlpyt_rollout_fc_f32``); ``rollout_head`` finishes the sum.  Returns (partials, ksplit)."""
+    _lib.require_gpu()
+    x = _f32(x)
+    M, K = x.shape
+    N = weight.shape[0]
+    w = _f32(weight.detach())
+    ws = _workspace("rollout_fc", lib.rlpyt_rollout_fc_workspace_bytes(M, N, K), x.device)
+    check(lib.rlpyt_rollout_fc_f32(ptr(x), ptr(w), ptr(ws), M, N, K, stream()),
+          "rlpyt_rollout_fc_f32")
+    return ws, lib.rlpyt_rollout_fc_ksplit(K)
+
+
+def rollout_fc_ok(M, N, K):
+    return 0 < M <= 1024 and N % 64 == 0 and K % 16 == 0 and 0 < K <= 4096
+
+
+def rollout_head(partial, ksplit, fc_bias, w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, prob_rows,
+                 value_rows, action_rows, lo, action_out, bootstrap_out=None):
+    """Trunk finish + heads + softmax + draw + the step's row writes, one workgroup per row
+    (``rlpyt_rollout_head_f32``); ``bootstrap_out`` ([n] f32): only the value head, written there
+    (every row / uniform argument may then be None)."""
+    _lib.require_gpu()
+    A, K = w_pi.shape
+    if bootstrap_out is None:
+        B = prob_rows.shape[1]
+        assert prob_rows.is_contiguous() and value_rows.is_contiguous() and action_rows.is_contiguous()
+        assert action_rows.dtype == torch.int64 and action_out.dtype == torch.int64
+        assert uniforms.shape[-1] == n and uniforms.is_contiguous()
+    else:
+        B = 0
+        assert bootstrap_out.dtype == torch.float32 and bootstrap_out.is_contiguous()
+        assert bootstrap_out.numel() == n
+    check(lib.rlpyt_rollout_head_f32(
+        ptr(partial), int(ksplit), ptr(_f32(fc_bias.detach())), ptr(_f32(w_pi.detach())),
+        ptr(_f32(b_pi.detach())), ptr(_f32(w_v.detach()).reshape(-1)),
+        ptr(_f32(b_v.detach()).reshape(-1)), ptr(uniforms), ptr(t_dev), int(n), K, A,
+        ptr(prob_rows), ptr(value_rows), ptr(action_rows), B, int(lo), ptr(action_out),
+        ptr(bootstrap_out), stream()), "rlpyt_rollout_head_f32")
+
+
 def frame_push(obs, t_dev, lo, new_frame, full_rows, slot, stage=None, scalar_rows=None):
     """Rebuild row ``t`` (device counter) of a frame-stacked uint8 observation batch
     ``[T,B,C,*img]`` for columns ``lo:lo+Bg`` from the newest frames ``[Bg,*img]``:
@@ -872,13 +922,18 @@ def frame_push(obs, t_dev, lo, new_frame, full_rows, slot, stage=None, scalar_ro
 
 
 def atari_sample_convs(obs, t_dev, lo, new_frame, full_rows, slot, w1, b1, w2, b2,
-                       scalar_rows=None, scale=1. / 255, out=None):
+                       scalar_rows=None, scale=1. / 255, out=None, dst_stage=None):
     """``frame_push`` + conv1 + conv2 of the AtariFfModel geometry in one launch (sampling
     forward, no grad): rebuilds row ``t`` of ``obs [T,B,4,104,80]`` for columns ``lo:lo+Bg``
     exactly like ``frame_push`` and returns the conv features ``[Bg, 3456]`` of the rebuilt
-    stacks (bit-identical to ``atari_conv_stack`` on that row)."""
+    stacks (bit-identical to ``atari_conv_stack`` on that row).  ``dst_stage`` (u8
+    ``[Bg,4,104,80]``): the rebuilt stacks go there instead of ``obs[t]`` (bootstrap-value pass at
+    ``t = T``, which reads ``obs[T-1]`` but must not write a row ``T``)."""
     _lib.require_gpu()
     assert obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape[2:]) == (4, 104, 80)
+    if dst_stage is not None:
+        assert (dst_stage.dtype == torch.uint8 and dst_stage.is_contiguous()
+                and tuple(dst_stage.shape) == (new_frame.shape[0], 4, 104, 80))
     B, Bg = obs.shape[1], new_frame.shape[0]
     assert slot.dtype == torch.int32 and slot.numel() == Bg
     rr = rs = dr = ds = None
@@ -888,10 +943,10 @@ def atari_sample_convs(obs, t_dev, lo, new_frame, full_rows, slot, w1, b1, w2, b
         dr, ds = dr.view(torch.uint8), ds.view(torch.uint8)
     if out is None:
         out = torch.empty((Bg, 3456), dtype=torch.float32, device=obs.device)
-    check(lib.rlpyt_atari_sample_convs_f32(
+    check(lib.rlpyt_atari_sample_convs_to_f32(
         ptr(obs), ptr(t_dev), B, int(lo), Bg, ptr(new_frame), ptr(full_rows), ptr(slot), ptr(rr),
         ptr(rs), ptr(dr), ptr(ds), ptr(w1.contiguous()), ptr(b1), ptr(w2.contiguous()), ptr(b2),
-        float(scale), ptr(out), stream()), "rlpyt_atari_sample_convs_f32")
+        float(scale), ptr(out), ptr(dst_stage), stream()), "rlpyt_atari_sample_convs_to_f32")
     return out
 
 

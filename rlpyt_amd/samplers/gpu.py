@@ -512,7 +512,8 @@ class GpuSampler(BaseSampler):
 
     def __init__(self, *args, n_workers=None, mid_batch_reset=True, pin_step_buffer=True,
                  n_groups=None, use_graph=True, frame_dedup=True, native_loop=True, fused_step=True,
-                 fused_push=True, split_workers=False, zero_copy=False, **kwargs):
+                 fused_push=True, split_workers=False, zero_copy=True, zero_copy_frames=False,
+                 **kwargs):
         super().__init__(*args, **kwargs)
         # n_workers=None: one env worker per entry of affinity["workers_cpus"], the reference's
         # rule (rlpyt/samplers/parallel/base.py:157-172), resolved in initialize(); an explicit
@@ -527,7 +528,11 @@ class GpuSampler(BaseSampler):
         self.fused_step = bool(fused_step)
         self.fused_push = bool(fused_push)
         self._split_workers = bool(split_workers)
+        # zero_copy: the step's head kernel writes the sampled actions straight into the page-locked
+        # step buffer the workers read (no D2H copy node / launch); zero_copy_frames: the conv
+        # kernel also READS the newest frames in place over PCIe (measured slower: off)
         self.zero_copy = bool(zero_copy)
+        self.zero_copy_frames = bool(zero_copy_frames)
         self._native = None
         self._resolve_layout(None)
         self._pinned_ptrs = []
@@ -627,19 +632,25 @@ class GpuSampler(BaseSampler):
             # ... followed by the int64 time index of the step (master-written)
             t_off = 8 * Bg + ((2 * Bg + 15) // 16) * 16
             nbytes = t_off + 16
-            misc = (np_mp_array(nbytes, np.uint8) if shared else np.zeros(nbytes, np.uint8))
-            misc[:] = 0
+            # frame-stacked envs: the newest frames and the misc block are ONE contiguous region
+            # (frames first), so a group-step's whole upload is a single H2D transfer
+            fr_bytes = Bg * int(o[-1].nbytes) if self._dedup_capable else 0
+            blk = (np_mp_array(fr_bytes + nbytes, np.uint8) if shared
+                   else np.zeros(fr_bytes + nbytes, np.uint8))
+            blk[:] = 0
+            misc = blk[fr_bytes:]
             fields = dict(
                 observation=buffer_from_example(o, (Bg,), share_memory=shared),
                 action=buffer_from_example(a_t, (Bg,), share_memory=shared),
                 reward=misc[:4 * Bg].view(np.float32),
                 done=misc[8 * Bg:9 * Bg].view(np.bool_))
             if self._dedup_capable:
-                step_np = StepBufferFs(frame=buffer_from_example(o[-1], (Bg,), share_memory=shared),
+                step_np = StepBufferFs(frame=blk[:fr_bytes].view(o.dtype).reshape((Bg,) + o[-1].shape),
                                        reset=misc[9 * Bg:10 * Bg].view(np.bool_), **fields)
             else:
                 step_np = StepBuffer(**fields)
-            G = AttrDict(idx=g, lo=lo, hi=hi, Bg=Bg, step_np=step_np, misc_np=misc, calls=0,
+            G = AttrDict(idx=g, lo=lo, hi=hi, Bg=Bg, step_np=step_np, misc_np=misc, blk_np=blk,
+                         fr_bytes=fr_bytes, calls=0,
                          graph=None, t_np=misc[t_off:t_off + 8].view(np.int64), t_off=t_off)
             self.groups.append(G)
             # workers of this group: every worker (each then serves all groups in turn; default),
@@ -777,7 +788,9 @@ class GpuSampler(BaseSampler):
             G.step_pyt = torchify_buffer(G.step_np)
             G.misc_h = torch.from_numpy(G.misc_np)
             G.obs_stage = buffer_from_example(ex["observation"], (Bg,), device=dev)
-            G.misc_stage = torch.zeros(G.misc_np.size, dtype=torch.uint8, device=dev)
+            G.blk_h = torch.from_numpy(G.blk_np)
+            G.blk_stage = torch.zeros(G.blk_np.size, dtype=torch.uint8, device=dev)
+            G.misc_stage = G.blk_stage[G.fr_bytes:]
             G.reward_stage = G.misc_stage[:4 * Bg].view(torch.float32)
             G.done_stage = G.misc_stage[8 * Bg:9 * Bg].view(torch.bool)
             G.dedup = self._dedup_capable and cuda
@@ -785,8 +798,7 @@ class GpuSampler(BaseSampler):
                 G.slot_np = G.misc_np[4 * Bg:8 * Bg].view(np.int32)
                 G.slot_stage = G.misc_stage[4 * Bg:8 * Bg].view(torch.int32)
                 G.frame_h = torch.from_numpy(G.step_np.frame)
-                G.frame_stage = torch.zeros((Bg,) + tuple(observation.shape[3:]),
-                                            dtype=torch.uint8, device=dev)
+                G.frame_stage = G.blk_stage[:G.fr_bytes].view((Bg,) + tuple(observation.shape[3:]))
                 G.full_rows = torch.zeros((Bg,) + tuple(observation.shape[2:]),
                                           dtype=torch.uint8, device=dev)
                 G.slot_all = np.arange(Bg, dtype=np.int32)
@@ -823,9 +835,7 @@ class GpuSampler(BaseSampler):
             if cuda and self.pin_step_buffer:
                 from .. import _lib
                 arrs = buffer_leaves(G.step_np.observation) + buffer_leaves(G.step_np.action)
-                if G.dedup:
-                    arrs = arrs + [G.step_np.frame]
-                for arr in arrs + [G.misc_np]:
+                for arr in arrs + [G.blk_np]:      # (frames + misc are one block)
                     rc = _lib.lib.rlpyt_host_register(ctypes.c_void_p(arr.ctypes.data),
                                                       int(arr.nbytes))
                     if rc == 0:
@@ -833,23 +843,32 @@ class GpuSampler(BaseSampler):
                     else:
                         logger.log(f"hipHostRegister failed ({_lib.last_error()}); "
                                    "falling back to pageable copies.")
-        # zero-copy (option, off by default): the device reads the workers' newest frames and
-        # writes the sampled actions directly in the page-locked step buffer -- two DMA transfers
-        # less per group-step.  Bit-identical batches; measured neutral on the bench host
-        # (490-500 K SPS either way: the DMA latencies were not on the critical path)
+        # zero-copy hand-off of the actions (default): the head kernel of the step writes them in
+        # place in the page-locked step buffer the workers read -- no D2H launch per group-step (it
+        # was a 3.8 us blit kernel on the device's serial chain plus one API call on the host's).
+        # zero_copy_frames (off): also READ the workers' newest frames in place over PCIe; measured
+        # slower in round 3 (the conv kernel then waits ~10 us for 532 KB of PCIe reads while it
+        # holds every CU), so the frames + misc block keep travelling as ONE DMA.
         for G in self.groups:
-            G.zc = False
-            if (cuda and self.zero_copy and self.pin_step_buffer and G.dedup
+            G.zc_out = G.zc_in = False
+            pinned = self._pinned_ptrs
+            if (cuda and self.zero_copy and self.pin_step_buffer
                     and isinstance(G.step_np.action, np.ndarray)
-                    and G.step_np.frame.ctypes.data in self._pinned_ptrs
-                    and G.step_np.action.ctypes.data in self._pinned_ptrs):
+                    and G.step_np.action.ctypes.data in pinned):
+                try:
+                    from .. import _lib
+                    G.action_out = _lib.host_mapped_tensor(G.step_np.action, dev)
+                    G.zc_out = True
+                except Exception as e:  # noqa: BLE001
+                    logger.log(f"GpuSampler: zero-copy action hand-off unavailable ({e}); using DMA.")
+            if (G.zc_out and self.zero_copy_frames and G.dedup and G.blk_np.ctypes.data in pinned):
                 try:
                     from .. import _lib
                     G.frame_stage = _lib.host_mapped_tensor(G.step_np.frame, dev)
-                    G.action_out = _lib.host_mapped_tensor(G.step_np.action, dev)
-                    G.zc = True
+                    G.zc_in = True
                 except Exception as e:  # noqa: BLE001
-                    logger.log(f"GpuSampler: zero-copy step buffer unavailable ({e}); using DMA.")
+                    logger.log(f"GpuSampler: zero-copy frame reads unavailable ({e}); using DMA.")
+            G.zc = G.zc_out        # (name kept for the tests / bench line)
         self._lazy_obs.value = bool(all(G.dedup for G in self.groups))
         self._device_ready = True
 
@@ -956,6 +975,38 @@ class GpuSampler(BaseSampler):
             self._commit_rows(s.agent.agent_info, agent_info, G, t)
             _copy_leaves(G.action_out, action)
 
+    def _tail_fused(self, G, cuda):
+        """The tail as ONE more step of the group's fused kernels (non-recurrent agents that ignore
+        prev inputs, frame-stacked uploads, mid-batch reset): upload the newest frames + misc
+        block with t = T, rebuild obs_T into the staging buffer, commit reward / done rows T, and
+        run trunk + VALUE head only -> bootstrap_value[0, lo:hi].  Round 3 went through the
+        training-time conv kernels, three library GEMMs and a softmax per group here (2.3 ms of
+        wall for the 4 groups).  Returns False when it does not apply."""
+        T = self.batch_spec.T
+        s = self.samples
+        agent = self.agent
+        if not (cuda and G.dedup and G.u_all is not None and self.mid_batch_reset
+                and self.fused_step and self.fused_push and not G.zc_in
+                and "bootstrap_value" in s.agent and not agent.recurrent
+                and not getattr(agent, "uses_prev_inputs", True)
+                and hasattr(agent, "value_into") and isinstance(self._all_action, torch.Tensor)):
+            return False
+        bv = s.agent.bootstrap_value
+        if not (isinstance(bv, torch.Tensor) and bv.dtype == torch.float32 and bv.is_contiguous()):
+            return False
+        G.t_np[0] = T
+        self._upload_special(G, cuda, first=False)
+        self._upload_steady(G, cuda)
+        binding = StepBinding(
+            action_rows=self._all_action, agent_info_rows=s.agent.agent_info,
+            action_out=G.action_out, uniforms=G.u_all, t_dev=G.t_dev, lo=G.lo,
+            push=FramePush(obs=s.env.observation, new_frame=G.frame_stage,
+                           full_rows=G.full_rows, slot=G.slot_stage,
+                           scalar_rows=(self._all_reward, G.reward_stage, self._all_done,
+                                        G.done_stage)))
+        agent.select_envs(G.lo, G.hi)
+        return bool(agent.value_into(binding, G.obs_stage, bv[0, G.lo:G.hi]))
+
     def _tail_body(self, G):
         """After the last env step of the batch: commit reward/done of step T-1 and compute
         the bootstrap value on obs_T (action_server.py:60-62)."""
@@ -1001,15 +1052,15 @@ class GpuSampler(BaseSampler):
     def _upload_steady(self, G, nb):
         """Fixed-address part of the upload: newest frames (or whole observations) + the
         reward/slot/done/reset block."""
-        if G.dedup:
-            if not G.zc:
-                G.frame_stage.copy_(G.frame_h, non_blocking=nb)
-        else:
+        if G.dedup and not G.zc_in:
+            G.blk_stage.copy_(G.blk_h, non_blocking=nb)      # newest frames + misc: one transfer
+            return
+        if not G.dedup:
             _copy_leaves(G.obs_stage, G.step_pyt.observation, non_blocking=nb)
         G.misc_stage.copy_(G.misc_h, non_blocking=nb)
 
     def _download(self, G, nb):
-        if not G.zc:      # zero-copy: the step kernel already wrote the host buffer
+        if not G.zc_out:      # zero-copy: the step kernel already wrote the host buffer
             _copy_leaves(G.step_pyt.action, G.action_out, non_blocking=nb)
 
     def _on_stream(self, G):
@@ -1063,13 +1114,14 @@ class GpuSampler(BaseSampler):
             sg.act_word, sg.obs_word = self.sync.act[G.idx], self.sync.obs[G.idx]
             sg.n_workers = G.n_workers
             h2d = []
-            if G.dedup:
-                if not G.zc:
-                    h2d.append((G.frame_stage, G.frame_h))
+            if G.dedup and not G.zc_in:
+                h2d.append((G.blk_stage, G.blk_h))
             else:
-                h2d += list(zip(buffer_leaves(G.obs_stage), buffer_leaves(G.step_pyt.observation)))
-            h2d.append((G.misc_stage, G.misc_h))
-            d2h = ([] if G.zc else
+                if not G.dedup:
+                    h2d += list(zip(buffer_leaves(G.obs_stage),
+                                    buffer_leaves(G.step_pyt.observation)))
+                h2d.append((G.misc_stage, G.misc_h))
+            d2h = ([] if G.zc_out else
                    list(zip(buffer_leaves(G.step_pyt.action), buffer_leaves(G.action_out))))
             if len(h2d) > 8 or len(d2h) > 4:
                 self.native_loop = False
@@ -1211,6 +1263,9 @@ class GpuSampler(BaseSampler):
             if par:
                 self._wait_obs(G)
             with self._on_stream(G):
+                if getattr(G, "tail_fused", True) and self._tail_fused(G, cuda):
+                    continue
+                G.tail_fused = False      # decided once per group: the conditions do not change
                 _copy_leaves(G.obs_stage, G.step_pyt.observation, non_blocking=cuda)
                 G.misc_stage.copy_(G.misc_h, non_blocking=cuda)
                 self._tail_body(G)

@@ -31,7 +31,7 @@ RLPYT_ENVLOOP=0 run python_worker_loop           # the worker's per-step loop bo
 run default_again
 RLPYT_SERVE_SPIN=0 run serve_spin0               # serve threads sleep instead of polling
 RLPYT_SERVE_SPIN=2000 run serve_spin2000
-run zero_copy --zero-copy                        # kernels read frames / write actions in the pinned step buffer
+run zero_copy_frames --zero-copy-frames                        # kernels read frames / write actions in the pinned step buffer
 run groups3 --groups 3
 run groups6 --groups 6
 run workers16 --workers 16

@@ -250,11 +250,14 @@ def test_fused_step_matches_unfused_step():
 
 
 def test_zero_copy_step_buffer_matches_dma():
-    """Kernels reading the newest frames / writing the actions in place in the page-locked step
-    buffer (zero-copy) give exactly the batches of the DMA path."""
-    def run(zc):
+    """The head kernel writing the actions in place in the page-locked step buffer (zero-copy, the
+    default), and additionally the conv kernel reading the newest frames in place
+    (``zero_copy_frames``), give exactly the batches of the all-DMA path (one H2D of the
+    frames + misc block, one D2H of the actions)."""
+    def run(zc, zcf=False):
         s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=7), batch_T=6, batch_B=8,
-                       n_workers=2, n_groups=2, zero_copy=zc, max_decorrelation_steps=0)
+                       n_workers=2, n_groups=2, zero_copy=zc, zero_copy_frames=zcf,
+                       max_decorrelation_steps=0)
         a = AtariFfAgent()
         torch.manual_seed(41)
         np.random.seed(41)
@@ -270,13 +273,13 @@ def test_zero_copy_step_buffer_matches_dma():
                                             smp.env.reward, smp.env.done,
                                             smp.agent.agent_info.dist_info.prob,
                                             smp.agent.bootstrap_value)])
-        assert all(G.zc == zc for G in s.groups)
+        assert all(G.zc_out == zc and G.zc_in == zcf for G in s.groups)
         s.shutdown()
         return out
-    a, b = run(True), run(False)
-    for x, y in zip(a, b):
-        for u, v in zip(x, y):
-            assert torch.equal(u, v)
+    a, b, c = run(True), run(False), run(True, True)
+    for x, y, z in zip(a, b, c):
+        for u, v, w in zip(x, y, z):
+            assert torch.equal(u, v) and torch.equal(u, w)
 
 
 def test_sample_convs_kernel_matches_separate_launches():
@@ -355,4 +358,46 @@ def test_fused_push_step_matches_separate_push():
                 assert torch.equal(u, v)
             else:          # values: conv1 is an f32-MFMA chain in the fused sampling kernel and
                            # exact bf16x3 in conv1_fwd -- same products, other accumulation order
+                torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-6)
+
+
+def test_fused_tail_matches_agent_value_tail(monkeypatch):
+    """The bootstrap value computed by one more pass of the step's fused kernels (frame push at
+    t = T into the staging buffer + convs, trunk, value head only) equals ``agent.value`` on the
+    uploaded full observation (round 3's tail); reward / done rows T and everything else of the
+    batches are identical, through resets on the last step of a batch."""
+    from rlpyt_amd import _lib
+
+    def run(fused_tail):
+        if not fused_tail:
+            monkeypatch.setattr(GpuSampler, "_tail_fused", lambda self, G, cuda: False)
+        s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=6), batch_T=6, batch_B=8,
+                       n_workers=2, n_groups=2, max_decorrelation_steps=0)
+        a = AtariFfAgent()
+        torch.manual_seed(61)
+        np.random.seed(61)
+        s.initialize(a, seed=12, bootstrap_value=True)
+        torch.cuda.set_device(0)
+        a.to_device(0)
+        torch.manual_seed(62)
+        out = []
+        _lib.variant_reset()
+        for itr in range(5):
+            smp, _ = s.obtain_samples(itr)
+            torch.cuda.synchronize()
+            out.append([x.clone() for x in (smp.env.observation, smp.agent.action, smp.env.reward,
+                                            smp.env.done, smp.agent.agent_info.dist_info.prob,
+                                            smp.agent.agent_info.value, smp.agent.bootstrap_value)])
+        cnt = _lib.variant_counts()
+        s.shutdown()
+        monkeypatch.undo()
+        return out, cnt
+    (a, ca), (b, cb) = run(True), run(False)
+    assert ca.get("rollout_head_kernel<2>", 0) > cb.get("rollout_head_kernel<2>", 0) > 0
+    assert any(x[3][-1].any() for x in a)       # an env finished on the last step of a batch
+    for x, y in zip(a, b):
+        for k, (u, v) in enumerate(zip(x, y)):
+            if k < 4:
+                assert torch.equal(u, v)
+            else:
                 torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-6)

@@ -457,6 +457,82 @@ CASES["pg_sample_head_kernel<8>"] = _sample_head_case(512)
 CASES["pg_sample_head_kernel<4>"] = _sample_head_case(256)
 
 
+def _rollout_head_case(K):
+    def run():
+        """Round-4 trunk (64 columns x 128-K slices, ksplit up to 27 here) + one-workgroup-per-row
+        head vs torch (f64) and vs round 3's kernels on the same inputs; step mode and value-only
+        (bootstrap) mode; n crosses a 64-row block, Kin leaves a short last slice."""
+        ops = _ops()
+        from rlpyt_amd import _lib
+        g = torch.Generator().manual_seed(K + 1)
+        A, T, B, lo = 6, 4, 90, 5
+        for n, Kin in ((70, 3456), (37, 160), (3, 16)):
+            x = torch.randn(n, Kin, generator=g).cuda()
+            w = (torch.randn(K, Kin, generator=g) * (2.0 / Kin ** 0.5)).cuda()
+            fb = torch.randn(K, generator=g).cuda()
+            wp, bp = (torch.randn(A, K, generator=g) * 0.05).cuda(), torch.randn(A, generator=g).cuda()
+            wv, bv = (torch.randn(1, K, generator=g) * 0.05).cuda(), torch.randn(1, generator=g).cuda()
+            u = torch.rand(T, n, generator=g).cuda()
+            t_dev = torch.tensor([2], dtype=torch.int64, device="cuda")
+            prob = torch.zeros(T, B, A, device="cuda")
+            val = torch.zeros(T, B, device="cuda")
+            act = torch.zeros(T + 1, B, dtype=torch.int64, device="cuda")
+            out = torch.zeros(n, dtype=torch.int64, device="cuda")
+            _lib.variant_reset()
+            part, ks = ops.rollout_fc_partials(x, w)
+            assert ks == -(-Kin // 128) and part.numel() >= ks * n * K * 4
+            ops.rollout_head(part, ks, fb, wp, bp, wv, bv, u, t_dev, n, prob, val, act, lo, out)
+            cnt = _lib.variant_counts()
+            assert cnt.get("rollout_fc_kernel", 0) == 1
+            assert cnt.get(f"rollout_head_kernel<{K // 256}>", 0) == 1
+            h = torch.relu(x.double() @ w.double().t() + fb.double())
+            rp = torch.softmax(h @ wp.double().t() + bp.double(), -1)
+            rv = (h @ wv.double().t()).squeeze(-1) + bv.double()
+            np.testing.assert_allclose(host(prob[2, lo:lo + n]), host(rp), rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(host(val[2, lo:lo + n]), host(rv), rtol=2e-5, atol=2e-5)
+            cum = np.cumsum(host(prob[2, lo:lo + n]), axis=1, dtype=np.float32)
+            exp = np.minimum((cum <= host(u[2])[:, None]).sum(1), A - 1)
+            assert np.array_equal(host(act[3, lo:lo + n]), exp) and np.array_equal(host(out), exp)
+            # the partial sums themselves: slice s of x @ w.T
+            pv = part[:ks * n * K * 4].view(torch.float32).reshape(ks, n, K)
+            ref_s = torch.stack([x[:, 128 * s_:128 * (s_ + 1)].double() @ w[:, 128 * s_:128 * (s_ + 1)].double().t()
+                                 for s_ in range(ks)])
+            assert (pv.double() - ref_s).abs().max().item() <= 2e-5 * ref_s.abs().max().item() + 1e-6
+            # value-only mode writes the same value and nothing else
+            keep = [prob.clone(), val.clone(), act.clone(), out.clone()]
+            bvout = torch.zeros(n, device="cuda")
+            ops.rollout_head(part, ks, fb, wp, bp, wv, bv, None, None, n, None, None, None, 0, None,
+                             bootstrap_out=bvout)
+            assert torch.equal(bvout, val[2, lo:lo + n])
+            for a_, b_ in zip(keep, (prob, val, act, out)):
+                assert torch.equal(a_, b_)
+            # run-to-run deterministic
+            part2, _ = ops.rollout_fc_partials(x, w)
+            bv2 = torch.zeros(n, device="cuda")
+            ops.rollout_head(part2, ks, fb, wp, bp, wv, bv, None, None, n, None, None, None, 0, None,
+                             bootstrap_out=bv2)
+            assert torch.equal(bv2, bvout)
+            if Kin % 16 == 0 and n <= 256:      # round 3's pair on the same inputs
+                p3 = torch.zeros(T, B, A, device="cuda")
+                v3 = torch.zeros(T, B, device="cuda")
+                a3 = torch.zeros(T + 1, B, dtype=torch.int64, device="cuda")
+                o3 = torch.zeros(n, dtype=torch.int64, device="cuda")
+                part3, ks3 = ops.fc_small_partials(x, w)
+                ops.pg_sample_head(part3, ks3, fb, wp, bp, wv, bv, u, t_dev, n, p3, v3, a3, lo, o3)
+                torch.testing.assert_close(prob, p3, rtol=2e-5, atol=1e-7)
+                torch.testing.assert_close(val, v3, rtol=2e-5, atol=2e-5)
+            prob[2, lo:lo + n] = 0
+            val[2, lo:lo + n] = 0
+            act[3, lo:lo + n] = 0
+            assert not prob.any() and not val.any() and not act.any()   # nothing else written
+    return run
+
+
+CASES["rollout_head_kernel<2>"] = _rollout_head_case(512)
+CASES["rollout_head_kernel<1>"] = _rollout_head_case(256)
+CASES["rollout_fc_kernel"] = _rollout_head_case(512)
+
+
 @case("frame_push_kernel")
 def _frame_push():
     """obs[t] = concat(obs[t-1][1:], newest frame), or a full row where slot >= 0; reward / done
