@@ -116,6 +116,9 @@ def parse():
     ap.add_argument("--zero-copy-frames", action="store_true",
                     help="A/B: the conv kernel also reads the newest frames in place over PCIe "
                          "(round 3's --zero-copy; measured slower)")
+    ap.add_argument("--frozen-env", action="store_true",
+                    help="diagnostics: env.step() returns the standing observation (no dynamics, no "
+                         "drawing) -- the rollout's floor without the synthetic env's own cost")
     ap.add_argument("--no-fused-push", action="store_true",
                     help="debug: separate frame_push / conv1 / conv2 launches in the sampling step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
@@ -203,6 +206,8 @@ def main():
     # under the already forked env workers
     cost_ref = mp.get_context("fork").RawValue("d", float(args.env_cost_us))
     env_kwargs = dict(step_cost_ref=cost_ref)
+    if args.frozen_env:
+        env_kwargs["frozen"] = True
     leg_steps = args.env_cost_leg_steps if (args.env_cost_leg_us > 0 and args.env_cost_us == 0) else 0
     n_itr_total = args.warmup + args.steps + (1 + leg_steps if leg_steps else 0)
     # worker processes and their CPUs the reference's way: one worker per entry of
@@ -269,6 +274,8 @@ def main():
         ktimer.enable(True)
     for k in sampler.timing:
         sampler.timing[k] = 0.
+    wt = getattr(getattr(sampler, "ctrl", None), "worker_timing", None)
+    wt0 = None if wt is None else wt.copy()
     sync()
     t0 = time.perf_counter()
     t_sample = 0.
@@ -284,6 +291,20 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimer.enable(False)
     timing = dict(sampler.timing)         # (the env-cost leg below keeps adding to sampler.timing)
+    worker_ms = None
+    if wt0 is not None:
+        # per env worker and time step: ms waiting for the master's actions / ms stepping envs
+        d = (wt - wt0) / (args.steps * T) * 1e-6
+        dd = wt - wt0
+        worker_ms = {"wait_mean": float(d[:, 0].mean()), "wait_max": float(d[:, 0].max()),
+                     "step_mean": float(d[:, 1].mean()), "step_max": float(d[:, 1].max()),
+                     # of the group-steps a worker really had to wait for: share, and us from the
+                     # master's post to the worker running again
+                     "waited_frac": float(dd[:, 4].sum() / max(dd[:, 2].sum(), 1.)),
+                     "wake_us_mean": float(dd[:, 3].sum() / max(dd[:, 4].sum(), 1.) * 1e-3)}
+        n_gs = max(timing.get("chain_steps", 0.), 1.)
+        worker_ms["chain_us"] = {k: timing.get(f"chain_{k}_s", 0.) / n_gs * 1e6
+                                 for k in ("issue", "device", "post")}
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -388,7 +409,8 @@ def main():
                         "master_wait_device_ms":
                             timing["device_wait_s"] / args.steps / T * 1e3,
                         "per_batch_ms": {k[:-2]: timing[k] / args.steps * 1e3
-                                         for k in ("pre_s", "loop_s", "tail_s", "post_s")}},
+                                         for k in ("pre_s", "loop_s", "tail_s", "post_s")},
+                        "worker_ms_per_time_step": worker_ms},
             "last_loss": opt_info.loss[-1] if opt_info.loss else None,
             "losses_finite": all(x == x and abs(x) != float("inf") for x in opt_info.loss),
         }

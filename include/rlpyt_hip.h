@@ -393,7 +393,7 @@ typedef struct rlpyt_step_group {
   void* event;      /* hipEvent_t */
 } rlpyt_step_group;
 int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t_begin, int t_end,
-                        int spin_iters, int timeout_ms, double* timing /*[3], nullable*/);
+                        int spin_iters, int timeout_ms, double* timing /*[8], nullable*/);
 
 /* Small-batch fully connected layer (+ optional ReLU) for the sampling forward -- the
  * 3456 -> 512 trunk of rlpyt/models/pg/atari_ff_model.py:52-55 (rlpyt/models/mlp.py) at

@@ -29,6 +29,11 @@
 
 /* The step hand-off words of csrc/hostsync.cpp (rlpyt_seq_wait / rlpyt_seq_arrive), restated here so
  * that a worker's wait -> step -> arrive of one pipeline group is ONE call from Python. */
+static inline uint64_t mono_ns(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
 static inline int seq_reached(uint32_t cur, uint32_t target) { return (int32_t)(cur - target) >= 0; }
 /* Returns 0 once the word reached `target`, 1 after a futex wait ended without that (timeout of
  * 50 ms, or EINTR from a signal): the caller -- which holds no GIL while in here -- then lets the
@@ -91,6 +96,9 @@ typedef struct {
   PyTypeObject* info_type;     /* borrowed: only compared, never dereferenced */
   PyObject *s_step, *s_traj_done, *s_game_score;
   PyObject** small_ints;       /* cached action objects 0..63 */
+  /* where a worker's time goes (step_synced only): waiting for the master's actions vs stepping */
+  uint64_t wait_ns, step_ns, n_synced;
+  uint64_t wake_ns, n_waited;  /* post -> running again, for the waits that really waited */
 } EnvLoop;
 
 static int kind_of(const char* fmt, Py_ssize_t itemsize) {
@@ -158,6 +166,7 @@ static int EnvLoop_init(EnvLoop* self, PyObject* args, PyObject* kw) {
   self->f64_mode = f64_mode;
   self->has_td = self->has_score = -1;
   self->info_type = NULL;
+  self->wait_ns = self->step_ns = self->n_synced = self->wake_ns = self->n_waited = 0;
   if (buf_get(act, &self->act, 0) || buf_get(rew, &self->rew, 1) || buf_get(done, &self->done, 1) ||
       buf_get(frame, &self->frame, 1) || buf_get(reset, &self->reset, 1) || buf_get(obs, &self->obs, 1) ||
       buf_get(len_, &self->len_, 1) || buf_get(nz, &self->nz, 1) || buf_get(g, &self->g, 1) ||
@@ -392,6 +401,9 @@ static PyObject* EnvLoop_step_synced(EnvLoop* self, PyObject* args) {
     return NULL;
   /* the wait releases the GIL (as the ctypes call it replaces did) and lets Python-level signal
    * handlers (SIGINT, a SIGTERM handler) run between futex sleeps */
+  const uint64_t t0 = mono_ns();
+  const int had_to_wait = !seq_reached(__atomic_load_n((uint32_t*)(uintptr_t)act_word, __ATOMIC_ACQUIRE),
+                                       (uint32_t)act_target);
   for (;;) {
     int again;
     Py_BEGIN_ALLOW_THREADS
@@ -401,6 +413,15 @@ static PyObject* EnvLoop_step_synced(EnvLoop* self, PyObject* args) {
     if (PyErr_CheckSignals() != 0) return NULL;
     spin = 0;
   }
+  const uint64_t t1 = mono_ns();
+  if (had_to_wait) {
+    /* the master stamps CLOCK_MONOTONIC ns of its post next to the sequence word (csrc/serve.cpp) */
+    const uint64_t posted = *(volatile uint64_t*)((char*)(uintptr_t)act_word + 8);
+    if (posted != 0 && t1 >= posted && t1 - posted < 1000000000ull) {
+      self->wake_ns += t1 - posted;
+      self->n_waited += 1;
+    }
+  }
   PyObject* a2 = Py_BuildValue("(ni)", t, lazy);
   if (!a2) return NULL;
   PyObject* r = EnvLoop_step(self, a2);
@@ -408,7 +429,19 @@ static PyObject* EnvLoop_step_synced(EnvLoop* self, PyObject* args) {
   if (!r) return NULL;
   Py_DECREF(r);
   seq_arrive((uint32_t*)(uintptr_t)obs_word, (uint32_t)wake_at);
+  self->wait_ns += t1 - t0;
+  self->step_ns += mono_ns() - t1;
+  self->n_synced += 1;
   Py_RETURN_NONE;
+}
+
+/* timing() -> (wait_ns, step_ns, calls) accumulated by step_synced since the last call; resets. */
+static PyObject* EnvLoop_timing(EnvLoop* self, PyObject* Py_UNUSED(ignored)) {
+  PyObject* r = Py_BuildValue("(KKKKK)", (unsigned long long)self->wait_ns,
+                              (unsigned long long)self->step_ns, (unsigned long long)self->n_synced,
+                              (unsigned long long)self->wake_ns, (unsigned long long)self->n_waited);
+  self->wait_ns = self->step_ns = self->n_synced = self->wake_ns = self->n_waited = 0;
+  return r;
 }
 
 static PyObject* EnvLoop_f64_mode(EnvLoop* self, PyObject* Py_UNUSED(ignored)) {
@@ -419,6 +452,8 @@ static PyMethodDef EnvLoop_methods[] = {
     {"step", (PyCFunction)EnvLoop_step, METH_VARARGS, "step(t, lazy): one time step of every env"},
     {"step_synced", (PyCFunction)EnvLoop_step_synced, METH_VARARGS,
      "step_synced(t, lazy, act_word, act_target, spin, obs_word, wake_at): wait, step, arrive"},
+    {"timing", (PyCFunction)EnvLoop_timing, METH_NOARGS,
+     "timing() -> (wait_ns, step_ns, calls) of step_synced since the last call (and reset)"},
     {"f64_mode", (PyCFunction)EnvLoop_f64_mode, METH_NOARGS, "True once the float64 sums are live"},
     {NULL, NULL, 0, NULL}};
 

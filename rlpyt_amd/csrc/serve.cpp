@@ -97,6 +97,11 @@ struct ServeShared {
   std::atomic<int> remaining;
   std::atomic<int> error;      // first error code (0 = none)
   double t_wait_dev;           // retire thread: idle time with work in flight on the device
+  // hand-off chain of a group-step, summed over all of them (seconds): workers all arrived ->
+  // issue calls returned -> completion seen by the retire thread -> actions published
+  double t_ready[16], t_issued[16];
+  double lat_issue, lat_device, lat_post;
+  long n_steps;
 };
 
 void retire_loop(ServeShared* sh) {
@@ -119,8 +124,16 @@ void retire_loop(ServeShared* sh) {
         sh->error.store(RLPYT_EHIP);
         return;
       }
+      const double t_seen = now_s();
       g.acts += 1;
+      // CLOCK_MONOTONIC ns of this post, next to the sequence word: a worker that had to wait
+      // measures its wake-up latency against it (csrc/envloop.c)
+      *reinterpret_cast<volatile uint64_t*>(reinterpret_cast<char*>(g.act_word) + 8) =
+          (uint64_t)(t_seen * 1e9);
       rlpyt_seq_post(g.act_word, g.acts);
+      sh->lat_device += t_seen - sh->t_issued[gi];
+      sh->lat_post += now_s() - t_seen;
+      sh->n_steps += 1;
       if (++sh->tcur[gi] == sh->t_end) {
         sh->state[gi].store(DONE, std::memory_order_release);
         sh->remaining.fetch_sub(1, std::memory_order_acq_rel);
@@ -159,6 +172,9 @@ extern "C" int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t
   sh.remaining.store(n_groups);
   sh.error.store(0);
   sh.t_wait_dev = 0.;
+  sh.lat_issue = sh.lat_device = sh.lat_post = 0.;
+  sh.n_steps = 0;
+  double lat_issue = 0.;
   for (int gi = 0; gi < n_groups; ++gi) {
     sh.tcur[gi] = t_begin;
     groups[gi].rounds += 1;
@@ -185,7 +201,10 @@ extern "C" int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t
         sh.error.store(rc);
         break;
       }
-      t_issue += now_s() - t0;
+      const double t1 = now_s();
+      t_issue += t1 - t0;
+      sh.t_issued[gi] = t1;
+      lat_issue += t1 - t0;
       sh.state[gi].store(WAIT_DEV, std::memory_order_release);
       progressed = true;
     }
@@ -217,6 +236,12 @@ extern "C" int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t
     timing[0] += t_wait_env;
     timing[1] += t_issue;
     timing[2] += sh.t_wait_dev;
+    // [3..6]: per-group-step chain sums (issue calls, issue-returned -> completion seen, post call)
+    // and the number of group-steps they cover
+    timing[3] += lat_issue;
+    timing[4] += sh.lat_device;
+    timing[5] += sh.lat_post;
+    timing[6] += (double)sh.n_steps;
   }
   return rc_out;
 }

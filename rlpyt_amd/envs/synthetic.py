@@ -29,7 +29,7 @@ class SyntheticPong(Env):
     obs_newest_frame_last = True
 
     def __init__(self, num_img_obs=4, points_to_end=3, max_steps=2000, step_cost_us=0.,
-                 opponent_skill=0.6, seed=0, step_cost_ref=None):
+                 opponent_skill=0.6, seed=0, step_cost_ref=None, frozen=False):
         self._n = num_img_obs
         self._observation_space = IntBox(0, 256, shape=(num_img_obs, H, W), dtype="uint8")
         self._action_space = IntBox(0, 6)
@@ -41,6 +41,9 @@ class SyntheticPong(Env):
         # lets a bench change the declared emulator cost of already forked env workers
         self._cost_ref = step_cost_ref
         self._skill = opponent_skill
+        # diagnostics only (bench --frozen-env): step() returns the standing observation with no
+        # dynamics and no drawing -- the framework's own per-env-step floor
+        self._frozen = bool(frozen)
         self._rng = np.random.RandomState(seed)
         self.reset()
 
@@ -80,6 +83,9 @@ class SyntheticPong(Env):
             end = time.perf_counter() + cost
             while time.perf_counter() < end:
                 pass
+        if self._frozen:
+            return EnvStep(self._stack.frames, np.float32(0.), False,
+                           AtariEnvInfo(game_score=0., traj_done=False))
         a = int(action)
         if a in (2, 4):
             self._py = max(6., self._py - 3.)

@@ -1,288 +1,289 @@
-"""Training-loop runners (protocol of rlpyt/runners/minibatch_rl.py:16-286 and
-rlpyt/runners/sync_rl.py:11-193).
+"""Training-loop drivers for this repo's Sampler / Algo / Agent classes.
 
-``MinibatchRl``: one process, one MI355X.  ``SyncRl``: one process PER GPU -- every rank runs
-the same sampler->algo loop on its own ``[T, B]`` batch (weak scaling: global batch =
-world_size x T x B, sync_rl.py:40-45); the only coupling is DistributedDataParallel's
-gradient all-reduce, which on ROCm's "nccl" backend is RCCL over xGMI.  Unlike the
-reference, ranks are not forked from a master that already holds a HIP context: each rank
-is its own process launched by ``torch.distributed.run`` (or ``launch_sync`` below, which
-spawns), reads RANK / WORLD_SIZE / LOCAL_RANK, and logs only on rank 0.
+The reference's own runners (rlpyt/runners/minibatch_rl.py:232-357, rlpyt/runners/sync_rl.py) drive
+these classes unmodified wherever rlpyt is importable -- ``tests/test_protocol.py`` does exactly that
+-- because the protocol they call is kept.  This module is the stand-in for
+boxes without the reference (the GPU box, ``bench.py``, the GPU tests): the same constructor keywords
+and ``train()``, the same tabular output (names and order pinned by tests/golden/runner_keys.json, which
+was recorded from the reference's runners), its own structure:
+
+* ``schedule()``     -- iteration count / logging period from ``n_steps`` and the global batch size;
+* ``RunLog``         -- every number that reaches the log: optimisation-info accumulation, the
+                        trajectory window, wall-clock rates; one ``emit`` per logging period whose
+                        rows come from a table, not from a statement sequence;
+* ``_Driver``        -- bring-up order (sampler forks its env workers BEFORE the first HIP call,
+                        then device placement, DDP wrap, algorithm), the iteration, the report;
+* ``MinibatchRl`` / ``MinibatchRlEval`` / ``SyncRl`` -- configurations of the driver.
+
+``SyncRl``: one process PER GPU, launched from outside (``torch.distributed.run``, ``bench.py --gpus
+N`` or ``launch_sync`` below) instead of forked from a master that already owns a HIP context; every
+rank runs the same loop on its own ``[T, B]`` batch (weak scaling, sync_rl.py:40-45) and the only
+coupling is DistributedDataParallel's gradient all-reduce -- RCCL over xGMI with the "nccl" backend.
 """
 import os
 import time
-from collections import deque
+from collections import deque, namedtuple
 
 import torch
 
 from ..utils import logger
-from ..utils.quick_args import save__init__args
 from ..utils.seed import make_seed, set_seed
 
+Schedule = namedtuple("Schedule", ["n_itr", "log_every", "itr_batch"])
 
-class MinibatchRlBase:
-    _eval = False
+
+def schedule(n_steps, itr_batch, log_interval_steps):
+    """Whole logging periods covering ``n_steps`` env steps at ``itr_batch`` steps per iteration
+    (the rounding of rlpyt/runners/minibatch_rl.py:108-118: up to the next multiple of the period)."""
+    log_every = max(int(log_interval_steps) // itr_batch, 1)
+    n_itr = -(-(int(n_steps) // itr_batch) // log_every) * log_every
+    return Schedule(max(n_itr, 1), log_every, itr_batch)
+
+
+class RunLog:
+    """What a run reports.  ``absorb`` takes one iteration's trajectory records and optimisation
+    info; ``emit`` writes one tabular row set.  Counter rows are listed in ``COUNTERS`` /
+    ``TRAIN_HEAD`` / ``EVAL_HEAD`` as (key, field) pairs and filled from one dict of numbers."""
+
+    TRAIN_HEAD = (("NewCompletedTrajs", "new_trajs"), ("StepsInTrajWindow", "window_steps"))
+    EVAL_HEAD = (("StepsInEval", "eval_steps"), ("TrajsInEval", "eval_trajs"),
+                 ("CumEvalTime", "eval_seconds"), ("CumTrainTime", "train_seconds"))
+    COUNTERS = (("Iteration", "itr"), ("CumTime (s)", "seconds"), ("CumSteps", "steps"),
+                ("CumCompletedTrajs", "trajs"), ("CumUpdates", "updates"),
+                ("StepsPerSecond", "steps_per_s"), ("UpdatesPerSecond", "updates_per_s"),
+                ("ReplayRatio", "replay_ratio"), ("CumReplayRatio", "cum_replay_ratio"))
+
+    def __init__(self, opt_fields, traj_window=None, prefix="Diagnostics/"):
+        self.prefix = prefix
+        self.opt = {name: [] for name in opt_fields}
+        self.window = None if traj_window is None else deque(maxlen=int(traj_window))
+        self.trajs = self.new_trajs = 0
+        self.eval_seconds = 0.
+        self.restart_clock()
+        self.updates_seen = 0
+
+    def restart_clock(self):
+        self.t_start = self.t_mark = time.time()
+
+    def absorb(self, traj_infos, opt_info):
+        n = len(traj_infos)
+        self.trajs += n
+        self.new_trajs += n
+        if self.window is not None:
+            self.window.extend(traj_infos)
+        for name, bucket in self.opt.items():
+            got = getattr(opt_info, name, [])
+            bucket += got if isinstance(got, list) else [got]
+
+    def drop_period(self):
+        """Forget the period's accumulations without printing (non-logging ranks)."""
+        for bucket in self.opt.values():
+            bucket.clear()
+        self.new_trajs = 0
+
+    def emit(self, itr, period_steps, cum_steps, algo, sampler_batch, world, eval_trajs=None,
+             eval_seconds=0.):
+        now = time.time()
+        span = now - self.t_mark - eval_seconds
+        d_updates = algo.update_counter - self.updates_seen
+        first = itr == 0
+        self.eval_seconds += eval_seconds
+        num = dict(
+            itr=itr, seconds=now - self.t_start, steps=cum_steps, trajs=self.trajs,
+            updates=algo.update_counter, new_trajs=self.new_trajs,
+            steps_per_s=float("nan") if first else period_steps / span,
+            updates_per_s=float("nan") if first else d_updates / span,
+            replay_ratio=d_updates * algo.batch_size * world / period_steps,
+            cum_replay_ratio=algo.batch_size * algo.update_counter / ((itr + 1) * sampler_batch),
+            eval_seconds=self.eval_seconds, train_seconds=now - self.t_start - self.eval_seconds)
+        if eval_trajs is None:
+            head, shown = self.TRAIN_HEAD, self.window
+            num["window_steps"] = sum(t["Length"] for t in self.window)
+        else:
+            head, shown = self.EVAL_HEAD, eval_trajs
+            num["eval_steps"] = sum(t["Length"] for t in eval_trajs)
+            num["eval_trajs"] = len(eval_trajs)
+        with logger.tabular_prefix(self.prefix):
+            for key, field in head + self.COUNTERS:
+                logger.record_tabular(key, num[field])
+        if shown:
+            for key in (k for k in shown[0] if not k.startswith("_")):
+                logger.record_tabular_misc_stat(key, [t[key] for t in shown])
+        for name, bucket in self.opt.items():
+            logger.record_tabular_misc_stat(name, bucket)
+        logger.dump_tabular(with_prefix=False)
+        self.drop_period()
+        self.t_mark, self.updates_seen = now, algo.update_counter
+        return num["steps_per_s"]
+
+
+class _Driver:
+    """Bring-up, iteration and report shared by the three runner configurations."""
+
+    evaluates = False          # True: offline evaluation at itr 0 and at every logging period
+    traj_window = None
 
     def __init__(self, algo, agent, sampler, n_steps, seed=None, affinity=None,
                  log_interval_steps=1e5):
-        n_steps = int(n_steps)
-        log_interval_steps = int(log_interval_steps)
-        affinity = dict() if affinity is None else affinity
-        save__init__args(locals())
-        self.min_itr_learn = getattr(self.algo, "min_itr_learn", 0)
-        self.rank = 0
-        self.world_size = 1
+        self.algo, self.agent, self.sampler = algo, agent, sampler
+        self.n_steps, self.log_interval_steps = int(n_steps), int(log_interval_steps)
+        self.seed = seed
+        self.affinity = dict(affinity or {})
+        self.min_itr_learn = getattr(algo, "min_itr_learn", 0)
+        self.rank, self.world_size = 0, 1
+        self.log = None
 
-    def startup(self):
-        # Every kernel wrapper launches on torch's CURRENT device / stream and the replay /
-        # sum-tree handles allocate on it: make the rank's GPU current before anything touches
-        # the device (sampler buffers, agent.to_device, workspaces).
-        cuda_idx = self.affinity.get("cuda_idx", None)
-        if cuda_idx is not None and torch.cuda.is_available():
-            torch.cuda.set_device(cuda_idx)
-        torch_threads = self.affinity.get("master_torch_threads", None)
-        if torch_threads is not None:
-            torch.set_num_threads(torch_threads)
-        if self.seed is None:
-            self.seed = make_seed()
+    # -- bring-up -----------------------------------------------------------------------------
+    def _device(self):
+        return self.affinity.get("cuda_idx", None)
+
+    def _select_device(self):
+        # kernel wrappers launch on torch's CURRENT device / stream and the replay / sum-tree
+        # handles allocate there: the rank's GPU becomes current before anything touches it
+        if self._device() is not None and torch.cuda.is_available():
+            torch.cuda.set_device(self._device())
+
+    def _bring_up(self):
+        self._select_device()
+        threads = self.affinity.get("master_torch_threads", None)
+        if threads is not None:
+            torch.set_num_threads(threads)
+        self.seed = make_seed() if self.seed is None else self.seed
         set_seed(self.seed)
-        rank, world_size = self.rank, self.world_size
-        examples = self.sampler.initialize(
-            agent=self.agent, affinity=self.affinity, seed=self.seed + 1,
-            bootstrap_value=getattr(self.algo, "bootstrap_value", False),
-            traj_info_kwargs=self.get_traj_info_kwargs(), rank=rank, world_size=world_size)
-        self.itr_batch_size = self.sampler.batch_spec.size * world_size
-        n_itr = self.get_n_itr()
-        self.agent.to_device(self.affinity.get("cuda_idx", None))
-        if world_size > 1:
-            self.agent.data_parallel()
-        self.algo.initialize(agent=self.agent, n_itr=n_itr,
-                             batch_spec=self.sampler.batch_spec,
-                             mid_batch_reset=self.sampler.mid_batch_reset, examples=examples,
-                             world_size=world_size, rank=rank)
-        self.initialize_logging()
-        return n_itr
+        algo, agent, sampler = self.algo, self.agent, self.sampler
+        # the sampler first: it forks its env workers, which must happen before this process
+        # creates a HIP context (the order of rlpyt/runners/minibatch_rl.py:74-96)
+        examples = sampler.initialize(
+            agent=agent, affinity=self.affinity, seed=self.seed + 1,
+            bootstrap_value=getattr(algo, "bootstrap_value", False),
+            traj_info_kwargs=dict(discount=getattr(algo, "discount", 1)),
+            rank=self.rank, world_size=self.world_size)
+        plan = schedule(self.n_steps, sampler.batch_spec.size * self.world_size,
+                        self.log_interval_steps)
+        self.n_itr, self.log_interval_itrs, self.itr_batch_size = plan
+        logger.log(f"Running {plan.n_itr} iterations of minibatch RL.")
+        agent.to_device(self._device())
+        if self.world_size > 1:
+            agent.data_parallel()
+        algo.initialize(agent=agent, n_itr=plan.n_itr, batch_spec=sampler.batch_spec,
+                        mid_batch_reset=sampler.mid_batch_reset, examples=examples,
+                        world_size=self.world_size, rank=self.rank)
+        if self.traj_window is not None:
+            logger.log(f"Optimizing over {plan.log_every} iterations.")
+        self.log = RunLog(algo.opt_info_fields, self.traj_window)
+        return plan
 
-    def get_traj_info_kwargs(self):
-        return dict(discount=getattr(self.algo, "discount", 1))
+    # -- one iteration / one report -----------------------------------------------------------------
+    def _iterate(self, itr):
+        logger.set_iteration(itr)
+        self.agent.sample_mode(itr)
+        samples, traj_infos = self.sampler.obtain_samples(itr)
+        self.agent.train_mode(itr)
+        self.log.absorb(traj_infos, self.algo.optimize_agent(itr, samples))
 
-    def get_n_itr(self):
-        log_interval_itrs = max(self.log_interval_steps // self.itr_batch_size, 1)
-        n_itr = self.n_steps // self.itr_batch_size
-        if n_itr % log_interval_itrs > 0:
-            n_itr += log_interval_itrs
-            n_itr -= n_itr % log_interval_itrs
-        self.log_interval_itrs = log_interval_itrs
-        self.n_itr = max(n_itr, 1)
-        logger.log(f"Running {self.n_itr} iterations of minibatch RL.")
-        return self.n_itr
+    def _evaluate(self, itr):
+        if itr and itr < self.min_itr_learn - 1:
+            logger.log("Evaluation runs complete.")
+            return [], 0.
+        logger.log("Evaluating agent...")
+        self.agent.eval_mode(itr)
+        t0 = time.time()
+        trajs = self.sampler.evaluate_agent(itr)
+        seconds = time.time() - t0
+        logger.log("Evaluation runs complete.")
+        if not trajs:
+            logger.log("WARNING: had no complete trajectories in eval.")
+        return trajs, seconds
 
-    def initialize_logging(self):
-        self._opt_infos = {k: list() for k in self.algo.opt_info_fields}
-        self._start_time = self._last_time = time.time()
-        self._cum_time = 0.
-        self._cum_completed_trajs = 0
-        self._last_update_counter = 0
+    def _snapshot(self, itr):
+        """Snapshot in the reference's layout (minibatch_rl.py:136-147): interchangeable files."""
+        logger.save_itr_params(itr, dict(
+            itr=itr, cum_steps=itr * self.sampler.batch_size * self.world_size,
+            agent_state_dict=self.agent.state_dict(),
+            optimizer_state_dict=self.algo.optim_state_dict()))
 
-    def shutdown(self):
+    def _logs(self):
+        return True
+
+    def _report(self, itr, eval_trajs=None, eval_seconds=0.):
+        if not self._logs():
+            self.log.drop_period()
+            return
+        if itr >= self.min_itr_learn - 1:
+            self._snapshot(itr)
+        per_itr = self.sampler.batch_size * self.world_size
+        self.last_steps_per_second = self.log.emit(
+            itr, per_itr * self.log_interval_itrs, (itr + 1) * per_itr, self.algo,
+            self.sampler.batch_size, self.world_size, eval_trajs, eval_seconds)
+
+    def train(self):
+        plan = self._bring_up()
+        if self.evaluates:
+            self._report(0, *self._evaluate(0))
+        for itr in range(plan.n_itr):
+            self._iterate(itr)
+            if (itr + 1) % plan.log_every == 0:
+                self._report(itr, *(self._evaluate(itr) if self.evaluates else ()))
         logger.log("Training complete.")
         self.sampler.shutdown()
 
-    def get_itr_snapshot(self, itr):
-        return dict(itr=itr, cum_steps=itr * self.sampler.batch_size * self.world_size,
-                    agent_state_dict=self.agent.state_dict(),
-                    optimizer_state_dict=self.algo.optim_state_dict())
-
-    def save_itr_snapshot(self, itr):
-        logger.save_itr_params(itr, self.get_itr_snapshot(itr))
-
-    def store_diagnostics(self, itr, traj_infos, opt_info):
-        self._cum_completed_trajs += len(traj_infos)
-        for k, v in self._opt_infos.items():
-            new_v = getattr(opt_info, k, [])
-            v.extend(new_v if isinstance(new_v, list) else [new_v])
-
-    def log_diagnostics(self, itr, traj_infos=None, eval_time=0, prefix="Diagnostics/"):
-        if itr >= self.min_itr_learn - 1:      # minibatch_rl.py:168-169
-            self.save_itr_snapshot(itr)
-        new_time = time.time()
-        self._cum_time = new_time - self._start_time
-        train_time_elapsed = new_time - self._last_time - eval_time
-        new_updates = self.algo.update_counter - self._last_update_counter
-        new_samples = self.sampler.batch_size * self.world_size * self.log_interval_itrs
-        updates_per_second = (float("nan") if itr == 0 else new_updates / train_time_elapsed)
-        samples_per_second = (float("nan") if itr == 0 else new_samples / train_time_elapsed)
-        replay_ratio = (new_updates * self.algo.batch_size * self.world_size / new_samples)
-        cum_replay_ratio = (self.algo.batch_size * self.algo.update_counter /
-                            ((itr + 1) * self.sampler.batch_size))
-        cum_steps = (itr + 1) * self.sampler.batch_size * self.world_size
-        self.last_steps_per_second = samples_per_second
-        with logger.tabular_prefix(prefix):
-            if self._eval:
-                logger.record_tabular("CumTrainTime", self._cum_time - getattr(self, "_cum_eval_time", 0))
-            logger.record_tabular("Iteration", itr)
-            logger.record_tabular("CumTime (s)", self._cum_time)
-            logger.record_tabular("CumSteps", cum_steps)
-            logger.record_tabular("CumCompletedTrajs", self._cum_completed_trajs)
-            logger.record_tabular("CumUpdates", self.algo.update_counter)
-            logger.record_tabular("StepsPerSecond", samples_per_second)
-            logger.record_tabular("UpdatesPerSecond", updates_per_second)
-            logger.record_tabular("ReplayRatio", replay_ratio)
-            logger.record_tabular("CumReplayRatio", cum_replay_ratio)
-        self._log_infos(traj_infos)
-        logger.dump_tabular(with_prefix=False)
-        self._last_time = new_time
-        self._last_update_counter = self.algo.update_counter
-
-    def _log_infos(self, traj_infos=None):
-        if traj_infos is None:
-            traj_infos = self._traj_infos
-        if traj_infos:
-            for k in traj_infos[0]:
-                if not k.startswith("_"):
-                    logger.record_tabular_misc_stat(k, [info[k] for info in traj_infos])
-        if self._opt_infos:
-            for k, v in self._opt_infos.items():
-                logger.record_tabular_misc_stat(k, v)
-        self._opt_infos = {k: list() for k in self._opt_infos}
+    @property
+    def _cum_eval_time(self):
+        return self.log.eval_seconds
 
 
-class MinibatchRl(MinibatchRlBase):
-    """Online tracking of training trajectories (minibatch_rl.py:232-283)."""
+class MinibatchRl(_Driver):
+    """Online tracking: statistics over a window of the training trajectories themselves."""
 
     def __init__(self, log_traj_window=100, **kwargs):
         super().__init__(**kwargs)
-        self.log_traj_window = int(log_traj_window)
-
-    def train(self):
-        n_itr = self.startup()
-        for itr in range(n_itr):
-            logger.set_iteration(itr)
-            self.agent.sample_mode(itr)
-            samples, traj_infos = self.sampler.obtain_samples(itr)
-            self.agent.train_mode(itr)
-            opt_info = self.algo.optimize_agent(itr, samples)
-            self.store_diagnostics(itr, traj_infos, opt_info)
-            if (itr + 1) % self.log_interval_itrs == 0:
-                self.log_diagnostics(itr)
-        self.shutdown()
-
-    def initialize_logging(self):
-        self._traj_infos = deque(maxlen=self.log_traj_window)
-        self._new_completed_trajs = 0
-        logger.log(f"Optimizing over {self.log_interval_itrs} iterations.")
-        super().initialize_logging()
-
-    def store_diagnostics(self, itr, traj_infos, opt_info):
-        self._new_completed_trajs += len(traj_infos)
-        self._traj_infos.extend(traj_infos)
-        super().store_diagnostics(itr, traj_infos, opt_info)
-
-    def log_diagnostics(self, itr, prefix="Diagnostics/"):
-        with logger.tabular_prefix(prefix):
-            logger.record_tabular("NewCompletedTrajs", self._new_completed_trajs)
-            logger.record_tabular("StepsInTrajWindow",
-                                  sum(info["Length"] for info in self._traj_infos))
-        super().log_diagnostics(itr, prefix=prefix)
-        self._new_completed_trajs = 0
+        self.traj_window = int(log_traj_window)
 
 
-class MinibatchRlEval(MinibatchRlBase):
-    """Offline tracking: pauses at every log interval to run evaluation trajectories through
-    ``sampler.evaluate_agent`` (minibatch_rl.py:286-357)."""
+class MinibatchRlEval(_Driver):
+    """Offline tracking: at itr 0 and at every logging period the agent is evaluated through
+    ``sampler.evaluate_agent`` and the statistics are those of the evaluation trajectories."""
 
-    _eval = True
+    evaluates = True
 
-    def train(self):
-        n_itr = self.startup()
-        eval_traj_infos, eval_time = self.evaluate_agent(0)
-        self.log_diagnostics(0, eval_traj_infos, eval_time)
-        for itr in range(n_itr):
-            logger.set_iteration(itr)
-            self.agent.sample_mode(itr)
-            samples, traj_infos = self.sampler.obtain_samples(itr)
-            self.agent.train_mode(itr)
-            opt_info = self.algo.optimize_agent(itr, samples)
-            self.store_diagnostics(itr, traj_infos, opt_info)
-            if (itr + 1) % self.log_interval_itrs == 0:
-                eval_traj_infos, eval_time = self.evaluate_agent(itr)
-                self.log_diagnostics(itr, eval_traj_infos, eval_time)
-        self.shutdown()
-
-    def evaluate_agent(self, itr):
-        if itr >= self.min_itr_learn - 1 or itr == 0:
-            logger.log("Evaluating agent...")
-            self.agent.eval_mode(itr)
-            eval_time = -time.time()
-            traj_infos = self.sampler.evaluate_agent(itr)
-            eval_time += time.time()
-        else:
-            traj_infos, eval_time = [], 0.0
-        logger.log("Evaluation runs complete.")
-        return traj_infos, eval_time
-
-    def initialize_logging(self):
-        super().initialize_logging()
-        self._cum_eval_time = 0
-
-    def log_diagnostics(self, itr, eval_traj_infos, eval_time, prefix="Diagnostics/"):
-        if not eval_traj_infos:
-            logger.log("WARNING: had no complete trajectories in eval.")
-        steps_in_eval = sum(info["Length"] for info in eval_traj_infos)
-        with logger.tabular_prefix(prefix):
-            logger.record_tabular("StepsInEval", steps_in_eval)
-            logger.record_tabular("TrajsInEval", len(eval_traj_infos))
-            self._cum_eval_time += eval_time
-            logger.record_tabular("CumEvalTime", self._cum_eval_time)
-        super().log_diagnostics(itr, eval_traj_infos, eval_time, prefix=prefix)
+    def __init__(self, algo, agent, sampler, n_steps, seed=None, affinity=None,
+                 log_interval_steps=1e5):
+        super().__init__(algo, agent, sampler, n_steps, seed, affinity, log_interval_steps)
 
 
 class SyncRl(MinibatchRl):
-    """Data-parallel training, one process per GPU (sync_rl.py:11-193 semantics)."""
+    """Data-parallel training, one process per GPU (see the module docstring)."""
 
     def __init__(self, backend=None, init_method=None, **kwargs):
         super().__init__(**kwargs)
-        self.backend = backend
-        self.init_method = init_method
+        self.backend, self.init_method = backend, init_method
 
-    def startup(self):
+    def _logs(self):
+        return self.rank == 0
+
+    def _bring_up(self):
         import torch.distributed as dist
+        self._select_device()
         if not dist.is_initialized():
-            rank = int(os.environ.get("RANK", 0))
-            world_size = int(os.environ.get("WORLD_SIZE", 1))
-            backend = self.backend or (
-                "gloo" if self.affinity.get("cuda_idx", None) is None else "nccl")
-            if self.affinity.get("cuda_idx", None) is not None:
-                torch.cuda.set_device(self.affinity["cuda_idx"])
-            kw = dict(init_method=self.init_method) if self.init_method else {}
-            dist.init_process_group(backend=backend, rank=rank, world_size=world_size, **kw)
+            env = os.environ
+            extra = dict(init_method=self.init_method) if self.init_method else {}
+            dist.init_process_group(
+                backend=self.backend or ("gloo" if self._device() is None else "nccl"),
+                rank=int(env.get("RANK", 0)), world_size=int(env.get("WORLD_SIZE", 1)), **extra)
         self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
-        if self.affinity.get("cuda_idx", None) is not None and torch.cuda.is_available():
-            torch.cuda.set_device(self.affinity["cuda_idx"])
         if self.seed is None:
-            # the master draws the seed, the workers derive theirs from it (sync_rl.py:52,82):
-            # rank 0's draw is broadcast so that a run is reproducible from rank 0's log
-            box = [make_seed() if self.rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            self.seed = int(box[0])
-        self.seed = self.seed + 100 * self.rank  # sync_rl.py:82
-        if self.rank > 0:
-            logger.set_quiet(True)  # workers do no logging (sync_rl.py:178-179)
-        n_itr = super().startup()
+            # rank 0 draws, everybody derives (sync_rl.py:52,82): a run is reproducible from
+            # rank 0's log
+            drawn = [make_seed() if self.rank == 0 else None]
+            dist.broadcast_object_list(drawn, src=0)
+            self.seed = int(drawn[0])
+        self.seed += 100 * self.rank
+        if self.rank > 0:           # only rank 0 talks (sync_rl.py:178-179)
+            logger.set_quiet(True)
+        plan = super()._bring_up()
         dist.barrier()
-        self._start_time = self._last_time = time.time()
-        return n_itr
-
-    def log_diagnostics(self, itr, prefix="Diagnostics/"):
-        if self.rank == 0:
-            super().log_diagnostics(itr, prefix=prefix)
-        else:
-            self._opt_infos = {k: list() for k in self._opt_infos}
-            self._new_completed_trajs = 0
-
-    def save_itr_snapshot(self, itr):
-        if self.rank == 0:
-            super().save_itr_snapshot(itr)
+        self.log.restart_clock()
+        return plan
 
 
 def _sync_entry(rank, world_size, port, backend, build_fn, args):

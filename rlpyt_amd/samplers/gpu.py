@@ -374,7 +374,10 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus, eval_runner=None):
     for _, rn in runners:
         rn.start(ctrl.max_decorrelation_steps)
     ctrl.barrier_out.wait()
-    seq = _StepSync(ctrl.sync_words, ctrl.group_workers, ctrl.n_workers, ctrl.worker_spin)
+    spin = ctrl.worker_spin
+    if os.environ.get("RLPYT_WORKER_SPIN"):           # A/B experiments (rollout sweep)
+        spin = int(os.environ["RLPYT_WORKER_SPIN"])
+    seq = _StepSync(ctrl.sync_words, ctrl.group_workers, ctrl.n_workers, spin)
     ti_keys, ti_table, ti_count = ctrl.ti_keys, ctrl.ti_table, ctrl.ti_count
     while True:
         seq.worker_wait_batch()
@@ -411,6 +414,17 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus, eval_runner=None):
             ti_count[rank] = -n
             for info in completed:
                 ctrl.traj_infos_queue.put(dict(info))
+        # where this worker's batch went: waiting for actions vs stepping envs (native body only)
+        wt = ctrl.worker_timing
+        for _, rn in runners:
+            if rn._native is not None:
+                tm_ = rn._native.timing()
+                w_ns, s_ns, calls, wake_ns, n_waited = tm_
+                wt[rank, 0] += w_ns
+                wt[rank, 1] += s_ns
+                wt[rank, 2] += calls
+                wt[rank, 3] += wake_ns
+                wt[rank, 4] += n_waited
         seq.worker_batch_done()
 
 
@@ -739,6 +753,8 @@ class GpuSampler(BaseSampler):
         self.ctrl.ti_keys = keys
         self.ctrl.ti_table = np_mp_array((n, max(cap, 1), max(len(keys), 1)), np.float64)
         self.ctrl.ti_count = np_mp_array(n, np.int32)
+        # per worker: ns waited for actions, ns stepping, group-steps (cumulative; diagnostics)
+        self.ctrl.worker_timing = np_mp_array((n, 5), np.float64)
         # CPU pinning as the reference (parallel/base.py:236-237): worker w on workers_cpus[w],
         # unless affinity["set_affinity"] is False
         cpus = affinity.get("workers_cpus", None) if affinity.get("set_affinity", True) else None
@@ -890,6 +906,12 @@ class GpuSampler(BaseSampler):
         once); elsewhere torch ``index_copy_`` does the same thing leaf by leaf."""
         s, t = self.samples, G.t_dev
         lo, hi = G.lo, G.hi
+        if os.environ.get("RLPYT_NULL_STEP") == "1":
+            # diagnostics only: no device work in the step (action 0 everywhere) -- what is left
+            # of a time step is the host side (env stepping, hand-offs, launches, DMA)
+            _map(lambda x: x.zero_(), G.action_out)
+            G.post_entries = None
+            return
         fusable = (G.u_all is not None and self.mid_batch_reset and self.fused_step
                    and isinstance(self._all_action, torch.Tensor))
         if (fusable and G.dedup and G.pre_commit is not None and self.fused_push
@@ -986,7 +1008,7 @@ class GpuSampler(BaseSampler):
         s = self.samples
         agent = self.agent
         if not (cuda and G.dedup and G.u_all is not None and self.mid_batch_reset
-                and self.fused_step and self.fused_push and not G.zc_in
+                and self.fused_step and self.fused_push
                 and "bootstrap_value" in s.agent and not agent.recurrent
                 and not getattr(agent, "uses_prev_inputs", True)
                 and hasattr(agent, "value_into") and isinstance(self._all_action, torch.Tensor)):
@@ -1146,7 +1168,7 @@ class GpuSampler(BaseSampler):
             G.event.record(G.stream or torch.cuda.current_stream(self.device))
             sg.event = G.event.cuda_event
         self._native = arr
-        self._native_timing = (ctypes.c_double * 3)()
+        self._native_timing = (ctypes.c_double * 8)()
         logger.log("GpuSampler: time-step loop handed to rlpyt_sampler_serve (native).")
         return True
 
@@ -1179,7 +1201,8 @@ class GpuSampler(BaseSampler):
         for G, sg in zip(self.groups, arr):
             sg.acts, sg.rounds = self.sync.acts[G.idx] & 0xffffffff, self.sync.rounds[G.idx] & 0xffffffff
         tmg = self._native_timing
-        tmg[0] = tmg[1] = tmg[2] = 0.
+        for i in range(8):
+            tmg[i] = 0.
         _lib.check(_lib.lib.rlpyt_sampler_serve(arr, len(self.groups), 0, T, self._serve_spin(),
                                                 120000, tmg), "rlpyt_sampler_serve")
         for G in self.groups:
@@ -1189,6 +1212,9 @@ class GpuSampler(BaseSampler):
         self.timing["wait_env_s"] += tmg[0]
         self.timing["device_issue_s"] += tmg[1]
         self.timing["device_wait_s"] += tmg[2]
+        for k, i in (("chain_issue_s", 3), ("chain_device_s", 4), ("chain_post_s", 5),
+                     ("chain_steps", 6)):
+            self.timing[k] = self.timing.get(k, 0.) + tmg[i]
 
     def _capture(self, G):
         """Capture the device work of one group's step into a hipGraph (torch.cuda.CUDAGraph
