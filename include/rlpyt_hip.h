@@ -462,7 +462,52 @@ int rlpyt_rollout_head_f32(const float* partial, int ksplit, const float* fc_bia
                            const int64_t* t_dev, int64_t n, int K, int A, float* prob_rows,
                            float* value_rows, int64_t* action_rows, int64_t B, int64_t lo,
                            int64_t* action_out, float* bootstrap_out /*nullable: [n]*/,
+                           int64_t* t_next /*nullable: receives t + 1 (device-driven stepping)*/,
                            rlpyt_stream_t stream);
+
+/* First node of a DEVICE-DRIVEN rollout step: one launch pulls the step's inputs out of the
+ * page-locked, fork-shared step buffer over PCIe -- newest frames, reward / done scalars, and for
+ * environments whose frame stack was reset (host reset flag) or at the first step of a batch
+ * (*t_ctr == 0) the full observation row, with slot[b] = b / -1 set accordingly -- and publishes
+ * t = *t_ctr in the device misc block.  Same effect as the host-side uploads of
+ * rlpyt_sampler_serve (role of the H2D in rlpyt/agents/pg/categorical.py:37 and of
+ * ActionServer.serve_actions' per-step bookkeeping, action_server.py:44-58), with no host call,
+ * so the whole step can be enqueued ahead of time behind a stream wait on the workers' arrival
+ * counter (rlpyt_sampler_serve_ahead).  host_* are DEVICE-mapped addresses of page-locked host
+ * memory (rlpyt_host_device_pointer); misc layout: reward f32[Bg] | slot i32[Bg] | done u8[Bg] |
+ * reset u8[Bg] | pad | t i64 at t_off. */
+int rlpyt_rollout_fetch(const uint8_t* host_frame, const uint8_t* host_misc,
+                        const uint8_t* host_obs, uint8_t* dev_frame, uint8_t* dev_misc,
+                        uint8_t* full_rows, int Bg, int64_t frame_bytes, int64_t row_bytes,
+                        int t_off, const int64_t* t_ctr, rlpyt_stream_t stream);
+
+/* Enqueue-ahead serve loop: for every time step t in [0, T) and pipeline group g the caller's
+ * thread enqueues, WITHOUT waiting for anything,
+ *     hipStreamWaitValue32(stream_g, obs_word_g >= rounds_g * n_workers_g)   (workers arrived)
+ *     hipGraphLaunch(step graph of g)            (fetch + forward + action / row writes)
+ *     hipStreamWriteValue32(stream_g, act_word_g, ++acts_g)                  (actions published)
+ * and, with tail graphs, one more wait + graph per group for the bootstrap value at t = T.  The
+ * GPU's command processor takes the hand-off from the env workers itself; a helper thread only
+ * turns the GPU's act-word writes into futex wake-ups for workers that went to sleep.  Returns
+ * when every group's last act word (and tail) has completed.  obs / act words must be page-locked
+ * and mapped (their *_dev addresses are what the stream operations use); counters must stay below
+ * 2^31 (the wait is an unsigned >=).  timing[0] = seconds spent enqueueing, [1] = seconds waiting for
+ * completion afterwards. */
+typedef struct rlpyt_ahead_group {
+  uint32_t* act_word;      /* host address (futex word of the workers) */
+  uint32_t* obs_word;
+  void* act_word_dev;      /* device-mapped addresses of the same words */
+  void* obs_word_dev;
+  uint32_t acts;
+  uint32_t rounds;
+  int32_t n_workers;
+  int32_t reserved;
+  void* graph_exec;        /* hipGraphExec_t: one time step */
+  void* tail_graph_exec;   /* hipGraphExec_t or NULL: bootstrap-value pass at t = T */
+  void* stream;            /* hipStream_t */
+} rlpyt_ahead_group;
+int rlpyt_sampler_serve_ahead(rlpyt_ahead_group* groups, int n_groups, int T, int timeout_ms,
+                              double* timing /*[2], nullable*/);
 
 /* Frame-stack push for frame-stacked environments (rlpyt/envs/atari/atari_env.py:115-118:
  * the observation is the last C frames, newest last): the host uploads only the newest

@@ -36,6 +36,14 @@ class StepGroup(ctypes.Structure):
                 ("stream", c_void_p), ("event", c_void_p)]
 
 
+class AheadGroup(ctypes.Structure):
+    """Mirror of ``rlpyt_ahead_group`` (include/rlpyt_hip.h)."""
+    _fields_ = [("act_word", c_void_p), ("obs_word", c_void_p), ("act_word_dev", c_void_p),
+                ("obs_word_dev", c_void_p), ("acts", c_uint32), ("rounds", c_uint32),
+                ("n_workers", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("graph_exec", c_void_p), ("tail_graph_exec", c_void_p), ("stream", c_void_p)]
+
+
 class AdamTensor(ctypes.Structure):
     """Mirror of ``rlpyt_adam_tensor`` (include/rlpyt_hip.h)."""
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
@@ -143,7 +151,9 @@ _SIGNATURES = {
     "rlpyt_rollout_fc_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "rlpyt_rollout_fc_f32": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p]),
     "rlpyt_rollout_head_f32": (c_int, [_p, c_int] + [_p] * 7 + [c_int64, c_int, c_int, _p, _p, _p,
-                                                            c_int64, c_int64, _p, _p, _p]),
+                                                            c_int64, c_int64, _p, _p, _p, _p]),
+    "rlpyt_rollout_fetch": (c_int, [_p, _p, _p, _p, _p, _p, c_int, c_int64, c_int64, c_int, _p, _p]),
+    "rlpyt_sampler_serve_ahead": (c_int, [_p, c_int, c_int, c_int, _p]),
     "rlpyt_atari_conv2_dgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p]),
     "rlpyt_atari_conv_wgrad_workspace_bytes": (c_int64, []),
     "rlpyt_atari_conv2_wgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p, _p]),

@@ -650,7 +650,8 @@ __global__ __launch_bounds__(256) void rollout_head_kernel(
     const float* __restrict__ b_v, const float* __restrict__ uniforms,
     const int64_t* __restrict__ t_dev, int64_t n, int A, float* __restrict__ prob_rows,
     float* __restrict__ value_rows, int64_t* __restrict__ action_rows, int64_t B, int64_t lo,
-    int64_t* __restrict__ action_out, float* __restrict__ bootstrap_out) {
+    int64_t* __restrict__ action_out, float* __restrict__ bootstrap_out,
+    int64_t* __restrict__ t_next) {
   constexpr int K = 256 * KW;
   constexpr int AMAX = 8;
   __shared__ float red[4][AMAX + 1];
@@ -742,9 +743,115 @@ __global__ __launch_bounds__(256) void rollout_head_kernel(
   const int64_t act = pick >= 0 ? pick : last_pos;
   action_rows[(t + 1) * B + lo + row] = act;
   action_out[row] = act;
+  // device-driven stepping: this launch is the last reader of t; the fetch kernel of the NEXT
+  // step (stream-ordered behind it) picks the counter up
+  if (t_next != nullptr && row == 0) *t_next = t + 1;
+}
+
+// --------------------------------------------------------------------------------------
+// First node of a device-driven step (no host call on the per-step path): pulls the step's
+// inputs out of the page-locked, fork-shared step buffer over PCIe -- what the master's
+// hipMemcpyAsync calls (newest frames + misc block, full stacks of reset envs) and its slot
+// bookkeeping did on the host (csrc/serve.cpp issue_group_step) -- so that the whole step can be
+// enqueued AHEAD of time behind a hipStreamWaitValue32 on the workers' arrival counter.
+// One workgroup per environment b:
+//   frame_stage[b] <- host frame[b]                (8320 B)
+//   reward_stage[b], done_stage[b] <- host misc    (scalars)
+//   full = host reset[b] || t == 0  (fresh stack / first step of a batch)
+//   full ? (full_rows[b] <- host observation[b] (33 KB), slot[b] = b) : slot[b] = -1
+//   t_dev <- t = *t_ctr   (workgroup 0; the step's other kernels read t_dev, the head kernel hands
+//                          t + 1 back to t_ctr)
+// The frame loads are issued before the reset flag is known (one PCIe latency, not two).
+// Loads are issued through asm so that ALL of them are in flight before the first wait: written as
+// plain C++ the compiler pairs every (predicated) load with its store and an s_waitcnt vmcnt(0) in
+// between -- five serialized PCIe round trips per workgroup, measured +45 us per group-step.
+typedef uint32_t st_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ st_u32x4 st_ld16_issue(const void* p) {
+  st_u32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ uint32_t st_ld1_issue(const void* p) {
+  uint32_t r;
+  asm volatile("global_load_ubyte %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ uint32_t st_ld4_issue(const void* p) {
+  uint32_t r;
+  asm volatile("global_load_dword %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ void st_loads_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(256) void rollout_fetch_kernel(
+    const uint8_t* __restrict__ h_frame, const uint8_t* __restrict__ h_misc,
+    const uint8_t* __restrict__ h_obs, uint8_t* __restrict__ d_frame, uint8_t* __restrict__ d_misc,
+    uint8_t* __restrict__ full_rows, int Bg, int hw16, int row16, int t_off,
+    const int64_t* __restrict__ t_ctr) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const st_u32x4* __restrict__ src = reinterpret_cast<const st_u32x4*>(h_frame) + (int64_t)b * hw16;
+  st_u32x4* __restrict__ dst = reinterpret_cast<st_u32x4*>(d_frame) + (int64_t)b * hw16;
+  // misc layout (samplers/gpu.py): reward f32[Bg] | slot i32[Bg] | done u8[Bg] | reset u8[Bg] | .. | t
+  const uint32_t rs = st_ld1_issue(h_misc + 9 * Bg + b);
+  st_u32x4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = st_ld16_issue(src + min(tid + 256 * i, hw16 - 1));  // clamped
+  const uint32_t rew = st_ld4_issue(h_misc + 4 * b);
+  const uint32_t dn = st_ld1_issue(h_misc + 8 * Bg + b);
+  const int64_t t = *t_ctr;
+  st_loads_wait();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = tid + 256 * i;
+    if (w < hw16) dst[w] = v[i];
+  }
+  for (int w = tid + 1024; w < hw16; w += 256) dst[w] = src[w];   // frames larger than 16 KB
+  if (tid == 0) reinterpret_cast<uint32_t*>(d_misc)[b] = rew;
+  if (tid == 1) {
+    d_misc[8 * Bg + b] = (uint8_t)dn;
+    d_misc[9 * Bg + b] = (uint8_t)rs;
+  }
+  const bool full = rs != 0 || t == 0;
+  if (tid == 2) reinterpret_cast<int32_t*>(d_misc + 4 * Bg)[b] = full ? b : -1;
+  if (b == 0 && tid == 3) *reinterpret_cast<int64_t*>(d_misc + t_off) = t;
+  if (full) {
+    const st_u32x4* __restrict__ fs = reinterpret_cast<const st_u32x4*>(h_obs) + (int64_t)b * row16;
+    st_u32x4* __restrict__ fd = reinterpret_cast<st_u32x4*>(full_rows) + (int64_t)b * row16;
+    for (int w0 = 0; w0 < row16; w0 += 256 * 9) {
+      st_u32x4 u[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) u[i] = st_ld16_issue(fs + min(w0 + tid + 256 * i, row16 - 1));
+      st_loads_wait();
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int w = w0 + tid + 256 * i;
+        if (w < row16) fd[w] = u[i];
+      }
+    }
+  }
 }
 }  // namespace
 }  // namespace rlpyt
+
+extern "C" int rlpyt_rollout_fetch(const uint8_t* host_frame, const uint8_t* host_misc,
+                                   const uint8_t* host_obs, uint8_t* dev_frame, uint8_t* dev_misc,
+                                   uint8_t* full_rows, int Bg, int64_t frame_bytes,
+                                   int64_t row_bytes, int t_off, const int64_t* t_ctr,
+                                   rlpyt_stream_t stream) {
+  RL_CHECK_ARG(host_frame && host_misc && host_obs && dev_frame && dev_misc && full_rows && t_ctr,
+               RLPYT_EINVAL, "rlpyt_rollout_fetch: null pointer");
+  RL_CHECK_ARG(Bg > 0 && frame_bytes > 0 && frame_bytes % 16 == 0 && row_bytes > 0 &&
+                   row_bytes % 16 == 0 && t_off >= 10 * Bg && t_off % 8 == 0,
+               RLPYT_ESHAPE, "rlpyt_rollout_fetch: frame / row bytes must be multiples of 16");
+  RL_CHECK_ARG(RL_ALIGNED16(host_frame) && RL_ALIGNED16(host_obs) && RL_ALIGNED16(dev_frame) &&
+                   RL_ALIGNED16(full_rows) && RL_ALIGNED16(host_misc) && RL_ALIGNED16(dev_misc),
+               RLPYT_ESHAPE, "rlpyt_rollout_fetch: buffers must be 16-byte aligned");
+  RL_LAUNCH(rlpyt::rollout_fetch_kernel, dim3((unsigned)Bg), dim3(256), 0, (hipStream_t)stream,
+            host_frame, host_misc, host_obs, dev_frame, dev_misc, full_rows, Bg,
+            (int)(frame_bytes / 16), (int)(row_bytes / 16), t_off, t_ctr);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
 
 extern "C" int rlpyt_rollout_fc_ksplit(int K) {
   return K > 0 ? (int)rlpyt::ceil_div(K, rlpyt::kRfcKc) : 0;
@@ -778,7 +885,8 @@ extern "C" int rlpyt_rollout_head_f32(const float* partial, int ksplit, const fl
                                       const int64_t* t_dev, int64_t n, int K, int A,
                                       float* prob_rows, float* value_rows, int64_t* action_rows,
                                       int64_t B, int64_t lo, int64_t* action_out,
-                                      float* bootstrap_out, rlpyt_stream_t stream) {
+                                      float* bootstrap_out, int64_t* t_next,
+                                      rlpyt_stream_t stream) {
   RL_CHECK_ARG(partial && fc_bias && w_pi && b_pi && w_v && b_v, RLPYT_EINVAL,
                "rlpyt_rollout_head_f32: null pointer");
   RL_CHECK_ARG(bootstrap_out != nullptr ||
@@ -792,11 +900,11 @@ extern "C" int rlpyt_rollout_head_f32(const float* partial, int ksplit, const fl
   if (K == 512)
     RL_LAUNCH((rlpyt::rollout_head_kernel<2>), grid, block, 0, s, partial, ksplit, fc_bias, w_pi,
               b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows, action_rows, B, lo,
-              action_out, bootstrap_out);
+              action_out, bootstrap_out, t_next);
   else
     RL_LAUNCH((rlpyt::rollout_head_kernel<1>), grid, block, 0, s, partial, ksplit, fc_bias, w_pi,
               b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows, action_rows, B, lo,
-              action_out, bootstrap_out);
+              action_out, bootstrap_out, t_next);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

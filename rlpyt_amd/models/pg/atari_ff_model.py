@@ -166,7 +166,8 @@ class AtariFfModel(torch.nn.Module):
             ops.rollout_head(partial, ksplit, lin.bias, self.pi.weight, self.pi.bias,
                              self.value.weight, self.value.bias, out.uniforms, out.t_dev, B,
                              out.prob_rows, out.value_rows, out.action_rows, out.lo, out.action_out,
-                             bootstrap_out=bootstrap_out)
+                             bootstrap_out=bootstrap_out,
+                             t_next=None if bootstrap_out is not None else getattr(out, "t_next", None))
             return True
         if bootstrap_out is not None:
             return False
@@ -174,6 +175,8 @@ class AtariFfModel(torch.nn.Module):
         ops.pg_sample_head(partial, ksplit, lin.bias, self.pi.weight, self.pi.bias,
                            self.value.weight, self.value.bias, out.uniforms, out.t_dev, B,
                            out.prob_rows, out.value_rows, out.action_rows, out.lo, out.action_out)
+        if getattr(out, "t_next", None) is not None:     # (A/B path: the v1 head does not do it)
+            out.t_next.copy_(out.t_dev + 1)
         return True
 
     @torch.no_grad()

@@ -872,8 +872,23 @@ def rollout_fc_ok(M, N, K):
     return 0 < M <= 1024 and N % 64 == 0 and K % 16 == 0 and 0 < K <= 4096
 
 
+def rollout_fetch(h_frame, h_misc, h_obs, d_frame, d_misc, full_rows, t_off, t_ctr):
+    """First node of a device-driven rollout step (``rlpyt_rollout_fetch``): pull the step's newest
+    frames / reward / done (and the full stacks of reset envs, or of all envs when ``*t_ctr == 0``)
+    out of the page-locked step buffer -- ``h_*`` are host-MAPPED tensors (``_lib.host_mapped_tensor``)
+    -- into the device staging buffers, set ``slot`` and publish ``t = *t_ctr`` at ``d_misc[t_off]``."""
+    _lib.require_gpu()
+    Bg = h_frame.shape[0]
+    frame_bytes = h_frame[0].numel() * h_frame.element_size()
+    row_bytes = h_obs[0].numel() * h_obs.element_size()
+    assert t_ctr.dtype == torch.int64 and full_rows.shape[0] >= Bg
+    check(lib.rlpyt_rollout_fetch(ptr(h_frame), ptr(h_misc), ptr(h_obs), ptr(d_frame), ptr(d_misc),
+                                  ptr(full_rows), int(Bg), int(frame_bytes), int(row_bytes),
+                                  int(t_off), ptr(t_ctr), stream()), "rlpyt_rollout_fetch")
+
+
 def rollout_head(partial, ksplit, fc_bias, w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, prob_rows,
-                 value_rows, action_rows, lo, action_out, bootstrap_out=None):
+                 value_rows, action_rows, lo, action_out, bootstrap_out=None, t_next=None):
     """Trunk finish + heads + softmax + draw + the step's row writes, one workgroup per row
     (``rlpyt_rollout_head_f32``); ``bootstrap_out`` ([n] f32): only the value head, written there
     (every row / uniform argument may then be None)."""
@@ -893,7 +908,7 @@ def rollout_head(partial, ksplit, fc_bias, w_pi, b_pi, w_v, b_v, uniforms, t_dev
         ptr(_f32(b_pi.detach())), ptr(_f32(w_v.detach()).reshape(-1)),
         ptr(_f32(b_v.detach()).reshape(-1)), ptr(uniforms), ptr(t_dev), int(n), K, A,
         ptr(prob_rows), ptr(value_rows), ptr(action_rows), B, int(lo), ptr(action_out),
-        ptr(bootstrap_out), stream()), "rlpyt_rollout_head_f32")
+        ptr(bootstrap_out), ptr(t_next), stream()), "rlpyt_rollout_head_f32")
 
 
 def frame_push(obs, t_dev, lo, new_frame, full_rows, slot, stage=None, scalar_rows=None):

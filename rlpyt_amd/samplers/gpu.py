@@ -45,6 +45,7 @@ from ..utils import logger
 from ..utils.buffer import (_map, buffer_from_example, buffer_leaves, np_mp_array,
                             torchify_buffer)
 from ..utils.collections import AttrDict, namedarraytuple
+from ..utils.misc import usable_cpus
 from ..utils.seed import set_seed
 from .base import BaseSampler
 from .collections import (AgentSamples, AgentSamplesBsv, EnvSamples, FramePush, Samples,
@@ -375,6 +376,12 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus, eval_runner=None):
         rn.start(ctrl.max_decorrelation_steps)
     ctrl.barrier_out.wait()
     spin = ctrl.worker_spin
+    if spin is None and ctrl.n_workers <= 2 * usable_cpus():
+        # poll ~1 ms for the next action set before sleeping: the hand-off is a few tens of us, a
+        # futex wake-up of 20 sleepers costs the poster ~7 us and the last sleeper ~10 us more
+        # (profiles/r4_rollout_chain_spin.jsonl: +4..6 % SPS); with many more workers than CPUs
+        # polling only steals time from the workers that have envs to step
+        spin = 30000
     if os.environ.get("RLPYT_WORKER_SPIN"):           # A/B experiments (rollout sweep)
         spin = int(os.environ["RLPYT_WORKER_SPIN"])
     seq = _StepSync(ctrl.sync_words, ctrl.group_workers, ctrl.n_workers, spin)
@@ -527,7 +534,7 @@ class GpuSampler(BaseSampler):
     def __init__(self, *args, n_workers=None, mid_batch_reset=True, pin_step_buffer=True,
                  n_groups=None, use_graph=True, frame_dedup=True, native_loop=True, fused_step=True,
                  fused_push=True, split_workers=False, zero_copy=True, zero_copy_frames=False,
-                 **kwargs):
+                 device_fetch=False, **kwargs):
         super().__init__(*args, **kwargs)
         # n_workers=None: one env worker per entry of affinity["workers_cpus"], the reference's
         # rule (rlpyt/samplers/parallel/base.py:157-172), resolved in initialize(); an explicit
@@ -547,6 +554,13 @@ class GpuSampler(BaseSampler):
         # kernel also READS the newest frames in place over PCIe (measured slower: off)
         self.zero_copy = bool(zero_copy)
         self.zero_copy_frames = bool(zero_copy_frames)
+        # device_fetch: the step's first kernel pulls the newest frames / scalars / reset stacks out
+        # of the page-locked step buffer itself and the time index lives in a device counter, so a
+        # step needs NO host call besides its graph launch -- and the native loop enqueues whole
+        # batches ahead of time behind stream waits on the workers' arrival counters
+        # (rlpyt_sampler_serve_ahead).  False (or RLPYT_DEVICE_FETCH=0): round 3's host-issued
+        # uploads + event-driven serve loop.
+        self.device_fetch = bool(device_fetch) and os.environ.get("RLPYT_DEVICE_FETCH", "1") != "0"
         self._native = None
         self._resolve_layout(None)
         self._pinned_ptrs = []
@@ -885,6 +899,25 @@ class GpuSampler(BaseSampler):
                 except Exception as e:  # noqa: BLE001
                     logger.log(f"GpuSampler: zero-copy frame reads unavailable ({e}); using DMA.")
             G.zc = G.zc_out        # (name kept for the tests / bench line)
+        # device-driven stepping (see __init__): host-mapped views of the step buffer for the fetch
+        # kernel + the device step counter
+        for G in self.groups:
+            G.dev_fetch = False
+            G.t_ctr = torch.zeros(1, dtype=torch.int64, device=dev) if cuda else None
+            pinned = self._pinned_ptrs
+            obs_np = G.step_np.observation
+            if (cuda and self.device_fetch and G.dedup and G.zc_out and not G.zc_in
+                    and isinstance(obs_np, np.ndarray) and obs_np.ctypes.data in pinned
+                    and G.blk_np.ctypes.data in pinned and obs_np[0].nbytes % 16 == 0
+                    and G.blk_np.ctypes.data % 16 == 0 and obs_np.ctypes.data % 16 == 0):
+                try:
+                    from .. import _lib
+                    G.h_frame = _lib.host_mapped_tensor(G.step_np.frame, dev)
+                    G.h_misc = _lib.host_mapped_tensor(G.misc_np, dev)
+                    G.h_obs = _lib.host_mapped_tensor(obs_np, dev)
+                    G.dev_fetch = True
+                except Exception as e:  # noqa: BLE001
+                    logger.log(f"GpuSampler: device-side fetch unavailable ({e}); host uploads.")
         self._lazy_obs.value = bool(all(G.dedup for G in self.groups))
         self._device_ready = True
 
@@ -904,6 +937,21 @@ class GpuSampler(BaseSampler):
         ``agent.step``; writes action -> all_action[t+1] (= action[t]) and agent_info[t].
         On the GPU the row writes are two ``rlpyt_commit_rows`` launches (all leaves at
         once); elsewhere torch ``index_copy_`` does the same thing leaf by leaf."""
+        t_next = None
+        if G.dev_fetch:
+            # device-driven stepping: the step pulls its own inputs out of the page-locked step
+            # buffer and reads / advances the device step counter -- no host upload precedes it
+            from .. import ops
+            ops.rollout_fetch(G.h_frame, G.h_misc, G.h_obs, G.frame_stage, G.misc_stage, G.full_rows,
+                              G.t_off, G.t_ctr)
+            t_next = G.t_ctr
+        if self._step_core(G, capturing, t_next) and t_next is not None:
+            # nobody downstream handed t + 1 to the counter (non-fused paths): one tiny launch
+            t_next.add_(1)
+
+    def _step_core(self, G, capturing, t_next):
+        """The step proper; returns True when the device step counter (``t_next``) still has to be
+        advanced by the caller."""
         s, t = self.samples, G.t_dev
         lo, hi = G.lo, G.hi
         if os.environ.get("RLPYT_NULL_STEP") == "1":
@@ -911,7 +959,7 @@ class GpuSampler(BaseSampler):
             # of a time step is the host side (env stepping, hand-offs, launches, DMA)
             _map(lambda x: x.zero_(), G.action_out)
             G.post_entries = None
-            return
+            return True
         fusable = (G.u_all is not None and self.mid_batch_reset and self.fused_step
                    and isinstance(self._all_action, torch.Tensor))
         if (fusable and G.dedup and G.pre_commit is not None and self.fused_push
@@ -923,10 +971,10 @@ class GpuSampler(BaseSampler):
                 push=FramePush(obs=s.env.observation, new_frame=G.frame_stage,
                                full_rows=G.full_rows, slot=G.slot_stage,
                                scalar_rows=(self._all_reward, G.reward_stage, self._all_done,
-                                            G.done_stage)))
+                                            G.done_stage)), t_next=t_next)
             if self.agent.step_into(None, None, None, binding):
                 G.post_entries = None
-                return
+                return False      # the head kernel advanced the step counter
         if G.pre_commit is not None:
             if G.dedup:
                 # one launch: rebuild the frame stacks of row t + commit the reward/done rows
@@ -969,7 +1017,7 @@ class GpuSampler(BaseSampler):
                                   push=None)
             if self.agent.step_into(G.obs_stage, prev_action, prev_reward, binding):
                 G.post_entries = None
-                return
+                return True
         self.agent.sample_generator = G.gen
         self.agent.sample_uniforms = None if G.u_all is None else (G.u_all, t)
         action, agent_info = self.agent.step(G.obs_stage, prev_action, prev_reward)
@@ -996,6 +1044,7 @@ class GpuSampler(BaseSampler):
             self._commit_rows(self._all_action, action, G, t + 1)
             self._commit_rows(s.agent.agent_info, agent_info, G, t)
             _copy_leaves(G.action_out, action)
+        return True
 
     def _tail_fused(self, G, cuda):
         """The tail as ONE more step of the group's fused kernels (non-recurrent agents that ignore
@@ -1016,9 +1065,14 @@ class GpuSampler(BaseSampler):
         bv = s.agent.bootstrap_value
         if not (isinstance(bv, torch.Tensor) and bv.dtype == torch.float32 and bv.is_contiguous()):
             return False
-        G.t_np[0] = T
-        self._upload_special(G, cuda, first=False)
-        self._upload_steady(G, cuda)
+        if G.dev_fetch:     # the device counter stands at T after the batch's T steps
+            from .. import ops
+            ops.rollout_fetch(G.h_frame, G.h_misc, G.h_obs, G.frame_stage, G.misc_stage, G.full_rows,
+                              G.t_off, G.t_ctr)
+        else:
+            G.t_np[0] = T
+            self._upload_special(G, cuda, first=False)
+            self._upload_steady(G, cuda)
         binding = StepBinding(
             action_rows=self._all_action, agent_info_rows=s.agent.agent_info,
             action_out=G.action_out, uniforms=G.u_all, t_dev=G.t_dev, lo=G.lo,
@@ -1057,7 +1111,7 @@ class GpuSampler(BaseSampler):
     def _upload_special(self, G, nb, first):
         """Host-dependent part of the upload (frame-stacked envs only): full stacks for the
         first step of a batch and for the few envs whose stack was reset."""
-        if not G.dedup:
+        if not G.dedup or G.dev_fetch:
             return
         if first:
             G.slot_np[:] = G.slot_all
@@ -1074,6 +1128,8 @@ class GpuSampler(BaseSampler):
     def _upload_steady(self, G, nb):
         """Fixed-address part of the upload: newest frames (or whole observations) + the
         reward/slot/done/reset block."""
+        if G.dev_fetch:
+            return          # the step's fetch kernel reads the page-locked buffer itself
         if G.dedup and not G.zc_in:
             G.blk_stage.copy_(G.blk_h, non_blocking=nb)      # newest frames + misc: one transfer
             return
@@ -1172,6 +1228,63 @@ class GpuSampler(BaseSampler):
         logger.log("GpuSampler: time-step loop handed to rlpyt_sampler_serve (native).")
         return True
 
+    def _ahead_ready(self):
+        """Device-driven stepping for every group (fetch kernel first in each captured step graph,
+        actions written in place): the native loop can enqueue the whole batch ahead of time
+        (``rlpyt_sampler_serve_ahead``).  Builds the group table once."""
+        if getattr(self, "_ahead", None) is not None:
+            return True
+        if getattr(self, "_ahead_failed", False) or os.environ.get("RLPYT_SERVE_AHEAD", "1") == "0":
+            return False
+        if not all(G.graph is not None and G.u_all is not None and G.dev_fetch and G.zc_out
+                   for G in self.groups):
+            return False
+        from .. import _lib
+        words = self.ctrl.sync_words
+        if words.ctypes.data not in self._pinned_ptrs:
+            rc = _lib.lib.rlpyt_host_register(ctypes.c_void_p(words.ctypes.data), int(words.nbytes))
+            if rc != 0:
+                logger.log(f"GpuSampler: cannot page-lock the hand-off words ({_lib.last_error()}); "
+                           "host-driven step loop.")
+                self._ahead_failed = True
+                return False
+            self._pinned_ptrs.append(words.ctypes.data)
+        base_dev = ctypes.c_void_p()
+        _lib.check(_lib.lib.rlpyt_host_device_pointer(ctypes.c_void_p(words.ctypes.data),
+                                                      ctypes.byref(base_dev)),
+                   "rlpyt_host_device_pointer")
+        arr = (_lib.AheadGroup * len(self.groups))()
+        for G, ag in zip(self.groups, arr):
+            ag.act_word, ag.obs_word = self.sync.act[G.idx], self.sync.obs[G.idx]
+            ag.act_word_dev = base_dev.value + 128 * G.idx
+            ag.obs_word_dev = base_dev.value + 128 * G.idx + 64
+            ag.n_workers = G.n_workers
+            ag.graph_exec = G.graph.raw_cuda_graph_exec()
+            ag.tail_graph_exec = None
+            ag.stream = (G.stream or torch.cuda.current_stream(self.device)).cuda_stream
+        self._ahead = arr
+        self._ahead_timing = (ctypes.c_double * 2)()
+        logger.log("GpuSampler: time-step loop enqueued ahead of the env workers "
+                   "(rlpyt_sampler_serve_ahead: stream waits on the arrival counters).")
+        return True
+
+    def _serve_ahead(self, T):
+        from .. import _lib
+        arr = self._ahead
+        for G, ag in zip(self.groups, arr):
+            ag.acts = self.sync.acts[G.idx] & 0xffffffff
+            ag.rounds = self.sync.rounds[G.idx] & 0xffffffff
+        tmg = self._ahead_timing
+        tmg[0] = tmg[1] = 0.
+        _lib.check(_lib.lib.rlpyt_sampler_serve_ahead(arr, len(self.groups), T, 120000, tmg),
+                   "rlpyt_sampler_serve_ahead")
+        for G in self.groups:
+            self.sync.acts[G.idx] += T
+            self.sync.rounds[G.idx] += T
+            G.calls += T
+        self.timing["device_issue_s"] += tmg[0]
+        self.timing["device_wait_s"] += tmg[1]
+
     def _native_ready_safe(self):
         try:
             return self._native_ready()
@@ -1180,6 +1293,16 @@ class GpuSampler(BaseSampler):
                        "using the Python loop.")
             self.native_loop = False
             self._native = None
+            return False
+
+    def _ahead_ready_safe(self):
+        try:
+            return self._ahead_ready()
+        except Exception as e:  # noqa: BLE001
+            logger.log(f"GpuSampler: enqueue-ahead step loop unavailable ({type(e).__name__}: {e}); "
+                       "host-driven loop.")
+            self._ahead_failed = True
+            self._ahead = None
             return False
 
     def _serve_spin(self):
@@ -1258,6 +1381,8 @@ class GpuSampler(BaseSampler):
             if G.stream is not None:
                 G.stream.wait_stream(torch.cuda.current_stream())   # see the updated weights
             with self._on_stream(G):
+                if G.t_ctr is not None:
+                    G.t_ctr.zero_()
                 if G.u_all is not None:
                     G.u_all.uniform_(generator=G.gen)
                 # leading prev_action row (collectors.py:23-24); prev_reward[0] and the
@@ -1265,7 +1390,9 @@ class GpuSampler(BaseSampler):
                 _map(lambda d, s: d[0, G.lo:G.hi].copy_(s, non_blocking=True),
                      self._all_action, G.step_pyt.action)
         tp1 = time.perf_counter()
-        if par and cuda and self.native_loop and self._native_ready_safe():
+        if par and cuda and self.native_loop and self._ahead_ready_safe():
+            self._serve_ahead(T)
+        elif par and cuda and self.native_loop and self._native_ready_safe():
             self._serve_native(T)
         else:
             for t in range(T):

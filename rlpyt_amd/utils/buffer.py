@@ -30,8 +30,12 @@ def np_mp_array(shape, dtype):
     shape = (shape,) if isinstance(shape, int) else tuple(shape)
     size = int(np.prod(shape))
     nbytes = max(size * np.dtype(dtype).itemsize, 1)
-    raw = mp.RawArray(ctypes.c_char, nbytes)
-    return np.frombuffer(raw, dtype=dtype, count=size).reshape(shape)
+    # 64-byte aligned (multiprocessing's heap only guarantees 8): kernels that read a page-locked
+    # step buffer in place use 16-byte lanes, and a cache-line-aligned start keeps neighbouring
+    # hand-off words of different arrays off one line
+    raw = mp.RawArray(ctypes.c_char, nbytes + 64)
+    off = (-ctypes.addressof(raw)) % 64
+    return np.frombuffer(raw, dtype=dtype, count=size, offset=off).reshape(shape)
 
 
 def buffer_from_example(example, leading_dims, share_memory=False, device=None, pinned=False):

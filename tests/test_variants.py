@@ -533,6 +533,12 @@ CASES["rollout_head_kernel<1>"] = _rollout_head_case(256)
 CASES["rollout_fc_kernel"] = _rollout_head_case(512)
 
 
+@case("rollout_fetch_kernel")
+def _rollout_fetch():
+    import test_sampler_gpu as S
+    S.test_rollout_fetch_kernel_matches_host_uploads()
+
+
 @case("frame_push_kernel")
 def _frame_push():
     """obs[t] = concat(obs[t-1][1:], newest frame), or a full row where slot >= 0; reward / done
