@@ -209,7 +209,8 @@ def main():
     if args.frozen_env:
         env_kwargs["frozen"] = True
     leg_steps = args.env_cost_leg_steps if (args.env_cost_leg_us > 0 and args.env_cost_us == 0) else 0
-    n_itr_total = args.warmup + args.steps + (1 + leg_steps if leg_steps else 0)
+    n_itr_total = (args.warmup + args.steps + (0 if args.no_kernel_timing else 2)
+                   + (1 + leg_steps if leg_steps else 0))
     # worker processes and their CPUs the reference's way: one worker per entry of
     # affinity["workers_cpus"] (rlpyt/samplers/parallel/base.py:157-172); rank r takes the r-th
     # block of the hardware threads
@@ -269,9 +270,6 @@ def main():
 
     for itr in range(args.warmup):
         one_step(itr)
-    if not args.no_kernel_timing:
-        ktimer.reset()
-        ktimer.enable(True)
     for k in sampler.timing:
         sampler.timing[k] = 0.
     wt = getattr(getattr(sampler, "ctrl", None), "worker_timing", None)
@@ -289,7 +287,6 @@ def main():
         opt_info = algo.optimize_agent(itr, samples)
     sync()
     elapsed = time.perf_counter() - t0
-    ktimer.enable(False)
     timing = dict(sampler.timing)         # (the env-cost leg below keeps adding to sampler.timing)
     worker_ms = None
     if wt0 is not None:
@@ -309,17 +306,36 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
-    ksum = ktimer.summary() if not args.no_kernel_timing else {}
+    # ---- kernel-timing leg: HIP events around every launch of the path's kernels.  Outside the
+    # timed region (which replays a captured update graph and takes no per-launch events): two
+    # more iterations with the update launched kernel by kernel, same shapes, same data path.
+    ksum = {}
+    KTIMER_NOTE = ("HIP events around each launch, on the launching stream, in 2 iterations run "
+                   "right after the timed region with the update launched eagerly (the timed region "
+                   "replays a captured update graph: no per-launch events inside it)")
+    if not args.no_kernel_timing:
+        graph_was = getattr(algo, "use_update_graph", None)
+        if graph_was is not None:
+            algo.use_update_graph = False
+        ktimer.reset()
+        ktimer.enable(True)
+        for k in range(2):
+            one_step(args.warmup + args.steps + k)
+        sync()
+        ktimer.enable(False)
+        ksum = ktimer.summary()
+        if graph_was is not None:
+            algo.use_update_graph = graph_was
     # ---- second leg: the same iteration with a declared ALE-like emulator cost per env step ----
     leg = None
     if leg_steps:
         cost_ref.value = float(args.env_cost_leg_us)
-        one_step(args.warmup + args.steps)               # untimed: workers pick up the new cost
+        one_step(args.warmup + args.steps + 2)           # untimed: workers pick up the new cost
         sync()
         tl = time.perf_counter()
         ts_leg = 0.
         for k in range(leg_steps):
-            itr = args.warmup + args.steps + 1 + k
+            itr = args.warmup + args.steps + 3 + k
             t1 = time.perf_counter()
             agent.sample_mode(itr)
             samples, _infos = sampler.obtain_samples(itr)
@@ -458,14 +474,14 @@ def main():
                                    "frac_alg_vs_bf16_peak": g["TFLOPs"] / BF16_MFMA_PEAK_TFLOPS,
                                    "alg_fp32_TFLOPs": g["TFLOPs"],
                                    "alg_over_f32_mfma_peak": g["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
-                                   "avg_us": g["avg_us"], "launches": g["launches"],
+                                   "avg_us": g["avg_us"], "avg_us_source": KTIMER_NOTE, "launches": g["launches"],
                                    "alg_flops_per_launch": g["alg_flops_per_launch"],
                                    "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
             elif "TFLOPs" in g:   # dense f32 contraction: priced against the fp32 MFMA peak
                 out["roofline"] = {"kernel": names.get(name, name), "bound": "mfma",
                                    "achieved": g["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": g["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
-                                   "traffic": None, "avg_us": g["avg_us"],
+                                   "traffic": None, "avg_us": g["avg_us"], "avg_us_source": KTIMER_NOTE,
                                    "launches": g["launches"],
                                    "alg_flops_per_launch": g["alg_flops_per_launch"],
                                    "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
@@ -474,7 +490,7 @@ def main():
                                    "bound": "hbm", "achieved": g["GBps"],
                                    "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                    "frac": g["GBps"] / HBM_PEAK_GBPS, "traffic": None,
-                                   "avg_us": g["avg_us"], "launches": g["launches"],
+                                   "avg_us": g["avg_us"], "avg_us_source": KTIMER_NOTE, "launches": g["launches"],
                                    "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
             if name != "conv2_bwd" and "conv2_bwd" in ksum:
                 # the conv2 backward pass, kept beside the dominant

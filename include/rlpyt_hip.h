@@ -191,6 +191,18 @@ int rlpyt_ppo_trunk_head_loss_fwd_bwd_f32(const float* z, const float* trunk_bia
                                           float* out_scalars, float* grad_z, float* grad_params,
                                           void* workspace, rlpyt_stream_t stream);
 
+/* The same for CAPTURED update graphs: ratio_clip_dev (nullable, device, 1 float) overrides
+ * ratio_clip at run time, so that one captured launch serves the reference's linear clip schedule
+ * (rlpyt/algos/pg/ppo.py:112-114). */
+int rlpyt_ppo_trunk_head_loss_fwd_bwd_dev_f32(
+    const float* z, const float* trunk_bias /*nullable*/, const float* w_pi, const float* b_pi,
+    const float* w_v, const float* b_v, const float* prob_old, const int64_t* action,
+    const float* advantage, const float* return_, const float* valid /*nullable*/,
+    const int64_t* flat_idx /*nullable*/, int T, int64_t B, int64_t M, int K, int A,
+    float ratio_clip, const float* ratio_clip_dev /*nullable*/, float value_loss_coeff,
+    float entropy_loss_coeff, float* out_scalars, float* grad_z, float* grad_params,
+    void* workspace, rlpyt_stream_t stream);
+
 /* c[M,N] = a[M,K] * b[N,K]^T, all f32 row-major -- the trunk Linear of the update
  * (rlpyt/models/mlp.py:24-31 via torch.nn.functional.linear: forward x W^T; with b = W^T the input
  * gradient g W).  Computed on the bf16 matrix pipe from exact three-piece bf16 splits of both
@@ -681,6 +693,26 @@ int rlpyt_clip_adam_step_f32(const rlpyt_adam_tensor* tensors_host, int n_tensor
                              double beta1, double beta2, double eps, double weight_decay,
                              int64_t step, double max_norm, void* workspace,
                              float* grad_norm_out, rlpyt_stream_t stream);
+/* Variants for CAPTURED minibatch updates (one hipGraph replayed for every update of the epochs x
+ * minibatches loop of rlpyt/algos/pg/ppo.py:92-104):
+ *  rlpyt_update_tick -- first launch of an update: cur = *ctr (clamped to the table);
+ *    hyper_cur[0:n_cols] = table[cur]; idx_static[0:M] = idx_all[cur*M : (cur+1)*M] (the update's
+ *    minibatch indices, at the fixed address the captured kernels read; both nullable together);
+ *    tick_idx[0] = cur (nullable).  table [n_rows, n_cols] f32 is computed on the host per
+ *    iteration (row k: lr / bc1, 1 / sqrt(bc2) of the k-th update, then free columns, e.g. the
+ *    ratio clip) -- the same double-precision bias corrections as the eager path, bit for bit.
+ *  rlpyt_clip_adam_step_dev_f32 -- rlpyt_clip_adam_step_f32 with hyper_dev (nullable, device:
+ *    {lr / bc1, 1 / sqrt(bc2)}) overriding lr / step at run time, and tick_ctr (nullable) advanced
+ *    by one at the end of the update. */
+int rlpyt_update_tick(const int64_t* ctr, const float* table, int n_rows, int n_cols,
+                      float* hyper_cur, const int64_t* idx_all /*nullable*/,
+                      int64_t* idx_static /*nullable*/, int64_t M, int64_t* tick_idx /*nullable*/,
+                      rlpyt_stream_t stream);
+int rlpyt_clip_adam_step_dev_f32(const rlpyt_adam_tensor* tensors_host, int n_tensors, double lr,
+                                 double beta1, double beta2, double eps, double weight_decay,
+                                 int64_t step, double max_norm, void* workspace,
+                                 float* grad_norm_out, const float* hyper_dev /*nullable*/,
+                                 int64_t* tick_ctr /*nullable*/, rlpyt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,9 @@ _SIGNATURES = {
     "rlpyt_ppo_trunk_head_loss_fwd_bwd_f32": (c_int, [_p] * 12 + [c_int, c_int64, c_int64, c_int, c_int,
                                                           c_float, c_float, c_float, _p, _p, _p, _p,
                                                           _p]),
+    "rlpyt_ppo_trunk_head_loss_fwd_bwd_dev_f32": (c_int, [_p] * 12 + [c_int, c_int64, c_int64, c_int,
+                                                              c_int, c_float, _p, c_float, c_float,
+                                                              _p, _p, _p, _p, _p]),
     "rlpyt_gemm_nt_f32": (c_int, [_p, _p, _p, c_int64, c_int64, c_int64, _p]),
     "rlpyt_gemm_nt_pp_f32": (c_int, [_p, _p, _p, c_int64, c_int64, c_int64, _p]),
     "rlpyt_gemm_nn_f32": (c_int, [_p, _p, _p, c_int64, c_int64, c_int64, _p]),
@@ -173,6 +176,9 @@ _SIGNATURES = {
     "rlpyt_clip_adam_workspace_bytes": (c_int64, []),
     "rlpyt_clip_adam_step_f32": (c_int, [_p, c_int, c_double, c_double, c_double, c_double, c_double,
                                          c_int64, c_double, _p, _p, _p]),
+    "rlpyt_clip_adam_step_dev_f32": (c_int, [_p, c_int, c_double, c_double, c_double, c_double,
+                                             c_double, c_int64, c_double, _p, _p, _p, _p, _p]),
+    "rlpyt_update_tick": (c_int, [_p, _p, c_int, c_int, _p, _p, _p, c_int64, _p, _p]),
     "rlpyt_sumtree_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_double,
                                      c_int, c_int]),
     "rlpyt_sumtree_destroy": (None, [_p]),

@@ -333,7 +333,10 @@ __global__ __launch_bounds__(64 * kHeadWavesPerBlock, 2) void ppo_head_loss_kern
     const float* __restrict__ valid, int64_t M, int A, float ratio_clip, float c_v, float c_e,
     float* __restrict__ grad_h, float* __restrict__ wpart, LossWs* __restrict__ ws,
     int n_valid_part, const int64_t* __restrict__ flat_idx, int T, int64_t B,
-    const float* __restrict__ trunk_bias) {
+    const float* __restrict__ trunk_bias, const float* __restrict__ ratio_clip_dev) {
+  // ratio_clip_dev != NULL (captured update graphs): the clip range of this update is read from
+  // device memory, so that one captured launch serves the whole schedule
+  if (ratio_clip_dev != nullptr) ratio_clip = *ratio_clip_dev;
   // trunk_bias != NULL: ``h`` is the trunk's PRE-activation without its bias, z = x W^T; the kernel
   // applies h = relu(z + b) while loading the row, returns dL/dz (masked by h > 0) in grad_h and
   // the bias gradient sum_m dL/dz[m] as K more floats of the partial row -- the trunk's bias add,
@@ -789,6 +792,19 @@ extern "C" int rlpyt_ppo_trunk_head_loss_fwd_bwd_f32(
     int T, int64_t B, int64_t M, int K, int A, float ratio_clip, float value_loss_coeff,
     float entropy_loss_coeff, float* out_scalars, float* grad_h, float* grad_params,
     void* workspace, rlpyt_stream_t stream) {
+  return rlpyt_ppo_trunk_head_loss_fwd_bwd_dev_f32(
+      h, trunk_bias, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, flat_idx, T,
+      B, M, K, A, ratio_clip, nullptr, value_loss_coeff, entropy_loss_coeff, out_scalars, grad_h,
+      grad_params, workspace, stream);
+}
+
+extern "C" int rlpyt_ppo_trunk_head_loss_fwd_bwd_dev_f32(
+    const float* h, const float* trunk_bias, const float* w_pi, const float* b_pi,
+    const float* w_v, const float* b_v, const float* prob_old, const int64_t* action,
+    const float* advantage, const float* return_, const float* valid, const int64_t* flat_idx,
+    int T, int64_t B, int64_t M, int K, int A, float ratio_clip, const float* ratio_clip_dev,
+    float value_loss_coeff, float entropy_loss_coeff, float* out_scalars, float* grad_h,
+    float* grad_params, void* workspace, rlpyt_stream_t stream) {
   RL_CHECK_ARG(flat_idx == nullptr || (T > 0 && B > 0), RLPYT_EINVAL,
                "rlpyt_ppo_trunk_head_loss_fwd_bwd_f32: flat_idx needs T, B");
   RL_CHECK_ARG(flat_idx == nullptr || valid == nullptr, RLPYT_ESHAPE,
@@ -818,7 +834,7 @@ extern "C" int rlpyt_ppo_trunk_head_loss_fwd_bwd_f32(
   RL_LAUNCH((ppo_head_loss_kernel<KI_, AM_, TB_>), dim3(grid), dim3(64 * kHeadWavesPerBlock), lds, \
             s, h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid, M, A,          \
             ratio_clip, value_loss_coeff, entropy_loss_coeff, grad_h, wpart, ws, n_valid_part,      \
-            flat_idx, T, B, trunk_bias)
+            flat_idx, T, B, trunk_bias, ratio_clip_dev)
 #define RL_HEAD(KI_, AM_)                                                                         \
   do {                                                                                            \
     if (trunk_bias != nullptr) RL_HEAD_TB(KI_, AM_, true); else RL_HEAD_TB(KI_, AM_, false);        \

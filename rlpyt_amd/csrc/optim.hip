@@ -54,7 +54,17 @@ __global__ __launch_bounds__(kOptBlock) void clip_adam_norm_kernel(AdamTable tab
 __global__ __launch_bounds__(kOptBlock) void clip_adam_apply_kernel(
     AdamTable tab, const double* __restrict__ partial, int n_partial, float lr_over_bc1,
     float inv_sqrt_bc2, float beta1, float beta2, float eps, float weight_decay, float max_norm,
-    float* __restrict__ grad_norm_out) {
+    float* __restrict__ grad_norm_out, const float* __restrict__ hyper,
+    int64_t* __restrict__ tick_ctr) {
+  // hyper != NULL (captured update graphs): {lr / bc1, 1 / sqrt(bc2)} of THIS update come from
+  // device memory (rlpyt_update_tick put them there from a host-computed table), so one captured
+  // launch serves every update; tick_ctr: the update counter that table is indexed by, advanced
+  // here -- the last launch of an update -- by one thread (nobody reads it in this kernel)
+  if (hyper != nullptr) {
+    lr_over_bc1 = hyper[0];
+    inv_sqrt_bc2 = hyper[1];
+  }
+  if (tick_ctr != nullptr && blockIdx.x == 0 && threadIdx.x == 0) tick_ctr[0] += 1;
   __shared__ double scratch[16];
   __shared__ float coef_s;
   double acc[1] = {0.0};
@@ -109,10 +119,44 @@ __global__ __launch_bounds__(kOptBlock) void clip_adam_apply_kernel(
   }
 }
 
+// First launch of a captured update: row `cur = *ctr` of the host-computed per-update table becomes
+// the update's hyper-parameters, the update's minibatch indices idx_all[cur * M : (cur + 1) * M]
+// are copied to the fixed address the captured kernels read, and `cur` is published as a device
+// index (for in-graph index_copy_ of the diagnostics row).  ctr itself is advanced by the update's
+// last launch (clip_adam_apply_kernel).
+__global__ __launch_bounds__(256) void update_tick_kernel(
+    const int64_t* __restrict__ ctr, const float* __restrict__ table, int n_rows, int n_cols,
+    float* __restrict__ hyper_cur, const int64_t* __restrict__ idx_all,
+    int64_t* __restrict__ idx_static, int64_t M, int64_t* __restrict__ tick_idx) {
+  const int64_t cur = min(max(ctr[0], (int64_t)0), (int64_t)n_rows - 1);
+  if (blockIdx.x == 0 && threadIdx.x < n_cols) hyper_cur[threadIdx.x] = table[cur * n_cols + threadIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && tick_idx != nullptr) tick_idx[0] = cur;
+  if (idx_all != nullptr) {
+    const int64_t* __restrict__ src = idx_all + cur * M;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
+         i += (int64_t)gridDim.x * blockDim.x)
+      idx_static[i] = src[i];
+  }
+}
+
 }  // namespace
 }  // namespace rlpyt
 
 using namespace rlpyt;
+
+extern "C" int rlpyt_update_tick(const int64_t* ctr, const float* table, int n_rows, int n_cols,
+                                 float* hyper_cur, const int64_t* idx_all, int64_t* idx_static,
+                                 int64_t M, int64_t* tick_idx, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(ctr && table && hyper_cur && n_rows > 0 && n_cols > 0 && n_cols <= 64, RLPYT_EINVAL,
+               "rlpyt_update_tick: bad arguments");
+  RL_CHECK_ARG((idx_all == nullptr) == (idx_static == nullptr) && M >= 0, RLPYT_EINVAL,
+               "rlpyt_update_tick: idx_all and idx_static go together");
+  const int grid = idx_all != nullptr ? (int)std::min<int64_t>(std::max<int64_t>(ceil_div(M, 256), 1), 64) : 1;
+  RL_LAUNCH(update_tick_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ctr, table, n_rows,
+            n_cols, hyper_cur, idx_all, idx_static, M, tick_idx);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
 
 extern "C" int64_t rlpyt_clip_adam_workspace_bytes(void) { return (int64_t)kOptGrid * sizeof(double); }
 
@@ -121,6 +165,17 @@ extern "C" int rlpyt_clip_adam_step_f32(const rlpyt_adam_tensor* tensors_host, i
                                         double weight_decay, int64_t step, double max_norm,
                                         void* workspace, float* grad_norm_out,
                                         rlpyt_stream_t stream) {
+  return rlpyt_clip_adam_step_dev_f32(tensors_host, n_tensors, lr, beta1, beta2, eps, weight_decay,
+                                      step, max_norm, workspace, grad_norm_out, nullptr, nullptr,
+                                      stream);
+}
+
+extern "C" int rlpyt_clip_adam_step_dev_f32(const rlpyt_adam_tensor* tensors_host, int n_tensors,
+                                            double lr, double beta1, double beta2, double eps,
+                                            double weight_decay, int64_t step, double max_norm,
+                                            void* workspace, float* grad_norm_out,
+                                            const float* hyper_dev, int64_t* tick_ctr,
+                                            rlpyt_stream_t stream) {
   RL_CHECK_ARG(tensors_host != nullptr && workspace != nullptr, RLPYT_EINVAL,
                "rlpyt_clip_adam_step_f32: null pointer");
   RL_CHECK_ARG(n_tensors > 0 && n_tensors <= RLPYT_ADAM_MAX_TENSORS, RLPYT_ESHAPE,
@@ -150,7 +205,7 @@ extern "C" int rlpyt_clip_adam_step_f32(const rlpyt_adam_tensor* tensors_host, i
   RL_LAUNCH_CHECK();
   RL_LAUNCH(clip_adam_apply_kernel, dim3(grid), dim3(kOptBlock), 0, s, tab, partial, grid,
             (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2, (float)eps,
-            (float)weight_decay, (float)max_norm, grad_norm_out);
+            (float)weight_decay, (float)max_norm, grad_norm_out, hyper_dev, tick_ctr);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

@@ -211,6 +211,10 @@ class _PpoHeadLoss(torch.autograd.Function):
     def forward(ctx, h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid,
                 ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None, trunk_bias=None):
         _lib.require_gpu()
+        rc_dev = None
+        if isinstance(ratio_clip, torch.Tensor):     # device scalar (captured update graphs)
+            rc_dev, ratio_clip = ratio_clip, 0.
+            assert rc_dev.dtype == torch.float32 and rc_dev.is_cuda and rc_dev.numel() == 1
         K = h.shape[-1]
         A = w_pi.shape[0]
         hc = _f32(h).reshape(-1, K)
@@ -235,12 +239,12 @@ class _PpoHeadLoss(torch.autograd.Function):
                               dtype=torch.float32, device=hc.device)
         ws = _workspace("head_loss", lib.rlpyt_ppo_head_loss_workspace_bytes(K, A), hc.device)
         with ktimer.region("ppo_head_loss", M * (8 * K + 8 * A + 28)):
-            check(lib.rlpyt_ppo_trunk_head_loss_fwd_bwd_f32(
+            check(lib.rlpyt_ppo_trunk_head_loss_fwd_bwd_dev_f32(
                 ptr(hc), ptr(tb), ptr(wp), ptr(bp), ptr(wv), ptr(bv), ptr(po), ptr(act), ptr(adv),
                 ptr(ret), ptr(val), ptr(flat_idx), int(T), int(B), M, K, A, float(ratio_clip),
-                float(value_loss_coeff),
+                ptr(rc_dev), float(value_loss_coeff),
                 float(entropy_loss_coeff), ptr(out), ptr(gh), ptr(gparams), ptr(ws), stream()),
-                "rlpyt_ppo_trunk_head_loss_fwd_bwd_f32")
+                "rlpyt_ppo_trunk_head_loss_fwd_bwd_dev_f32")
         ctx.save_for_backward(gh, gparams)
         ctx.meta = (h.shape, w_pi.shape, b_pi.shape, w_v.shape, b_v.shape, A, K,
                     None if trunk_bias is None else trunk_bias.shape)
@@ -851,6 +855,22 @@ def pg_sample_head(partial, ksplit, fc_bias, w_pi, b_pi, w_v, b_v, uniforms, t_d
         ptr(_f32(b_v.detach()).reshape(-1)), ptr(uniforms), ptr(t_dev), int(n), K, A,
         ptr(prob_rows), ptr(value_rows), ptr(action_rows), B, int(lo), ptr(action_out), stream()),
         "rlpyt_pg_sample_head_f32")
+
+
+def update_tick(ctr, table, hyper_cur, idx_all, idx_static, tick_idx):
+    """First launch of a captured minibatch update (``rlpyt_update_tick``): row ``*ctr`` of the
+    per-update hyper-parameter ``table [n, cols]`` -> ``hyper_cur [cols]``; the update's index chunk
+    ``idx_all[cur * M : (cur + 1) * M]`` -> ``idx_static [M]``; ``tick_idx[0] = cur``."""
+    _lib.require_gpu()
+    n_rows, n_cols = table.shape
+    assert table.dtype == torch.float32 and table.is_contiguous() and hyper_cur.numel() >= n_cols
+    assert ctr.dtype == torch.int64 and tick_idx.dtype == torch.int64
+    M = 0 if idx_static is None else idx_static.numel()
+    if idx_all is not None:
+        assert idx_all.dtype == torch.int64 and idx_all.is_contiguous() and idx_all.numel() >= n_rows * M
+    check(lib.rlpyt_update_tick(ptr(ctr), ptr(table), int(n_rows), int(n_cols), ptr(hyper_cur),
+                                ptr(idx_all), ptr(idx_static), int(M), ptr(tick_idx), stream()),
+          "rlpyt_update_tick")
 
 
 def rollout_fc_partials(x, weight):

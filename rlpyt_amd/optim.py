@@ -16,6 +16,7 @@ work unchanged), same ``state_dict`` layout (``step`` / ``exp_avg`` / ``exp_avg_
 optimizer snapshots interchange with the reference's.  ``step()`` alone is torch's own.
 """
 import ctypes
+import math
 
 import torch
 
@@ -43,6 +44,72 @@ class ClipAdam(torch.optim.Adam):
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                     return False
         return True
+
+    @torch.no_grad()
+    def launch_captured_step(self, max_norm, hyper_dev, tick_ctr):
+        """The two launches of ``clip_and_step`` with the update's ``lr / bc1`` and ``1 / sqrt(bc2)``
+        read from ``hyper_dev`` (device, 2 floats) at run time and ``tick_ctr`` (device int64)
+        advanced at the end -- for use INSIDE a captured update graph.  No host-side step counting:
+        the caller adds the number of replays to every ``state[p]["step"]`` (``advance_steps``).
+        Requires ``supports_fused()``, every parameter with a gradient and initialised state."""
+        group = self.param_groups[0]
+        rows = []
+        for p in group["params"]:
+            st = self.state[p]
+            g = p.grad
+            assert g is not None and len(st) and g.is_contiguous() and g.dtype == torch.float32
+            rows.append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+        assert 0 < len(rows) <= MAX_TENSORS
+        table = (AdamTensor * len(rows))()
+        for k, (p, g, m, v) in enumerate(rows):
+            table[k] = AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+        b1, b2 = group["betas"]
+        check(lib.rlpyt_clip_adam_step_dev_f32(
+            ctypes.cast(table, ctypes.c_void_p), len(rows), float(group["lr"]), float(b1), float(b2),
+            float(group["eps"]), float(group["weight_decay"]), 1,
+            float(max_norm) if max_norm else 0., ctypes.c_void_p(self._ws.data_ptr()),
+            ctypes.c_void_p(self._norm.data_ptr()), ctypes.c_void_p(hyper_dev.data_ptr()),
+            ctypes.c_void_p(tick_ctr.data_ptr()),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "rlpyt_clip_adam_step_dev_f32")
+        self._keep = rows
+        return self._norm
+
+    def captured_ready(self):
+        """True once ``launch_captured_step`` may be captured: fused path, every parameter has state
+        (an eager update ran) on one common step count."""
+        if not self.supports_fused() or self._ws is None:
+            return False
+        steps = set()
+        for p in self.param_groups[0]["params"]:
+            st = self.state.get(p, {})
+            if not len(st) or st["step"].is_cuda:
+                return False
+            steps.add(int(st["step"].item()))
+        return len(steps) == 1
+
+    def common_step(self):
+        p = self.param_groups[0]["params"][0]
+        return int(self.state[p]["step"].item())
+
+    def hyper_rows(self, n_updates):
+        """[(lr / bc1, 1 / sqrt(bc2))] of the next ``n_updates`` updates -- the eager path's
+        double-precision host arithmetic (csrc/optim.hip), one row per update."""
+        group = self.param_groups[0]
+        b1, b2 = group["betas"]
+        lr, step0 = float(group["lr"]), self.common_step()
+        rows = []
+        for k in range(1, n_updates + 1):
+            bc1, bc2 = 1.0 - b1 ** (step0 + k), 1.0 - b2 ** (step0 + k)
+            rows.append((lr / bc1, 1.0 / math.sqrt(bc2)))
+        return rows
+
+    def advance_steps(self, n_updates):
+        """Host-side bookkeeping of ``n_updates`` captured updates."""
+        params = self.param_groups[0]["params"]
+        for p in params:
+            self.state[p]["step"] += n_updates
+        torch.autograd.graph.increment_version(list(params))
+        self._opt_called = True
 
     @torch.no_grad()
     def clip_and_step(self, max_norm):
