@@ -138,8 +138,13 @@ class PPO(PolicyGradientAlgo):
     # minibatch: what changes between updates -- the minibatch indices, lr / Adam bias corrections,
     # the ratio clip -- comes from device memory (``ops.update_tick`` fills it from a per-iteration
     # host table, same double-precision arithmetic as the eager path), the diagnostics row goes to
-    # a device ring.  RLPYT_UPDATE_GRAPH=0 (or ``use_update_graph = False``) keeps the eager loop.
-    use_update_graph = os.environ.get("RLPYT_UPDATE_GRAPH", "1") != "0"
+    # a device ring.  MEASURED (profiles/r4_update_graph_trace_gaps.txt): the replayed update has no
+    # gaps between its kernels, yet its period is the eager loop's (1301.6 vs 1299.2 us per
+    # minibatch) -- what the eager trace shows as ~10 us "gaps" is the dispatch / cache write-back
+    # latency between dependent kernels, which a graph pays inside the next kernel's duration
+    # instead.  Bit-identical results (tests/test_pg_gpu.py), no speed-up: opt-in only
+    # (RLPYT_UPDATE_GRAPH=1 or ``use_update_graph = True``).
+    use_update_graph = os.environ.get("RLPYT_UPDATE_GRAPH", "0") == "1"
 
     def _update_graph_ok(self, observation):
         opt = self.optimizer
