@@ -660,6 +660,12 @@ int rlpyt_sumtree_advance(rlpyt_sumtree* t, int T_new, const double* priorities,
  * The sampled tree indices are remembered inside the handle (device) for update(). */
 int rlpyt_sumtree_sample(rlpyt_sumtree* t, const double* uniforms, int n, int64_t* T_idxs,
                          int64_t* B_idxs, double* priorities, rlpyt_stream_t stream);
+/* Last step of sample(n, unique=True) -- sum_tree.py:109-128: `leaves` (device int64 [n], leaf =
+ * T_idx * B + B_idx) become the set the next rlpyt_sumtree_update applies to; their priorities are
+ * returned (nullable).  The de-duplication / re-draw loop itself runs in the binding, on the host
+ * RNG stream the reference uses. */
+int rlpyt_sumtree_set_sampled(rlpyt_sumtree* t, const int64_t* leaves, int n, double* priorities,
+                              rlpyt_stream_t stream);
 /* update_batch_priorities -- sum_tree.py:130-153,206-209.  new_priorities device f64 [n]
  * (already ** alpha); duplicates among the last sampled indices are removed keeping the
  * FIRST occurrence in batch order (np.unique(return_index=True) semantics). */

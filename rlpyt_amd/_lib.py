@@ -190,6 +190,7 @@ _SIGNATURES = {
     "rlpyt_sumtree_copy_tree": (c_int, [_p, _p, _p]),
     "rlpyt_sumtree_advance": (c_int, [_p, c_int, _p, c_int, _p]),
     "rlpyt_sumtree_sample": (c_int, [_p, _p, c_int, _p, _p, _p, _p]),
+    "rlpyt_sumtree_set_sampled": (c_int, [_p, _p, c_int, _p, _p]),
     "rlpyt_sumtree_update": (c_int, [_p, _p, c_int, _p]),
 }
 

@@ -14,24 +14,18 @@ import torch
 
 from ... import ops
 from ...agents.base import AgentInputs
-from ...replays.sequence import (PrioritizedSequenceReplayFrameBuffer,
-                                 UniformSequenceReplayFrameBuffer)
-from ...utils import logger
 from ...utils.buffer import buffer_method
-from ...utils.collections import namedarraytuple
-from ...utils.quick_args import save__init__args
 from ...utils.tensor import select_at_indexes, valid_mean
-from .dqn import DQN, SamplesToBuffer
+from .dqn import DQN
+from .replay_algo import Prioritised, ReplayFeed
 
 OptInfo = namedtuple("OptInfo", ["loss", "gradNorm", "tdAbsErr", "priority"])
-SamplesToBufferRnn = namedarraytuple("SamplesToBufferRnn",
-                                     SamplesToBuffer._fields + ("prev_rnn_state",))
-PrioritiesSamplesToBuffer = namedarraytuple("PrioritiesSamplesToBuffer",
-                                            ["priorities", "samples"])
 
 
 class R2D1(DQN):
     opt_info_fields = tuple(OptInfo._fields)
+    OptInfoCls = OptInfo
+    SEQUENCE_REPLAY = True
 
     def __init__(self, discount=0.997, batch_T=80, batch_B=64, warmup_T=40,
                  store_rnn_state_interval=40, min_steps_learn=int(1e5), delta_clip=None,
@@ -42,108 +36,66 @@ class R2D1(DQN):
                  pri_beta_init=0.9, pri_beta_final=0.9, pri_beta_steps=int(50e6), pri_eta=0.9,
                  default_priority=None, input_priorities=True, input_priority_shift=None,
                  value_scale_eps=1e-3, ReplayBufferCls=None, updates_per_sync=1):
-        if optim_kwargs is None:
-            optim_kwargs = dict(eps=1e-3)
-        if default_priority is None:
-            default_priority = delta_clip or 1.
-        if input_priority_shift is None:
-            input_priority_shift = warmup_T // store_rnn_state_interval
-        target_update_tau = 1
-        save__init__args(locals())
-        self._batch_size = (self.batch_T + self.warmup_T) * self.batch_B
+        hp = dict(locals())
+        hp.pop("self")
+        hp["optim_kwargs"] = dict(eps=1e-3) if optim_kwargs is None else optim_kwargs
+        hp["default_priority"] = (delta_clip or 1.) if default_priority is None else default_priority
+        if input_priority_shift is None:      # priorities of a batch belong to sequences that
+            hp["input_priority_shift"] = warmup_T // store_rnn_state_interval   # started earlier
+        hp["target_update_tau"] = 1
+        self.__dict__.update(hp)
+        # a "training batch" for the replay-ratio arithmetic: every stored step of every sequence
+        self._batch_size = (batch_T + warmup_T) * batch_B
         self.update_counter = 0
 
-    @property
-    def batch_size(self):
-        return self._batch_size
+    def make_feed(self):
+        keeps_state = self.store_rnn_state_interval > 0
+        return ReplayFeed(ReplayFeed.RNN if keeps_state else ReplayFeed.STEP,
+                          "SamplesToBufferRnn" if keeps_state else "SamplesToBuffer")
 
-    def initialize_replay_buffer(self, examples, batch_spec, async_=False):
-        example_to_buffer = SamplesToBuffer(observation=examples["observation"],
-                                            action=examples["action"],
-                                            reward=examples["reward"], done=examples["done"])
-        if self.store_rnn_state_interval > 0:
-            example_to_buffer = SamplesToBufferRnn(
-                *example_to_buffer, prev_rnn_state=examples["agent_info"].prev_rnn_state)
-        replay_kwargs = dict(example=example_to_buffer, size=self.replay_size, B=batch_spec.B,
-                             discount=self.discount, n_step_return=self.n_step_return,
-                             rnn_state_interval=self.store_rnn_state_interval,
-                             batch_T=self.batch_T + self.warmup_T, device=self.agent.device)
+    def replay_settings(self, batch_spec):
+        kw = super().replay_settings(batch_spec)
+        kw.update(rnn_state_interval=self.store_rnn_state_interval,
+                  batch_T=self.batch_T + self.warmup_T)
         if self.prioritized_replay:
-            replay_kwargs.update(dict(alpha=self.pri_alpha, beta=self.pri_beta_init,
-                                      default_priority=self.default_priority,
-                                      input_priorities=self.input_priorities,
-                                      input_priority_shift=self.input_priority_shift))
-            ReplayCls = PrioritizedSequenceReplayFrameBuffer
-        else:
-            ReplayCls = UniformSequenceReplayFrameBuffer
-        if self.ReplayBufferCls is not None:
-            ReplayCls = self.ReplayBufferCls
-            logger.log(f"WARNING: ignoring internal selection logic and using input replay "
-                       f"buffer class: {ReplayCls} -- compatibility not guaranteed.")
-        self.replay_buffer = ReplayCls(**replay_kwargs)
-        return self.replay_buffer
+            kw.update(input_priorities=self.input_priorities,
+                      input_priority_shift=self.input_priority_shift)
+        return kw
 
-    def optimize_agent(self, itr, samples=None, sampler_itr=None):
-        itr = itr if sampler_itr is None else sampler_itr
-        if samples is not None:
-            self.replay_buffer.append_samples(self.samples_to_buffer(samples))
-        opt_info = OptInfo(*([] for _ in range(len(OptInfo._fields))))
-        if itr < self.min_itr_learn:
-            return opt_info
-        stats, tds, pris = [], [], []
-        for _ in range(self.updates_per_optimize):
-            samples_from_replay = self.replay_buffer.sample_batch(self.batch_B)
-            self.optimizer.zero_grad(set_to_none=True)
-            loss, td_abs_errors, priorities = self.loss(samples_from_replay)
-            loss.backward()
-            grad_norm = self.clip_and_step()
-            if self.prioritized_replay:
-                self.replay_buffer.update_batch_priorities(priorities)
-            stats.append(torch.stack([loss.detach(), grad_norm.to(loss.dtype)]))
-            tds.append(td_abs_errors[::8].reshape(-1))     # every 8th time step (r2d1.py:166)
-            pris.append(priorities)
-            self.update_counter += 1
-            if self.update_counter % self.target_update_interval == 0:
-                self.agent.update_target()
-        host = torch.stack(stats).cpu().tolist()    # one D2H per call for the diagnostics
-        opt_info.loss.extend(r[0] for r in host)
-        opt_info.gradNorm.extend(r[1] for r in host)
-        opt_info.tdAbsErr.extend(torch.cat(tds).cpu().tolist())
-        opt_info.priority.extend(torch.cat(pris).cpu().tolist())
-        self.update_itr_hyperparams(itr)
-        return opt_info
+    def ingest(self, samples):
+        record = self.feed.from_samples(samples)
+        if self.input_priorities:      # fresh sequences enter the tree with their own TD errors
+            record = Prioritised(priorities=self.input_priorities_of(samples), samples=record)
+        self.replay_buffer.append_samples(record)
 
-    def samples_to_buffer(self, samples):
-        samples_to_buffer = super().samples_to_buffer(samples)
-        if self.store_rnn_state_interval > 0:
-            samples_to_buffer = SamplesToBufferRnn(
-                *samples_to_buffer, prev_rnn_state=samples.agent.agent_info.prev_rnn_state)
-        if self.input_priorities:
-            samples_to_buffer = PrioritiesSamplesToBuffer(
-                priorities=self.compute_input_priorities(samples), samples=samples_to_buffer)
-        return samples_to_buffer
+    def one_update(self, log):
+        batch = self.replay_buffer.sample_batch(self.batch_B)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss, td_abs, priorities = self.loss(batch)
+        loss.backward()
+        grad_norm = self.clip_and_step()
+        if self.prioritized_replay:
+            self.replay_buffer.update_batch_priorities(priorities)
+        log.add((loss, grad_norm), tdAbsErr=td_abs[::8], priority=priorities)   # r2d1.py:166
 
     @torch.no_grad()
-    def compute_input_priorities(self, samples):
-        """n-step TD errors from the Q-values recorded while sampling, value-rescaled, reduced
-        over time to one priority per env column: eta*max + (1-eta)*mean over valid steps
-        (r2d1.py:181-242), all on the device."""
+    def input_priorities_of(self, samples):
+        """One priority per env column of a fresh sampler batch, on the device: the n-step TD
+        errors implied by the Q-values recorded while sampling (value-rescaled targets), reduced
+        over the valid time steps as ``eta * max + (1 - eta) * mean`` (r2d1.py:181-242)."""
+        n, eta = self.n_step_return, self.pri_eta
+        lag = max(1, n - 1)
         q = samples.agent.agent_info.q
-        action = samples.agent.action
-        q_max = torch.max(q, dim=-1).values
-        q_at_a = select_at_indexes(action, q)
-        return_n, done_n = ops.discount_return_n_step(samples.env.reward, samples.env.done,
-                                                      self.n_step_return, self.discount,
-                                                      do_truncated=False)
-        nm1 = max(1, self.n_step_return - 1)
-        y = self.value_scale(return_n + (1 - done_n.float()) * self.inv_value_scale(q_max[nm1:]))
-        delta = torch.abs(q_at_a[:-nm1] - y)
+        chosen = select_at_indexes(samples.agent.action, q)[:-lag]
+        best_later = q.max(dim=-1).values[lag:]
+        ret, done_n = ops.discount_return_n_step(samples.env.reward, samples.env.done, n,
+                                                 self.discount, do_truncated=False)
+        target = self.squash(ret + (1 - done_n.float()) * self.unsquash(best_later))
+        err = (chosen - target).abs()
         if self.delta_clip is not None:
-            delta = torch.clamp(delta, 0, self.delta_clip)
-        valid = ops.valid_from_done(samples.env.done[:-nm1].contiguous())
-        max_d = torch.max(delta * valid, dim=0).values
-        mean_d = valid_mean(delta, valid, dim=0)
-        return self.pri_eta * max_d + (1 - self.pri_eta) * mean_d
+            err = err.clamp(0, self.delta_clip)
+        live = ops.valid_from_done(samples.env.done[:-lag].contiguous())
+        return eta * (err * live).max(dim=0).values + (1 - eta) * valid_mean(err, live, dim=0)
 
     def loss(self, samples):
         """r2d1.py:244-334: warm the LSTM up on the first ``warmup_T`` steps (no grad), train on
@@ -186,10 +138,10 @@ class R2D1(DQN):
                              self.discount ** self.n_step_return, self.delta_clip,
                              self.value_scale_eps, self.pri_eta)
 
-    def value_scale(self, x):
+    def squash(self, x):
         return torch.sign(x) * (torch.sqrt(torch.abs(x) + 1) - 1) + self.value_scale_eps * x
 
-    def inv_value_scale(self, z):
+    def unsquash(self, z):
         e = self.value_scale_eps
         return torch.sign(z) * (((torch.sqrt(1 + 4 * e * (torch.abs(z) + 1 + e)) - 1)
                                  / (2 * e)) ** 2 - 1)

@@ -482,6 +482,42 @@ extern "C" int rlpyt_sumtree_sample(rlpyt_sumtree* t, const double* uniforms, in
   return RLPYT_OK;
 }
 
+namespace rlpyt {
+namespace {
+__global__ __launch_bounds__(256) void set_sampled_kernel(const double* __restrict__ tree,
+                                                          int64_t low_idx, int64_t n_leaves,
+                                                          const int64_t* __restrict__ leaves, int n,
+                                                          int64_t* __restrict__ prev_idx,
+                                                          double* __restrict__ priorities) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t leaf = min(max(leaves[i], (int64_t)0), n_leaves - 1);
+  prev_idx[i] = low_idx + leaf;
+  if (priorities != nullptr) priorities[i] = tree[low_idx + leaf];
+}
+}  // namespace
+}  // namespace rlpyt
+
+// Declares `leaves` (leaf = T_idx * B + B_idx, device int64 [n]) the set the next
+// rlpyt_sumtree_update applies to, and returns their priorities: the last step of the reference's
+// `sample(n, unique=True)` (rlpyt/replays/sum_tree.py:109-128), whose de-duplication / re-draw loop
+// runs on the host RNG stream in the binding.
+extern "C" int rlpyt_sumtree_set_sampled(rlpyt_sumtree* t, const int64_t* leaves, int n,
+                                         double* priorities, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(t && (leaves || n == 0), RLPYT_EINVAL, "rlpyt_sumtree_set_sampled: null pointer");
+  RL_CHECK_ARG(n >= 0, RLPYT_EINVAL, "rlpyt_sumtree_set_sampled: negative n");
+  DeviceGuard dev_guard(t->device);
+  int rc = ensure_prev(t, std::max(n, 1));
+  if (rc != RLPYT_OK) return rc;
+  t->n_prev = n;
+  if (n == 0) return RLPYT_OK;
+  RL_LAUNCH(rlpyt::set_sampled_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+            (hipStream_t)stream, t->tree, t->low_idx, (int64_t)t->T * t->B, leaves, n, t->prev_idx,
+            priorities);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
 extern "C" int rlpyt_sumtree_update(rlpyt_sumtree* t, const double* new_priorities, int n,
                                     rlpyt_stream_t stream) {
   RL_CHECK_ARG(t && new_priorities, RLPYT_EINVAL, "rlpyt_sumtree_update: null pointer");

@@ -1230,6 +1230,32 @@ class DeviceSumTree:
                                        stream()), "rlpyt_sumtree_sample")
         return T_idxs, B_idxs, pri
 
+    def sample_unique(self, n, max_tries=100):
+        """``sample(n, unique=True)`` of rlpyt/replays/sum_tree.py:101-128: ``n`` DISTINCT leaves,
+        sorted by tree index.  The descents run on the device; the de-duplication / re-draw loop
+        consumes ``np.random.rand`` exactly as the reference does (n values, then 2 x the shortfall
+        per retry) and needs the indices on the host -- an off-hot-path option."""
+        import numpy as np
+
+        def find(k):
+            u = torch.from_numpy(np.random.rand(int(k))).to(self.device)
+            T_i, B_i, _ = self.sample(u)
+            return (T_i * self.B + B_i).cpu().numpy()
+
+        leaves = find(n)
+        for _ in range(max_tries):
+            leaves = np.unique(leaves)
+            if len(leaves) >= n:
+                break
+            leaves = np.concatenate([leaves, find(2 * (n - len(leaves)))])
+        if len(leaves) < n:
+            raise RuntimeError("After 100 tries, unable to get unique indexes.")
+        leaves = torch.from_numpy(np.ascontiguousarray(leaves[:n])).to(self.device)
+        pri = torch.empty(n, dtype=torch.float64, device=self.device)
+        check(lib.rlpyt_sumtree_set_sampled(self._h, ptr(leaves), int(n), ptr(pri), stream()),
+              "rlpyt_sumtree_set_sampled")
+        return leaves // self.B, leaves % self.B, pri
+
     def update_batch_priorities(self, priorities):
         p = priorities.to(device=self.device, dtype=torch.float64).contiguous()
         check(lib.rlpyt_sumtree_update(self._h, ptr(p), p.numel(), stream()),

@@ -349,6 +349,30 @@ def gen_sumtree():
     save("sumtree", **out)
 
 
+def gen_sumtree_unique():
+    """The reference ``SumTree.sample(n, unique=True)`` (rlpyt/replays/sum_tree.py:109-128) on a
+    skewed tree: several draws (with their re-draw loops consuming np.random), each followed by
+    ``update_batch_priorities``; a near-full draw that needs many retries."""
+    out = {}
+    T, B = 24, 3
+    t = SumTree(T, B, 2, 1, default_value=1)
+    rng = np.random.RandomState(7)
+    t.advance(10, priorities=rng.rand(10, B) ** 4 + 1e-3) if t.input_priorities is not None \
+        else t.advance(10)
+    np.random.seed(11)
+    for k, n in enumerate([6, 12, 5, 20]):
+        (Ti, Bi), p = t.sample(n, unique=True)
+        new = rng.rand(n) ** 3 + 1e-3
+        t.update_batch_priorities(new)
+        out.update({f"T{k}": Ti, f"B{k}": Bi, f"p{k}": p, f"new{k}": new,
+                    f"root{k}": np.float64(t.tree[0]), f"tree{k}": t.tree.copy()})
+        if k == 1:
+            t.advance(5)
+    out["after"] = np.random.rand(3)         # where the host RNG stream stands afterwards
+    out["geom"] = np.array([T, B, 2, 1, 10, 5])
+    save("sumtree_unique", **out)
+
+
 def gen_frames():
     from rlpyt.replays.non_sequence.frame import NStepFrameBuffer
     from rlpyt.replays.sequence.frame import SequenceNStepFrameBuffer
@@ -1192,7 +1216,7 @@ if __name__ == "__main__":
     np.random.seed(0)
     gens = dict(scans=gen_scans, nstep=gen_nstep, normalize=gen_normalize, losses=gen_losses,
                 categorical=gen_categorical,
-                sumtree=gen_sumtree, frames=gen_frames, replay=gen_replay,
+                sumtree=gen_sumtree, sumtree_unique=gen_sumtree_unique, frames=gen_frames, replay=gen_replay,
                 seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
                 models=gen_models, sampler=gen_sampler, algos=gen_algos, algos_big=gen_algos_big,
                 dqn_iterations=gen_dqn_iterations,

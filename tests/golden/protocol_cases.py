@@ -33,17 +33,17 @@ PROTOCOL = {
         ("rlpyt_amd.agents.dqn.r2d1_agent.AtariR2d1Agent", _DQN_AGENT),
     # replay buffers (algos/dqn/dqn.py:133-156,169-182,279)
     "rlpyt.replays.non_sequence.frame.UniformReplayFrameBuffer":
-        ("rlpyt_amd.replays.non_sequence.UniformReplayFrameBuffer", _REPLAY),
+        ("rlpyt_amd.replays.buffers.UniformReplayFrameBuffer", _REPLAY),
     "rlpyt.replays.non_sequence.frame.PrioritizedReplayFrameBuffer":
-        ("rlpyt_amd.replays.non_sequence.PrioritizedReplayFrameBuffer", _PRI_REPLAY),
+        ("rlpyt_amd.replays.buffers.PrioritizedReplayFrameBuffer", _PRI_REPLAY),
     "rlpyt.replays.non_sequence.uniform.UniformReplayBuffer":
-        ("rlpyt_amd.replays.non_sequence.UniformReplayBuffer", _REPLAY),
+        ("rlpyt_amd.replays.buffers.UniformReplayBuffer", _REPLAY),
     "rlpyt.replays.non_sequence.prioritized.PrioritizedReplayBuffer":
-        ("rlpyt_amd.replays.non_sequence.PrioritizedReplayBuffer", _PRI_REPLAY),
+        ("rlpyt_amd.replays.buffers.PrioritizedReplayBuffer", _PRI_REPLAY),
     "rlpyt.replays.sequence.frame.UniformSequenceReplayFrameBuffer":
-        ("rlpyt_amd.replays.sequence.UniformSequenceReplayFrameBuffer", _REPLAY),
+        ("rlpyt_amd.replays.buffers.UniformSequenceReplayFrameBuffer", _REPLAY),
     "rlpyt.replays.sequence.frame.PrioritizedSequenceReplayFrameBuffer":
-        ("rlpyt_amd.replays.sequence.PrioritizedSequenceReplayFrameBuffer", _PRI_REPLAY),
+        ("rlpyt_amd.replays.buffers.PrioritizedSequenceReplayFrameBuffer", _PRI_REPLAY),
     # runners (the classes under which the path drops in)
     "rlpyt.runners.minibatch_rl.MinibatchRl": ("rlpyt_amd.runners.minibatch_rl.MinibatchRl",
                                                ["__init__", "train"]),

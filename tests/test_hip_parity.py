@@ -502,7 +502,7 @@ def test_replay_buffer_stream_vs_reference(ops, name):
     UniformReplayFrameBuffer (appends with ring wraps, n-step returns, frame store
     duplication, sampling with the same np.random seed, priority updates): every sampled
     field must be identical; importance weights within fp32 tolerance (device pow)."""
-    from rlpyt_amd.replays.non_sequence import (PrioritizedReplayFrameBuffer,
+    from rlpyt_amd.replays.buffers import (PrioritizedReplayFrameBuffer,
                                                 UniformReplayFrameBuffer)
     from rlpyt_amd.utils.collections import namedarraytuple
     g = load_golden("replay")
@@ -554,7 +554,7 @@ def test_sequence_replay_stream_vs_reference(ops, name):
     """Stream recorded from the reference's (Prioritized|Uniform)SequenceReplayFrameBuffer
     (R2D1 geometry in miniature: rnn_state_interval=4, batch_T=8, n_step=2, input
     priorities with shift 1, alpha=1 so the tree stream is exact): every field identical."""
-    from rlpyt_amd.replays.sequence import (PrioritizedSequenceReplayFrameBuffer,
+    from rlpyt_amd.replays.buffers import (PrioritizedSequenceReplayFrameBuffer,
                                             UniformSequenceReplayFrameBuffer)
     from rlpyt_amd.utils.collections import namedarraytuple
     g = load_golden("seq_replay")
@@ -674,3 +674,25 @@ def test_model_matches_cpu_port_weights(ops):
     pg, vg = gpu(x.cuda(), None, None)
     np.testing.assert_allclose(host(pg.detach()), pc.detach().numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(host(vg.detach()), vc.detach().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_sumtree_unique_sampling_matches_reference():
+    """``DeviceSumTree.sample_unique`` == the reference's ``SumTree.sample(n, unique=True)``
+    (rlpyt/replays/sum_tree.py:109-128; golden recorded from the reference class,
+    make_golden.py gen_sumtree_unique): same distinct, sorted leaves, same priorities, same
+    consumption of the host RNG stream by the re-draw loop, same tree after every update."""
+    from rlpyt_amd import ops
+    g = load_golden("sumtree_unique")
+    T, B, ob, of, adv0, adv1 = (int(x) for x in g["geom"])
+    tree = ops.DeviceSumTree(T=T, B=B, off_backward=ob, off_forward=of, default_value=1.)
+    tree.advance(adv0)
+    np.random.seed(11)
+    for k, n in enumerate([6, 12, 5, 20]):
+        Ti, Bi, p = tree.sample_unique(n)
+        assert np.array_equal(Ti.cpu().numpy(), g[f"T{k}"]) and np.array_equal(Bi.cpu().numpy(), g[f"B{k}"])
+        assert np.array_equal(p.cpu().numpy(), g[f"p{k}"])
+        tree.update_batch_priorities(torch.from_numpy(g[f"new{k}"]).cuda())
+        assert np.array_equal(tree.tree_tensor().cpu().numpy(), g[f"tree{k}"])
+        if k == 1:
+            tree.advance(adv1)
+    assert np.array_equal(np.random.rand(3), g["after"])

@@ -689,6 +689,32 @@ def _sumtree():
     P.test_sumtree_vs_oracle_random_stream(_ops())
 
 
+@case("set_sampled_kernel")
+def _sumtree_unique():
+    import test_hip_parity as P
+    P.test_sumtree_unique_sampling_matches_reference()
+
+
+@case("update_tick_kernel")
+def _update_tick():
+    """Row ``*ctr`` of the hyper table + the update's index chunk land at their fixed addresses; the
+    counter itself is advanced by the optimizer's apply kernel."""
+    ops = _ops()
+    n, cols, M = 5, 4, 1000
+    g = torch.Generator().manual_seed(3)
+    table = torch.randn(n, cols, generator=g).cuda()
+    idx_all = torch.randint(0, 10 ** 6, (n * M,), generator=g).cuda()
+    hyper = torch.zeros(cols, device="cuda")
+    idx = torch.zeros(M, dtype=torch.int64, device="cuda")
+    tick = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for cur in (0, 3, 4, 9):            # 9: beyond the table -> clamped to its last row
+        ctr = torch.tensor([cur], dtype=torch.int64, device="cuda")
+        ops.update_tick(ctr, table, hyper, idx_all, idx, tick)
+        c = min(cur, n - 1)
+        assert torch.equal(hyper, table[c]) and torch.equal(idx, idx_all[c * M:(c + 1) * M])
+        assert int(tick.item()) == c and int(ctr.item()) == cur
+
+
 @case("fill_f64_kernel", "write_input_pri_kernel")
 def _sumtree_input_priorities():
     import test_hip_parity as P
