@@ -13,7 +13,6 @@ import torch
 from ..models.utils import strip_ddp_state_dict
 from ..utils import logger
 from ..utils.collections import namedarraytuple
-from ..utils.quick_args import save__init__args
 
 AgentInputs = namedarraytuple("AgentInputs", ["observation", "prev_action", "prev_reward"])
 AgentStep = namedarraytuple("AgentStep", ["action", "agent_info"])
@@ -27,43 +26,47 @@ class BaseAgent:
 
     def __init__(self, ModelCls=None, model_kwargs=None, initial_model_state_dict=None,
                  host_outputs=False):
-        save__init__args(locals())
-        self.model = None
-        self.shared_model = None
-        self.distribution = None
+        self.ModelCls, self.model_kwargs = ModelCls, dict(model_kwargs or {})
+        self.initial_model_state_dict, self.host_outputs = initial_model_state_dict, host_outputs
+        self.model = self.shared_model = self.distribution = None
         self.device = torch.device("cpu")
         self._mode = None
         self.sample_generator = None   # torch.Generator for action draws (None: default)
         # (uniform table [T', B], device row index) for agents whose sampling forward can draw
         # from pre-generated uniforms (keeps RNG state out of captured hipGraphs)
         self.sample_uniforms = None
-        if self.model_kwargs is None:
-            self.model_kwargs = dict()
 
     def __call__(self, observation, prev_action, prev_reward):
         raise NotImplementedError
 
+    def _new_model(self, state_dict=None):
+        """A model instance for this agent's env (``make_env_to_model_kwargs``) and settings,
+        optionally loaded with ``state_dict``."""
+        model = self.ModelCls(**self.env_model_kwargs, **self.model_kwargs)
+        if state_dict is not None:
+            model.load_state_dict(state_dict)
+        return model
+
     def initialize(self, env_spaces, share_memory=False, **kwargs):
+        """Build the model for ``env_spaces`` on the host (samplers call this before any worker is
+        forked; ``share_memory`` keeps a fork-shared copy for CPU samplers, base.py:64-93)."""
+        self.env_spaces, self.share_memory = env_spaces, share_memory
         self.env_model_kwargs = self.make_env_to_model_kwargs(env_spaces)
-        self.model = self.ModelCls(**self.env_model_kwargs, **self.model_kwargs)
+        self.model = self._new_model(self.initial_model_state_dict)
         if share_memory:
-            self.model.share_memory()
-            self.shared_model = self.model
-        if self.initial_model_state_dict is not None:
-            self.model.load_state_dict(self.initial_model_state_dict)
-        self.env_spaces = env_spaces
-        self.share_memory = share_memory
+            self.shared_model = self.model.share_memory()
 
     def make_env_to_model_kwargs(self, env_spaces):
         return {}
 
     def to_device(self, cuda_idx=None):
+        """Move the model to ``cuda:<cuda_idx>`` (None: stay on the host).  A fork-shared model
+        stays behind for the CPU workers; the device gets its own copy."""
         if cuda_idx is None:
             return
-        if self.shared_model is not None:
-            self.model = self.ModelCls(**self.env_model_kwargs, **self.model_kwargs)
-            self.model.load_state_dict(self.shared_model.state_dict())
         self.device = torch.device("cuda", index=cuda_idx)
+        if self.shared_model is not None:
+            self.model = self._new_model(self.shared_model.state_dict())
         self.model.to(self.device)
         logger.log(f"Initialized agent model on device: {self.device}.")
 
@@ -142,19 +145,26 @@ class BaseAgent:
     def load_state_dict(self, state_dict):
         self.model.load_state_dict(state_dict)
 
+    # The three modes differ in: the module's train flag, whether fused-step weight buffers need a
+    # refresh (any mode the sampler steps the agent in), and what subclasses hook on (epsilon,
+    # recurrent state): one table, one transition function.
+    _MODES = {"train": (True, False), "sample": (False, True), "eval": (False, True)}
+
+    def _enter(self, mode, itr):
+        training, steps_envs = self._MODES[mode]
+        self.model.train(training)
+        self._mode = mode
+        if steps_envs:
+            self._refresh_step_weights()
+
     def train_mode(self, itr):
-        self.model.train()
-        self._mode = "train"
+        self._enter("train", itr)
 
     def sample_mode(self, itr):
-        self.model.eval()
-        self._mode = "sample"
-        self._refresh_step_weights()
+        self._enter("sample", itr)
 
     def eval_mode(self, itr):
-        self.model.eval()
-        self._mode = "eval"
-        self._refresh_step_weights()
+        self._enter("eval", itr)
 
     def _refresh_step_weights(self):
         """Models that keep derived weight buffers for their fused sampling step (read by address
@@ -164,8 +174,11 @@ class BaseAgent:
             m()
 
     def sync_shared_memory(self):
-        if self.shared_model is not None and self.shared_model is not self.model:
-            self.shared_model.load_state_dict(strip_ddp_state_dict(self.model.state_dict()))
+        """Publish the trained parameters to the fork-shared copy the CPU workers read."""
+        shared = self.shared_model
+        if shared is None or shared is self.model:
+            return
+        shared.load_state_dict(strip_ddp_state_dict(self.model.state_dict()))
 
     def toggle_alt(self):
         pass
@@ -236,19 +249,14 @@ class RecurrentAgentMixin:
             for x in buffer_leaves(cur):
                 x.mul_((~mask).reshape(1, -1, 1).to(x.dtype))
 
-    def train_mode(self, itr):
-        if self._mode == "sample":
-            self._stash = self._rnn_states
-        self._rnn_states = {}
-        super().train_mode(itr)
-
-    def sample_mode(self, itr):
-        if self._mode != "sample" and self._stash is not None:
-            self._rnn_states = self._stash
-        super().sample_mode(itr)
-
-    def eval_mode(self, itr):
-        if self._mode == "sample":
-            self._stash = self._rnn_states
-        self._rnn_states = {}
-        super().eval_mode(itr)
+    def _enter(self, mode, itr):
+        """Sampling state survives the excursions into training / evaluation: it is parked when the
+        agent leaves sample mode and restored when it comes back; train and eval start stateless."""
+        if mode == "sample":
+            if self._mode != "sample" and self._stash is not None:
+                self._rnn_states = self._stash
+        else:
+            if self._mode == "sample":
+                self._stash = self._rnn_states
+            self._rnn_states = {}
+        super()._enter(mode, itr)

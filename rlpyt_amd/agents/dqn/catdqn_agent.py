@@ -11,23 +11,26 @@ AgentInfo = namedarraytuple("AgentInfo", ["p"])
 
 
 class CatDqnAgent(DqnAgent):
+    """Acts greedily on the MEAN of its categorical return distributions: the atom grid ``z``
+    belongs to the algorithm (``V_min`` / ``V_max``), which hands it over with ``set_support``;
+    until then a unit grid stands in."""
+
     def __init__(self, n_atoms=51, **kwargs):
         super().__init__(**kwargs)
         self.n_atoms = self.model_kwargs["n_atoms"] = n_atoms
 
-    def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
-        super().initialize(env_spaces, share_memory, global_B, env_ranks)
-        # z is a placeholder until the algorithm hands over V_min / V_max
-        self.distribution = CategoricalEpsilonGreedy(dim=env_spaces.action.n,
-                                                     z=torch.linspace(-1, 1, self.n_atoms))
+    def make_distribution(self, n_actions):
+        return CategoricalEpsilonGreedy(dim=n_actions, z=torch.linspace(-1, 1, self.n_atoms))
 
     def to_device(self, cuda_idx=None):
         super().to_device(cuda_idx)
         self.distribution.set_z(self.distribution.z.to(self.device))
 
-    def give_V_min_max(self, V_min, V_max):
+    def set_support(self, V_min, V_max):
         self.V_min, self.V_max = V_min, V_max
         self.distribution.set_z(torch.linspace(V_min, V_max, self.n_atoms, device=self.device))
+
+    give_V_min_max = set_support       # the reference's name for it (catdqn_agent.py:28)
 
     @torch.no_grad()
     def step(self, observation, prev_action, prev_reward):

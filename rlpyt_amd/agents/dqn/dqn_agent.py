@@ -6,39 +6,70 @@ from ...models.dqn.atari_dqn_model import AtariDqnModel
 from ...models.utils import update_state_dict
 from ...utils import logger
 from ...utils.collections import namedarraytuple
-from ...utils.quick_args import save__init__args
 from ..base import AgentStep, BaseAgent
 
 AgentInfo = namedarraytuple("AgentInfo", "q")
 
 
+class EpsilonSchedule:
+    """Exploration rate as a function of the iteration: linear from ``init`` to ``final`` between
+    ``itr_min`` and ``itr_max``, held afterwards; ``evaluation`` rate separately (fully random at
+    iteration 0, before anything was learned).  ``final`` becomes a per-environment vector when a
+    ``final_min`` is given: one log-spaced ladder over the GLOBAL environment index, of which every
+    rank takes the rungs of its own envs (values of rlpyt/agents/dqn/epsilon_greedy.py:47-63,
+    96-106,120-131; pinned by tests/golden/agents.npz)."""
+
+    def __init__(self, init, final, final_min, itr_min, itr_max, eval_eps):
+        self.init, self.final, self.final_min = init, final, final_min
+        self.itr_min, self.itr_max, self.eval_eps = itr_min, itr_max, eval_eps
+        self._scalar = (init, final)
+        self.current = init
+
+    def spread_over_envs(self, global_B, env_ranks):
+        init0, final0 = self._scalar
+        if self.final_min is not None and self.final_min != final0:
+            ladder = torch.logspace(torch.log10(torch.tensor(self.final_min)),
+                                    torch.log10(torch.tensor(final0)), global_B)
+            self.init, self.final = init0 * torch.ones(len(env_ranks)), ladder[env_ranks]
+        self.current = self.init
+
+    def sampling(self, itr):
+        if itr <= self.itr_max:
+            frac = min(1, max(0, itr - self.itr_min) / (self.itr_max - self.itr_min))
+            self.current = frac * self.final + (1 - frac) * self.init
+        return self.current
+
+    def evaluation(self, itr):
+        return self.eval_eps if itr > 0 else 1.
+
+
+def _schedule_field(name):
+    return property(lambda self: getattr(self.eps, name),
+                    lambda self, v: setattr(self.eps, name, v))
+
+
 class EpsilonGreedyAgentMixin:
-    """Epsilon schedule: linear from eps_init to eps_final between eps_itr_min and
-    eps_itr_max; optional log-spaced per-env vector epsilon (``eps_final_min``)."""
+    """Agents that act epsilon-greedily while sampling: owns an ``EpsilonSchedule`` (its fields are
+    readable / settable on the agent under the reference's attribute names) and applies it whenever
+    the agent enters sample or eval mode."""
 
     def __init__(self, eps_init=1, eps_final=0.01, eps_final_min=None, eps_itr_min=50,
                  eps_itr_max=1000, eps_eval=0.001, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        save__init__args(locals())
-        self._eps_final_scalar = eps_final
-        self._eps_init_scalar = eps_init
+        self.eps = EpsilonSchedule(eps_init, eps_final, eps_final_min, eps_itr_min, eps_itr_max,
+                                   eps_eval)
+
+    eps_init, eps_final = _schedule_field("init"), _schedule_field("final")
+    eps_itr_min, eps_itr_max = _schedule_field("itr_min"), _schedule_field("itr_max")
+    eps_eval, eps_sample = _schedule_field("eval_eps"), _schedule_field("current")
 
     def collector_initialize(self, global_B=1, env_ranks=None):
         if env_ranks is not None:
-            self.make_vec_eps(global_B, env_ranks)
-
-    def make_vec_eps(self, global_B, env_ranks):
-        if self.eps_final_min is not None and self.eps_final_min != self._eps_final_scalar:
-            self.eps_init = self._eps_init_scalar * torch.ones(len(env_ranks))
-            global_eps_final = torch.logspace(torch.log10(torch.tensor(self.eps_final_min)),
-                                              torch.log10(torch.tensor(self._eps_final_scalar)),
-                                              global_B)
-            self.eps_final = global_eps_final[env_ranks]
-        self.eps_sample = self.eps_init
+            self.eps.spread_over_envs(global_B, env_ranks)
 
     def set_epsilon_itr_min_max(self, eps_itr_min, eps_itr_max):
-        logger.log(f"Agent setting min/max epsilon itrs: {eps_itr_min}, {eps_itr_max}")
-        self.eps_itr_min, self.eps_itr_max = eps_itr_min, eps_itr_max
+        logger.log(f"Agent: epsilon anneals between iterations {eps_itr_min} and {eps_itr_max}.")
+        self.eps.itr_min, self.eps.itr_max = eps_itr_min, eps_itr_max
 
     def set_sample_epsilon_greedy(self, epsilon):
         self.distribution.set_epsilon(epsilon)
@@ -48,16 +79,12 @@ class EpsilonGreedyAgentMixin:
         vector epsilon is sliced accordingly."""
         self.distribution.select_envs(lo, hi)
 
-    def sample_mode(self, itr):
-        super().sample_mode(itr)
-        if itr <= self.eps_itr_max:
-            prog = min(1, max(0, itr - self.eps_itr_min) / (self.eps_itr_max - self.eps_itr_min))
-            self.eps_sample = prog * self.eps_final + (1 - prog) * self.eps_init
-        self.distribution.set_epsilon(self.eps_sample)
-
-    def eval_mode(self, itr):
-        super().eval_mode(itr)
-        self.distribution.set_epsilon(self.eps_eval if itr > 0 else 1.)
+    def _enter(self, mode, itr):
+        super()._enter(mode, itr)
+        if mode == "sample":
+            self.distribution.set_epsilon(self.eps.sampling(itr))
+        elif mode == "eval":
+            self.distribution.set_epsilon(self.eps.evaluation(itr))
 
 
 class DqnAgent(EpsilonGreedyAgentMixin, BaseAgent):
@@ -67,28 +94,30 @@ class DqnAgent(EpsilonGreedyAgentMixin, BaseAgent):
         return self._out(self.model(obs, pa, pr))
 
     def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
-        init_sd = self.initial_model_state_dict
-        self.initial_model_state_dict = None
+        """Online + target network.  An ``initial_model_state_dict`` is a ``{"model": ...}`` record
+        and seeds BOTH; without one the target keeps its OWN random initialisation until the first
+        target update, as in the reference (dqn_agent.py:39-43) -- pinned by the reference's DQN
+        iterations in tests/golden/dqn_iterations.npz."""
+        seed_sd, self.initial_model_state_dict = self.initial_model_state_dict, None
         super().initialize(env_spaces, share_memory, global_B=global_B, env_ranks=env_ranks)
-        self.target_model = self.ModelCls(**self.env_model_kwargs, **self.model_kwargs)
-        # as the reference (dqn_agent.py:39-43): without an initial state dict the target network
-        # keeps its OWN random initialisation until the first target update -- pinned by the
-        # reference's DQN iterations in tests/golden/dqn_iterations.npz
-        if init_sd is not None:
-            self.model.load_state_dict(init_sd["model"])
-            self.target_model.load_state_dict(init_sd["model"])
-        self.distribution = EpsilonGreedy(dim=env_spaces.action.n)
-        self.eps_sample = self.eps_init
+        self.initial_model_state_dict = seed_sd
+        self.target_model = self._new_model()
+        if seed_sd is not None:
+            for net in (self.model, self.target_model):
+                net.load_state_dict(seed_sd["model"])
+        self.distribution = self.make_distribution(env_spaces.action.n)
         self._n_local_envs = None if env_ranks is None else len(env_ranks)
-        if env_ranks is not None:
-            self.make_vec_eps(global_B, env_ranks)
+        self.collector_initialize(global_B, env_ranks)
+
+    def make_distribution(self, n_actions):
+        return EpsilonGreedy(dim=n_actions)
 
     def to_device(self, cuda_idx=None):
         super().to_device(cuda_idx)
         self.target_model.to(self.device)
         # epsilon in persistent device buffers: visible to step graphs captured earlier
         self.distribution.bind_device(self.device, getattr(self, "_n_local_envs", None))
-        self.distribution.set_epsilon(self.eps_sample)
+        self.distribution.set_epsilon(self.eps.current)
 
     @property
     def supports_sample_uniforms(self):

@@ -18,22 +18,24 @@ class PolicyGradientAlgo(RlAlgorithm):
 
     def initialize(self, agent, n_itr, batch_spec, mid_batch_reset=False, examples=None,
                    world_size=1, rank=0):
-        self.optimizer = self.make_optimizer(agent.parameters(), self.OptimCls, self.learning_rate,
-                                             self.optim_kwargs)
-        if self.initial_optim_state_dict is not None:
-            self.optimizer.load_state_dict(self.initial_optim_state_dict)
         if getattr(agent, "recurrent", False) and not getattr(self, "supports_recurrent", False):
-            # fail at initialize(), not in the middle of the first minibatch loop
+            # refuse here, not in the middle of the first minibatch loop
             raise NotImplementedError(
                 f"{type(self).__name__}: recurrent policy-gradient agents "
                 "(rlpyt/agents/pg/categorical.py:54-106, rlpyt/algos/pg/ppo.py:84-86) are not "
                 "built on this path yet; use a feed-forward agent (AtariFfAgent).")
-        self.agent = agent
-        self.n_itr = n_itr
-        self.batch_spec = batch_spec
-        self.mid_batch_reset = mid_batch_reset
-        self.rank = rank
-        self.world_size = world_size
+        self.__dict__.update(agent=agent, n_itr=n_itr, batch_spec=batch_spec,
+                             mid_batch_reset=mid_batch_reset, world_size=world_size, rank=rank)
+        self.optimizer = self._fresh_optimizer(agent)
+
+    def _fresh_optimizer(self, agent):
+        """The constructor's optimizer over the agent's parameters, resumed from
+        ``initial_optim_state_dict`` when one was given."""
+        opt = self.make_optimizer(agent.parameters(), self.OptimCls, self.learning_rate,
+                                  self.optim_kwargs)
+        if self.initial_optim_state_dict is not None:
+            opt.load_state_dict(self.initial_optim_state_dict)
+        return opt
 
     def process_returns(self, samples):
         """(return_, advantage, valid) as HBM tensors: one fused scan launch computes

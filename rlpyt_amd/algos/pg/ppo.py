@@ -40,11 +40,15 @@ class PPO(PolicyGradientAlgo):
 
     def initialize(self, *args, **kwargs):
         super().initialize(*args, **kwargs)
-        self._batch_size = self.batch_spec.size // self.minibatches
+        self._batch_size = self.batch_spec.size // self.minibatches     # per-update batch
         if self.linear_lr_schedule:
-            self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(
-                optimizer=self.optimizer, lr_lambda=lambda itr: (self.n_itr - itr) / self.n_itr)
+            # both the learning rate and the ratio clip decay linearly to 0 over the run
+            # (ppo.py:46-57,112-114): remaining(itr) is the factor for iteration itr
             self._ratio_clip = self.ratio_clip
+            self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, self.remaining)
+
+    def remaining(self, itr):
+        return (self.n_itr - itr) / self.n_itr
 
     def optimize_agent(self, itr, samples):
         recurrent = self.agent.recurrent

@@ -27,20 +27,23 @@ class ScaleGrad(torch.autograd.Function):
 scale_grad = ScaleGrad.apply
 
 
+_DDP_PREFIX = "module."
+
+
 def strip_ddp_state_dict(state_dict):
-    """Drop DistributedDataParallel's ``module.`` key prefix."""
-    out = type(state_dict)()
-    for k, v in state_dict.items():
-        out[k[7:] if k.startswith("module.") else k] = v
-    return out
+    """Keys without DistributedDataParallel's wrapper prefix (same mapping type, same order)."""
+    n = len(_DDP_PREFIX)
+    return type(state_dict)((k[n:] if k.startswith(_DDP_PREFIX) else k, v)
+                            for k, v in state_dict.items())
 
 
 def update_state_dict(model, state_dict, tau=1, strip_ddp=True):
-    """Hard (tau=1) or soft (0<tau<1: tau*new + (1-tau)*old) parameter update."""
-    if strip_ddp:
-        state_dict = strip_ddp_state_dict(state_dict)
-    if tau == 1:
-        model.load_state_dict(state_dict)
-    elif tau > 0:
-        model.load_state_dict({k: tau * state_dict[k] + (1 - tau) * v
-                               for k, v in model.state_dict().items()})
+    """Move ``model`` towards ``state_dict``: ``tau = 1`` copies, ``0 < tau < 1`` blends
+    ``tau * new + (1 - tau) * old`` entry by entry (target networks), ``tau <= 0`` does nothing."""
+    if tau <= 0:
+        return
+    new = strip_ddp_state_dict(state_dict) if strip_ddp else state_dict
+    if tau != 1:
+        old = model.state_dict()
+        new = {name: tau * new[name] + (1 - tau) * cur for name, cur in old.items()}
+    model.load_state_dict(new)
