@@ -555,6 +555,7 @@ def main():
             fn = isolated_functions(T, B)
             out["roofline_replay"] = fn.pop("roofline_replay")
             out["cpu_baseline"]["functions"] = fn
+        _canary_report(out)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -1003,8 +1004,21 @@ def replay_config_main(args):
         "roofline_replay": replay,
         "last_loss": (info.loss[-1] if info.loss else None),
     }
+    _canary_report(out)
     print(json.dumps(out), flush=True)
 
 
+def _canary_report(out):
+    """RLPYT_CANARY=1 (debug): every device buffer of the package sits between 0xFF guard bands
+    (rlpyt_amd/utils/canary.py); verify them once the run is over and say so in the line."""
+    if os.environ.get("RLPYT_CANARY", "0") == "1":
+        from rlpyt_amd.utils import canary
+        n = canary.check("at the end of bench.py")
+        out["canary"] = dict(canary.stats(), buffers_checked=n, result="clean")
+
+
 if __name__ == "__main__":
+    if os.environ.get("RLPYT_CANARY", "0") == "1":
+        from rlpyt_amd.utils import canary as _c
+        _c.enable()
     main()

@@ -21,3 +21,18 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+# ---- guard-band mode (RLPYT_CANARY=1): every CUDA buffer this package allocates is surrounded by
+# 0xFF guards (rlpyt_amd/utils/canary.py) and the guards are verified after every test ------------
+_CANARY = os.environ.get("RLPYT_CANARY", "0") == "1"
+if _CANARY:
+    from rlpyt_amd.utils import canary as _canary
+    _canary.enable()
+
+
+@pytest.fixture(autouse=True)
+def _canary_guard(request):
+    yield
+    if _CANARY and request.node.get_closest_marker("gpu") is not None:
+        _canary.check(f"after {request.node.nodeid}")

@@ -696,3 +696,28 @@ def test_sumtree_unique_sampling_matches_reference():
         if k == 1:
             tree.advance(adv1)
     assert np.array_equal(np.random.rand(3), g["after"])
+
+
+def test_canary_guard_bands_catch_out_of_bounds_writes():
+    """The guard-band debug mode itself (rlpyt_amd/utils/canary.py): an in-bounds kernel leaves the
+    guards alone, one byte written past a buffer is reported with the buffer's description, and an
+    out-of-bounds float read sees NaN."""
+    from rlpyt_amd.utils import canary
+    was_on = canary.enabled()
+    canary.enable()
+    try:
+        x = torch.zeros((5, 7), dtype=torch.float32, device="cuda")
+        y = torch.empty_like(x)
+        y.copy_(x + 1)
+        assert canary.check("self-test, clean") >= 2
+        raw = x._base                                    # the padded allocation behind the view
+        assert raw is not None and raw.numel() >= 2 * canary.GUARD + x.numel() * 4
+        after = raw[canary.GUARD + x.numel() * 4:canary.GUARD + x.numel() * 4 + 8]
+        assert torch.isnan(after[:4].view(torch.float32)).all()      # an OOB float read: NaN
+        after[3] = 7                                      # ... and an OOB write of one byte
+        with pytest.raises(AssertionError, match=r"\(5, 7\) torch.float32.*bytes after"):
+            canary.check("self-test, dirty")
+        assert canary.check("self-test, repaired") >= 2   # (check() restores the pattern)
+    finally:
+        if not was_on:
+            canary.disable()
