@@ -23,7 +23,7 @@ import torch
 
 GUARD = 4096
 _orig = {}
-_live = []          # [(weakref to the padded uint8 tensor, nbytes, description)]
+_live = []          # [(weakref to the tensor handed out, padded uint8 tensor, nbytes, description)]
 _stats = dict(allocs=0, checks=0)
 
 
@@ -54,8 +54,12 @@ def _padded(shape, dtype, device, zero):
     inner = raw[GUARD:GUARD + nbytes].view(dtype).reshape(shape)
     if zero:
         inner.zero_()
-    _live.append((weakref.ref(raw), nbytes, f"{tuple(shape)} {dtype} @ {_site()}"))
+    # the padded tensor is held HERE (a weak reference to it dies at once: a view keeps the storage
+    # alive, not the base's Python object) and let go when the tensor handed out has died
+    _live.append((weakref.ref(inner), raw, nbytes, f"{tuple(shape)} {dtype} @ {_site()}"))
     _stats["allocs"] += 1
+    if _stats["allocs"] % 256 == 0:
+        _live[:] = [e for e in _live if e[0]() is not None]
     return inner
 
 
@@ -116,11 +120,10 @@ def check(what=""):
         return 0
     torch.cuda.synchronize()
     bad, keep, n = [], [], 0
-    for ref, nbytes, desc in _live:
-        raw = ref()
-        if raw is None:
+    for ref, raw, nbytes, desc in _live:
+        if ref() is None:
             continue
-        keep.append((ref, nbytes, desc))
+        keep.append((ref, raw, nbytes, desc))
         n += 1
         head, tail = raw[:GUARD], raw[GUARD + nbytes:]
         if not (bool((head == 0xFF).all()) and bool((tail == 0xFF).all())):

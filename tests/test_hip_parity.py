@@ -712,6 +712,7 @@ def test_canary_guard_bands_catch_out_of_bounds_writes():
         assert canary.check("self-test, clean") >= 2
         raw = x._base                                    # the padded allocation behind the view
         assert raw is not None and raw.numel() >= 2 * canary.GUARD + x.numel() * 4
+        assert canary.stats()["live"] >= 2
         after = raw[canary.GUARD + x.numel() * 4:canary.GUARD + x.numel() * 4 + 8]
         assert torch.isnan(after[:4].view(torch.float32)).all()      # an OOB float read: NaN
         after[3] = 7                                      # ... and an OOB write of one byte
