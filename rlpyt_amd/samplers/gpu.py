@@ -364,6 +364,11 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus, eval_runner=None):
     [(group index, EnvRunner)]: this worker's environments, served in group order (with
     dedicated workers per pipeline group there is exactly one entry)."""
     _die_with_parent()
+    # Everything inherited from the master at fork time stays out of this process' garbage
+    # collector: device tensors caught in reference cycles there would be "freed" here, in a
+    # process without a HIP context (seen as a segfault inside gc under the guard-band debug mode).
+    import gc
+    gc.freeze()
     try:
         if cpus is not None:
             import psutil
@@ -773,6 +778,8 @@ class GpuSampler(BaseSampler):
         # unless affinity["set_affinity"] is False
         cpus = affinity.get("workers_cpus", None) if affinity.get("set_affinity", True) else None
         self.workers = []
+        import gc
+        gc.collect()       # (cyclic garbage of the master is collected HERE, where HIP is valid)
         for w in range(n):
             wc = None if cpus is None else cpus[w % len(cpus)]
             wc = [wc] if isinstance(wc, int) else wc
