@@ -142,5 +142,13 @@ def check(what=""):
     return n
 
 
+def guards_of(tensor):
+    """(guard before, guard after) of a tensor handed out by the canary -- uint8 views, for tests."""
+    for ref, raw, nbytes, _ in _live:
+        if ref() is tensor:
+            return raw[:GUARD], raw[GUARD + nbytes:]
+    raise KeyError("not a live canary allocation")
+
+
 def stats():
     return dict(_stats, live=len(_live))
