@@ -418,6 +418,13 @@ def main():
                        "host_cpu_quota": cpus,
                        "parallelism": f"dp{world}"},
             "sampling_frac_of_step": t_sample / (elapsed if elapsed > 0 else 1.),
+            # how the SAME launch rule lays out 2 / 4 / 8 ranks under this box's CPU quota: the
+            # rollout needs ~B env steps of host CPU per time step and rank, so the first scaling
+            # curve on a quota-limited box is a curve of host CPUs per rank
+            "layout_at_n_ranks": {str(n): {"cpu_quota_share": round(cpus / n, 2),
+                                           "env_workers": max(min(int(round(1.25 * cpus / n)), B // 10), 1),
+                                           "serve_threads_spin": bool(cpus / n >= 6)}
+                                  for n in (1, 2, 4, 8)},
             "sampler": {"pipeline_groups": sampler.n_groups, "hip_graph": not args.no_graph,
                         "ms_per_time_step": t_sample / args.steps / T * 1e3,
                         "master_wait_env_ms": timing["wait_env_s"] / args.steps / T * 1e3,
@@ -548,6 +555,8 @@ def main():
             out["kernels"] = {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv)
                                   for kk, vv in v.items()} for k, v in ksum.items()}
         out["roofline_gae_scaled"] = gae_scaled_roofline()
+        if world == 1 and not args.no_kernel_timing:
+            out["roofline_rollout"] = rollout_step_roofline(B // max(sampler.n_groups, 1))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, args.cpu_baseline_B, dict(step_cost_us=args.env_cost_us))
             # the isolated hot-path functions, HIP kernel beside the CPU restatement
@@ -617,6 +626,101 @@ def pmc_traffic(name, g):
                           "WRITE_SIZE passes over scripts/conv_bench.py / scripts/gemm_bench.py, "
                           "M=8192; scripts/pmc_update.sh)"}
     return None
+
+
+def rollout_step_roofline(Bg=64, T=128, B=256):
+    """The three kernels of a rollout group-step, each timed in isolation:
+    20 back-to-back launches of ONE kernel captured in a hipGraph, replayed 30x, HIP events around
+    the replays (steady-state time per launch including its dispatch, which is most of it at this
+    size).  Algorithmic flops / bytes per launch for ``Bg`` environments:
+      sample_convs: conv1 475 x 256 x 16 + conv2 108 x 256 x 32 MACs per env (5.66 MFLOP);
+                    bytes = frame read 8.3 KB + previous stack 25 KB read + stack 33 KB write +
+                    y2 13.8 KB write per env, + 50 KB of weights per workgroup-independent set;
+      trunk:        3456 x 512 MACs per env; bytes = 7.08 MB of weights + x 13.8 KB per env +
+                    27 partial slices x 2 KB per env written;
+      head:         reads the partials back + 7 x 512 head weights, writes 8 floats per env.
+    Priced against the fp32 MFMA peak and against HBM; both fractions are tiny BY DESIGN of the
+    workload (64 rows per launch): these launches are latency-class, the number that matters is
+    us per launch."""
+    from rlpyt_amd import ops
+    from rlpyt_amd.models.pg.atari_ff_model import AtariFfModel
+    m = AtariFfModel((4, 104, 80), 6).cuda().eval()
+    c1, c2 = m.conv.conv.conv[0], m.conv.conv.conv[2]
+    lin = m._single_fc()
+    obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, device="cuda")
+    new_frame = torch.randint(0, 256, (Bg, 104, 80), dtype=torch.uint8, device="cuda")
+    full_rows = torch.zeros((Bg, 4, 104, 80), dtype=torch.uint8, device="cuda")
+    slot = torch.full((Bg,), -1, dtype=torch.int32, device="cuda")
+    t_dev = torch.tensor([5], dtype=torch.int64, device="cuda")
+    rew, dn = torch.zeros(T + 1, B, device="cuda"), torch.zeros(T + 1, B, dtype=torch.bool, device="cuda")
+    rs, ds = torch.zeros(Bg, device="cuda"), torch.zeros(Bg, dtype=torch.bool, device="cuda")
+    y2 = torch.empty((Bg, 3456), device="cuda")
+    prob, value = torch.zeros((T, B, 6), device="cuda"), torch.zeros((T, B), device="cuda")
+    action = torch.zeros((T + 1, B), dtype=torch.int64, device="cuda")
+    action_out = torch.zeros(Bg, dtype=torch.int64, device="cuda")
+    u = torch.rand(T, Bg, device="cuda")
+
+    def timed(fn, n_inner=20, reps=30):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n_inner):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / (reps * n_inner) * 1e3
+
+    def convs():
+        ops.atari_sample_convs(obs, t_dev, 0, new_frame, full_rows, slot, c1.weight, c1.bias,
+                               c2.weight, c2.bias, scalar_rows=(rew, rs, dn, ds), out=y2)
+    part, ks = ops.rollout_fc_partials(y2, lin.weight)
+
+    def trunk():
+        ops.rollout_fc_partials(y2, lin.weight)
+
+    def head():
+        ops.rollout_head(part, ks, lin.bias, m.pi.weight, m.pi.bias, m.value.weight, m.value.bias,
+                         u, t_dev, Bg, prob, value, action, 0, action_out)
+    x = torch.zeros(64, device="cuda")
+    floor_us = timed(lambda: x.add_(1))
+    K, N = lin.weight.shape[1], lin.weight.shape[0]
+    rows = {
+        "sample_convs_kernel": (convs, Bg * 2 * (475 * 256 * 16 + 108 * 256 * 32),
+                                Bg * (8320 + 24960 + 33280 + 3456 * 4) + 4 * (16 * 256 + 32 * 256)),
+        "rollout_fc_kernel": (trunk, Bg * 2 * K * N, 4 * K * N + Bg * K * 4 + ks * Bg * N * 4),
+        "rollout_head_kernel<2>": (head, Bg * 2 * N * 7, ks * Bg * N * 4 + 7 * N * 4 + Bg * 64),
+    }
+    out = {"Bg": Bg, "empty_launch_us": round(floor_us, 2),
+           "how": "20 back-to-back launches of one kernel in a hipGraph, 30 replays, HIP events"}
+    total = 0.
+    for name, (fn, flops, nbytes) in rows.items():
+        us = timed(fn)
+        total += us
+        out[name] = {"us_per_launch": round(us, 2), "alg_flops": flops, "alg_bytes": nbytes,
+                     "TFLOPs": round(flops / us * 1e-6, 2), "GBps": round(nbytes / us * 1e-3, 1),
+                     "frac_f32_mfma_peak": round(flops / us * 1e-6 / F32_MFMA_PEAK_TFLOPS, 4),
+                     "frac_hbm_peak": round(nbytes / us * 1e-3 / HBM_PEAK_GBPS, 4),
+                     "traffic": None}
+    out["chain_us_per_group_step"] = round(total, 2)
+    # HBM traffic from the PMC passes over scripts/r4_step_microbench.py, when committed
+    try:
+        with open(os.path.join(ROOT, "profiles", "r4_rollout_pmc.json")) as f:
+            pmc = json.load(f)
+        for name in rows:
+            if name in pmc.get("kernels", {}):
+                out[name]["traffic"] = pmc["kernels"][name]["hbm_bytes_corrected"]
+                out[name]["traffic_source"] = "profiles/r4_rollout_pmc.json"
+    except (OSError, ValueError):
+        pass
+    return out
 
 
 def gae_scaled_roofline(T=128, log2n=20, iters=20):
@@ -809,8 +913,10 @@ def cpu_baseline(T, B_cpu, env_kwargs):
                          "semantics); /root/reference is not on the bench box.  The port's update is "
                          "pinned to the reference's own PPO.optimize_agent run at 1e-5 "
                          "(tests/test_oracle_golden.py) and was timed beside the real reference in "
-                         "the build container: port 1516 SPS vs reference 1416 SPS (+7 %, "
-                         "scripts/ref_vs_port.py)",
+                         "the build container (8 vCPU, scripts/ref_vs_port.py): at [128, 8] port "
+                         "1516 vs reference 1416 SPS (+7 %, round 2); at the benchmarked [128, 256] "
+                         "port 432 vs reference 398 SPS (+8 %, 2026-09-22, round 4; the container "
+                         "was also running the CPU test suite, so only the ratio carries over)",
             "sample": f"1 PPO iteration at [T={T}, B={B_cpu}] ({T * B_cpu} env steps, 16 "
                       f"minibatch updates), torch CPU with {res['cores']} threads (best of a thread-count "
                       f"calibration within the {usable_cpus():.0f} CPUs this process may use, "

@@ -381,11 +381,13 @@ def _worker_loop(rank, runners, ctrl, batch_T, seed, cpus, eval_runner=None):
         rn.start(ctrl.max_decorrelation_steps)
     ctrl.barrier_out.wait()
     spin = ctrl.worker_spin
-    if spin is None and ctrl.n_workers <= 2 * usable_cpus():
+    if spin is None and ctrl.n_workers + 2 <= 1.5 * ctrl.cpu_share:
         # poll ~1 ms for the next action set before sleeping: the hand-off is a few tens of us, a
         # futex wake-up of 20 sleepers costs the poster ~7 us and the last sleeper ~10 us more
-        # (profiles/r4_rollout_chain_spin.jsonl: +4..6 % SPS); with many more workers than CPUs
-        # polling only steals time from the workers that have envs to step
+        # (profiles/r4_rollout_chain_spin.jsonl: +4..6 % SPS).  Only while this rank's workers and
+        # its two serve threads roughly fit its share of the CPU quota: polling processes beyond
+        # it only take time from the workers that have envs to step (8 ranks under a 16-CPU quota
+        # keep the short poll)
         spin = 30000
     if os.environ.get("RLPYT_WORKER_SPIN"):           # A/B experiments (rollout sweep)
         spin = int(os.environ["RLPYT_WORKER_SPIN"])
@@ -757,7 +759,7 @@ class GpuSampler(BaseSampler):
             # one pair of hand-off words per pipeline group + one for evaluation + batch words
             sync_words=np_mp_array(32 * (len(self.groups) + 2), np.uint32), n_workers=n,
             group_workers=[G.n_workers for G in self.groups] + [n],
-            worker_spin=None,
+            worker_spin=None, cpu_share=usable_cpus() / max(self.world_size, 1),
             traj_infos_queue=ctx.Queue(),
             max_decorrelation_steps=self.max_decorrelation_steps)
         # completed-trajectory statistics come back through a fork-shared float table
