@@ -307,12 +307,14 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
     # ---- kernel-timing leg: HIP events around every launch of the path's kernels.  Outside the
-    # timed region (which replays a captured update graph and takes no per-launch events): two
-    # more iterations with the update launched kernel by kernel, same shapes, same data path.
+    # timed region (events between the kernels of the timed iterations can only
+    # slow the headline and fold launch gaps into the averages): two more iterations of the same
+    # workload, the update launched kernel by kernel (also when the opt-in update graph is on).
     ksum = {}
-    KTIMER_NOTE = ("HIP events around each launch, on the launching stream, in 2 iterations run "
-                   "right after the timed region with the update launched eagerly (the timed region "
-                   "replays a captured update graph: no per-launch events inside it)")
+    KTIMER_NOTE = ("HIP events around each launch, on the launching stream, in 2 iterations of the "
+                   "same workload run right after the timed region (the timed region itself carries "
+                   "no per-launch events: they would sit between its kernels); rocprofv3 averages of "
+                   "the same command: profiles/r4_bench_kernel_stats.csv")
     if not args.no_kernel_timing:
         graph_was = getattr(algo, "use_update_graph", None)
         if graph_was is not None:

@@ -606,3 +606,147 @@ def test_sampler_worker_dies_with_its_parent():
             break
         time.sleep(0.1)
     assert state in ("gone", "Z", "X"), f"worker {pid} still {state} after its parent was killed"
+
+
+# ------------------------------------------------------------------- round-4 host structure
+def test_runner_schedule_rounds_up_to_whole_logging_periods():
+    """``schedule`` (runners/minibatch_rl.py) == the reference's get_n_itr arithmetic
+    (rlpyt/runners/minibatch_rl.py:108-118): iterations rounded UP to a multiple of the logging
+    period, at least one period of at least one iteration."""
+    from rlpyt_amd.runners.minibatch_rl import schedule
+
+    def reference(n_steps, itr_batch, log_steps):
+        log_itrs = max(log_steps // itr_batch, 1)
+        n_itr = n_steps // itr_batch
+        if n_itr % log_itrs > 0:
+            n_itr += log_itrs
+            n_itr -= n_itr % log_itrs
+        return max(n_itr, 1), log_itrs
+    for n_steps, itr_batch, log_steps in [(1000, 32, 100), (32768 * 25, 32768, 10 ** 5), (5, 32, 100),
+                                          (960, 32, 96), (961, 32, 96), (10 ** 6, 512, 10 ** 4),
+                                          (100, 32, 10)]:
+        plan = schedule(n_steps, itr_batch, log_steps)
+        assert (plan.n_itr, plan.log_every) == reference(n_steps, itr_batch, log_steps)
+        assert plan.n_itr % plan.log_every == 0 or plan.n_itr == 1
+
+
+def test_update_plan_beta_anneal_and_replay_feed():
+    """The DQN family's iteration arithmetic as data (algos/dqn/replay_algo.py) against the
+    reference's formulas (rlpyt/algos/dqn/dqn.py:84-100,267-279)."""
+    from collections import namedtuple
+    from rlpyt_amd.algos.dqn.replay_algo import BetaAnneal, ReplayFeed, UpdateLog, plan_updates
+    p = plan_updates(sampler_batch=32, train_batch=128, replay_ratio=8, min_steps_learn=5000,
+                     eps_steps=10 ** 6, pri_beta_steps=5 * 10 ** 7)
+    assert p.updates_per_itr == max(1, round(8 * 32 / 128)) == 2
+    assert p.first_learn_itr == 5000 // 32 and p.eps_last_itr == 10 ** 6 // 32
+    assert p.beta_last_itr == 5 * 10 ** 7 // 32
+    assert plan_updates(7680, 7680, 1, 0, 1, 1).updates_per_itr == 1
+    b = BetaAnneal(0.4, 1.0, first_itr=10, last_itr=110)
+    assert b.at(0) == b.at(10) == 0.4 and abs(b.at(60) - 0.7) < 1e-12 and b.at(110) == 1.0
+    assert b.at(111) is None                     # past the anneal: the buffer keeps its beta
+    # feed: sampler batch / examples dict -> replay record
+    Env = namedtuple("Env", ["observation", "reward", "done"])
+    Info = namedtuple("Info", ["q", "prev_rnn_state"])
+    Agent = namedtuple("Agent", ["action", "agent_info"])
+    Samples = namedtuple("Samples", ["agent", "env"])
+    smp = Samples(agent=Agent(action="A", agent_info=Info(q="Q", prev_rnn_state="S")),
+                  env=Env(observation="O", reward="R", done="D"))
+    step, rnn = ReplayFeed(ReplayFeed.STEP, "SamplesToBuffer"), ReplayFeed(ReplayFeed.RNN, "SamplesToBufferRnn")
+    assert tuple(step.from_samples(smp)) == ("O", "A", "R", "D")
+    assert tuple(rnn.from_samples(smp)) == ("O", "A", "R", "D", "S")
+    ex = dict(observation="o", action="a", reward="r", done="d", agent_info=Info(q="q", prev_rnn_state="s"))
+    assert tuple(step.from_examples(ex)) == ("o", "a", "r", "d")
+    assert tuple(rnn.from_examples(ex)) == ("o", "a", "r", "d", "s")
+    assert type(rnn.from_samples(smp)).__name__ == "SamplesToBufferRnn"
+    # update log: one host copy at the end, scalar rows + vector fields in OptInfo order
+    OptInfo = namedtuple("OptInfo", ["loss", "gradNorm", "tdAbsErr"])
+    log = UpdateLog(OptInfo, ("loss", "gradNorm"))
+    assert log.to_opt_info() == OptInfo([], [], [])
+    log.add((torch.tensor(1.5), torch.tensor(2.0)), tdAbsErr=torch.tensor([0.1, 0.2]))
+    log.add((torch.tensor(0.5), torch.tensor(3.0)), tdAbsErr=torch.tensor([[0.3]]))
+    out = log.to_opt_info()
+    assert out.loss == [1.5, 0.5] and out.gradNorm == [2.0, 3.0]
+    assert np.allclose(out.tdAbsErr, [0.1, 0.2, 0.3])
+
+
+def test_epsilon_schedule_object():
+    """``EpsilonSchedule`` (agents/dqn/dqn_agent.py): anneal, hold, evaluation rate, and the rank's
+    slice of the global log-spaced ladder."""
+    from rlpyt_amd.agents.dqn.dqn_agent import EpsilonSchedule
+    s = EpsilonSchedule(1.0, 0.1, None, itr_min=2, itr_max=12, eval_eps=0.001)
+    assert s.sampling(0) == s.sampling(2) == 1.0 and abs(s.sampling(7) - 0.55) < 1e-12
+    assert abs(s.sampling(12) - 0.1) < 1e-12 and abs(s.sampling(500) - 0.1) < 1e-12      # held
+    assert s.evaluation(0) == 1.0 and s.evaluation(3) == 0.001
+    v = EpsilonSchedule(1.0, 0.1, 0.001, 0, 10, 0.001)
+    v.spread_over_envs(global_B=8, env_ranks=[4, 5, 6, 7])
+    ladder = torch.logspace(-3, -1, 8)
+    assert torch.allclose(v.final, ladder[4:]) and torch.equal(v.init, torch.ones(4))
+    assert torch.allclose(v.sampling(10), ladder[4:]) and torch.allclose(v.sampling(5), 0.5 + 0.5 * ladder[4:])
+
+
+def test_replay_class_factory_and_signatures():
+    """``replay_class`` maps the three switches onto the reference's eight class names, and the
+    classes keep the reference's constructor conventions (prioritized: keyword-only tail)."""
+    import inspect
+    from rlpyt_amd.replays import buffers as R
+    assert R.replay_class(True, False, True) is R.PrioritizedReplayFrameBuffer
+    assert R.replay_class(True, True, True) is R.PrioritizedSequenceReplayFrameBuffer
+    assert R.replay_class(False, False, False) is R.UniformReplayBuffer
+    assert R.replay_class(True, True, False) is R.UniformSequenceReplayFrameBuffer
+    seen = {R.replay_class(f, s, p) for f in (0, 1) for s in (0, 1) for p in (0, 1)}
+    assert len(seen) == 8
+    for cls in seen:
+        assert (cls.FRAMES, cls.SEQUENCE, cls.PRIORITIZED) == tuple(
+            w in cls.__name__ for w in ("Frame", "Sequence", "Prioritized"))
+    sig = inspect.signature(R.PrioritizedReplayBuffer.__init__).parameters
+    assert list(sig)[:7] == ["self", "alpha", "beta", "default_priority", "unique",
+                             "input_priorities", "input_priority_shift"]
+
+
+def test_replay_store_parts_on_host_tensors():
+    """The storage parts of the replay (replays/store.py) exercised on CPU tensors (1-step returns, so
+    no kernel is involved): ring writes with wrap anywhere, the frame store's layout contract
+    (oldest frame of time r at row r, the first C - 1 rows mirror the last C - 1 after
+    a wrap), cursor / full flag, and uniform draws staying outside the guard band."""
+    from rlpyt_amd.replays.buffers import UniformReplayFrameBuffer
+    from rlpyt_amd.utils.collections import namedarraytuple
+    S2B = namedarraytuple("SamplesToBuffer", ["observation", "action", "reward", "done"])
+    C, H, W, B, size = 4, 3, 2, 2, 20          # ring T = 10
+    ex = S2B(observation=np.zeros((C, H, W), np.uint8), action=np.int64(0),
+             reward=np.float32(0), done=np.bool_(False))
+    buf = UniformReplayFrameBuffer(example=ex, size=size, B=B, discount=0.99, n_step_return=1,
+                                   device="cpu")
+    assert (buf.T, buf.B, buf.t, buf._buffer_full) == (10, 2, 0, False)
+    assert (buf.off_backward, buf.off_forward) == (1, C - 1)
+    rng = np.random.RandomState(0)
+    stream = rng.randint(1, 255, size=(64 + C - 1, B, H, W)).astype(np.uint8)   # frame k of env b
+
+    def obs_at(k):                   # observation at global time k: frames k .. k + C - 1
+        return np.stack([stream[k + f] for f in range(C)], axis=1)              # [B, C, H, W]
+    k = 0
+    for T_new in (3, 4, 3, 5, 2, 7):          # 10 rows = exactly one lap, then wraps inside appends
+        obs = np.stack([obs_at(k + i) for i in range(T_new)])                   # [T, B, C, H, W]
+        rec = S2B(observation=torch.from_numpy(obs),
+                  action=torch.arange(k, k + T_new).repeat(B, 1).t().contiguous(),
+                  reward=torch.zeros(T_new, B), done=torch.zeros(T_new, B, dtype=torch.bool))
+        t_before = buf.t
+        T_ret, rows = buf.append_samples(rec)
+        k += T_new
+        assert T_ret == T_new and buf.t == k % buf.T
+        assert buf._buffer_full == (k >= buf.T)
+        frames = buf.samples_frames.numpy()
+        for j in range(max(0, k - buf.T), k):          # every step still in the ring
+            r = j % buf.T
+            assert np.array_equal(frames[r + C - 1], stream[j + C - 1]), (k, j)   # its newest frame
+            assert int(buf.samples.action[r, 0]) == j
+        if buf.t < t_before or k == T_new:             # lap closed (or very first rows): history rows
+            lap0 = (k // buf.T) * buf.T
+            for f in range(C - 1):
+                assert np.array_equal(frames[f], stream[lap0 + f]), (k, f)
+    # uniform draws never land in the guard band around the cursor
+    np.random.seed(1)
+    T_idxs, B_idxs = buf.sample_idxs(4000)
+    t, b, f = buf.t, buf.off_backward, buf.off_forward
+    banned = {(t - 1 - i) % buf.T for i in range(b)} | {(t + i) % buf.T for i in range(f)}
+    assert set(T_idxs.tolist()) == set(range(buf.T)) - banned
+    assert set(B_idxs.tolist()) == {0, 1}
