@@ -55,6 +55,12 @@ class BaseAgent:
         self.model = self._new_model(self.initial_model_state_dict)
         if share_memory:
             self.shared_model = self.model.share_memory()
+        if hasattr(env_spaces.action, "n"):       # discrete actions: the agent's action distribution
+            self.distribution = self.make_distribution(env_spaces.action.n)
+
+    def make_distribution(self, n_actions):
+        """The distribution object of a discrete-action agent (None: the agent has none)."""
+        return None
 
     def make_env_to_model_kwargs(self, env_spaces):
         return {}

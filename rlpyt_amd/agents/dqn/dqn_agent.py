@@ -105,7 +105,6 @@ class DqnAgent(EpsilonGreedyAgentMixin, BaseAgent):
         if seed_sd is not None:
             for net in (self.model, self.target_model):
                 net.load_state_dict(seed_sd["model"])
-        self.distribution = self.make_distribution(env_spaces.action.n)
         self._n_local_envs = None if env_ranks is None else len(env_ranks)
         self.collector_initialize(global_B, env_ranks)
 

@@ -50,9 +50,8 @@ class CategoricalPgAgent(BaseAgent):
         m = self.sampling_model
         return z, tb, m.pi, m.value
 
-    def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
-        super().initialize(env_spaces, share_memory, global_B=global_B, env_ranks=env_ranks)
-        self.distribution = Categorical(dim=env_spaces.action.n)
+    def make_distribution(self, n_actions):
+        return Categorical(dim=n_actions)
 
     @torch.no_grad()
     def step(self, observation, prev_action, prev_reward):
@@ -132,9 +131,8 @@ class RecurrentCategoricalPgAgentBase(BaseAgent):
         dist_info, value = self._out((DistInfo(prob=pi), value))
         return dist_info, value, next_rnn_state      # the state stays on the device
 
-    def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
-        super().initialize(env_spaces, share_memory, global_B=global_B, env_ranks=env_ranks)
-        self.distribution = Categorical(dim=env_spaces.action.n)
+    def make_distribution(self, n_actions):
+        return Categorical(dim=n_actions)
 
     @torch.no_grad()
     def step(self, observation, prev_action, prev_reward):
