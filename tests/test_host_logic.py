@@ -434,7 +434,7 @@ def test_epsilon_schedule_matches_reference(name, kw, global_B, env_ranks):
     reference's AtariDqnAgent."""
     from conftest import load_golden
     from rlpyt_amd.agents.dqn.dqn_agent import AtariDqnAgent
-    from rlpyt_amd.envs.base import EnvSpaces
+    from rlpyt_amd.envs import EnvSpaces
     from rlpyt_amd.spaces import IntBox
     g = load_golden("agents")
     agent = AtariDqnAgent(**kw)

@@ -32,7 +32,7 @@ N_ITR = 2
 
 
 def _spaces():
-    from rlpyt_amd.envs.base import EnvSpaces
+    from rlpyt_amd.envs import EnvSpaces
     from rlpyt_amd.spaces import IntBox
     return EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
                      action=IntBox(0, A))
