@@ -10,7 +10,7 @@ from rlpyt_amd.agents.pg.atari import AtariFfAgent  # noqa: E402
 from rlpyt_amd.agents.pg.categorical import AgentInfo  # noqa: E402
 from rlpyt_amd.algos.pg.ppo import PPO  # noqa: E402
 from rlpyt_amd.distributions.categorical import DistInfo  # noqa: E402
-from rlpyt_amd.envs.base import EnvSpaces  # noqa: E402
+from rlpyt_amd.envs import EnvSpaces  # noqa: E402
 from rlpyt_amd.samplers.collections import AgentSamplesBsv, BatchSpec, EnvSamples, Samples  # noqa: E402
 from rlpyt_amd.spaces import IntBox  # noqa: E402
 from rlpyt_amd.utils import logger  # noqa: E402

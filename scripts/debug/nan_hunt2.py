@@ -10,7 +10,7 @@ from rlpyt_amd import ops  # noqa: E402
 from rlpyt_amd.agents.base import AgentInputs  # noqa: E402
 from rlpyt_amd.agents.pg.atari import AtariFfAgent  # noqa: E402
 from rlpyt_amd.algos.pg.ppo import PPO  # noqa: E402
-from rlpyt_amd.envs.base import EnvSpaces  # noqa: E402
+from rlpyt_amd.envs import EnvSpaces  # noqa: E402
 from rlpyt_amd.models.pg.atari_ff_model import ObsGather  # noqa: E402
 from rlpyt_amd.samplers.collections import BatchSpec  # noqa: E402
 from rlpyt_amd.spaces import IntBox  # noqa: E402
