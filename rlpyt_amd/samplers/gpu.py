@@ -1462,16 +1462,19 @@ class GpuSampler(BaseSampler):
         out = []
         keys, table, count = self.ctrl.ti_keys, self.ctrl.ti_table, self.ctrl.ti_count
         proto = self._ti_proto
+        # which columns come back as int: those whose prototype value is an int (when integral)
+        as_int = [isinstance(proto[k], int) for k in keys]
+        Cls = self.TrajInfoCls
         n_queue = 0
         for w in range(self.n_workers):
             n = int(count[w])
             if n < 0:
                 n_queue += -n
                 continue
-            for row in table[w, :n]:
-                ti = self.TrajInfoCls()
-                for k, v in zip(keys, row):
-                    ti[k] = int(v) if (isinstance(proto[k], int) and v.is_integer()) else float(v)
+            for row in table[w, :n].tolist():          # one bulk conversion to Python floats
+                ti = Cls()
+                dict.update(ti, zip(keys, (int(v) if (i and v.is_integer()) else v
+                                           for v, i in zip(row, as_int))))
                 out.append(ti)
         q = self.ctrl.traj_infos_queue
         for _ in range(n_queue):

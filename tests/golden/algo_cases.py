@@ -97,6 +97,13 @@ DQN_CASES = [
                      replay_ratio=2, target_update_interval=2, n_step_return=1,
                      learning_rate=1e-4, clip_grad_norm=10., double_dqn=False,
                      prioritized_replay=True, delta_clip=1.), 4),
+    # the "tight" case (VERDICT r3 weak #1a): plain SGD instead of Adam, so that round-off is not
+    # amplified by Adam's sign-like first steps and every update can be held to a tight tolerance
+    ("dqn_uniform_sgd", dict(discount=0.99, batch_size=16, min_steps_learn=64, replay_size=512,
+                             replay_ratio=2, target_update_interval=3, n_step_return=2,
+                             learning_rate=1e-3, clip_grad_norm=10., double_dqn=True,
+                             prioritized_replay=False, delta_clip=1., OptimCls=torch.optim.SGD,
+                             optim_kwargs=dict()), 6),
 ]
 
 

@@ -240,7 +240,13 @@ def test_dqn_iterations_match_reference(case):
             assert got.shape == ref.shape, (itr, f, got.shape, ref.shape)
             if got.size and first and f != "tdAbsErr":
                 np.testing.assert_allclose(got[0], ref[0], rtol=1e-3, atol=1e-5, err_msg=f)
-            np.testing.assert_allclose(got, ref, rtol=2e-2, atol=5e-3, err_msg=f"{f} itr {itr}")
+            if name.endswith("_sgd"):
+                # the tight case: plain SGD keeps the comparison linear in the gradient (no
+                # Adam sign-amplification of round-off), so EVERY update is held 4x tighter
+                np.testing.assert_allclose(got, ref, rtol=5e-3, atol=2e-3 if f == "tdAbsErr" else 1e-4,
+                                           err_msg=f"{f} itr {itr} (SGD)")
+            else:
+                np.testing.assert_allclose(got, ref, rtol=2e-2, atol=5e-3, err_msg=f"{f} itr {itr}")
         if len(info.loss):
             first = False
         abs_sums = C.param_stats([p.cpu() for p in agent.model.parameters()])[1]
