@@ -23,9 +23,10 @@ Prints ONE JSON line (rank 0).  Extra objects:
   value_env200us -- the same metric with a declared ALE-like host cost of 200 us per env step
                    (busy wait in the env workers; `value` itself is measured at 0 us: the
                    framework's own ceiling);
-  cpu_baseline  -- the oracle's CPU port of the reference iteration (oracle/ppo_cpu_port.py,
-                   pinned to the reference's PPO.optimize_agent) timed on this box's host cores at
-                   the full [128, 256] batch (rank 0, N=1 only);
+  cpu_baseline  -- the UNMODIFIED reference (oracle/_ref, copied from /root/reference at build time by
+                   oracle/make_ref.py: SerialSampler + PPO + AtariFfAgent) timed on this box's host
+                   cores at the full [128, 256] batch (rank 0, N=1 only; kind "reference"); the oracle's
+                   CPU port (kind "port") only when that copy is absent;
   multi_gpu     -- (N>1) world size as torch.distributed sees it, per-rank usable CPUs, the
                    all-reduce time of one gradient set measured live, per-GPU SPS.
 `--config dqn` / `--config r2d1` run BASELINE configs #3 / #5 end to end instead (full-size HBM
@@ -898,33 +899,77 @@ def isolated_functions(T, B):
 
 
 def cpu_baseline(T, B_cpu, env_kwargs):
-    """Oracle CPU port of the reference iteration on this box's host cores: by default ONE whole
-    iteration at the bench batch [T, 256] (SerialSampler-style rollout + GAE loop + 16 updates)."""
-    from oracle.ppo_cpu_port import time_cpu_baseline
+    """The reference iteration on this box's host cores, ONE whole iteration at the bench batch
+    [T, 256] (SerialSampler rollout + the reference's GAE loop + 16 updates).  ``kind: "reference"``
+    = the unmodified reference from ``oracle/_ref`` (oracle/make_ref.py; present whenever the repo
+    was built where /root/reference exists, and shipped with the snapshot); ``kind: "port"`` = the
+    oracle's CPU port (oracle/ppo_cpu_port.py) when that copy is absent."""
+    from oracle import ref_runner
+    from oracle.ppo_cpu_port import calibrate_threads, time_cpu_baseline
     from rlpyt_amd.envs.synthetic import SyntheticPong
     from rlpyt_amd.utils.misc import usable_cpus
+    quota = usable_cpus()
+    if ref_runner.available():
+        B = B_cpu if B_cpu > 0 else 64
+        threads, _rate = calibrate_threads(max_threads=quota)
+        res = ref_runner.time_ppo(SyntheticPong, env_kwargs, T=T, B=B, iters=1, threads=threads)
+        return {"value": res["value"], "unit": "env-steps/s", "cores": res["cores"],
+                "kind": "reference",
+                "kind_note": "the UNMODIFIED reference (copy of /root/reference/rlpyt made by "
+                             "oracle/make_ref.py at build time, git-ignored, shipped with the "
+                             "snapshot): " + res["classes"] + ", driven by the statement sequence of "
+                             "MinibatchRl.train (rlpyt/runners/minibatch_rl.py:253-262) on this "
+                             "repo's SyntheticPong env, CPU tensors",
+                "functions_kind": "numpy / torch-CPU oracle restatements (oracle/np_oracle.py) -- FASTER "
+                                  "than the reference's own torch loops (GAE: 0.3 ms here vs 7.2 ms for "
+                                  "rlpyt/algos/utils.py:24-40 on CPU tensors, SURVEY 8a), so the per-"
+                                  "function ratios understate the gain over the reference",
+                "sample": f"1 PPO iteration at [T={T}, B={B}] ({T * B} env steps, 16 minibatch "
+                          f"updates), torch CPU with {res['cores']} threads (best fwd+bwd rate of a "
+                          f"thread-count calibration within the {quota:.0f} CPUs this process may use, "
+                          f"{os.cpu_count()} hardware threads on the box), {res['seconds']:.1f} s",
+                "seconds": res["seconds"], "last_loss": res["last_loss"]}
     res = time_cpu_baseline(SyntheticPong, env_kwargs, T=T, B=B_cpu if B_cpu > 0 else None,
-                            iters=1, threads=None, max_threads=usable_cpus())
+                            iters=1, threads=None, max_threads=quota)
     B_cpu = res["B"]
     return {"value": res["value"], "unit": "env-steps/s", "cores": res["cores"], "kind": "port",
-            "functions_kind": "numpy / torch-CPU oracle restatements (oracle/np_oracle.py) -- FASTER "
-                              "than the reference's own torch loops (GAE: 0.3 ms here vs 7.2 ms for "
-                              "rlpyt/algos/utils.py:24-40 on CPU tensors, SURVEY 8a), so the per-"
-                              "function ratios understate the gain over the reference",
-            "kind_note": "CPU port of the reference iteration (rlpyt SerialSampler + PPO + AtariFfAgent "
-                         "semantics); /root/reference is not on the bench box.  The port's update is "
-                         "pinned to the reference's own PPO.optimize_agent run at 1e-5 "
-                         "(tests/test_oracle_golden.py) and was timed beside the real reference in "
-                         "the build container (8 vCPU, scripts/ref_vs_port.py): at [128, 8] port "
-                         "1516 vs reference 1416 SPS (+7 %, round 2); at the benchmarked [128, 256] "
-                         "port 432 vs reference 398 SPS (+8 %, 2026-09-22, round 4; the container "
-                         "was also running the CPU test suite, so only the ratio carries over)",
+            "kind_note": "oracle/_ref is absent on this box (the repo was not built where "
+                         "/root/reference exists): CPU port of the reference iteration, pinned to the "
+                         "reference's own PPO.optimize_agent run at 1e-5 (tests/test_oracle_golden.py); "
+                         "timed beside the real reference at [128, 256]: port 432 vs reference 398 SPS",
             "sample": f"1 PPO iteration at [T={T}, B={B_cpu}] ({T * B_cpu} env steps, 16 "
-                      f"minibatch updates), torch CPU with {res['cores']} threads (best of a thread-count "
-                      f"calibration within the {usable_cpus():.0f} CPUs this process may use, "
-                      f"{os.cpu_count()} hardware threads on the box), "
-                      f"{res['seconds']:.1f} s",
+                      f"minibatch updates), torch CPU with {res['cores']} threads, {res['seconds']:.1f} s",
             "seconds": res["seconds"]}
+
+
+def cpu_baseline_replay(config, env_kwargs):
+    """``cpu_baseline`` of the ``--config dqn|r2d1`` lines: the reference's own DQN / R2D1 iteration
+    (SerialSampler + algorithm + agent + its host replay buffer) on this box's cores, bounded
+    sample, reduced replay ring (stated).  None when ``oracle/_ref`` is absent."""
+    from oracle import ref_runner
+    from oracle.ppo_cpu_port import calibrate_threads
+    from rlpyt_amd.envs.synthetic import SyntheticPong
+    from rlpyt_amd.utils.misc import usable_cpus
+    if not ref_runner.available():
+        return {"value": None, "kind": "absent",
+                "kind_note": "oracle/_ref (the reference copy made by oracle/make_ref.py) is not on "
+                             "this box"}
+    quota = usable_cpus()
+    threads, _ = calibrate_threads(max_threads=quota)
+    if config == "dqn":
+        res = ref_runner.time_dqn(SyntheticPong, env_kwargs, iters=40, threads=threads)
+        sample = (f"{res['iters']} DQN iterations of [2, 16] env steps + 2 updates of batch 128 after "
+                  f"10 untimed ones; host replay ring reduced to {res['replay_frames']} frames "
+                  "(the config's 1e6 = 8.3 GB; the ring size only sets the tree depth)")
+    else:
+        res = ref_runner.time_r2d1(SyntheticPong, env_kwargs, iters=1, threads=threads)
+        sample = (f"{res['iters']} R2D1 iteration of [40, 192] env steps + {res['updates']} update(s) "
+                  f"over 64 sequences of 125 steps, after 5 untimed sampling-only iterations; host "
+                  f"replay ring reduced to {res['replay_frames']} frames (the config's 4e6 = 33 GB)")
+    return {"value": res["value"], "unit": "env-steps/s", "updates_per_s": res["updates_per_s"],
+            "cores": res["cores"], "kind": "reference", "kind_note": res["classes"] +
+            " -- the unmodified reference from oracle/_ref on this repo's SyntheticPong env",
+            "sample": sample + f", {res['seconds']:.1f} s", "seconds": res["seconds"]}
 
 
 # ============================================================================================
@@ -1112,6 +1157,8 @@ def replay_config_main(args):
         "roofline_replay": replay,
         "last_loss": (info.loss[-1] if info.loss else None),
     }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_replay(args.config, dict(step_cost_us=args.env_cost_us))
     _canary_report(out)
     print(json.dumps(out), flush=True)
 

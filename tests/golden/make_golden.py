@@ -812,6 +812,78 @@ def gen_sampler():
     save("sampler", **out)
 
 
+def gen_sampler_ff():
+    """The reference GpuSampler (GpuResetCollector workers + ActionServer.serve_actions,
+    rlpyt/samplers/parallel/gpu/*.py) driving the reference's OWN AtariFfAgent
+    (CategoricalPgAgent + AtariFfModel, rlpyt/agents/pg/atari.py, agents/pg/categorical.py:20-51)
+    on CPU over this repo's synthetic env, with a policy head sharpened until every sampled action
+    is deterministic (sampler_cases.ff_sharpen).  Recorded: every field of 11 consecutive batches,
+    incl. dist_info.prob, value and bootstrap_value -- what tests/test_sampler_gpu_parity.py holds
+    the fused device chain of the MI355X sampler to."""
+    import sampler_cases as C
+    from rlpyt.agents.pg.atari import AtariFfAgent
+    from rlpyt.models.pg.atari_ff_model import AtariFfModel
+    from rlpyt.samplers.parallel.gpu.collectors import GpuResetCollector
+    from rlpyt.samplers.parallel.gpu.sampler import GpuSampler as RefGpuSampler
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from rlpyt_amd.envs.synthetic import SyntheticPong
+    s = RefGpuSampler(EnvCls=SyntheticPong, env_kwargs=C.FF_ENV_KWARGS, batch_T=C.FF_T, batch_B=C.B,
+                      CollectorCls=GpuResetCollector, max_decorrelation_steps=0)
+    agent = AtariFfAgent()
+    s.initialize(agent, affinity=dict(workers_cpus=list(range(C.N_WORKERS)), cuda_idx=None,
+                                      set_affinity=False),
+                 seed=C.SEED, bootstrap_value=True, traj_info_kwargs=dict(discount=0.9))
+    torch.manual_seed(C.FF_INIT_SEED)
+    fresh = AtariFfModel(image_shape=(4, 104, 80), output_size=6)
+    agent.model.load_state_dict(fresh.state_dict())
+    C.ff_sharpen(agent.model)
+    out = {"param_abs_sums": C.param_checksums(list(agent.model.parameters()))}
+    try:
+        min_gap = _record_ff_batches(s, agent, C, out)
+    finally:
+        s.shutdown()
+    acts = np.concatenate([out[f"ff{i}_action"].reshape(-1) for i in range(C.FF_BATCHES)])
+    print("sampler_ff: min top-2 logit gap", min_gap, "action histogram", np.bincount(acts, minlength=6))
+    assert min_gap >= C.FF_MIN_GAP_REQUIRED, min_gap
+    assert len(np.unique(acts)) >= 3, "degenerate policy: pick another FF_INIT_SEED"
+    out["min_logit_gap"] = np.float64(min_gap)
+    save("sampler_ff", **out)
+
+
+def _record_ff_batches(s, agent, C, out):
+    min_gap = np.inf
+    for itr in range(C.FF_BATCHES):
+        agent.sample_mode(itr)
+        smp, infos = s.obtain_samples(itr)
+        k = f"ff{itr}_"
+        prob = smp.agent.agent_info.dist_info.prob.numpy()
+        assert np.all((prob == 0) | (prob == 1)), "policy not sharp enough: stochastic draws recorded"
+        # top-2 logit gap of every forward of this batch (recomputed: the sampler stores prob only)
+        with torch.no_grad():
+            obs = smp.env.observation
+            m = agent.model
+            x = obs.reshape(-1, 4, 104, 80).float().mul(1. / 255)
+            h = m.conv(x)
+            top = torch.topk(m.pi(h), 2, dim=-1).values
+            min_gap = min(min_gap, float((top[:, 0] - top[:, 1]).min()))
+        out.update({
+            k + "obs_crc": C.obs_crc(smp.env.observation.numpy()),
+            k + "reward": smp.env.reward.numpy().copy(),
+            k + "prev_reward": smp.env.prev_reward.numpy().copy(),
+            k + "done": smp.env.done.numpy().copy(),
+            k + "game_score": smp.env.env_info.game_score.numpy().copy(),
+            k + "traj_done": smp.env.env_info.traj_done.numpy().copy(),
+            k + "action": smp.agent.action.numpy().copy(),
+            k + "prev_action": smp.agent.prev_action.numpy().copy(),
+            k + "prob": prob.copy(),
+            k + "value": smp.agent.agent_info.value.numpy().copy(),
+            k + "bootstrap_value": smp.agent.bootstrap_value.numpy().copy(),
+            k + "traj_fields": np.array(sorted(
+                (ti["Length"], ti["Return"], ti["NonzeroRewards"], ti["DiscountedReturn"])
+                for ti in infos), dtype=np.float64).reshape(-1, 4)})
+    return min_gap
+
+
 def gen_algos():
     """Whole update iterations of the REFERENCE algorithms: PPO.optimize_agent / A2C.optimize_agent
     (rlpyt/algos/pg/{ppo,a2c,base}.py) with the reference AtariFfAgent on CPU, two consecutive
@@ -1218,7 +1290,7 @@ if __name__ == "__main__":
                 categorical=gen_categorical,
                 sumtree=gen_sumtree, sumtree_unique=gen_sumtree_unique, frames=gen_frames, replay=gen_replay,
                 seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
-                models=gen_models, sampler=gen_sampler, algos=gen_algos, algos_big=gen_algos_big,
+                models=gen_models, sampler=gen_sampler, sampler_ff=gen_sampler_ff, algos=gen_algos, algos_big=gen_algos_big,
                 dqn_iterations=gen_dqn_iterations,
                 r2d1_iterations=gen_r2d1_iterations, agents=gen_agents,
                 runner_keys=gen_runner_keys, protocol=gen_protocol)

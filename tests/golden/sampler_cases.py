@@ -34,6 +34,29 @@ def reference_env_seed(base_seed, i, n_workers=N_WORKERS, batch_B=B):
     return base_seed + i // per + i % per
 
 
+# ---- the reference's own AtariFfAgent under the reference GpuSampler (gen_sampler_ff) -----------
+# The policy head's bias is zeroed (with the random bias one action wins on every observation) and
+# its weight scaled by FF_PI_SCALE after initialisation: every softmax output is then exactly
+# one-hot in float32 (top-2 logit gaps of the recorded run: FF_MIN_GAP_REQUIRED at
+# least), so torch.multinomial on the reference side and the inverse-CDF draw of the fused head
+# kernel pick the SAME action whatever their random streams do -- the recorded batches are a
+# function of the observations and the parameters only, and the device chain (frame push + conv1 +
+# conv2 -> trunk -> heads + softmax + draw + row writes) can be held to them field by field.
+FF_INIT_SEED, FF_PI_SCALE, FF_T, FF_BATCHES, FF_MIN_GAP_REQUIRED = 11, 1.0e7, 5, 11, 300.0
+FF_ENV_KWARGS = dict(points_to_end=1, max_steps=25)
+
+
+def ff_sharpen(model):
+    """Scale the policy head in place (both sides apply this to bit-identical parameters)."""
+    with torch.no_grad():
+        model.pi.weight.mul_(FF_PI_SCALE)
+        model.pi.bias.zero_()
+
+
+def param_checksums(params):
+    return np.array([float(p.detach().double().abs().sum()) for p in params], dtype=np.float64)
+
+
 EVAL_N_ENVS, EVAL_MAX_STEPS = 4, 4 * 60      # 60 time steps of 4 eval envs
 EVAL_ENV_KWARGS = dict(points_to_end=1, max_steps=21)
 

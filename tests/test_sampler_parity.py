@@ -98,6 +98,39 @@ def test_batches_match_reference_gpu_sampler(case, n_workers, n_groups, split):
     s.shutdown()
 
 
+@pytest.mark.parametrize("n_workers,n_groups", [(0, 1), (2, 2)])
+def test_atari_ff_agent_batches_match_reference_gpu_sampler(n_workers, n_groups):
+    """``sampler_ff.npz``: the reference's GpuSampler + its own AtariFfAgent with a sharpened policy
+    head (sampler_cases.ff_sharpen), reproduced by this repo's sampler and agent on CPU tensors
+    (the GPU twin -- the fused rollout kernels -- is tests/test_sampler_gpu_parity.py)."""
+    from rlpyt_amd.agents.pg.atari import AtariFfAgent
+    from rlpyt_amd.models.pg.atari_ff_model import AtariFfModel
+    g = load_golden("sampler_ff")
+    s = GpuSampler(RefSeededPong, C.FF_ENV_KWARGS, batch_T=C.FF_T, batch_B=C.B, n_workers=n_workers,
+                   n_groups=n_groups, mid_batch_reset=True, max_decorrelation_steps=0)
+    agent = AtariFfAgent()
+    s.initialize(agent, seed=C.SEED, bootstrap_value=True, traj_info_kwargs=dict(discount=0.9))
+    torch.manual_seed(C.FF_INIT_SEED)
+    agent.load_state_dict(AtariFfModel(image_shape=(4, 104, 80), output_size=6).state_dict())
+    C.ff_sharpen(agent.model)
+    assert np.array_equal(C.param_checksums(list(agent.parameters())), g["param_abs_sums"])
+    for itr in range(C.FF_BATCHES):
+        agent.sample_mode(itr)
+        smp, _infos = s.obtain_samples(itr)
+        k = f"ff{itr}_"
+        assert np.array_equal(C.obs_crc(smp.env.observation.numpy()), g[k + "obs_crc"]), itr
+        for field, got in [("reward", smp.env.reward), ("done", smp.env.done),
+                           ("action", smp.agent.action), ("prev_action", smp.agent.prev_action),
+                           ("prob", smp.agent.agent_info.dist_info.prob)]:
+            got = got.numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+            assert np.array_equal(got, g[k + field]), (itr, field)
+        np.testing.assert_allclose(smp.agent.agent_info.value.numpy(), g[k + "value"],
+                                   rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(smp.agent.bootstrap_value.numpy(), g[k + "bootstrap_value"],
+                                   rtol=1e-5, atol=1e-6)
+    s.shutdown()
+
+
 @pytest.mark.parametrize("n_workers", [0, 2])
 def test_evaluation_matches_reference_gpu_sampler(n_workers):
     """``evaluate_agent`` against the reference GpuSampler's evaluation (eval collectors in the
