@@ -310,16 +310,13 @@ def main():
     # ---- kernel-timing leg: HIP events around every launch of the path's kernels.  Outside the
     # timed region (events between the kernels of the timed iterations can only
     # slow the headline and fold launch gaps into the averages): two more iterations of the same
-    # workload, the update launched kernel by kernel (also when the opt-in update graph is on).
+    # workload.
     ksum = {}
     KTIMER_NOTE = ("HIP events around each launch, on the launching stream, in 2 iterations of the "
                    "same workload run right after the timed region (the timed region itself carries "
                    "no per-launch events: they would sit between its kernels); rocprofv3 averages of "
                    "the same command: profiles/r4_bench_kernel_stats.csv")
     if not args.no_kernel_timing:
-        graph_was = getattr(algo, "use_update_graph", None)
-        if graph_was is not None:
-            algo.use_update_graph = False
         ktimer.reset()
         ktimer.enable(True)
         for k in range(2):
@@ -327,8 +324,6 @@ def main():
         sync()
         ktimer.enable(False)
         ksum = ktimer.summary()
-        if graph_was is not None:
-            algo.use_update_graph = graph_was
     # ---- second leg: the same iteration with a declared ALE-like emulator cost per env step ----
     leg = None
     if leg_steps:

@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 5
+#define RLPYT_HIP_ABI_VERSION 6
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -68,6 +68,9 @@ int rlpyt_host_unregister(void* host_ptr);
  * address space): kernels may read the workers' newest frames and write the sampled actions
  * in place -- no staging copy, no DMA descriptor latency on the per-step critical path. */
 int rlpyt_host_device_pointer(void* host_ptr, void** dev_ptr);
+/* 1 when the current device supports hipStreamWriteValue32 / hipStreamWaitValue32 (the completion
+ * marker of rlpyt_sampler_serve's done_word), else 0. */
+int rlpyt_stream_write_value_supported(void);
 
 /* Step hand-off between the sampler master and its forked env workers: replaces the
  * 2 x n_workers semaphores per time step of rlpyt/samplers/parallel/gpu/action_server.py:44-58
@@ -210,24 +213,12 @@ int rlpyt_ppo_trunk_head_loss_fwd_bwd_dev_f32(
  * f32 out, f32-level error.  K must be a multiple of 32; a, b 16-byte aligned. */
 int rlpyt_gemm_nt_f32(const float* a, const float* b, float* c, int64_t M, int64_t N, int64_t K,
                       rlpyt_stream_t stream);
-/* The same contraction scheme for the trunk's BACKWARD (rlpyt/models/mlp.py:24-31 under autograd),
- * all f32 row-major, K a multiple of 32, pointers 16-byte aligned:
- *   rlpyt_gemm_nn_f32: c[M,N] = a[M,K] * b[K,N]    -- input gradient g W (W as stored, no transpose
- *                                                     copy); N a multiple of 4;
- *   rlpyt_gemm_tn_f32: c[M,N] = a[K,M]^T * b[K,N]  -- weight gradient g^T x, a contraction over the
- *                                                     batch axis; M, N multiples of 4.  For K >= 2048
- *                                                     K is cut into 8 chunks (one per XCD) whose
- *                                                     partial tiles go to `workspace`
- *                                                     (rlpyt_gemm_tn_workspace_bytes; 0 = none needed)
- *                                                     and are summed in a fixed order: results are
- *                                                     run-to-run identical;
- *   rlpyt_gemm_nt_pp_f32: rlpyt_gemm_nt_f32 on the same "ping-pong" kernel body as the two above
- *                         (wave halves alternate between a pure-MFMA segment and a load / split /
- *                         LDS segment; csrc/gemm_pp.hip). */
-int rlpyt_gemm_nt_pp_f32(const float* a, const float* b, float* c, int64_t M, int64_t N, int64_t K,
-                         rlpyt_stream_t stream);
-int rlpyt_gemm_nn_f32(const float* a, const float* b, float* c, int64_t M, int64_t N, int64_t K,
-                      rlpyt_stream_t stream);
+/* The weight gradient of the same Linear (rlpyt/models/mlp.py:24-31 under autograd), same
+ * arithmetic: c[M,N] = a[K,M]^T * b[K,N] -- g^T x, a contraction over the batch axis; all f32
+ * row-major, K a multiple of 32, M and N multiples of 4, pointers 16-byte aligned.  For K >= 2048
+ * K is cut into 8 chunks (one per XCD) whose partial tiles go to `workspace`
+ * (rlpyt_gemm_tn_workspace_bytes; 0 = none needed) and are summed in a fixed order: results are
+ * run-to-run identical. */
 int64_t rlpyt_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int rlpyt_gemm_tn_f32(const float* a, const float* b, float* c, int64_t M, int64_t N, int64_t K,
                       void* workspace, rlpyt_stream_t stream);
@@ -370,7 +361,8 @@ int rlpyt_categorical_head_f32(const float* h /*[n,K]*/, const float* w_pi /*[A,
  * group cycles on its own -- env workers arrived (obs_word reached rounds * n_workers) ->
  * enqueue the H2D copies of the page-locked step buffer (frame-stacked envs: newest frames +
  * the full stack of reset envs, t == 0: all full stacks), hipGraphLaunch, enqueue the D2H
- * action copies, record `event` -> event fired (hipEventQuery) -> rlpyt_seq_post(act_word) --
+ * action copies, completion marker (stream write of done_word, or `event`) -> marker seen ->
+ * rlpyt_seq_post(act_word) --
  * and the caller's thread services whichever hand-off is ready, so groups overlap freely and
  * may be at different time steps (each step's index reaches the device through t_host).
  * Returns RLPYT_ETIMEOUT after timeout_ms without any progress.  `acts` / `rounds`
@@ -402,7 +394,15 @@ typedef struct rlpyt_step_group {
   int64_t* t_host;  /* host, inside the page-locked misc block: receives the step index */
   void* graph_exec; /* hipGraphExec_t */
   void* stream;     /* hipStream_t */
-  void* event;      /* hipEvent_t */
+  void* event;      /* hipEvent_t (completion when done_word is NULL) */
+  /* completion word (nullable): page-locked host word + its device-mapped address.  When set, the
+   * step's completion is a hipStreamWriteValue32 of the step's sequence number behind the graph
+   * (the command processor writes it once the graph's kernels have retired) and the retiring
+   * thread polls plain memory -- no hipEventRecord / hipEventQuery on the hand-off chain. */
+  volatile uint32_t* done_word;
+  void* done_word_dev;
+  uint32_t done_seq; /* last sequence number handed out (updated in place) */
+  uint32_t reserved2;
 } rlpyt_step_group;
 int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t_begin, int t_end,
                         int spin_iters, int timeout_ms, double* timing /*[8], nullable*/);
@@ -413,7 +413,7 @@ int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t_begin, int
  * split over workgroups and a fixed-order partial sum (deterministic).  x [M,K], w [N,K]
  * (torch nn.Linear layout), bias [N] nullable, y [M,N]; N % 16 == 0, K % 16 == 0;
  * workspace: rlpyt_fc_small_workspace_bytes(M, N) bytes; with y == NULL only the split-K
- * partials [ksplit, M, N] are left in workspace (consumed by rlpyt_pg_sample_head_f32). */
+ * partials [ksplit, M, N] are left in workspace (consumed by rlpyt_lstm_cell_f32). */
 int64_t rlpyt_fc_small_workspace_bytes(int M, int N);
 int rlpyt_fc_small_ksplit(int K); /* number of K slices = leading dim of the partials */
 int rlpyt_fc_small_f32(const float* x, const float* w, const float* bias /*nullable*/, float* y,
@@ -439,28 +439,17 @@ int rlpyt_lstm_cell_f32(const float* partial, int ksplit, const float* b_ih, con
                         const float* c_prev, float* h_out, float* c_out, int64_t B, int H,
                         rlpyt_stream_t stream);
 
-/* Sampling head of the fused AtariFf step: h = relu(sum_s partial[s] + fc_bias) (the split-K
- * partials of rlpyt_fc_small_f32), policy / value heads + softmax + inverse-CDF draw
- * (uniforms[t, row]) as rlpyt_categorical_head_f32, and the row writes of the step:
- * prob_rows[t, lo+row, :], value_rows[t, lo+row], action_rows[t+1, lo+row], action_out[row];
- * t = *t_dev.  One launch instead of trunk-finish + head + commit nodes. */
-int rlpyt_pg_sample_head_f32(const float* partial, int ksplit, const float* fc_bias,
-                             const float* w_pi, const float* b_pi, const float* w_v,
-                             const float* b_v, const float* uniforms /*[T', n]*/,
-                             const int64_t* t_dev, int64_t n, int K, int A, float* prob_rows,
-                             float* value_rows, int64_t* action_rows, int64_t B, int64_t lo,
-                             int64_t* action_out, rlpyt_stream_t stream);
-
-/* Round-4 trunk + head of the rollout step (same roles as rlpyt_fc_small_f32 with y == NULL and
- * rlpyt_pg_sample_head_f32 -- the FC trunk of rlpyt/models/pg/atari_ff_model.py:52-55 and
- * rlpyt/agents/pg/categorical.py:34-43 + rlpyt/distributions/categorical.py:28-31 -- re-tiled so
- * that a CU ingests 64 KB instead of 218 KB per launch):
+/* Trunk + head of the rollout step -- the FC trunk of rlpyt/models/pg/atari_ff_model.py:52-55 and
+ * rlpyt/agents/pg/categorical.py:34-43 + rlpyt/distributions/categorical.py:28-31:
  *   rlpyt_rollout_fc_f32: partial[s][m][n] = sum_{k in slice s} x[m,k] w[n,k], slices of 128 along
  *     K (ksplit = rlpyt_rollout_fc_ksplit(K) <= 32), one workgroup per (64 columns, slice, 64 rows);
  *     x [M,K], w [N,K], N % 64 == 0, K % 16 == 0, K <= 4096, M <= 1024; partial holds
  *     rlpyt_rollout_fc_workspace_bytes(M, N, K) bytes.  fp32 MFMA, fixed order: deterministic.
- *   rlpyt_rollout_head_f32: arguments of rlpyt_pg_sample_head_f32 (ksplit <= 32), one workgroup
- *     per row; with bootstrap_out != NULL it writes ONLY the value head's output to
+ *   rlpyt_rollout_head_f32: h = relu(sum_s partial[s] + fc_bias), policy / value heads + softmax +
+ *     inverse-CDF draw (uniforms[t, row]) as rlpyt_categorical_head_f32, and the row writes of the
+ *     step: prob_rows[t, lo+row, :], value_rows[t, lo+row], action_rows[t+1, lo+row],
+ *     action_out[row] (may be a device-mapped address of the page-locked step buffer); t = *t_dev;
+ *     one workgroup per row; with bootstrap_out != NULL it writes ONLY the value head's output to
  *     bootstrap_out[row] (the bootstrap value after the last step of a batch,
  *     rlpyt/samplers/parallel/gpu/action_server.py:60-62) and every row / uniform pointer may be
  *     NULL. */
@@ -474,52 +463,7 @@ int rlpyt_rollout_head_f32(const float* partial, int ksplit, const float* fc_bia
                            const int64_t* t_dev, int64_t n, int K, int A, float* prob_rows,
                            float* value_rows, int64_t* action_rows, int64_t B, int64_t lo,
                            int64_t* action_out, float* bootstrap_out /*nullable: [n]*/,
-                           int64_t* t_next /*nullable: receives t + 1 (device-driven stepping)*/,
                            rlpyt_stream_t stream);
-
-/* First node of a DEVICE-DRIVEN rollout step: one launch pulls the step's inputs out of the
- * page-locked, fork-shared step buffer over PCIe -- newest frames, reward / done scalars, and for
- * environments whose frame stack was reset (host reset flag) or at the first step of a batch
- * (*t_ctr == 0) the full observation row, with slot[b] = b / -1 set accordingly -- and publishes
- * t = *t_ctr in the device misc block.  Same effect as the host-side uploads of
- * rlpyt_sampler_serve (role of the H2D in rlpyt/agents/pg/categorical.py:37 and of
- * ActionServer.serve_actions' per-step bookkeeping, action_server.py:44-58), with no host call,
- * so the whole step can be enqueued ahead of time behind a stream wait on the workers' arrival
- * counter (rlpyt_sampler_serve_ahead).  host_* are DEVICE-mapped addresses of page-locked host
- * memory (rlpyt_host_device_pointer); misc layout: reward f32[Bg] | slot i32[Bg] | done u8[Bg] |
- * reset u8[Bg] | pad | t i64 at t_off. */
-int rlpyt_rollout_fetch(const uint8_t* host_frame, const uint8_t* host_misc,
-                        const uint8_t* host_obs, uint8_t* dev_frame, uint8_t* dev_misc,
-                        uint8_t* full_rows, int Bg, int64_t frame_bytes, int64_t row_bytes,
-                        int t_off, const int64_t* t_ctr, rlpyt_stream_t stream);
-
-/* Enqueue-ahead serve loop: for every time step t in [0, T) and pipeline group g the caller's
- * thread enqueues, WITHOUT waiting for anything,
- *     hipStreamWaitValue32(stream_g, obs_word_g >= rounds_g * n_workers_g)   (workers arrived)
- *     hipGraphLaunch(step graph of g)            (fetch + forward + action / row writes)
- *     hipStreamWriteValue32(stream_g, act_word_g, ++acts_g)                  (actions published)
- * and, with tail graphs, one more wait + graph per group for the bootstrap value at t = T.  The
- * GPU's command processor takes the hand-off from the env workers itself; a helper thread only
- * turns the GPU's act-word writes into futex wake-ups for workers that went to sleep.  Returns
- * when every group's last act word (and tail) has completed.  obs / act words must be page-locked
- * and mapped (their *_dev addresses are what the stream operations use); counters must stay below
- * 2^31 (the wait is an unsigned >=).  timing[0] = seconds spent enqueueing, [1] = seconds waiting for
- * completion afterwards. */
-typedef struct rlpyt_ahead_group {
-  uint32_t* act_word;      /* host address (futex word of the workers) */
-  uint32_t* obs_word;
-  void* act_word_dev;      /* device-mapped addresses of the same words */
-  void* obs_word_dev;
-  uint32_t acts;
-  uint32_t rounds;
-  int32_t n_workers;
-  int32_t reserved;
-  void* graph_exec;        /* hipGraphExec_t: one time step */
-  void* tail_graph_exec;   /* hipGraphExec_t or NULL: bootstrap-value pass at t = T */
-  void* stream;            /* hipStream_t */
-} rlpyt_ahead_group;
-int rlpyt_sampler_serve_ahead(rlpyt_ahead_group* groups, int n_groups, int T, int timeout_ms,
-                              double* timing /*[2], nullable*/);
 
 /* Frame-stack push for frame-stacked environments (rlpyt/envs/atari/atari_env.py:115-118:
  * the observation is the last C frames, newest last): the host uploads only the newest
@@ -554,8 +498,10 @@ int rlpyt_frame_push(uint8_t* obs, const int64_t* t_dev, int64_t B, int64_t lo, 
 int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat_idx /*nullable*/, int T,
                               int64_t B, int64_t M, const float* w1, const float* b1,
                               float scale, float* y1, rlpyt_stream_t stream);
+/* relu_mask u32 [M, 32, 4]: the sign bits of y2 (bit j of word [m][co][w] = y2[m][co][32 w + j] > 0),
+ * written beside y2 -- all the backward pass needs of y2 (432 bits instead of 13.8 KB per image). */
 int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float* w2, const float* b2,
-                              float* y2, rlpyt_stream_t stream);
+                              float* y2, uint32_t* relu_mask, rlpyt_stream_t stream);
 /* Sampling-step front end in ONE launch (one environment per workgroup): the frame-stack push of
  * rlpyt_frame_push (obs[t, lo+b] rebuilt from slot / full_rows / obs[t-1] / new_frame, t = *t_dev,
  * optional reward/done row commit) followed by conv1 and conv2 of rlpyt_atari_conv{1,2}_fwd_f32 on
@@ -580,21 +526,14 @@ int rlpyt_atari_sample_convs_to_f32(uint8_t* obs, const int64_t* t_dev, int64_t 
                                     const float* b1, const float* w2, const float* b2, float scale,
                                     float* y2, uint8_t* dst_stage /*nullable*/,
                                     rlpyt_stream_t stream);
-int rlpyt_atari_conv2_dgrad_f32(const float* g2, const float* y2, const float* y1, int64_t M,
-                                const float* w2, float* dy1, rlpyt_stream_t stream);
 int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void);
-int rlpyt_atari_conv2_wgrad_f32(const float* g2, const float* y2, const float* y1, int64_t M,
-                                float* workspace, float* dw2, float* db2, rlpyt_stream_t stream);
-/* conv2 backward in one pass (dgrad + ReLU mask + weight/bias gradients; g2 / y2 / y1 read once) */
-int rlpyt_atari_conv2_bwd_f32(const float* g2, const float* y2, const float* y1, int64_t M,
-                              const float* w2, float* dy1, float* workspace, float* dw2,
-                              float* db2, rlpyt_stream_t stream);
-/* The same operation with both contractions on the bf16 matrix pipe (three-piece bf16 splits of
- * both operands, six products, f32 accumulate: f32-level error, like rlpyt_gemm_nt_f32); same
- * arguments, same workspace. */
-int rlpyt_atari_conv2_bwd_x6_f32(const float* g2, const float* y2, const float* y1, int64_t M,
-                              const float* w2, float* dy1, float* workspace, float* dw2,
-                              float* db2, rlpyt_stream_t stream);
+/* conv2 backward in one pass (dgrad + both ReLU masks + weight / bias gradients; g2 / y1 read once,
+ * conv2's ReLU mask from relu_mask as written by rlpyt_atari_conv2_fwd_f32), both contractions on
+ * the bf16 matrix pipe (three-piece bf16 splits of both operands, six products, f32 accumulate:
+ * f32-level error, like rlpyt_gemm_nt_f32). */
+int rlpyt_atari_conv2_bwd_x6_f32(const float* g2, const uint32_t* relu_mask, const float* y1,
+                                 int64_t M, const float* w2, float* dy1, float* workspace,
+                                 float* dw2, float* db2, rlpyt_stream_t stream);
 int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* flat_idx /*nullable*/, int T,
                                 int64_t B, int64_t M, const float* dy1, float scale,
                                 float* workspace, float* dw1, float* db1, rlpyt_stream_t stream);

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class CopyDesc(ctypes.Structure):
@@ -33,15 +33,8 @@ class StepGroup(ctypes.Structure):
                 ("reset_flags", c_void_p), ("slot_host", c_void_p), ("full_rows_dev", c_void_p),
                 ("obs_host", c_void_p), ("row_bytes", c_int64), ("t_host", c_void_p),
                 ("graph_exec", c_void_p),
-                ("stream", c_void_p), ("event", c_void_p)]
-
-
-class AheadGroup(ctypes.Structure):
-    """Mirror of ``rlpyt_ahead_group`` (include/rlpyt_hip.h)."""
-    _fields_ = [("act_word", c_void_p), ("obs_word", c_void_p), ("act_word_dev", c_void_p),
-                ("obs_word_dev", c_void_p), ("acts", c_uint32), ("rounds", c_uint32),
-                ("n_workers", ctypes.c_int32), ("reserved", ctypes.c_int32),
-                ("graph_exec", c_void_p), ("tail_graph_exec", c_void_p), ("stream", c_void_p)]
+                ("stream", c_void_p), ("event", c_void_p), ("done_word", c_void_p),
+                ("done_word_dev", c_void_p), ("done_seq", c_uint32), ("reserved2", c_uint32)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -81,6 +74,7 @@ _SIGNATURES = {
     "rlpyt_host_register": (c_int, [_p, c_int64]),
     "rlpyt_host_unregister": (c_int, [_p]),
     "rlpyt_host_device_pointer": (c_int, [_p, POINTER(c_void_p)]),
+    "rlpyt_stream_write_value_supported": (c_int, []),
     "rlpyt_seq_wait": (c_int, [_p, c_uint32, c_int, c_int]),
     "rlpyt_seq_post": (c_int, [_p, c_uint32]),
     "rlpyt_seq_arrive": (c_int, [_p, c_uint32]),
@@ -107,8 +101,6 @@ _SIGNATURES = {
                                                               c_int, c_float, _p, c_float, c_float,
                                                               _p, _p, _p, _p, _p]),
     "rlpyt_gemm_nt_f32": (c_int, [_p, _p, _p, c_int64, c_int64, c_int64, _p]),
-    "rlpyt_gemm_nt_pp_f32": (c_int, [_p, _p, _p, c_int64, c_int64, c_int64, _p]),
-    "rlpyt_gemm_nn_f32": (c_int, [_p, _p, _p, c_int64, c_int64, c_int64, _p]),
     "rlpyt_gemm_tn_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "rlpyt_gemm_tn_f32": (c_int, [_p, _p, _p, c_int64, c_int64, c_int64, _p, _p]),
     "rlpyt_a2c_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,
@@ -142,10 +134,8 @@ _SIGNATURES = {
     "rlpyt_fc_small_ksplit": (c_int, [c_int]),
     "rlpyt_eps_greedy_f32": (c_int, [_p, c_int64, c_int, _p, c_int, _p, _p, _p, _p]),
     "rlpyt_lstm_cell_f32": (c_int, [_p, c_int, _p, _p, _p, _p, _p, c_int64, c_int, _p]),
-    "rlpyt_pg_sample_head_f32": (c_int, [_p, c_int] + [_p] * 7 + [c_int64, c_int, c_int, _p, _p, _p,
-                                                              c_int64, c_int64, _p, _p]),
     "rlpyt_atari_conv1_fwd_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, _p, c_float, _p, _p]),
-    "rlpyt_atari_conv2_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p]),
+    "rlpyt_atari_conv2_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p]),
     "rlpyt_atari_sample_convs_f32": (c_int, [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, _p, _p,
                                              _p, _p, _p, _p, _p, _p, c_float, _p, _p]),
     "rlpyt_atari_sample_convs_to_f32": (c_int, [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, _p, _p,
@@ -154,13 +144,8 @@ _SIGNATURES = {
     "rlpyt_rollout_fc_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "rlpyt_rollout_fc_f32": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p]),
     "rlpyt_rollout_head_f32": (c_int, [_p, c_int] + [_p] * 7 + [c_int64, c_int, c_int, _p, _p, _p,
-                                                            c_int64, c_int64, _p, _p, _p, _p]),
-    "rlpyt_rollout_fetch": (c_int, [_p, _p, _p, _p, _p, _p, c_int, c_int64, c_int64, c_int, _p, _p]),
-    "rlpyt_sampler_serve_ahead": (c_int, [_p, c_int, c_int, c_int, _p]),
-    "rlpyt_atari_conv2_dgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p]),
+                                                            c_int64, c_int64, _p, _p, _p]),
     "rlpyt_atari_conv_wgrad_workspace_bytes": (c_int64, []),
-    "rlpyt_atari_conv2_wgrad_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p, _p]),
-    "rlpyt_atari_conv2_bwd_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p, _p, _p, _p]),
     "rlpyt_atari_conv2_bwd_x6_f32": (c_int, [_p, _p, _p, c_int64, _p, _p, _p, _p, _p, _p]),
     "rlpyt_atari_conv1_wgrad_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, c_float, _p, _p,
                                             _p, _p]),

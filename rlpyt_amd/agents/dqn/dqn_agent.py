@@ -62,6 +62,7 @@ class EpsilonGreedyAgentMixin:
     eps_init, eps_final = _schedule_field("init"), _schedule_field("final")
     eps_itr_min, eps_itr_max = _schedule_field("itr_min"), _schedule_field("itr_max")
     eps_eval, eps_sample = _schedule_field("eval_eps"), _schedule_field("current")
+    eps_final_min = _schedule_field("final_min")     # (the reference keeps it on the agent too)
 
     def collector_initialize(self, global_B=1, env_ranks=None):
         if env_ranks is not None:

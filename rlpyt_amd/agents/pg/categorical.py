@@ -10,7 +10,7 @@ from collections import namedtuple
 AgentInfo = namedarraytuple("AgentInfo", ["dist_info", "value"])
 AgentInfoRnn = namedarraytuple("AgentInfoRnn", ["dist_info", "value", "prev_rnn_state"])
 _HeadOut = namedtuple("_HeadOut", ["prob_rows", "value_rows", "action_rows", "action_out",
-                                   "uniforms", "t_dev", "lo", "t_next"], defaults=(None,))
+                                   "uniforms", "t_dev", "lo"])
 
 
 class CategoricalPgAgent(BaseAgent):
@@ -86,8 +86,7 @@ class CategoricalPgAgent(BaseAgent):
             return False
         out = _HeadOut(prob_rows=info.dist_info.prob, value_rows=info.value,
                        action_rows=binding.action_rows, action_out=binding.action_out,
-                       uniforms=binding.uniforms, t_dev=binding.t_dev, lo=binding.lo,
-                       t_next=getattr(binding, "t_next", None))
+                       uniforms=binding.uniforms, t_dev=binding.t_dev, lo=binding.lo)
         push = getattr(binding, "push", None)
         if push is not None:      # the model also rebuilds the frame stacks of row t
             return bool(m.sample_step_into(None, out, push=push))

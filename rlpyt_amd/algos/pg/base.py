@@ -51,18 +51,7 @@ class PolicyGradientAlgo(RlAlgorithm):
             return_, advantage = out[0], out[1]
             valid = out[2] if want_valid else None
         else:
-            dest = (None, None)
-            if getattr(self, "use_update_graph", False):
-                # captured update graph (opt-in): it reads advantage / return_ at fixed addresses,
-                # so they go to buffers that are re-allocated only when the batch shape changes.
-                # (Never by default: two calls would hand out the SAME tensors.)
-                dest = getattr(self, "_returns_dest", None)
-                if (dest is None or dest[0].shape != reward.shape
-                        or dest[0].device != reward.device):
-                    dest = self._returns_dest = (torch.empty_like(reward, dtype=torch.float32),
-                                                 torch.empty_like(reward, dtype=torch.float32))
             out = ops.gae(reward, value, done, bv, self.discount, self.gae_lambda,
-                          advantage_dest=dest[0], return_dest=dest[1],
                           with_valid=want_valid, variant=self.scan_variant)
             advantage, return_ = out[0], out[1]
             valid = out[2] if want_valid else None

@@ -104,6 +104,9 @@ constexpr int C0 = 4, H0 = 104, W0 = 80, HW0 = H0 * W0, IMG = C0 * HW0;  // 3328
 constexpr int C1 = 16, H1 = 25, W1 = 19, P1 = H1 * W1;                   // 475 positions
 constexpr int C2 = 32, H2 = 12, W2 = 9, P2 = H2 * W2;                    // 108 positions
 constexpr int F2 = C2 * P2;                                              // 3456 features
+// sign mask of y2 (written by the conv2 forward kernels, read by conv2's backward pass):
+// uint32 [m][co][4], bit j of word w = (y2[m][co][32 w + j] > 0), positions 108..127 unused (zero)
+constexpr int MASK2_W = C2 * 4;                                          // 128 words = 512 B / image
 constexpr int Y1 = P1 * C1;                                              // 7600 floats / image
 // padded conv2 input plane: rows -1..24, cols -1..18 (only the top row / left col are ever
 // out of range for k4 s2 p1 on 25x19)
@@ -426,7 +429,7 @@ __device__ __forceinline__ void split3_rn(float x0, float x1, uint32_t& hi, uint
 
 __global__ __launch_bounds__(C2X_THREADS) void conv2_fwd_x6_kernel(
     const float* __restrict__ y1, const float* __restrict__ w2, const float* __restrict__ b2,
-    float* __restrict__ y2, int64_t M) {
+    float* __restrict__ y2, uint32_t* __restrict__ mask, int64_t M) {
   // y1 pieces double-buffered (2 x 49,920 B): the next image is split and written into the other
   // buffer in the MIDDLE of this image's MFMA stream; the two tap halves exchange HALF of their
   // accumulators through a double-buffered 16 KB block -- one barrier per image.  The finished
@@ -487,8 +490,9 @@ __global__ __launch_bounds__(C2X_THREADS) void conv2_fwd_x6_kernel(
   // waited for by hand: hipcc merges the loop-entry state (no stores behind the loads) with the
   // back-edge state (this image's stores behind them) into "wait for vmcnt(0)", which makes
   // every staging wait for the HBM round trip of the stores issued just before it (measured:
-  // up to 3000 cycles per image).  Every wave issues exactly NPD loads (clamped index) and 2
-  // stores per image, and vector-memory operations retire in issue order.
+  // up to 3000 cycles per image).  Every wave issues exactly NPD loads (clamped index) and 4
+  // stores per image (2 of y2, 2 of its sign mask), and vector-memory operations retire in issue
+  // order.
   u32x4 pdy[NPD], qdy[NPD];            // in flight / waited-for copy
   static_assert(NPD == 4, "RLPYT_VMCNT_WAIT_COPY4 lists 4 registers");
 #define RLPYT_C2X_PREFETCH(mi)                                                                 \
@@ -557,14 +561,14 @@ __global__ __launch_bounds__(C2X_THREADS) void conv2_fwd_x6_kernel(
     // The two waves of a SIMD (same pt, kh = 0 / 1) stage at opposite ends of the tap stream, so
     // one wave's split / LDS-write work runs under the other's MFMAs.  The registers hold image
     // m + 1 since the middle of the previous iteration; behind those loads this wave has issued
-    // exactly the previous image's 2 stores (none before the first image).
+    // exactly the previous image's 4 stores (none before the first image).
     const bool more = m + gridDim.x < M;
 #define RLPYT_C2X_NEXT()                                                                       \
   if (more) {                                                                                  \
     if (m == (int64_t)blockIdx.x)                                                              \
       RLPYT_VMCNT_WAIT_COPY4(0, qdy[0], qdy[1], qdy[2], qdy[3], pdy[0], pdy[1], pdy[2], pdy[3]); \
     else                                                                                       \
-      RLPYT_VMCNT_WAIT_COPY4(2, qdy[0], qdy[1], qdy[2], qdy[3], pdy[0], pdy[1], pdy[2], pdy[3]); \
+      RLPYT_VMCNT_WAIT_COPY4(4, qdy[0], qdy[1], qdy[2], qdy[3], pdy[0], pdy[1], pdy[2], pdy[3]); \
     RLPYT_C2X_STAGE(cur ^ 1)                                                                   \
     if (m + 2 * (int64_t)gridDim.x < M) RLPYT_C2X_PREFETCH(m + 2 * (int64_t)gridDim.x)         \
   }
@@ -593,14 +597,27 @@ __global__ __launch_bounds__(C2X_THREADS) void conv2_fwd_x6_kernel(
       // next image's registers were requested before these stores, and with a store under a
       // branch hipcc cannot count how many memory operations follow those loads -- it waits for
       // vmcnt(0), i.e. for the HBM round trip of the stores, before the next staging
+      // ... and the SIGN MASK of y2 beside it (mask[m][co][word pt], bit j = position 32 pt + j is
+      // set iff y2 > 0): conv2's backward pass needs y2 only for its ReLU mask, 432 of these bits
+      // per image instead of 13.8 KB of floats.  The 8 lanes of a row build the word with three
+      // xor-shuffles and ALL of them store it (same address, same value: one unconditional
+      // wave-level store, see above).
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         int c8 = lane + 64 * k;
-        if (32 * pt + 4 * (c8 & 7) >= P2) c8 = (c8 & ~7) + (P2 - 96) / 4 - 1;
+        const bool past = 32 * pt + 4 * (c8 & 7) >= P2;
+        if (past) c8 = (c8 & ~7) + (P2 - 96) / 4 - 1;
         const int row = c8 >> 3, rr = 8 * kh + (row >> 1);
         const int co = (rr & 3) + 8 * (rr >> 2) + 4 * (row & 1), p0 = 32 * pt + 4 * (c8 & 7);
-        *reinterpret_cast<f32x4*>(y2 + m * F2 + co * P2 + p0) =
-            *reinterpret_cast<const f32x4*>(blk + 4 * c8);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(blk + 4 * c8);
+        *reinterpret_cast<f32x4*>(y2 + m * F2 + co * P2 + p0) = v;
+        uint32_t w = past ? 0u
+                          : ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) |
+                             (v[3] > 0.f ? 8u : 0u)) << (4 * (lane & 7));
+        w |= (uint32_t)__shfl_xor((int)w, 1, kWave);
+        w |= (uint32_t)__shfl_xor((int)w, 2, kWave);
+        w |= (uint32_t)__shfl_xor((int)w, 4, kWave);
+        mask[m * MASK2_W + co * 4 + pt] = w;
       }
     }
     RL_T(4)
@@ -612,636 +629,8 @@ __global__ __launch_bounds__(C2X_THREADS) void conv2_fwd_x6_kernel(
 #undef RLPYT_C2X_PREFETCH
 }
 
-// ======================================================================================
-// conv2 backward-data + ReLU mask of conv1:
-//   dy1[m, iy, ix, c] = (y1 > 0) * sum_{co, ky, kx} gm2[co, oy, ox] * w2[co, c, ky, kx],
-//   iy + 1 = 2 oy + ky, ix + 1 = 2 ox + kx, gm2 = g2 * (y2 > 0).
-// Stride 2 / kernel 4: an input pixel of parity (py,px) sees exactly 2x2 taps
-// ky = 1-py+2dy, kx = 1-px+2dx with oy = a+py-dy, ox = b+px-dx (iy = 2a+py, ix = 2b+px).
-// Wave w owns parity class w: its 32 K-steps of weights (co x 4 taps = 128) stay in VGPRs.
-//   A = w2 taps (rows c), B = gm2 transposed in LDS [pos][co] (stride 40 floats, row 108 = 0).
-// ======================================================================================
-constexpr int RS_D = 40;
-
-__global__ __launch_bounds__(256) void conv2_dgrad_kernel(
-    const float* __restrict__ g2, const float* __restrict__ y2, const float* __restrict__ y1,
-    const float* __restrict__ w2, float* __restrict__ dy1, int64_t M) {
-  __shared__ __attribute__((aligned(16))) float gT[(P2 + 1) * RS_D];  // 17,440 B
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 15, kq = lane >> 4;
-  const int py = wave >> 1, px = wave & 1;
-  const int na = py ? 12 : 13, nb = px ? 9 : 10, npx = na * nb;
-  const int ntile = (npx + 15) >> 4;
-  float wa[32];
-#pragma unroll
-  for (int dd = 0; dd < 4; ++dd)
-#pragma unroll
-    for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {
-        const int co = sg * 16 + 4 * kq + sp;
-        const int ky = 1 - py + 2 * (dd >> 1), kx = 1 - px + 2 * (dd & 1);
-        wa[(dd * 2 + sg) * 4 + sp] = w2[co * 256 + j * 16 + ky * 4 + kx];
-      }
-  for (int i = tid; i < (P2 + 1) * RS_D; i += 256) gT[i] = 0.f;
-
-  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
-    __syncthreads();
-    for (int i = tid; i < F2; i += 256) {
-      const int co = i / P2, pos = i - co * P2;
-      const float g = g2[m * F2 + i], y = y2[m * F2 + i];
-      gT[pos * RS_D + co] = y > 0.f ? g : 0.f;
-    }
-    __syncthreads();
-    for (int tile = 0; tile < ntile; tile += 2) {
-      int off[2][4];
-      int pix[2];
-      bool ok[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int p = (tile + u) * 16 + j;
-        ok[u] = p < npx;
-        const int pc = min(p, npx - 1);
-        const int a = pc / nb, b = pc - a * nb;
-        pix[u] = (2 * a + py) * W1 + 2 * b + px;
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-          const int oy = a + py - (dd >> 1), ox = b + px - (dd & 1);
-          const bool v = (oy >= 0) && (oy < H2) && (ox >= 0) && (ox < W2);
-          off[u][dd] = (v ? oy * W2 + ox : P2) * RS_D + 4 * kq;
-        }
-      }
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd)
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg) {
-          f32x4 bv[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-            bv[u] = *reinterpret_cast<const f32x4*>(gT + off[u][dd] + sg * 16);
-#pragma unroll
-          for (int sp = 0; sp < 4; ++sp)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-              acc[u] = mfma16(wa[(dd * 2 + sg) * 4 + sp], bv[u][sp], acc[u]);
-        }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (ok[u]) {
-          const int64_t e = m * Y1 + pix[u] * C1 + 4 * kq;
-          const f32x4 yv = *reinterpret_cast<const f32x4*>(y1 + e);
-          f32x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = yv[r] > 0.f ? acc[u][r] : 0.f;
-          *reinterpret_cast<f32x4*>(dy1 + e) = o;
-        }
-      }
-    }
-  }
-}
-
-// ======================================================================================
-// conv2 backward-weights (+ bias): dW2[co,c,ky,kx] = sum_{m,pos} gm2[m,co,pos] * y1pad[m,2oy+ky,2ox+kx,c]
-// Persistent workgroups; the 32x256 accumulator tile lives in VGPRs across all images of the
-// workgroup (wave w <-> ky = w; 4 kx tiles x 2 co tiles), partial sums are written once per
-// workgroup and reduced by reduce_partials_kernel (deterministic, no atomics).
-//   A = gm2 [co][pos] in LDS (stride 120, float4 over pos), B = y1pad [pix][c] (stride 18).
-//   K = positions: 7 groups of 16; MFMA slot kq of sub-step s' <-> pos = 16*sg + 4*kq + s'.
-// ======================================================================================
-constexpr int GS_W = 120, PS_W = 18, NSG2 = 7;
+// partial-gradient slot of one workgroup: dW2 [co][c][ky][kx] then db2 (conv2 backward)
 constexpr int DW2_N = C2 * 256, PART2 = DW2_N + C2;  // 8192 weights + 32 biases
-
-__global__ __launch_bounds__(256) void conv2_wgrad_kernel(
-    const float* __restrict__ g2, const float* __restrict__ y2, const float* __restrict__ y1,
-    float* __restrict__ partial, int64_t M) {
-  __shared__ __attribute__((aligned(16))) float gm[C2 * GS_W];        // 15,360 B
-  __shared__ __attribute__((aligned(16))) float pad[PPIX * PS_W];     // 37,440 B
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 15, kq = lane >> 4;
-  int pbase[NSG2 * 4];  // LDS float offset of the patch origin of this lane's positions
-#pragma unroll
-  for (int s = 0; s < NSG2 * 4; ++s) {
-    const int pos = min(16 * (s >> 2) + 4 * kq + (s & 3), P2 - 1);
-    const int oy = pos / W2, ox = pos - oy * W2;
-    pbase[s] = ((2 * oy + wave) * PW + 2 * ox) * PS_W + j;
-  }
-  for (int i = tid; i < C2 * GS_W; i += 256) gm[i] = 0.f;   // pos 108..119 stay zero
-  for (int i = tid; i < PPIX * PS_W; i += 256) pad[i] = 0.f;
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int kx = 0; kx < 4; ++kx)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) acc[kx][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum[2] = {0.f, 0.f};
-
-  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
-    __syncthreads();
-    for (int i = tid; i < F2; i += 256) {
-      const int co = i / P2, pos = i - co * P2;
-      const float g = g2[m * F2 + i], y = y2[m * F2 + i];
-      gm[co * GS_W + pos] = y > 0.f ? g : 0.f;
-    }
-    stage_y1_padded<PS_W>(pad, y1 + m * Y1, tid, 256);
-    __syncthreads();
-#pragma unroll
-    for (int sg = 0; sg < NSG2; ++sg) {
-      f32x4 av[2];
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-        av[ct] = *reinterpret_cast<const f32x4*>(gm + (ct * 16 + j) * GS_W + 16 * sg + 4 * kq);
-      if (wave == 0) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) bsum[ct] += (av[ct][0] + av[ct][1]) + (av[ct][2] + av[ct][3]);
-      }
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {
-        const float* bp = pad + pbase[sg * 4 + sp];
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-          const float bval = bp[kx * PS_W];
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) acc[kx][ct] = mfma16(av[ct][sp], bval, acc[kx][ct]);
-        }
-      }
-    }
-  }
-  // D[row = co_local = 4*kq + r][col = c = j] -> dW2[co][c][ky = wave][kx]
-  float* out = partial + (int64_t)blockIdx.x * PART2;
-#pragma unroll
-  for (int kx = 0; kx < 4; ++kx)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        out[(ct * 16 + 4 * kq + r) * 256 + j * 16 + wave * 4 + kx] = acc[kx][ct][r];
-  if (wave == 0) {
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      float v = bsum[ct];
-      v += __shfl_xor(v, 16, kWave);
-      v += __shfl_xor(v, 32, kWave);
-      if (kq == 0) out[DW2_N + ct * 16 + j] = v;
-    }
-  }
-}
-
-// ======================================================================================
-// conv2 backward, fused: dgrad (+ ReLU mask of conv1) and wgrad (+ bias grad) of the two
-// kernels above in ONE pass over the images, so g2 / y2 / y1 are read from HBM once:
-//   per image 27.6 KB (g2, y2) + 30.4 KB (y1) in, 30.4 KB (dy1) out, 1920 MFMAs
-//   = 15 360 matrix-pipe cycles per SIMD and 5.7 B/clk/CU of HBM traffic at the full MFMA rate.
-// The kernel only works if the matrix pipe never waits, so (round 2) it is built around that.
-// Round 1 had every wave play both roles at the 128-VGPR cap: ds_read -> wait -> 2 MFMAs, global
-// loads consumed right after their issue, 62 % MFMA busy, 385-407 us at M = 8192.  Now:
-//   * ONE 8-wave workgroup per CU, up to 256 VGPRs per wave: nothing spills and every MFMA B
-//     operand is requested from LDS one (wgrad) or two (dgrad) batches ahead of its use, the reads
-//     interleaved one by one with the MFMAs (sched_group_barrier) instead of issued as a block;
-//   * waves have SEPARATE roles, paired per SIMD (waves w and w + 4 share one: checked with
-//     s_getreg HW_ID, scripts/debug/simd_probe.hip), 15 units of 32 MFMAs per image and SIMD:
-//       wave 0-3: dgrad of parity class q = wave, tiles 0..6 of the class (16 pixels each), the
-//                 class's 128 weights in VGPRs, tile addressing from an LDS table, the epilogue
-//                 of tile t (mask + 16-byte store) deferred into the MFMA stream of tile t + 1;
-//       wave 4-7: wgrad of kernel row ky = wave - 4: 7 position groups, the 32x64 accumulator
-//                 slice in VGPRs across all images of the workgroup, PLUS the one spare dgrad tile
-//                 that the classes with 8 or 9 tiles have left over;
-//     the wgrad waves run at s_setprio 1: the matrix-pipe arbiter otherwise serves the older
-//     (dgrad) wave whenever both are ready and that wave finishes ~8 k cycles early (measured
-//     both ways, scripts/debug/bwd_timing.py; equal shares need the priority on the role that is
-//     ready less often);
-//   * LDS is double-buffered (2 x 53 KB): the NEXT image is fetched HBM -> registers early in an
-//     iteration (the dgrad waves first, the wgrad waves two groups later: one burst of 64 wave
-//     loads backs up the CU's address path for ~2.5 k cycles) and moved registers -> LDS in the
-//     MIDDLE of the wave's MFMA work, so there is one barrier per image and no staging phase
-//     during which the pipe idles; the staging work is split unevenly (dgrad threads 5 float4,
-//     wgrad threads 11) because the dgrad waves also carry the epilogues.
-// Three hipcc behaviours had to be worked around (each cost > 10 %): loop-invariant LDS addresses
-// hoisted out of the image loop into ~150 spilled VGPRs (runtime group loop instead of a full
-// unroll); vmcnt drained in the preheader of any loop that stores and "uses a VGPR loaded outside"
-// (the weights are consumed by an empty asm before the image loop); conditional prefetch inside
-// a loop turned into load -> wait -> copy (the prefetch sits between two loops instead).
-// gm2 = g2 * (y2 > 0) lives in LDS as [co][pos] (stride 124): the wgrad reads it as float2 over
-// pos, the dgrad as scalars (4*GS_B = 16 mod 32: the two kq lane halves of a ds_read_b32 hit
-// disjoint banks); y1 lives in the zero-bordered plane (stride 18) and also supplies the ReLU
-// mask of the dgrad epilogue.
-// ======================================================================================
-constexpr int B2_THREADS = 512;
-constexpr int GS_B = 124;
-constexpr int B2_GM = C2 * GS_B, B2_PAD = PPIX * PS_W;          // floats per buffer
-constexpr int B2_TABP = 176;                                    // pixel slots per class in the tile table (9 tiles + 2 of look-ahead)
-
-__global__ __launch_bounds__(B2_THREADS, 2) void conv2_bwd_kernel(
-    const float* __restrict__ g2, const float* __restrict__ y2, const float* __restrict__ y1,
-    const float* __restrict__ w2, float* __restrict__ dy1, float* __restrict__ partial, int64_t M) {
-  __shared__ __attribute__((aligned(16))) float gm_[2 * B2_GM];      // 31,744 B
-  __shared__ __attribute__((aligned(16))) float pad_[2 * B2_PAD];    // 74,880 B
-  // dgrad tile table: entry (class q, pixel slot p) = {gm2 offsets of the 4 taps (column 108 = the
-  // zero column where a tap falls outside), offset of y1[pix] in the padded plane, pix * 16};
-  // slots past the class's last pixel repeat it (10 tiles of 16: one tile of look-ahead)
-  __shared__ __attribute__((aligned(16))) int dtab_[4 * B2_TABP * 8];  // 22,528 B
-  // wgrad patch origins: position p (clamped to 107) -> float offset of pixel (2 oy, 2 ox) in the
-  // padded y1 plane.  Every plain VALU instruction beside an f32 MFMA costs the SIMD ~3 ns (DESIGN
-  // 4a): the origin arithmetic (clamp, /9, two multiply-adds per position) was ~0.75 VALU per MFMA
-  // of the wgrad stream; now one 8-byte table read per half-step, one group ahead.
-  __shared__ __attribute__((aligned(8))) int wtab_[128];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 15, kq = lane >> 4;
-  const int q = wave & 3;
-
-  for (int i = tid; i < 2 * B2_GM; i += B2_THREADS) gm_[i] = 0.f;    // pos 108..123 stay zero
-  for (int i = tid; i < 2 * B2_PAD; i += B2_THREADS) pad_[i] = 0.f;  // border stays zero
-  for (int i = tid; i < 128; i += B2_THREADS) {
-    const int pos = min(i, P2 - 1), oy = pos / W2, ox = pos - oy * W2;
-    wtab_[i] = ((2 * oy) * PW + 2 * ox) * PS_W;
-  }
-  for (int i = tid; i < 4 * B2_TABP; i += B2_THREADS) {
-    const int cq = i / B2_TABP, p = i - cq * B2_TABP;
-    const int py = cq >> 1, px = cq & 1;
-    const int nb = px ? 9 : 10, npx = (py ? 12 : 13) * nb;
-    const int pc = min(p, npx - 1);
-    const int a = pc / nb, b = pc - a * nb;
-    const int iy = 2 * a + py, ix = 2 * b + px;
-    int* e = dtab_ + i * 8;
-    for (int dd = 0; dd < 4; ++dd) {
-      const int oy = a + py - (dd >> 1), ox = b + px - (dd & 1);
-      const bool v = (oy >= 0) && (oy < H2) && (ox >= 0) && (ox < W2);
-      e[dd] = v ? oy * W2 + ox : P2;
-    }
-    e[4] = ((iy + 1) * PW + ix + 1) * PS_W;
-    e[5] = (iy * W1 + ix) * C1;
-    e[6] = e[7] = 0;
-  }
-
-  // ---- software pipeline over images: registers <- HBM, then registers -> the other LDS buffer.
-  // The fetch + staging work is split UNEVENLY between the roles (the dgrad waves, which carry
-  // the deferred epilogues and stores, were the critical path by ~2 k cycles per image with an
-  // even split): dgrad threads move y1 float4s [0, 1280) (5 each), wgrad threads all of g2 / y2
-  // (864 float4 each, 4 + 4 per thread) and y1 float4s [1280, 1900) (3 each).
-  const int rtid = tid & 255;
-  constexpr int B2_YSPLIT = 1280;
-  f32x4 pg[4], py2[4], py1[5];
-#define RLPYT_B2_PREFETCH_R(mi, NG_, NY_, YBASE_, YEND_)                                       \
-  {                                                                                            \
-    const f32x4* __restrict__ gs_ = reinterpret_cast<const f32x4*>(g2 + (mi) * F2);            \
-    const f32x4* __restrict__ ys_ = reinterpret_cast<const f32x4*>(y2 + (mi) * F2);            \
-    const f32x4* __restrict__ y1s_ = reinterpret_cast<const f32x4*>(y1 + (mi) * Y1);          \
-    _Pragma("unroll") for (int k = 0; k < (NG_); ++k) {                                        \
-      const int i = min(rtid + k * 256, F2 / 4 - 1);                                           \
-      pg[k] = gs_[i];                                                                          \
-      py2[k] = ys_[i];                                                                         \
-    }                                                                                          \
-    _Pragma("unroll") for (int k = 0; k < (NY_); ++k)                                          \
-      py1[k] = y1s_[min((YBASE_) + rtid + k * 256, (YEND_) - 1)];                              \
-  }
-#define RLPYT_B2_STAGE_R(gm_dst, pad_dst, NG_, NY_, YBASE_, YEND_)                             \
-  {                                                                                            \
-    _Pragma("unroll") for (int k = 0; k < (NG_); ++k) {                                        \
-      const int i = rtid + k * 256;                                                            \
-      if (i < F2 / 4) {                                                                        \
-        const int co = i / (P2 / 4), c4 = i - co * (P2 / 4);                                   \
-        f32x4 v;                                                                               \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = py2[k][e] > 0.f ? pg[k][e] : 0.f; \
-        *reinterpret_cast<f32x4*>((gm_dst) + co * GS_B + 4 * c4) = v;                          \
-      }                                                                                        \
-    }                                                                                          \
-    _Pragma("unroll") for (int k = 0; k < (NY_); ++k) {                                        \
-      const int i = (YBASE_) + rtid + k * 256;                                                 \
-      if (i < (YEND_)) {                                                                       \
-        const int p = i >> 2, c4 = i & 3;                                                      \
-        const int iy = p / W1, ix = p - iy * W1;                                               \
-        float* d = (pad_dst) + ((iy + 1) * PW + ix + 1) * PS_W + 4 * c4;                       \
-        d[0] = py1[k][0]; d[1] = py1[k][1]; d[2] = py1[k][2]; d[3] = py1[k][3];                \
-      }                                                                                        \
-    }                                                                                          \
-  }
-#define RLPYT_B2_PREFETCH_D(mi) RLPYT_B2_PREFETCH_R(mi, 0, 5, 0, B2_YSPLIT)
-#define RLPYT_B2_STAGE_D(g_, p_) RLPYT_B2_STAGE_R(g_, p_, 0, 5, 0, B2_YSPLIT)
-#define RLPYT_B2_PREFETCH_W(mi) RLPYT_B2_PREFETCH_R(mi, 4, 3, B2_YSPLIT, Y1 / 4)
-#define RLPYT_B2_STAGE_W(g_, p_) RLPYT_B2_STAGE_R(g_, p_, 4, 3, B2_YSPLIT, Y1 / 4)
-  __syncthreads();                                   // zero fill done
-  if ((int64_t)blockIdx.x < M) {
-    if (wave < 4) {
-      RLPYT_B2_PREFETCH_D((int64_t)blockIdx.x)
-      RLPYT_B2_STAGE_D(gm_, pad_)
-    } else {
-      RLPYT_B2_PREFETCH_W((int64_t)blockIdx.x)
-      RLPYT_B2_STAGE_W(gm_, pad_)
-    }
-  }
-  __syncthreads();
-
-  if (wave < 4) {
-    // =========================== dgrad role: parity class q ================================
-    // tiles 0..6 of the class (staging before the last 2); its 8th / 9th tile belongs to a wgrad wave
-    const int py = q >> 1, px = q & 1;
-    float wd[32];
-#pragma unroll
-    for (int dd = 0; dd < 4; ++dd)
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {
-          const int co = sg * 16 + 4 * kq + sp;
-          const int ky = 1 - py + 2 * (dd >> 1), kx = 1 - px + 2 * (dd & 1);
-          wd[(dd * 2 + sg) * 4 + sp] = w2[co * 256 + j * 16 + ky * 4 + kx];
-        }
-    // consume the weights once here: hipcc then waits for their loads BEFORE the image loop.
-    // Otherwise "a VGPR loaded outside the loop is used inside a loop that stores" makes it drain
-    // vmcnt in the tile loop's preheader on every image -- i.e. wait for the just-issued prefetch.
-#pragma unroll
-    for (int i = 0; i < 32; ++i) asm volatile("" ::"v"(wd[i]));
-    // per-lane view of the tile table: entry (q, p = 16 tile + j), plus this lane's k-slot terms
-    const int4* tab = reinterpret_cast<const int4*>(dtab_) + (q * B2_TABP + j) * 2;
-    const int kq_gm = 4 * kq * GS_B, kq4 = 4 * kq;
-    int cur = 0;
-    RL_T0()
-    for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
-      const bool more = m + gridDim.x < M;
-      if (more) RLPYT_B2_PREFETCH_D(m + gridDim.x)  // (the wgrad waves issue theirs 2 groups later)
-      RL_T(0)
-      const float* gm = gm_ + cur * B2_GM + kq_gm;
-      const float* pad = pad_ + cur * B2_PAD + kq4;
-      float* dyimg = dy1 + m * Y1 + kq4;
-#define RLPYT_B2_DLOAD(dst_, off_)                                                             \
-  _Pragma("unroll") for (int e = 0; e < 8; ++e) dst_[e] = gm[(off_) + ((e >> 2) * 16 + (e & 3)) * GS_B];
-      // software pipeline over tiles: [table entry of tile t+1] and [B operands one tap ahead] are
-      // requested before the MFMAs that hide them; the epilogue of tile t-1 (mask + 16-byte store)
-      // runs inside tile t's MFMA stream.  The body is branch-free (padding lanes repeat the class's
-      // last pixel and store the same value to the same address) so hipcc schedules it as one block.
-      int4 t0 = tab[0], t1 = tab[1];               // tile 0: {off[4]}, {yoff, pixoff, -, -}
-      int4 n0 = tab[32], n1 = tab[33];             // tile 1
-      // B operands run TWO taps (16 MFMAs) ahead of their use: with 8 waves on the LDS a read takes
-      // longer than the 8 MFMAs of one tap (one tap ahead measured 1600 cycles per tile for a wave
-      // alone on its SIMD, against 1024 of matrix-pipe time)
-      float b0[8], b1[8], b2[8];
-      RLPYT_B2_DLOAD(b0, t0.x)
-      RLPYT_B2_DLOAD(b1, t0.y)
-      f32x4 a0p = {0.f, 0.f, 0.f, 0.f}, a1p = {0.f, 0.f, 0.f, 0.f}, yvp = {0.f, 0.f, 0.f, 0.f};
-      int pixp = t1.y;                             // (first deferred epilogue: zeros, rewritten by tile 0's)
-// one tap = 8 MFMAs + the 8 operand reads of the tap after next, INTERLEAVED one by one
-// (sched_group_barrier: MFMA, DS read, 2 VALU, ...): a wave that issues its LDS / VALU work in a
-// block between MFMA blocks leaves the pipe to its SIMD partner for that long, and the two waves'
-// blocks coincide often enough to idle the pipe ~20 % of the time (measured)
-#define RLPYT_B2_TAP(dd_, cur_, nxt_, off_)                                                    \
-  RLPYT_B2_DLOAD(nxt_, off_)                                                                   \
-  _Pragma("unroll") for (int sp = 0; sp < 4; ++sp) {                                           \
-    a0 = mfma16(wd[((dd_) * 2 + 0) * 4 + sp], cur_[sp], a0);                                   \
-    a1 = mfma16(wd[((dd_) * 2 + 1) * 4 + sp], cur_[4 + sp], a1);                               \
-  }                                                                                            \
-  _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                           \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA    */                       \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* 1 DS read */                       \
-    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   /* 3 VALU    */                       \
-  }
-      // three tiles per trip so that the three operand buffers rotate by name (b0 b1 b2): 12 taps
-      auto dgrad_tile = [&](float (&c0)[8], float (&c1)[8], float (&c2)[8], int tile) __attribute__((always_inline)) {
-        // on entry: c0 = tap 0, c1 = tap 1 of this tile (requested earlier); c2 free
-        const int4 m0 = tab[(tile + 2) * 32], m1 = tab[(tile + 2) * 32 + 1];   // entry of tile + 2
-        f32x4 yv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) yv[r] = pad[t1.x + r];
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        RLPYT_B2_TAP(0, c0, c2, t0.z)              // request tap 2 -> c2
-        {                                          // deferred epilogue of the previous tile
-          f32x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = yvp[r] > 0.f ? a0p[r] + a1p[r] : 0.f;
-          *reinterpret_cast<f32x4*>(dyimg + pixp) = o;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        RLPYT_B2_TAP(1, c1, c0, t0.w)              // request tap 3 -> c0
-        __builtin_amdgcn_sched_barrier(0);
-        RLPYT_B2_TAP(2, c2, c1, n0.x)              // request next tile's tap 0 -> c1
-        __builtin_amdgcn_sched_barrier(0);
-        RLPYT_B2_TAP(3, c0, c2, n0.y)              // request next tile's tap 1 -> c2
-        __builtin_amdgcn_sched_barrier(0);
-        a0p = a0; a1p = a1; yvp = yv; pixp = t1.y;
-        t0 = n0; t1 = n1; n0 = m0; n1 = m1;
-        // on exit: next tile's tap 0 in c1, tap 1 in c2; c0 free
-      };
-      // (two loops with the staging BETWEEN them: a loop that consumed the prefetched registers
-      //  would make hipcc drain vmcnt in its preheader, i.e. wait for HBM before the first MFMA)
-      // 7 tiles; the buffer roles rotate (c0 c1 c2) -> (c1 c2 c0) per tile
-      dgrad_tile(b0, b1, b2, 0);
-      dgrad_tile(b1, b2, b0, 1);
-      dgrad_tile(b2, b0, b1, 2);
-      dgrad_tile(b0, b1, b2, 3);
-      dgrad_tile(b1, b2, b0, 4);
-      RL_T(1)
-      if (more)                                   // registers -> the other buffer, mid-stream
-        RLPYT_B2_STAGE_D(gm_ + (cur ^ 1) * B2_GM, pad_ + (cur ^ 1) * B2_PAD)
-      RL_T(2)
-      dgrad_tile(b2, b0, b1, 5);
-      dgrad_tile(b0, b1, b2, 6);
-#undef RLPYT_B2_TAP
-      {                                           // epilogue of the last tile
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = yvp[r] > 0.f ? a0p[r] + a1p[r] : 0.f;
-        *reinterpret_cast<f32x4*>(dyimg + pixp) = o;
-      }
-      RL_T(3)
-#undef RLPYT_B2_DLOAD
-      __syncthreads();   // every wave is done with buffer `cur` and has filled the other one
-      RL_T(4)
-    }
-    RL_TOUT()
-    return;
-  }
-  // ============================ wgrad role: ky = q =========================================
-  // K = positions: groups sg of 16, read as two half-groups of 8 (2 positions per MFMA k-slot
-  // and half: pos = 16 sg + 4 kq + 2 half + h).  A = gm2 [co][pos] (float2 over pos per half);
-  // B = y1pad[(2 oy + ky, 2 ox + kx)][c = j], read one half-group (8 values -> 16 MFMAs) ahead.
-  // Each wgrad wave also owns ONE spare dgrad tile per image (the 8th / 9th tile of the parity
-  // classes with more than 7): 7 groups + 1 tile here against 7 tiles in the dgrad wave of the
-  // same SIMD.  Measured: this role is "ready" less often than the dgrad role; given a static
-  // priority it takes ~47 % of the pipe, the dgrad wave fills ~43 % (91 % busy, against 82 % with
-  // equal or per-cluster priorities), and the 8 : 7 split makes both finish together.
-#ifndef RLPYT_B2_NOPRIO
-  __builtin_amdgcn_s_setprio(1);
-#endif
-  f32x4 acc[4][2];
-  float bsum[2] = {0.f, 0.f};
-#pragma unroll
-  for (int kx = 0; kx < 4; ++kx)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) acc[kx][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int nsg = NSG2;
-  // spare tile: (class, tile) = (0, 8), (1, 7), (2, 7), (0, 7) for ky = 0..3
-  const int xq = q == 3 ? 0 : q, xtile = q == 0 ? 8 : 7;
-  float wx[32];
-  {
-    const int xpy = xq >> 1, xpx = xq & 1;
-#pragma unroll
-    for (int dd = 0; dd < 4; ++dd)
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {
-          const int co = sg * 16 + 4 * kq + sp;
-          const int ky = 1 - xpy + 2 * (dd >> 1), kx = 1 - xpx + 2 * (dd & 1);
-          wx[(dd * 2 + sg) * 4 + sp] = w2[co * 256 + j * 16 + ky * 4 + kx];
-        }
-#pragma unroll
-    for (int i = 0; i < 32; ++i) asm volatile("" ::"v"(wx[i]));   // (loads complete before the loop)
-  }
-  const int4* xtab = reinterpret_cast<const int4*>(dtab_) + (xq * B2_TABP + xtile * 16 + j) * 2;
-  const int2* wt = reinterpret_cast<const int2*>(wtab_) + 2 * kq;
-  const int xkq_gm = 4 * kq * GS_B, xkq4 = 4 * kq;
-  {
-    int cur = 0;
-    RL_T0()
-    for (int64_t m = blockIdx.x; m < M; m += gridDim.x, cur ^= 1) {
-      const bool more = m + gridDim.x < M;
-      RL_T(0)
-      const float* gm = gm_ + cur * B2_GM;
-      const float* pad = pad_ + cur * B2_PAD;
-      {   // ---- the spare dgrad tile (same contraction as dgrad_tile above, not pipelined) -------
-        const int4 e0 = xtab[0], e1 = xtab[1];
-        const float* gx = gm + xkq_gm;
-        f32x4 yv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) yv[r] = pad[e1.x + xkq4 + r];
-        const int offs[4] = {e0.x, e0.y, e0.z, e0.w};
-        float xc[8], xn[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xc[e] = gx[offs[0] + ((e >> 2) * 16 + (e & 3)) * GS_B];
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-          if (dd < 3) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xn[e] = gx[offs[dd + 1] + ((e >> 2) * 16 + (e & 3)) * GS_B];
-          }
-          __builtin_amdgcn_sched_barrier(0x6);
-#pragma unroll
-          for (int sp = 0; sp < 4; ++sp) {
-            a0 = mfma16(wx[(dd * 2 + 0) * 4 + sp], xc[sp], a0);
-            a1 = mfma16(wx[(dd * 2 + 1) * 4 + sp], xc[4 + sp], a1);
-          }
-          __builtin_amdgcn_sched_barrier(0x6);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) xc[e] = xn[e];
-        }
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = yv[r] > 0.f ? a0[r] + a1[r] : 0.f;
-        *reinterpret_cast<f32x4*>(dy1 + m * Y1 + xkq4 + e1.y) = o;
-      }
-#define RLPYT_B2_WLOAD(dst_, tw_)   /* tw_ = origins of the half-step's two positions */       \
-  _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                           \
-    const float* bp_ = padq + (h_ ? (tw_).y : (tw_).x);                                        \
-    _Pragma("unroll") for (int kx = 0; kx < 4; ++kx) dst_[h_ * 4 + kx] = bp_[kx * PS_W];       \
-  }
-#define RLPYT_B2_ALOAD(dst_, sg_, half_)                                                       \
-  _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                           \
-    const float* ap_ = gm + (ct * 16 + j) * GS_B + 16 * (sg_) + 4 * kq + 2 * (half_);          \
-    dst_[ct][0] = ap_[0];                                                                      \
-    dst_[ct][1] = ap_[1];                                                                      \
-  }
-#define RLPYT_B2_WMMA(acc_, a_, b_, h)                                                         \
-  _Pragma("unroll") for (int kx = 0; kx < 4; ++kx)                                             \
-  _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                             \
-    acc_[kx][ct] = mfma16(a_[ct][h], b_[(h) * 4 + kx], acc_[kx][ct]);
-#define RLPYT_B2_WPATTERN                                                                      \
-  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                          \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA    */                       \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* 1 DS read */                       \
-    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   /* 3 VALU    */                       \
-  }
-      float b0[8], b1[8], alo[2][2], ahi[2][2];
-      const float* padq = pad + q * PW * PS_W + j;           // row offset of ky = q, channel j
-      // origins of (group sg, half): wt[8 sg + half]; held one group ahead
-      int2 t_h1 = wt[1], t_n0 = wt[8];
-      RLPYT_B2_ALOAD(alo, 0, 0)
-      {
-        const int2 t00 = wt[0];
-        RLPYT_B2_WLOAD(b0, t00)
-      }
-      // one group = two half-steps of 16 MFMAs; the operands of the NEXT half-step are requested
-      // between the two 8-MFMA halves of the current one (after its own operands have been waited
-      // for with nothing else in flight: requesting them first made hipcc wait for lgkmcnt(0),
-      // i.e. for the loads just issued).  sched_barrier(0x6): VALU / SALU may cross, DS reads and
-      // MFMAs may not.
-      auto wgrad_group = [&](int sg) __attribute__((always_inline)) {
-        const int sgn = min(sg + 1, NSG2 - 1);    // (past the last group: re-read, unused)
-        const int sgnn = min(sg + 2, NSG2 - 1);
-        // half-step 0: 16 MFMAs on (alo, b0) with the 6 reads of half-step 1 interleaved
-        RLPYT_B2_ALOAD(ahi, sg, 1)
-        RLPYT_B2_WLOAD(b1, t_h1)
-        t_h1 = wt[8 * sgn + 1];
-        RLPYT_B2_WMMA(acc, alo, b0, 0)
-        RLPYT_B2_WMMA(acc, alo, b0, 1)
-        if (q == 1) {
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) bsum[ct] += alo[ct][0] + alo[ct][1];
-        }
-        RLPYT_B2_WPATTERN
-        __builtin_amdgcn_sched_barrier(0);
-        // half-step 1: 16 MFMAs on (ahi, b1) with the reads of the next group's half-step 0
-        RLPYT_B2_ALOAD(alo, sgn, 0)
-        RLPYT_B2_WLOAD(b0, t_n0)
-        t_n0 = wt[8 * sgnn];
-        RLPYT_B2_WMMA(acc, ahi, b1, 0)
-        RLPYT_B2_WMMA(acc, ahi, b1, 1)
-        if (q == 1) {
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) bsum[ct] += ahi[ct][0] + ahi[ct][1];
-        }
-        RLPYT_B2_WPATTERN
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      // the 64 wave-level 1 KB loads of an image, issued by all 8 waves at once, queue up in the
-      // CU's address path and the waves that lose the arbitration sit ~2.5 k cycles in the issue
-      // stage (measured): the wgrad waves therefore issue theirs two groups after the dgrad waves
-#pragma unroll 1
-      for (int sg = 0; sg < 2; ++sg) wgrad_group(sg);
-      if (more) RLPYT_B2_PREFETCH_W(m + gridDim.x)
-#pragma unroll 1
-      for (int sg = 2; sg < 5; ++sg) wgrad_group(sg);
-      RL_T(1)
-      if (more)                                   // registers -> the other buffer, mid-stream
-        RLPYT_B2_STAGE_W(gm_ + (cur ^ 1) * B2_GM, pad_ + (cur ^ 1) * B2_PAD)
-      RL_T(2)
-#pragma unroll 1
-      for (int sg = 5; sg < nsg; ++sg) wgrad_group(sg);
-      RL_T(3)
-#undef RLPYT_B2_WMMA
-#undef RLPYT_B2_WPATTERN
-#undef RLPYT_B2_ALOAD
-#undef RLPYT_B2_WLOAD
-      __syncthreads();   // every wave is done with buffer `cur` and has filled the other one
-      RL_T(4)
-    }
-    RL_TOUT()
-  }
-#undef RLPYT_B2_PREFETCH_R
-#undef RLPYT_B2_STAGE_R
-#undef RLPYT_B2_PREFETCH_D
-#undef RLPYT_B2_STAGE_D
-#undef RLPYT_B2_PREFETCH_W
-#undef RLPYT_B2_STAGE_W
-  // D[row = co_local = 4*kq + r][col = c = j] -> dW2[co][c][ky = q][kx]: one partial row per
-  // workgroup leaves for the reduction kernel
-  float* out = partial + (int64_t)blockIdx.x * PART2;
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const f32x4 v = {acc[0][ct][r], acc[1][ct][r], acc[2][ct][r], acc[3][ct][r]};
-      *reinterpret_cast<f32x4*>(out + (ct * 16 + 4 * kq + r) * 256 + j * 16 + q * 4) = v;
-    }
-  if (q == 1) {
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      float v = bsum[ct];
-      v += __shfl_xor(v, 16, kWave);
-      v += __shfl_xor(v, 32, kWave);
-      if (kq == 0) out[DW2_N + ct * 16 + j] = v;
-    }
-  }
-}
 
 constexpr int DW1_N = C1 * 256, PART1 = DW1_N + C1;  // 4096 + 16
 
@@ -1490,7 +879,8 @@ __global__ __launch_bounds__(X3_THREADS) void conv1_wgrad_kernel(
 //     26 x 20): staging is three 8-byte writes per float4, and the weight gradient's B operand
 //     B[k = position][n = (tap, channel)] -- eight consecutive positions per lane, i.e. pixels two
 //     apart with row wraps -- is two transpose reads per piece whose lanes point at the right pixels;
-//   * gm2 = g2 * (y2 > 0) is staged in both orders by the thread that owns a 2 co x 4 position block
+//   * gm2 = g2 * (y2 > 0) -- the signs come as the bit mask conv2's forward pass wrote (MASK2_W words
+//     per image), y2 itself is not read -- is staged in both orders by the thread that owns a 2 co x 4 position block
 //     of it: [co][position] (the A operand of the weight gradient, K = position contiguous) and,
 //     re-paired with v_perm, [position][co] (the data gradient's B operand, K = co contiguous).
 // Roles (waves w and w + 4 share a SIMD): waves 0-3 = dgrad.  The four parity classes of the stride-2
@@ -1521,7 +911,7 @@ __device__ __forceinline__ uint2 lds_tr16(const uint8_t* p) {
 }
 
 __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
-    const float* __restrict__ g2, const float* __restrict__ y2, const float* __restrict__ y1,
+    const float* __restrict__ g2, const uint32_t* __restrict__ mask2, const float* __restrict__ y1,
     const float* __restrict__ w2, float* __restrict__ dy1, float* __restrict__ partial, int64_t M) {
   __shared__ __attribute__((aligned(16))) uint8_t y1p[2 * 3 * X6_YPB];   // 2 x 50,016 B
   __shared__ __attribute__((aligned(16))) uint8_t g0[3 * X6_G0_PB];      // 21,504 B
@@ -1564,16 +954,19 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     const int p = i >> 2, q = i & 3, iy = p / W1, ix = p - iy * W1;
     ydst[k] = ((iy + 1) * PW + ix + 1) * 32 + q * 8;
   }
-  f32x4 pg[2], py2[2], py1[X6_NY];
+  // (the ReLU mask of conv2 arrives as the sign-bit words conv2's forward pass left: one dword per
+  // (co, 32 positions) instead of the float4 of y2 this thread used to fetch for four signs)
+  const int gmw = gpq >> 3, gms = 4 * (gpq & 7);
+  f32x4 pg[2], py1[X6_NY];
+  uint32_t pm[2];
   float bsum[2] = {0.f, 0.f};
 #define RLPYT_X6_FETCH_G(mi)                                                                   \
   {                                                                                            \
     const f32x4* __restrict__ gs_ = reinterpret_cast<const f32x4*>(g2 + (mi) * F2);            \
-    const f32x4* __restrict__ ys_ = reinterpret_cast<const f32x4*>(y2 + (mi) * F2);            \
+    const uint32_t* __restrict__ ms_ = mask2 + (mi) * MASK2_W;                                 \
     _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                            \
-      const int i = (2 * gcp + c) * (P2 / 4) + gpq;                                            \
-      pg[c] = gs_[i];                                                                          \
-      py2[c] = ys_[i];                                                                         \
+      pg[c] = gs_[(2 * gcp + c) * (P2 / 4) + gpq];                                             \
+      pm[c] = ms_[(2 * gcp + c) * 4 + gmw];                                                    \
     }                                                                                          \
   }
 // ... one request at a time: in the main loops the rows of the next images are requested BETWEEN the
@@ -1583,7 +976,7 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
 #define RLPYT_X6_LOAD_G(mi, j_)                                                                \
   {                                                                                            \
     const int i_ = (2 * gcp + ((j_) >> 1)) * (P2 / 4) + gpq;                                   \
-    if ((j_) & 1) py2[(j_) >> 1] = reinterpret_cast<const f32x4*>(y2 + (mi) * F2)[i_];         \
+    if ((j_) & 1) pm[(j_) >> 1] = mask2[(mi) * MASK2_W + (2 * gcp + ((j_) >> 1)) * 4 + gmw];   \
     else          pg[(j_) >> 1] = reinterpret_cast<const f32x4*>(g2 + (mi) * F2)[i_];          \
   }
 #define RLPYT_X6_LOAD_Y(mi, k_)                                                                \
@@ -1599,7 +992,8 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
     uint32_t p_[3][2][2];                              /* [piece][co][position pair] */        \
     _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                            \
       float v_[4];                                                                             \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = py2[c][e] > 0.f ? pg[c][e] : 0.f;  \
+      const uint32_t nib_ = pm[c] >> gms;                                                      \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = ((nib_ >> e) & 1u) ? pg[c][e] : 0.f; \
       bsum[c] += (v_[0] + v_[1]) + (v_[2] + v_[3]);                                            \
       split3_rn(v_[0], v_[1], p_[0][c][0], p_[1][c][0], p_[2][c][0]);                          \
       split3_rn(v_[2], v_[3], p_[0][c][1], p_[1][c][1], p_[2][c][1]);                          \
@@ -1971,6 +1365,23 @@ __global__ __launch_bounds__(X6_THREADS) void conv2_bwd_x6_kernel(
 #undef RLPYT_X6_LOAD_G
 }
 
+// Sign mask of y2 for the batches the f32 sampling-size forward kernel serves (the bf16x6 kernel
+// writes it from its epilogue): thread (co, word w) of image m packs positions 32 w .. 32 w + 31.
+__global__ __launch_bounds__(MASK2_W) void relu_mask_kernel(const float* __restrict__ y2,
+                                                           uint32_t* __restrict__ mask) {
+  const int64_t m = blockIdx.x;
+  const int co = threadIdx.x >> 2, w = threadIdx.x & 3;
+  const float* __restrict__ row = y2 + m * F2 + co * P2;
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int p = 32 * w + j;
+    const float v = row[min(p, P2 - 1)];          // unconditional clamped load
+    bits |= (p < P2 && v > 0.f) ? (1u << j) : 0u;
+  }
+  mask[m * MASK2_W + threadIdx.x] = bits;
+}
+
 // out[e] = sum_g partial[g][e]; e < n.  Fixed order -> run-to-run deterministic.
 // 64 elements per workgroup, the G partials split over 16 waves with 4 independent 256-byte row
 // loads in flight each (4 waves x 2 in flight measured 11.5 us for 256 rows: a chain of 32
@@ -2208,18 +1619,23 @@ extern "C" int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat
 }
 
 extern "C" int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float* w2,
-                                         const float* b2, float* y2, rlpyt_stream_t stream) {
+                                         const float* b2, float* y2, uint32_t* relu_mask,
+                                         rlpyt_stream_t stream) {
   RL_CHECK_ARG(M >= 0, RLPYT_EINVAL, "rlpyt_atari_conv2_fwd_f32: bad sizes");
   if (M == 0) return RLPYT_OK;
-  RL_CHECK_ARG(y1 && w2 && b2 && y2, RLPYT_EINVAL, "rlpyt_atari_conv2_fwd_f32: null pointer");
-  RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(w2), RLPYT_ESHAPE,
-               "rlpyt_atari_conv2_fwd_f32: y1 / w2 must be 16-byte aligned");
-  if (M <= grid_for(1 << 30, 1))   // small (sampling) batch: two workgroups per image
-    RL_LAUNCH((conv2_fwd_kernel<2>), dim3(grid_for(2 * M, 3)), dim3(256), 0,
-                       (hipStream_t)stream, y1, w2, b2, y2, M);
-  else   // 116 KB of LDS, 8 waves: one workgroup per CU
-    RL_LAUNCH(conv2_fwd_x6_kernel, dim3(grid_for(M, 1)), dim3(C2X_THREADS), 0, (hipStream_t)stream,
-              y1, w2, b2, y2, M);
+  RL_CHECK_ARG(y1 && w2 && b2 && y2 && relu_mask, RLPYT_EINVAL,
+               "rlpyt_atari_conv2_fwd_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(w2) && RL_ALIGNED16(y2) && RL_ALIGNED16(relu_mask),
+               RLPYT_ESHAPE, "rlpyt_atari_conv2_fwd_f32: y1 / w2 / y2 / relu_mask must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= grid_for(1 << 30, 1)) {   // small (sampling) batch: two workgroups per image
+    RL_LAUNCH((conv2_fwd_kernel<2>), dim3(grid_for(2 * M, 3)), dim3(256), 0, s, y1, w2, b2, y2, M);
+    RL_LAUNCH_CHECK();
+    RL_LAUNCH(relu_mask_kernel, dim3((unsigned)M), dim3(MASK2_W), 0, s, y2, relu_mask);
+  } else {   // 116 KB of LDS, 8 waves: one workgroup per CU; the sign mask leaves with the epilogue
+    RL_LAUNCH(conv2_fwd_x6_kernel, dim3(grid_for(M, 1)), dim3(C2X_THREADS), 0, s, y1, w2, b2, y2,
+              relu_mask, M);
+  }
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }
@@ -2259,19 +1675,6 @@ extern "C" int rlpyt_atari_sample_convs_to_f32(
   return RLPYT_OK;
 }
 
-extern "C" int rlpyt_atari_conv2_dgrad_f32(const float* g2, const float* y2, const float* y1,
-                                           int64_t M, const float* w2, float* dy1,
-                                           rlpyt_stream_t stream) {
-  RL_CHECK_ARG(M >= 0, RLPYT_EINVAL, "rlpyt_atari_conv2_dgrad_f32: bad sizes");
-  if (M == 0) return RLPYT_OK;
-  RL_CHECK_ARG(g2 && y2 && y1 && w2 && dy1, RLPYT_EINVAL, "rlpyt_atari_conv2_dgrad_f32: null pointer");
-  RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(dy1), RLPYT_ESHAPE,
-               "rlpyt_atari_conv2_dgrad_f32: y1 / dy1 must be 16-byte aligned");
-  RL_LAUNCH(conv2_dgrad_kernel, dim3(grid_for(M, 6)), dim3(256), 0, (hipStream_t)stream,
-                     g2, y2, y1, w2, dy1, M);
-  RL_LAUNCH_CHECK();
-  return RLPYT_OK;
-}
 
 #ifdef RLPYT_TIMING
 extern "C" int rlpyt_debug_timing_read(float* host, int n) {
@@ -2283,22 +1686,6 @@ extern "C" int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void) {
   return (int64_t)kPartialRows * (PART1 > PART2 ? PART1 : PART2) * (int64_t)sizeof(float);
 }
 
-extern "C" int rlpyt_atari_conv2_wgrad_f32(const float* g2, const float* y2, const float* y1,
-                                           int64_t M, float* workspace, float* dw2, float* db2,
-                                           rlpyt_stream_t stream) {
-  RL_CHECK_ARG(M > 0, RLPYT_EINVAL, "rlpyt_atari_conv2_wgrad_f32: bad sizes");
-  RL_CHECK_ARG(g2 && y2 && y1 && workspace && dw2 && db2, RLPYT_EINVAL,
-               "rlpyt_atari_conv2_wgrad_f32: null pointer");
-  RL_CHECK_ARG(RL_ALIGNED16(y1), RLPYT_ESHAPE, "rlpyt_atari_conv2_wgrad_f32: y1 must be 16-byte aligned");
-  hipStream_t s = (hipStream_t)stream;
-  const int g = (int)std::min<int64_t>(M, kWgradGrid);
-  RL_LAUNCH(conv2_wgrad_kernel, dim3(g), dim3(256), 0, s, g2, y2, y1, workspace, M);
-  RL_LAUNCH_CHECK();
-  RL_LAUNCH(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(1024), 0, s, workspace,
-                     g, PART2, dw2, DW2_N, db2);
-  RL_LAUNCH_CHECK();
-  return RLPYT_OK;
-}
 
 extern "C" int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* flat_idx, int T,
                                            int64_t B, int64_t M, const float* dy1, float scale,
@@ -2320,20 +1707,20 @@ extern "C" int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* fl
   return RLPYT_OK;
 }
 
-extern "C" int rlpyt_atari_conv2_bwd_x6_f32(const float* g2, const float* y2, const float* y1,
-                                            int64_t M, const float* w2, float* dy1,
+extern "C" int rlpyt_atari_conv2_bwd_x6_f32(const float* g2, const uint32_t* relu_mask,
+                                            const float* y1, int64_t M, const float* w2, float* dy1,
                                             float* workspace, float* dw2, float* db2,
                                             rlpyt_stream_t stream) {
   RL_CHECK_ARG(M > 0, RLPYT_EINVAL, "rlpyt_atari_conv2_bwd_x6_f32: bad sizes");
-  RL_CHECK_ARG(g2 && y2 && y1 && w2 && dy1 && workspace && dw2 && db2, RLPYT_EINVAL,
+  RL_CHECK_ARG(g2 && relu_mask && y1 && w2 && dy1 && workspace && dw2 && db2, RLPYT_EINVAL,
                "rlpyt_atari_conv2_bwd_x6_f32: null pointer");
-  RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(dy1) && RL_ALIGNED16(g2) && RL_ALIGNED16(y2) &&
+  RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(dy1) && RL_ALIGNED16(g2) && RL_ALIGNED16(relu_mask) &&
                    RL_ALIGNED16(workspace),
-               RLPYT_ESHAPE, "rlpyt_atari_conv2_bwd_x6_f32: g2 / y2 / y1 / dy1 / workspace must be "
-                             "16-byte aligned");
+               RLPYT_ESHAPE, "rlpyt_atari_conv2_bwd_x6_f32: g2 / relu_mask / y1 / dy1 / workspace must "
+                             "be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const int g = std::min(grid_for(M, 1), kPartialRows);   // one persistent workgroup per CU
-  RL_LAUNCH(conv2_bwd_x6_kernel, dim3(g), dim3(X6_THREADS), 0, s, g2, y2, y1, w2, dy1, workspace, M);
+  RL_LAUNCH(conv2_bwd_x6_kernel, dim3(g), dim3(X6_THREADS), 0, s, g2, relu_mask, y1, w2, dy1, workspace, M);
   RL_LAUNCH_CHECK();
   RL_LAUNCH(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(1024), 0, s, workspace,
                      g, PART2, dw2, DW2_N, db2);
@@ -2341,25 +1728,3 @@ extern "C" int rlpyt_atari_conv2_bwd_x6_f32(const float* g2, const float* y2, co
   return RLPYT_OK;
 }
 
-extern "C" int rlpyt_atari_conv2_bwd_f32(const float* g2, const float* y2, const float* y1,
-                                         int64_t M, const float* w2, float* dy1,
-                                         float* workspace, float* dw2, float* db2,
-                                         rlpyt_stream_t stream) {
-  RL_CHECK_ARG(M > 0, RLPYT_EINVAL, "rlpyt_atari_conv2_bwd_f32: bad sizes");
-  RL_CHECK_ARG(g2 && y2 && y1 && w2 && dy1 && workspace && dw2 && db2, RLPYT_EINVAL,
-               "rlpyt_atari_conv2_bwd_f32: null pointer");
-  RL_CHECK_ARG(RL_ALIGNED16(y1) && RL_ALIGNED16(dy1) && RL_ALIGNED16(g2) && RL_ALIGNED16(y2) &&
-                   RL_ALIGNED16(workspace),
-               RLPYT_ESHAPE, "rlpyt_atari_conv2_bwd_f32: g2 / y2 / y1 / dy1 / workspace must be "
-                             "16-byte aligned");
-  hipStream_t s = (hipStream_t)stream;
-  // one persistent 8-wave workgroup per CU (107 KB of LDS each); <= kPartialRows partial rows
-  const int g = std::min(grid_for(M, 1), kPartialRows);
-  RL_LAUNCH(conv2_bwd_kernel, dim3(g), dim3(B2_THREADS), 0, s, g2, y2, y1, w2, dy1,
-                     workspace, M);
-  RL_LAUNCH_CHECK();
-  RL_LAUNCH(reduce_partials_kernel, dim3((PART2 + 63) / 64), dim3(1024), 0, s, workspace,
-                     g, PART2, dw2, DW2_N, db2);
-  RL_LAUNCH_CHECK();
-  return RLPYT_OK;
-}

@@ -2,8 +2,9 @@
 // ActionServer.serve_actions (rlpyt/samplers/parallel/gpu/action_server.py:17-74) once the
 // per-step device work is a captured hipGraph.  Per step and pipeline group it waits for the
 // env workers (futex sequence word), enqueues the H2D copies of the page-locked step buffer,
-// launches the group's graph, enqueues the D2H copy of the actions and records an event;
-// when the event has fired it publishes the actions to the workers.
+// launches the group's graph, enqueues the D2H copy of the actions (none when the head kernel
+// writes them in place) and a completion marker -- a stream write of a page-locked word, or an
+// event; when the marker is seen it publishes the actions to the workers.
 // Running this loop in C removes ~20 interpreter-level calls per group-step from the critical
 // path (the device work of a step is ~100 us, so they were of the same order).
 #include <hip/hip_runtime.h>
@@ -61,7 +62,14 @@ int issue_group_step(rlpyt_step_group& g, int t) {
   for (int i = 0; i < g.n_d2h; ++i)
     RL_HIP(hipMemcpyAsync(g.d2h[i].dst, g.d2h[i].src, (size_t)g.d2h[i].nbytes,
                           hipMemcpyDeviceToHost, s));
-  RL_HIP(hipEventRecord((hipEvent_t)g.event, s));
+  if (g.done_word != nullptr) {
+    // completion marker written by the command processor behind the graph (and the D2H copies):
+    // the retiring thread polls plain memory -- no event record here, no hipEventQuery there
+    g.done_seq += 1;
+    RL_HIP(hipStreamWriteValue32(s, g.done_word_dev, g.done_seq, 0));
+  } else {
+    RL_HIP(hipEventRecord((hipEvent_t)g.event, s));
+  }
   return RLPYT_OK;
 }
 }  // namespace
@@ -118,15 +126,23 @@ void retire_loop(ServeShared* sh) {
     for (int gi = 0; gi < sh->n_groups; ++gi) {
       if (sh->state[gi].load(std::memory_order_acquire) != WAIT_DEV) continue;
       rlpyt_step_group& g = sh->groups[gi];
-      const hipError_t q = hipEventQuery((hipEvent_t)g.event);
-      if (q == hipErrorNotReady) {
-        in_flight = true;
-        continue;
-      }
-      if (q != hipSuccess) {
-        rlpyt::set_error("rlpyt_sampler_serve: hipEventQuery: %s", hipGetErrorString(q));
-        sh->error.store(RLPYT_EHIP);
-        return;
+      if (g.done_word != nullptr) {
+        // (the WAIT_DEV state was published with release after done_seq was bumped)
+        if (__atomic_load_n(g.done_word, __ATOMIC_ACQUIRE) != g.done_seq) {
+          in_flight = true;
+          continue;
+        }
+      } else {
+        const hipError_t q = hipEventQuery((hipEvent_t)g.event);
+        if (q == hipErrorNotReady) {
+          in_flight = true;
+          continue;
+        }
+        if (q != hipSuccess) {
+          rlpyt::set_error("rlpyt_sampler_serve: hipEventQuery: %s", hipGetErrorString(q));
+          sh->error.store(RLPYT_EHIP);
+          return;
+        }
       }
       const double t_seen = now_s();
       g.acts += 1;
@@ -246,161 +262,6 @@ extern "C" int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t
     timing[4] += sh.lat_device;
     timing[5] += sh.lat_post;
     timing[6] += (double)sh.n_steps;
-  }
-  return rc_out;
-}
-
-// --------------------------------------------------------------------------------------
-// Enqueue-ahead serve loop (round 4).  Measured on the bench box (profiles/r4_rollout_chain_spin.jsonl,
-// r4_waitvalue_probe.txt): with the loop above a group-step's hand-off chain is ~95 us -- 14 us of
-// HIP calls after the workers arrived, ~35 us until a 533 KB DMA + the launch behind it have
-// started and finished, ~30 us of kernels, event poll, post, wake -- against the ~57 us of other
-// groups' env stepping a worker has to hide it behind: the rollout was latency-bound, every worker
-// idle ~45 % of a time step.  A stream wait on the arrival counter + kernels that read the
-// page-locked step buffer themselves (rlpyt_rollout_fetch) + a stream write of the act word take
-// the host out of the chain: round trip wait -> kernel -> write 11 us instead of 22 us issue-after,
-// and the HIP calls (3 per group-step) are made ahead of time, off the critical path.
-namespace {
-struct AheadShared {
-  rlpyt_ahead_group* groups;
-  int n_groups;
-  uint32_t final_act[16];
-  std::atomic<int> stop;
-};
-
-// Turns act-word changes (written by the GPU) into futex wake-ups for sleeping workers.
-void waker_loop(AheadShared* sh) {
-  uint32_t seen[16];
-  for (int gi = 0; gi < sh->n_groups; ++gi)
-    seen[gi] = __atomic_load_n(sh->groups[gi].act_word, __ATOMIC_ACQUIRE);
-  int idle = 0;
-  while (sh->stop.load(std::memory_order_acquire) == 0) {
-    bool moved = false;
-    for (int gi = 0; gi < sh->n_groups; ++gi) {
-      const uint32_t cur = __atomic_load_n(sh->groups[gi].act_word, __ATOMIC_ACQUIRE);
-      if (cur != seen[gi]) {
-        seen[gi] = cur;
-        syscall(SYS_futex, sh->groups[gi].act_word, FUTEX_WAKE, INT_MAX, nullptr, nullptr, 0);
-        moved = true;
-      }
-    }
-    if (moved) idle = 0;
-    else if (++idle > 200000) {            // nothing for a long time: do not burn a core
-      struct timespec ts = {0, 20 * 1000};
-      nanosleep(&ts, nullptr);
-    } else {
-      __builtin_ia32_pause();
-    }
-  }
-  // final sweep: a write that landed between the last poll and the stop flag
-  for (int gi = 0; gi < sh->n_groups; ++gi)
-    syscall(SYS_futex, sh->groups[gi].act_word, FUTEX_WAKE, INT_MAX, nullptr, nullptr, 0);
-}
-}  // namespace
-
-extern "C" int rlpyt_sampler_serve_ahead(rlpyt_ahead_group* groups, int n_groups, int T,
-                                         int timeout_ms, double* timing) {
-  RL_CHECK_ARG(groups != nullptr && n_groups > 0 && n_groups <= 16 && T >= 0, RLPYT_EINVAL,
-               "rlpyt_sampler_serve_ahead: bad arguments");
-  for (int gi = 0; gi < n_groups; ++gi) {
-    const rlpyt_ahead_group& g = groups[gi];
-    RL_CHECK_ARG(g.act_word && g.obs_word && g.act_word_dev && g.obs_word_dev && g.graph_exec &&
-                     g.n_workers > 0,
-                 RLPYT_EINVAL, "rlpyt_sampler_serve_ahead: incomplete group");
-    // unsigned >= in the stream wait: stay clear of the wrap
-    RL_CHECK_ARG((uint64_t)(g.rounds + (uint32_t)T + 2u) * (uint64_t)g.n_workers < 0x7fffffffull &&
-                     (uint64_t)g.acts + (uint64_t)T + 2u < 0x7fffffffull,
-                 RLPYT_EINVAL, "rlpyt_sampler_serve_ahead: hand-off counters too close to 2^31");
-  }
-  AheadShared sh;
-  sh.groups = groups;
-  sh.n_groups = n_groups;
-  sh.stop.store(0);
-  const double t0 = now_s();
-  std::thread waker(waker_loop, &sh);
-  int rc_out = RLPYT_OK;
-  auto fail = [&](hipError_t e, const char* what) {
-    rlpyt::set_error("rlpyt_sampler_serve_ahead: %s: %s", what, hipGetErrorString(e));
-    rc_out = RLPYT_EHIP;
-  };
-  for (int t = 0; t <= T && rc_out == RLPYT_OK; ++t) {
-    for (int gi = 0; gi < n_groups && rc_out == RLPYT_OK; ++gi) {
-      rlpyt_ahead_group& g = groups[gi];
-      hipStream_t s = (hipStream_t)g.stream;
-      if (t == T && g.tail_graph_exec == nullptr) continue;
-      g.rounds += 1;
-      hipError_t e = hipStreamWaitValue32(s, g.obs_word_dev, g.rounds * (uint32_t)g.n_workers,
-                                          hipStreamWaitValueGte, 0xffffffffu);
-      if (e != hipSuccess) { fail(e, "hipStreamWaitValue32"); break; }
-      e = hipGraphLaunch((hipGraphExec_t)(t < T ? g.graph_exec : g.tail_graph_exec), s);
-      if (e != hipSuccess) { fail(e, "hipGraphLaunch"); break; }
-      if (t < T) {
-        g.acts += 1;
-        e = hipStreamWriteValue32(s, g.act_word_dev, g.acts, 0);
-        if (e != hipSuccess) { fail(e, "hipStreamWriteValue32"); break; }
-      }
-    }
-  }
-  const double t1 = now_s();
-  // completion: every stream drained (the last act word written, the tail graph finished).
-  // Polled with a watchdog instead of a blocking synchronize: if an env worker died the GPU
-  // would wait on its arrival counter forever.
-  if (rc_out == RLPYT_OK) {
-    hipEvent_t evs[16];
-    int n_ev = 0;
-    for (int gi = 0; gi < n_groups; ++gi) {
-      hipError_t e = hipEventCreateWithFlags(&evs[gi], hipEventDisableTiming);
-      if (e != hipSuccess) { fail(e, "hipEventCreate"); break; }
-      ++n_ev;
-      e = hipEventRecord(evs[gi], (hipStream_t)groups[gi].stream);
-      if (e != hipSuccess) { fail(e, "hipEventRecord"); break; }
-    }
-    double t_progress = now_s();
-    uint32_t last_sum = 0;
-    int done = 0, idle = 0;
-    bool finished[16] = {false};
-    while (rc_out == RLPYT_OK && done < n_ev) {
-      for (int gi = 0; gi < n_ev; ++gi) {
-        if (finished[gi]) continue;
-        const hipError_t q = hipEventQuery(evs[gi]);
-        if (q == hipSuccess) { finished[gi] = true; ++done; }
-        else if (q != hipErrorNotReady) { fail(q, "hipEventQuery"); break; }
-      }
-      uint32_t sum = 0;
-      for (int gi = 0; gi < n_groups; ++gi)
-        sum += __atomic_load_n(groups[gi].act_word, __ATOMIC_ACQUIRE) +
-               __atomic_load_n(groups[gi].obs_word, __ATOMIC_ACQUIRE);
-      const double t_now = now_s();
-      if (sum != last_sum) { last_sum = sum; t_progress = t_now; }
-      if (timeout_ms > 0 && (t_now - t_progress) * 1e3 > (double)timeout_ms) {
-        // release every pending stream wait so the queues drain, then report
-        for (int gi = 0; gi < n_groups; ++gi)
-          __atomic_store_n(groups[gi].obs_word, 0x7ffffff0u, __ATOMIC_RELEASE);
-        for (int gi = 0; gi < n_ev; ++gi) (void)hipEventSynchronize(evs[gi]);
-        rlpyt::set_error("rlpyt_sampler_serve_ahead: no progress for %d ms (env worker died?); "
-                         "the hand-off counters are no longer valid", timeout_ms);
-        rc_out = RLPYT_ETIMEOUT;
-        break;
-      }
-      if (++idle > 2000) {
-        struct timespec ts = {0, 20 * 1000};
-        nanosleep(&ts, nullptr);
-      } else {
-        __builtin_ia32_pause();
-      }
-    }
-    for (int gi = 0; gi < n_ev; ++gi) (void)hipEventDestroy(evs[gi]);
-  } else {
-    // a call failed mid-way: let whatever was enqueued drain (release its waits), best effort
-    for (int gi = 0; gi < n_groups; ++gi)
-      __atomic_store_n(groups[gi].obs_word, 0x7ffffff0u, __ATOMIC_RELEASE);
-    for (int gi = 0; gi < n_groups; ++gi) (void)hipStreamSynchronize((hipStream_t)groups[gi].stream);
-  }
-  sh.stop.store(1, std::memory_order_release);
-  waker.join();
-  if (timing != nullptr) {
-    timing[0] += t1 - t0;
-    timing[1] += now_s() - t1;
   }
   return rc_out;
 }

@@ -1,5 +1,5 @@
 // f32 contractions on the bf16 matrix pipe: exact three-piece bf16 splits and the MFMA wrapper shared
-// by the GEMM kernels (gemm.hip, gemm_pp.hip).  x == hi + mid + lo exactly for finite x (3 x 8
+// by the GEMM kernels (gemm.hip, gemm_tn.hip).  x == hi + mid + lo exactly for finite x (3 x 8
 // significand bits, every remainder exact in f32); products of pieces are exact in the MFMA's f32
 // accumulator (tests/test_split_arith.py pins the arithmetic on the CPU).
 #pragma once

@@ -444,137 +444,8 @@ extern "C" int rlpyt_fc_small_f32(const float* x, const float* w, const float* b
 }
 
 // --------------------------------------------------------------------------------------
-// Sampling head of the fused AtariFf step: finishes the split-K trunk (sum of partials + bias +
-// ReLU, in registers), runs the policy / value heads, softmax and the inverse-CDF draw, and
-// writes prob[t], value[t], action[t+1] of the HBM batch plus the host-bound action copy --
-// three graph nodes (trunk finish, head, row commit) in one.  One wave per row.
-namespace rlpyt {
-namespace {
-template <int KI>
-__global__ __launch_bounds__(256) void pg_sample_head_kernel(
-    const float* __restrict__ partial, int ksplit, const float* __restrict__ fc_bias,
-    const float* __restrict__ w_pi, const float* __restrict__ b_pi, const float* __restrict__ w_v,
-    const float* __restrict__ b_v, const float* __restrict__ uniforms,
-    const int64_t* __restrict__ t_dev, int64_t n, int A, float* __restrict__ prob_rows,
-    float* __restrict__ value_rows, int64_t* __restrict__ action_rows, int64_t B, int64_t lo,
-    int64_t* __restrict__ action_out) {
-  constexpr int K = 64 * KI;
-  constexpr int AMAX = 8;
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= n) return;
-  const int64_t t = *t_dev;
-  // Every load below is unconditional (indices clamped, unused values masked afterwards): with
-  // predicated loads the compiler emitted a branch and an s_waitcnt vmcnt(0) per load, i.e. ~60
-  // serialized L2 round trips (20 us for this kernel); now they are all in flight together.
-  float hv[KI];
-#pragma unroll
-  for (int i = 0; i < KI; ++i) {
-    const int k = lane + 64 * i;
-    float pv[kFcKSplit];
-#pragma unroll
-    for (int sidx = 0; sidx < kFcKSplit; ++sidx) {
-      const int ss = min(sidx, ksplit - 1);
-      pv[sidx] = partial[((int64_t)ss * n + row) * K + k];
-    }
-    // the adds keep the summation order of fc_small_finish_kernel (x + 0 is exact)
-    float v = pv[0];
-#pragma unroll
-    for (int sidx = 1; sidx < kFcKSplit; ++sidx) v += (sidx < ksplit ? pv[sidx] : 0.f);
-    hv[i] = fmaxf(v + fc_bias[k], 0.f);
-  }
-  float wp[AMAX][KI], wvv[KI];
-#pragma unroll
-  for (int i = 0; i < KI; ++i) {
-    const int k = lane + 64 * i;
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a) wp[a][i] = w_pi[min(a, A - 1) * K + k];
-    wvv[i] = w_v[k];
-  }
-  float bpi[AMAX];
-#pragma unroll
-  for (int a = 0; a < AMAX; ++a) bpi[a] = b_pi[min(a, A - 1)];
-  const float bvv = b_v[0];
-  const float u = uniforms[t * n + row];
-  float acc[AMAX + 1];
-#pragma unroll
-  for (int a = 0; a <= AMAX; ++a) acc[a] = 0.f;
-#pragma unroll
-  for (int i = 0; i < KI; ++i) {
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a) acc[a] = fmaf(hv[i], wp[a][i], acc[a]);
-    acc[AMAX] = fmaf(hv[i], wvv[i], acc[AMAX]);
-  }
-#pragma unroll
-  for (int a = 0; a <= AMAX; ++a) acc[a] = wave_sum(acc[a]);
-  if (lane == 0) {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a)
-      if (a < A) {
-        acc[a] += bpi[a];
-        mx = fmaxf(mx, acc[a]);
-      }
-    float den = 0.f;
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a)
-      if (a < A) {
-        acc[a] = expf(acc[a] - mx);
-        den += acc[a];
-      }
-    const float inv = 1.f / den;
-    float cum = 0.f;
-    int pick = -1, last_pos = 0;
-    float* __restrict__ pr = prob_rows + (t * B + lo + row) * A;
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a)
-      if (a < A) {
-        const float p = acc[a] * inv;
-        pr[a] = p;
-        cum += p;
-        if (p > 0.f) last_pos = a;
-        if (pick < 0 && cum > u) pick = a;
-      }
-    value_rows[t * B + lo + row] = acc[AMAX] + bvv;
-    const int64_t act = pick >= 0 ? pick : last_pos;
-    action_rows[(t + 1) * B + lo + row] = act;
-    action_out[row] = act;
-  }
-}
-}  // namespace
-}  // namespace rlpyt
-
-extern "C" int rlpyt_pg_sample_head_f32(const float* partial, int ksplit, const float* fc_bias,
-                                        const float* w_pi, const float* b_pi, const float* w_v,
-                                        const float* b_v, const float* uniforms,
-                                        const int64_t* t_dev, int64_t n, int K, int A,
-                                        float* prob_rows, float* value_rows, int64_t* action_rows,
-                                        int64_t B, int64_t lo, int64_t* action_out,
-                                        rlpyt_stream_t stream) {
-  RL_CHECK_ARG(partial && fc_bias && w_pi && b_pi && w_v && b_v && uniforms && t_dev && prob_rows &&
-                   value_rows && action_rows && action_out,
-               RLPYT_EINVAL, "rlpyt_pg_sample_head_f32: null pointer");
-  RL_CHECK_ARG(n > 0 && ksplit > 0 && ksplit <= rlpyt::kFcKSplit && A > 0 && A <= 8 &&
-                   (K == 512 || K == 256) && lo >= 0 && lo + n <= B,
-               RLPYT_ESHAPE, "rlpyt_pg_sample_head_f32: need 0<A<=8, K in {256,512}, lo+n<=B");
-  const dim3 grid((unsigned)ceil_div(n, 4)), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  if (K == 512)
-    RL_LAUNCH((rlpyt::pg_sample_head_kernel<8>), grid, block, 0, s, partial, ksplit, fc_bias,
-                       w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows,
-                       action_rows, B, lo, action_out);
-  else
-    RL_LAUNCH((rlpyt::pg_sample_head_kernel<4>), grid, block, 0, s, partial, ksplit, fc_bias,
-                       w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows,
-                       action_rows, B, lo, action_out);
-  RL_LAUNCH_CHECK();
-  return RLPYT_OK;
-}
-
-
-// --------------------------------------------------------------------------------------
-// Round-4 rollout chain, trunk + head (replaces fc_small_kernel<1> + pg_sample_head_kernel<8> on the
-// sampler's per-step path; those stay for M > 64 callers, the LSTM gate GEMM and A/B tests).
+// Rollout chain, trunk + head (round 4; fc_small_kernel stays for M > 64 callers and the LSTM gate
+// GEMM, its one-wave-per-row head kernel of round 3 is gone).
 //
 // Why: round 3's split (16 columns x K/8 per workgroup) made every CU ingest the x slab of its K
 // slice for ALL rows plus its W rows once per WAVE -- 56 MB of L2 -> L1 traffic per launch for
@@ -641,7 +512,7 @@ __global__ __launch_bounds__(256) void rollout_fc_kernel(const float* __restrict
 // One workgroup per row: wave w finishes the trunk for k in [w K/4, (w+1) K/4) (sum of the ksplit
 // partials in slice order, + bias, ReLU), takes its share of the 7 head dot products, the four
 // shares meet in LDS and thread 0 does softmax + inverse-CDF draw + the step's row writes (as
-// pg_sample_head_kernel).  bootstrap_out != NULL: value only, written to bootstrap_out[row] (the
+// rlpyt_categorical_head_f32).  bootstrap_out != NULL: value only, written to bootstrap_out[row] (the
 // bootstrap-value pass after the last step of a batch).
 template <int KW>   // trunk width = 256 * KW
 __global__ __launch_bounds__(256) void rollout_head_kernel(
@@ -650,14 +521,14 @@ __global__ __launch_bounds__(256) void rollout_head_kernel(
     const float* __restrict__ b_v, const float* __restrict__ uniforms,
     const int64_t* __restrict__ t_dev, int64_t n, int A, float* __restrict__ prob_rows,
     float* __restrict__ value_rows, int64_t* __restrict__ action_rows, int64_t B, int64_t lo,
-    int64_t* __restrict__ action_out, float* __restrict__ bootstrap_out,
-    int64_t* __restrict__ t_next) {
+    int64_t* __restrict__ action_out, float* __restrict__ bootstrap_out) {
   constexpr int K = 256 * KW;
   constexpr int AMAX = 8;
   __shared__ float red[4][AMAX + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = blockIdx.x;
-  // unconditional clamped loads, masked sums (see pg_sample_head_kernel)
+  // unconditional clamped loads, masked sums: predicated loads compile to a branch and an
+  // s_waitcnt vmcnt(0) EACH on gfx950 (~60 serialized L2 round trips in the first version)
   float hv[KW];
 #pragma unroll
   for (int i = 0; i < KW; ++i) hv[i] = 0.f;
@@ -743,115 +614,10 @@ __global__ __launch_bounds__(256) void rollout_head_kernel(
   const int64_t act = pick >= 0 ? pick : last_pos;
   action_rows[(t + 1) * B + lo + row] = act;
   action_out[row] = act;
-  // device-driven stepping: this launch is the last reader of t; the fetch kernel of the NEXT
-  // step (stream-ordered behind it) picks the counter up
-  if (t_next != nullptr && row == 0) *t_next = t + 1;
 }
 
-// --------------------------------------------------------------------------------------
-// First node of a device-driven step (no host call on the per-step path): pulls the step's
-// inputs out of the page-locked, fork-shared step buffer over PCIe -- what the master's
-// hipMemcpyAsync calls (newest frames + misc block, full stacks of reset envs) and its slot
-// bookkeeping did on the host (csrc/serve.cpp issue_group_step) -- so that the whole step can be
-// enqueued AHEAD of time behind a hipStreamWaitValue32 on the workers' arrival counter.
-// One workgroup per environment b:
-//   frame_stage[b] <- host frame[b]                (8320 B)
-//   reward_stage[b], done_stage[b] <- host misc    (scalars)
-//   full = host reset[b] || t == 0  (fresh stack / first step of a batch)
-//   full ? (full_rows[b] <- host observation[b] (33 KB), slot[b] = b) : slot[b] = -1
-//   t_dev <- t = *t_ctr   (workgroup 0; the step's other kernels read t_dev, the head kernel hands
-//                          t + 1 back to t_ctr)
-// The frame loads are issued before the reset flag is known (one PCIe latency, not two).
-// Loads are issued through asm so that ALL of them are in flight before the first wait: written as
-// plain C++ the compiler pairs every (predicated) load with its store and an s_waitcnt vmcnt(0) in
-// between -- five serialized PCIe round trips per workgroup, measured +45 us per group-step.
-typedef uint32_t st_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ st_u32x4 st_ld16_issue(const void* p) {
-  st_u32x4 r;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
-  return r;
-}
-__device__ __forceinline__ uint32_t st_ld1_issue(const void* p) {
-  uint32_t r;
-  asm volatile("global_load_ubyte %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
-  return r;
-}
-__device__ __forceinline__ uint32_t st_ld4_issue(const void* p) {
-  uint32_t r;
-  asm volatile("global_load_dword %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
-  return r;
-}
-__device__ __forceinline__ void st_loads_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-__global__ __launch_bounds__(256) void rollout_fetch_kernel(
-    const uint8_t* __restrict__ h_frame, const uint8_t* __restrict__ h_misc,
-    const uint8_t* __restrict__ h_obs, uint8_t* __restrict__ d_frame, uint8_t* __restrict__ d_misc,
-    uint8_t* __restrict__ full_rows, int Bg, int hw16, int row16, int t_off,
-    const int64_t* __restrict__ t_ctr) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const st_u32x4* __restrict__ src = reinterpret_cast<const st_u32x4*>(h_frame) + (int64_t)b * hw16;
-  st_u32x4* __restrict__ dst = reinterpret_cast<st_u32x4*>(d_frame) + (int64_t)b * hw16;
-  // misc layout (samplers/gpu.py): reward f32[Bg] | slot i32[Bg] | done u8[Bg] | reset u8[Bg] | .. | t
-  const uint32_t rs = st_ld1_issue(h_misc + 9 * Bg + b);
-  st_u32x4 v[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = st_ld16_issue(src + min(tid + 256 * i, hw16 - 1));  // clamped
-  const uint32_t rew = st_ld4_issue(h_misc + 4 * b);
-  const uint32_t dn = st_ld1_issue(h_misc + 8 * Bg + b);
-  const int64_t t = *t_ctr;
-  st_loads_wait();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int w = tid + 256 * i;
-    if (w < hw16) dst[w] = v[i];
-  }
-  for (int w = tid + 1024; w < hw16; w += 256) dst[w] = src[w];   // frames larger than 16 KB
-  if (tid == 0) reinterpret_cast<uint32_t*>(d_misc)[b] = rew;
-  if (tid == 1) {
-    d_misc[8 * Bg + b] = (uint8_t)dn;
-    d_misc[9 * Bg + b] = (uint8_t)rs;
-  }
-  const bool full = rs != 0 || t == 0;
-  if (tid == 2) reinterpret_cast<int32_t*>(d_misc + 4 * Bg)[b] = full ? b : -1;
-  if (b == 0 && tid == 3) *reinterpret_cast<int64_t*>(d_misc + t_off) = t;
-  if (full) {
-    const st_u32x4* __restrict__ fs = reinterpret_cast<const st_u32x4*>(h_obs) + (int64_t)b * row16;
-    st_u32x4* __restrict__ fd = reinterpret_cast<st_u32x4*>(full_rows) + (int64_t)b * row16;
-    for (int w0 = 0; w0 < row16; w0 += 256 * 9) {
-      st_u32x4 u[9];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) u[i] = st_ld16_issue(fs + min(w0 + tid + 256 * i, row16 - 1));
-      st_loads_wait();
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        const int w = w0 + tid + 256 * i;
-        if (w < row16) fd[w] = u[i];
-      }
-    }
-  }
-}
 }  // namespace
 }  // namespace rlpyt
-
-extern "C" int rlpyt_rollout_fetch(const uint8_t* host_frame, const uint8_t* host_misc,
-                                   const uint8_t* host_obs, uint8_t* dev_frame, uint8_t* dev_misc,
-                                   uint8_t* full_rows, int Bg, int64_t frame_bytes,
-                                   int64_t row_bytes, int t_off, const int64_t* t_ctr,
-                                   rlpyt_stream_t stream) {
-  RL_CHECK_ARG(host_frame && host_misc && host_obs && dev_frame && dev_misc && full_rows && t_ctr,
-               RLPYT_EINVAL, "rlpyt_rollout_fetch: null pointer");
-  RL_CHECK_ARG(Bg > 0 && frame_bytes > 0 && frame_bytes % 16 == 0 && row_bytes > 0 &&
-                   row_bytes % 16 == 0 && t_off >= 10 * Bg && t_off % 8 == 0,
-               RLPYT_ESHAPE, "rlpyt_rollout_fetch: frame / row bytes must be multiples of 16");
-  RL_CHECK_ARG(RL_ALIGNED16(host_frame) && RL_ALIGNED16(host_obs) && RL_ALIGNED16(dev_frame) &&
-                   RL_ALIGNED16(full_rows) && RL_ALIGNED16(host_misc) && RL_ALIGNED16(dev_misc),
-               RLPYT_ESHAPE, "rlpyt_rollout_fetch: buffers must be 16-byte aligned");
-  RL_LAUNCH(rlpyt::rollout_fetch_kernel, dim3((unsigned)Bg), dim3(256), 0, (hipStream_t)stream,
-            host_frame, host_misc, host_obs, dev_frame, dev_misc, full_rows, Bg,
-            (int)(frame_bytes / 16), (int)(row_bytes / 16), t_off, t_ctr);
-  RL_LAUNCH_CHECK();
-  return RLPYT_OK;
-}
 
 extern "C" int rlpyt_rollout_fc_ksplit(int K) {
   return K > 0 ? (int)rlpyt::ceil_div(K, rlpyt::kRfcKc) : 0;
@@ -885,8 +651,7 @@ extern "C" int rlpyt_rollout_head_f32(const float* partial, int ksplit, const fl
                                       const int64_t* t_dev, int64_t n, int K, int A,
                                       float* prob_rows, float* value_rows, int64_t* action_rows,
                                       int64_t B, int64_t lo, int64_t* action_out,
-                                      float* bootstrap_out, int64_t* t_next,
-                                      rlpyt_stream_t stream) {
+                                      float* bootstrap_out, rlpyt_stream_t stream) {
   RL_CHECK_ARG(partial && fc_bias && w_pi && b_pi && w_v && b_v, RLPYT_EINVAL,
                "rlpyt_rollout_head_f32: null pointer");
   RL_CHECK_ARG(bootstrap_out != nullptr ||
@@ -900,11 +665,11 @@ extern "C" int rlpyt_rollout_head_f32(const float* partial, int ksplit, const fl
   if (K == 512)
     RL_LAUNCH((rlpyt::rollout_head_kernel<2>), grid, block, 0, s, partial, ksplit, fc_bias, w_pi,
               b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows, action_rows, B, lo,
-              action_out, bootstrap_out, t_next);
+              action_out, bootstrap_out);
   else
     RL_LAUNCH((rlpyt::rollout_head_kernel<1>), grid, block, 0, s, partial, ksplit, fc_bias, w_pi,
               b_pi, w_v, b_v, uniforms, t_dev, n, A, prob_rows, value_rows, action_rows, B, lo,
-              action_out, bootstrap_out, t_next);
+              action_out, bootstrap_out);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

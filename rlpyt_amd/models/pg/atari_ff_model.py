@@ -140,7 +140,8 @@ class AtariFfModel(torch.nn.Module):
             ok = (isinstance(image, torch.Tensor) and image.is_cuda
                   and image.dtype == torch.uint8 and image.dim() == 4 and image.shape[0] <= 256)
         if not (ok and self.fused_conv and self.fused_head_loss and lin is not None
-                and lin.in_features % 16 == 0):
+                and ops.rollout_fc_ok(push.new_frame.shape[0] if push is not None else image.shape[0],
+                                      *lin.weight.shape)):
             return False
         if push is not None:
             B = push.new_frame.shape[0]
@@ -154,29 +155,14 @@ class AtariFfModel(torch.nn.Module):
         self._trunk_and_head(feat, lin, out, B)
         return True
 
-    # False (or RLPYT_ROLLOUT_V1=1): round 3's trunk / head kernels on the rollout step (A/B)
-    use_rollout_v2 = os.environ.get("RLPYT_ROLLOUT_V1", "0") != "1"
-
     def _trunk_and_head(self, feat, lin, out, B, bootstrap_out=None):
         """Split-K trunk partials + the head kernel that finishes them (see csrc/step.hip)."""
         from ... import ops
-        N, K = lin.weight.shape
-        if self.use_rollout_v2 and ops.rollout_fc_ok(B, N, K):
-            partial, ksplit = ops.rollout_fc_partials(feat, lin.weight)
-            ops.rollout_head(partial, ksplit, lin.bias, self.pi.weight, self.pi.bias,
-                             self.value.weight, self.value.bias, out.uniforms, out.t_dev, B,
-                             out.prob_rows, out.value_rows, out.action_rows, out.lo, out.action_out,
-                             bootstrap_out=bootstrap_out,
-                             t_next=None if bootstrap_out is not None else getattr(out, "t_next", None))
-            return True
-        if bootstrap_out is not None:
-            return False
-        partial, ksplit = ops.fc_small_partials(feat, lin.weight)
-        ops.pg_sample_head(partial, ksplit, lin.bias, self.pi.weight, self.pi.bias,
-                           self.value.weight, self.value.bias, out.uniforms, out.t_dev, B,
-                           out.prob_rows, out.value_rows, out.action_rows, out.lo, out.action_out)
-        if getattr(out, "t_next", None) is not None:     # (A/B path: the v1 head does not do it)
-            out.t_next.copy_(out.t_dev + 1)
+        partial, ksplit = ops.rollout_fc_partials(feat, lin.weight)
+        ops.rollout_head(partial, ksplit, lin.bias, self.pi.weight, self.pi.bias,
+                         self.value.weight, self.value.bias, out.uniforms, out.t_dev, B,
+                         out.prob_rows, out.value_rows, out.action_rows, out.lo, out.action_out,
+                         bootstrap_out=bootstrap_out)
         return True
 
     @torch.no_grad()
@@ -190,8 +176,7 @@ class AtariFfModel(torch.nn.Module):
         obs = push.obs
         ok = (obs.is_cuda and obs.dtype == torch.uint8 and obs.dim() == 5
               and tuple(obs.shape[2:]) == (4, 104, 80) and push.new_frame.shape[0] <= 256)
-        if not (ok and self.use_rollout_v2 and self.fused_conv and self.fused_head_loss
-                and lin is not None and lin.in_features % 16 == 0):
+        if not (ok and self.fused_conv and self.fused_head_loss and lin is not None):
             return False
         B = push.new_frame.shape[0]
         if not ops.rollout_fc_ok(B, *lin.weight.shape):

@@ -209,8 +209,10 @@ def ppo_loss(prob_new, value, prob_old, action, advantage, return_, valid, ratio
 class _PpoHeadLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid,
-                ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None, trunk_bias=None):
+                ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None, trunk_bias=None,
+                unit_grad=False):
         _lib.require_gpu()
+        ctx.unit_grad = bool(unit_grad)
         rc_dev = None
         if isinstance(ratio_clip, torch.Tensor):     # device scalar (captured update graphs)
             rc_dev, ratio_clip = ratio_clip, 0.
@@ -255,17 +257,20 @@ class _PpoHeadLoss(torch.autograd.Function):
     def backward(ctx, g_loss, _g_out):
         gh, gp = ctx.saved_tensors
         hs, wps, bps, wvs, bvs, A, K, tbs = ctx.meta
-        gp = gp * g_loss
+        if not ctx.unit_grad:
+            # (unit_grad: the caller runs ``loss.backward()`` on the returned loss itself, the
+            # incoming gradient is exactly 1 -- two elementwise launches over 16 MB less per update)
+            gp, gh = gp * g_loss, gh * g_loss
         o = A * K
         g_tb = None if tbs is None else gp[o + K + A + 1:].reshape(tbs)
-        return ((gh * g_loss).reshape(hs), gp[:o].reshape(wps), gp[o + K:o + K + A].reshape(bps),
+        return (gh.reshape(hs), gp[:o].reshape(wps), gp[o + K:o + K + A].reshape(bps),
                 gp[o:o + K].reshape(wvs), gp[o + K + A:o + K + A + 1].reshape(bvs)) + \
-            (None,) * 9 + (g_tb,)
+            (None,) * 9 + (g_tb, None)
 
 
 def ppo_head_loss(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid,
                   ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None,
-                  trunk_bias=None):
+                  trunk_bias=None, unit_grad=False):
     """PPO.loss (rlpyt/algos/pg/ppo.py:117-154) with the policy / value heads of
     rlpyt/models/pg/atari_ff_model.py:56-58 fused in: takes the trunk output ``h [M, K]`` and the
     head parameters, returns ``(loss, scalars)`` like ``ppo_loss``; differentiable w.r.t. ``h``
@@ -275,10 +280,12 @@ def ppo_head_loss(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_,
     With ``trunk_bias [K]``, ``h`` is the trunk's pre-activation WITHOUT its bias (``x W^T``) and
     the kernel applies ``relu(h + trunk_bias)`` itself (the op is then differentiable w.r.t. the
     pre-activation and the bias: the Linear's bias add, the ReLU, its backward and the bias
-    gradient reduction never launch)."""
+    gradient reduction never launch).
+    ``unit_grad=True``: a promise that backward is seeded with exactly 1 (``loss.backward()`` on the
+    returned loss): the gradients saved by the forward kernel are handed on as they are."""
     return _PpoHeadLoss.apply(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_,
                               valid, ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx,
-                              trunk_bias)
+                              trunk_bias, unit_grad)
 
 
 class _A2cLoss(torch.autograd.Function):
@@ -494,9 +501,7 @@ def obs_normalize(x, mean, var, var_clip=1e-6, obs_clip=10.):
 ATARI_IMG = (4, 104, 80)
 ATARI_P1, ATARI_C1, ATARI_F2 = 25 * 19, 16, 32 * 12 * 9
 # algorithmic flops per image (2 * MACs): conv1 475x256x16, conv2 108x256x32
-# conv2 backward: bf16x6 kernel (csrc/conv.hip conv2_bwd_x6_kernel) or, RLPYT_CONV2_BWD_X6=0, the
-# f32-MFMA kernel of rounds 1-2 (A/B timing)
-CONV2_BWD_X6 = os.environ.get("RLPYT_CONV2_BWD_X6", "1") != "0"
+ATARI_MASK2_WORDS = 32 * 4       # sign mask of y2: uint32 [M, 32 co, 4 words of 32 positions]
 _FL_C1, _FL_C2 = 2 * 475 * 256 * 16, 2 * 108 * 256 * 32
 _FL_C2D = 2 * 475 * 128 * 16      # transposed conv: 2x2 taps x 32 channels per input pixel
 
@@ -522,21 +527,24 @@ class _AtariConvStack(torch.autograd.Function):
         assert w1c.shape == (16, 4, 8, 8) and w2c.shape == (32, 16, 4, 4)
         y1 = torch.empty((M, ATARI_P1, ATARI_C1), dtype=torch.float32, device=obs.device)
         y2 = torch.empty((M, ATARI_F2), dtype=torch.float32, device=obs.device)
+        # sign bits of y2, written by the conv2 forward kernel beside it: all that conv2's backward
+        # pass needs of y2 (512 B instead of 13.8 KB per image on its load path)
+        mask2 = torch.empty((M, ATARI_MASK2_WORDS), dtype=torch.int32, device=obs.device)
         with ktimer.region("conv1_fwd", M * (33280 + 4 * 7600), M * _FL_C1):
             check(lib.rlpyt_atari_conv1_fwd_f32(ptr(obs), ptr(idx), T, B, M, ptr(w1c), ptr(b1c),
                                                 float(scale), ptr(y1), stream()),
                   "rlpyt_atari_conv1_fwd_f32")
-        with ktimer.region("conv2_fwd", M * 4 * (7600 + 3456), M * _FL_C2):
-            check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1), M, ptr(w2c), ptr(b2c), ptr(y2),
+        with ktimer.region("conv2_fwd", M * (4 * (7600 + 3456) + 4 * ATARI_MASK2_WORDS), M * _FL_C2):
+            check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1), M, ptr(w2c), ptr(b2c), ptr(y2), ptr(mask2),
                                                 stream()), "rlpyt_atari_conv2_fwd_f32")
         if any(ctx.needs_input_grad):
-            ctx.save_for_backward(obs, idx, w2c, y1, y2)
+            ctx.save_for_backward(obs, idx, w2c, y1, mask2)
             ctx.dims = (T, B, M, float(scale))
         return y2
 
     @staticmethod
     def backward(ctx, g2):
-        obs, idx, w2c, y1, y2 = ctx.saved_tensors
+        obs, idx, w2c, y1, mask2 = ctx.saved_tensors
         T, B, M, scale = ctx.dims
         g2 = _f32(g2)
         dev = obs.device
@@ -546,10 +554,12 @@ class _AtariConvStack(torch.autograd.Function):
         db1 = torch.empty(16, dtype=torch.float32, device=dev)
         dw2 = torch.empty((32, 16, 4, 4), dtype=torch.float32, device=dev)
         db2 = torch.empty(32, dtype=torch.float32, device=dev)
-        bwd = lib.rlpyt_atari_conv2_bwd_x6_f32 if CONV2_BWD_X6 else lib.rlpyt_atari_conv2_bwd_f32
-        with ktimer.region("conv2_bwd", M * 4 * (2 * 3456 + 2 * 7600), M * (_FL_C2D + _FL_C2)):
-            check(bwd(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2c), ptr(dy1), ptr(ws), ptr(dw2), ptr(db2),
-                      stream()), "rlpyt_atari_conv2_bwd_f32")
+        # g2 + mask + y1 in, dy1 out (the kernel: bf16x6, dgrad + both ReLU masks + wgrad fused)
+        with ktimer.region("conv2_bwd", M * (4 * (3456 + 2 * 7600) + 4 * ATARI_MASK2_WORDS),
+                           M * (_FL_C2D + _FL_C2)):
+            check(lib.rlpyt_atari_conv2_bwd_x6_f32(ptr(g2), ptr(mask2), ptr(y1), M, ptr(w2c), ptr(dy1),
+                                                   ptr(ws), ptr(dw2), ptr(db2), stream()),
+                  "rlpyt_atari_conv2_bwd_x6_f32")
         with ktimer.region("conv1_wgrad", M * (33280 + 4 * 7600), M * _FL_C1):
             check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs), ptr(idx), T, B, M, ptr(dy1), scale,
                                                   ptr(ws), ptr(dw1), ptr(db1), stream()),
@@ -644,48 +654,27 @@ def fc_small(x, weight, bias=None, relu=True):
 
 
 # Which kernel serves which trunk GEMM (M = 8192, gemm_bench on the MI355X, profiles/r3_gemm_*):
-#   forward   x W^T : lock-step NT kernel (csrc/gemm.hip) 156-163 us; the producer / consumer
-#                     kernel body of csrc/gemm_pp.hip 196-233 us (RLPYT_GEMM_PP=1 selects it: A/B);
-#   dgrad     g W   : lock-step NT kernel on a transposed copy of W, 195-200 (+12 for the copy)
-#                     against 228-240 for gemm_nn reading W as stored (RLPYT_GEMM_NN=1 selects it);
-#   wgrad     g^T x : gemm_tn 223-240 against 265-274 for the library GEMM it replaces.
+#   forward   x W^T : lock-step NT kernel (csrc/gemm.hip) 156-163 us (a producer / consumer-wave
+#                     body measured 196-233 us and was removed in round 5);
+#   dgrad     g W   : the same kernel on a transposed copy of W, 195-200 (+12 for the copy; a kernel
+#                     reading W as stored measured 228-240 and was removed);
+#   wgrad     g^T x : gemm_tn (csrc/gemm_tn.hip) 223-240 against 265-274 for the library GEMM.
 # (On gfx950 VALU and MFMA instructions of one SIMD do not overlap, whichever wave issues them, so a
 # bf16x6 GEMM that splits its operands in-kernel is bounded by matrix-pipe + split-VALU time, ~2200
 # cycles per 128 x 128 x 32 step; the lock-step kernel sits within 10 % of that.)
-GEMM_NT_PINGPONG = os.environ.get("RLPYT_GEMM_PP", "0") != "0"
-GEMM_DGRAD_NN = os.environ.get("RLPYT_GEMM_NN", "0") != "0"
-
-
-def gemm_nt(a, b, pingpong=None, region="gemm_nt"):
+def gemm_nt(a, b, region="gemm_nt"):
     """``a @ b.T`` for f32 ``a [M, K]``, ``b [N, K]`` (K a multiple of 32) on the bf16 matrix pipe
     from exact three-piece bf16 splits of both operands (six products, f32 accumulation, dropped
     terms <= 2^-24 |ab|, 2^-27 rms -- f32-level error, 2.7x less matrix-pipe time than an f32-MFMA
-    GEMM).  ``rlpyt_gemm_nt_pp_f32`` (ping-pong schedule) or ``rlpyt_gemm_nt_f32`` (lock-step)."""
+    GEMM): ``rlpyt_gemm_nt_f32`` (lock-step kernel, csrc/gemm.hip)."""
     _lib.require_gpu()
     a, b = _f32(a), _f32(b)
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    pp = GEMM_NT_PINGPONG if pingpong is None else pingpong
-    fn = lib.rlpyt_gemm_nt_pp_f32 if pp else lib.rlpyt_gemm_nt_f32
     with ktimer.region(region, 4 * (M * K + N * K + M * N), 2 * M * N * K):
-        check(fn(ptr(a), ptr(b), ptr(c), M, N, K, stream()), "rlpyt_gemm_nt_f32")
-    return c
-
-
-def gemm_nn(a, b):
-    """``a @ b`` for f32 ``a [M, K]``, ``b [K, N]`` (K a multiple of 32, N of 4), same arithmetic as
-    ``gemm_nt``; ``b`` is read as stored (the kernel transposes while staging): the input gradient
-    ``g W`` of a Linear without a transposed copy of ``W`` (``rlpyt_gemm_nn_f32``)."""
-    _lib.require_gpu()
-    a, b = _f32(a), _f32(b)
-    M, K = a.shape
-    N = b.shape[1]
-    assert b.shape[0] == K
-    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    with ktimer.region("gemm_nn", 4 * (M * K + N * K + M * N), 2 * M * N * K):
-        check(lib.rlpyt_gemm_nn_f32(ptr(a), ptr(b), ptr(c), M, N, K, stream()), "rlpyt_gemm_nn_f32")
+        check(lib.rlpyt_gemm_nt_f32(ptr(a), ptr(b), ptr(c), M, N, K, stream()), "rlpyt_gemm_nt_f32")
     return c
 
 
@@ -711,8 +700,8 @@ def gemm_tn(a, b):
 class _LinearNoBias(torch.autograd.Function):
     """``x @ W.T`` (torch.nn.functional.linear without bias) for the update-size trunk, all three
     GEMMs of forward + backward on the bf16 matrix pipe (rlpyt/models/mlp.py:24-31 under
-    autograd): forward ``gemm_nt(x, W)``, input gradient ``gemm_nt(g, W^T copy)`` (or
-    ``gemm_nn(g, W)``, see the table above), weight gradient ``gemm_tn(g, x)``.  No vendor GEMM."""
+    autograd): forward ``gemm_nt(x, W)``, input gradient ``gemm_nt(g, W^T copy)``, weight gradient
+    ``gemm_tn(g, x)``.  No vendor GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -725,11 +714,8 @@ class _LinearNoBias(torch.autograd.Function):
         g = g.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            if GEMM_DGRAD_NN:
-                gx = gemm_nn(g, weight.detach())
-            else:       # g W as g (W^T)^T on the faster lock-step kernel; 7 MB transposed copy
-                gx = gemm_nt(g, weight.detach().t().contiguous(), pingpong=False,
-                             region="gemm_nt_dgrad")
+            # g W as g (W^T)^T on the same kernel; 7 MB transposed copy
+            gx = gemm_nt(g, weight.detach().t().contiguous(), region="gemm_nt_dgrad")
         if ctx.needs_input_grad[1]:
             gw = gemm_tn(g, x)
         return gx, gw
@@ -838,25 +824,6 @@ class LstmStep:
         return h1, c1
 
 
-def pg_sample_head(partial, ksplit, fc_bias, w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, prob_rows,
-                   value_rows, action_rows, lo, action_out):
-    """Trunk finish + heads + softmax + draw + the step's row writes in one launch
-    (``rlpyt_pg_sample_head_f32``): writes ``prob_rows[t, lo:lo+n]``, ``value_rows[t, lo:lo+n]``,
-    ``action_rows[t+1, lo:lo+n]`` and ``action_out[:n]`` with ``t = *t_dev``."""
-    _lib.require_gpu()
-    A, K = w_pi.shape
-    B = prob_rows.shape[1]
-    assert prob_rows.is_contiguous() and value_rows.is_contiguous() and action_rows.is_contiguous()
-    assert action_rows.dtype == torch.int64 and action_out.dtype == torch.int64
-    assert uniforms.shape[-1] == n and uniforms.is_contiguous()
-    check(lib.rlpyt_pg_sample_head_f32(
-        ptr(partial), int(ksplit), ptr(_f32(fc_bias.detach())), ptr(_f32(w_pi.detach())),
-        ptr(_f32(b_pi.detach())), ptr(_f32(w_v.detach()).reshape(-1)),
-        ptr(_f32(b_v.detach()).reshape(-1)), ptr(uniforms), ptr(t_dev), int(n), K, A,
-        ptr(prob_rows), ptr(value_rows), ptr(action_rows), B, int(lo), ptr(action_out), stream()),
-        "rlpyt_pg_sample_head_f32")
-
-
 def update_tick(ctr, table, hyper_cur, idx_all, idx_static, tick_idx):
     """First launch of a captured minibatch update (``rlpyt_update_tick``): row ``*ctr`` of the
     per-update hyper-parameter ``table [n, cols]`` -> ``hyper_cur [cols]``; the update's index chunk
@@ -892,23 +859,8 @@ def rollout_fc_ok(M, N, K):
     return 0 < M <= 1024 and N % 64 == 0 and K % 16 == 0 and 0 < K <= 4096
 
 
-def rollout_fetch(h_frame, h_misc, h_obs, d_frame, d_misc, full_rows, t_off, t_ctr):
-    """First node of a device-driven rollout step (``rlpyt_rollout_fetch``): pull the step's newest
-    frames / reward / done (and the full stacks of reset envs, or of all envs when ``*t_ctr == 0``)
-    out of the page-locked step buffer -- ``h_*`` are host-MAPPED tensors (``_lib.host_mapped_tensor``)
-    -- into the device staging buffers, set ``slot`` and publish ``t = *t_ctr`` at ``d_misc[t_off]``."""
-    _lib.require_gpu()
-    Bg = h_frame.shape[0]
-    frame_bytes = h_frame[0].numel() * h_frame.element_size()
-    row_bytes = h_obs[0].numel() * h_obs.element_size()
-    assert t_ctr.dtype == torch.int64 and full_rows.shape[0] >= Bg
-    check(lib.rlpyt_rollout_fetch(ptr(h_frame), ptr(h_misc), ptr(h_obs), ptr(d_frame), ptr(d_misc),
-                                  ptr(full_rows), int(Bg), int(frame_bytes), int(row_bytes),
-                                  int(t_off), ptr(t_ctr), stream()), "rlpyt_rollout_fetch")
-
-
 def rollout_head(partial, ksplit, fc_bias, w_pi, b_pi, w_v, b_v, uniforms, t_dev, n, prob_rows,
-                 value_rows, action_rows, lo, action_out, bootstrap_out=None, t_next=None):
+                 value_rows, action_rows, lo, action_out, bootstrap_out=None):
     """Trunk finish + heads + softmax + draw + the step's row writes, one workgroup per row
     (``rlpyt_rollout_head_f32``); ``bootstrap_out`` ([n] f32): only the value head, written there
     (every row / uniform argument may then be None)."""
@@ -928,7 +880,7 @@ def rollout_head(partial, ksplit, fc_bias, w_pi, b_pi, w_v, b_v, uniforms, t_dev
         ptr(_f32(b_pi.detach())), ptr(_f32(w_v.detach()).reshape(-1)),
         ptr(_f32(b_v.detach()).reshape(-1)), ptr(uniforms), ptr(t_dev), int(n), K, A,
         ptr(prob_rows), ptr(value_rows), ptr(action_rows), B, int(lo), ptr(action_out),
-        ptr(bootstrap_out), ptr(t_next), stream()), "rlpyt_rollout_head_f32")
+        ptr(bootstrap_out), stream()), "rlpyt_rollout_head_f32")
 
 
 def frame_push(obs, t_dev, lo, new_frame, full_rows, slot, stage=None, scalar_rows=None):

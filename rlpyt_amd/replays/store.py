@@ -122,7 +122,11 @@ class FrameStore:
         if claim.start == 0:                 # the very first rows of a lap: the history of row 0
             for f in range(older):
                 self.frames[f] = obs[0, :, f]
-        elif claim.wrapped and older:        # the lap closed: its tail is the next lap's history
+        elif older and self.cursor.t <= claim.start:
+            # the lap closed: its tail is the next lap's history.  ``<=`` as the reference's frame
+            # mixin (rlpyt/replays/frame.py:56, ``self.t <= t``): a write of exactly T rows from a
+            # non-zero start lands back on its start and has wrapped all the same -- the strict
+            # ``claim.wrapped`` is the sum tree's rule (replays/sum_tree.py advance), not this one
             self.frames[:older] = self.frames[-older:]
 
 

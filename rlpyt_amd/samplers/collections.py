@@ -35,11 +35,8 @@ StepBuffer = namedarraytuple("StepBuffer", ["observation", "action", "reward", "
 # frame-stacked envs additionally publish the newest frame and a "stack was reset" flag
 StepBufferFs = namedarraytuple("StepBufferFs", StepBuffer._fields + ("frame", "reset"))
 # what an agent's ``step_into`` gets to write the rows of a step itself (BaseAgent.step_into)
-# ``t_next`` (device int64[1] or None): under device-driven stepping the step's LAST kernel hands
-# ``t + 1`` to the counter the next step's fetch kernel reads
 StepBinding = namedtuple("StepBinding", ["action_rows", "agent_info_rows", "action_out",
-                                         "uniforms", "t_dev", "lo", "push", "t_next"],
-                         defaults=(None,))
+                                         "uniforms", "t_dev", "lo", "push"])
 # frame-stack rebuild of row t handed to the agent together with the step: the arguments of
 # ``ops.frame_push`` minus the staging copy
 FramePush = namedtuple("FramePush", ["obs", "new_frame", "full_rows", "slot", "scalar_rows"])

@@ -99,13 +99,10 @@ def test_ppo_minibatch_at_bench_size_product_vs_miopen_vs_f64():
     loss.backward()
     torch.cuda.synchronize()
     ran = {k: v for k, v in _lib.variant_counts().items() if v > 0}
-    from rlpyt_amd import ops
-    nt = "gemm_nt_pp_kernel" if ops.GEMM_NT_PINGPONG else "gemm_nt_x6_kernel<128>"
-    dg = "gemm_nn_pp_kernel" if ops.GEMM_DGRAD_NN else "gemm_nt_x6_kernel<256>"
-    expected = {"conv1_fwd_kernel", "conv2_fwd_x6_kernel", nt, "ppo_head_loss_kernel<8, 6, true>",
-                dg, "gemm_tn_x6_kernel", "gemm_reduce_slots_kernel",
-                "conv2_bwd_x6_kernel" if ops.CONV2_BWD_X6 else "conv2_bwd_kernel",
-                "conv1_wgrad_kernel", "head_reduce_finalize_kernel"}
+    expected = {"conv1_fwd_kernel", "conv2_fwd_x6_kernel", "gemm_nt_x6_kernel<128>",
+                "ppo_head_loss_kernel<8, 6, true>", "gemm_nt_x6_kernel<256>", "gemm_tn_x6_kernel",
+                "gemm_reduce_slots_kernel", "conv2_bwd_x6_kernel", "conv1_wgrad_kernel",
+                "head_reduce_finalize_kernel"}
     assert expected <= set(ran), sorted(expected - set(ran))
     # nothing of the alternative paths ran (f32-MFMA conv2 forward, unfused loss, gathers)
     for k in ran:

@@ -68,9 +68,12 @@ def test_conv_forward_kernels(ops, M):
     _close(y1, y1_ref, what="conv1 fwd")
     # conv2 on the float64 reference's y1 (isolates conv2 from conv1's rounding)
     y1_in = y1_ref.float().cuda().contiguous()
-    check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1_in), M, ptr(w2), ptr(b2), ptr(y2), stream()), "conv2")
+    mask = torch.full((M, 128), -1, dtype=torch.int32, device="cuda")
+    check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1_in), M, ptr(w2), ptr(b2), ptr(y2), ptr(mask), stream()),
+          "conv2")
     _close(y2, y2_ref, what="conv2 fwd")
     assert not torch.isnan(y1).any() and not torch.isnan(y2).any()   # every element written
+    assert torch.equal(mask, _sign_mask(y2))      # the sign bits of the y2 the kernel itself wrote
 
 
 def test_conv_identity_weights_asymmetric(ops):
@@ -95,6 +98,19 @@ def test_conv_identity_weights_asymmetric(ops):
         np.testing.assert_allclose(y1[..., co].numpy(), exp.numpy(), rtol=1e-6, atol=1e-7)
 
 
+def _sign_mask(y2):
+    """uint32 [M, 32, 4] sign mask of y2 [M, 3456] as the conv2 forward kernels write it (bit j of
+    word w = y2[m, co, 32 w + j] > 0; positions 108..127 zero), as int32 [M, 128]."""
+    M = y2.shape[0]
+    pos = (y2.reshape(M, 32, 108) > 0)
+    pad = torch.zeros((M, 32, 128), dtype=torch.bool, device=y2.device)
+    pad[:, :, :108] = pos
+    bits = pad.reshape(M, 32, 4, 32).to(torch.int64)
+    w = (bits << torch.arange(32, device=y2.device)).sum(-1)          # [M, 32, 4] in [0, 2^32)
+    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w)
+    return w.to(torch.int32).reshape(M, 128)
+
+
 @pytest.mark.parametrize("M", [1, 5, 700, 1100])
 def test_conv_backward_kernels(ops, M):
     from rlpyt_amd._lib import check, lib, ptr, stream
@@ -112,33 +128,15 @@ def test_conv_backward_kernels(ops, M):
     y2 = y2_ref.detach().float().cuda().contiguous()
     g2d = g2.float().cuda().contiguous()
     obs_d = obs.cuda()
-    dy1 = torch.full((M, 475, 16), float("nan"), device="cuda")
-    check(lib.rlpyt_atari_conv2_dgrad_f32(ptr(g2d), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1),
-                                          stream()), "dgrad")
-    _close(dy1, dy1_ref, what="conv2 dgrad")
-    assert not torch.isnan(dy1).any()
     ws = torch.empty(lib.rlpyt_atari_conv_wgrad_workspace_bytes(), dtype=torch.uint8, device="cuda")
-    dw2 = torch.full((32, 16, 4, 4), float("nan"), device="cuda")
-    db2 = torch.full((32,), float("nan"), device="cuda")
-    check(lib.rlpyt_atari_conv2_wgrad_f32(ptr(g2d), ptr(y2), ptr(y1), M, ptr(ws), ptr(dw2),
-                                          ptr(db2), stream()), "wgrad2")
-    _close(dw2, p64[2].grad, what="conv2 wgrad")
-    _close(db2, p64[3].grad, what="conv2 bias grad")
-    # fused conv2 backward (dgrad + wgrad in one pass) gives the same three results
-    dy1f = torch.full((M, 475, 16), float("nan"), device="cuda")
-    dw2f = torch.full((32, 16, 4, 4), float("nan"), device="cuda")
-    db2f = torch.full((32,), float("nan"), device="cuda")
-    check(lib.rlpyt_atari_conv2_bwd_f32(ptr(g2d), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1f), ptr(ws),
-                                        ptr(dw2f), ptr(db2f), stream()), "conv2 bwd fused")
-    _close(dy1f, dy1_ref, what="fused conv2 dgrad")
-    _close(dw2f, p64[2].grad, what="fused conv2 wgrad")
-    _close(db2f, p64[3].grad, what="fused conv2 bias grad")
-    assert not torch.isnan(dy1f).any()
-    # ... and so does the bf16x6 version of the fused kernel (both contractions on the bf16 pipe)
+    # fused conv2 backward on the bf16 pipe: dgrad + both ReLU masks + weight / bias gradients in one
+    # pass; conv2's ReLU mask arrives as the sign bits of y2 (checked against the forward kernels'
+    # own mask in test_conv_forward_kernels / test_conv2_sign_mask_*)
+    mask = _sign_mask(y2)
     dy1x = torch.full((M, 475, 16), float("nan"), device="cuda")
     dw2x = torch.full((32, 16, 4, 4), float("nan"), device="cuda")
     db2x = torch.full((32,), float("nan"), device="cuda")
-    check(lib.rlpyt_atari_conv2_bwd_x6_f32(ptr(g2d), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1x), ptr(ws),
+    check(lib.rlpyt_atari_conv2_bwd_x6_f32(ptr(g2d), ptr(mask), ptr(y1), M, ptr(w2), ptr(dy1x), ptr(ws),
                                            ptr(dw2x), ptr(db2x), stream()), "conv2 bwd x6")
     _close(dy1x, dy1_ref, what="bf16x6 conv2 dgrad")
     _close(dw2x, p64[2].grad, what="bf16x6 conv2 wgrad")
@@ -390,8 +388,8 @@ def test_bf16_split_kernels_are_f32_accurate(ops):
 
 
 def _gemm_case(ops, layout, M, N, K, **kw):
-    """C[M,N] in layout NT (a[M,K] b[N,K]^T) / NN (a[M,K] b[K,N]) / TN (a[K,M]^T b[K,N]) against
-    float64, beside torch's own f32 GEMM of the same operands: (ours, theirs, scale)."""
+    """C[M,N] in layout NT (a[M,K] b[N,K]^T) / TN (a[K,M]^T b[K,N]) against float64, beside torch's
+    own f32 GEMM of the same operands: (ours, theirs, scale)."""
     g = torch.Generator().manual_seed(M + N + K)
     a64 = _wide((M, K), g, 2.0).float().double().cuda()          # logical A [M, K]
     b64 = _wide((N, K), g, 2.0).float().double().cuda()          # logical B [N, K]
@@ -400,8 +398,6 @@ def _gemm_case(ops, layout, M, N, K, **kw):
     a, b = a64.float(), b64.float()
     if layout == "NT":
         c = ops.gemm_nt(a, b, **kw)
-    elif layout == "NN":
-        c = ops.gemm_nn(a, b.t().contiguous())
     else:
         c = ops.gemm_tn(a.t().contiguous(), b.t().contiguous())
     assert c.shape == ref.shape
@@ -411,23 +407,13 @@ def _gemm_case(ops, layout, M, N, K, **kw):
 # (8192, 3456, 512) and (8000, 2100, 64): >= 512 tiles of 256 x 128 -> the 256-row-tile variant of
 # the lock-step kernel; (8192, 512, 3456) / (8192, 3456, 512) / (512, 3456, 8192): the three trunk
 # GEMMs of the update at M = 8192 (forward, input gradient, weight gradient)
-@pytest.mark.parametrize("pingpong", [True, False])
 @pytest.mark.parametrize("M,N,K", [(8192, 512, 3456), (8192, 3456, 512), (8000, 2100, 64),
                                    (1000, 3456, 512), (130, 200, 96), (1, 1, 32)])
-def test_gemm_nt_bf16x6_is_f32_accurate(ops, M, N, K, pingpong):
-    """ops.gemm_nt (a b^T from three-piece bf16 splits, six products; ping-pong kernel
-    rlpyt_gemm_nt_pp_f32 and lock-step kernel rlpyt_gemm_nt_f32) against float64 beside torch's own
-    f32 GEMM on wide-range operands: error <= 2x torch-f32's (+ 2^-22 of the output scale),
-    including ragged tile edges."""
-    ours, theirs, scale = _gemm_case(ops, "NT", M, N, K, pingpong=pingpong)
-    assert ours <= 2 * theirs + scale * 2.0 ** -22, (ours, theirs)
-
-
-@pytest.mark.parametrize("M,N,K", [(8192, 3456, 512), (1024, 3456, 512), (130, 200, 96),
-                                   (1, 4, 32), (257, 132, 160)])
-def test_gemm_nn_bf16x6_is_f32_accurate(ops, M, N, K):
-    """ops.gemm_nn (a b with b [K, N] read as stored: the trunk's input gradient g W), same bound."""
-    ours, theirs, scale = _gemm_case(ops, "NN", M, N, K)
+def test_gemm_nt_bf16x6_is_f32_accurate(ops, M, N, K):
+    """ops.gemm_nt (a b^T from three-piece bf16 splits, six products; lock-step kernel
+    rlpyt_gemm_nt_f32, both tile variants) against float64 beside torch's own f32 GEMM on wide-range
+    operands: error <= 2x torch-f32's (+ 2^-22 of the output scale), including ragged tile edges."""
+    ours, theirs, scale = _gemm_case(ops, "NT", M, N, K)
     assert ours <= 2 * theirs + scale * 2.0 ** -22, (ours, theirs)
 
 
@@ -460,15 +446,13 @@ def test_gemm_layouts_agree_on_asymmetric_data(ops):
         torch.rand(N, K, generator=g, dtype=torch.float64)
     ref = (a @ b.t()).cuda()
     a32, b32 = a.float().cuda(), b.float().cuda()
-    for name, c in (("nt_pp", ops.gemm_nt(a32, b32, pingpong=True)),
-                    ("nt", ops.gemm_nt(a32, b32, pingpong=False)),
-                    ("nn", ops.gemm_nn(a32, b32.t().contiguous())),
+    for name, c in (("nt", ops.gemm_nt(a32, b32)),
                     ("tn", ops.gemm_tn(a32.t().contiguous(), b32.t().contiguous()))):
         _close(c, ref, rel=1e-5, what=name)
 
 
 def test_linear_nobias_autograd(ops):
-    """ops.linear_nobias (gemm_nt forward, gemm_nn input gradient, gemm_tn weight gradient) against
+    """ops.linear_nobias (gemm_nt forward and input gradient, gemm_tn weight gradient) against
     F.linear in float64."""
     g = torch.Generator().manual_seed(3)
     x64 = torch.randn(1024, 3456, generator=g, dtype=torch.float64).cuda().requires_grad_(True)
@@ -482,6 +466,17 @@ def test_linear_nobias_autograd(ops):
     _close(y, F.linear(x64, w64), rel=3e-6, what="linear_nobias fwd")
     _close(x.grad, x64.grad, rel=3e-6, what="linear_nobias dx")
     _close(w.grad, w64.grad, rel=3e-6, what="linear_nobias dw")
+
+
+def _check_conv2_bwd_tail(y1, y2, g2, w2, dy1, n):
+    """dy1 of the LAST n images against a float64 evaluation of conv2's backward-data pass."""
+    M = y1.shape[0]
+    a1 = y1[-n:].double().reshape(n, 25, 19, 16).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    z2 = F.conv2d(a1, w2.double(), None, stride=2, padding=1)
+    gm2 = g2[-n:].double().reshape(n, 32, 12, 9) * (y2[-n:].reshape(n, 32, 12, 9) > 0)
+    (z2 * gm2).sum().backward()
+    ref = (a1.grad * (a1 > 0)).permute(0, 2, 3, 1).reshape(n, 475, 16)
+    _close(dy1[-n:], ref, what=f"conv2_bwd_x6 dy1, last {n} images of M = {M}")
 
 
 def test_conv_kernels_run_to_run_identical_at_update_size(ops):
@@ -509,24 +504,20 @@ def test_conv_kernels_run_to_run_identical_at_update_size(ops):
         dw2, db2, dw1, db1 = (torch.empty_like(t) for t in (w2, b2, w1, b1))
         check(lib.rlpyt_atari_conv1_fwd_f32(ptr(obs), ptr(idx), T, B, M, ptr(w1), ptr(b1), 1. / 255,
                                             ptr(y1), stream()))
-        check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1), M, ptr(w2), ptr(b2), ptr(y2), stream()))
-        check(lib.rlpyt_atari_conv2_bwd_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1), ptr(ws),
-                                            ptr(dw2), ptr(db2), stream()))
+        mask = torch.empty((M, 128), dtype=torch.int32, device="cuda")
+        check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1), M, ptr(w2), ptr(b2), ptr(y2), ptr(mask), stream()))
+        # the bf16x6 conv2 backward (32 images per persistent workgroup: its double-buffered planes
+        # and register pipelines in steady state), fed by the forward kernel's own sign mask
+        check(lib.rlpyt_atari_conv2_bwd_x6_f32(ptr(g2), ptr(mask), ptr(y1), M, ptr(w2), ptr(dy1), ptr(ws),
+                                               ptr(dw2), ptr(db2), stream()))
         check(lib.rlpyt_atari_conv1_wgrad_f32(ptr(obs), ptr(idx), T, B, M, ptr(dy1), 1. / 255, ptr(ws),
                                               ptr(dw1), ptr(db1), stream()))
-        # the bf16x6 conv2 backward on the same inputs (32 images per persistent workgroup: its
-        # double-buffered planes and register pipelines in steady state)
-        dy1x = torch.empty_like(y1)
-        dw2x, db2x = torch.empty_like(w2), torch.empty_like(b2)
-        check(lib.rlpyt_atari_conv2_bwd_x6_f32(ptr(g2), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1x), ptr(ws),
-                                               ptr(dw2x), ptr(db2x), stream()))
-        if it == 0:      # the two conv2 backward kernels agree (f32 kernel = reference here)
-            _close(dy1x, dy1, rel=2e-5, what="conv2_bwd_x6 dy1 vs f32 kernel at M = 8192")
-            _close(dw2x, dw2, rel=2e-5, what="conv2_bwd_x6 dw2 vs f32 kernel at M = 8192")
-            _close(db2x, db2, rel=2e-5, what="conv2_bwd_x6 db2 vs f32 kernel at M = 8192")
-        cur = dict(y1=y1, y2=y2, dy1=dy1, dw2=dw2, db2=db2, dw1=dw1, db1=db1, gemm=ops.gemm_nt(a, wt),
-                   dy1x=dy1x, dw2x=dw2x, db2x=db2x,
-                   gemm_nn=ops.gemm_nn(g512, wt), gemm_tn=ops.gemm_tn(g512, a))
+        if it == 0:
+            assert torch.equal(mask, _sign_mask(y2))      # mask at M = 8192 (bf16x6 epilogue)
+            # conv2 backward against float64 on the last 48 images (chunked reference)
+            _check_conv2_bwd_tail(y1, y2, g2, w2, dy1, n=48)
+        cur = dict(y1=y1, y2=y2, mask=mask, dy1=dy1, dw2=dw2, db2=db2, dw1=dw1, db1=db1,
+                   gemm=ops.gemm_nt(a, wt), gemm_tn=ops.gemm_tn(g512, a))
         torch.cuda.synchronize()
         if ref is None:
             ref = {k: v.clone() for k, v in cur.items()}

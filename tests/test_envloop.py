@@ -9,7 +9,7 @@ import pytest
 from rlpyt_amd.envs import EnvStep
 from rlpyt_amd.envs.synthetic import SyntheticPong, TinyDiscreteEnv
 from rlpyt_amd.samplers.collections import AtariTrajInfo, StepBuffer, StepBufferFs, TrajInfo
-from rlpyt_amd.samplers.gpu import EnvRunner
+from rlpyt_amd.samplers.workers import EnvRunner
 from rlpyt_amd.utils.collections import namedarraytuple
 
 EnvInfo = namedarraytuple("EnvInfo", ["game_score", "traj_done"])

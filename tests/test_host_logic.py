@@ -743,6 +743,19 @@ def test_replay_store_parts_on_host_tensors():
             lap0 = (k // buf.T) * buf.T
             for f in range(C - 1):
                 assert np.array_equal(frames[f], stream[lap0 + f]), (k, f)
+    # one append of EXACTLY T rows from a non-zero start lands back on its start: still a closed lap
+    # (rlpyt/replays/frame.py:56 tests ``self.t <= t``), the history rows must be refreshed
+    assert buf.t == 4
+    obs = np.stack([obs_at(k + i) for i in range(buf.T)])
+    buf.append_samples(S2B(observation=torch.from_numpy(obs),
+                           action=torch.arange(k, k + buf.T).repeat(B, 1).t().contiguous(),
+                           reward=torch.zeros(buf.T, B), done=torch.zeros(buf.T, B, dtype=torch.bool)))
+    k += buf.T
+    assert buf.t == 4
+    frames = buf.samples_frames.numpy()
+    lap0 = (k // buf.T) * buf.T
+    for f in range(C - 1):
+        assert np.array_equal(frames[f], stream[lap0 + f]), ("full-lap append", f)
     # uniform draws never land in the guard band around the cursor
     np.random.seed(1)
     T_idxs, B_idxs = buf.sample_idxs(4000)

@@ -251,13 +251,11 @@ def test_fused_step_matches_unfused_step():
 
 def test_zero_copy_step_buffer_matches_dma():
     """The head kernel writing the actions in place in the page-locked step buffer (zero-copy, the
-    default), and additionally the conv kernel reading the newest frames in place
-    (``zero_copy_frames``), give exactly the batches of the all-DMA path (one H2D of the
-    frames + misc block, one D2H of the actions)."""
-    def run(zc, zcf=False):
+    default) gives exactly the batches of the all-DMA path (one H2D of the frames + misc block,
+    one D2H of the actions)."""
+    def run(zc):
         s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=7), batch_T=6, batch_B=8,
-                       n_workers=2, n_groups=2, zero_copy=zc, zero_copy_frames=zcf,
-                       max_decorrelation_steps=0)
+                       n_workers=2, n_groups=2, zero_copy=zc, max_decorrelation_steps=0)
         a = AtariFfAgent()
         torch.manual_seed(41)
         np.random.seed(41)
@@ -273,13 +271,13 @@ def test_zero_copy_step_buffer_matches_dma():
                                             smp.env.reward, smp.env.done,
                                             smp.agent.agent_info.dist_info.prob,
                                             smp.agent.bootstrap_value)])
-        assert all(G.zc_out == zc and G.zc_in == zcf for G in s.groups)
+        assert all(G.zc == zc for G in s.groups)
         s.shutdown()
         return out
-    a, b, c = run(True), run(False), run(True, True)
-    for x, y, z in zip(a, b, c):
-        for u, v, w in zip(x, y, z):
-            assert torch.equal(u, v) and torch.equal(u, w)
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
 
 
 def test_sample_convs_kernel_matches_separate_launches():
@@ -370,7 +368,8 @@ def test_fused_tail_matches_agent_value_tail(monkeypatch):
 
     def run(fused_tail):
         if not fused_tail:
-            monkeypatch.setattr(GpuSampler, "_tail_fused", lambda self, G, cuda: False)
+            from rlpyt_amd.samplers.device import DeviceBatch
+            monkeypatch.setattr(DeviceBatch, "tail_fused", lambda self, G: False)
         s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=6), batch_T=6, batch_B=8,
                        n_workers=2, n_groups=2, max_decorrelation_steps=0)
         a = AtariFfAgent()
@@ -401,108 +400,3 @@ def test_fused_tail_matches_agent_value_tail(monkeypatch):
                 assert torch.equal(u, v)
             else:
                 torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-6)
-
-
-def test_rollout_fetch_kernel_matches_host_uploads():
-    """``rlpyt_rollout_fetch`` (first node of a device-driven step) does on the device what the
-    master's per-step uploads did on the host: newest frames, reward / done scalars, full stacks +
-    slot for reset envs (or for every env at t = 0), and publishes t -- read in place from the
-    page-locked step buffer."""
-    import ctypes
-    from rlpyt_amd import _lib, ops
-    from rlpyt_amd.utils.buffer import np_mp_array
-    Bg, C, H, W = 7, 4, 104, 80
-    rng = np.random.RandomState(5)
-    t_off = 8 * Bg + ((2 * Bg + 15) // 16) * 16
-    fr_bytes = Bg * H * W
-    blk = np_mp_array(fr_bytes + t_off + 16, np.uint8)
-    obs = np_mp_array((Bg, C, H, W), np.uint8)
-    pinned = []
-    for a in (blk, obs):
-        assert _lib.lib.rlpyt_host_register(ctypes.c_void_p(a.ctypes.data), int(a.nbytes)) == 0
-        pinned.append(a.ctypes.data)
-    try:
-        frame = blk[:fr_bytes].reshape(Bg, H, W)
-        misc = blk[fr_bytes:]
-        dev = torch.device("cuda:0")
-        h_frame = _lib.host_mapped_tensor(frame, dev)
-        h_misc = _lib.host_mapped_tensor(misc, dev)
-        h_obs = _lib.host_mapped_tensor(obs, dev)
-        d_blk = torch.zeros(blk.size, dtype=torch.uint8, device=dev)
-        d_frame = d_blk[:fr_bytes].view(Bg, H, W)
-        d_misc = d_blk[fr_bytes:]
-        full_rows = torch.zeros((Bg, C, H, W), dtype=torch.uint8, device=dev)
-        t_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-        for t, resets in ((0, []), (3, [1, 5]), (9, []), (4, list(range(Bg)))):
-            frame[:] = rng.randint(0, 256, frame.shape)
-            obs[:] = rng.randint(0, 256, obs.shape)
-            misc[:4 * Bg].view(np.float32)[:] = rng.randn(Bg)
-            misc[8 * Bg:9 * Bg] = rng.rand(Bg) < 0.4
-            misc[9 * Bg:10 * Bg] = 0
-            misc[9 * Bg:10 * Bg][resets] = 1
-            misc[4 * Bg:8 * Bg] = 77                     # host slot area: must NOT be copied
-            full_rows.zero_()
-            d_blk.zero_()
-            t_ctr.fill_(t)
-            ops.rollout_fetch(h_frame, h_misc, h_obs, d_frame, d_misc, full_rows, t_off, t_ctr)
-            torch.cuda.synchronize()
-            got = d_blk.cpu().numpy()
-            assert np.array_equal(got[:fr_bytes], blk[:fr_bytes])
-            gm = got[fr_bytes:]
-            assert np.array_equal(gm[:4 * Bg], misc[:4 * Bg])                   # reward
-            assert np.array_equal(gm[8 * Bg:10 * Bg], misc[8 * Bg:10 * Bg])     # done, reset
-            full = np.ones(Bg, bool) if t == 0 else np.isin(np.arange(Bg), resets)
-            slot = gm[4 * Bg:8 * Bg].view(np.int32)
-            assert np.array_equal(slot, np.where(full, np.arange(Bg), -1))
-            assert int(gm[t_off:t_off + 8].view(np.int64)[0]) == t
-            fr = full_rows.cpu().numpy()
-            for b in range(Bg):
-                assert np.array_equal(fr[b], obs[b] if full[b] else np.zeros_like(obs[b]))
-            assert int(t_ctr.item()) == t               # the fetch kernel only reads the counter
-    finally:
-        for p_ in pinned:
-            _lib.lib.rlpyt_host_unregister(ctypes.c_void_p(p_))
-
-
-@pytest.mark.parametrize("agent_kind", ["ff", "dqn"])
-def test_device_driven_stepping_matches_host_driven(agent_kind, monkeypatch):
-    """Batches collected with the fetch kernel + device step counter + enqueue-ahead serve loop
-    (``device_fetch=True``, the default) are bit-identical to round 3's host-issued uploads +
-    event-driven loop, for the fused AtariFf step and for a non-fused agent (DQN), through resets,
-    over several batches."""
-    def run(dev_fetch):
-        kw = dict(batch_T=6, batch_B=8, n_workers=2, n_groups=2, max_decorrelation_steps=0,
-                  device_fetch=dev_fetch)
-        s = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=7), **kw)
-        if agent_kind == "ff":
-            a = AtariFfAgent()
-        else:
-            from rlpyt_amd.agents.dqn.dqn_agent import AtariDqnAgent
-            a = AtariDqnAgent(eps_final=0.2)
-        torch.manual_seed(71)
-        np.random.seed(71)
-        s.initialize(a, seed=13, bootstrap_value=(agent_kind == "ff"))
-        torch.cuda.set_device(0)
-        a.to_device(0)
-        torch.manual_seed(72)
-        out = []
-        for itr in range(6):
-            smp, _ = s.obtain_samples(itr)
-            torch.cuda.synchronize()
-            leaves = [smp.env.observation, smp.agent.action, smp.env.reward, smp.env.done]
-            if agent_kind == "ff":
-                leaves += [smp.agent.agent_info.dist_info.prob, smp.agent.agent_info.value,
-                           smp.agent.bootstrap_value]
-            else:
-                leaves += [smp.agent.agent_info.q]
-            out.append([x.clone() for x in leaves])
-        assert all(G.dev_fetch == dev_fetch for G in s.groups)
-        ahead = getattr(s, "_ahead", None) is not None
-        s.shutdown()
-        return out, ahead
-    (a, ahead_a), (b, ahead_b) = run(True), run(False)
-    assert ahead_a and not ahead_b          # the enqueue-ahead loop really served the batches
-    assert any(x[3].any() for x in a)
-    for x, y in zip(a, b):
-        for u, v in zip(x, y):
-            assert torch.equal(u, v)

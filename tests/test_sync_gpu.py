@@ -155,9 +155,7 @@ def test_two_ranks_product_ppo_matches_mean_gradient_run(tmp_path, T, B):
     r1 = torch.load(tmp_path / "rank1.pt")
     for res in (r0, r1):       # the product path ran in the rank processes, under DDP
         assert res["ddp"] == "DistributedDataParallel"
-        from rlpyt_amd import ops
-        for k in ("ppo_head_loss_kernel<8, 6, true>",
-                  "conv2_bwd_x6_kernel" if ops.CONV2_BWD_X6 else "conv2_bwd_kernel", "conv1_wgrad_kernel",
+        for k in ("ppo_head_loss_kernel<8, 6, true>", "conv2_bwd_x6_kernel", "conv1_wgrad_kernel",
                   "conv1_fwd_kernel", "scan_exact_kernel<0, 1, 32, false>"):
             assert res["variants"].get(k, 0) > 0, (k, sorted(res["variants"]))
         big = T * B // PPO_KW["minibatches"] >= 1024      # _LinearNoBias under DDP's hooks
