@@ -11,12 +11,13 @@ A "step" = one full PPO iteration of the hot path on one synthetic batch:
 `python bench.py --gpus N` launches its own N ranks (one process per GPU, RCCL).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      -- the dominant own kernel of the timed region by total HIP-event time, timed live
-                   inside the timed steps: an f32-MFMA kernel is priced against the 157.3 TFLOP/s
-                   f32 MFMA peak; a bf16-split kernel (f32 contraction issued as 3 / 6 bf16 MFMAs
-                   per MAC) against both the HBM peak and the 2.5 PFLOP/s dense bf16
-                   peak with its ISSUED flops; roofline_conv2_bwd keeps the remaining f32-MFMA
-                   kernel visible when it is not the dominant one;
+  roofline      -- the kernel with the largest TOTAL time over a whole timed iteration, rollout
+                   kernels included (512 + launches each per iteration against 16 of every update
+                   kernel): an f32-MFMA kernel is priced against the 157.3 TFLOP/s f32 MFMA peak; a
+                   bf16-split kernel (f32 contraction issued as 3 / 6 bf16 MFMAs per MAC)
+                   against both the HBM peak and the 2.5 PFLOP/s dense bf16 peak with its ISSUED
+                   flops; roofline_update = the largest kernel of the update, roofline_gemm_tn the
+                   weight gradient; durations measured live in this run;
   kernels       -- the same live measurement for every own kernel of the update;
   roofline_gae_scaled -- the GAE scan at T=128, N=2^20 columns (the shape at which the
                    HBM criterion of BASELINE.md section 3 is meaningful), timed in this run;
@@ -51,18 +52,16 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, den
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 # bf16-split kernels (DESIGN.md "fp32 contractions on the bf16 pipe"): issued bf16 MFMA flops per
 # algorithmic fp32 flop (3 exact pieces of one operand; 6 products of two 3-piece operands)
-BF16_SPLIT = {"conv1_fwd": 3, "conv1_wgrad": 3, "conv2_fwd": 6, "gemm_nt": 6, "gemm_nt_dgrad": 6,
-              "gemm_nn": 6, "gemm_tn": 6}
+BF16_SPLIT = {"conv1_fwd": 3, "conv1_wgrad": 3, "conv2_fwd": 6, "conv2_bwd": 6, "gemm_nt": 6,
+              "gemm_nt_dgrad": 6, "gemm_tn": 6}
 KERNEL_NAMES = {
     "conv1_fwd": "conv1_fwd_kernel (gather + u8->bf16 + conv 4->16 k8 s4 + bias + ReLU; exact "
                  "bf16x3 split of w1, f32 accumulate)",
-    "conv2_fwd": "conv2_fwd_x6_kernel (conv 16->32 k4 s2 p1 + bias + ReLU; bf16x6 split, f32 "
-                 "accumulate, dropped terms <= 2^-24, 2^-27 rms)",
-    "conv2_bwd": "conv2_bwd_kernel (dgrad + ReLU masks + weight/bias grad in one pass, fp32 MFMA)",
-    "conv2_bwd_x6": "conv2_bwd_x6_kernel (dgrad + ReLU masks + weight/bias grad in one pass over the "
-                    "images; bf16x6 split of both operands of both contractions, f32 accumulate)",
-    "conv2_dgrad": "conv2_dgrad_kernel (transposed conv + ReLU masks, fp32 MFMA)",
-    "conv2_wgrad": "conv2_wgrad_kernel (+ bias grad, fp32 MFMA)",
+    "conv2_fwd": "conv2_fwd_x6_kernel (conv 16->32 k4 s2 p1 + bias + ReLU + sign mask of y2; bf16x6 "
+                 "split, f32 accumulate, dropped terms <= 2^-24, 2^-27 rms)",
+    "conv2_bwd": "conv2_bwd_x6_kernel (dgrad + ReLU masks + weight/bias grad in one pass over the "
+                 "images, conv2's ReLU mask from the forward pass's sign bits; bf16x6 split of both "
+                 "operands of both contractions, f32 accumulate)",
     "conv1_wgrad": "conv1_wgrad_kernel (gather + u8->bf16 + weight/bias grad; exact bf16x3 split "
                    "of dy1, f32 accumulate)",
     "gemm_nt": "gemm_nt_x6_kernel<128> (update trunk forward x W^T [8192,3456]x[512,3456]^T: f32 GEMM "
@@ -70,8 +69,6 @@ KERNEL_NAMES = {
                "terms <= 2^-24, 2^-27 rms)",
     "gemm_nt_dgrad": "gemm_nt_x6_kernel<256> (update trunk input gradient g W [8192,512]x[512,3456] as "
                      "g (W^T)^T on a transposed copy of W; same bf16x6 arithmetic)",
-    "gemm_nn": "gemm_nn_pp_kernel (update trunk input gradient g W [8192,512]x[512,3456], W read as "
-               "stored; bf16x6, producer / consumer waves)",
     "gemm_tn": "gemm_tn_x6_kernel + gemm_reduce_slots_kernel (update trunk weight gradient g^T x "
                "[8192,512]^T x [8192,3456]: 8 K chunks <-> XCDs, partial tiles, fixed-order sum; "
                "bf16x6 in lock step, K-major LDS tiles read with ds_read_b64_tr_b16)",
@@ -88,8 +85,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-T", type=int, default=128)
     ap.add_argument("--batch-B", type=int, default=256)
-    ap.add_argument("--workers", type=int, default=-1, help="env worker processes per rank "
-                    "(-1: host cores / ranks, capped at B/10)")
+    ap.add_argument("--workers", "--workers-per-rank", dest="workers", type=int, default=-1,
+                    help="env worker processes per rank (-1: 1.25 x this rank's share of the CPU "
+                         "quota, capped at B/10; set it on boxes without the 16-CPU quota)")
     ap.add_argument("--env-cost-us", type=float, default=0., help="declared extra host cost "
                     "per env step (busy wait) to emulate an ALE-like emulator")
     ap.add_argument("--config", default="ppo", choices=["ppo", "dqn", "r2d1"],
@@ -114,9 +112,6 @@ def parse():
     ap.add_argument("--no-zero-copy", action="store_true",
                     help="A/B: hand the sampled actions to the env workers through a D2H copy instead "
                          "of letting the step's head kernel write them in the page-locked step buffer")
-    ap.add_argument("--zero-copy-frames", action="store_true",
-                    help="A/B: the conv kernel also reads the newest frames in place over PCIe "
-                         "(round 3's --zero-copy; measured slower)")
     ap.add_argument("--frozen-env", action="store_true",
                     help="diagnostics: env.step() returns the standing observation (no dynamics, no "
                          "drawing) -- the rollout's floor without the synthetic env's own cost")
@@ -211,7 +206,7 @@ def main():
         env_kwargs["frozen"] = True
     leg_steps = args.env_cost_leg_steps if (args.env_cost_leg_us > 0 and args.env_cost_us == 0) else 0
     n_itr_total = (args.warmup + args.steps + (0 if args.no_kernel_timing else 2)
-                   + (1 + leg_steps if leg_steps else 0))
+                   + (1 + leg_steps if leg_steps else 0) + (2 if world > 1 else 0))
     # worker processes and their CPUs the reference's way: one worker per entry of
     # affinity["workers_cpus"] (rlpyt/samplers/parallel/base.py:157-172); rank r takes the r-th
     # block of the hardware threads
@@ -237,8 +232,7 @@ def main():
                          TrajInfoCls=AtariTrajInfo, max_decorrelation_steps=100,
                          n_groups=None if args.groups < 0 else args.groups,
                          use_graph=not args.no_graph, fused_push=not args.no_fused_push,
-                         split_workers=args.split_workers, zero_copy=not args.no_zero_copy,
-                         zero_copy_frames=args.zero_copy_frames)
+                         split_workers=args.split_workers, zero_copy=not args.no_zero_copy)
     agent = AtariFfAgent()
     algo = PPO(discount=0.99, learning_rate=1e-3, value_loss_coeff=1., entropy_loss_coeff=0.01,
                clip_grad_norm=1., gae_lambda=0.98, minibatches=4, epochs=4, ratio_clip=0.1,
@@ -287,7 +281,7 @@ def main():
         agent.train_mode(itr)
         opt_info = algo.optimize_agent(itr, samples)
     sync()
-    elapsed = time.perf_counter() - t0
+    elapsed = elapsed_local = time.perf_counter() - t0
     timing = dict(sampler.timing)         # (the env-cost leg below keeps adding to sampler.timing)
     worker_ms = None
     if wt0 is not None:
@@ -312,10 +306,6 @@ def main():
     # slow the headline and fold launch gaps into the averages): two more iterations of the same
     # workload.
     ksum = {}
-    KTIMER_NOTE = ("HIP events around each launch, on the launching stream, in 2 iterations of the "
-                   "same workload run right after the timed region (the timed region itself carries "
-                   "no per-launch events: they would sit between its kernels); rocprofv3 averages of "
-                   "the same command: profiles/r4_bench_kernel_stats.csv")
     if not args.no_kernel_timing:
         ktimer.reset()
         ktimer.enable(True)
@@ -361,19 +351,46 @@ def main():
             dist.all_reduce(buf)
         torch.cuda.synchronize()
         ar_us = (time.perf_counter() - ta) / n_ar * 1e6
+        # exposed all-reduce time of an iteration's 16 updates: the same update with DDP's gradient
+        # synchronisation on and off (model.no_sync()), both bracketed by device synchronisation, on
+        # the batch of one more rollout.  Run LAST: without the all-reduce the ranks' parameters
+        # drift apart (nothing is measured after this).
+        upd_ms = {}
+        if not args.check_params:
+            import contextlib
+            itr_x = n_itr_total - 2
+            agent.sample_mode(itr_x)
+            samples, _ = sampler.obtain_samples(itr_x)
+            agent.train_mode(itr_x)
+            for key, ctx in (("sync", contextlib.nullcontext), ("no_sync", agent.model.no_sync)):
+                sync()
+                tu = time.perf_counter()
+                with ctx():
+                    algo.optimize_agent(itr_x, samples)
+                torch.cuda.synchronize()
+                upd_ms[key] = (time.perf_counter() - tu) * 1e3
         cpu_list = [None] * world
         dist.all_gather_object(cpu_list, dict(
             rank=rank, device=torch.cuda.current_device(),
             device_name=torch.cuda.get_device_name(torch.cuda.current_device()),
             cpu_quota_share=round(cpus / world, 2), env_workers=sampler.n_workers,
-            cpu_block=[block[0], block[-1]]))
+            cpu_block=[block[0], block[-1]],
+            # where this rank's iteration goes: a curve that bends with rollout_ms is host-bound (CPUs
+            # per rank), one that bends with allreduce_exposed_ms is xGMI-bound
+            rollout_ms=t_sample / args.steps * 1e3,
+            update_ms=(elapsed_local - t_sample) / args.steps * 1e3,
+            ms_per_time_step=t_sample / args.steps / T * 1e3,
+            update_ms_ddp_sync=upd_ms.get("sync"), update_ms_no_sync=upd_ms.get("no_sync"),
+            allreduce_exposed_ms=(upd_ms["sync"] - upd_ms["no_sync"]) if upd_ms else None))
         multi = dict(dist_world_size=dist.get_world_size(), backend=dist.get_backend(),
                      rccl_version=_rccl_version(), host_cpu_quota=cpus,
                      ranks=cpu_list, grad_bytes=nparam * 4,
                      allreduce_us_per_minibatch=ar_us,
                      allreduce_ms_per_iteration=ar_us * algo.epochs * algo.minibatches / 1e3,
-                     note="stand-alone all-reduce of one gradient-sized buffer after the timed "
-                          "region (inside the iteration DDP overlaps it with backward)")
+                     note="allreduce_us_per_minibatch: stand-alone all-reduce of one gradient-sized "
+                          "buffer after the timed region; ranks[].allreduce_exposed_ms: one iteration's "
+                          "16 updates with DDP's gradient synchronisation on minus off (no_sync), i.e. "
+                          "what of the all-reduce is NOT hidden under backward")
     sampler.shutdown()
     # a throughput number over non-finite training is not a measurement
     assert all(torch.isfinite(p).all().item() for p in agent.parameters()), \
@@ -450,111 +467,15 @@ def main():
         if multi is not None:
             multi["per_gpu_value"] = out["value"] / world
             out["multi_gpu"] = multi
+        rollout = None
+        if world == 1 and not args.no_kernel_timing:
+            rollout = rollout_step_roofline(B // max(sampler.n_groups, 1), T, B)
+            out["roofline_rollout"] = rollout
         if ksum:
-            # dominant own kernel of the timed region = largest total HIP-event time
-            name, g = max(ksum.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])
-            from rlpyt_amd import ops as _ops
-            conv2_bwd_x6 = bool(getattr(_ops, "CONV2_BWD_X6", False))
-            split = dict(BF16_SPLIT, **({"conv2_bwd": 6} if conv2_bwd_x6 else {}))
-            names = dict(KERNEL_NAMES, **({"conv2_bwd": KERNEL_NAMES["conv2_bwd_x6"]}
-                                          if conv2_bwd_x6 else {}))
-            if name in split:
-                # fp32 contraction issued as split[name] bf16 MFMAs per algorithmic MAC: priced
-                # against BOTH ceilings, "bound" = the one it sits closer to
-                issued = g["TFLOPs"] * split[name]
-                f_hbm, f_mfma = g["GBps"] / HBM_PEAK_GBPS, issued / BF16_MFMA_PEAK_TFLOPS
-                hbm = f_hbm >= f_mfma
-                nx = split[name]
-                out["roofline"] = {"kernel": names.get(name, name),
-                                   "bound": "hbm" if hbm else "mfma",
-                                   "achieved": g["GBps"] if hbm else issued,
-                                   "peak": HBM_PEAK_GBPS if hbm else BF16_MFMA_PEAK_TFLOPS,
-                                   "unit": "GB/s" if hbm else "TFLOP/s",
-                                   "frac": max(f_hbm, f_mfma), "traffic": None,
-                                   "frac_note": f"mfma bound: ISSUED bf16 flops ({nx} MFMAs per "
-                                                f"algorithmic MAC) over the dense bf16 peak = the "
-                                                f"fraction of the bf16x{nx} emulation ceiling "
-                                                f"({BF16_MFMA_PEAK_TFLOPS / nx:.0f} TFLOP/s algorithmic)",
-                                   "frac_hbm": f_hbm, f"frac_of_bf16x{nx}_ceiling": f_mfma,
-                                   "frac_alg_vs_bf16_peak": g["TFLOPs"] / BF16_MFMA_PEAK_TFLOPS,
-                                   "alg_fp32_TFLOPs": g["TFLOPs"],
-                                   "alg_over_f32_mfma_peak": g["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
-                                   "avg_us": g["avg_us"], "avg_us_source": KTIMER_NOTE, "launches": g["launches"],
-                                   "alg_flops_per_launch": g["alg_flops_per_launch"],
-                                   "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
-            elif "TFLOPs" in g:   # dense f32 contraction: priced against the fp32 MFMA peak
-                out["roofline"] = {"kernel": names.get(name, name), "bound": "mfma",
-                                   "achieved": g["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": g["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
-                                   "traffic": None, "avg_us": g["avg_us"], "avg_us_source": KTIMER_NOTE,
-                                   "launches": g["launches"],
-                                   "alg_flops_per_launch": g["alg_flops_per_launch"],
-                                   "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
-            else:
-                out["roofline"] = {"kernel": names.get(name, name),
-                                   "bound": "hbm", "achieved": g["GBps"],
-                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                   "frac": g["GBps"] / HBM_PEAK_GBPS, "traffic": None,
-                                   "avg_us": g["avg_us"], "avg_us_source": KTIMER_NOTE, "launches": g["launches"],
-                                   "alg_bytes_per_launch": g["alg_bytes_per_launch"]}
-            if name != "conv2_bwd" and "conv2_bwd" in ksum:
-                # the conv2 backward pass, kept beside the dominant
-                # kernel: bf16x6 since round 3 -- 88 KB of rows per image against 23 K bf16-MFMA
-                # cycles per CU, the HBM side is the nearer ceiling
-                gb = ksum["conv2_bwd"]
-                if conv2_bwd_x6:
-                    f_hbm = gb["GBps"] / HBM_PEAK_GBPS
-                    f_mfma = gb["TFLOPs"] * 6 / BF16_MFMA_PEAK_TFLOPS
-                    out["roofline_conv2_bwd"] = {
-                        "kernel": KERNEL_NAMES["conv2_bwd_x6"],
-                        "bound": "hbm" if f_hbm >= f_mfma else "mfma",
-                        "achieved": gb["GBps"] if f_hbm >= f_mfma else gb["TFLOPs"] * 6,
-                        "peak": HBM_PEAK_GBPS if f_hbm >= f_mfma else BF16_MFMA_PEAK_TFLOPS,
-                        "unit": "GB/s" if f_hbm >= f_mfma else "TFLOP/s",
-                        "frac": max(f_hbm, f_mfma), "frac_hbm": f_hbm,
-                        "frac_of_bf16x6_ceiling": f_mfma, "alg_fp32_TFLOPs": gb["TFLOPs"],
-                        "alg_over_f32_mfma_peak": gb["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
-                        "avg_us": gb["avg_us"], "launches": gb["launches"],
-                        "alg_bytes_per_launch": gb["alg_bytes_per_launch"]}
-                else:
-                    out["roofline_conv2_bwd"] = {
-                        "kernel": KERNEL_NAMES["conv2_bwd"], "bound": "mfma",
-                        "achieved": gb["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": gb["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, "avg_us": gb["avg_us"],
-                        "launches": gb["launches"]}
-            if name != "gemm_tn" and "gemm_tn" in ksum:
-                # the largest matrix-pipe-bound kernel beside the dominant one (the two trade places
-                # from box to box: conv2 backward 195-206 us, weight gradient 187-224 us)
-                gt = ksum["gemm_tn"]
-                tt = pmc_traffic("gemm_tn", gt)
-                out["roofline_gemm_tn"] = {
-                    "kernel": names["gemm_tn"], "bound": "mfma", "achieved": gt["TFLOPs"] * 6,
-                    "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": gt["TFLOPs"] * 6 / BF16_MFMA_PEAK_TFLOPS,
-                    "frac_of_bf16x6_ceiling": gt["TFLOPs"] * 6 / BF16_MFMA_PEAK_TFLOPS,
-                    "frac_hbm": gt["GBps"] / HBM_PEAK_GBPS, "alg_fp32_TFLOPs": gt["TFLOPs"],
-                    "avg_us": gt["avg_us"], "launches": gt["launches"],
-                    "alg_bytes_per_launch": gt["alg_bytes_per_launch"],
-                    "traffic": None if tt is None else tt["bytes_per_launch"],
-                    "traffic_over_alg": None if tt is None else tt["traffic_over_alg"],
-                    "traffic_source": None if tt is None else tt["source"]}
-            # HBM traffic of that kernel from the separate rocprofv3 --pmc passes (a PMC pass
-            # cannot run inside this timed process); committed under profiles/
-            traffic = pmc_traffic(name, g)
-            if traffic is not None:
-                out["roofline"]["traffic"] = traffic["bytes_per_launch"]
-                out["roofline"]["traffic_over_alg"] = traffic["traffic_over_alg"]
-                out["roofline"]["traffic_source"] = traffic["source"]
-            tb = pmc_traffic("conv2_bwd", ksum["conv2_bwd"]) if "roofline_conv2_bwd" in out else None
-            if tb is not None and conv2_bwd_x6:
-                out["roofline_conv2_bwd"]["traffic"] = tb["bytes_per_launch"]
-                out["roofline_conv2_bwd"]["traffic_over_alg"] = tb["traffic_over_alg"]
-                out["roofline_conv2_bwd"]["traffic_source"] = tb["source"]
+            out.update(roofline_objects(ksum, rollout, T, sampler.n_groups))
             out["kernels"] = {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv)
                                   for kk, vv in v.items()} for k, v in ksum.items()}
         out["roofline_gae_scaled"] = gae_scaled_roofline()
-        if world == 1 and not args.no_kernel_timing:
-            out["roofline_rollout"] = rollout_step_roofline(B // max(sampler.n_groups, 1))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, args.cpu_baseline_B, dict(step_cost_us=args.env_cost_us))
             # the isolated hot-path functions, HIP kernel beside the CPU restatement
@@ -567,6 +488,146 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
+# roofline objects of the line: which kernel, priced how
+# ---------------------------------------------------------------------------------------------
+KTIMER_NOTE = ("HIP events around each launch, on the launching stream, in 2 iterations of the same "
+               "workload run right after the timed region (the timed region itself carries no "
+               "per-launch events: they would sit between its kernels)")
+# bench region -> kernel names as rocprofv3 prints them (profiles/r*_bench_kernel_stats.csv)
+ROCPROF_NAMES = {"conv1_fwd": ["conv1_fwd_kernel"], "conv2_fwd": ["conv2_fwd_x6_kernel"],
+                 "conv2_bwd": ["conv2_bwd_x6_kernel"], "conv1_wgrad": ["conv1_wgrad_kernel"],
+                 "gemm_nt": ["gemm_nt_x6_kernel<128>"], "gemm_nt_dgrad": ["gemm_nt_x6_kernel<256>"],
+                 "gemm_tn": ["gemm_tn_x6_kernel", "gemm_reduce_slots_kernel"],
+                 "ppo_head_loss": ["ppo_head_loss_kernel"],
+                 "sample_convs_kernel": ["sample_convs_kernel"],
+                 "rollout_fc_kernel": ["rollout_fc_kernel"],
+                 "rollout_head_kernel<2>": ["rollout_head_kernel<2>"]}
+
+
+def rocprof_kernel_stats():
+    """{kernel name substring: average us} from the newest committed rocprofv3 --kernel-trace
+    --stats summary of THIS command (profiles/r*_bench_kernel_stats.csv): the event-free,
+    in-pipeline durations.  ({} when none is committed.)"""
+    import csv
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")), reverse=True)
+    if not paths:
+        return {}, None
+    rows = {}
+    with open(paths[0]) as f:
+        for r in csv.DictReader(f):
+            rows[r["Name"]] = (float(r["AverageNs"]) * 1e-3, int(r["Calls"]))
+    return rows, os.path.relpath(paths[0], ROOT)
+
+
+def _rocprof_avg(rows, region):
+    """Average us per launch of a bench region in the rocprof summary (sum over its kernels)."""
+    tot = 0.
+    for pat in ROCPROF_NAMES.get(region, []):
+        hit = [v for k, v in rows.items() if pat in k]
+        if not hit:
+            return None
+        tot += max(hit, key=lambda v: v[1])[0]
+    return tot or None
+
+
+def price_update_kernel(name, g, names, split):
+    """Roofline object of one update-kernel region from its live HIP-event timing ``g``: an f32
+    contraction issued as split[name] bf16 MFMAs per algorithmic MAC is priced against BOTH
+    ceilings (HBM with its algorithmic bytes, the 2.5 PFLOP/s dense bf16 peak with its ISSUED flops),
+    ``bound`` = the one it sits closer to; other flop-carrying regions against the f32 MFMA peak;
+    the rest against HBM."""
+    base = {"kernel": names.get(name, name), "avg_us": g["avg_us"], "avg_us_source": KTIMER_NOTE,
+            "launches": g["launches"], "alg_bytes_per_launch": g["alg_bytes_per_launch"],
+            "traffic": None}
+    if name in split:
+        nx = split[name]
+        issued = g["TFLOPs"] * nx
+        f_hbm, f_mfma = g["GBps"] / HBM_PEAK_GBPS, issued / BF16_MFMA_PEAK_TFLOPS
+        hbm = f_hbm >= f_mfma
+        base.update({"bound": "hbm" if hbm else "mfma", "achieved": g["GBps"] if hbm else issued,
+                     "peak": HBM_PEAK_GBPS if hbm else BF16_MFMA_PEAK_TFLOPS,
+                     "unit": "GB/s" if hbm else "TFLOP/s", "frac": max(f_hbm, f_mfma),
+                     "frac_note": f"mfma side: ISSUED bf16 flops ({nx} MFMAs per algorithmic MAC) "
+                                  f"over the dense bf16 peak = the fraction of the bf16x{nx} "
+                                  f"emulation ceiling ({BF16_MFMA_PEAK_TFLOPS / nx:.0f} TFLOP/s "
+                                  "algorithmic)",
+                     "frac_hbm": f_hbm, f"frac_of_bf16x{nx}_ceiling": f_mfma,
+                     "alg_fp32_TFLOPs": g["TFLOPs"],
+                     "alg_over_f32_mfma_peak": g["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
+                     "alg_flops_per_launch": g["alg_flops_per_launch"]})
+    elif "TFLOPs" in g:
+        base.update({"bound": "mfma", "achieved": g["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": g["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
+                     "alg_flops_per_launch": g["alg_flops_per_launch"]})
+    else:
+        base.update({"bound": "hbm", "achieved": g["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": g["GBps"] / HBM_PEAK_GBPS})
+    tr = pmc_traffic(name, g)
+    if tr is not None:
+        base.update(traffic=tr["bytes_per_launch"], traffic_over_alg=tr["traffic_over_alg"],
+                    traffic_source=tr["source"])
+    return base
+
+
+def roofline_objects(ksum, rollout, T, n_groups):
+    """``roofline`` = the kernel with the largest TOTAL time over a whole timed iteration (rollout
+    kernels included: T x n_groups + n_groups launches each per iteration, against 16 of every
+    update kernel), ``roofline_update`` = the largest update kernel, ``roofline_gemm_tn`` = the
+    weight gradient (largest matrix-pipe-side kernel).  Totals use the in-pipeline averages of the
+    committed rocprofv3 summary of this command where there is one (event-free), else the live
+    measurements; every object's own ``avg_us`` / ``achieved`` is the LIVE measurement of this run."""
+    names, split = KERNEL_NAMES, BF16_SPLIT
+    rows, csv_path = rocprof_kernel_stats()
+    totals = {}
+    for k, g in ksum.items():
+        per_iter = g["launches"] / 2.                      # the timing leg runs 2 iterations
+        us = _rocprof_avg(rows, k) or g["avg_us"]
+        totals[k] = per_iter * us
+    n_roll = T * n_groups + n_groups
+    if rollout is not None:
+        for k in ("sample_convs_kernel", "rollout_fc_kernel", "rollout_head_kernel<2>"):
+            us = _rocprof_avg(rows, k) or rollout[k]["us_per_launch"]
+            totals[k] = n_roll * us
+    out = {}
+    upd = max((k for k in ksum), key=lambda k: totals[k])
+    out["roofline_update"] = price_update_kernel(upd, ksum[upd], names, split)
+    top = max(totals, key=totals.get)
+    if top in ksum:
+        out["roofline"] = dict(out["roofline_update"])
+    else:
+        r = rollout[top]
+        us_pipe = _rocprof_avg(rows, top)
+        out["roofline"] = {
+            "kernel": top + " (rollout group-step: frame-stack rebuild + conv1 + conv2 of "
+                            f"{rollout['Bg']} environments per launch, f32 MFMA)"
+            if top == "sample_convs_kernel" else top,
+            "bound": "mfma", "achieved": r["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": r["frac_f32_mfma_peak"], "frac_hbm": r["frac_hbm_peak"],
+            "avg_us": r["us_per_launch"],
+            "avg_us_source": "live, isolated: " + rollout["how"] + " (a captured graph node cannot carry "
+                             "its own events; in-pipeline average of the rocprofv3 trace of this "
+                             "command: avg_us_in_pipeline)",
+            "avg_us_in_pipeline": us_pipe, "avg_us_in_pipeline_source": csv_path,
+            "frac_in_pipeline": (r["alg_flops"] / us_pipe * 1e-6 / F32_MFMA_PEAK_TFLOPS
+                                 if us_pipe else None),
+            "launches_per_iteration": n_roll, "alg_flops_per_launch": r["alg_flops"],
+            "alg_bytes_per_launch": r["alg_bytes"], "traffic": r.get("traffic"),
+            "traffic_source": r.get("traffic_source"),
+            "note": "latency-class launch (64 environments): the empty-launch floor is "
+                    f"{rollout['empty_launch_us']} us of its {r['us_per_launch']} us"}
+    out["roofline"]["share_of_iteration_kernel_time"] = totals[top] / max(sum(totals.values()), 1e-9)
+    out["roofline"]["selection"] = ("largest total kernel time per iteration; per-launch averages for the "
+                                    "ranking from " + (csv_path or "this run's live timings"))
+    if upd != "gemm_tn" and "gemm_tn" in ksum:
+        out["roofline_gemm_tn"] = price_update_kernel("gemm_tn", ksum["gemm_tn"], names, split)
+    if upd != "conv2_bwd" and "conv2_bwd" in ksum:
+        out["roofline_conv2_bwd"] = price_update_kernel("conv2_bwd", ksum["conv2_bwd"], names, split)
+    return out
+
 
 
 def _rccl_version():
@@ -585,7 +646,10 @@ def dry_run(args, rank, world, local_rank, cpus, workers, block):
     backend = args.backend if torch.cuda.is_available() and not args.same_gpu else "gloo"
     info = dict(rank=rank, device=0 if args.same_gpu else local_rank,
                 cpu_quota_share=round(cpus / world, 2), env_workers=workers,
-                cpu_block=[block[0], block[-1]], pid=os.getpid())
+                cpu_block=[block[0], block[-1]], pid=os.getpid(),
+                # filled by a real run (per rank): see multi_gpu.ranks[] of the bench line
+                rollout_ms=None, update_ms=None, ms_per_time_step=None,
+                update_ms_ddp_sync=None, update_ms_no_sync=None, allreduce_exposed_ms=None)
     ranks = [info]
     if world > 1:
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -708,15 +772,22 @@ def rollout_step_roofline(Bg=64, T=128, B=256):
                      "frac_hbm_peak": round(nbytes / us * 1e-3 / HBM_PEAK_GBPS, 4),
                      "traffic": None}
     out["chain_us_per_group_step"] = round(total, 2)
-    # HBM traffic from the PMC passes over scripts/r4_step_microbench.py, when committed
+    # HBM traffic from the PMC passes over scripts/step_microbench.py (scripts/rollout_pmc.sh), newest
+    # committed file.  rollout_fc's weight rows are read as 64-byte runs: for that pattern the raw
+    # FETCH_SIZE already equals the bytes (7.1 MB = W once), the guide's x2 is for wide 16 B/lane
+    # streams -- it gets the raw figure, the other two the corrected one.
     try:
-        with open(os.path.join(ROOT, "profiles", "r4_rollout_pmc.json")) as f:
+        import glob
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rollout_pmc.json")))[-1]
+        with open(path) as f:
             pmc = json.load(f)
         for name in rows:
-            if name in pmc.get("kernels", {}):
-                out[name]["traffic"] = pmc["kernels"][name]["hbm_bytes_corrected"]
-                out[name]["traffic_source"] = "profiles/r4_rollout_pmc.json"
-    except (OSError, ValueError):
+            k = pmc.get("kernels", {}).get(name)
+            if k:
+                raw = k.get("hbm_bytes_raw", int((k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024))
+                out[name]["traffic"] = raw if name == "rollout_fc_kernel" else k["hbm_bytes_corrected"]
+                out[name]["traffic_source"] = os.path.relpath(path, ROOT)
+    except (OSError, ValueError, IndexError):
         pass
     return out
 

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-4 rollout A/Bs on ONE box (interleaved): the re-tiled trunk / head kernels and the in-place
-# action hand-off against round 3's device chain, then worker / group counts on the new chain.
-# usage: scripts/r4_rollout_ab.sh <out.jsonl> [quick]
+# Interleaved A/B runs of the default bench on ONE box: `source scripts/ab_lib.sh; OUT=...jsonl;
+# [ENV=..] run <tag> [bench args]` appends one summary line per run (SPS, ms per time step, the
+# sampler's per-batch phases, worker wait / step split).
 run() {
   local tag="$1"; shift
   local line

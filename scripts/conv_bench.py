@@ -37,6 +37,7 @@ def main():
     w1, b1, w2, b2 = (p.detach().contiguous() for p in (c1.weight, c1.bias, c2.weight, c2.bias))
     y1 = torch.empty((M, 475, 16), device="cuda")
     y2 = torch.empty((M, 3456), device="cuda")
+    mask2 = torch.empty((M, 128), dtype=torch.int32, device="cuda")
     g2 = torch.randn(M, 3456, device="cuda")
     dy1 = torch.empty_like(y1)
     ws = torch.empty(lib.rlpyt_atari_conv_wgrad_workspace_bytes(), dtype=torch.uint8, device="cuda")
@@ -47,16 +48,9 @@ def main():
         "conv1_fwd": (lambda: check(lib.rlpyt_atari_conv1_fwd_f32(
             ptr(obs), ptr(idx), T, B, M, ptr(w1), ptr(b1), 1. / 255, ptr(y1), st)), ops._FL_C1),
         "conv2_fwd": (lambda: check(lib.rlpyt_atari_conv2_fwd_f32(
-            ptr(y1), M, ptr(w2), ptr(b2), ptr(y2), st)), ops._FL_C2),
-        "conv2_dgrad": (lambda: check(lib.rlpyt_atari_conv2_dgrad_f32(
-            ptr(g2), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1), st)), ops._FL_C2D),
-        "conv2_wgrad": (lambda: check(lib.rlpyt_atari_conv2_wgrad_f32(
-            ptr(g2), ptr(y2), ptr(y1), M, ptr(ws), ptr(dw2), ptr(db2), st)), ops._FL_C2),
-        "conv2_bwd_fused": (lambda: check(lib.rlpyt_atari_conv2_bwd_f32(
-            ptr(g2), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1), ptr(ws), ptr(dw2), ptr(db2), st)),
-            ops._FL_C2D + ops._FL_C2),
+            ptr(y1), M, ptr(w2), ptr(b2), ptr(y2), ptr(mask2), st)), ops._FL_C2),
         "conv2_bwd_x6": (lambda: check(lib.rlpyt_atari_conv2_bwd_x6_f32(
-            ptr(g2), ptr(y2), ptr(y1), M, ptr(w2), ptr(dy1), ptr(ws), ptr(dw2), ptr(db2), st)),
+            ptr(g2), ptr(mask2), ptr(y1), M, ptr(w2), ptr(dy1), ptr(ws), ptr(dw2), ptr(db2), st)),
             ops._FL_C2D + ops._FL_C2),
         "conv1_wgrad": (lambda: check(lib.rlpyt_atari_conv1_wgrad_f32(
             ptr(obs), ptr(idx), T, B, M, ptr(dy1), 1. / 255, ptr(ws), ptr(dw1), ptr(db1), st)),

@@ -35,13 +35,11 @@ w = torch.randn(N, K, device="cuda") * 0.02
 g = torch.randn(M, N, device="cuda")
 fl = 2 * M * N * K
 res = {"shape": {"M": M, "N": N, "K": K, "GFLOP": fl / 1e9}}
-res["fwd_nt_warp_specialised"] = entry(timeit(lambda: ops.gemm_nt(x, w, pingpong=True)), fl)
-res["fwd_nt_lockstep"] = entry(timeit(lambda: ops.gemm_nt(x, w, pingpong=False)), fl)
+res["fwd_nt_lockstep"] = entry(timeit(lambda: ops.gemm_nt(x, w)), fl)
 res["fwd_torch_f32"] = entry(timeit(lambda: torch.mm(x, w.t())), fl)
-res["dgrad_nn_warp_specialised"] = entry(timeit(lambda: ops.gemm_nn(g, w)), fl)
 wt = w.t().contiguous()
-res["dgrad_nt_lockstep_on_transposed_w"] = entry(timeit(lambda: ops.gemm_nt(g, wt, pingpong=False)), fl)
+res["dgrad_nt_lockstep_on_transposed_w"] = entry(timeit(lambda: ops.gemm_nt(g, wt)), fl)
 res["dgrad_torch_f32"] = entry(timeit(lambda: torch.mm(g, w)), fl)
-res["wgrad_tn_warp_specialised_split_k"] = entry(timeit(lambda: ops.gemm_tn(g, x)), fl)
+res["wgrad_tn_lockstep_split_k"] = entry(timeit(lambda: ops.gemm_tn(g, x)), fl)
 res["wgrad_torch_f32"] = entry(timeit(lambda: torch.mm(g.t(), x)), fl)
 print(json.dumps(res))

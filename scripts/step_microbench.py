@@ -1,6 +1,6 @@
 """Steady-state time of each rollout-step kernel in isolation: N back-to-back launches of ONE kernel
 captured in a hipGraph, replayed; HIP-event time / launches.  Separates the kernels' own time from
-the hand-off chain around them.  usage: r4_step_microbench.py [Bg=64]"""
+the hand-off chain around them.  usage: step_microbench.py [Bg=64]"""
 import json
 import os
 import sys
@@ -56,11 +56,6 @@ def main():
     out["sample_convs"] = timed(lambda: ops.atari_sample_convs(
         obs, t_dev, 0, new_frame, full_rows, slot, c1.weight, c1.bias, c2.weight, c2.bias,
         scalar_rows=(rew, rs, dn, ds), out=y2))
-    out["fc_small_v1"] = timed(lambda: ops.fc_small_partials(feat, lin.weight))
-    p1, k1 = ops.fc_small_partials(feat, lin.weight)
-    out["head_v1"] = timed(lambda: ops.pg_sample_head(p1, k1, lin.bias, m.pi.weight, m.pi.bias,
-                                                      m.value.weight, m.value.bias, u, t_dev, Bg, prob,
-                                                      value, action, 0, action_out))
     out["rollout_fc"] = timed(lambda: ops.rollout_fc_partials(feat, lin.weight))
     p2, k2 = ops.rollout_fc_partials(feat, lin.weight)
     out["rollout_head"] = timed(lambda: ops.rollout_head(p2, k2, lin.bias, m.pi.weight, m.pi.bias,
@@ -72,21 +67,13 @@ def main():
     eps = torch.full((1,), 0.1, device="cuda")
     out["eps_greedy_tiny"] = timed(lambda: ops.eps_greedy(q, eps, u, t_dev))
 
-    def chain_v1():
-        f = ops.atari_sample_convs(obs, t_dev, 0, new_frame, full_rows, slot, c1.weight, c1.bias,
-                                   c2.weight, c2.bias, scalar_rows=(rew, rs, dn, ds), out=y2)
-        p, k = ops.fc_small_partials(f, lin.weight)
-        ops.pg_sample_head(p, k, lin.bias, m.pi.weight, m.pi.bias, m.value.weight, m.value.bias, u,
-                           t_dev, Bg, prob, value, action, 0, action_out)
-
-    def chain_v2():
+    def chain():
         f = ops.atari_sample_convs(obs, t_dev, 0, new_frame, full_rows, slot, c1.weight, c1.bias,
                                    c2.weight, c2.bias, scalar_rows=(rew, rs, dn, ds), out=y2)
         p, k = ops.rollout_fc_partials(f, lin.weight)
         ops.rollout_head(p, k, lin.bias, m.pi.weight, m.pi.bias, m.value.weight, m.value.bias, u,
                          t_dev, Bg, prob, value, action, 0, action_out)
-    out["chain_v1_per_step"] = round(timed(chain_v1, n_inner=8) , 2)
-    out["chain_v2_per_step"] = round(timed(chain_v2, n_inner=8), 2)
+    out["chain_per_step"] = round(timed(chain, n_inner=8), 2)
     print(json.dumps(out))
 
 

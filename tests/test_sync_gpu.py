@@ -38,12 +38,12 @@ def _spaces():
                      action=IntBox(0, A))
 
 
-def _agent():
+def _agent(device=0):
     from rlpyt_amd.agents.pg.atari import AtariFfAgent
     torch.manual_seed(INIT_SEED)
     agent = AtariFfAgent()
     agent.initialize(_spaces())
-    agent.to_device(0)
+    agent.to_device(device)
     return agent
 
 
@@ -73,17 +73,20 @@ def _flat(agent):
     return torch.cat([p.detach().reshape(-1) for p in agent.parameters()]).cpu()
 
 
-def _rank_main(rank, world_size, port, outdir, T, B):
+def _rank_main(rank, world_size, port, outdir, T, B, backend="gloo"):
+    """``backend="nccl"`` (RCCL): rank r on cuda:r, as rlpyt/runners/sync_rl.py:60-101 places them."""
     import torch.distributed as dist
     from rlpyt_amd import _lib
     from rlpyt_amd.algos.pg.ppo import PPO
     from rlpyt_amd.samplers.collections import BatchSpec
     from rlpyt_amd.utils import logger
     logger.set_quiet(True)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world_size,
+    device = rank if backend == "nccl" else 0
+    torch.cuda.set_device(device)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend, rank=rank, world_size=world_size,
                             init_method=f"tcp://127.0.0.1:{port}")
-    agent = _agent()
+    agent = _agent(device)
     samples = _samples(agent, rank, T, B)    # BEFORE the DDP wrap: same forward on every rank
     agent.data_parallel()
     algo = PPO(**PPO_KW)
@@ -178,6 +181,30 @@ def test_two_ranks_product_ppo_matches_mean_gradient_run(tmp_path, T, B):
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-6)
     moved = (r0["params"][-1] - _flat(_agent())).abs().max().item()
     assert moved > 1e-4        # the updates were not no-ops
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank "
+                    "(two ranks on one GPU: 'Duplicate GPU detected', profiles/r4_two_rank_nccl_same_gpu.txt)")
+def test_two_ranks_product_ppo_over_rccl(tmp_path):
+    """The same two-rank run with the process group on RCCL (backend "nccl"), rank r on cuda:r --
+    the configuration ``bench.py --gpus N`` and ``SyncRl`` run on a multi-GPU node: DDP over RCCL
+    with the custom autograd Functions of the product path.  Needs >= 2 devices (skipped on the
+    1-GPU test boxes; the gloo twin above covers the same code on one device)."""
+    import torch.multiprocessing as tmp
+    T, B = SHAPES[1]
+    tmp.spawn(_rank_main, args=(2, 29547, str(tmp_path), T, B, "nccl"), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    assert r0["ddp"] == r1["ddp"] == "DistributedDataParallel"
+    assert r0["info"][0]["loss"] != r1["info"][0]["loss"]        # different data per rank
+    for p0, p1 in zip(r0["params"], r1["params"]):
+        assert torch.equal(p0, p1)                               # same model after every iteration
+    ref_params, _ = _one_process_mean_gradient_run(T, B)
+    for got, ref in zip(r0["params"], ref_params):
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-6)
+    for k in ("gemm_nt_x6_kernel<128>", "gemm_tn_x6_kernel", "conv2_bwd_x6_kernel",
+              "ppo_head_loss_kernel<8, 6, true>"):
+        assert r0["variants"].get(k, 0) > 0 and r1["variants"].get(k, 0) > 0, k
 
 
 def _sync_rl_rank(rank, world_size, outdir):
