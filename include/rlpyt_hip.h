@@ -68,9 +68,6 @@ int rlpyt_host_unregister(void* host_ptr);
  * address space): kernels may read the workers' newest frames and write the sampled actions
  * in place -- no staging copy, no DMA descriptor latency on the per-step critical path. */
 int rlpyt_host_device_pointer(void* host_ptr, void** dev_ptr);
-/* 1 when the current device supports hipStreamWriteValue32 / hipStreamWaitValue32 (the completion
- * marker of rlpyt_sampler_serve's done_word), else 0. */
-int rlpyt_stream_write_value_supported(void);
 
 /* Step hand-off between the sampler master and its forked env workers: replaces the
  * 2 x n_workers semaphores per time step of rlpyt/samplers/parallel/gpu/action_server.py:44-58
@@ -361,8 +358,7 @@ int rlpyt_categorical_head_f32(const float* h /*[n,K]*/, const float* w_pi /*[A,
  * group cycles on its own -- env workers arrived (obs_word reached rounds * n_workers) ->
  * enqueue the H2D copies of the page-locked step buffer (frame-stacked envs: newest frames +
  * the full stack of reset envs, t == 0: all full stacks), hipGraphLaunch, enqueue the D2H
- * action copies, completion marker (stream write of done_word, or `event`) -> marker seen ->
- * rlpyt_seq_post(act_word) --
+ * action copies, record `event` -> event fired (hipEventQuery) -> rlpyt_seq_post(act_word) --
  * and the caller's thread services whichever hand-off is ready, so groups overlap freely and
  * may be at different time steps (each step's index reaches the device through t_host).
  * Returns RLPYT_ETIMEOUT after timeout_ms without any progress.  `acts` / `rounds`
@@ -394,15 +390,13 @@ typedef struct rlpyt_step_group {
   int64_t* t_host;  /* host, inside the page-locked misc block: receives the step index */
   void* graph_exec; /* hipGraphExec_t */
   void* stream;     /* hipStream_t */
-  void* event;      /* hipEvent_t (completion when done_word is NULL) */
-  /* completion word (nullable): page-locked host word + its device-mapped address.  When set, the
-   * step's completion is a hipStreamWriteValue32 of the step's sequence number behind the graph
-   * (the command processor writes it once the graph's kernels have retired) and the retiring
-   * thread polls plain memory -- no hipEventRecord / hipEventQuery on the hand-off chain. */
-  volatile uint32_t* done_word;
-  void* done_word_dev;
-  uint32_t done_seq; /* last sequence number handed out (updated in place) */
-  uint32_t reserved2;
+  void* event;      /* hipEvent_t */
+  /* tail pass (nullable): hipGraphExec_t run ONCE per group after step t_end - 1, behind the same
+   * uploads with *t_host = t_end, when the workers' arrival after their last env step is in: the
+   * bootstrap value / reward and done rows of the observation the batch ends on
+   * (rlpyt/samplers/parallel/gpu/action_server.py:60-62).  No actions are published for it;
+   * `rounds` advances by t_end - t_begin + 1 instead of t_end - t_begin. */
+  void* tail_graph_exec;
 } rlpyt_step_group;
 int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t_begin, int t_end,
                         int spin_iters, int timeout_ms, double* timing /*[8], nullable*/);

@@ -33,8 +33,7 @@ class StepGroup(ctypes.Structure):
                 ("reset_flags", c_void_p), ("slot_host", c_void_p), ("full_rows_dev", c_void_p),
                 ("obs_host", c_void_p), ("row_bytes", c_int64), ("t_host", c_void_p),
                 ("graph_exec", c_void_p),
-                ("stream", c_void_p), ("event", c_void_p), ("done_word", c_void_p),
-                ("done_word_dev", c_void_p), ("done_seq", c_uint32), ("reserved2", c_uint32)]
+                ("stream", c_void_p), ("event", c_void_p), ("tail_graph_exec", c_void_p)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -74,7 +73,6 @@ _SIGNATURES = {
     "rlpyt_host_register": (c_int, [_p, c_int64]),
     "rlpyt_host_unregister": (c_int, [_p]),
     "rlpyt_host_device_pointer": (c_int, [_p, POINTER(c_void_p)]),
-    "rlpyt_stream_write_value_supported": (c_int, []),
     "rlpyt_seq_wait": (c_int, [_p, c_uint32, c_int, c_int]),
     "rlpyt_seq_post": (c_int, [_p, c_uint32]),
     "rlpyt_seq_arrive": (c_int, [_p, c_uint32]),

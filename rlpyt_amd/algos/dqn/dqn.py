@@ -24,6 +24,10 @@ class DQN(RlAlgorithm):
     opt_info_fields = tuple(OptInfo._fields)
     OptInfoCls = OptInfo
     SEQUENCE_REPLAY = False
+    # one update = one captured hipGraph once the optimizer state exists (algos/dqn/captured.py);
+    # subclasses whose update is not ``sample_batch -> loss -> clip_and_step`` switch it off
+    CAPTURABLE = True
+    _captured = None
 
     def __init__(self, discount=0.99, batch_size=32, min_steps_learn=int(5e4), delta_clip=1.,
                  replay_size=int(1e6), replay_ratio=8, target_update_tau=1,
@@ -40,6 +44,7 @@ class DQN(RlAlgorithm):
         self._batch_size = hp.pop("batch_size")
         self.__dict__.update(hp)
         self.update_counter = 0
+        self._captured = None
 
     # ------------------------------------------------------------------ set-up
     def initialize(self, agent, n_itr, batch_spec, mid_batch_reset, examples, world_size=1,
@@ -96,11 +101,15 @@ class DQN(RlAlgorithm):
             self.ingest(samples)
         log = UpdateLog(self.OptInfoCls, ("loss", "gradNorm"))
         if itr >= self.min_itr_learn:
-            for _ in range(self.updates_per_optimize):
-                self.one_update(log)
-                self.update_counter += 1
-                if self.update_counter % self.target_update_interval == 0:
-                    self.agent.update_target(self.target_update_tau)
+            if self._captured is None:
+                from .captured import CapturedUpdates
+                self._captured = CapturedUpdates(self)
+            if not self._captured.run(itr, log):
+                for _ in range(self.updates_per_optimize):
+                    self.one_update(log)
+                    self.update_counter += 1
+                    if self.update_counter % self.target_update_interval == 0:
+                        self.agent.update_target(self.target_update_tau)
             if self.beta is not None:
                 new_beta = self.beta.at(itr)
                 if new_beta is not None:

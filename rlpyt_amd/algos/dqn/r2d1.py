@@ -26,6 +26,7 @@ class R2D1(DQN):
     opt_info_fields = tuple(OptInfo._fields)
     OptInfoCls = OptInfo
     SEQUENCE_REPLAY = True
+    CAPTURABLE = False      # sequence batches: three outputs of ``loss``, kernel-bound updates
 
     def __init__(self, discount=0.997, batch_T=80, batch_B=64, warmup_T=40,
                  store_rnn_state_interval=40, min_steps_learn=int(1e5), delta_clip=None,

@@ -92,6 +92,13 @@ class UpdateLog:
         for name, v in vectors.items():
             self.vectors[name].append(v.reshape(-1))
 
+    def add_rows(self, rows, **vectors):
+        """Several updates at once: ``rows [k, n_scalars]`` and ``[k, m]`` vector diagnostics, all
+        device tensors (the rings a captured update graph writes; cloned: the rings are reused)."""
+        self.rows.extend(rows.detach().float().clone().unbind(0))
+        for name, v in vectors.items():
+            self.vectors[name].append(v.detach().clone().reshape(-1))
+
     def to_opt_info(self):
         out = {f: [] for f in self.OptInfo._fields}
         if self.rows:

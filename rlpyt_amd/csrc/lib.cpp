@@ -131,14 +131,6 @@ extern "C" int rlpyt_host_device_pointer(void* host_ptr, void** dev_ptr) {
   return RLPYT_OK;
 }
 
-extern "C" int rlpyt_stream_write_value_supported(void) {
-  int dev = 0, can = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess)
-    return 0;
-  return can != 0;
-}
-
 extern "C" int rlpyt_host_unregister(void* host_ptr) {
   RL_CHECK_ARG(host_ptr != nullptr, RLPYT_EINVAL, "rlpyt_host_unregister: null pointer");
   RL_HIP(hipHostUnregister(host_ptr));

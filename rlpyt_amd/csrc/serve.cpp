@@ -3,8 +3,8 @@
 // per-step device work is a captured hipGraph.  Per step and pipeline group it waits for the
 // env workers (futex sequence word), enqueues the H2D copies of the page-locked step buffer,
 // launches the group's graph, enqueues the D2H copy of the actions (none when the head kernel
-// writes them in place) and a completion marker -- a stream write of a page-locked word, or an
-// event; when the marker is seen it publishes the actions to the workers.
+// writes them in place) and records an event; when the event has fired it publishes the actions to
+// the workers.
 // Running this loop in C removes ~20 interpreter-level calls per group-step from the critical
 // path (the device work of a step is ~100 us, so they were of the same order).
 #include <hip/hip_runtime.h>
@@ -32,7 +32,7 @@ namespace {
 inline bool reached(uint32_t cur, uint32_t target) { return (int32_t)(cur - target) >= 0; }
 
 // Host-dependent uploads + graph launch + action download of one group-step.
-int issue_group_step(rlpyt_step_group& g, int t) {
+int issue_group_step(rlpyt_step_group& g, int t, bool tail) {
   hipStream_t s = (hipStream_t)g.stream;
   *g.t_host = t;
   if (g.dedup) {
@@ -58,18 +58,16 @@ int issue_group_step(rlpyt_step_group& g, int t) {
   for (int i = 0; i < g.n_h2d; ++i)
     RL_HIP(hipMemcpyAsync(g.h2d[i].dst, g.h2d[i].src, (size_t)g.h2d[i].nbytes,
                           hipMemcpyHostToDevice, s));
-  RL_HIP(hipGraphLaunch((hipGraphExec_t)g.graph_exec, s));
-  for (int i = 0; i < g.n_d2h; ++i)
+  // tail: the pass on the observation AFTER the last step of the batch (bootstrap value, reward /
+  // done rows T; action_server.py:60-62) -- same uploads, its own graph, no actions come back
+  RL_HIP(hipGraphLaunch((hipGraphExec_t)(tail ? g.tail_graph_exec : g.graph_exec), s));
+  for (int i = 0; i < (tail ? 0 : g.n_d2h); ++i)
     RL_HIP(hipMemcpyAsync(g.d2h[i].dst, g.d2h[i].src, (size_t)g.d2h[i].nbytes,
                           hipMemcpyDeviceToHost, s));
-  if (g.done_word != nullptr) {
-    // completion marker written by the command processor behind the graph (and the D2H copies):
-    // the retiring thread polls plain memory -- no event record here, no hipEventQuery there
-    g.done_seq += 1;
-    RL_HIP(hipStreamWriteValue32(s, g.done_word_dev, g.done_seq, 0));
-  } else {
-    RL_HIP(hipEventRecord((hipEvent_t)g.event, s));
-  }
+  // (completion through hipStreamWriteValue32 of a page-locked word + a memory poll instead of
+  // event record / query was built and measured in round 5: the chain's device leg grew from 67-71
+  // to 87-90 us per group-step, 843-870 K -> 769-781 K SPS, profiles/r5_ab_completion_marker.jsonl)
+  RL_HIP(hipEventRecord((hipEvent_t)g.event, s));
   return RLPYT_OK;
 }
 }  // namespace
@@ -126,25 +124,23 @@ void retire_loop(ServeShared* sh) {
     for (int gi = 0; gi < sh->n_groups; ++gi) {
       if (sh->state[gi].load(std::memory_order_acquire) != WAIT_DEV) continue;
       rlpyt_step_group& g = sh->groups[gi];
-      if (g.done_word != nullptr) {
-        // (the WAIT_DEV state was published with release after done_seq was bumped)
-        if (__atomic_load_n(g.done_word, __ATOMIC_ACQUIRE) != g.done_seq) {
-          in_flight = true;
-          continue;
-        }
-      } else {
-        const hipError_t q = hipEventQuery((hipEvent_t)g.event);
-        if (q == hipErrorNotReady) {
-          in_flight = true;
-          continue;
-        }
-        if (q != hipSuccess) {
-          rlpyt::set_error("rlpyt_sampler_serve: hipEventQuery: %s", hipGetErrorString(q));
-          sh->error.store(RLPYT_EHIP);
-          return;
-        }
+      const hipError_t q = hipEventQuery((hipEvent_t)g.event);
+      if (q == hipErrorNotReady) {
+        in_flight = true;
+        continue;
+      }
+      if (q != hipSuccess) {
+        rlpyt::set_error("rlpyt_sampler_serve: hipEventQuery: %s", hipGetErrorString(q));
+        sh->error.store(RLPYT_EHIP);
+        return;
       }
       const double t_seen = now_s();
+      if (sh->tcur[gi] == sh->t_end) {      // that was the tail pass: nothing to publish
+        sh->state[gi].store(DONE, std::memory_order_release);
+        sh->remaining.fetch_sub(1, std::memory_order_acq_rel);
+        progressed = true;
+        continue;
+      }
       g.acts += 1;
       // CLOCK_MONOTONIC ns of this post, next to the sequence word: a worker that had to wait
       // measures its wake-up latency against it (csrc/envloop.c)
@@ -154,10 +150,10 @@ void retire_loop(ServeShared* sh) {
       sh->lat_device += t_seen - sh->t_issued[gi];
       sh->lat_post += now_s() - t_seen;
       sh->n_steps += 1;
-      if (++sh->tcur[gi] == sh->t_end) {
+      if (++sh->tcur[gi] == sh->t_end && g.tail_graph_exec == nullptr) {
         sh->state[gi].store(DONE, std::memory_order_release);
         sh->remaining.fetch_sub(1, std::memory_order_acq_rel);
-      } else {
+      } else {               // next step -- or, at t_end, the tail pass -- once the workers arrived
         g.rounds += 1;
         sh->state[gi].store(WAIT_OBS, std::memory_order_release);
       }
@@ -216,7 +212,7 @@ extern "C" int rlpyt_sampler_serve(rlpyt_step_group* groups, int n_groups, int t
         continue;
       }
       const double t0 = now_s();
-      const int rc = issue_group_step(g, sh.tcur[gi]);
+      const int rc = issue_group_step(g, sh.tcur[gi], sh.tcur[gi] == t_end);
       if (rc != RLPYT_OK) {
         sh.error.store(rc);
         break;

@@ -121,6 +121,23 @@ class ReplayBuffer:
             return batch
         return (SeqBatchPri if self.SEQUENCE else StepBatchPri)(*batch, is_weights=weights)
 
+    def can_sample_on_device(self):
+        """True when a batch can be drawn without any host work inside the draw (captured update
+        graphs): single-step batches, non-unique priority draws or plain index pairs."""
+        return not self.SEQUENCE and not getattr(self.draws, "unique", False)
+
+    def sample_batch_device(self, batch_B, uniforms=None, idxs=None, beta=None):
+        """``sample_batch`` with the randomness handed in as DEVICE tensors at fixed addresses --
+        ``uniforms`` (f64 ``[batch_B]``, prioritized: what ``np.random.rand`` would have produced)
+        or ``idxs`` (``(T_idxs, B_idxs)`` int64, uniform replay) -- and the importance exponent as a
+        device scalar ``beta``: every step is a kernel launch on the current stream, so the call
+        can sit inside a captured hipGraph (``algos/dqn/captured.py``)."""
+        assert self.can_sample_on_device()
+        if self.PRIORITIZED:
+            T_idxs, B_idxs, weights = self.draws.draw_device(uniforms, beta)
+            return StepBatchPri(*self._steps(T_idxs, B_idxs), is_weights=weights)
+        return self._steps(*idxs)
+
     def update_batch_priorities(self, priorities):
         self.draws.update(priorities)
 

@@ -95,6 +95,15 @@ class PriorityDraw:
         w = (1. / (pri + self.weight_eps)) ** self.beta
         return T_idxs, B_idxs, (w / w.max()).float()
 
+    def draw_device(self, uniforms, beta):
+        """``draw`` from device-resident uniforms (f64 ``[n]``) with the importance exponent as a
+        device scalar: no host work, capturable."""
+        T_idxs, B_idxs, pri = self.tree.sample(uniforms)
+        if self.stride > 1:
+            T_idxs = T_idxs * self.stride
+        w = torch.pow(1. / (pri + self.weight_eps), beta.to(pri.dtype))
+        return T_idxs, B_idxs, (w / w.max()).float()
+
     def update(self, priorities):
         """New priorities of the last drawn batch: ``** alpha`` in the caller's dtype (as numpy does
         in the reference), then the f64 tree update."""

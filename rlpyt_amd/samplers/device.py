@@ -161,6 +161,7 @@ class DeviceBatch:
     def release(self):
         for G in self.groups:
             G.graph = None
+            G.tail_graph = None
         if self.pinned_ptrs:
             from .. import _lib
             for p in self.pinned_ptrs:
@@ -281,13 +282,7 @@ class DeviceBatch:
             copy_leaves(G.action_out, action)
 
     # ------------------------------------------------------------------ end of batch
-    def tail_fused(self, G):
-        """The tail as ONE more step of the group's fused kernels (non-recurrent agents that ignore
-        prev inputs, frame-stacked uploads, mid-batch reset): upload the newest frames + misc
-        block with t = T, rebuild obs_T into the staging buffer, commit reward / done rows T, and
-        run trunk + VALUE head only -> bootstrap_value[0, lo:hi].  Returns False when it does not
-        apply (the caller then runs ``tail_body``)."""
-        T = self.batch_spec.T
+    def _tail_fused_applies(self, G):
         s, agent, opts = self.samples, self.agent, self.opts
         if not (self.cuda and G.dedup and G.u_all is not None and opts.mid_batch_reset
                 and opts.fused_step and opts.fused_push
@@ -296,13 +291,49 @@ class DeviceBatch:
                 and hasattr(agent, "value_into") and isinstance(self.all_action, torch.Tensor)):
             return False
         bv = s.agent.bootstrap_value
-        if not (isinstance(bv, torch.Tensor) and bv.dtype == torch.float32 and bv.is_contiguous()):
+        return isinstance(bv, torch.Tensor) and bv.dtype == torch.float32 and bv.is_contiguous()
+
+    def _tail_fused_device(self, G):
+        """Device part of the fused tail (capturable: fixed addresses, t = T arrives in the misc
+        block): rebuild obs_T into the staging buffer, commit reward / done rows T, trunk + VALUE
+        head only -> bootstrap_value[0, lo:hi]."""
+        self.agent.select_envs(G.lo, G.hi)
+        bv = self.samples.agent.bootstrap_value
+        return bool(self.agent.value_into(self._push_binding(G), G.obs_stage, bv[0, G.lo:G.hi]))
+
+    def tail_fused(self, G):
+        """The tail as ONE more step of the group's fused kernels (non-recurrent agents that ignore
+        prev inputs, frame-stacked uploads, mid-batch reset): upload the newest frames + misc
+        block with t = T, then ``_tail_fused_device`` -- eagerly the first time, as a captured
+        hipGraph from the second batch on (which is also what lets the C serve loop run the tail
+        itself, ``NativeServe``).  Returns False when it does not apply (the caller then runs
+        ``tail_body``)."""
+        if not self._tail_fused_applies(G):
             return False
-        G.t_np[0] = T
+        G.t_np[0] = self.batch_spec.T
         self.upload_special(G, first=False)
         self.upload_steady(G)
-        agent.select_envs(G.lo, G.hi)
-        return bool(agent.value_into(self._push_binding(G), G.obs_stage, bv[0, G.lo:G.hi]))
+        if G.get("tail_graph") is not None:
+            G.tail_graph.replay()
+            return True
+        if self.use_graph and G.get("tail_calls", 0) >= 1:
+            try:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=G.stream, capture_error_mode="thread_local"):
+                    ok = self._tail_fused_device(G)
+                if ok:
+                    G.tail_graph = graph
+                    graph.replay()
+                    return True
+            except Exception as e:  # noqa: BLE001  (the eager tail is correct)
+                logger.log(f"GpuSampler: tail-graph capture failed ({type(e).__name__}: {e}); "
+                           "eager bootstrap pass.")
+                torch.cuda.synchronize()
+            G.tail_calls = -(1 << 30)          # do not try again
+        ok = self._tail_fused_device(G)
+        G.tail_calls = G.get("tail_calls", 0) + 1
+        return ok
 
     def tail_body(self, G):
         """After the last env step of the batch: commit reward/done of step T-1 and compute

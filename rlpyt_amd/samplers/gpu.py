@@ -324,15 +324,17 @@ class GpuSampler(BaseSampler):
         dev.begin_batch()
         tp1 = time.perf_counter()
         native = self._native_serve()
+        tail_done = False
         if native is not None:
-            native.serve(T, tm)
+            tail_done = native.serve(T, tm)       # (with captured tail graphs: the tail too)
         else:
             serve_python(dev, self.sync if par else None, self.runners[0], T, tm, completed)
         tp2 = time.perf_counter()
-        for G in self.groups:
-            if par:
-                self.sync.master_wait_obs(G.idx)
-            dev.tail(G)
+        if not tail_done:
+            for G in self.groups:
+                if par:
+                    self.sync.master_wait_obs(G.idx)
+                dev.tail(G)
         dev.synchronize()
         # end of batch: null the prev action / reward the next batch starts from where the
         # env finished (action_server.py:63-68); ``done`` stays set as the carry flag.

@@ -46,9 +46,8 @@ class NativeServe:
     """Group table of ``rlpyt_sampler_serve`` + the call.  ``build`` returns None when the native
     loop does not apply (a group without a captured, RNG-free graph; too many copy descriptors)."""
 
-    def __init__(self, table, dev, sync, world_size, done_words=None):
+    def __init__(self, table, dev, sync, world_size):
         self.table, self.dev, self.sync = table, dev, sync
-        self.done_words = done_words        # page-locked completion words (kept alive here)
         self.tmg = (ctypes.c_double * 8)()
         self.spin = None
         self.world_size = world_size
@@ -60,11 +59,6 @@ class NativeServe:
         if not all(G.graph is not None and G.u_all is not None for G in groups):
             return None
         arr = (_lib.StepGroup * len(groups))()
-        # completion marker: one page-locked word per group, written by the command processor behind
-        # the step's graph (hipStreamWriteValue32) and polled as plain memory by the retiring thread
-        # -- no hipEventRecord / hipEventQuery on the hand-off chain.  RLPYT_SERVE_EVENT=1 (or a
-        # device without stream write-value): the event path.
-        done_words = cls._done_words(len(groups), dev)
         for G, sg in zip(groups, arr):
             sg.act_word, sg.obs_word = sync.act[G.idx], sync.obs[G.idx]
             sg.n_workers = G.n_workers
@@ -98,38 +92,8 @@ class NativeServe:
             sg.stream = stream.cuda_stream
             G.event.record(stream)
             sg.event = G.event.cuda_event
-            if done_words is not None:
-                host, dptr = done_words
-                sg.done_word = host.ctypes.data + 64 * G.idx
-                sg.done_word_dev = dptr + 64 * G.idx
-                sg.done_seq = 0
-        logger.log("GpuSampler: time-step loop handed to rlpyt_sampler_serve (native"
-                   + (", stream-write completion)." if done_words is not None else ", events)."))
-        return cls(arr, dev, sync, world_size, done_words)
-
-    @staticmethod
-    def _done_words(n_groups, dev):
-        from .. import _lib
-        if os.environ.get("RLPYT_SERVE_EVENT", "0") == "1":
-            return None
-        if not _lib.lib.rlpyt_stream_write_value_supported():
-            return None
-        import numpy as np
-        # (the window is a view: its .base keeps the backing array alive with it)
-        raw = np.zeros(64 * n_groups + 4096, dtype=np.uint8)
-        off = (-raw.ctypes.data) % 4096                    # page-aligned window
-        host = raw[off:off + 64 * n_groups]
-        host[:] = 0
-        if _lib.lib.rlpyt_host_register(ctypes.c_void_p(host.ctypes.data), int(host.nbytes)) != 0:
-            logger.log(f"GpuSampler: cannot page-lock the completion words ({_lib.last_error()}); "
-                       "using events.")
-            return None
-        dev.pinned_ptrs.append(host.ctypes.data)
-        dptr = ctypes.c_void_p()
-        _lib.check(_lib.lib.rlpyt_host_device_pointer(ctypes.c_void_p(host.ctypes.data),
-                                                      ctypes.byref(dptr)),
-                   "rlpyt_host_device_pointer")
-        return host, dptr.value
+        logger.log("GpuSampler: time-step loop handed to rlpyt_sampler_serve (native).")
+        return cls(arr, dev, sync, world_size)
 
     def _spin(self):
         """Idle passes the two serve threads may poll before they start sleeping: polling needs
@@ -143,10 +107,15 @@ class NativeServe:
         return self.spin
 
     def serve(self, T, timing):
+        """Run the T steps of a batch (and, once every group has a captured tail graph, the
+        bootstrap pass behind them).  Returns True when the tail ran here."""
         from .. import _lib
         sync, groups = self.sync, self.dev.groups
+        tail = (all(G.get("tail_graph") is not None for G in groups)
+                and os.environ.get("RLPYT_NATIVE_TAIL", "1") != "0")      # (A/B switch)
         for G, sg in zip(groups, self.table):
             sg.acts, sg.rounds = sync.acts[G.idx] & 0xffffffff, sync.rounds[G.idx] & 0xffffffff
+            sg.tail_graph_exec = G.tail_graph.raw_cuda_graph_exec() if tail else None
         tmg = self.tmg
         for i in range(8):
             tmg[i] = 0.
@@ -154,7 +123,7 @@ class NativeServe:
                                                 120000, tmg), "rlpyt_sampler_serve")
         for G in groups:
             sync.acts[G.idx] += T
-            sync.rounds[G.idx] += T
+            sync.rounds[G.idx] += T + (1 if tail else 0)
             G.calls += T
         timing["wait_env_s"] += tmg[0]
         timing["device_issue_s"] += tmg[1]
@@ -162,3 +131,4 @@ class NativeServe:
         for k, i in (("chain_issue_s", 3), ("chain_device_s", 4), ("chain_post_s", 5),
                      ("chain_steps", 6)):
             timing[k] = timing.get(k, 0.) + tmg[i]
+        return tail

@@ -188,25 +188,15 @@ def test_iterations_match_reference_at_split_kernel_size():
         assert k in ran, (k, sorted(ran))
 
 
-@pytest.mark.parametrize("case", C.DQN_CASES, ids=[c[0] for c in C.DQN_CASES])
-def test_dqn_iterations_match_reference(case):
-    """DQN / CategoricalDQN.optimize_agent over several iterations (append to the HBM frame replay, sample --
-    same np.random stream as the reference --, fused loss, clip, Adam, priority and target
-    updates) vs the reference's own run with its AtariDqnAgent on CPU.  The conv stack of this
-    model family runs through MIOpen; tolerances as for the PPO iterations."""
-    from collections import namedtuple
+def _dqn_case_objects(case):
     from rlpyt_amd.agents.dqn.dqn_agent import AtariDqnAgent
     from rlpyt_amd.algos.dqn.dqn import DQN
     from rlpyt_amd.envs import EnvSpaces
     from rlpyt_amd.samplers.collections import BatchSpec
     from rlpyt_amd.spaces import IntBox
     name, kwargs, n_itr = case
-    g = load_golden("dqn_iterations")
     spaces = EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
                        action=IntBox(0, C.A))
-    Env = namedtuple("Env", ["observation", "reward", "done"])
-    Agent = namedtuple("Agent", ["action"])
-    Smp = namedtuple("Smp", ["agent", "env"])
     batches = C.dqn_batches(n_itr)
     torch.manual_seed(C.INIT_SEED)
     if name.startswith("catdqn"):
@@ -222,14 +212,35 @@ def test_dqn_iterations_match_reference(case):
                     reward=b0["reward"][0, 0], done=b0["done"][0, 0])
     algo.initialize(agent=agent, n_itr=n_itr, batch_spec=BatchSpec(C.DQN_T, C.DQN_B),
                     mid_batch_reset=True, examples=examples, world_size=1, rank=0)
+    return agent, algo, batches
+
+
+def _dqn_samples(b):
+    from collections import namedtuple
+    Env = namedtuple("Env", ["observation", "reward", "done"])
+    Agent = namedtuple("Agent", ["action"])
+    Smp = namedtuple("Smp", ["agent", "env"])
+    return Smp(agent=Agent(action=b["action"].cuda()),
+               env=Env(observation=b["observation"].cuda(), reward=b["reward"].cuda(),
+                       done=b["done"].cuda()))
+
+
+@pytest.mark.parametrize("case", C.DQN_CASES, ids=[c[0] for c in C.DQN_CASES])
+def test_dqn_iterations_match_reference(case):
+    """DQN / CategoricalDQN.optimize_agent over several iterations (append to the HBM frame replay, sample --
+    same np.random stream as the reference --, fused loss, clip, Adam, priority and target
+    updates) vs the reference's own run with its AtariDqnAgent on CPU.  The conv stack of this
+    model family runs through MIOpen; tolerances as for the PPO iterations.  The Adam cases run
+    their later iterations through the CAPTURED update graph (algos/dqn/captured.py: it engages
+    once the optimizer state exists), the ``_sgd`` case -- the tight pin -- stays eager."""
+    name, kwargs, n_itr = case
+    g = load_golden("dqn_iterations")
+    agent, algo, batches = _dqn_case_objects(case)
     np.random.seed(C.SHUFFLE_SEED)
     first = True
     for itr, b in enumerate(batches):
         agent.train_mode(itr)
-        info = algo.optimize_agent(itr, Smp(
-            agent=Agent(action=b["action"].cuda()),
-            env=Env(observation=b["observation"].cuda(), reward=b["reward"].cuda(),
-                    done=b["done"].cuda())))
+        info = algo.optimize_agent(itr, _dqn_samples(b))
         for f in ("loss", "gradNorm", "tdAbsErr"):
             got = np.array(getattr(info, f), dtype=np.float64)
             ref = g[f"{name}_itr{itr}_{f}"]
@@ -253,6 +264,45 @@ def test_dqn_iterations_match_reference(case):
             root = float(algo.replay_buffer.priority_tree.tree_tensor()[0])
             np.testing.assert_allclose(root, float(g[f"{name}_itr{itr}_tree_root"]), rtol=2e-3)
     assert algo.update_counter == int(g[f"{name}_update_counter"])
+    used_graph = algo._captured is not None and algo._captured.graph is not None
+    assert used_graph == (not name.endswith("_sgd")), "Adam cases must have replayed the update graph"
+
+
+@pytest.mark.parametrize("case", [c for c in C.DQN_CASES if not c[0].endswith("_sgd")],
+                         ids=[c[0] for c in C.DQN_CASES if not c[0].endswith("_sgd")])
+def test_dqn_captured_update_graph_equals_eager_updates(case, monkeypatch):
+    """The captured update (draw from device-resident uniforms / index pairs, gathers, online and
+    target passes, fused loss, backward, clip + Adam from device-resident step scalars, priority
+    write-back -- one hipGraph replay per update) against the eager loop on the same stream of
+    sampler batches and the same ``np.random`` state: same diagnostics, parameters, target
+    parameters and tree root after every iteration (fp32 round-off of two schedules of the same
+    kernels: rtol 1e-5), same number of updates and target updates (dqn.py:158-190)."""
+    from rlpyt_amd.algos.dqn import captured
+
+    def run(enabled):
+        monkeypatch.setattr(captured, "ENABLED", enabled)
+        agent, algo, batches = _dqn_case_objects(case)
+        np.random.seed(C.SHUFFLE_SEED)
+        out = []
+        for itr, b in enumerate(batches):
+            agent.train_mode(itr)
+            info = algo.optimize_agent(itr, _dqn_samples(b))
+            out.append(dict(
+                info={f: np.array(getattr(info, f), dtype=np.float64) for f in info._fields},
+                params=torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()]).cpu(),
+                target=torch.cat([p.detach().reshape(-1) for p in agent.target_model.parameters()]).cpu(),
+                root=(float(algo.replay_buffer.priority_tree.tree_tensor()[0])
+                      if case[1]["prioritized_replay"] else 0.)))
+        used = algo._captured is not None and algo._captured.graph is not None
+        return out, used, algo.update_counter
+    (a, ua, ca), (b, ub, cb) = run(True), run(False)
+    assert ua and not ub and ca == cb > 0
+    for x, y in zip(a, b):
+        for f in x["info"]:
+            np.testing.assert_allclose(x["info"][f], y["info"][f], rtol=1e-5, atol=1e-7, err_msg=f)
+        torch.testing.assert_close(x["params"], y["params"], rtol=1e-5, atol=1e-8)
+        torch.testing.assert_close(x["target"], y["target"], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(x["root"], y["root"], rtol=1e-9)
 
 
 def test_r2d1_iterations_match_reference():

@@ -363,7 +363,9 @@ def test_bf16_split_kernels_are_f32_accurate(ops):
     y1_in = a1_64.float().permute(0, 2, 3, 1).reshape(M, 475, 16).contiguous()
     w2, b2 = w2_64.float().cuda().contiguous(), b2_64.float().cuda().contiguous()
     y2 = torch.empty(M, 3456, device="cuda")
-    check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1_in), M, ptr(w2), ptr(b2), ptr(y2), stream()), "conv2")
+    mask2 = torch.empty((M, 128), dtype=torch.int32, device="cuda")
+    check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1_in), M, ptr(w2), ptr(b2), ptr(y2), ptr(mask2), stream()),
+          "conv2")
     from rlpyt_amd import _lib
     assert _lib.last_variant().startswith("conv2_fwd_x6_kernel"), _lib.last_variant()
     ours = (y2.reshape(M, 32, 12, 9).double() - y2_64).abs().max().item()
