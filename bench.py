@@ -1072,7 +1072,8 @@ def replay_config_main(args):
         # sampling-only iterations before the timed region: by default until the 62 500-row ring
         # has WRAPPED (the timed sampling / updates then run on a full ring: every leaf of the
         # 1M-leaf tree live, frame windows crossing the wrap point)
-        workers, fill = 2, (int(1e6) // B // T + 400 if args.replay_fill_itrs < 0 else args.replay_fill_itrs)
+        workers = args.workers if args.workers > 0 else 2
+        fill = int(1e6) // B // T + 400 if args.replay_fill_itrs < 0 else args.replay_fill_itrs
         steps = args.steps if args.steps != 5 else 300
         warmup = args.warmup if args.warmup != 2 else 20
         name = "DQN AtariDqnAgent, PrioritizedReplayFrameBuffer 1e6 frames, sampler [2,16], batch 128"
@@ -1086,7 +1087,7 @@ def replay_config_main(args):
                     double_dqn=True, prioritized_replay=True, n_step_return=5, pri_alpha=0.9,
                     pri_beta_init=0.6, pri_beta_final=0.6, input_priority_shift=2,
                     replay_size=int(4e6))
-        workers = max(min(int(round(1.6 * cpus)) - 1, B // 10), 1)
+        workers = args.workers if args.workers > 0 else max(min(int(round(1.6 * cpus)) - 1, B // 10), 1)
         fill = int(4e6) // B // T + 8 if args.replay_fill_itrs < 0 else args.replay_fill_itrs   # wraps
         steps = args.steps if args.steps != 5 else 20
         warmup = args.warmup if args.warmup != 2 else 3

@@ -537,6 +537,21 @@ int rlpyt_atari_conv1_wgrad_f32(const uint8_t* obs, const int64_t* flat_idx /*nu
 int rlpyt_gather_rows(const void* src, const int64_t* t_idx, const int64_t* b_idx, void* dst,
                       int T, int64_t B, int64_t elem_bytes, int64_t M, rlpyt_stream_t stream);
 
+/* The small fields of a single-step replay batch in one launch -- NStepReturnBuffer.extract_batch,
+ * rlpyt/replays/non_sequence/n_step.py:16-43 without the observations: for sample i at ring row
+ * t = t_idx[i] (negative wraps once), column b = b_idx[i]:
+ *   prev_action / prev_reward  = action / reward of row t - 1 (row -1 = T - 1), 0 where done[t - 1];
+ *   out_action, out_return, out_done, out_done_n = row t of action / return_ / done / done_n;
+ *   tgt_prev_action / tgt_prev_reward = action / reward of row (t + n_step) % T - 1, as stored.
+ * Ring arrays [T, B]: action i64, reward / return_ f32, done / done_n u8 (bool).  Bit-exact moves. */
+int rlpyt_replay_step_fields(const int64_t* action, const float* reward, const uint8_t* done,
+                             const float* return_, const uint8_t* done_n, const int64_t* t_idx,
+                             const int64_t* b_idx, int64_t n, int T, int64_t B, int n_step,
+                             int64_t* prev_action, float* prev_reward, int64_t* out_action,
+                             float* out_return, uint8_t* out_done, uint8_t* out_done_n,
+                             int64_t* tgt_prev_action, float* tgt_prev_reward,
+                             rlpyt_stream_t stream);
+
 /* NStepFrameBuffer.extract_observation -- rlpyt/replays/non_sequence/frame.py:14-30.
  * frames u8 [T+C-1, B, H*W]; done u8 [T,B]; obs[i,c,:] = frames[t_i+c, b_i, :], then for
  * f=1..C-1: if done[(t_i-f) mod T, b_i]: obs[i, :C-f] = 0. */

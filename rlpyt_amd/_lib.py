@@ -148,6 +148,7 @@ _SIGNATURES = {
     "rlpyt_atari_conv1_wgrad_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, c_float, _p, _p,
                                             _p, _p]),
     "rlpyt_gather_rows": (c_int, [_p, _p, _p, _p, c_int, c_int64, c_int64, c_int64, _p]),
+    "rlpyt_replay_step_fields": (c_int, [_p] * 7 + [c_int64, c_int, c_int64, c_int] + [_p] * 9),
     "rlpyt_frames_gather": (c_int, [_p, _p, _p, _p, _p, c_int64, c_int, c_int64, c_int, c_int64,
                                     _p]),
     "rlpyt_frames_gather_seq": (c_int, [_p, _p, _p, _p, _p, c_int64, c_int, c_int, c_int64,

@@ -273,6 +273,68 @@ extern "C" int rlpyt_gather_rows(const void* src, const int64_t* t_idx, const in
   return launch_gather(src, dst, map, M, elem_bytes, (hipStream_t)stream);
 }
 
+// The small fields of one single-step replay batch in ONE launch -- NStepReturnBuffer.extract_batch,
+// rlpyt/replays/non_sequence/n_step.py:16-43 minus the observations (rlpyt_frames_gather_pair):
+//   prev_action / prev_reward = action / reward of ring row t - 1 (row -1 = the last row), nulled
+//     where done[t - 1] (n_step.py:30-33);   action, return_, done, done_n of row t;
+//   target_prev_action / target_prev_reward = action / reward of row (t + n_step) % T - 1, as stored.
+// One thread per sample; pure index arithmetic and moves: bit-exact.  Replaces eleven row gathers,
+// two selects and the index arithmetic between them (~18 launches of a few microseconds).
+namespace rlpyt {
+namespace {
+__global__ __launch_bounds__(256) void replay_step_fields_kernel(
+    const int64_t* __restrict__ action, const float* __restrict__ reward,
+    const uint8_t* __restrict__ done, const float* __restrict__ return_,
+    const uint8_t* __restrict__ done_n, const int64_t* __restrict__ t_idx,
+    const int64_t* __restrict__ b_idx, int64_t n, int T, int64_t B, int n_step,
+    int64_t* __restrict__ prev_action, float* __restrict__ prev_reward,
+    int64_t* __restrict__ out_action, float* __restrict__ out_return, uint8_t* __restrict__ out_done,
+    uint8_t* __restrict__ out_done_n, int64_t* __restrict__ tgt_prev_action,
+    float* __restrict__ tgt_prev_reward) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t t = t_idx[i];
+  const int64_t b = b_idx[i];
+  if (t < 0) t += T;                                   // numpy negative indexing (wraps once)
+  const int64_t tm1 = t == 0 ? T - 1 : t - 1;
+  const int64_t nxt = (t + n_step) % T;
+  const int64_t nm1 = nxt == 0 ? T - 1 : nxt - 1;
+  const bool was_done = done[tm1 * B + b] != 0;
+  prev_action[i] = was_done ? 0 : action[tm1 * B + b];
+  prev_reward[i] = was_done ? 0.f : reward[tm1 * B + b];
+  out_action[i] = action[t * B + b];
+  out_return[i] = return_[t * B + b];
+  out_done[i] = done[t * B + b];
+  out_done_n[i] = done_n[t * B + b];
+  tgt_prev_action[i] = action[nm1 * B + b];
+  tgt_prev_reward[i] = reward[nm1 * B + b];
+}
+}  // namespace
+}  // namespace rlpyt
+
+extern "C" int rlpyt_replay_step_fields(const int64_t* action, const float* reward,
+                                        const uint8_t* done, const float* return_,
+                                        const uint8_t* done_n, const int64_t* t_idx,
+                                        const int64_t* b_idx, int64_t n, int T, int64_t B,
+                                        int n_step, int64_t* prev_action, float* prev_reward,
+                                        int64_t* out_action, float* out_return, uint8_t* out_done,
+                                        uint8_t* out_done_n, int64_t* tgt_prev_action,
+                                        float* tgt_prev_reward, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(action && reward && done && return_ && done_n && t_idx && b_idx && prev_action &&
+                   prev_reward && out_action && out_return && out_done && out_done_n &&
+                   tgt_prev_action && tgt_prev_reward,
+               RLPYT_EINVAL, "rlpyt_replay_step_fields: null pointer");
+  RL_CHECK_ARG(n >= 0 && T > 0 && B > 0 && n_step > 0, RLPYT_EINVAL,
+               "rlpyt_replay_step_fields: bad sizes");
+  if (n == 0) return RLPYT_OK;
+  RL_LAUNCH(rlpyt::replay_step_fields_kernel, dim3((unsigned)rlpyt::ceil_div(n, 256)), dim3(256), 0,
+            (hipStream_t)stream, action, reward, done, return_, done_n, t_idx, b_idx, n, T, B, n_step,
+            prev_action, prev_reward, out_action, out_return, out_done, out_done_n, tgt_prev_action,
+            tgt_prev_reward);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
 extern "C" int rlpyt_frames_gather(const uint8_t* frames, const uint8_t* done,
                                    const int64_t* t_idx, const int64_t* b_idx, uint8_t* obs,
                                    int64_t n, int T, int64_t B, int C, int64_t HW,

@@ -1031,6 +1031,26 @@ def gather_rows(src, t_idx, b_idx, out=None):
     return out
 
 
+def replay_step_fields(action, reward, done, return_, done_n, t_idx, b_idx, n_step):
+    """The small fields of a single-step replay batch (``rlpyt_replay_step_fields``: one launch for
+    NStepReturnBuffer.extract_batch minus the observations) -> (prev_action, prev_reward, action,
+    return_, done, done_n, target_prev_action, target_prev_reward), each ``[n]``.  Ring arrays
+    ``[T, B]``: int64 action, float32 reward / return_, bool done / done_n, all contiguous."""
+    _lib.require_gpu()
+    T, B = action.shape
+    n = t_idx.numel()
+    dev = action.device
+    i64 = lambda: torch.empty(n, dtype=torch.int64, device=dev)        # noqa: E731
+    f32 = lambda: torch.empty(n, dtype=torch.float32, device=dev)      # noqa: E731
+    bl = lambda: torch.empty(n, dtype=torch.bool, device=dev)          # noqa: E731
+    pa, pr, a, r, d, dn, tpa, tpr = i64(), f32(), i64(), f32(), bl(), bl(), i64(), f32()
+    check(lib.rlpyt_replay_step_fields(
+        ptr(action), ptr(reward), ptr(done), ptr(return_), ptr(done_n), ptr(t_idx.contiguous()),
+        ptr(b_idx.contiguous()), n, int(T), int(B), int(n_step), ptr(pa), ptr(pr), ptr(a), ptr(r),
+        ptr(d), ptr(dn), ptr(tpa), ptr(tpr), stream()), "rlpyt_replay_step_fields")
+    return pa, pr, a, r, d, dn, tpa, tpr
+
+
 def frames_gather(frames, done, t_idx, b_idx, n_frames, out=None):
     """NStepFrameBuffer.extract_observation (replays/non_sequence/frame.py:14-30).
 

@@ -162,6 +162,17 @@ class ReplayBuffer:
         later; the action / reward ENTERING a step are those of row ``t - 1`` (row -1 = the ring's
         last row), nulled where that row ended an episode."""
         d, row = self.fields.data, ops.gather_rows
+        ret_ring, dn_ring = self.fields.return_, self.fields.done_n
+        if self.frame_store is not None and self._fused_fields_ok(d, ret_ring, dn_ring):
+            # product path: every small field in ONE launch, both 4-frame stacks in one more
+            pa, pr, act, ret, dn, dnn, tpa, tpr = ops.replay_step_fields(
+                d.action, d.reward, d.done, ret_ring, dn_ring, T_idxs, B_idxs, self.n_step_return)
+            obs, nxt_obs = ops.frames_gather_pair(self.frame_store.frames, d.done, T_idxs, B_idxs,
+                                                  self.frame_store.C, self.n_step_return)
+            return StepBatch(
+                agent_inputs=AgentInputs(observation=obs, prev_action=pa, prev_reward=pr),
+                action=act, return_=ret, done=dn, done_n=dnn,
+                target_inputs=AgentInputs(observation=nxt_obs, prev_action=tpa, prev_reward=tpr))
         nxt = (T_idxs + self.n_step_return) % self.T
         was_done = row(d.done, T_idxs - 1, B_idxs)
         pa, pr = row(d.action, T_idxs - 1, B_idxs), row(d.reward, T_idxs - 1, B_idxs)
@@ -175,12 +186,27 @@ class ReplayBuffer:
         return StepBatch(
             agent_inputs=AgentInputs(observation=obs, prev_action=pa, prev_reward=pr),
             action=row(d.action, T_idxs, B_idxs),
-            return_=row(self.fields.return_, T_idxs, B_idxs),
+            return_=row(ret_ring, T_idxs, B_idxs),
             done=row(d.done, T_idxs, B_idxs),
-            done_n=row(self.fields.done_n, T_idxs, B_idxs),
+            done_n=row(dn_ring, T_idxs, B_idxs),
             target_inputs=AgentInputs(observation=nxt_obs,
                                       prev_action=row(d.action, nxt - 1, B_idxs),
                                       prev_reward=row(d.reward, nxt - 1, B_idxs)))
+
+    @staticmethod
+    def _fused_fields_ok(d, ret_ring, dn_ring):
+        """The one-launch field gather covers the standard record: scalar int64 actions, float32
+        reward / return, bool done flags, all plain contiguous ``[T, B]`` device tensors (RLPYT_
+        FUSED_FIELDS=0: the row-by-row gathers, for A/B and as the general path)."""
+        import os
+        if os.environ.get("RLPYT_FUSED_FIELDS", "1") == "0":
+            return False
+        t = torch.Tensor
+        return (isinstance(d.action, t) and d.action.dtype == torch.int64 and d.action.dim() == 2
+                and isinstance(d.reward, t) and d.reward.dtype == torch.float32 and d.reward.dim() == 2
+                and d.done.dtype == torch.bool and ret_ring.dtype == torch.float32
+                and dn_ring.dtype == torch.bool and d.action.is_cuda
+                and all(x.is_contiguous() for x in (d.action, d.reward, d.done, ret_ring, dn_ring)))
 
     def _sequences(self, T_idxs, B_idxs, T):
         """``[T (+ n_step), B]`` sequences starting at ``(t, b)``: observations from row t, the

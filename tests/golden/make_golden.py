@@ -837,7 +837,7 @@ def gen_sampler_ff():
     fresh = AtariFfModel(image_shape=(4, 104, 80), output_size=6)
     agent.model.load_state_dict(fresh.state_dict())
     C.ff_sharpen(agent.model)
-    out = {"param_abs_sums": C.param_checksums(list(agent.model.parameters()))}
+    out = {"param_crc": C.param_checksums(list(agent.model.parameters()))}
     try:
         min_gap = _record_ff_batches(s, agent, C, out)
     finally:

@@ -54,7 +54,10 @@ def ff_sharpen(model):
 
 
 def param_checksums(params):
-    return np.array([float(p.detach().double().abs().sum()) for p in params], dtype=np.float64)
+    """CRC32 of every parameter's bytes (exact: a floating-point sum depends on the thread count
+    of the host that computes it)."""
+    return np.array([zlib.crc32(np.ascontiguousarray(p.detach().cpu().numpy()).tobytes())
+                     for p in params], dtype=np.uint32)
 
 
 EVAL_N_ENVS, EVAL_MAX_STEPS = 4, 4 * 60      # 60 time steps of 4 eval envs

@@ -302,7 +302,7 @@ def test_dqn_captured_update_graph_equals_eager_updates(case, monkeypatch):
             np.testing.assert_allclose(x["info"][f], y["info"][f], rtol=1e-5, atol=1e-7, err_msg=f)
         torch.testing.assert_close(x["params"], y["params"], rtol=1e-5, atol=1e-8)
         torch.testing.assert_close(x["target"], y["target"], rtol=1e-5, atol=1e-8)
-        np.testing.assert_allclose(x["root"], y["root"], rtol=1e-9)
+        np.testing.assert_allclose(x["root"], y["root"], rtol=1e-6)   # f64 sums of f32-noise priorities
 
 
 def test_r2d1_iterations_match_reference():

@@ -554,6 +554,39 @@ def _gemm_tn_x6():
     Cv.test_gemm_tn_bf16x6_is_f32_accurate(_ops(), 132, 200, 2080)    # ragged K chunks + partials
 
 
+@case("replay_step_fields_kernel")
+def _replay_step_fields():
+    """One-launch field gather of a single-step replay batch vs the row-by-row gathers + selects it
+    replaces (and vs the reference's own arithmetic, n_step.py:16-43, in numpy): bit-exact, incl.
+    rows 0 / T - 1 (wraps of t - 1 and t + n_step) and done flags on the row before."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    T, B, n, n_step = 37, 5, 300, 3
+    action = torch.randint(0, 6, (T, B), generator=g).cuda()
+    reward = torch.randn(T, B, generator=g).cuda()
+    done = (torch.rand(T, B, generator=g) < 0.3).cuda()
+    ret = torch.randn(T, B, generator=g).cuda()
+    done_n = (torch.rand(T, B, generator=g) < 0.3).cuda()
+    t = torch.randint(0, T, (n,), generator=g)
+    t[:4] = torch.tensor([0, T - 1, T - n_step, 1])
+    b = torch.randint(0, B, (n,), generator=g)
+    td, bd = t.cuda(), b.cuda()
+    pa, pr, a, r, d, dn, tpa, tpr = ops.replay_step_fields(action, reward, done, ret, done_n, td, bd,
+                                                           n_step)
+    A, R, D, RT, DN = (host(x) for x in (action, reward, done, ret, done_n))
+    tn, bn = t.numpy(), b.numpy()
+    was = D[tn - 1, bn]                                   # numpy negative index = the ring wrap
+    assert np.array_equal(host(pa), np.where(was, 0, A[tn - 1, bn]))
+    assert np.array_equal(host(pr), np.where(was, np.float32(0), R[tn - 1, bn]))
+    assert np.array_equal(host(a), A[tn, bn]) and np.array_equal(host(r), RT[tn, bn])
+    assert np.array_equal(host(d), D[tn, bn]) and np.array_equal(host(dn), DN[tn, bn])
+    nxt = (tn + n_step) % T
+    assert np.array_equal(host(tpa), A[nxt - 1, bn]) and np.array_equal(host(tpr), R[nxt - 1, bn])
+    # ... and the row-by-row device path gives the same tensors
+    row = ops.gather_rows
+    assert torch.equal(a, row(action, td, bd)) and torch.equal(tpr, row(reward, (td + n_step) % T - 1, bd))
+
+
 @case("eps_greedy_kernel")
 def _eps_greedy():
     import test_dqn_gpu as D
