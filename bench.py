@@ -64,11 +64,11 @@ KERNEL_NAMES = {
                  "operands of both contractions, f32 accumulate)",
     "conv1_wgrad": "conv1_wgrad_kernel (gather + u8->bf16 + weight/bias grad; exact bf16x3 split "
                    "of dy1, f32 accumulate)",
-    "gemm_nt": "gemm_nt_x6_kernel<128, presplit W> (update trunk forward x W^T [8192,3456]x[512,3456]^T: f32 GEMM "
+    "gemm_nt": "gemm_nt_x6_kernel<128> (update trunk forward x W^T [8192,3456]x[512,3456]^T: f32 GEMM "
                "from three-piece bf16 splits of both operands, six products, f32 accumulate, dropped "
                "terms <= 2^-24, 2^-27 rms)",
-    "gemm_nt_dgrad": "gemm_nt_x6_kernel<256, presplit W^T> (update trunk input gradient g W "
-                     "[8192,512]x[512,3456] as g (W^T)^T on the pre-split pieces of W^T; same bf16x6 arithmetic)",
+    "gemm_nt_dgrad": "gemm_nt_x6_kernel<256> (update trunk input gradient g W [8192,512]x[512,3456] as "
+                     "g (W^T)^T on a transposed copy of W; same bf16x6 arithmetic)",
     "gemm_tn": "gemm_tn_x6_kernel + gemm_reduce_slots_kernel (update trunk weight gradient g^T x "
                "[8192,512]^T x [8192,3456]: 8 K chunks <-> XCDs, partial tiles, fixed-order sum; "
                "bf16x6 in lock step, K-major LDS tiles read with ds_read_b64_tr_b16)",
@@ -499,7 +499,7 @@ KTIMER_NOTE = ("HIP events around each launch, on the launching stream, in 2 ite
 # bench region -> kernel names as rocprofv3 prints them (profiles/r*_bench_kernel_stats.csv)
 ROCPROF_NAMES = {"conv1_fwd": ["conv1_fwd_kernel"], "conv2_fwd": ["conv2_fwd_x6_kernel"],
                  "conv2_bwd": ["conv2_bwd_x6_kernel"], "conv1_wgrad": ["conv1_wgrad_kernel"],
-                 "gemm_nt": ["gemm_nt_x6_kernel<128, true>"], "gemm_nt_dgrad": ["gemm_nt_x6_kernel<256, true>"],
+                 "gemm_nt": ["gemm_nt_x6_kernel<128>"], "gemm_nt_dgrad": ["gemm_nt_x6_kernel<256>"],
                  "gemm_tn": ["gemm_tn_x6_kernel", "gemm_reduce_slots_kernel"],
                  "ppo_head_loss": ["ppo_head_loss_kernel"],
                  "sample_convs_kernel": ["sample_convs_kernel"],

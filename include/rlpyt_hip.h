@@ -210,18 +210,6 @@ int rlpyt_ppo_trunk_head_loss_fwd_bwd_dev_f32(
  * f32 out, f32-level error.  K must be a multiple of 32; a, b 16-byte aligned. */
 int rlpyt_gemm_nt_f32(const float* a, const float* b, float* c, int64_t M, int64_t N, int64_t K,
                       rlpyt_stream_t stream);
-/* The same GEMM with the B operand ALREADY split into its three bf16 pieces (b_pieces: bf16
- * [3][N][K], piece s of b[n][k] at b_pieces[(s * N + n) * K + k]; hi + mid + lo == b exactly) --
- * for a B that is the same for every call of an optimizer step, the trunk weight: the pieces are
- * made once by rlpyt_split_weight_bf16x3 instead of inside the K loop of every workgroup.  Same
- * pieces, same six products, same order: c is bit-identical to rlpyt_gemm_nt_f32(a, b).
- * rlpyt_split_weight_bf16x3: w f32 [N][K] (N, K multiples of 64) -> w_pieces [3][N][K] (B operand of
- * the forward x W^T) and wt_pieces [3][K][N] (pieces of W^T: B operand of the input gradient
- * g W = g (W^T)^T; no transposed f32 copy of W is needed any more). */
-int rlpyt_gemm_nt_bsplit_f32(const float* a, const uint16_t* b_pieces, float* c, int64_t M, int64_t N,
-                             int64_t K, rlpyt_stream_t stream);
-int rlpyt_split_weight_bf16x3(const float* w, int64_t N, int64_t K, uint16_t* w_pieces,
-                              uint16_t* wt_pieces, rlpyt_stream_t stream);
 /* The weight gradient of the same Linear (rlpyt/models/mlp.py:24-31 under autograd), same
  * arithmetic: c[M,N] = a[K,M]^T * b[K,N] -- g^T x, a contraction over the batch axis; all f32
  * row-major, K a multiple of 32, M and N multiples of 4, pointers 16-byte aligned.  For K >= 2048

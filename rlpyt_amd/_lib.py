@@ -99,8 +99,6 @@ _SIGNATURES = {
                                                               c_int, c_float, _p, c_float, c_float,
                                                               _p, _p, _p, _p, _p]),
     "rlpyt_gemm_nt_f32": (c_int, [_p, _p, _p, c_int64, c_int64, c_int64, _p]),
-    "rlpyt_gemm_nt_bsplit_f32": (c_int, [_p, _p, _p, c_int64, c_int64, c_int64, _p]),
-    "rlpyt_split_weight_bf16x3": (c_int, [_p, c_int64, c_int64, _p, _p, _p]),
     "rlpyt_gemm_tn_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "rlpyt_gemm_tn_f32": (c_int, [_p, _p, _p, c_int64, c_int64, c_int64, _p, _p]),
     "rlpyt_a2c_loss_fwd_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, c_int64, c_int, c_float,

@@ -16,6 +16,12 @@
 // split / LDS phase idled the matrix pipe: 226 us).  Per K-step a thread moves 1 + 1 float4
 // HBM -> registers (one step ahead), splits them and writes 6 x 8 B to the other LDS stage; one
 // barrier per K-step.  blockIdx -> tile map keeps the column tiles of one row block on one XCD.
+// (Round 5 built a variant whose B operand -- the trunk weight, the same for all 64 row blocks --
+// arrives pre-split as three bf16 planes made once per optimizer step: bit-identical results, half
+// the split VALU, and SLOWER -- forward 148.7 -> 192.7 us in the bench, 175 -> 188 us isolated,
+// profiles/r5_ab_presplit_weight.jsonl, r5_gemm_bench_presplit_weight.json: three 8-byte loads per
+// thread and step instead of one 16-byte load.  The kernel is bound by its vector-memory requests,
+// not by the split VALU beside the MFMAs; removed.)
 #include <algorithm>
 #include "common.h"
 
@@ -79,15 +85,7 @@ constexpr int G_ROWB = 2 * G_BK + 16;    // bytes per (piece, row) of a K-step: 
 // (4 M outputs) is one 128 x 128 tile per CU.  For TM = 256 three padded LDS stages would need
 // 166 KB, so the B operand is stored unpadded (32 B per row) with its two 16-byte K halves swapped
 // in every other group of 4 rows -- conflict-free for the 8-lane groups of ds_read_b128 as well.
-// BPRE: the B operand arrives ALREADY split -- three bf16 planes [3][N][K] written once per
-// optimizer step by split_weight_kernel (B is the trunk weight W, or W^T for the input gradient:
-// the same 1.77 M numbers for every one of the 64 / 32 row blocks, so splitting them inside the
-// K loop of every workgroup repeated the same 22 VALU instructions per thread and K-step 64 x over).
-// On gfx950 VALU issued beside MFMAs of the same SIMD costs matrix-pipe time, so
-// what is saved is pipe time: the staging of B becomes three 8-byte loads and three 8-byte LDS
-// writes per thread and step.  Same pieces, same products, same order: results are bit-identical
-// to the BPRE = false kernel.
-template <int TM, bool BPRE>
+template <int TM>
 __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
     int K, int tiles_m, int tiles_n) {
@@ -135,28 +133,16 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
   }
   const int brow = tid >> 2, bkq = tid & 3;
   const float* gb = B + (int64_t)min(tn * GT + brow, N - 1) * K + 4 * bkq;
-  // BPRE: B points at bf16 pieces [3][N][K]; 4 consecutive k of one row = 8 bytes per plane
-  const uint16_t* gbp = reinterpret_cast<const uint16_t*>(B) +
-                        (int64_t)min(tn * GT + brow, N - 1) * K + 4 * bkq;
-  const int64_t bplane = (int64_t)N * K;
   // swizzle: 16-byte half (bkq >> 1) of row r goes to half ^ ((r >> 2) & 1)
   const int sdst_b = OB_A + brow * ROWB_B +
                      (BSW ? ((((bkq >> 1) ^ ((brow >> 2) & 1)) << 4) | ((bkq & 1) << 3)) : bkq * 8);
   // two register sets: the rows of step s are requested two steps before they are split
-  // (BPRE: a register set of B is three 8-byte piece words instead of one float4)
-  struct BRegs { f32x4 f; uint2 p[3]; };
-  f32x4 ra0[NA], ra1[NA];
-  BRegs rb0, rb1;
+  f32x4 ra0[NA], ra1[NA], rb0, rb1;
 #define RLPYT_G_FETCH(ra, rb, k0_)                                                             \
   {                                                                                            \
     _Pragma("unroll") for (int i = 0; i < NA; ++i)                                             \
       ra[i] = *reinterpret_cast<const f32x4*>(ga[i] + (k0_));                                  \
-    if constexpr (BPRE) {                                                                      \
-      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
-        rb.p[s_] = *reinterpret_cast<const uint2*>(gbp + s_ * bplane + (k0_));                 \
-    } else {                                                                                   \
-      rb.f = *reinterpret_cast<const f32x4*>(gb + (k0_));                                      \
-    }                                                                                          \
+    rb = *reinterpret_cast<const f32x4*>(gb + (k0_));                                          \
   }
 #define RLPYT_G_STAGE(ra, rb, st_)                                                             \
   {                                                                                            \
@@ -168,17 +154,12 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
       _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
         *reinterpret_cast<uint2*>(d_ + s_ * PB_A) = uint2{p_[s_][0], p_[s_][1]};               \
     }                                                                                          \
+    uint32_t q_[3][2];                                                                         \
+    split3_rn(rb[0], rb[1], q_[0][0], q_[1][0], q_[2][0]);                                     \
+    split3_rn(rb[2], rb[3], q_[0][1], q_[1][1], q_[2][1]);                                     \
     uint8_t* e_ = lds + (st_) * SB + sdst_b;                                                   \
-    if constexpr (BPRE) {                                                                      \
-      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
-        *reinterpret_cast<uint2*>(e_ + s_ * PB_B) = rb.p[s_];                                  \
-    } else {                                                                                   \
-      uint32_t q_[3][2];                                                                       \
-      split3_rn(rb.f[0], rb.f[1], q_[0][0], q_[1][0], q_[2][0]);                               \
-      split3_rn(rb.f[2], rb.f[3], q_[0][1], q_[1][1], q_[2][1]);                               \
-      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
-        *reinterpret_cast<uint2*>(e_ + s_ * PB_B) = uint2{q_[s_][0], q_[s_][1]};               \
-    }                                                                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                           \
+      *reinterpret_cast<uint2*>(e_ + s_ * PB_B) = uint2{q_[s_][0], q_[s_][1]};                 \
   }
   f32x16 acc[2][NJ];
 #pragma unroll
@@ -236,8 +217,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
   // one step: prefetch the next fragments, MFMAs on the current ones with the split of step
   // ks + 2 in their gaps, then request step ks + 4 into the registers just consumed
   constexpr int NMMA = 12 * NJ;                          // MFMAs per step
-  // split VALU per MFMA gap: 4 / 3 (BPRE: 2 / 2 -- only A is split here)
-  constexpr int NV = (22 * (NA + (BPRE ? 0 : 1)) + NMMA - 1) / NMMA;
+  constexpr int NV = (22 * (NA + 1) + NMMA - 1) / NMMA;  // split VALU per MFMA gap: 4 / 3
 #define RLPYT_G_STEP(afc_, bfc_, afn_, bfn_, ra, rb, ks_)                                      \
   {                                                                                            \
     RL_T(3)                                                                                    \
@@ -289,48 +269,6 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
     }
 }
 
-// W [N][K] f32 -> its three bf16 pieces, once per optimizer step, in BOTH orientations the update's
-// two NT GEMMs take as their B operand: wp [3][N][K] (forward x W^T) and wtp [3][K][N] (input gradient
-// g W = g (W^T)^T -- this also replaces the transposed f32 copy of W the backward pass used to make).
-// One 64 x 64 tile per workgroup of 256 threads: float4 loads along K, pieces stored along K at once,
-// and through an LDS tile [piece][k][n] for the transposed planes (128-byte row segments out).
-constexpr int SW_T = 64, SW_LD = SW_T + 8;           // LDS row pitch in bf16 (144 B: 16-byte aligned)
-__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int N, int K,
-                                                           uint16_t* __restrict__ wp,
-                                                           uint16_t* __restrict__ wtp) {
-  __shared__ __attribute__((aligned(16))) uint16_t tile[3][SW_T][SW_LD];
-  const int tid = threadIdx.x;
-  const int k0 = blockIdx.x * SW_T, n0 = blockIdx.y * SW_T;
-  const int c = tid & 15, r0 = tid >> 4;              // float4 column (4 k), first row
-  const int64_t plane = (int64_t)N * K;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int r = r0 + 16 * it;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)(n0 + r) * K + k0 + 4 * c);
-    uint32_t p[3][2];
-    split3_rn(v[0], v[1], p[0][0], p[1][0], p[2][0]);
-    split3_rn(v[2], v[3], p[0][1], p[1][1], p[2][1]);
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      *reinterpret_cast<uint2*>(wp + s * plane + (int64_t)(n0 + r) * K + k0 + 4 * c) =
-          uint2{p[s][0], p[s][1]};
-      tile[s][4 * c + 0][r] = (uint16_t)(p[s][0] & 0xffffu);
-      tile[s][4 * c + 1][r] = (uint16_t)(p[s][0] >> 16);
-      tile[s][4 * c + 2][r] = (uint16_t)(p[s][1] & 0xffffu);
-      tile[s][4 * c + 3][r] = (uint16_t)(p[s][1] >> 16);
-    }
-  }
-  __syncthreads();
-  const int kr = tid >> 2, seg = tid & 3;              // row k of the tile, 16 n (32 B) per thread
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const uint4* src = reinterpret_cast<const uint4*>(&tile[s][kr][16 * seg]);
-    uint4* dst = reinterpret_cast<uint4*>(wtp + s * plane + (int64_t)(k0 + kr) * N + n0 + 16 * seg);
-    dst[0] = src[0];
-    dst[1] = src[1];
-  }
-}
-
 }  // namespace
 }  // namespace rlpyt
 
@@ -342,58 +280,29 @@ extern "C" int rlpyt_debug_timing_read_gemm(float* host, int n) {
 }
 #endif
 
-static int gemm_nt_launch(const char* fn, const float* a, const void* b, bool b_presplit, float* c,
-                          int64_t M, int64_t N, int64_t K, rlpyt_stream_t stream) {
-  RL_CHECK_ARG(a && b && c, RLPYT_EINVAL, "%s: null pointer", fn);
-  RL_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 32 == 0 && M < (1 << 30) && N < (1 << 30) &&
-                   K < (1 << 30),
-               RLPYT_ESHAPE, "%s: need M, N > 0 and K a positive multiple of 32 (M=%ld N=%ld K=%ld)",
-               fn, (long)M, (long)N, (long)K);
-  RL_CHECK_ARG((reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0,
-               RLPYT_ESHAPE, "%s: a / b must be 16-byte aligned", fn);
-  const int tiles_n = (int)ceil_div(N, GT);
-  hipStream_t s = (hipStream_t)stream;
-  const float* bf = static_cast<const float*>(b);
-  // 256-row tiles when they still fill the chip twice over (the trunk's input gradient: 32 x 27)
-  const bool tall = ceil_div(M, 256) * tiles_n >= 512;
-  const int tiles_m = (int)ceil_div(M, tall ? 256 : GT);
-  const int grid = 8 * ((tiles_m * tiles_n + 7) / 8);       // whole rounds over the 8 XCDs
-  if (tall && b_presplit)
-    RL_LAUNCH((gemm_nt_x6_kernel<256, true>), dim3(grid), dim3(G_THREADS), 0, s, a, bf, c, (int)M,
-              (int)N, (int)K, tiles_m, tiles_n);
-  else if (tall)
-    RL_LAUNCH((gemm_nt_x6_kernel<256, false>), dim3(grid), dim3(G_THREADS), 0, s, a, bf, c, (int)M,
-              (int)N, (int)K, tiles_m, tiles_n);
-  else if (b_presplit)
-    RL_LAUNCH((gemm_nt_x6_kernel<128, true>), dim3(grid), dim3(G_THREADS), 0, s, a, bf, c, (int)M,
-              (int)N, (int)K, tiles_m, tiles_n);
-  else
-    RL_LAUNCH((gemm_nt_x6_kernel<128, false>), dim3(grid), dim3(G_THREADS), 0, s, a, bf, c, (int)M,
-              (int)N, (int)K, tiles_m, tiles_n);
-  RL_LAUNCH_CHECK();
-  return RLPYT_OK;
-}
-
 extern "C" int rlpyt_gemm_nt_f32(const float* a, const float* b, float* c, int64_t M, int64_t N,
                                  int64_t K, rlpyt_stream_t stream) {
-  return gemm_nt_launch("rlpyt_gemm_nt_f32", a, b, false, c, M, N, K, stream);
-}
-
-extern "C" int rlpyt_gemm_nt_bsplit_f32(const float* a, const uint16_t* b_pieces, float* c,
-                                        int64_t M, int64_t N, int64_t K, rlpyt_stream_t stream) {
-  return gemm_nt_launch("rlpyt_gemm_nt_bsplit_f32", a, b_pieces, true, c, M, N, K, stream);
-}
-
-extern "C" int rlpyt_split_weight_bf16x3(const float* w, int64_t N, int64_t K, uint16_t* w_pieces,
-                                         uint16_t* wt_pieces, rlpyt_stream_t stream) {
-  RL_CHECK_ARG(w && w_pieces && wt_pieces, RLPYT_EINVAL, "rlpyt_split_weight_bf16x3: null pointer");
-  RL_CHECK_ARG(N > 0 && K > 0 && N % SW_T == 0 && K % SW_T == 0 && N < (1 << 24) && K < (1 << 24),
-               RLPYT_ESHAPE, "rlpyt_split_weight_bf16x3: N and K must be positive multiples of 64 "
-                             "(N=%ld K=%ld)", (long)N, (long)K);
-  RL_CHECK_ARG(RL_ALIGNED16(w) && RL_ALIGNED16(w_pieces) && RL_ALIGNED16(wt_pieces), RLPYT_ESHAPE,
-               "rlpyt_split_weight_bf16x3: buffers must be 16-byte aligned");
-  RL_LAUNCH(split_weight_kernel, dim3((unsigned)(K / SW_T), (unsigned)(N / SW_T)), dim3(256), 0,
-            (hipStream_t)stream, w, (int)N, (int)K, w_pieces, wt_pieces);
+  RL_CHECK_ARG(a && b && c, RLPYT_EINVAL, "rlpyt_gemm_nt_f32: null pointer");
+  RL_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 32 == 0 && M < (1 << 30) && N < (1 << 30) &&
+                   K < (1 << 30),
+               RLPYT_ESHAPE, "rlpyt_gemm_nt_f32: need M, N > 0 and K a positive multiple of 32 "
+                             "(M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
+  RL_CHECK_ARG((reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0,
+               RLPYT_ESHAPE, "rlpyt_gemm_nt_f32: a / b must be 16-byte aligned");
+  const int tiles_n = (int)ceil_div(N, GT);
+  hipStream_t s = (hipStream_t)stream;
+  // 256-row tiles when they still fill the chip twice over (the trunk's input gradient: 32 x 27)
+  if (ceil_div(M, 256) * tiles_n >= 512) {
+    const int tiles_m = (int)ceil_div(M, 256);
+    const int grid = 8 * ((tiles_m * tiles_n + 7) / 8);     // whole rounds over the 8 XCDs
+    RL_LAUNCH((gemm_nt_x6_kernel<256>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, (int)N,
+              (int)K, tiles_m, tiles_n);
+  } else {
+    const int tiles_m = (int)ceil_div(M, GT);
+    const int grid = 8 * ((tiles_m * tiles_n + 7) / 8);
+    RL_LAUNCH((gemm_nt_x6_kernel<128>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, (int)N,
+              (int)K, tiles_m, tiles_n);
+  }
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

@@ -662,10 +662,6 @@ def fc_small(x, weight, bias=None, relu=True):
 # (On gfx950 VALU and MFMA instructions of one SIMD do not overlap, whichever wave issues them, so a
 # bf16x6 GEMM that splits its operands in-kernel is bounded by matrix-pipe + split-VALU time, ~2200
 # cycles per 128 x 128 x 32 step; the lock-step kernel sits within 10 % of that.)
-# False (RLPYT_W_PRESPLIT=0): the trunk GEMMs split W inside their K loops (A/B)
-W_PRESPLIT = os.environ.get("RLPYT_W_PRESPLIT", "1") != "0"
-
-
 def gemm_nt(a, b, region="gemm_nt"):
     """``a @ b.T`` for f32 ``a [M, K]``, ``b [N, K]`` (K a multiple of 32) on the bf16 matrix pipe
     from exact three-piece bf16 splits of both operands (six products, f32 accumulation, dropped
@@ -679,36 +675,6 @@ def gemm_nt(a, b, region="gemm_nt"):
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
     with ktimer.region(region, 4 * (M * K + N * K + M * N), 2 * M * N * K):
         check(lib.rlpyt_gemm_nt_f32(ptr(a), ptr(b), ptr(c), M, N, K, stream()), "rlpyt_gemm_nt_f32")
-    return c
-
-
-def split_weight(weight):
-    """``weight`` f32 ``[N, K]`` (N, K multiples of 64) -> its three bf16 pieces in both orientations
-    (``rlpyt_split_weight_bf16x3``): ``wp`` int16 ``[3, N, K]`` and ``wtp`` int16 ``[3, K, N]`` (pieces of
-    ``weight.T``), the pre-split B operands of ``gemm_nt_bsplit``."""
-    _lib.require_gpu()
-    w = _f32(weight.detach())
-    N, K = w.shape
-    wp = torch.empty((3, N, K), dtype=torch.int16, device=w.device)
-    wtp = torch.empty((3, K, N), dtype=torch.int16, device=w.device)
-    with ktimer.region("split_weight", 16 * N * K):
-        check(lib.rlpyt_split_weight_bf16x3(ptr(w), N, K, ptr(wp), ptr(wtp), stream()),
-              "rlpyt_split_weight_bf16x3")
-    return wp, wtp
-
-
-def gemm_nt_bsplit(a, b_pieces, region="gemm_nt"):
-    """``gemm_nt(a, b)`` with ``b`` given as its bf16 pieces ``[3, N, K]`` (``split_weight``):
-    bit-identical result, no split of B inside the kernel (``rlpyt_gemm_nt_bsplit_f32``)."""
-    _lib.require_gpu()
-    a = _f32(a)
-    M, K = a.shape
-    _three, N, Kb = b_pieces.shape
-    assert _three == 3 and Kb == K and b_pieces.dtype == torch.int16 and b_pieces.is_contiguous()
-    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    with ktimer.region(region, 4 * (M * K + M * N) + 6 * N * K, 2 * M * N * K):
-        check(lib.rlpyt_gemm_nt_bsplit_f32(ptr(a), ptr(b_pieces), ptr(c), M, N, K, stream()),
-              "rlpyt_gemm_nt_bsplit_f32")
     return c
 
 
@@ -740,14 +706,6 @@ class _LinearNoBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
-        N, K = weight.shape
-        ctx.wtp = None
-        if W_PRESPLIT and N % 64 == 0 and K % 64 == 0:
-            # the weight's bf16 pieces, made ONCE per optimizer step for both GEMMs that take W as
-            # their B operand (forward here, input gradient in backward: wtp also stands in for
-            # the transposed copy of W that pass used to make)
-            wp, ctx.wtp = split_weight(weight)
-            return gemm_nt_bsplit(x, wp)
         return gemm_nt(x, weight.detach())
 
     @staticmethod
@@ -756,10 +714,8 @@ class _LinearNoBias(torch.autograd.Function):
         g = g.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            if ctx.wtp is not None:
-                gx = gemm_nt_bsplit(g, ctx.wtp, region="gemm_nt_dgrad")
-            else:   # g W as g (W^T)^T on the same kernel; 7 MB transposed copy
-                gx = gemm_nt(g, weight.detach().t().contiguous(), region="gemm_nt_dgrad")
+            # g W as g (W^T)^T on the same kernel; 7 MB transposed copy
+            gx = gemm_nt(g, weight.detach().t().contiguous(), region="gemm_nt_dgrad")
         if ctx.needs_input_grad[1]:
             gw = gemm_tn(g, x)
         return gx, gw

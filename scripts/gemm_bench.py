@@ -36,10 +36,6 @@ g = torch.randn(M, N, device="cuda")
 fl = 2 * M * N * K
 res = {"shape": {"M": M, "N": N, "K": K, "GFLOP": fl / 1e9}}
 res["fwd_nt_lockstep"] = entry(timeit(lambda: ops.gemm_nt(x, w)), fl)
-wp, wtp = ops.split_weight(w)
-res["split_weight"] = {"us": round(timeit(lambda: ops.split_weight(w)), 1)}
-res["fwd_nt_presplit_w"] = entry(timeit(lambda: ops.gemm_nt_bsplit(x, wp)), fl)
-res["dgrad_nt_presplit_wt"] = entry(timeit(lambda: ops.gemm_nt_bsplit(g, wtp)), fl)
 res["fwd_torch_f32"] = entry(timeit(lambda: torch.mm(x, w.t())), fl)
 wt = w.t().contiguous()
 res["dgrad_nt_lockstep_on_transposed_w"] = entry(timeit(lambda: ops.gemm_nt(g, wt)), fl)

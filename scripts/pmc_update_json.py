@@ -19,8 +19,8 @@ REGIONS = {
     "conv2_fwd": (["conv2_fwd_x6_kernel"], M * (4 * (7600 + 3456) + 512)),
     "conv2_bwd": (["conv2_bwd_x6_kernel"], M * (4 * (3456 + 2 * 7600) + 512)),
     "conv1_wgrad": (["conv1_wgrad_kernel"], M * (33280 + 4 * 7600)),
-    "gemm_nt": (["gemm_nt_x6_kernel<128, true>"], GEMM_ALG),
-    "gemm_nt_dgrad": (["gemm_nt_x6_kernel<256, true>"], GEMM_ALG),
+    "gemm_nt": (["gemm_nt_x6_kernel<128>"], GEMM_ALG),
+    "gemm_nt_dgrad": (["gemm_nt_x6_kernel<256>"], GEMM_ALG),
     "gemm_tn": (["gemm_tn_x6_kernel", "gemm_reduce_slots_kernel"], GEMM_ALG),
 }
 RENAME = {"SQ_VALU_MFMA_BUSY_CYCLES": "mfma_busy_cycles", "SQ_BUSY_CYCLES": "sq_busy_cycles",

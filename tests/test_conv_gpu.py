@@ -436,33 +436,6 @@ def test_gemm_tn_bf16x6_is_f32_accurate(ops, M, N, K):
         assert torch.equal(ops.gemm_tn(a, b), c0)
 
 
-def test_gemm_nt_with_presplit_weight_is_bit_identical(ops):
-    """``split_weight`` + ``gemm_nt_bsplit`` (the trunk weight's bf16 pieces made once per optimizer
-    step, B operand of the forward GEMM and -- transposed planes -- of the input gradient) against
-    ``gemm_nt`` splitting the same weight inside its K loop: same pieces, same six products, same
-    order => bit-identical outputs, for both tile variants, ragged M, and on wide-range data; the
-    pieces themselves add up to the weight exactly."""
-    g = torch.Generator().manual_seed(3)
-    N, K = 512, 3456
-    w = _wide((N, K), g, 2.0).float().cuda()
-    wp, wtp = ops.split_weight(w)
-    assert wp.shape == (3, N, K) and wtp.shape == (3, K, N)
-    pieces = (wp.view(torch.bfloat16).float()).double().sum(0)
-    assert torch.equal(pieces, w.double())                           # hi + mid + lo == w exactly
-    assert torch.equal(wtp.view(torch.bfloat16), wp.view(torch.bfloat16).transpose(1, 2))
-    for M in (8192, 1000, 77):
-        x = _wide((M, K), g, 2.0).float().cuda()                     # forward: x W^T   (<128>)
-        assert torch.equal(ops.gemm_nt_bsplit(x, wp), ops.gemm_nt(x, w))
-        gy = _wide((M, N), g, 2.0).float().cuda()                    # dgrad: g (W^T)^T (<256> at 8192)
-        assert torch.equal(ops.gemm_nt_bsplit(gy, wtp), ops.gemm_nt(gy, w.t().contiguous()))
-    from rlpyt_amd import _lib
-    _lib.variant_reset()
-    ops.gemm_nt_bsplit(_wide((8192, K), g, 1.0).float().cuda(), wp)
-    ops.gemm_nt_bsplit(_wide((8192, N), g, 1.0).float().cuda(), wtp)
-    ran = {k for k, v in _lib.variant_counts().items() if v > 0}
-    assert {"gemm_nt_x6_kernel<128, true>", "gemm_nt_x6_kernel<256, true>"} <= ran, sorted(ran)
-
-
 def test_gemm_layouts_agree_on_asymmetric_data(ops):
     """Index-map check on data where a transposed / permuted operand would show: every layout
     reproduces the float64 product of the SAME logical matrices element by element (an error in a

@@ -162,7 +162,7 @@ def test_two_ranks_product_ppo_matches_mean_gradient_run(tmp_path, T, B):
                   "conv1_fwd_kernel", "scan_exact_kernel<0, 1, 32, false>"):
             assert res["variants"].get(k, 0) > 0, (k, sorted(res["variants"]))
         big = T * B // PPO_KW["minibatches"] >= 1024      # _LinearNoBias under DDP's hooks
-        for k in ("gemm_nt_x6_kernel<128, true>", "gemm_tn_x6_kernel", "conv2_fwd_x6_kernel"):
+        for k in ("gemm_nt_x6_kernel<128>", "gemm_tn_x6_kernel", "conv2_fwd_x6_kernel"):
             assert (res["variants"].get(k, 0) > 0) == big, (k, big, sorted(res["variants"]))
     # ranks saw different data ...
     assert r0["info"][0]["loss"] != r1["info"][0]["loss"]
@@ -202,7 +202,7 @@ def test_two_ranks_product_ppo_over_rccl(tmp_path):
     ref_params, _ = _one_process_mean_gradient_run(T, B)
     for got, ref in zip(r0["params"], ref_params):
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-6)
-    for k in ("gemm_nt_x6_kernel<128, true>", "gemm_tn_x6_kernel", "conv2_bwd_x6_kernel",
+    for k in ("gemm_nt_x6_kernel<128>", "gemm_tn_x6_kernel", "conv2_bwd_x6_kernel",
               "ppo_head_loss_kernel<8, 6, true>"):
         assert r0["variants"].get(k, 0) > 0 and r1["variants"].get(k, 0) > 0, k
 

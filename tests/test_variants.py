@@ -536,22 +536,16 @@ def _conv_bwd():
         Cv.test_conv_backward_kernels(_ops(), M)
 
 
-@case("gemm_nt_x6_kernel<128, false>")
+@case("gemm_nt_x6_kernel<128>")
 def _gemm_nt():
     import test_conv_gpu as Cv
     Cv.test_gemm_nt_bf16x6_is_f32_accurate(_ops(), 130, 200, 96)
 
 
-@case("gemm_nt_x6_kernel<256, false>")
+@case("gemm_nt_x6_kernel<256>")
 def _gemm_nt_tall():
     import test_conv_gpu as Cv
     Cv.test_gemm_nt_bf16x6_is_f32_accurate(_ops(), 8000, 2100, 64)     # 32 x 17 tiles of 256 x 128
-
-
-@case("gemm_nt_x6_kernel<128, true>", "gemm_nt_x6_kernel<256, true>", "split_weight_kernel")
-def _gemm_nt_presplit():
-    import test_conv_gpu as Cv
-    Cv.test_gemm_nt_with_presplit_weight_is_bit_identical(_ops())
 
 
 @case("gemm_tn_x6_kernel", "gemm_reduce_slots_kernel")
