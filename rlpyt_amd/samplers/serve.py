@@ -111,8 +111,7 @@ class NativeServe:
         bootstrap pass behind them).  Returns True when the tail ran here."""
         from .. import _lib
         sync, groups = self.sync, self.dev.groups
-        tail = (all(G.get("tail_graph") is not None for G in groups)
-                and os.environ.get("RLPYT_NATIVE_TAIL", "1") != "0")      # (A/B switch)
+        tail = all(G.get("tail_graph") is not None for G in groups)
         for G, sg in zip(groups, self.table):
             sg.acts, sg.rounds = sync.acts[G.idx] & 0xffffffff, sync.rounds[G.idx] & 0xffffffff
             sg.tail_graph_exec = G.tail_graph.raw_cuda_graph_exec() if tail else None
