@@ -78,6 +78,12 @@ KERNEL_NAMES = {
     "gather_tb_small": "gather_flat_kernel (minibatch scalar fields)"}
 
 
+def trace_marker(args):
+    if args.trace_markers:
+        torch.full((64,), 0.5, device="cuda").erfinv_()
+        torch.cuda.synchronize()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +132,10 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="launch contract only: every rank joins the process group, reports what "
                          "it would use (device, CPUs, env workers) and exits without touching a GPU")
+    ap.add_argument("--trace-markers", action="store_true",
+                    help="profiling: one erfinv kernel (used nowhere else) right before and right after "
+                         "the timed region, so scripts/trace_region.py can cut a rocprofv3 kernel trace "
+                         "to exactly that region")
     ap.add_argument("--master-port", type=int, default=0,
                     help="rendezvous port of the self-launched ranks (0: a free one)")
     return ap.parse_args()
@@ -270,6 +280,7 @@ def main():
     wt = getattr(getattr(sampler, "ctrl", None), "worker_timing", None)
     wt0 = None if wt is None else wt.copy()
     sync()
+    trace_marker(args)
     t0 = time.perf_counter()
     t_sample = 0.
     for k in range(args.steps):
@@ -282,6 +293,7 @@ def main():
         opt_info = algo.optimize_agent(itr, samples)
     sync()
     elapsed = elapsed_local = time.perf_counter() - t0
+    trace_marker(args)
     timing = dict(sampler.timing)         # (the env-cost leg below keeps adding to sampler.timing)
     worker_ms = None
     if wt0 is not None:
@@ -1117,6 +1129,7 @@ def replay_config_main(args):
     for itr in range(fill + warmup):
         one(itr)
     torch.cuda.synchronize()
+    trace_marker(args)
     u0 = algo.update_counter
     t0 = time.perf_counter()
     t_sample = 0.
@@ -1130,6 +1143,7 @@ def replay_config_main(args):
         info = algo.optimize_agent(itr, samples)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    trace_marker(args)
     updates = algo.update_counter - u0
     sampler.shutdown()
 

@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 6
+#define RLPYT_HIP_ABI_VERSION 7
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -521,6 +521,20 @@ int rlpyt_atari_sample_convs_to_f32(uint8_t* obs, const int64_t* t_dev, int64_t 
                                     float* y2, uint8_t* dst_stage /*nullable*/,
                                     rlpyt_stream_t stream);
 int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void);
+/* No-grad forward of the DQN-family conv stack with its default geometry -- Conv2d(4,32,8,s4) ReLU
+ * Conv2d(32,64,4,s2,p1) ReLU Conv2d(64,64,3,s1,p1) ReLU, flattened: `self.conv` of
+ * rlpyt/models/dqn/atari_dqn_model.py:30-37 and rlpyt/models/dqn/atari_r2d1_model.py:33-41 as
+ * agent.step (agents/dqn/dqn_agent.py:61-68, r2d1_agent.py:40-53) and the target-network pass
+ * (algos/dqn/dqn.py:226-234) run it.  obs: uint8 [N,4,104,80]; w1 [32,4,8,8], w2 [64,32,4,4],
+ * w3 [64,64,3,3] in the torch layout, b* the biases; out: f32 [N, 64*12*9] in the order of
+ * `conv(img).view(N, -1)`.  scale multiplies the pixels (1/255).  workspace: at least
+ * rlpyt_dqn_convs_workspace_floats(N) floats (packed weights + the two intermediate layers).
+ * Four launches (weight packing + one per layer), f32 MFMA, f32 accumulate. */
+int64_t rlpyt_dqn_convs_workspace_floats(int64_t N);
+int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const float* w1, const float* b1,
+                            const float* w2, const float* b2, const float* w3, const float* b3,
+                            float scale, float* workspace, float* out, rlpyt_stream_t stream);
+
 /* conv2 backward in one pass (dgrad + both ReLU masks + weight / bias gradients; g2 / y1 read once,
  * conv2's ReLU mask from relu_mask as written by rlpyt_atari_conv2_fwd_f32), both contractions on
  * the bf16 matrix pipe (three-piece bf16 splits of both operands, six products, f32 accumulate:

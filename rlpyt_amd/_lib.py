@@ -17,7 +17,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class CopyDesc(ctypes.Structure):
@@ -138,6 +138,8 @@ _SIGNATURES = {
                                              _p, _p, _p, _p, _p, _p, c_float, _p, _p]),
     "rlpyt_atari_sample_convs_to_f32": (c_int, [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, _p, _p,
                                                 _p, _p, _p, _p, _p, _p, c_float, _p, _p, _p]),
+    "rlpyt_dqn_convs_workspace_floats": (c_int64, [c_int64]),
+    "rlpyt_dqn_convs_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, _p, c_float, _p, _p, _p]),
     "rlpyt_rollout_fc_ksplit": (c_int, [c_int]),
     "rlpyt_rollout_fc_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "rlpyt_rollout_fc_f32": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p]),

@@ -1,0 +1,261 @@
+// No-grad forward of the DQN-family conv stack on sampling-size batches:
+//   Conv2d(4, 32, 8, stride 4) -> ReLU -> Conv2d(32, 64, 4, stride 2, pad 1) -> ReLU ->
+//   Conv2d(64, 64, 3, stride 1, pad 1) -> ReLU -> flatten                 (uint8 [N, 4, 104, 80] in)
+// = `self.conv` of rlpyt/models/dqn/atari_dqn_model.py:30-37 and (inside Conv2dHeadModel)
+// rlpyt/models/dqn/atari_r2d1_model.py:33-41 with their default geometry, as the reference's
+// collectors / action server run it once per time step (agent.step, rlpyt/agents/dqn/dqn_agent.py:61-68,
+// r2d1_agent.py:40-53) and the algorithms once per update for the target network
+// (rlpyt/algos/dqn/dqn.py:226-234).
+//
+// Why own kernels: through the library path one sampling step of 8..48 environments was ~18 launches
+// for this part (uint8 -> f32 NHWC conversion, three implicit-GEMM convolutions tuned for large
+// batches, their workspace fills, three bias adds, three clamps, layout copies) -- 120-160 us of
+// 4-38 us kernels per group-step, the dominating share of the DQN / R2D1 rollout
+// (profiles/r5 dqn_region.txt, r2d1_region.txt).  Here: weight packing + one kernel per layer.
+//
+// Arithmetic: v_mfma_f32_16x16x4_f32, f32 accumulate (the batch is latency-bound: a few thousand
+// MFMAs per image; splitting into bf16 pieces per launch would cost more than it saves -- same
+// reasoning as sample_convs_kernel, conv.hip).  A wave owns one 16-channel tile and keeps ITS
+// weights for the whole contraction in registers (64 / 128 / 144 VGPRs), fetched as coalesced
+// 256-byte rows from a packed copy `[channel tile][register][lane]` that dqn_pack_weights_kernel
+// makes from the torch layout [Cout][Cin][kh][kw] -- in the same stream, right before the layers, so
+// the packed copy can never be stale (parameters change under optimizers and target updates that this
+// code does not see).  The layer's input plane sits in LDS with a zero border (padding = 1 without
+// branches) in [pixel][channel] order: one ds_read_b128 feeds four MFMAs (K-slot = channel quad).
+//   conv1: workgroup = (image, quarter of the 30 position tiles), 16 waves = 8 tiles x 2 channel
+//          tiles; the image as uint8 planes (33 KB); k-slot = (ky & 1, kx >> 2), one dword = four
+//          consecutive kx (the scheme of sample_convs_kernel); 1/255, bias, ReLU in the epilogue;
+//          y1 -> HBM as [N][475][32]
+//   conv2: workgroup = (image, channel tile), 7 waves = the 7 position tiles of 12 x 9; y1 plane
+//          27 x 21 pixels x (32 + 4) floats = 81.6 KB; y2 -> HBM as [N][108][64]
+//   conv3: the same over the 14 x 11 x (64 + 4) plane of y2 (41.9 KB); output in the flatten order of
+//          the reference's `conv(img).view(T * B, -1)`: [N][64][108].
+#include "common.h"
+
+namespace rlpyt {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int C0 = 4, H0 = 104, W0 = 80, HW0 = H0 * W0, IMG = C0 * HW0;      // 33,280 B
+constexpr int C1 = 32, H1 = 25, W1 = 19, P1 = H1 * W1;                        // 475 positions
+constexpr int C2 = 64, H2 = 12, W2 = 9, P2 = H2 * W2;                         // 108
+constexpr int C3 = 64;
+constexpr int K1 = C0 * 64, K2 = C1 * 16, K3 = C2 * 9;                        // 256, 512, 576
+constexpr int R1 = K1 / 4, R2 = K2 / 4, R3 = K3 / 4;                          // weight registers per lane
+constexpr int PK1 = (C1 / 16) * R1 * 64, PK2 = (C2 / 16) * R2 * 64, PK3 = (C3 / 16) * R3 * 64;
+constexpr int PACKED = PK1 + PK2 + PK3;                                       // 77,824 floats
+constexpr int T1 = (P1 + 15) / 16;                                            // 30 position tiles
+constexpr int T2 = (P2 + 15) / 16;                                            // 7
+constexpr int D1_PARTS = 4, D1_TILES = 8, D1_THREADS = D1_TILES * 2 * 64;     // 1024
+constexpr int D2_THREADS = T2 * 64;                                           // 448
+
+// K index of (register r, k-slot kq) of each layer -> offset inside one output channel's weights
+// conv1 (sample_convs_kernel's map): r = 4 g + e, g = 4 c + ky_hi: ky = 2 ky_hi + (kq >> 1),
+//                                    kx = 4 (kq & 1) + e
+__device__ __forceinline__ int k1_of(int r, int kq) {
+  const int g = r >> 2, e = r & 3;
+  return (g >> 2) * 64 + (2 * (g & 3) + (kq >> 1)) * 8 + 4 * (kq & 1) + e;
+}
+// conv2: r = (tap * 2 + hc) * 4 + sp: channel = 16 hc + 4 kq + sp, tap = ky * 4 + kx
+__device__ __forceinline__ int k2_of(int r, int kq) {
+  const int sp = r & 3, hc = (r >> 2) & 1, tap = r >> 3;
+  return (16 * hc + 4 * kq + sp) * 16 + tap;
+}
+// conv3: r = (tap * 4 + hc) * 4 + sp: channel = 16 hc + 4 kq + sp, tap = ky * 3 + kx
+__device__ __forceinline__ int k3_of(int r, int kq) {
+  const int sp = r & 3, hc = (r >> 2) & 3, tap = r >> 4;
+  return (16 * hc + 4 * kq + sp) * 9 + tap;
+}
+
+__global__ __launch_bounds__(256) void dqn_pack_weights_kernel(const float* __restrict__ w1,
+                                                               const float* __restrict__ w2,
+                                                               const float* __restrict__ w3,
+                                                               float* __restrict__ packed) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= PACKED) return;
+  const int lane = i & 63, j = lane & 15, kq = lane >> 4;
+  if (i < PK1) {
+    const int r = (i >> 6) % R1, ct = (i >> 6) / R1;
+    packed[i] = w1[(ct * 16 + j) * K1 + k1_of(r, kq)];
+  } else if (i < PK1 + PK2) {
+    const int q = i - PK1, r = (q >> 6) % R2, ct = (q >> 6) / R2;
+    packed[i] = w2[(ct * 16 + j) * K2 + k2_of(r, kq)];
+  } else {
+    const int q = i - PK1 - PK2, r = (q >> 6) % R3, ct = (q >> 6) / R3;
+    packed[i] = w3[(ct * 16 + j) * K3 + k3_of(r, kq)];
+  }
+}
+
+// ---- conv1: uint8 planes -> y1 [N][475][32] ---------------------------------------------------
+__global__ __launch_bounds__(D1_THREADS) void dqn_conv1_kernel(const uint8_t* __restrict__ obs,
+                                                               const float* __restrict__ packed,
+                                                               const float* __restrict__ b1,
+                                                               float scale, float* __restrict__ y1) {
+  __shared__ __attribute__((aligned(16))) uint8_t img[IMG];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int64_t n = blockIdx.x / D1_PARTS;
+  const int part = (int)(blockIdx.x % D1_PARTS);
+  const int tile = part * D1_TILES + (wave >> 1), ct = wave & 1;
+  // the whole image (2080 x 16 B) and this wave's weights in flight together
+  const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(obs + n * IMG);
+  u32x4 v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v[k] = src[min(tid + k * D1_THREADS, IMG / 16 - 1)];
+  float wa[R1];
+  const float* __restrict__ wp = packed + (int64_t)ct * R1 * 64 + lane;
+#pragma unroll
+  for (int r = 0; r < R1; ++r) wa[r] = wp[r * 64];
+  f32x4 bias = *reinterpret_cast<const f32x4*>(b1 + ct * 16 + 4 * kq);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (tid + k * D1_THREADS < IMG / 16) reinterpret_cast<u32x4*>(img)[tid + k * D1_THREADS] = v[k];
+  __syncthreads();
+  if (tile >= T1) return;
+  const int lpos = tile * 16 + j, q = min(lpos, P1 - 1);
+  const int oy = q / W1, ox = q - oy * W1;
+  const int a0 = oy * (4 * W0) + ox * 4 + (kq >> 1) * W0 + 4 * (kq & 1);
+  // two accumulator chains (even / odd dwords): half the length of each dependent MFMA chain and of
+  // each running sum
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 16; g += 2) {
+    const int off = (g >> 2) * HW0 + 2 * (g & 3) * W0;
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(img + a0 + off);
+    const uint32_t wb = *reinterpret_cast<const uint32_t*>(img + a0 + off + 2 * W0);   // g + 1: ky_hi + 1
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc = mfma16(wa[4 * g + e], (float)((w >> (8 * e)) & 0xffu), acc);
+      acc_b = mfma16(wa[4 * g + 4 + e], (float)((wb >> (8 * e)) & 0xffu), acc_b);
+    }
+  }
+  acc += acc_b;
+  if (lpos < P1) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r] * scale + bias[r], 0.f);
+    *reinterpret_cast<f32x4*>(y1 + (n * P1 + q) * C1 + ct * 16 + 4 * kq) = o;
+  }
+}
+
+// ---- conv2 / conv3: [pixel][channel] plane with a zero border in LDS ---------------------------
+// CIN channels, HI x WI input pixels, KH x KW taps with stride S (padding 1), 12 x 9 outputs,
+// R = KH KW CIN / 4 weight registers; NCHW_OUT: out[n][channel][position] instead of
+// [n][position][channel]
+template <int CIN, int HI, int WI, int KH, int KW, int S, int R, bool NCHW_OUT>
+__global__ __launch_bounds__(D2_THREADS) void dqn_conv23_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ packed,
+                                                                const float* __restrict__ bvec,
+                                                                float* __restrict__ out) {
+  constexpr int PW = WI + 2, PH = HI + 2, CS = CIN + 4, Q = CIN / 4;
+  constexpr int NV = PH * PW * Q;                          // float4 of the padded plane (pad lanes aside)
+  constexpr int NIT = (NV + D2_THREADS - 1) / D2_THREADS;
+  constexpr int COUT = 64;
+  __shared__ __attribute__((aligned(16))) float plane[PH * PW * CS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int64_t n = blockIdx.x >> 2;
+  const int ct = (int)(blockIdx.x & 3);
+  const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(x + n * (HI * WI * CIN));
+  // interior pixels from HBM / L2, border pixels zero: one pass, all loads in flight
+  f32x4 v[NIT];
+  int dst[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int f = min(tid + k * D2_THREADS, NV - 1);
+    const int pix = f / Q, qd = f - pix * Q, py = pix / PW, px = pix - py * PW;
+    const bool in = (py >= 1) && (py <= HI) && (px >= 1) && (px <= WI);
+    const int sp = in ? ((py - 1) * WI + (px - 1)) * Q + qd : 0;
+    v[k] = src[sp];
+    if (!in) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dst[k] = pix * CS + 4 * qd;
+  }
+  float wa[R];
+  const float* __restrict__ wp = packed + (int64_t)ct * R * 64 + lane;
+#pragma unroll
+  for (int r = 0; r < R; ++r) wa[r] = wp[r * 64];
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(bvec + ct * 16 + 4 * kq);
+#pragma unroll
+  for (int k = 0; k < NIT; ++k)
+    if (tid + k * D2_THREADS < NV) *reinterpret_cast<f32x4*>(plane + dst[k]) = v[k];
+  __syncthreads();
+  const int lpos = wave * 16 + j, q = min(lpos, P2 - 1);
+  const int oy = q / W2, ox = q - oy * W2;
+  const float* base = plane + ((S * oy) * PW + S * ox) * CS + 4 * kq;
+  // two accumulator chains (even / odd channel groups): see conv1
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tap = 0; tap < KH * KW; ++tap) {
+    const int ky = tap / KW, kx = tap - ky * KW;
+#pragma unroll
+    for (int hc = 0; hc < CIN / 16; hc += 2) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(base + (ky * PW + kx) * CS + 16 * hc);
+      const f32x4 bw = *reinterpret_cast<const f32x4*>(base + (ky * PW + kx) * CS + 16 * hc + 16);
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        acc = mfma16(wa[(tap * (CIN / 16) + hc) * 4 + sp], bv[sp], acc);
+        acc_b = mfma16(wa[(tap * (CIN / 16) + hc + 1) * 4 + sp], bw[sp], acc_b);
+      }
+    }
+  }
+  acc += acc_b;
+  if (lpos < P2) {
+    if (NCHW_OUT) {
+      float* o = out + n * (COUT * P2) + (ct * 16 + 4 * kq) * P2 + q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r * P2] = fmaxf(acc[r] + bias[r], 0.f);
+    } else {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r] + bias[r], 0.f);
+      *reinterpret_cast<f32x4*>(out + (n * P2 + q) * COUT + ct * 16 + 4 * kq) = o;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace rlpyt
+
+using namespace rlpyt;
+
+extern "C" int64_t rlpyt_dqn_convs_workspace_floats(int64_t N) {
+  return (int64_t)PACKED + N * (int64_t)(P1 * C1 + P2 * C2);
+}
+
+extern "C" int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const float* w1, const float* b1,
+                                       const float* w2, const float* b2, const float* w3,
+                                       const float* b3, float scale, float* workspace, float* out,
+                                       rlpyt_stream_t stream) {
+  RL_CHECK_ARG(N >= 0, RLPYT_EINVAL, "rlpyt_dqn_convs_fwd_f32: bad sizes");
+  if (N == 0) return RLPYT_OK;
+  RL_CHECK_ARG(obs && w1 && b1 && w2 && b2 && w3 && b3 && workspace && out, RLPYT_EINVAL,
+               "rlpyt_dqn_convs_fwd_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(b1) && RL_ALIGNED16(b2) && RL_ALIGNED16(b3) &&
+                   RL_ALIGNED16(workspace) && RL_ALIGNED16(out),
+               RLPYT_ESHAPE, "rlpyt_dqn_convs_fwd_f32: obs / biases / workspace / out must be 16-byte aligned");
+  RL_CHECK_ARG(N <= (1 << 20), RLPYT_ESHAPE, "rlpyt_dqn_convs_fwd_f32: N too large");
+  hipStream_t s = (hipStream_t)stream;
+  float* packed = workspace;
+  float* y1 = workspace + PACKED;
+  float* y2 = y1 + N * (int64_t)(P1 * C1);
+  RL_LAUNCH(dqn_pack_weights_kernel, dim3((PACKED + 255) / 256), dim3(256), 0, s, w1, w2, w3, packed);
+  RL_LAUNCH_CHECK();
+  RL_LAUNCH(dqn_conv1_kernel, dim3((unsigned)(N * D1_PARTS)), dim3(D1_THREADS), 0, s, obs, packed, b1,
+            scale, y1);
+  RL_LAUNCH_CHECK();
+  RL_LAUNCH((dqn_conv23_kernel<C1, H1, W1, 4, 4, 2, R2, false>), dim3((unsigned)(N * 4)),
+            dim3(D2_THREADS), 0, s, y1, packed + PK1, b2, y2);
+  RL_LAUNCH_CHECK();
+  RL_LAUNCH((dqn_conv23_kernel<C2, H2, W2, 3, 3, 1, R3, true>), dim3((unsigned)(N * 4)),
+            dim3(D2_THREADS), 0, s, y2, packed + PK1 + PK2, b3, out);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}

@@ -1,6 +1,15 @@
 """Conv stacks with the module/parameter naming of rlpyt/models/conv2d.py:8-117
 (``conv.<i>`` inside ``Conv2dModel``; ``conv`` + ``head`` inside ``Conv2dHeadModel``), so
-state dicts interchange with the reference."""
+state dicts interchange with the reference.
+
+``Conv2dModel.features`` is the entry the DQN-family models use: raw observations in, flattened
+features out.  For the DQN geometry (4x104x80 uint8 frames, 32-64-64 channels, kernels 8/4/3,
+strides 4/2/1, paddings 0/1/1, ReLU) a no-grad forward on the device -- every sampling step, every
+target-network pass -- runs ``rlpyt_dqn_convs_fwd_f32`` (weight packing + one f32-MFMA kernel per
+layer, ``csrc/dqn_convs.hip``) instead of ~18 library launches; anything else (autograd, other
+geometries, float images, CPU) takes the ``torch.nn.Conv2d`` modules."""
+import os
+
 import torch
 
 from .mlp import MlpModel
@@ -23,9 +32,35 @@ class Conv2dModel(torch.nn.Module):
             if ms > 1:
                 seq.append(torch.nn.MaxPool2d(ms))
         self.conv = torch.nn.Sequential(*seq)
+        self._dqn_geometry = (
+            in_channels == 4 and list(channels) == [32, 64, 64] and list(kernel_sizes) == [8, 4, 3]
+            and list(strides) == [4, 2, 1] and list(paddings) == [0, 1, 1] and not use_maxpool
+            and nonlinearity is torch.nn.ReLU)
+
+    # set False (or RLPYT_DQN_CONVS=0) for the library convolutions in no-grad forwards too (A/B tests)
+    use_fused_nograd_convs = os.environ.get("RLPYT_DQN_CONVS", "1") != "0"
+    FUSED_MAX_IMAGES = 1024         # beyond sampling / target-batch sizes the library kernels are the tuned ones
 
     def forward(self, input):
         return self.conv(input)
+
+    def _fused_ok(self, observation, T_B, img_shape):
+        return (self.use_fused_nograd_convs and self._dqn_geometry and not torch.is_grad_enabled()
+                and observation.is_cuda and observation.dtype == torch.uint8
+                and tuple(img_shape) == (4, 104, 80) and 0 < T_B <= self.FUSED_MAX_IMAGES
+                and self.conv[0].weight.dtype == torch.float32 and self.conv[0].weight.is_cuda
+                and all(self.conv[i].weight.is_contiguous() for i in (0, 2, 4)))
+
+    def features(self, observation, T_B, img_shape):
+        """Flattened features ``[T*B, n]`` (the reference's ``conv(img).view(T * B, -1)``,
+        rlpyt/models/dqn/atari_dqn_model.py:62-63) of raw observations with leading dims folded."""
+        if self._fused_ok(observation, T_B, img_shape):
+            from .. import ops
+            c1, c2, c3 = self.conv[0], self.conv[2], self.conv[4]
+            return ops.dqn_convs_fwd(observation.reshape(T_B, *img_shape), c1.weight, c1.bias,
+                                     c2.weight, c2.bias, c3.weight, c3.bias)
+        from .pg.atari_ff_model import prepare_image
+        return self.conv(prepare_image(observation, T_B, img_shape)).reshape(T_B, -1)
 
     def conv_out_size(self, h, w, c=None):
         for m in self.conv.children():
@@ -55,6 +90,10 @@ class Conv2dHeadModel(torch.nn.Module):
 
     def forward(self, input):
         return self.head(self.conv(input).reshape(input.shape[0], -1))
+
+    def from_observation(self, observation, T_B, img_shape):
+        """``forward`` on raw observations (see ``Conv2dModel.features``)."""
+        return self.head(self.conv.features(observation, T_B, img_shape))
 
     @property
     def output_size(self):

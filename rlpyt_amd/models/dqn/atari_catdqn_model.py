@@ -7,7 +7,6 @@ import torch.nn.functional as F
 from ...utils.tensor import infer_leading_dims, restore_leading_dims
 from ..conv2d import Conv2dModel
 from ..mlp import MlpModel
-from ..pg.atari_ff_model import prepare_image
 from .dueling import DistributionalDuelingHeadModel
 
 
@@ -42,6 +41,5 @@ class AtariCatDqnModel(torch.nn.Module):
     def forward(self, observation, prev_action, prev_reward):
         """Probability masses [.., A, n_atoms] (softmax over atoms)."""
         lead_dim, T, B, img_shape = infer_leading_dims(observation, 3)
-        img = prepare_image(observation, T * B, img_shape)
-        p = F.softmax(self.head(self.conv(img).reshape(T * B, -1)), dim=-1)
+        p = F.softmax(self.head(self.conv.features(observation, T * B, img_shape)), dim=-1)
         return restore_leading_dims(p, lead_dim, T, B)

@@ -1,12 +1,13 @@
 """AtariDqnModel: conv 32-64-64 (k 8/4/3, s 4/2/1, p 0/1/1) + MLP(512) -> Q[A]
 (architecture and names of rlpyt/models/dqn/atari_dqn_model.py:10-68); input preparation as
-in ``AtariFfModel`` (one fused HIP kernel, channels-last)."""
+in ``AtariFfModel`` (one fused HIP kernel, channels-last) under autograd; no-grad forwards on the
+device (sampling steps, target network) run the conv stack as ``rlpyt_dqn_convs_fwd_f32``
+(``Conv2dModel.features``)."""
 import torch
 
 from ...utils.tensor import infer_leading_dims, restore_leading_dims
 from ..conv2d import Conv2dModel
 from ..mlp import MlpModel
-from ..pg.atari_ff_model import prepare_image
 from .dueling import DuelingHeadModel
 
 
@@ -27,6 +28,5 @@ class AtariDqnModel(torch.nn.Module):
 
     def forward(self, observation, prev_action, prev_reward):
         lead_dim, T, B, img_shape = infer_leading_dims(observation, 3)
-        img = prepare_image(observation, T * B, img_shape)
-        q = self.head(self.conv(img).reshape(T * B, -1))
+        q = self.head(self.conv.features(observation, T * B, img_shape))
         return restore_leading_dims(q, lead_dim, T, B)

@@ -3,7 +3,8 @@
 rlpyt/models/dqn/atari_r2d1_model.py:13-77, so state dicts interchange).
 
 On the device the uint8 frames are converted by ``rlpyt_obs_to_nhwc_f32`` (one kernel, no f32
-NCHW copy); the LSTM runs through torch's ``nn.LSTM`` (MIOpen RNN on ROCm) for sequences and for
+NCHW copy) under autograd, and go straight into ``rlpyt_dqn_convs_fwd_f32`` in no-grad forwards of
+up to 1024 images (sampling steps; ``Conv2dModel.features``); the LSTM runs through torch's ``nn.LSTM`` (MIOpen RNN on ROCm) for sequences and for
 anything under autograd, and through ``ops.LstmStep`` (split-K gate GEMM + one cell kernel) for the
 one-step sampling forward; the returned state ``RnnState(h, c)`` always keeps the B dimension,
 shape ``[N, B, H]``."""
@@ -15,7 +16,6 @@ from ...utils.collections import namedarraytuple
 from ...utils.tensor import infer_leading_dims, restore_leading_dims
 from ..conv2d import Conv2dHeadModel
 from ..mlp import MlpModel
-from ..pg.atari_ff_model import prepare_image
 from .dueling import DuelingHeadModel
 
 RnnState = namedarraytuple("RnnState", ["h", "c"])
@@ -57,7 +57,7 @@ class AtariR2d1Model(torch.nn.Module):
     def forward(self, observation, prev_action, prev_reward, init_rnn_state):
         """Leading dims [T,B], [B] or []; prev_action one-hot; returns (q, RnnState [N,B,H])."""
         lead_dim, T, B, img_shape = infer_leading_dims(observation, 3)
-        conv_out = self.conv(prepare_image(observation, T * B, img_shape))
+        conv_out = self.conv.from_observation(observation, T * B, img_shape)
         if self._fused_step_ok(T, B, conv_out, init_rnn_state):
             # sampling forward, one time step: gate GEMM + cell as two launches (ops.LstmStep)
             if self._lstm_step is None:

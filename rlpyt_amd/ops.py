@@ -937,6 +937,30 @@ def atari_sample_convs(obs, t_dev, lo, new_frame, full_rows, slot, w1, b1, w2, b
     return out
 
 
+def dqn_convs_fwd(obs, w1, b1, w2, b2, w3, b3, scale=1. / 255, out=None):
+    """No-grad forward of the DQN-family conv stack (Conv2d(4,32,8,s4) / (32,64,4,s2,p1) /
+    (64,64,3,s1,p1), ReLU after each; rlpyt/models/dqn/atari_dqn_model.py:30-37) on uint8 frames
+    ``[N,4,104,80]``: returns ``[N, 6912]`` in the order of ``conv(img).view(N, -1)``.  Weights in
+    the torch layout; they are re-packed on the stream in front of the layer kernels, so the call
+    (also as a captured graph node) always sees the current parameters."""
+    _lib.require_gpu()
+    assert obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape[1:]) == (4, 104, 80)
+    assert tuple(w1.shape) == (32, 4, 8, 8) and tuple(w2.shape) == (64, 32, 4, 4)
+    assert tuple(w3.shape) == (64, 64, 3, 3)
+    for x in (w1, b1, w2, b2, w3, b3):
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.device == obs.device
+    N = obs.shape[0]
+    ws = torch.empty(int(lib.rlpyt_dqn_convs_workspace_floats(N)), dtype=torch.float32,
+                     device=obs.device)
+    if out is None:
+        out = torch.empty((N, 6912), dtype=torch.float32, device=obs.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (N, 6912)
+    check(lib.rlpyt_dqn_convs_fwd_f32(ptr(obs), N, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3),
+                                      ptr(b3), float(scale), ptr(ws), ptr(out), stream()),
+          "rlpyt_dqn_convs_fwd_f32")
+    return out
+
+
 def categorical_head(h, w_pi, b_pi, w_v=None, b_v=None, uniforms=None, u_row=None):
     """Policy / value heads + softmax (+ inverse-CDF action sampling when ``uniforms`` is
     given) in one kernel -- the no-grad sampling forward of

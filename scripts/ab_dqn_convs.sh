@@ -1,0 +1,19 @@
+#!/bin/bash
+# A/B of the fused no-grad DQN conv stack (ON THE GPU BOX): tests, then dqn / r2d1 bench lines with
+# RLPYT_DQN_CONVS=0|1 interleaved (short ring fill: the per-iteration work does not depend on it).
+OUT=$PWD/gpurun_out/r5_dqn_convs
+rm -rf $OUT; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_dqn_convs_gpu.py tests/test_variants.py tests/test_algo_parity.py tests/test_models_gpu.py -m gpu -q -x --timeout 300 -p no:cacheprovider > $OUT/tests.log 2>&1
+echo "pytest rc=$?" >> $OUT/tests.log
+tail -15 $OUT/tests.log
+for rep in 1 2; do
+  for v in 0 1; do
+    for cfg in dqn r2d1; do
+      if [ $cfg = dqn ]; then A="--replay-fill-itrs 3000"; else A="--replay-fill-itrs 60 --steps 15"; fi
+      RLPYT_DQN_CONVS=$v timeout 300 python bench.py --config $cfg $A --no-cpu-baseline 2> $OUT/${cfg}_${v}_${rep}.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(json.dumps(dict(cfg='$cfg', fused=$v, rep=$rep, sps=round(d['value']), ms_per_step=round(d['ms_per_step'],3), updates_per_s=round(d.get('updates_per_s') or 0,1), sampling_frac=round(d.get('sampling_frac_of_step',0),3))))" | tee -a $OUT/ab.jsonl
+    done
+  done
+done

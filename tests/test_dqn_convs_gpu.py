@@ -1,0 +1,162 @@
+"""No-grad forward of the DQN-family conv stack (``rlpyt_dqn_convs_fwd_f32``, csrc/dqn_convs.hip)
+against ``torch.nn.Conv2d`` -- the modules the reference's models are made of
+(rlpyt/models/conv2d.py:8-57 under rlpyt/models/dqn/atari_dqn_model.py:30-37,
+atari_r2d1_model.py:33-41).  f32 MFMA, f32 accumulate, another summation order: held to three times torch-f32's
+own error against float64 (measured: 1.0-2.3x), at every launch geometry (1 image .. beyond one wave of workgroups), and
+through the models that dispatch to it."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _stack(seed, scale_w=1.0):
+    torch.manual_seed(seed)
+    convs = [torch.nn.Conv2d(4, 32, 8, stride=4), torch.nn.Conv2d(32, 64, 4, stride=2, padding=1),
+             torch.nn.Conv2d(64, 64, 3, stride=1, padding=1)]
+    with torch.no_grad():
+        for c in convs:
+            c.weight.mul_(scale_w)
+            c.bias.uniform_(-0.2, 0.2)       # biases that move ReLU's zero crossings
+    return convs
+
+
+@torch.no_grad()
+def _reference(convs, obs, dtype):
+    x = obs.to(dtype) * (1. / 255)
+    for c in convs:
+        x = torch.relu(torch.nn.functional.conv2d(x, c.weight.to(dtype), c.bias.to(dtype),
+                                                  stride=c.stride, padding=c.padding))
+    return x.reshape(obs.shape[0], -1)
+
+
+def _check(ops, convs, obs):
+    dev = [c.cuda() for c in convs]
+    got = ops.dqn_convs_fwd(obs.cuda(), *[p for c in dev for p in (c.weight.detach(), c.bias.detach())])
+    torch.cuda.synchronize()
+    got = got.cpu().double()
+    ref64 = _reference([c.cpu() for c in convs], obs.cpu(), torch.float64)
+    ref32 = _reference([c.cpu() for c in convs], obs.cpu(), torch.float32).double()
+    scale = ref64.abs().max().item() + 1e-12
+    err = (got - ref64).abs().max().item() / scale
+    err32 = (ref32 - ref64).abs().max().item() / scale
+    assert got.shape == ref64.shape
+    assert err <= max(3 * err32, 3e-7), (err, err32)
+    return got, ref64
+
+
+@pytest.mark.parametrize("N", [1, 3, 16, 48, 130, 300])
+def test_dqn_convs_match_torch_conv2d(N):
+    from rlpyt_amd import ops
+    g = torch.Generator().manual_seed(N)
+    obs = torch.randint(0, 256, (N, 4, 104, 80), dtype=torch.uint8, generator=g)
+    _check(ops, _stack(N), obs)
+
+
+def test_dqn_convs_edge_images_and_wide_weights():
+    """All-black / all-white frames (border handling: padding must contribute exact zeros), single
+    hot pixels in every corner, weights 8x the default scale (large activations through three ReLUs)."""
+    from rlpyt_amd import ops
+    obs = torch.zeros((6, 4, 104, 80), dtype=torch.uint8)
+    obs[1] = 255
+    obs[2, 0, 0, 0] = 255
+    obs[3, 3, 103, 79] = 255
+    obs[4, 1, 0, 79] = 200
+    obs[5, 2, 103, 0] = 17
+    _check(ops, _stack(5), obs)
+    g = torch.Generator().manual_seed(1)
+    _check(ops, _stack(6, scale_w=8.0), torch.randint(0, 256, (9, 4, 104, 80), dtype=torch.uint8, generator=g))
+
+
+def test_dqn_convs_identity_like_weights_asymmetric():
+    """Weights that pick ONE input tap / channel per output channel: any transposition of (ky, kx),
+    channel order or position order inside the packed layout shows up as a wrong pixel, not as a
+    small numeric difference."""
+    from rlpyt_amd import ops
+    convs = _stack(0)
+    with torch.no_grad():
+        for li, c in enumerate(convs):
+            c.weight.zero_()
+            c.bias.zero_()
+            co, ci, kh, kw = c.weight.shape
+            for o in range(co):
+                c.weight[o, (3 * o + li) % ci, (o + 2 * li) % kh, (5 * o + 1) % kw] = 1.0 + 0.01 * o
+    g = torch.Generator().manual_seed(3)
+    obs = torch.randint(0, 256, (5, 4, 104, 80), dtype=torch.uint8, generator=g)
+    got, ref = _check(ops, convs, obs)
+    assert ref.abs().max() > 0.1
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=3e-6, atol=1e-6)
+
+
+def test_dqn_convs_see_parameter_updates_without_refresh():
+    """The packed weight copy is rebuilt on the stream at every call: an in-place parameter change
+    (optimizer step, target update) is visible to the very next call, also from a captured graph."""
+    from rlpyt_amd import ops
+    convs = [c.cuda() for c in _stack(2)]
+    args = [p for c in convs for p in (c.weight.detach(), c.bias.detach())]
+    g = torch.Generator().manual_seed(4)
+    obs = torch.randint(0, 256, (8, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    out = torch.empty((8, 6912), device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.dqn_convs_fwd(obs, *args, out=out)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            ops.dqn_convs_fwd(obs, *args, out=out)
+    torch.cuda.synchronize()
+    first = out.clone()
+    with torch.no_grad():
+        convs[1].weight.mul_(0.5)
+        convs[2].bias.add_(0.05)
+    graph.replay()
+    torch.cuda.synchronize()
+    want = _reference([c.cpu() for c in convs], obs.cpu(), torch.float64)
+    assert not torch.allclose(out, first)
+    np.testing.assert_allclose(out.cpu().double().numpy(), want.numpy(), rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("lead", [(), (5,), (2, 3)])
+def test_dqn_family_models_dispatch_to_the_fused_convs(lead):
+    """AtariDqnModel / AtariCatDqnModel / AtariR2d1Model: the no-grad device forward (fused convs)
+    equals the same model's library path (``use_fused_nograd_convs = False``) and its autograd
+    forward, and the launch counters show which one ran."""
+    from rlpyt_amd import _lib
+    from rlpyt_amd.models.dqn.atari_catdqn_model import AtariCatDqnModel
+    from rlpyt_amd.models.dqn.atari_dqn_model import AtariDqnModel
+    from rlpyt_amd.models.dqn.atari_r2d1_model import AtariR2d1Model
+    g = torch.Generator().manual_seed(7)
+    obs = torch.randint(0, 256, lead + (4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    pa = torch.zeros(lead + (6,), device="cuda")
+    pr = torch.zeros(lead, device="cuda")
+
+    def ran_fused():
+        return any("dqn_conv23_kernel" in k and v > 0 for k, v in _lib.variant_counts().items())
+
+    for Cls, kw in [(AtariDqnModel, {}), (AtariDqnModel, dict(dueling=True)), (AtariCatDqnModel, {})]:
+        torch.manual_seed(1)
+        m = Cls(image_shape=(4, 104, 80), output_size=6, **kw).cuda()
+        _lib.variant_reset()
+        with torch.no_grad():
+            fused = m(obs, pa, pr)
+        assert ran_fused()
+        _lib.variant_reset()
+        grad = m(obs, pa, pr)                      # autograd: library convolutions
+        assert not ran_fused() and grad.requires_grad
+        m.conv.use_fused_nograd_convs = False
+        with torch.no_grad():
+            lib = m(obs, pa, pr)
+        assert not ran_fused()
+        np.testing.assert_allclose(fused.cpu().numpy(), lib.cpu().numpy(), rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(fused.cpu().numpy(), grad.detach().cpu().numpy(), rtol=2e-4, atol=2e-6)
+    if len(lead) == 2:
+        torch.manual_seed(2)
+        m = AtariR2d1Model(image_shape=(4, 104, 80), output_size=6, dueling=True).cuda()
+        with torch.no_grad():
+            _lib.variant_reset()
+            q1, s1 = m(obs, pa, pr, None)
+            assert ran_fused()
+            m.conv.conv.use_fused_nograd_convs = False
+            q2, s2 = m(obs, pa, pr, None)
+        np.testing.assert_allclose(q1.cpu().numpy(), q2.cpu().numpy(), rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(s1.h.cpu().numpy(), s2.h.cpu().numpy(), rtol=2e-4, atol=2e-6)

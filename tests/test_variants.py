@@ -554,6 +554,15 @@ def _gemm_tn_x6():
     Cv.test_gemm_tn_bf16x6_is_f32_accurate(_ops(), 132, 200, 2080)    # ragged K chunks + partials
 
 
+@case("dqn_pack_weights_kernel", "dqn_conv1_kernel",
+      "dqn_conv23_kernel<32, 25, 19, 4, 4, 2, 128, false>",
+      "dqn_conv23_kernel<64, 12, 9, 3, 3, 1, 144, true>")
+def _dqn_convs():
+    import test_dqn_convs_gpu as D
+    D.test_dqn_convs_match_torch_conv2d(3)
+    D.test_dqn_convs_identity_like_weights_asymmetric()
+
+
 @case("replay_step_fields_kernel")
 def _replay_step_fields():
     """One-launch field gather of a single-step replay batch vs the row-by-row gathers + selects it
