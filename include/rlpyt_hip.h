@@ -530,6 +530,14 @@ int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void);
  * `conv(img).view(N, -1)`.  scale multiplies the pixels (1/255).  workspace: at least
  * rlpyt_dqn_convs_workspace_floats(N) floats (packed weights + the two intermediate layers).
  * Four launches (weight packing + one per layer), f32 MFMA, f32 accumulate. */
+/* No-grad forward of a single-layer LSTM over a sequence (torch.nn.LSTM in
+ * rlpyt/models/dqn/atari_r2d1_model.py:61-63 as the target / warm-up / double-DQN passes of
+ * rlpyt/algos/dqn/r2d1.py:199-224 run it).  xproj [T,B,4H] = x W_ih^T + b_ih + b_hh for every step
+ * (torch gate order i,f,g,o; made by the caller with one GEMM); w_hh [4H,H]; h0 [B,H]; c [B,H]:
+ * c0 on entry, c_T on return (updated in place); out [T,B,H] = h_1..h_T.  One launch per time
+ * step; H in {256, 512}. */
+int rlpyt_lstm_seq_f32(const float* xproj, const float* w_hh, const float* h0, float* c, float* out,
+                       int T, int B, int H, rlpyt_stream_t stream);
 int64_t rlpyt_dqn_convs_workspace_floats(int64_t N);
 int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const float* w1, const float* b1,
                             const float* w2, const float* b2, const float* w3, const float* b3,

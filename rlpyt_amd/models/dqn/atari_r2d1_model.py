@@ -5,8 +5,9 @@ rlpyt/models/dqn/atari_r2d1_model.py:13-77, so state dicts interchange).
 On the device the uint8 frames are converted by ``rlpyt_obs_to_nhwc_f32`` (one kernel, no f32
 NCHW copy) under autograd, and go straight into ``rlpyt_dqn_convs_fwd_f32`` in no-grad forwards of
 up to 1024 images (sampling steps; ``Conv2dModel.features``); the LSTM runs through torch's ``nn.LSTM`` (MIOpen RNN on ROCm) for sequences and for
-anything under autograd, and through ``ops.LstmStep`` (split-K gate GEMM + one cell kernel) for the
-one-step sampling forward; the returned state ``RnnState(h, c)`` always keeps the B dimension,
+anything under autograd, through ``ops.LstmStep`` (split-K gate GEMM + one cell kernel) for the
+one-step sampling forward and through ``ops.lstm_sequence`` (one launch per time step) for the no-grad
+sequence passes of the update; the returned state ``RnnState(h, c)`` always keeps the B dimension,
 shape ``[N, B, H]``."""
 import os
 
@@ -37,6 +38,8 @@ class AtariR2d1Model(torch.nn.Module):
 
     # set False (or RLPYT_LSTM_STEP=0) for the library RNN in the one-step sampling forward too (A/B tests)
     use_fused_lstm_step = os.environ.get("RLPYT_LSTM_STEP", "1") != "0"
+    # ... and RLPYT_LSTM_SEQ=0 for the library RNN in no-grad SEQUENCE forwards
+    use_fused_lstm_sequence = os.environ.get("RLPYT_LSTM_SEQ", "1") != "0"
     _lstm_step = None
 
     def _fused_step_ok(self, T, B, conv_out, init_rnn_state):
@@ -72,6 +75,14 @@ class AtariR2d1Model(torch.nn.Module):
                                 prev_action.reshape(T, B, -1).to(conv_out.dtype),
                                 prev_reward.reshape(T, B, 1).to(conv_out.dtype)], dim=2)
         state = None if init_rnn_state is None else tuple(x.contiguous() for x in init_rnn_state)
+        if self.use_fused_lstm_sequence and T > 1:
+            from ... import ops
+            if ops.lstm_sequence_ok(self.lstm, lstm_input, None if state is None else state[0]):
+                # no-grad sequence (target / warm-up / double-DQN passes of the update): one launch
+                # per time step
+                lstm_out, (hn, cn) = ops.lstm_sequence(self.lstm, lstm_input, *(state or (None, None)))
+                q = self.head(lstm_out.reshape(T * B, -1))
+                return restore_leading_dims(q, lead_dim, T, B), RnnState(h=hn, c=cn)
         lstm_out, (hn, cn) = self.lstm(lstm_input, state)
         q = self.head(lstm_out.reshape(T * B, -1))
         return restore_leading_dims(q, lead_dim, T, B), RnnState(h=hn, c=cn)

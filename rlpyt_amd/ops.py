@@ -824,6 +824,41 @@ class LstmStep:
         return h1, c1
 
 
+LSTM_SEQ_HIDDEN = (256, 512)     # hidden sizes rlpyt_lstm_seq_f32 is instantiated for
+
+
+def lstm_sequence_ok(lstm, x, h0):
+    """Whether ``lstm_sequence`` serves this call: no autograd, single-layer f32 LSTM on the device,
+    a hidden size the kernel is built for, ``x [T,B,I]``."""
+    return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3
+            and lstm.num_layers == 1 and not lstm.bidirectional and lstm.bias
+            and not lstm.batch_first and getattr(lstm, "proj_size", 0) == 0
+            and lstm.hidden_size in LSTM_SEQ_HIDDEN and lstm.weight_hh_l0.dtype == torch.float32
+            and (h0 is None or (h0.dim() == 3 and h0.shape[0] == 1 and h0.shape[1] == x.shape[1])))
+
+
+def lstm_sequence(lstm, x, h0=None, c0=None):
+    """No-grad ``torch.nn.LSTM`` forward over a sequence ``x [T,B,I]`` (state ``[1,B,H]`` or None):
+    one library GEMM for the input projection of all time steps, then ONE launch per time step
+    (``rlpyt_lstm_seq_f32``: recurrent product + gates + cell) instead of the library RNN's five.
+    Returns ``(out [T,B,H], (h_T [1,B,H], c_T [1,B,H]))`` like the module."""
+    _lib.require_gpu()
+    T, B, _ = x.shape
+    H = lstm.hidden_size
+    xproj = torch.addmm(lstm.bias_ih_l0 + lstm.bias_hh_l0, x.reshape(T * B, -1), lstm.weight_ih_l0.t())
+    h0 = (torch.zeros((B, H), dtype=torch.float32, device=x.device) if h0 is None
+          else _f32(h0.reshape(B, H)))
+    c = (torch.zeros((B, H), dtype=torch.float32, device=x.device) if c0 is None
+         else c0.reshape(B, H).to(torch.float32).clone())
+    out = torch.empty((T, B, H), dtype=torch.float32, device=x.device)
+    w_hh = lstm.weight_hh_l0
+    assert w_hh.is_contiguous()
+    check(lib.rlpyt_lstm_seq_f32(ptr(xproj), ptr(w_hh), ptr(h0), ptr(c), ptr(out), T, B, H, stream()),
+          "rlpyt_lstm_seq_f32")
+    hn = out[T - 1:T] if T > 0 else h0.unsqueeze(0)
+    return out, (hn, c.unsqueeze(0))
+
+
 def update_tick(ctr, table, hyper_cur, idx_all, idx_static, tick_idx):
     """First launch of a captured minibatch update (``rlpyt_update_tick``): row ``*ctr`` of the
     per-update hyper-parameter ``table [n, cols]`` -> ``hyper_cur [cols]``; the update's index chunk

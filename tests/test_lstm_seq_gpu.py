@@ -1,0 +1,89 @@
+"""No-grad LSTM sequence forward (``rlpyt_lstm_seq_f32``, csrc/lstm_seq.hip) against
+``torch.nn.LSTM`` -- the module rlpyt/models/dqn/atari_r2d1_model.py:61-63 runs the target /
+warm-up / double-DQN passes of R2D1's update through (rlpyt/algos/dqn/r2d1.py:199-224)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(H, I, T, B, seed, with_state):
+    torch.manual_seed(seed)
+    lstm = torch.nn.LSTM(I, H)
+    x = torch.randn(T, B, I)
+    state = (torch.randn(1, B, H) * 0.5, torch.randn(1, B, H) * 0.5) if with_state else None
+    return lstm, x, state
+
+
+@torch.no_grad()
+def _check(ops, lstm, x, state):
+    ref_mod = torch.nn.LSTM(lstm.input_size, lstm.hidden_size).double()
+    ref_mod.load_state_dict({k: v.double() for k, v in lstm.state_dict().items()})
+    st64 = None if state is None else tuple(s.double() for s in state)
+    ref, (rh, rc) = ref_mod(x.double(), st64)
+    dev = lstm.cuda()
+    xs, sts = x.cuda(), None if state is None else tuple(s.cuda() for s in state)
+    assert ops.lstm_sequence_ok(dev, xs, None if sts is None else sts[0])
+    out, (hn, cn) = ops.lstm_sequence(dev, xs, *(sts or (None, None)))
+    lib_out, (lh, lc) = dev(xs, sts)                      # the library RNN, f32
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape and hn.shape == rh.shape and cn.shape == rc.shape
+    for got, lib, want in [(out, lib_out, ref), (hn, lh, rh), (cn, lc, rc)]:
+        err = (got.cpu().double() - want).abs().max().item()
+        err_lib = (lib.cpu().double() - want).abs().max().item()
+        assert err <= max(3 * err_lib, 2e-6), (err, err_lib)
+    if sts is not None:                                    # inputs untouched (c is cloned, not updated in place)
+        assert torch.equal(sts[1].cpu(), state[1])
+
+
+@pytest.mark.parametrize("H,I", [(512, 519), (256, 37)])
+@pytest.mark.parametrize("T,B", [(1, 1), (7, 5), (12, 32), (9, 64), (5, 70), (45, 64)])
+@pytest.mark.parametrize("with_state", [False, True])
+def test_lstm_sequence_matches_torch_lstm(H, I, T, B, with_state):
+    from rlpyt_amd import ops
+    _check(ops, *_case(H, I, T, B, seed=T * 100 + B, with_state=with_state))
+
+
+def test_lstm_sequence_saturating_gates():
+    """Large pre-activations (sigmoid / tanh saturate, exp overflows to inf inside sigmoid): finite
+    outputs equal to the library's."""
+    from rlpyt_amd import ops
+    lstm, x, state = _case(512, 40, 6, 33, seed=3, with_state=True)
+    with torch.no_grad():
+        lstm.weight_ih_l0.mul_(40.)
+        lstm.weight_hh_l0.mul_(10.)
+    _check(ops, lstm, x * 3, state)
+
+
+def test_r2d1_model_dispatches_no_grad_sequences_to_the_fused_lstm():
+    from rlpyt_amd import _lib
+    from rlpyt_amd.models.dqn.atari_r2d1_model import AtariR2d1Model
+    torch.manual_seed(4)
+    m = AtariR2d1Model(image_shape=(4, 104, 80), output_size=6).cuda()
+    g = torch.Generator().manual_seed(5)
+    T, B = 6, 9
+    obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    pa = torch.nn.functional.one_hot(torch.randint(0, 6, (T, B), generator=g), 6).float().cuda()
+    pr = torch.randn(T, B, generator=g).cuda()
+    init = tuple(torch.randn(1, B, 512, generator=g).cuda() * 0.3 for _ in range(2))
+
+    def ran():
+        return any("lstm_seq_step_kernel" in k and v > 0 for k, v in _lib.variant_counts().items())
+
+    with torch.no_grad():
+        _lib.variant_reset()
+        q1, s1 = m(obs, pa, pr, init)
+        assert ran()
+        m.use_fused_lstm_sequence = False
+        _lib.variant_reset()
+        q2, s2 = m(obs, pa, pr, init)
+        assert not ran()
+    m.use_fused_lstm_sequence = True
+    _lib.variant_reset()
+    q3, _ = m(obs, pa, pr, init)                           # autograd: library RNN
+    assert not ran() and q3.requires_grad
+    np.testing.assert_allclose(q1.cpu().numpy(), q2.cpu().numpy(), rtol=2e-4, atol=5e-6)
+    np.testing.assert_allclose(s1.h.cpu().numpy(), s2.h.cpu().numpy(), rtol=2e-4, atol=5e-6)
+    np.testing.assert_allclose(s1.c.cpu().numpy(), s2.c.cpu().numpy(), rtol=2e-4, atol=5e-6)
+    assert tuple(s1.h.shape) == (1, B, 512) and tuple(s1.c.shape) == (1, B, 512)

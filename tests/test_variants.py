@@ -563,6 +563,14 @@ def _dqn_convs():
     D.test_dqn_convs_identity_like_weights_asymmetric()
 
 
+@case("lstm_seq_step_kernel<8>", "lstm_seq_step_kernel<4>")
+def _lstm_seq():
+    import test_lstm_seq_gpu as L
+    for H, I in ((512, 519), (256, 37)):
+        L.test_lstm_sequence_matches_torch_lstm(H, I, 7, 5, True)
+        L.test_lstm_sequence_matches_torch_lstm(H, I, 5, 70, False)
+
+
 @case("replay_step_fields_kernel")
 def _replay_step_fields():
     """One-launch field gather of a single-step replay batch vs the row-by-row gathers + selects it
