@@ -422,6 +422,16 @@ int rlpyt_eps_greedy_f32(const float* q, int64_t n, int A, const float* eps, int
                          const float* uniforms /*[T, n]*/, const int64_t* t_dev /*nullable*/,
                          int64_t* action /*[n]*/, rlpyt_stream_t stream);
 
+/* Inputs of one recurrent sampling step in one launch (rlpyt/agents/dqn/r2d1_agent.py:23-40 + the
+ * reset handling of rlpyt/samplers/parallel/gpu/action_server.py:49-53, rlpyt/agents/base.py:283-297):
+ * xh [B,Kp] = [act(feat [B,F]) | onehot(action [B], A) | reward [B] | h [B,H] | 0-pad], with null action 0 /
+ * zero reward / zero state for rows with done[b] (done nullable: no resets); prev_h, prev_c [B,H] = the
+ * state the step starts from; c zeroed in place for reset rows.  relu != 0: act = ReLU. */
+int rlpyt_rnn_step_inputs_f32(const float* feat, int F, int relu, const int64_t* action, int A,
+                              const float* reward, const uint8_t* done /*nullable*/, const float* h,
+                              float* c, int H, float* xh, int Kp, float* prev_h, float* prev_c,
+                              int64_t B, rlpyt_stream_t stream);
+
 /* One LSTM cell step for the per-time-step sampling forward of the recurrent agents
  * (torch.nn.LSTM with T = 1 as used by rlpyt/models/dqn/atari_r2d1_model.py:61-63 and
  * rlpyt/models/pg/atari_lstm_model.py): the gate pre-activations arrive as the split-K partials

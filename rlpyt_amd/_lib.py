@@ -138,6 +138,8 @@ _SIGNATURES = {
                                              _p, _p, _p, _p, _p, _p, c_float, _p, _p]),
     "rlpyt_atari_sample_convs_to_f32": (c_int, [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, _p, _p,
                                                 _p, _p, _p, _p, _p, _p, c_float, _p, _p, _p]),
+    "rlpyt_rnn_step_inputs_f32": (c_int, [_p, c_int, c_int, _p, c_int, _p, _p, _p, _p, c_int, _p, c_int, _p,
+                                          _p, c_int64, _p]),
     "rlpyt_lstm_seq_f32": (c_int, [_p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
     "rlpyt_dqn_convs_workspace_floats": (c_int64, [c_int64]),
     "rlpyt_dqn_convs_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, _p, c_float, _p, _p, _p]),

@@ -341,6 +341,64 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
 }  // namespace
 }  // namespace rlpyt
 
+// Inputs of one recurrent sampling step, assembled in ONE launch (rlpyt/agents/dqn/r2d1_agent.py:23-40
+// with the collector's reset handling, rlpyt/samplers/parallel/gpu/action_server.py:49-53 and
+// rlpyt/agents/base.py:283-297): row b of
+//   xh = [ act(feat[b]) | onehot(prev_action[b]) | prev_reward[b] | h[b] | 0-pad ]   ([B, Kp], the
+//        [x | h] row rlpyt_fc_small_f32 multiplies with [W_ih | W_hh])
+// where for an environment that was reset before this step (done[b]) the previous action is the
+// null action 0, the previous reward 0 and the recurrent state zero; prev_h / prev_c receive the state
+// the step starts from (what the reference stores as agent_info.prev_rnn_state) and c is zeroed IN
+// PLACE for reset environments (h needs no write-back: the cell kernel overwrites it).  Replaces
+// where x 2 + fills + one-hot scatter + mask casts + two state multiplies + concatenation + two
+// state clones of the eager path (14 launches).  One workgroup per row.
+namespace rlpyt {
+namespace {
+__global__ __launch_bounds__(256) void rnn_step_inputs_kernel(
+    const float* __restrict__ feat, int F, int relu, const int64_t* __restrict__ action, int A,
+    const float* __restrict__ reward, const uint8_t* __restrict__ done, const float* __restrict__ h,
+    float* __restrict__ c, int H, float* __restrict__ xh, int Kp, float* __restrict__ prev_h,
+    float* __restrict__ prev_c) {
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const bool keep = done == nullptr || done[b] == 0;
+  float* __restrict__ row = xh + b * Kp;
+  for (int k = tid; k < F; k += 256) {
+    const float v = feat[b * F + k];
+    row[k] = relu ? fmaxf(v, 0.f) : v;
+  }
+  const int64_t act = keep ? action[b] : 0;
+  for (int a = tid; a < A; a += 256) row[F + a] = (a == act) ? 1.f : 0.f;
+  if (tid == 0) row[F + A] = keep ? reward[b] : 0.f;
+  const int h0 = F + A + 1;
+  for (int k = tid; k < H; k += 256) {
+    const float hv = keep ? h[b * H + k] : 0.f, cv = keep ? c[b * H + k] : 0.f;
+    row[h0 + k] = hv;
+    prev_h[b * H + k] = hv;
+    prev_c[b * H + k] = cv;
+    if (!keep) c[b * H + k] = 0.f;
+  }
+  for (int k = h0 + H + tid; k < Kp; k += 256) row[k] = 0.f;
+}
+}  // namespace
+}  // namespace rlpyt
+
+extern "C" int rlpyt_rnn_step_inputs_f32(const float* feat, int F, int relu, const int64_t* action,
+                                         int A, const float* reward, const uint8_t* done,
+                                         const float* h, float* c, int H, float* xh, int Kp,
+                                         float* prev_h, float* prev_c, int64_t B,
+                                         rlpyt_stream_t stream) {
+  RL_CHECK_ARG(feat && action && reward && h && c && xh && prev_h && prev_c, RLPYT_EINVAL,
+               "rlpyt_rnn_step_inputs_f32: null pointer");
+  RL_CHECK_ARG(B > 0 && F > 0 && A > 0 && H > 0 && Kp >= F + A + 1 + H, RLPYT_ESHAPE,
+               "rlpyt_rnn_step_inputs_f32: need B, F, A, H > 0 and Kp >= F + A + 1 + H (F=%d A=%d H=%d Kp=%d)",
+               F, A, H, Kp);
+  RL_LAUNCH(rlpyt::rnn_step_inputs_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, feat,
+            F, relu, action, A, reward, done, h, c, H, xh, Kp, prev_h, prev_c);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
 // Epsilon-greedy action selection of the DQN-family agents' sampling step
 // (rlpyt/distributions/epsilon_greedy.py:17-29: argmax, then with probability epsilon a uniformly
 // random action) from ONE pre-drawn uniform per environment and step: u < eps -> the action

@@ -57,6 +57,40 @@ class AtariR2d1Model(torch.nn.Module):
         if self._lstm_step is not None:
             self._lstm_step.refresh(force=True)
 
+    def sample_step_ok(self, observation, prev_action):
+        """Whether ``sample_step`` serves this sampling step (else: ``forward`` through the agent's
+        eager path)."""
+        lin = getattr(self.conv.head, "model", None)
+        return (self.use_fused_lstm_step and not torch.is_grad_enabled() and observation.is_cuda
+                and observation.dim() == 4 and observation.shape[0] <= 256
+                and isinstance(prev_action, torch.Tensor) and prev_action.dtype == torch.int64
+                and prev_action.dim() == 1 and self.lstm.hidden_size % 16 == 0
+                and self.lstm.weight_ih_l0.dtype == torch.float32
+                and isinstance(lin, torch.nn.Sequential) and len(lin) == 2
+                and isinstance(lin[0], torch.nn.Linear) and isinstance(lin[1], torch.nn.ReLU))
+
+    def sample_step(self, observation, prev_action, prev_reward, done, h_state, c_state):
+        """One sampling step with the collector's reset handling folded in: ``observation [B,C,H,W]``,
+        ``prev_action [B]`` (indices), ``prev_reward [B]`` as stored -- NOT nulled --, ``done [B]``
+        (bool; None: no resets) = environments that were reset before this step, ``h_state`` /
+        ``c_state [B,H]`` the persistent recurrent state, UPDATED IN PLACE.  Conv stack -> trunk
+        GEMM -> ``rlpyt_rnn_step_inputs_f32`` (trunk ReLU, one-hot, nulling, state zeroing, ``[x | h]``
+        row, the state the step starts from) -> gate GEMM -> cell -> head.  Returns
+        ``(q [B,A], prev_h [B,H], prev_c [B,H])``."""
+        from ... import ops
+        B, img_shape = observation.shape[0], observation.shape[1:]
+        lin = self.conv.head.model[0]
+        pre = torch.nn.functional.linear(self.conv.conv.features(observation, B, img_shape),
+                                         lin.weight, lin.bias)
+        if self._lstm_step is None:
+            self._lstm_step = ops.LstmStep(self.lstm)
+        step = self._lstm_step
+        n_actions = self.lstm.input_size - self.conv.output_size - 1
+        xh, prev_h, prev_c = ops.rnn_step_inputs(pre, prev_action, prev_reward.float(), done, h_state,
+                                                 c_state, n_actions, step.Kp, relu=True)
+        step.step_rows(xh, h_state, c_state)
+        return self.head(h_state), prev_h, prev_c
+
     def forward(self, observation, prev_action, prev_reward, init_rnn_state):
         """Leading dims [T,B], [B] or []; prev_action one-hot; returns (q, RnnState [N,B,H])."""
         lead_dim, T, B, img_shape = infer_leading_dims(observation, 3)

@@ -823,6 +823,47 @@ class LstmStep:
               "rlpyt_lstm_cell_f32")
         return h1, c1
 
+    def step_rows(self, xh, h_state, c_state):
+        """The step on rows assembled by ``rnn_step_inputs`` (``xh [B, Kp]``), the new state written
+        IN PLACE into ``h_state`` / ``c_state`` ``[B, H]`` (persistent buffers of the sampler's
+        pipeline group: no copy-back, a captured graph keeps their addresses)."""
+        _lib.require_gpu()
+        self.refresh()
+        B = xh.shape[0]
+        assert xh.shape[1] == self.Kp and h_state.is_contiguous() and c_state.is_contiguous()
+        assert h_state.numel() == B * self.H == c_state.numel()
+        partial, ksplit = fc_small_partials(xh, self.wc)
+        lstm = self.lstm
+        check(lib.rlpyt_lstm_cell_f32(ptr(partial), ksplit, ptr(lstm.bias_ih_l0), ptr(lstm.bias_hh_l0),
+                                      ptr(c_state), ptr(h_state), ptr(c_state), B, self.H, stream()),
+              "rlpyt_lstm_cell_f32")
+
+
+def rnn_step_inputs(feat, action, reward, done, h, c, n_actions, Kp, relu=False):
+    """``[act(feat) | onehot(action) | reward | h | 0-pad]`` rows ``[B, Kp]`` of one recurrent
+    sampling step in one launch, with the reset handling folded in (``rlpyt_rnn_step_inputs_f32``):
+    rows with ``done`` see the null action 0, zero reward and a zero state; ``c`` is zeroed in place
+    there.  Returns ``(xh, prev_h, prev_c)``, the last two being the state the step starts from."""
+    _lib.require_gpu()
+    B, F = feat.shape
+    H = h.shape[-1]
+    assert feat.dtype == torch.float32 and feat.is_contiguous()
+    assert action.dtype == torch.int64 and action.numel() == B and action.is_contiguous()
+    assert reward.dtype == torch.float32 and reward.numel() == B and reward.is_contiguous()
+    assert h.dtype == torch.float32 and c.dtype == torch.float32 and h.numel() == B * H == c.numel()
+    assert h.is_contiguous() and c.is_contiguous()
+    if done is not None:
+        assert done.dtype in (torch.bool, torch.uint8) and done.numel() == B and done.is_contiguous()
+        done = done.view(torch.uint8)
+    xh = torch.empty((B, Kp), dtype=torch.float32, device=feat.device)
+    prev_h = torch.empty((B, H), dtype=torch.float32, device=feat.device)
+    prev_c = torch.empty((B, H), dtype=torch.float32, device=feat.device)
+    check(lib.rlpyt_rnn_step_inputs_f32(ptr(feat), F, int(bool(relu)), ptr(action), int(n_actions),
+                                        ptr(reward), ptr(done), ptr(h), ptr(c), H, ptr(xh), int(Kp),
+                                        ptr(prev_h), ptr(prev_c), B, stream()),
+          "rlpyt_rnn_step_inputs_f32")
+    return xh, prev_h, prev_c
+
 
 LSTM_SEQ_HIDDEN = (256, 512)     # hidden sizes rlpyt_lstm_seq_f32 is instantiated for
 

@@ -229,7 +229,23 @@ class DeviceBatch:
             prev_action = _map(lambda x: x[:, lo:hi].index_select(0, t).squeeze(0),
                                self.all_action)
             prev_reward = G.reward_stage
-            if opts.mid_batch_reset:
+        else:
+            prev_action = prev_reward = None
+        agent.select_envs(lo, hi)
+        stepped = None
+        if agent.recurrent:
+            # one persistent [N, B_g, H] state per pipeline group
+            agent.select_slot(G.idx)
+            if uses_prev and hasattr(agent, "step_with_reset"):
+                # agents that fold the reset handling into their step's kernels take the inputs as
+                # stored plus the mask of the environments reset before this step
+                agent.sample_generator = G.gen
+                agent.sample_uniforms = None if G.u_all is None else (G.u_all, t)
+                stepped = agent.step_with_reset(G.obs_stage, prev_action, prev_reward,
+                                                G.done_stage if opts.mid_batch_reset else None)
+                agent.sample_generator = agent.sample_uniforms = None
+        if stepped is None and opts.mid_batch_reset:
+            if uses_prev:
                 # after a reset the agent sees null prev action/reward
                 # (action_server.py:49-53); the stored rows stay untouched.
                 dn = G.done_stage
@@ -237,16 +253,10 @@ class DeviceBatch:
                     dn.reshape((-1,) + (1,) * (x.dim() - 1)), torch.zeros_like(x), x),
                     prev_action)
                 prev_reward = torch.where(dn, torch.zeros_like(prev_reward), prev_reward)
-        else:
-            prev_action = prev_reward = None
-        agent.select_envs(lo, hi)
-        if agent.recurrent:
-            # one persistent [N, B_g, H] state per pipeline group; after a reset the env starts
-            # from a zero state (action_server.py:49-53)
-            agent.select_slot(G.idx)
-            if opts.mid_batch_reset:
+            if agent.recurrent:
+                # ... and starts from a zero state (action_server.py:49-53)
                 agent.reset_where(G.done_stage)
-        if fusable:
+        if fusable and stepped is None:
             # the agent runs the forward AND writes the step's rows (fused head kernel)
             binding = StepBinding(action_rows=self.all_action, agent_info_rows=s.agent.agent_info,
                                   action_out=G.action_out, uniforms=G.u_all, t_dev=t, lo=lo,
@@ -254,10 +264,13 @@ class DeviceBatch:
             if agent.step_into(G.obs_stage, prev_action, prev_reward, binding):
                 G.post_entries = None
                 return
-        agent.sample_generator = G.gen
-        agent.sample_uniforms = None if G.u_all is None else (G.u_all, t)
-        action, agent_info = agent.step(G.obs_stage, prev_action, prev_reward)
-        agent.sample_generator = agent.sample_uniforms = None
+        if stepped is not None:
+            action, agent_info = stepped
+        else:
+            agent.sample_generator = G.gen
+            agent.sample_uniforms = None if G.u_all is None else (G.u_all, t)
+            action, agent_info = agent.step(G.obs_stage, prev_action, prev_reward)
+            agent.sample_generator = agent.sample_uniforms = None
         if not opts.mid_batch_reset:
             # wait-reset: finished envs record blank action / agent_info
             # (collectors.py:85-91)

@@ -433,3 +433,121 @@ def test_eps_greedy_kernel_semantics():
     assert abs((a2 != greedy).float().mean().item() - 0.25 * (A - 1) / A) < 0.03
     a3 = d.sample(q)                                  # no uniforms: the torch path
     assert a3.shape == a2.shape and _lib.variant_counts().get("eps_greedy_kernel", 0) == 1
+
+
+def _r2d1_agent(model_kwargs=None):
+    from rlpyt_amd.agents.dqn.r2d1_agent import AtariR2d1Agent
+    env = SyntheticPong()
+    agent = AtariR2d1Agent(model_kwargs=model_kwargs or {}, eps_final=0.1)
+    torch.manual_seed(3)
+    agent.initialize(env.spaces, global_B=8, env_ranks=list(range(8)))
+    torch.cuda.set_device(0)
+    agent.to_device(0)
+    agent.sample_mode(0)
+    return agent
+
+
+@pytest.mark.parametrize("model_kwargs", [{}, dict(fc_size=64, lstm_size=32, head_size=32, dueling=True)])
+@pytest.mark.parametrize("with_resets", [True, False])
+def test_r2d1_fused_sampling_step_equals_eager_step(model_kwargs, with_resets):
+    """``R2d1Agent.step_with_reset`` (conv stack, trunk GEMM, ``rlpyt_rnn_step_inputs_f32``, gate GEMM,
+    cell, head; state updated in place) against the eager sequence it replaces -- null previous action
+    / reward after a reset, ``reset_where``, ``step`` (rlpyt/samplers/parallel/gpu/action_server.py:49-53
+    + rlpyt/agents/dqn/r2d1_agent.py:23-40): same actions (same pre-drawn uniforms), Q-values, stored
+    ``prev_rnn_state`` and internal state over a run of steps with resets."""
+    from rlpyt_amd import _lib
+    agent = _r2d1_agent(model_kwargs)
+    B, T, A = 8, 12, 6
+    H = agent.model.lstm.hidden_size
+    g = torch.Generator().manual_seed(11)
+    u_all = torch.rand(T, B, generator=g).cuda()
+    prev_a = torch.randint(0, A, (B,), generator=g).cuda()
+    agent.select_envs(0, B)
+    for t in range(T):
+        obs = torch.randint(0, 256, (B, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+        prev_r = torch.randn(B, generator=g).cuda()
+        done = ((torch.rand(B, generator=g) < 0.3) if with_resets and t > 0
+                else torch.zeros(B, dtype=torch.bool)).cuda()
+        t_dev = torch.tensor([t], device="cuda")
+        mask = done if with_resets else None
+        # fused
+        agent.select_slot("fused")
+        agent.sample_uniforms = (u_all, t_dev)
+        _lib.variant_reset()
+        out = agent.step_with_reset(obs, prev_a, prev_r, mask)
+        assert out is not None
+        assert any("rnn_step_inputs_kernel" in k and v > 0 for k, v in _lib.variant_counts().items())
+        # eager, on its own state slot
+        agent.select_slot("eager")
+        pa, pr = prev_a, prev_r
+        if mask is not None:
+            pa = torch.where(mask, torch.zeros_like(pa), pa)
+            pr = torch.where(mask, torch.zeros_like(pr), pr)
+            agent.reset_where(mask)
+        agent.sample_uniforms = (u_all, t_dev)
+        ref = agent.step(obs, pa, pr)
+        agent.sample_uniforms = None
+        torch.cuda.synchronize()
+        assert torch.equal(out.action, ref.action), t
+        np.testing.assert_allclose(out.agent_info.q.cpu().numpy(), ref.agent_info.q.cpu().numpy(),
+                                   rtol=2e-4, atol=2e-6)
+        for f in ("h", "c"):
+            a, b = getattr(out.agent_info.prev_rnn_state, f), getattr(ref.agent_info.prev_rnn_state, f)
+            assert tuple(a.shape) == tuple(b.shape) == (B, 1, H)
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6)
+            if mask is not None and bool(mask.any()):
+                assert float(a[mask].abs().max()) == 0.0          # reset rows start from zero
+        sf, se = agent._rnn_states["fused"], agent._rnn_states["eager"]
+        np.testing.assert_allclose(sf.h.cpu().numpy(), se.h.cpu().numpy(), rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(sf.c.cpu().numpy(), se.c.cpu().numpy(), rtol=2e-4, atol=2e-6)
+        prev_a = out.action
+
+
+@pytest.mark.parametrize("mid_batch_reset", [True, False])
+def test_r2d1_sampler_batches_equal_with_and_without_fused_step(mid_batch_reset, monkeypatch):
+    """Whole batches of the HBM sampler (captured step graphs, C serve loop) with the fused recurrent
+    step against the same sampler with ``step_with_reset`` disabled: identical observations / rewards /
+    dones / actions, Q-values and stored recurrent states to fp32 tolerance -- reset and wait-reset
+    collectors."""
+    from rlpyt_amd.agents.dqn.r2d1_agent import AtariR2d1Agent, R2d1AgentBase
+
+    def run(fused):
+        if not fused:
+            monkeypatch.setattr(R2d1AgentBase, "step_with_reset", lambda self, *a: None)
+        T, B = 6, 8
+        sampler = GpuSampler(SyntheticPong, dict(points_to_end=1, max_steps=9), batch_T=T, batch_B=B,
+                             n_workers=2, n_groups=2, mid_batch_reset=mid_batch_reset,
+                             max_decorrelation_steps=0)
+        agent = AtariR2d1Agent(model_kwargs=dict(fc_size=64, lstm_size=32, head_size=32), eps_final=0.1)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        sampler.initialize(agent, seed=5, bootstrap_value=False)
+        torch.cuda.set_device(0)
+        agent.to_device(0)
+        out = []
+        try:
+            for itr in range(4):
+                agent.sample_mode(itr)
+                s, _ = sampler.obtain_samples(itr)
+                torch.cuda.synchronize()
+                out.append(dict(obs=s.env.observation.float().mean((2, 3, 4)).cpu().numpy(),
+                                reward=s.env.reward.cpu().numpy(), done=s.env.done.cpu().numpy(),
+                                action=s.agent.action.cpu().numpy(),
+                                q=s.agent.agent_info.q.cpu().numpy(),
+                                h=s.agent.agent_info.prev_rnn_state.h.cpu().numpy(),
+                                c=s.agent.agent_info.prev_rnn_state.c.cpu().numpy()))
+            graphs = all(G.graph is not None for G in sampler.groups)
+        finally:
+            sampler.shutdown()
+        monkeypatch.undo()
+        return out, graphs
+
+    a, ga = run(True)
+    b, gb = run(False)
+    assert ga and gb
+    assert any(x["done"].any() for x in a)
+    for x, y in zip(a, b):
+        for k in ("obs", "reward", "done", "action"):
+            assert np.array_equal(x[k], y[k]), k
+        for k in ("q", "h", "c"):
+            np.testing.assert_allclose(x[k], y[k], rtol=5e-4, atol=5e-6, err_msg=k)

@@ -571,6 +571,12 @@ def _lstm_seq():
         L.test_lstm_sequence_matches_torch_lstm(H, I, 5, 70, False)
 
 
+@case("rnn_step_inputs_kernel")
+def _rnn_step_inputs():
+    import test_dqn_gpu as D
+    D.test_r2d1_fused_sampling_step_equals_eager_step(dict(fc_size=64, lstm_size=32, head_size=32, dueling=True), True)
+
+
 @case("replay_step_fields_kernel")
 def _replay_step_fields():
     """One-launch field gather of a single-step replay batch vs the row-by-row gathers + selects it
