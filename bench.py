@@ -78,6 +78,31 @@ KERNEL_NAMES = {
     "gather_tb_small": "gather_flat_kernel (minibatch scalar fields)"}
 
 
+def sampler_stats(sampler, timing, wt, wt0, steps, T, t_sample, use_graph):
+    """The `sampler` object of a bench line: master-side times per time step, per-batch phases and
+    what the env workers did (waiting for the master's actions / stepping envs)."""
+    worker_ms = None
+    if wt0 is not None:
+        d = (wt - wt0) / (steps * T) * 1e-6
+        dd = wt - wt0
+        worker_ms = {"wait_mean": float(d[:, 0].mean()), "wait_max": float(d[:, 0].max()),
+                     "step_mean": float(d[:, 1].mean()), "step_max": float(d[:, 1].max()),
+                     "waited_frac": float(dd[:, 4].sum() / max(dd[:, 2].sum(), 1.)),
+                     "wake_us_mean": float(dd[:, 3].sum() / max(dd[:, 4].sum(), 1.) * 1e-3)}
+        n_gs = max(timing.get("chain_steps", 0.), 1.)
+        worker_ms["chain_us"] = {k: timing.get(f"chain_{k}_s", 0.) / n_gs * 1e6
+                                 for k in ("issue", "device", "post")}
+    return {"pipeline_groups": sampler.n_groups, "hip_graph": use_graph,
+            "native_serve_loop": getattr(sampler, "_native", None) is not None,
+            "ms_per_time_step": t_sample / steps / T * 1e3,
+            "master_wait_env_ms": timing["wait_env_s"] / steps / T * 1e3,
+            "master_issue_ms": timing["device_issue_s"] / steps / T * 1e3,
+            "master_wait_device_ms": timing["device_wait_s"] / steps / T * 1e3,
+            "per_batch_ms": {k[:-2]: timing[k] / steps * 1e3
+                             for k in ("pre_s", "loop_s", "tail_s", "post_s")},
+            "worker_ms_per_time_step": worker_ms}
+
+
 def trace_marker(args):
     if args.trace_markers:
         torch.full((64,), 0.5, device="cuda").erfinv_()
@@ -1129,6 +1154,10 @@ def replay_config_main(args):
     for itr in range(fill + warmup):
         one(itr)
     torch.cuda.synchronize()
+    for k in sampler.timing:
+        sampler.timing[k] = 0.
+    wt = getattr(getattr(sampler, "ctrl", None), "worker_timing", None)
+    wt0 = None if wt is None else wt.copy()
     trace_marker(args)
     u0 = algo.update_counter
     t0 = time.perf_counter()
@@ -1145,6 +1174,8 @@ def replay_config_main(args):
     elapsed = time.perf_counter() - t0
     trace_marker(args)
     updates = algo.update_counter - u0
+    sampler_obj = sampler_stats(sampler, dict(sampler.timing), wt, wt0, steps, T, t_sample,
+                                not args.no_graph)
     sampler.shutdown()
 
     # ---- replay kernels on the REAL buffers (HIP events), at the config's batch shape ------------
@@ -1227,6 +1258,7 @@ def replay_config_main(args):
                    "batch_size": int(algo.batch_size)},
         "updates_per_s": updates / elapsed, "updates": updates,
         "sampling_frac_of_step": t_sample / elapsed,
+        "sampler": sampler_obj,
         "roofline": dict(kernel=replay[key].get("kernel", key),
                          **{k: v for k, v in replay[key].items() if k != "kernel"},
                          traffic=None if traffic is None else traffic["bytes_per_launch"],

@@ -432,6 +432,13 @@ int rlpyt_rnn_step_inputs_f32(const float* feat, int F, int relu, const int64_t*
                               float* c, int H, float* xh, int Kp, float* prev_h, float* prev_c,
                               int64_t B, rlpyt_stream_t stream);
 
+/* Q-value head behind a split-K hidden layer (rlpyt/models/mlp.py:24-31 as the Linear-ReLU-Linear `head`
+ * of rlpyt/models/dqn/atari_dqn_model.py:50-51 / atari_r2d1_model.py:44-45): partial = the split-K
+ * partials [ksplit, n, K] of rlpyt_fc_small_f32(x, W_hidden) (y == NULL); q[n,A] = W_out relu(sum partial +
+ * b_hidden) + b_out.  K in {256, 512}, A <= 18. */
+int rlpyt_q_head_f32(const float* partial, int ksplit, const float* b_hidden, const float* w_out,
+                     const float* b_out, int64_t n, int K, int A, float* q, rlpyt_stream_t stream);
+
 /* One LSTM cell step for the per-time-step sampling forward of the recurrent agents
  * (torch.nn.LSTM with T = 1 as used by rlpyt/models/dqn/atari_r2d1_model.py:61-63 and
  * rlpyt/models/pg/atari_lstm_model.py): the gate pre-activations arrive as the split-K partials
@@ -531,15 +538,6 @@ int rlpyt_atari_sample_convs_to_f32(uint8_t* obs, const int64_t* t_dev, int64_t 
                                     float* y2, uint8_t* dst_stage /*nullable*/,
                                     rlpyt_stream_t stream);
 int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void);
-/* No-grad forward of the DQN-family conv stack with its default geometry -- Conv2d(4,32,8,s4) ReLU
- * Conv2d(32,64,4,s2,p1) ReLU Conv2d(64,64,3,s1,p1) ReLU, flattened: `self.conv` of
- * rlpyt/models/dqn/atari_dqn_model.py:30-37 and rlpyt/models/dqn/atari_r2d1_model.py:33-41 as
- * agent.step (agents/dqn/dqn_agent.py:61-68, r2d1_agent.py:40-53) and the target-network pass
- * (algos/dqn/dqn.py:226-234) run it.  obs: uint8 [N,4,104,80]; w1 [32,4,8,8], w2 [64,32,4,4],
- * w3 [64,64,3,3] in the torch layout, b* the biases; out: f32 [N, 64*12*9] in the order of
- * `conv(img).view(N, -1)`.  scale multiplies the pixels (1/255).  workspace: at least
- * rlpyt_dqn_convs_workspace_floats(N) floats (packed weights + the two intermediate layers).
- * Four launches (weight packing + one per layer), f32 MFMA, f32 accumulate. */
 /* No-grad forward of a single-layer LSTM over a sequence (torch.nn.LSTM in
  * rlpyt/models/dqn/atari_r2d1_model.py:61-63 as the target / warm-up / double-DQN passes of
  * rlpyt/algos/dqn/r2d1.py:199-224 run it).  xproj [T,B,4H] = x W_ih^T + b_ih + b_hh for every step
@@ -548,10 +546,27 @@ int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void);
  * step; H in {256, 512}. */
 int rlpyt_lstm_seq_f32(const float* xproj, const float* w_hh, const float* h0, float* c, float* out,
                        int T, int B, int H, rlpyt_stream_t stream);
+
+/* No-grad forward of the DQN-family conv stack with its default geometry -- Conv2d(4,32,8,s4) ReLU
+ * Conv2d(32,64,4,s2,p1) ReLU Conv2d(64,64,3,s1,p1) ReLU, flattened: `self.conv` of
+ * rlpyt/models/dqn/atari_dqn_model.py:30-37 and rlpyt/models/dqn/atari_r2d1_model.py:33-41 as
+ * agent.step (agents/dqn/dqn_agent.py:61-68, r2d1_agent.py:40-53) and the target-network pass
+ * (algos/dqn/dqn.py:226-234) run it.  obs: uint8 [N,4,104,80]; w1 [32,4,8,8], w2 [64,32,4,4],
+ * w3 [64,64,3,3] in the torch layout, b* the biases; out: f32 [N, 64*12*9] in the order of
+ * `conv(img).view(N, -1)`.  scale multiplies the pixels (1/255).  workspace: at least
+ * rlpyt_dqn_convs_workspace_floats(N) floats (packed weights + the two intermediate layers).
+ * packed == NULL: the weights are re-packed on the stream in front of the layers (four launches; always
+ * current); packed != NULL: a copy made by rlpyt_dqn_convs_pack_f32 (rlpyt_dqn_convs_packed_floats()
+ * floats) from the SAME weights -- three launches, w1 / w2 / w3 may then be NULL.  f32 MFMA, f32
+ * accumulate. */
 int64_t rlpyt_dqn_convs_workspace_floats(int64_t N);
+int64_t rlpyt_dqn_convs_packed_floats(void);
+int rlpyt_dqn_convs_pack_f32(const float* w1, const float* w2, const float* w3, float* packed,
+                             rlpyt_stream_t stream);
 int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const float* w1, const float* b1,
                             const float* w2, const float* b2, const float* w3, const float* b3,
-                            float scale, float* workspace, float* out, rlpyt_stream_t stream);
+                            const float* packed /*nullable*/, float scale, float* workspace, float* out,
+                            rlpyt_stream_t stream);
 
 /* conv2 backward in one pass (dgrad + both ReLU masks + weight / bias gradients; g2 / y1 read once,
  * conv2's ReLU mask from relu_mask as written by rlpyt_atari_conv2_fwd_f32), both contractions on

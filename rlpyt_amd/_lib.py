@@ -142,7 +142,10 @@ _SIGNATURES = {
                                           _p, c_int64, _p]),
     "rlpyt_lstm_seq_f32": (c_int, [_p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
     "rlpyt_dqn_convs_workspace_floats": (c_int64, [c_int64]),
-    "rlpyt_dqn_convs_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, _p, c_float, _p, _p, _p]),
+    "rlpyt_dqn_convs_packed_floats": (c_int64, []),
+    "rlpyt_dqn_convs_pack_f32": (c_int, [_p, _p, _p, _p, _p]),
+    "rlpyt_dqn_convs_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, _p, _p, c_float, _p, _p, _p]),
+    "rlpyt_q_head_f32": (c_int, [_p, c_int, _p, _p, _p, c_int64, c_int, c_int, _p, _p]),
     "rlpyt_rollout_fc_ksplit": (c_int, [c_int]),
     "rlpyt_rollout_fc_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "rlpyt_rollout_fc_f32": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p]),

@@ -230,24 +230,38 @@ extern "C" int64_t rlpyt_dqn_convs_workspace_floats(int64_t N) {
   return (int64_t)PACKED + N * (int64_t)(P1 * C1 + P2 * C2);
 }
 
+extern "C" int64_t rlpyt_dqn_convs_packed_floats(void) { return (int64_t)PACKED; }
+
+extern "C" int rlpyt_dqn_convs_pack_f32(const float* w1, const float* w2, const float* w3, float* packed,
+                                        rlpyt_stream_t stream) {
+  RL_CHECK_ARG(w1 && w2 && w3 && packed, RLPYT_EINVAL, "rlpyt_dqn_convs_pack_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(packed), RLPYT_ESHAPE, "rlpyt_dqn_convs_pack_f32: packed must be 16-byte aligned");
+  RL_LAUNCH(dqn_pack_weights_kernel, dim3((PACKED + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1, w2,
+            w3, packed);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
 extern "C" int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const float* w1, const float* b1,
                                        const float* w2, const float* b2, const float* w3,
-                                       const float* b3, float scale, float* workspace, float* out,
-                                       rlpyt_stream_t stream) {
+                                       const float* b3, const float* packed_in, float scale,
+                                       float* workspace, float* out, rlpyt_stream_t stream) {
   RL_CHECK_ARG(N >= 0, RLPYT_EINVAL, "rlpyt_dqn_convs_fwd_f32: bad sizes");
   if (N == 0) return RLPYT_OK;
-  RL_CHECK_ARG(obs && w1 && b1 && w2 && b2 && w3 && b3 && workspace && out, RLPYT_EINVAL,
+  RL_CHECK_ARG(obs && b1 && b2 && b3 && workspace && out && (packed_in || (w1 && w2 && w3)), RLPYT_EINVAL,
                "rlpyt_dqn_convs_fwd_f32: null pointer");
   RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(b1) && RL_ALIGNED16(b2) && RL_ALIGNED16(b3) &&
-                   RL_ALIGNED16(workspace) && RL_ALIGNED16(out),
+                   RL_ALIGNED16(workspace) && RL_ALIGNED16(out) && RL_ALIGNED16(packed_in),
                RLPYT_ESHAPE, "rlpyt_dqn_convs_fwd_f32: obs / biases / workspace / out must be 16-byte aligned");
   RL_CHECK_ARG(N <= (1 << 20), RLPYT_ESHAPE, "rlpyt_dqn_convs_fwd_f32: N too large");
   hipStream_t s = (hipStream_t)stream;
-  float* packed = workspace;
+  const float* packed = packed_in != nullptr ? packed_in : workspace;
   float* y1 = workspace + PACKED;
   float* y2 = y1 + N * (int64_t)(P1 * C1);
-  RL_LAUNCH(dqn_pack_weights_kernel, dim3((PACKED + 255) / 256), dim3(256), 0, s, w1, w2, w3, packed);
-  RL_LAUNCH_CHECK();
+  if (packed_in == nullptr) {
+    RL_LAUNCH(dqn_pack_weights_kernel, dim3((PACKED + 255) / 256), dim3(256), 0, s, w1, w2, w3, workspace);
+    RL_LAUNCH_CHECK();
+  }
   RL_LAUNCH(dqn_conv1_kernel, dim3((unsigned)(N * D1_PARTS)), dim3(D1_THREADS), 0, s, obs, packed, b1,
             scale, y1);
   RL_LAUNCH_CHECK();

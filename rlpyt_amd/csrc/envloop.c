@@ -91,6 +91,9 @@ typedef struct {
   Buf len_, nz, g, score;      /* i64, i64, f64, f64 (score optional) */
   Buf ret32, disc32, ret64, disc64;
   int f64_mode;                /* 0: float32 accumulators are live, 1: float64 */
+  int wait_reset;              /* 1: the wait-reset collector (collectors.py:73-126): a finished env
+                                * idles until the batch ends, its observation row is blanked */
+  Buf force_full;              /* wait-reset only: bool [n], "the next observation starts a new stack" */
   double discount;
   int has_td, has_score;       /* -1 unknown, 0 no, 1 yes -- for infos of type `info_type` */
   PyTypeObject* info_type;     /* borrowed: only compared, never dereferenced */
@@ -118,6 +121,7 @@ static int kind_of(const char* fmt, Py_ssize_t itemsize) {
 static void EnvLoop_dealloc(EnvLoop* self) {
   Py_XDECREF(self->envs);
   Py_XDECREF(self->on_done);
+  buf_rel(&self->force_full);
   Py_XDECREF(self->f32_type);
   Py_XDECREF(self->s_step);
   Py_XDECREF(self->s_traj_done);
@@ -148,14 +152,15 @@ static int EnvLoop_init(EnvLoop* self, PyObject* args, PyObject* kw) {
   static char* kwl[] = {"envs", "action", "reward", "done", "frame", "reset", "observation",
                         "info_arrays", "length", "ret32", "nonzero", "disc32", "ret64", "disc64",
                         "cur_discount", "score", "discount", "f64_mode", "on_done", "float32_type",
-                        NULL};
+                        "wait_reset", "force_full", NULL};
   PyObject *envs, *act, *rew, *done, *frame, *reset, *obs, *infos, *len_, *ret32, *nz, *disc32, *ret64,
-      *disc64, *g, *score, *on_done, *f32t;
+      *disc64, *g, *score, *on_done, *f32t, *force_full = Py_None;
   double discount;
-  int f64_mode;
-  if (!PyArg_ParseTupleAndKeywords(args, kw, "OOOOOOOOOOOOOOOOdiOO", kwl, &envs, &act, &rew, &done,
+  int f64_mode, wait_reset = 0;
+  if (!PyArg_ParseTupleAndKeywords(args, kw, "OOOOOOOOOOOOOOOOdiOO|iO", kwl, &envs, &act, &rew, &done,
                                    &frame, &reset, &obs, &infos, &len_, &ret32, &nz, &disc32, &ret64,
-                                   &disc64, &g, &score, &discount, &f64_mode, &on_done, &f32t))
+                                   &disc64, &g, &score, &discount, &f64_mode, &on_done, &f32t,
+                                   &wait_reset, &force_full))
     return -1;
   if (!PyList_Check(envs)) { PyErr_SetString(PyExc_TypeError, "EnvLoop: envs must be a list"); return -1; }
   self->n = PyList_GET_SIZE(envs);
@@ -164,6 +169,9 @@ static int EnvLoop_init(EnvLoop* self, PyObject* args, PyObject* kw) {
   Py_INCREF(f32t); self->f32_type = f32t;
   self->discount = discount;
   self->f64_mode = f64_mode;
+  self->wait_reset = wait_reset;
+  self->force_full.ok = 0;
+  if (buf_get(force_full, &self->force_full, 1)) return -1;
   self->has_td = self->has_score = -1;
   self->info_type = NULL;
   self->wait_ns = self->step_ns = self->n_synced = self->wake_ns = self->n_waited = 0;
@@ -182,6 +190,7 @@ static int EnvLoop_init(EnvLoop* self, PyObject* args, PyObject* kw) {
       expect(&self->ret64, K_F64, n, "ret64") || expect(&self->disc64, K_F64, n, "disc64"))
     return -1;
   if (self->score.ok && expect(&self->score, K_F64, n, "score")) return -1;
+  if (self->force_full.ok && expect(&self->force_full, K_BOOL, n, "force_full")) return -1;
   if (!self->obs.ok || self->obs.view.len % n) {
     PyErr_SetString(PyExc_TypeError, "EnvLoop: observation buffer required, [n, ...]");
     return -1;
@@ -291,7 +300,14 @@ static PyObject* EnvLoop_step(EnvLoop* self, PyObject* args) {
   double *ret64 = (double*)self->ret64.view.buf, *disc64 = (double*)self->disc64.view.buf;
   if (!frame) lazy = 0;
 
+  uint8_t* force_full = self->force_full.ok ? (uint8_t*)self->force_full.view.buf : NULL;
   for (Py_ssize_t b = 0; b < self->n; ++b) {
+    if (self->wait_reset && done[b]) {
+      /* wait-reset: a finished env idles with done = True and a blank reward until the batch ends
+       * (collectors.py:85-91); nothing else of its rows is touched */
+      rew[b] = 0.f;
+      continue;
+    }
     PyObject* env = PyList_GET_ITEM(self->envs, b);
     const int64_t a = act[b];
     PyObject* a_obj = (a >= 0 && a < 64) ? self->small_ints[a] : NULL;
@@ -363,20 +379,38 @@ static PyObject* EnvLoop_step(EnvLoop* self, PyObject* args) {
       }
     }
     /* ---- end of a trajectory: record + reset through the Python callback ---- */
-    int fresh = 0;
+    int fresh = 0, blank = 0;
     PyObject* o_keep = NULL;
-    if (td) {
+    if (!self->wait_reset) {
+      if (td) {
+        PyObject* b_obj = PyLong_FromSsize_t(b);
+        if (!b_obj) { Py_DECREF(res); return NULL; }
+        o_keep = PyObject_CallFunctionObjArgs(self->on_done, b_obj, o, NULL);
+        Py_DECREF(b_obj);
+        if (!o_keep) { Py_DECREF(res); return NULL; }
+        o = o_keep;
+        fresh = 1;
+      }
+    } else if (td || d) {
+      /* wait-reset: on_done(b, final_obs, traj_done, done) records the trajectory / marks the env for
+       * the reset between batches / holds the final observation; the env itself is NOT reset here and
+       * a done env's observation row goes blank (collectors.py:96-103) */
       PyObject* b_obj = PyLong_FromSsize_t(b);
       if (!b_obj) { Py_DECREF(res); return NULL; }
-      o_keep = PyObject_CallFunctionObjArgs(self->on_done, b_obj, o, NULL);
+      PyObject* r_ = PyObject_CallFunctionObjArgs(self->on_done, b_obj, o, td ? Py_True : Py_False,
+                                                  d ? Py_True : Py_False, NULL);
       Py_DECREF(b_obj);
-      if (!o_keep) { Py_DECREF(res); return NULL; }
-      o = o_keep;
-      fresh = 1;
+      if (!r_) { Py_DECREF(res); return NULL; }
+      Py_DECREF(r_);
+      if (d) { blank = 1; fresh = 1; }
     }
+    if (force_full && force_full[b]) { fresh = 1; force_full[b] = 0; }
     /* ---- step buffer rows ---- */
-    if (copy_obs(o, obs + b * self->obs_bytes, self->obs_bytes, frame ? frame + b * self->frame_bytes : NULL,
-                 self->frame_bytes, fresh || !lazy) != 0) {
+    if (blank) {
+      if (frame) memset(frame + b * self->frame_bytes, 0, (size_t)self->frame_bytes);
+      memset(obs + b * self->obs_bytes, 0, (size_t)self->obs_bytes);
+    } else if (copy_obs(o, obs + b * self->obs_bytes, self->obs_bytes, frame ? frame + b * self->frame_bytes : NULL,
+                        self->frame_bytes, fresh || !lazy) != 0) {
       Py_XDECREF(o_keep);
       Py_DECREF(res);
       return NULL;

@@ -305,7 +305,11 @@ __global__ __launch_bounds__(256) void fc_small_finish_kernel(const float* __res
 //   gates[b, :] = sum_s partial[s][b][:] + b_ih + b_hh      (partials of [x | h] [W_ih | W_hh]^T)
 //   i, f, g, o = gates[0:H], [H:2H], [2H:3H], [3H:4H]        (torch gate order)
 //   c' = sigmoid(f) c + sigmoid(i) tanh(g);   h' = sigmoid(o) tanh(c')
-// One thread per (row, 4 hidden units); fixed summation order -> deterministic.
+// One thread per (row, hidden unit), all its partials (<= 8 slices x 4 gates, clamped addresses,
+// masked sums: no branch between the loads) in flight at once; slices summed in slice order ->
+// deterministic.  (Until round 5: one thread per FOUR units with the slice loop around dependent
+// 16-byte loads -- 24 workgroups and eight latency trips for B = 48, H = 512: 10.8 us in the R2D1
+// rollout's step graph, profiles/r5_r2d1_region_fused_convs.txt.)
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ partial, int ksplit,
                                                         const float* __restrict__ b_ih,
@@ -313,30 +317,29 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
                                                         const float* __restrict__ c_prev,
                                                         float* __restrict__ h_out,
                                                         float* __restrict__ c_out, int64_t B, int H) {
-  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;     // element of [B, H]
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // element of [B, H]
   if (e >= B * H) return;
   const int64_t b = e / H;
   const int j = (int)(e - b * H);
   const int64_t BN = B * 4 * (int64_t)H;
-  fc_f32x4 g[4];
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < ksplit; s0 += 8) {
+    float pv[4][8];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int64_t off = b * 4 * (int64_t)H + (int64_t)q * H + j;
-    fc_f32x4 v = *reinterpret_cast<const fc_f32x4*>(partial + off);
-    for (int k = 1; k < ksplit; ++k) v += *reinterpret_cast<const fc_f32x4*>(partial + (int64_t)k * BN + off);
-    const fc_f32x4 bi = *reinterpret_cast<const fc_f32x4*>(b_ih + q * H + j);
-    const fc_f32x4 bh = *reinterpret_cast<const fc_f32x4*>(b_hh + q * H + j);
-    g[q] = (v + bi) + bh;               // (x W_ih^T + h W_hh^T + b_ih) + b_hh
-  }
-  const fc_f32x4 c0 = *reinterpret_cast<const fc_f32x4*>(c_prev + e);
-  fc_f32x4 c1, h1;
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    c1[r] = sigmoid_f(g[1][r]) * c0[r] + sigmoid_f(g[0][r]) * tanhf(g[2][r]);
-    h1[r] = sigmoid_f(g[3][r]) * tanhf(c1[r]);
+      for (int u = 0; u < 8; ++u)
+        pv[q][u] = partial[(int64_t)min(s0 + u, ksplit - 1) * BN + b * 4 * (int64_t)H + (int64_t)q * H + j];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g[q] += (s0 + u < ksplit ? pv[q][u] : 0.f);
   }
-  *reinterpret_cast<fc_f32x4*>(c_out + e) = c1;
-  *reinterpret_cast<fc_f32x4*>(h_out + e) = h1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) g[q] = (g[q] + b_ih[q * H + j]) + b_hh[q * H + j];   // (x W_ih^T + h W_hh^T + b_ih) + b_hh
+  const float c1 = sigmoid_f(g[1]) * c_prev[e] + sigmoid_f(g[0]) * tanhf(g[2]);
+  c_out[e] = c1;
+  h_out[e] = sigmoid_f(g[3]) * tanhf(c1);
 }
 }  // namespace
 }  // namespace rlpyt
@@ -454,8 +457,7 @@ extern "C" int rlpyt_lstm_cell_f32(const float* partial, int ksplit, const float
                  reinterpret_cast<uintptr_t>(b_hh) | reinterpret_cast<uintptr_t>(c_prev) |
                  reinterpret_cast<uintptr_t>(h_out) | reinterpret_cast<uintptr_t>(c_out)) & 15) == 0,
                RLPYT_ESHAPE, "rlpyt_lstm_cell_f32: buffers must be 16-byte aligned");
-  const int64_t n4 = B * H / 4;
-  RL_LAUNCH(rlpyt::lstm_cell_kernel, dim3((unsigned)rlpyt::ceil_div(n4, 256)), dim3(256), 0,
+  RL_LAUNCH(rlpyt::lstm_cell_kernel, dim3((unsigned)rlpyt::ceil_div(B * H, 256)), dim3(256), 0,
             (hipStream_t)stream, partial, ksplit, b_ih, b_hh, c_prev, h_out, c_out, B, H);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
@@ -676,6 +678,81 @@ __global__ __launch_bounds__(256) void rollout_head_kernel(
 
 }  // namespace
 }  // namespace rlpyt
+
+// Q-value head of the DQN-family sampling / target passes behind a split-K hidden layer
+// (rlpyt/models/mlp.py:24-31 as the `head` of rlpyt/models/dqn/atari_dqn_model.py:50-51 and
+// atari_r2d1_model.py:44-45: Linear -> ReLU -> Linear): one workgroup per row finishes the hidden layer
+// (sum of the ksplit partials of rlpyt_fc_small_f32 in slice order, + bias, ReLU) and takes the A output
+// dot products -- the structure of rollout_head_kernel without the sampling.  Replaces library GEMM +
+// clamp + library GEMM (20-25 us for 8..48 rows) by the split-K kernel + this one.
+namespace rlpyt {
+namespace {
+template <int KW>   // hidden width = 256 * KW
+__global__ __launch_bounds__(256) void q_head_kernel(const float* __restrict__ partial, int ksplit,
+                                                     const float* __restrict__ b_hidden,
+                                                     const float* __restrict__ w_out,
+                                                     const float* __restrict__ b_out, int64_t n, int A,
+                                                     float* __restrict__ q) {
+  constexpr int K = 256 * KW;
+  constexpr int AMAX = 18;                             // the full Atari action set
+  __shared__ float red[4][AMAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = blockIdx.x;
+  float hv[KW];
+#pragma unroll
+  for (int i = 0; i < KW; ++i) hv[i] = 0.f;
+  const int kb = wave * 64 * KW + lane;
+  for (int s0 = 0; s0 < ksplit; s0 += 8) {
+    float pv[KW][8];
+#pragma unroll
+    for (int i = 0; i < KW; ++i)
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        pv[i][u] = partial[((int64_t)min(s0 + u, ksplit - 1) * n + row) * K + kb + 64 * i];
+#pragma unroll
+    for (int i = 0; i < KW; ++i)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) hv[i] += (s0 + u < ksplit ? pv[i][u] : 0.f);
+  }
+  float acc[AMAX];
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a) acc[a] = 0.f;
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    const int k = kb + 64 * i;
+    hv[i] = fmaxf(hv[i] + b_hidden[k], 0.f);
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) acc[a] = fmaf(hv[i], w_out[(int64_t)min(a, A - 1) * K + k], acc[a]);
+  }
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a) acc[a] = wave_sum(acc[a]);
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) red[wave][a] = acc[a];
+  }
+  __syncthreads();
+  const int a = threadIdx.x;
+  if (a < A) q[row * A + a] = (((red[0][a] + red[1][a]) + red[2][a]) + red[3][a]) + b_out[a];
+}
+}  // namespace
+}  // namespace rlpyt
+
+extern "C" int rlpyt_q_head_f32(const float* partial, int ksplit, const float* b_hidden,
+                                const float* w_out, const float* b_out, int64_t n, int K, int A, float* q,
+                                rlpyt_stream_t stream) {
+  RL_CHECK_ARG(partial && b_hidden && w_out && b_out && q, RLPYT_EINVAL, "rlpyt_q_head_f32: null pointer");
+  RL_CHECK_ARG(n > 0 && ksplit > 0 && A > 0 && A <= 18 && (K == 512 || K == 256), RLPYT_ESHAPE,
+               "rlpyt_q_head_f32: need n > 0, 0 < A <= 18, K in {256, 512} (K=%d A=%d)", K, A);
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 512)
+    RL_LAUNCH((rlpyt::q_head_kernel<2>), dim3((unsigned)n), dim3(256), 0, s, partial, ksplit, b_hidden,
+              w_out, b_out, n, A, q);
+  else
+    RL_LAUNCH((rlpyt::q_head_kernel<1>), dim3((unsigned)n), dim3(256), 0, s, partial, ksplit, b_hidden,
+              w_out, b_out, n, A, q);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
 
 extern "C" int rlpyt_rollout_fc_ksplit(int K) {
   return K > 0 ? (int)rlpyt::ceil_div(K, rlpyt::kRfcKc) : 0;

@@ -41,8 +41,24 @@ class Conv2dModel(torch.nn.Module):
     use_fused_nograd_convs = os.environ.get("RLPYT_DQN_CONVS", "1") != "0"
     FUSED_MAX_IMAGES = 1024         # beyond sampling / target-batch sizes the library kernels are the tuned ones
 
+    _packed = None                  # the weights in the kernels' register order (sampling only)
+
     def forward(self, input):
         return self.conv(input)
+
+    def refresh_step_weights(self):
+        """Called by the agent when it enters sample / eval mode: re-pack the weights for the fused
+        kernels ONCE; the forwards of that phase (module in eval mode, parameters frozen until the
+        next mode change) then skip the per-call packing launch.  Any other no-grad forward -- target
+        network, double-DQN pass during training -- packs on the stream and is always current."""
+        w = self.conv[0].weight if self._dqn_geometry else None
+        if (w is None or not (self.use_fused_nograd_convs and w.is_cuda and w.dtype == torch.float32)
+                or torch.cuda.is_current_stream_capturing()):
+            return
+        from .. import ops
+        with torch.no_grad():
+            self._packed = ops.dqn_convs_pack(self.conv[0].weight, self.conv[2].weight,
+                                              self.conv[4].weight, out=self._packed)
 
     def _fused_ok(self, observation, T_B, img_shape):
         return (self.use_fused_nograd_convs and self._dqn_geometry and not torch.is_grad_enabled()
@@ -57,8 +73,10 @@ class Conv2dModel(torch.nn.Module):
         if self._fused_ok(observation, T_B, img_shape):
             from .. import ops
             c1, c2, c3 = self.conv[0], self.conv[2], self.conv[4]
+            packed = self._packed if (not self.training and self._packed is not None
+                                      and self._packed.device == observation.device) else None
             return ops.dqn_convs_fwd(observation.reshape(T_B, *img_shape), c1.weight, c1.bias,
-                                     c2.weight, c2.bias, c3.weight, c3.bias)
+                                     c2.weight, c2.bias, c3.weight, c3.bias, packed=packed)
         from .pg.atari_ff_model import prepare_image
         return self.conv(prepare_image(observation, T_B, img_shape)).reshape(T_B, -1)
 
@@ -90,6 +108,9 @@ class Conv2dHeadModel(torch.nn.Module):
 
     def forward(self, input):
         return self.head(self.conv(input).reshape(input.shape[0], -1))
+
+    def refresh_step_weights(self):
+        self.conv.refresh_step_weights()
 
     def from_observation(self, observation, T_B, img_shape):
         """``forward`` on raw observations (see ``Conv2dModel.features``)."""

@@ -38,6 +38,10 @@ class AtariCatDqnModel(torch.nn.Module):
         Head = DistributionalDuelingHeadModel if dueling else DistributionalHeadModel
         self.head = Head(n, fc_sizes, output_size=output_size, n_atoms=n_atoms)
 
+    def refresh_step_weights(self):
+        """Entering sample / eval mode: the conv stack packs its weights once for that phase."""
+        self.conv.refresh_step_weights()
+
     def forward(self, observation, prev_action, prev_reward):
         """Probability masses [.., A, n_atoms] (softmax over atoms)."""
         lead_dim, T, B, img_shape = infer_leading_dims(observation, 3)

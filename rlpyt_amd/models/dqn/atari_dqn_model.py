@@ -26,6 +26,10 @@ class AtariDqnModel(torch.nn.Module):
         self.head = (DuelingHeadModel(n, fc_sizes, output_size) if dueling
                      else MlpModel(n, fc_sizes, output_size))
 
+    def refresh_step_weights(self):
+        """Entering sample / eval mode: the conv stack packs its weights once for that phase."""
+        self.conv.refresh_step_weights()
+
     def forward(self, observation, prev_action, prev_reward):
         lead_dim, T, B, img_shape = infer_leading_dims(observation, 3)
         q = self.head(self.conv.features(observation, T * B, img_shape))

@@ -56,6 +56,7 @@ class AtariR2d1Model(torch.nn.Module):
         parameters (a raw-pointer kernel does not have to bump ``Tensor._version``)."""
         if self._lstm_step is not None:
             self._lstm_step.refresh(force=True)
+        self.conv.refresh_step_weights()
 
     def sample_step_ok(self, observation, prev_action):
         """Whether ``sample_step`` serves this sampling step (else: ``forward`` through the agent's

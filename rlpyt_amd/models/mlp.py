@@ -1,4 +1,6 @@
 """MLP with the module/parameter naming of rlpyt/models/mlp.py:5-46 (``model.<i>``)."""
+import os
+
 import torch
 
 
@@ -17,8 +19,21 @@ class MlpModel(torch.nn.Module):
         self.model = torch.nn.Sequential(*layers)
         self._output_size = n_in if output_size is None else output_size
 
+    # set False (or RLPYT_Q_HEAD=0) for the library GEMMs in no-grad forwards too (A/B tests)
+    use_fused_q_head = os.environ.get("RLPYT_Q_HEAD", "1") != "0"
+
     def forward(self, input):
-        return self.model(input)
+        m = self.model
+        if (self.use_fused_q_head and len(m) == 3 and not torch.is_grad_enabled()
+                and isinstance(input, torch.Tensor) and input.is_cuda and input.dim() == 2
+                and isinstance(m[1], torch.nn.ReLU) and isinstance(m[0], torch.nn.Linear)
+                and isinstance(m[2], torch.nn.Linear)):
+            # Linear -> ReLU -> Linear with few outputs on a sampling / target batch: the Q-value
+            # heads of the DQN family (split-K hidden layer + one finishing kernel)
+            from .. import ops
+            if ops.mlp_q_head_ok(input, m[0], m[2]):
+                return ops.mlp_q_head(input.contiguous(), m[0], m[2])
+        return m(input)
 
     @property
     def output_size(self):

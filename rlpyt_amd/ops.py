@@ -1013,12 +1013,29 @@ def atari_sample_convs(obs, t_dev, lo, new_frame, full_rows, slot, w1, b1, w2, b
     return out
 
 
-def dqn_convs_fwd(obs, w1, b1, w2, b2, w3, b3, scale=1. / 255, out=None):
+def dqn_convs_pack(w1, w2, w3, out=None):
+    """The DQN conv stack's weights in the kernels' register order (``rlpyt_dqn_convs_pack_f32``):
+    made once per iteration by models that step environments, passed to ``dqn_convs_fwd`` as
+    ``packed`` -- valid as long as the three weights do not change."""
+    _lib.require_gpu()
+    n = int(lib.rlpyt_dqn_convs_packed_floats())
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=w1.device)
+    assert out.numel() == n and out.dtype == torch.float32 and out.is_contiguous()
+    for x in (w1, w2, w3):
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.device == out.device
+    check(lib.rlpyt_dqn_convs_pack_f32(ptr(w1), ptr(w2), ptr(w3), ptr(out), stream()),
+          "rlpyt_dqn_convs_pack_f32")
+    return out
+
+
+def dqn_convs_fwd(obs, w1, b1, w2, b2, w3, b3, scale=1. / 255, out=None, packed=None):
     """No-grad forward of the DQN-family conv stack (Conv2d(4,32,8,s4) / (32,64,4,s2,p1) /
     (64,64,3,s1,p1), ReLU after each; rlpyt/models/dqn/atari_dqn_model.py:30-37) on uint8 frames
     ``[N,4,104,80]``: returns ``[N, 6912]`` in the order of ``conv(img).view(N, -1)``.  Weights in
-    the torch layout; they are re-packed on the stream in front of the layer kernels, so the call
-    (also as a captured graph node) always sees the current parameters."""
+    the torch layout; without ``packed`` they are re-packed on the stream in front of the layer
+    kernels, so the call (also as a captured graph node) always sees the current parameters; with
+    ``packed`` (``dqn_convs_pack`` of the same weights) that launch is skipped."""
     _lib.require_gpu()
     assert obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape[1:]) == (4, 104, 80)
     assert tuple(w1.shape) == (32, 4, 8, 8) and tuple(w2.shape) == (64, 32, 4, 4)
@@ -1032,9 +1049,31 @@ def dqn_convs_fwd(obs, w1, b1, w2, b2, w3, b3, scale=1. / 255, out=None):
         out = torch.empty((N, 6912), dtype=torch.float32, device=obs.device)
     assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (N, 6912)
     check(lib.rlpyt_dqn_convs_fwd_f32(ptr(obs), N, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3),
-                                      ptr(b3), float(scale), ptr(ws), ptr(out), stream()),
+                                      ptr(b3), ptr(packed), float(scale), ptr(ws), ptr(out), stream()),
           "rlpyt_dqn_convs_fwd_f32")
     return out
+
+
+def mlp_q_head_ok(x, lin1, lin2):
+    """Whether ``mlp_q_head`` serves ``lin2(relu(lin1(x)))``: no autograd, f32 on the device, at most
+    256 rows, hidden width 256 / 512, at most 18 outputs."""
+    return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+            and 0 < x.shape[0] <= 256 and lin1.out_features in (256, 512) and lin1.in_features % 16 == 0
+            and 0 < lin2.out_features <= 18 and lin1.bias is not None and lin2.bias is not None
+            and lin1.weight.dtype == torch.float32 and lin1.weight.is_cuda)
+
+
+def mlp_q_head(x, lin1, lin2):
+    """``lin2(relu(lin1(x)))`` for the Q-value head of a sampling / target pass: the hidden layer as
+    split-K partials (``rlpyt_fc_small_f32``), their sum + bias + ReLU + the output dot products in
+    ``rlpyt_q_head_f32`` -- two launches instead of GEMM + clamp + GEMM."""
+    _lib.require_gpu()
+    partial, ksplit = fc_small_partials(x, lin1.weight)
+    n, A, K = x.shape[0], lin2.out_features, lin1.out_features
+    q = torch.empty((n, A), dtype=torch.float32, device=x.device)
+    check(lib.rlpyt_q_head_f32(ptr(partial), ksplit, ptr(lin1.bias), ptr(_f32(lin2.weight.detach())),
+                               ptr(lin2.bias), n, K, A, ptr(q), stream()), "rlpyt_q_head_f32")
+    return q
 
 
 def categorical_head(h, w_pi, b_pi, w_v=None, b_v=None, uniforms=None, u_row=None):

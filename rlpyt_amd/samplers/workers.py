@@ -110,16 +110,15 @@ class EnvRunner:
     # ------------------------------------------------------------------ native loop body
     # With the device side of a time step at ~100 us the rollout is priced in host CPU-seconds per
     # env step under the box's CPU quota, and ~1/3 of them were the interpreter overhead of the loop
-    # body below (TrajInfo dict updates, numpy scalar stores, attribute probing).  For the
-    # mid-batch-reset collector with the stock trajectory statistics that body runs in C
+    # body below (TrajInfo dict updates, numpy scalar stores, attribute probing).  With the stock
+    # trajectory statistics that body -- reset and wait-reset collector alike -- runs in C
     # (rlpyt_amd/_envloop, csrc/envloop.c); ``env.step`` stays the Python call it is.  The running
     # statistics live in numpy arrays typed as the reference's per-step updates leave them
     # (np.float32 rewards: float32 sums, float64 discount); a finished trajectory is turned back
     # into a ``TrajInfoCls`` record in ``_native_on_done``.
     def _native_ok(self, first_obs):
         from .collections import AtariTrajInfo, TrajInfo
-        if not (self.use_native and self.mid_batch_reset
-                and self.TrajInfoCls in (TrajInfo, AtariTrajInfo)
+        if not (self.use_native and self.TrajInfoCls in (TrajInfo, AtariTrajInfo)
                 and (self.env_info is None or self._info_arrays is not None)):
             return False
         step = self.step
@@ -165,12 +164,32 @@ class EnvRunner:
             observation=step.observation, info_arrays=self._info_arrays, length=st.length,
             ret32=st.ret32, nonzero=st.nonzero, disc32=st.disc32, ret64=st.ret64, disc64=st.disc64,
             cur_discount=st.g, score=st.score, discount=float(self.TrajInfoCls._discount),
-            f64_mode=int(f64), on_done=self._native_on_done, float32_type=np.float32)
+            f64_mode=int(f64), float32_type=np.float32,
+            on_done=self._native_on_done if self.mid_batch_reset else self._native_on_done_wait,
+            wait_reset=int(not self.mid_batch_reset),
+            force_full=None if self.mid_batch_reset else self.force_full)
         self._completed = None
+
+    def _native_on_done_wait(self, b, final_obs, traj_done, done):
+        """Wait-reset collector (collectors.py:92-103): a finished trajectory is recorded and its env
+        marked for the reset between batches; a done env's final observation is held for the first row
+        of the next batch.  The env is NOT reset here."""
+        if traj_done:
+            self._native_record(b, final_obs)
+            self.need_reset[b] = True
+        if done:
+            self.temp_observation[b] = final_obs
+            self.last_obs[b] = 0
 
     def _native_on_done(self, b, final_obs):
         """Env ``b`` finished a trajectory: record it (fields typed as the reference's updates leave
         them), restart the statistics, reset the env; returns the first observation."""
+        self._native_record(b, final_obs)
+        o = self.envs[b].reset()
+        self.last_obs[b] = o
+        return o
+
+    def _native_record(self, b, final_obs):
         st = self._nstats
         f64 = self._native.f64_mode()
         info = self.TrajInfoCls()
@@ -187,9 +206,6 @@ class EnvRunner:
         st.ret32[b] = st.disc32[b] = 0
         st.ret64[b] = st.disc64[b] = 0
         st.g[b] = 1
-        o = self.envs[b].reset()
-        self.last_obs[b] = o
-        return o
 
     def step_synced(self, seq, g, t, completed):
         """``seq.worker_wait_act(g)`` + ``step_all`` + ``seq.worker_arrive(g)`` as one native call."""

@@ -160,3 +160,41 @@ def test_dqn_family_models_dispatch_to_the_fused_convs(lead):
             q2, s2 = m(obs, pa, pr, None)
         np.testing.assert_allclose(q1.cpu().numpy(), q2.cpu().numpy(), rtol=2e-4, atol=2e-6)
         np.testing.assert_allclose(s1.h.cpu().numpy(), s2.h.cpu().numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_packed_weights_are_made_once_per_sampling_phase_and_never_stale_in_training():
+    """``Conv2dModel.refresh_step_weights`` (the agent calls it on entering sample / eval mode) packs
+    the weights once; forwards in eval mode then skip the packing launch; a module in training mode
+    (target network, double-DQN pass between optimizer steps) packs per call and sees parameter
+    changes at once."""
+    from rlpyt_amd import _lib
+    from rlpyt_amd.models.dqn.atari_dqn_model import AtariDqnModel
+    torch.manual_seed(8)
+    m = AtariDqnModel(image_shape=(4, 104, 80), output_size=6).cuda()
+    g = torch.Generator().manual_seed(9)
+    obs = torch.randint(0, 256, (7, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    pa, pr = torch.zeros(7, 6, device="cuda"), torch.zeros(7, device="cuda")
+
+    def packs():
+        return sum(v for k, v in _lib.variant_counts().items() if "dqn_pack_weights_kernel" in k)
+
+    with torch.no_grad():
+        m.train()
+        _lib.variant_reset()
+        q_train = m(obs, pa, pr)
+        assert packs() == 1
+        m.eval()
+        m.refresh_step_weights()
+        _lib.variant_reset()
+        q_eval = m(obs, pa, pr)
+        q_eval2 = m(obs, pa, pr)
+        assert packs() == 0
+        assert torch.equal(q_train, q_eval) and torch.equal(q_eval, q_eval2)
+        # an optimizer step while training: the next no-grad forward is current
+        m.train()
+        m.conv.conv[2].weight.mul_(0.5)
+        q_new = m(obs, pa, pr)
+        m.conv.use_fused_nograd_convs = False
+        q_lib = m(obs, pa, pr)
+    assert not torch.allclose(q_new, q_train)
+    np.testing.assert_allclose(q_new.cpu().numpy(), q_lib.cpu().numpy(), rtol=2e-4, atol=2e-6)

@@ -551,3 +551,29 @@ def test_r2d1_sampler_batches_equal_with_and_without_fused_step(mid_batch_reset,
             assert np.array_equal(x[k], y[k]), k
         for k in ("q", "h", "c"):
             np.testing.assert_allclose(x[k], y[k], rtol=5e-4, atol=5e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("n,K_in,hidden,A", [(1, 512, 512, 6), (8, 6912, 512, 6), (48, 512, 512, 18),
+                                            (130, 6912, 512, 4), (5, 64, 256, 3), (256, 512, 256, 9)])
+def test_mlp_q_head_matches_torch(n, K_in, hidden, A):
+    """``Linear -> ReLU -> Linear`` Q head of a no-grad sampling / target pass (split-K hidden layer +
+    ``rlpyt_q_head_f32``) against the modules it replaces (rlpyt/models/mlp.py:24-31), through
+    ``MlpModel.forward``; the launch counters say which path ran, autograd keeps the modules."""
+    from rlpyt_amd import _lib
+    from rlpyt_amd.models.mlp import MlpModel
+    torch.manual_seed(n + A)
+    m = MlpModel(K_in, hidden, output_size=A).cuda()
+    x = torch.randn(n, K_in, device="cuda")
+    ref64 = m.double()(x.double())
+    m = m.float()
+    _lib.variant_reset()
+    lib = m(x)                                           # autograd: library GEMMs
+    assert lib.requires_grad
+    assert not any("q_head_kernel" in k and v > 0 for k, v in _lib.variant_counts().items())
+    with torch.no_grad():
+        got = m(x)
+    assert any("q_head_kernel" in k and v > 0 for k, v in _lib.variant_counts().items())
+    scale = ref64.abs().max().item()
+    err = (got.double() - ref64).abs().max().item() / scale
+    err_lib = (lib.detach().double() - ref64).abs().max().item() / scale
+    assert got.shape == (n, A) and err <= max(3 * err_lib, 3e-7), (err, err_lib)

@@ -23,7 +23,7 @@ class Float64RewardPong(SyntheticPong):
         return EnvStep(o, np.float64(r), d, info)
 
 
-def _runner(EnvCls, n, T, native, TrajInfoCls, lazy, frames=True, **env_kw):
+def _runner(EnvCls, n, T, native, TrajInfoCls, lazy, frames=True, mbr=True, **env_kw):
     envs = [EnvCls(seed=100 + i, **env_kw) for i in range(n)]
     o = envs[0].reset()
     fields = dict(observation=np.zeros((n,) + o.shape, o.dtype), action=np.zeros(n, np.int64),
@@ -36,7 +36,7 @@ def _runner(EnvCls, n, T, native, TrajInfoCls, lazy, frames=True, **env_kw):
     big = EnvInfo(game_score=np.zeros((T, n + 3), np.float32), traj_done=np.zeros((T, n + 3), bool))
     info = EnvInfo(game_score=big.game_score[:, 2:2 + n], traj_done=big.traj_done[:, 2:2 + n]) \
         if EnvCls is not TinyDiscreteEnv else None
-    r = EnvRunner(envs, step, info, TrajInfoCls, True)
+    r = EnvRunner(envs, step, info, TrajInfoCls, mbr)
     r.use_native = native
     if lazy:
         class L:
@@ -47,23 +47,28 @@ def _runner(EnvCls, n, T, native, TrajInfoCls, lazy, frames=True, **env_kw):
     return r, step, big
 
 
+@pytest.mark.parametrize("mbr", [True, False], ids=["reset", "wait_reset"])
 @pytest.mark.parametrize("EnvCls,TI,env_kw,frames,lazy", [
     (SyntheticPong, AtariTrajInfo, dict(points_to_end=1, max_steps=40), True, True),
     (SyntheticPong, TrajInfo, dict(points_to_end=2, max_steps=25), True, False),
     (Float64RewardPong, AtariTrajInfo, dict(points_to_end=1, max_steps=30), True, True),
     (TinyDiscreteEnv, TrajInfo, dict(horizon=9), False, False),
 ])
-def test_native_loop_body_equals_python_loop_body(EnvCls, TI, env_kw, frames, lazy):
-    n, T, n_batches = 5, 16, 6
+def test_native_loop_body_equals_python_loop_body(EnvCls, TI, env_kw, frames, lazy, mbr):
+    """Reset collector and wait-reset collector (a finished env idles with a blank observation row
+    until ``begin_batch`` resets it, collectors.py:73-126)."""
+    n, T, n_batches = 5, 16, 6 if mbr else 14
     TI._discount = 0.97
     try:
         runs = []
         for native in (True, False):
-            r, step, big = _runner(EnvCls, n, T, native, TI, lazy, frames, **env_kw)
+            r, step, big = _runner(EnvCls, n, T, native, TI, lazy, frames, mbr, **env_kw)
             assert (r._native is not None) == native
             rng = np.random.RandomState(3)
             rows, completed = [], []
             for _ in range(n_batches):
+                r.begin_batch()
+                rows.append([np.array(x).copy() for x in step])
                 for t in range(T):
                     step.action[:] = rng.randint(0, 2 if EnvCls is TinyDiscreteEnv else 6, n)
                     r.step_all(t, completed)
@@ -93,9 +98,9 @@ def test_native_loop_declines_what_it_does_not_cover():
     o = envs[0].reset()
     step = StepBuffer(observation=np.zeros((2,) + o.shape, o.dtype), action=np.zeros(2, np.int64),
                       reward=np.zeros(2, np.float32), done=np.zeros(2, bool))
-    r = EnvRunner(envs, step, None, TrajInfo, False)     # wait-reset collector
+    r = EnvRunner(envs, step, None, TrajInfo, False)     # wait-reset collector: covered since round 5
     r.start(0)
-    assert r._native is None
+    assert r._native is not None
 
 
 def test_native_loop_declines_env_info_dtypes_the_c_body_cannot_store():

@@ -577,6 +577,18 @@ def _rnn_step_inputs():
     D.test_r2d1_fused_sampling_step_equals_eager_step(dict(fc_size=64, lstm_size=32, head_size=32, dueling=True), True)
 
 
+@case("q_head_kernel<2>")
+def _q_head_512():
+    import test_dqn_gpu as D
+    D.test_mlp_q_head_matches_torch(8, 6912, 512, 6)
+
+
+@case("q_head_kernel<1>")
+def _q_head_256():
+    import test_dqn_gpu as D
+    D.test_mlp_q_head_matches_torch(5, 64, 256, 3)
+
+
 @case("replay_step_fields_kernel")
 def _replay_step_fields():
     """One-launch field gather of a single-step replay batch vs the row-by-row gathers + selects it
