@@ -306,6 +306,11 @@ static PyObject* EnvLoop_step(EnvLoop* self, PyObject* args) {
       /* wait-reset: a finished env idles with done = True and a blank reward until the batch ends
        * (collectors.py:85-91); nothing else of its rows is touched */
       rew[b] = 0.f;
+      /* its blank stack was uploaded whole with the step that finished it; from here on "previous
+       * stack shifted + blank newest frame" IS the blank stack: no upload per idle step (with the flag
+       * left standing the master copied 33 KB per idle env and step -- a separate transfer each: the
+       * R2D1 rollout's issue thread spent 48 us per group-step on them, profiles/r5_replay_sampler_breakdown.txt) */
+      if (reset) reset[b] = 0;
       continue;
     }
     PyObject* env = PyList_GET_ITEM(self->envs, b);

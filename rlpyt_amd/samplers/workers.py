@@ -240,6 +240,10 @@ class EnvRunner:
                 # wait-reset: a finished env idles with done=True and blank reward
                 # (collectors.py:85-91); the master blanks its action / agent_info rows.
                 rew_buf[b] = 0
+                if frames:
+                    # its blank stack went up whole with the step that finished it; "previous stack
+                    # shifted + blank newest frame" is that same blank stack: nothing to upload
+                    reset_buf[b] = False
                 continue
             a = act_buf[b]
             o, r, d, info = env.step(a)
