@@ -1,7 +1,8 @@
 #!/bin/bash
 # The measurements committed under profiles/r5_* (ON THE GPU BOX; ~20 min):
 #   whole GPU suite, the three bench lines (ppo / dqn / r2d1), rocprofv3 kernel trace of the ppo bench,
-#   PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) over the update's kernels and the rollout-step kernels.
+#   PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) over the update's kernels and the rollout-step kernels,
+#   timed-region kernel statistics of the three lines.
 # usage: scripts/final_measurements.sh [tag=r5]      -> gpurun_out/<tag>_final/
 TAG=${1:-r5}
 OUT=$PWD/gpurun_out/${TAG}_final
@@ -23,6 +24,9 @@ bash scripts/pmc_update.sh ${TAG}_final_upd > $OUT/pmc_update.log 2>&1
 cp gpurun_out/${TAG}_final_upd_pmc/counters.json $OUT/pmc_counters.json 2>/dev/null
 bash scripts/rollout_pmc.sh ${TAG}_final_roll > $OUT/pmc_rollout.log 2>&1
 cp gpurun_out/${TAG}_final_roll/rollout_pmc.json $OUT/rollout_pmc.json 2>/dev/null
+# kernel statistics of the TIMED REGION of each line (bench.py --trace-markers + scripts/trace_region.py)
+bash scripts/dqn_trace.sh ${TAG}_final > $OUT/region_traces.log 2>&1
+cp gpurun_out/${TAG}_final_region_trace/*_region.txt gpurun_out/${TAG}_final_region_trace/*_region.json $OUT/ 2>/dev/null
 python - $OUT <<'PY'
 import json, sys
 out = sys.argv[1]
