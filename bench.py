@@ -31,8 +31,12 @@ Prints ONE JSON line (rank 0).  Extra objects:
   multi_gpu     -- (N>1) world size as torch.distributed sees it, per-rank usable CPUs, the
                    all-reduce time of one gradient set measured live, per-GPU SPS.
 `--config dqn` / `--config r2d1` run BASELINE configs #3 / #5 end to end instead (full-size HBM
-replay, prioritized tree, frame / sequence gathers) and report SPS, updates/s and the replay
-kernels' rooflines taken from those buffers.
+replay, prioritized tree, frame / sequence gathers; every no-grad network pass on own kernels, the
+DQN update as one captured hipGraph) and report SPS, updates/s, the replay kernels' rooflines
+taken from those buffers, the rollout's hand-off breakdown (`sampler`) and the reference's own
+iteration on the host cores (`cpu_baseline`).
+`--trace-markers` brackets the timed region with a marker kernel so that
+`scripts/trace_region.py` can cut a rocprofv3 kernel trace to exactly that region.
 Data: synthetic Atari-shaped env (no ALE in the image), random-init weights.
 """
 import argparse

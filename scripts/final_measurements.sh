@@ -25,7 +25,7 @@ cp gpurun_out/${TAG}_final_upd_pmc/counters.json $OUT/pmc_counters.json 2>/dev/n
 bash scripts/rollout_pmc.sh ${TAG}_final_roll > $OUT/pmc_rollout.log 2>&1
 cp gpurun_out/${TAG}_final_roll/rollout_pmc.json $OUT/rollout_pmc.json 2>/dev/null
 # kernel statistics of the TIMED REGION of each line (bench.py --trace-markers + scripts/trace_region.py)
-bash scripts/dqn_trace.sh ${TAG}_final > $OUT/region_traces.log 2>&1
+bash scripts/region_trace.sh ${TAG}_final > $OUT/region_traces.log 2>&1
 cp gpurun_out/${TAG}_final_region_trace/*_region.txt gpurun_out/${TAG}_final_region_trace/*_region.json $OUT/ 2>/dev/null
 python - $OUT <<'PY'
 import json, sys

@@ -88,3 +88,37 @@ def test_pmc_traffic_reads_the_committed_counters():
         half = bench.pmc_traffic(name, {"alg_bytes_per_launch": alg // 2})
         assert abs(half["bytes_per_launch"] * 2 - t["bytes_per_launch"]) <= 2 + 1e-6 * t["bytes_per_launch"]
     assert bench.pmc_traffic("no_such_region", {"alg_bytes_per_launch": 1}) is None
+
+
+def test_trace_region_cuts_a_kernel_trace_to_the_marked_region(tmp_path):
+    """scripts/trace_region.py: dispatches between the two ``erfinv`` markers of ``bench.py
+    --trace-markers``, per-kernel statistics and the device-busy share (union of the intervals)."""
+    import csv
+    import json
+    import subprocess
+    import sys
+    trace = tmp_path / "kernel_trace.csv"
+    rows = [("warmup_kernel", 0, 10_000), ("void at::native::erfinv_kernel", 20_000, 21_000),
+            ("b_kernel", 40_000, 50_000), ("c_kernel", 45_000, 70_000), ("b_kernel", 80_000, 90_000),
+            ("void at::native::erfinv_kernel", 121_000, 122_000), ("after_kernel", 130_000, 140_000)]
+    with open(trace, "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_ALL)
+        w.writerow(["Kind", "Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        for n, s, e in rows:
+            w.writerow(["KERNEL_DISPATCH", n, s, e])
+    out = tmp_path / "region.json"
+    script = os.path.join(ROOT, "scripts", "trace_region.py")
+    r = subprocess.run([sys.executable, script, str(trace), "--steps", "2", "--json", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(out.read_text())
+    assert d["dispatches"] == 3 and abs(d["region_wall_ms"] - 0.1) < 1e-9
+    assert abs(d["device_busy_ms"] - 0.04) < 1e-9 and abs(d["kernel_sum_ms"] - 0.045) < 1e-9
+    names = {k["name"]: k for k in d["kernels"]}
+    assert set(names) == {"b_kernel", "c_kernel"} and names["b_kernel"]["calls"] == 2
+    assert names["b_kernel"]["calls_per_step"] == 1.0
+    # no markers: a clear message instead of statistics of the whole run
+    rows2 = tmp_path / "nomark.csv"
+    rows2.write_text('"Kind","Kernel_Name","Start_Timestamp","End_Timestamp"\\n"K","a",0,10\\n')
+    r = subprocess.run([sys.executable, script, str(rows2)], capture_output=True, text=True)
+    assert r.returncode != 0 and "trace-markers" in (r.stderr + r.stdout)
