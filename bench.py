@@ -1137,8 +1137,11 @@ def replay_config_main(args):
     sampler = GpuSampler(SyntheticPong, dict(step_cost_us=args.env_cost_us), batch_T=T, batch_B=B,
                          n_workers=workers, TrajInfoCls=AtariTrajInfo, max_decorrelation_steps=100,
                          mid_batch_reset=(args.config == "dqn"),
-                         n_groups=None if args.groups < 0 else args.groups,
+                         n_groups=((1 if args.config == "dqn" else None) if args.groups < 0
+                                   else args.groups),
                          use_graph=not args.no_graph)
+    # (dqn: ONE pipeline group for the 16 envs -- 958 vs 932 and 846 vs 828 updates/s against the
+    # sampler's default of two, profiles/r5_ab_groups_replay.jsonl, r5_dqn_knobs.txt)
     examples = sampler.initialize(agent, seed=1, bootstrap_value=False)
     torch.cuda.set_device(0)
     agent.to_device(0)
