@@ -116,8 +116,11 @@ def trace_marker(args):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed iterations (default: 20 for ppo / r2d1, 300 for dqn -- a few seconds)")
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed iterations before them (default: 5 / 3 / 20): step and tail graphs are "
+                         "captured and the C serve loop takes over during the first two")
     ap.add_argument("--batch-T", type=int, default=128)
     ap.add_argument("--batch-B", type=int, default=256)
     ap.add_argument("--workers", "--workers-per-rank", dest="workers", type=int, default=-1,
@@ -205,6 +208,10 @@ def main():
     args = parse()
     if args.config != "ppo":
         return replay_config_main(args)
+    if args.steps is None:
+        args.steps = 20
+    if args.warmup is None:
+        args.warmup = 5
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
@@ -1115,8 +1122,8 @@ def replay_config_main(args):
         # 1M-leaf tree live, frame windows crossing the wrap point)
         workers = args.workers if args.workers > 0 else 2
         fill = int(1e6) // B // T + 400 if args.replay_fill_itrs < 0 else args.replay_fill_itrs
-        steps = args.steps if args.steps != 5 else 300
-        warmup = args.warmup if args.warmup != 2 else 20
+        steps = args.steps if args.steps is not None else 300
+        warmup = args.warmup if args.warmup is not None else 20
         name = "DQN AtariDqnAgent, PrioritizedReplayFrameBuffer 1e6 frames, sampler [2,16], batch 128"
     else:
         from rlpyt_amd.agents.dqn.r2d1_agent import AtariR2d1Agent
@@ -1130,8 +1137,8 @@ def replay_config_main(args):
                     replay_size=int(4e6))
         workers = args.workers if args.workers > 0 else max(min(int(round(1.6 * cpus)) - 1, B // 10), 1)
         fill = int(4e6) // B // T + 8 if args.replay_fill_itrs < 0 else args.replay_fill_itrs   # wraps
-        steps = args.steps if args.steps != 5 else 20
-        warmup = args.warmup if args.warmup != 2 else 3
+        steps = args.steps if args.steps is not None else 20
+        warmup = args.warmup if args.warmup is not None else 3
         name = ("R2D1 AtariR2d1Agent (conv + LSTM 512), PrioritizedSequenceReplayFrameBuffer 4e6 "
                 "frames, sampler [40,192], sequences [40+80+5, 64]")
     sampler = GpuSampler(SyntheticPong, dict(step_cost_us=args.env_cost_us), batch_T=T, batch_B=B,
