@@ -53,3 +53,35 @@ def test_product_does_not_import_oracle():
                         "/root/reference" in txt:
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_round5_entry_points_validate_their_arguments_without_a_gpu():
+    """Empty inputs return OK before any device call; null pointers and unsupported shapes are
+    refused with the library's error codes and a message (no compute without a GPU here)."""
+    import ctypes
+
+    from rlpyt_amd import _lib
+    lib = _lib.lib
+    OK = 0
+    assert lib.rlpyt_dqn_convs_fwd_f32(None, -1, *([None] * 7), 1.0, None, None, None) == -1   # RLPYT_EINVAL
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    # N = 0 / T = 0: nothing to do
+    assert lib.rlpyt_dqn_convs_fwd_f32(None, 0, *([None] * 7), 1.0, None, None, None) == OK
+    assert lib.rlpyt_lstm_seq_f32(None, None, None, None, None, 0, 4, 512, None) == OK
+    # null pointers
+    assert lib.rlpyt_dqn_convs_fwd_f32(None, 3, *([None] * 7), 1.0, None, None, None) != OK
+    assert b"null pointer" in lib.rlpyt_hip_last_error()
+    assert lib.rlpyt_lstm_seq_f32(None, None, None, None, None, 2, 4, 512, None) != OK
+    assert lib.rlpyt_rnn_step_inputs_f32(None, 512, 1, None, 6, None, None, None, None, 512, None, 1040,
+                                         None, None, 4, None) != OK
+    assert lib.rlpyt_q_head_f32(None, 8, None, None, None, 4, 512, 6, None, None) != OK
+    # unsupported shapes (pointers non-null so the shape check is what fires)
+    assert lib.rlpyt_lstm_seq_f32(p, p, p, p, p, 2, 4, 384, None) != OK
+    assert b"H must be 256 or 512" in lib.rlpyt_hip_last_error()
+    assert lib.rlpyt_q_head_f32(p, 8, p, p, p, 4, 512, 19, p, None) != OK
+    assert lib.rlpyt_q_head_f32(p, 8, p, p, p, 4, 384, 6, p, None) != OK
+    assert lib.rlpyt_rnn_step_inputs_f32(p, 512, 1, p, 6, p, None, p, p, 512, p, 1000, p, p, 4, None) != OK
+    assert b"Kp >= F + A + 1 + H" in lib.rlpyt_hip_last_error()
+    assert lib.rlpyt_dqn_convs_packed_floats() == 32 * 256 + 64 * 512 + 64 * 576
+    assert lib.rlpyt_dqn_convs_workspace_floats(10) == 77824 + 10 * (475 * 32 + 108 * 64)
