@@ -46,7 +46,11 @@ class CapturedUpdates:
         a device-resident ring, and a fixed number of updates per call."""
         a = self.algo
         opt, rb = a.optimizer, a.replay_buffer
-        return (ENABLED and not self.failed and a.agent.device.type == "cuda"
+        # single rank only: under DistributedDataParallel the reducer's bookkeeping and the RCCL
+        # all-reduces would land inside the capture (and ranks could end up on different paths)
+        single = (getattr(a, "world_size", 1) == 1 and not isinstance(
+            getattr(a.agent, "model", None), torch.nn.parallel.DistributedDataParallel))
+        return (ENABLED and single and not self.failed and a.agent.device.type == "cuda"
                 and hasattr(opt, "captured_ready") and opt.captured_ready()
                 and hasattr(rb, "sample_batch_device") and rb.can_sample_on_device()
                 and a.updates_per_optimize >= 1 and getattr(a, "CAPTURABLE", False))
@@ -118,19 +122,21 @@ class CapturedUpdates:
         self._fill_tables(itr)
         done = 0
         if self.graph is None:
+            # the first body runs eagerly and OUTSIDE the try: an error of the update itself (a
+            # shape assertion, a missing kernel) must surface, not turn into a slower run
+            self._body()                           # stream workspaces, autograd buffers
+            done = 1
+            self._after_update()
+            torch.cuda.synchronize()
+            a.optimizer.zero_grad(set_to_none=True)
             try:
-                self._body()                       # eager: stream workspaces, autograd buffers
-                done = 1
-                self._after_update()
-                torch.cuda.synchronize()
-                a.optimizer.zero_grad(set_to_none=True)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._body()
                 self.graph = graph
                 logger.log(f"{type(a).__name__}: one update captured as a hipGraph "
                            f"({self.k} replays per iteration).")
-            except Exception as e:  # noqa: BLE001  (keep training: eager updates are correct)
+            except RuntimeError as e:     # the capture itself refused: eager bodies are correct
                 logger.log(f"{type(a).__name__}: update-graph capture failed "
                            f"({type(e).__name__}: {e}); continuing with eager updates.")
                 self.failed = True

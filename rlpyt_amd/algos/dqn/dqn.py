@@ -49,7 +49,7 @@ class DQN(RlAlgorithm):
     # ------------------------------------------------------------------ set-up
     def initialize(self, agent, n_itr, batch_spec, mid_batch_reset, examples, world_size=1,
                    rank=0):
-        self.agent, self.n_itr, self.rank = agent, n_itr, rank
+        self.agent, self.n_itr, self.rank, self.world_size = agent, n_itr, rank, world_size
         self.mid_batch_reset = mid_batch_reset
         self.sampler_bs = batch_spec.size
         plan = self.plan = plan_updates(batch_spec.size, self.batch_size, self.replay_ratio,

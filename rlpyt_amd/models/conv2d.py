@@ -59,6 +59,21 @@ class Conv2dModel(torch.nn.Module):
         with torch.no_grad():
             self._packed = ops.dqn_convs_pack(self.conv[0].weight, self.conv[2].weight,
                                               self.conv[4].weight, out=self._packed)
+        self._packed_versions = self._weight_versions()
+
+    def _weight_versions(self):
+        """(storage address, in-place version counter) of the three conv weights: any optimizer
+        step, ``load_state_dict`` / ``copy_`` or ``.to()`` after the pack changes one of them."""
+        return tuple((self.conv[i].weight.data_ptr(), self.conv[i].weight._version) for i in (0, 2, 4))
+
+    def _current_pack(self, device):
+        """The phase's packed weights if they still describe the live parameters, else None (the
+        forward then packs on the stream): weights can change while the module stays in eval mode
+        -- ``agent.load_state_dict`` after ``eval_mode``, a direct ``model.eval()``."""
+        if (self.training or self._packed is None or self._packed.device != device
+                or getattr(self, "_packed_versions", None) != self._weight_versions()):
+            return None
+        return self._packed
 
     def _fused_ok(self, observation, T_B, img_shape):
         return (self.use_fused_nograd_convs and self._dqn_geometry and not torch.is_grad_enabled()
@@ -73,9 +88,8 @@ class Conv2dModel(torch.nn.Module):
         if self._fused_ok(observation, T_B, img_shape):
             from .. import ops
             c1, c2, c3 = self.conv[0], self.conv[2], self.conv[4]
-            packed = self._packed if (not self.training and self._packed is not None
-                                      and self._packed.device == observation.device) else None
-            return ops.dqn_convs_fwd(observation.reshape(T_B, *img_shape), c1.weight, c1.bias,
+            packed = self._current_pack(observation.device)
+            return ops.dqn_convs_fwd(observation.reshape(T_B, *img_shape).contiguous(), c1.weight, c1.bias,
                                      c2.weight, c2.bias, c3.weight, c3.bias, packed=packed)
         from .pg.atari_ff_model import prepare_image
         return self.conv(prepare_image(observation, T_B, img_shape)).reshape(T_B, -1)

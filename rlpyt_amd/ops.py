@@ -1177,15 +1177,18 @@ def replay_step_fields(action, reward, done, return_, done_n, t_idx, b_idx, n_st
     ``[T, B]``: int64 action, float32 reward / return_, bool done / done_n, all contiguous."""
     _lib.require_gpu()
     T, B = action.shape
-    n = t_idx.numel()
     dev = action.device
+    assert t_idx.device == dev and b_idx.device == dev, "replay indices must live on the ring's device"
+    t_idx, b_idx = t_idx.long().contiguous(), b_idx.long().contiguous()
+    n = t_idx.numel()
+    assert b_idx.numel() == n
     i64 = lambda: torch.empty(n, dtype=torch.int64, device=dev)        # noqa: E731
     f32 = lambda: torch.empty(n, dtype=torch.float32, device=dev)      # noqa: E731
     bl = lambda: torch.empty(n, dtype=torch.bool, device=dev)          # noqa: E731
     pa, pr, a, r, d, dn, tpa, tpr = i64(), f32(), i64(), f32(), bl(), bl(), i64(), f32()
     check(lib.rlpyt_replay_step_fields(
-        ptr(action), ptr(reward), ptr(done), ptr(return_), ptr(done_n), ptr(t_idx.contiguous()),
-        ptr(b_idx.contiguous()), n, int(T), int(B), int(n_step), ptr(pa), ptr(pr), ptr(a), ptr(r),
+        ptr(action), ptr(reward), ptr(done), ptr(return_), ptr(done_n), ptr(t_idx),
+        ptr(b_idx), n, int(T), int(B), int(n_step), ptr(pa), ptr(pr), ptr(a), ptr(r),
         ptr(d), ptr(dn), ptr(tpa), ptr(tpr), stream()), "rlpyt_replay_step_fields")
     return pa, pr, a, r, d, dn, tpa, tpr
 

@@ -123,10 +123,14 @@ class FrameStore:
             for f in range(older):
                 self.frames[f] = obs[0, :, f]
         elif older and self.cursor.t <= claim.start:
-            # the lap closed: its tail is the next lap's history.  ``<=`` as the reference's frame
-            # mixin (rlpyt/replays/frame.py:56, ``self.t <= t``): a write of exactly T rows from a
-            # non-zero start lands back on its start and has wrapped all the same -- the strict
-            # ``claim.wrapped`` is the sum tree's rule (replays/sum_tree.py advance), not this one
+            # the lap closed: its tail is the next lap's history.  INTENTIONAL deviation from the
+            # reference in one corner: rlpyt/replays/frame.py:57 tests the strict ``self.t < t``, so
+            # an append of exactly T rows from a non-zero start (cursor lands back on its start)
+            # leaves its mirror rows stale there; ``<=`` refreshes them.  Every other append takes
+            # the same branch on both sides (a sampler batch is shorter than the ring in every
+            # reference config); pinned by tests/test_host_logic.py
+            # ::test_replay_store_parts_on_host_tensors.  The sum tree keeps the strict rule
+            # (``claim.wrapped``, replays/sum_tree.py advance).
             self.frames[:older] = self.frames[-older:]
 
 

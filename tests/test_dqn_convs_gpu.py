@@ -198,3 +198,39 @@ def test_packed_weights_are_made_once_per_sampling_phase_and_never_stale_in_trai
         q_lib = m(obs, pa, pr)
     assert not torch.allclose(q_new, q_train)
     np.testing.assert_allclose(q_new.cpu().numpy(), q_lib.cpu().numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_packed_weights_are_dropped_when_parameters_change_in_eval_mode():
+    """weights can change while the module STAYS in eval mode (``load_state_dict`` after
+    ``eval_mode``, an in-place edit): the phase's pack then no longer describes the parameters and the
+    forward must pack on the stream again instead of running with stale conv weights."""
+    from rlpyt_amd import _lib
+    from rlpyt_amd.models.dqn.atari_dqn_model import AtariDqnModel
+    torch.manual_seed(18)
+    m = AtariDqnModel(image_shape=(4, 104, 80), output_size=6).cuda()
+    other = AtariDqnModel(image_shape=(4, 104, 80), output_size=6).cuda()
+    g = torch.Generator().manual_seed(19)
+    obs = torch.randint(0, 256, (5, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    pa, pr = torch.zeros(5, 6, device="cuda"), torch.zeros(5, device="cuda")
+
+    def packs():
+        return sum(v for k, v in _lib.variant_counts().items() if "dqn_pack_weights_kernel" in k)
+
+    with torch.no_grad():
+        m.eval()
+        m.refresh_step_weights()
+        q0 = m(obs, pa, pr)
+        m.load_state_dict(other.state_dict())           # still in eval mode, no refresh
+        _lib.variant_reset()
+        q1 = m(obs, pa, pr)
+        assert packs() == 1, "stale pack used after load_state_dict in eval mode"
+        other.eval()
+        other.conv.use_fused_nograd_convs = False
+        q_lib = other(obs, pa, pr)
+        m.refresh_step_weights()                        # a refresh makes the pack current again
+        _lib.variant_reset()
+        q2 = m(obs, pa, pr)
+        assert packs() == 0
+    assert not torch.allclose(q0, q1)
+    assert torch.equal(q1, q2)
+    np.testing.assert_allclose(q1.cpu().numpy(), q_lib.cpu().numpy(), rtol=2e-4, atol=2e-6)

@@ -743,8 +743,9 @@ def test_replay_store_parts_on_host_tensors():
             lap0 = (k // buf.T) * buf.T
             for f in range(C - 1):
                 assert np.array_equal(frames[f], stream[lap0 + f]), (k, f)
-    # one append of EXACTLY T rows from a non-zero start lands back on its start: still a closed lap
-    # (rlpyt/replays/frame.py:56 tests ``self.t <= t``), the history rows must be refreshed
+    # one append of EXACTLY T rows from a non-zero start lands back on its start: still a closed lap,
+    # the history rows must be refreshed.  (Intentional fix of a reference corner case:
+    # rlpyt/replays/frame.py:57 tests the strict ``self.t < t`` and would leave them stale here.)
     assert buf.t == 4
     obs = np.stack([obs_at(k + i) for i in range(buf.T)])
     buf.append_samples(S2B(observation=torch.from_numpy(obs),
@@ -763,3 +764,27 @@ def test_replay_store_parts_on_host_tensors():
     banned = {(t - 1 - i) % buf.T for i in range(b)} | {(t + i) % buf.T for i in range(f)}
     assert set(T_idxs.tolist()) == set(range(buf.T)) - banned
     assert set(B_idxs.tolist()) == {0, 1}
+
+
+def test_conv_pack_guard_follows_weight_versions():
+    """``Conv2dModel._current_pack``: the packed copy of the conv weights is only handed
+    to the fused kernels while the module is in eval mode AND no weight changed since the pack
+    (storage address + in-place version counter)."""
+    from rlpyt_amd.models.conv2d import Conv2dModel
+    m = Conv2dModel(4, [32, 64, 64], [8, 4, 3], [4, 2, 1], paddings=[0, 1, 1])
+    m._packed = torch.zeros(1)                      # stands for the device pack
+    m._packed_versions = m._weight_versions()
+    dev = m._packed.device
+    m.eval()
+    assert m._current_pack(dev) is m._packed
+    m.train()
+    assert m._current_pack(dev) is None             # training: always pack on the stream
+    m.eval()
+    with torch.no_grad():
+        m.conv[2].weight.mul_(0.5)                  # in-place edit in eval mode
+    assert m._current_pack(dev) is None
+    m._packed_versions = m._weight_versions()
+    assert m._current_pack(dev) is m._packed
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)                           # copy_ bumps the version counters
+    assert m._current_pack(dev) is None
