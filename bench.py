@@ -13,7 +13,10 @@ A "step" = one full PPO iteration of the hot path on one synthetic batch:
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      -- the kernel with the largest TOTAL time over a whole timed iteration, rollout
                    kernels included (512 + launches each per iteration against 16 of every update
-                   kernel): an f32-MFMA kernel is priced against the 157.3 TFLOP/s f32 MFMA peak; a
+                   kernel); a rollout kernel (a captured graph node: no events of its own) is priced
+                   on its IN-PIPELINE average from the committed rocprofv3 summary of this command
+                   (profiles/r*_bench_kernel_stats.csv), its isolated live timing is the side field
+                   `avg_us_isolated`; an f32-MFMA kernel is priced against the 157.3 TFLOP/s f32 MFMA peak; a
                    bf16-split kernel (f32 contraction issued as 3 / 6 bf16 MFMAs per MAC)
                    against both the HBM peak and the 2.5 PFLOP/s dense bf16 peak with its ISSUED
                    flops; roofline_update = the largest kernel of the update, roofline_gemm_tn the
@@ -24,6 +27,10 @@ Prints ONE JSON line (rank 0).  Extra objects:
   value_env200us -- the same metric with a declared ALE-like host cost of 200 us per env step
                    (busy wait in the env workers; `value` itself is measured at 0 us: the
                    framework's own ceiling);
+  cpu_baseline_env200us, ratio_env200us -- the reference iteration with the SAME declared 200 us per
+                   env step, and value_env200us over it (like for like);
+  configs       -- (1 GPU) compact objects of BASELINE configs #3 (dqn) and #5 (r2d1): child runs of
+                   `bench.py --config ...` after the headline's timed region (--no-extra-configs skips);
   cpu_baseline  -- the UNMODIFIED reference (oracle/_ref, copied from /root/reference at build time by
                    oracle/make_ref.py: SerialSampler + PPO + AtariFfAgent) timed on this box's host
                    cores at the full [128, 256] batch (rank 0, N=1 only; kind "reference"); the oracle's
@@ -141,6 +148,12 @@ def parse():
     ap.add_argument("--groups", type=int, default=-1, help="sampler pipeline groups (-1: auto)")
     ap.add_argument("--no-graph", action="store_true", help="no hipGraph for the sampling step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline-leg", action="store_true",
+                    help="skip the second cpu_baseline iteration at the declared env cost (~25 s)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="ppo, 1 GPU: do not append the compact BASELINE config #3 / #5 objects "
+                         "(`configs.dqn`, `configs.r2d1`: each a `bench.py --config ...` child run "
+                         "after the headline measurement, ~1.5 min each)")
     ap.add_argument("--cpu-baseline-B", type=int, default=256,
                     help="B of the CPU sample (default: the full batch, one iteration ~20 s; "
                          "0: sized for ~15 s of CPU work)")
@@ -526,16 +539,75 @@ def main():
         out["roofline_gae_scaled"] = gae_scaled_roofline()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, args.cpu_baseline_B, dict(step_cost_us=args.env_cost_us))
+            if leg is not None and not args.no_cpu_baseline_leg:
+                # like-for-like at the declared emulator cost: the same reference
+                # iteration with the same busy wait per env step, beside value_env<cost>us
+                key = f"value_env{int(args.env_cost_leg_us)}us"
+                cb = cpu_baseline(T, args.cpu_baseline_B, dict(step_cost_us=args.env_cost_leg_us))
+                out["cpu_baseline_env%dus" % int(args.env_cost_leg_us)] = {
+                    k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "seconds")}
+                out["ratio_env%dus" % int(args.env_cost_leg_us)] = {
+                    "value": out[key] / cb["value"],
+                    "note": f"{key} / cpu_baseline_env{int(args.env_cost_leg_us)}us.value: both sides pay "
+                            f"{args.env_cost_leg_us:.0f} us of host CPU per env step (here spread over "
+                            f"{workers} env worker processes, there inside the reference's SerialSampler "
+                            "process, which is what north_star names as the baseline)"}
+                out["ratio_env0us"] = {"value": out["value"] / out["cpu_baseline"]["value"],
+                                       "note": "value / cpu_baseline.value (zero-cost synthetic env)"}
             # the isolated hot-path functions, HIP kernel beside the CPU restatement
             # on the same synthetic inputs (also yields the replay-kernel HBM rooflines)
             fn = isolated_functions(T, B)
             out["roofline_replay"] = fn.pop("roofline_replay")
             out["cpu_baseline"]["functions"] = fn
+        if world == 1 and not args.no_extra_configs and (T, B) == (128, 256):
+            out["configs"] = extra_configs(args)
         _canary_report(out)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extra_configs(args, timeout_s=600):
+    """BASELINE configs #3 (DQN) and #5 (R2D1) under the same clock as the headline (VERDICT r5 item
+    6): each is a child ``python bench.py --config <c>`` run AFTER the PPO measurement is over (its
+    sampler shut down, nothing of it timed any more), with that config's own default steps / warmup
+    and a full-size replay ring wrapped before its timed region; the child's JSON line is cut down
+    to the fields a reader needs.  A child that fails is reported as such -- it never takes the
+    headline line with it."""
+    import subprocess
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "updates_per_s", "updates",
+            "sampling_frac_of_step", "dtype", "roofline", "cpu_baseline", "last_loss")
+    res = {}
+    for cfg in ("dqn", "r2d1"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s,
+                               env=dict(os.environ))
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                res[cfg] = {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr[-600:]}
+                continue
+            doc = json.loads(lines[-1])
+            obj = {k: doc[k] for k in keep if k in doc}
+            obj["config"] = {k: doc["config"][k] for k in ("workload", "T", "B", "replay_frames",
+                                                          "ring_wrapped", "updates_per_iteration",
+                                                          "batch_size") if k in doc["config"]}
+            obj["ms_per_time_step"] = doc.get("sampler", {}).get("ms_per_time_step")
+            if isinstance(obj.get("cpu_baseline"), dict):
+                obj["cpu_baseline"] = {k: v for k, v in obj["cpu_baseline"].items() if k != "kind_note"}
+            obj["wall_s"] = round(time.perf_counter() - t0, 1)
+            res[cfg] = obj
+        except subprocess.TimeoutExpired:
+            res[cfg] = {"error": f"no line within {timeout_s} s"}
+        except (ValueError, KeyError, OSError) as e:
+            res[cfg] = {"error": f"{type(e).__name__}: {e}"}
+    res["note"] = ("child runs of `python bench.py --config dqn|r2d1` after the headline's timed region; "
+                   "full lines: the same commands on their own (profiles/r*_bench_{dqn,r2d1}.json)")
+    return res
 
 
 # ---------------------------------------------------------------------------------------------
@@ -649,24 +721,32 @@ def roofline_objects(ksum, rollout, T, n_groups):
     else:
         r = rollout[top]
         us_pipe = _rocprof_avg(rows, top)
+        # priced on the IN-PIPELINE average (what the timed region runs: the kernel queued behind the
+        # other pipeline groups' kernels) whenever a rocprofv3 summary of this command is committed;
+        # the isolated graph-replay figure of this run is the side field
+        us = us_pipe or r["us_per_launch"]
+        tf = r["alg_flops"] / us * 1e-6
         out["roofline"] = {
             "kernel": top + " (rollout group-step: frame-stack rebuild + conv1 + conv2 of "
                             f"{rollout['Bg']} environments per launch, f32 MFMA)"
             if top == "sample_convs_kernel" else top,
-            "bound": "mfma", "achieved": r["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": r["frac_f32_mfma_peak"], "frac_hbm": r["frac_hbm_peak"],
-            "avg_us": r["us_per_launch"],
-            "avg_us_source": "live, isolated: " + rollout["how"] + " (a captured graph node cannot carry "
-                             "its own events; in-pipeline average of the rocprofv3 trace of this "
-                             "command: avg_us_in_pipeline)",
-            "avg_us_in_pipeline": us_pipe, "avg_us_in_pipeline_source": csv_path,
-            "frac_in_pipeline": (r["alg_flops"] / us_pipe * 1e-6 / F32_MFMA_PEAK_TFLOPS
-                                 if us_pipe else None),
+            "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / F32_MFMA_PEAK_TFLOPS,
+            "frac_hbm": r["alg_bytes"] / us * 1e-3 / HBM_PEAK_GBPS,
+            "avg_us": us,
+            "avg_us_source": (f"in-pipeline average of the committed rocprofv3 --kernel-trace --stats "
+                              f"summary of this command ({csv_path}): a captured graph node cannot "
+                              "carry its own HIP events" if us_pipe else
+                              "live, isolated (no rocprofv3 summary of this command is committed): "
+                              + rollout["how"]),
+            "avg_us_isolated": r["us_per_launch"], "frac_isolated": r["frac_f32_mfma_peak"],
+            "avg_us_isolated_source": "live in this run: " + rollout["how"],
             "launches_per_iteration": n_roll, "alg_flops_per_launch": r["alg_flops"],
             "alg_bytes_per_launch": r["alg_bytes"], "traffic": r.get("traffic"),
+            "traffic_over_alg": (round(r["traffic"] / r["alg_bytes"], 3) if r.get("traffic") else None),
             "traffic_source": r.get("traffic_source"),
             "note": "latency-class launch (64 environments): the empty-launch floor is "
-                    f"{rollout['empty_launch_us']} us of its {r['us_per_launch']} us"}
+                    f"{rollout['empty_launch_us']} us; alone it runs {r['us_per_launch']} us"}
     out["roofline"]["share_of_iteration_kernel_time"] = totals[top] / max(sum(totals.values()), 1e-9)
     out["roofline"]["selection"] = ("largest total kernel time per iteration; per-launch averages for the "
                                     "ranking from " + (csv_path or "this run's live timings"))
