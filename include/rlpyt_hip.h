@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 7
+#define RLPYT_HIP_ABI_VERSION 8
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -714,6 +714,20 @@ int rlpyt_clip_adam_step_dev_f32(const rlpyt_adam_tensor* tensors_host, int n_te
                                  int64_t step, double max_norm, void* workspace,
                                  float* grad_norm_out, const float* hyper_dev /*nullable*/,
                                  int64_t* tick_ctr /*nullable*/, rlpyt_stream_t stream);
+/* rlpyt_clip_adam_step_dev_f32 that ALSO keeps a transposed copy of one parameter current: tensor
+ * `mirror_index` of the table is a row-major [mirror_rows, mirror_cols] matrix (both multiples of 32,
+ * 16-byte aligned) and `mirror_pt` [mirror_cols, mirror_rows] receives its new values transposed, from
+ * the launch that writes them (32 x 32 tiles through LDS).  For the update trunk's weight W of
+ * rlpyt/models/mlp.py:24-31: its input-gradient GEMM g W reads W^T (rlpyt_gemm_nt_f32 on the
+ * transposed operand), which was a 7 MB transposing copy per minibatch.  mirror_index < 0: no mirror
+ * (= rlpyt_clip_adam_step_dev_f32). */
+int rlpyt_clip_adam_step_mirror_f32(const rlpyt_adam_tensor* tensors_host, int n_tensors, double lr,
+                                    double beta1, double beta2, double eps, double weight_decay,
+                                    int64_t step, double max_norm, void* workspace,
+                                    float* grad_norm_out, const float* hyper_dev /*nullable*/,
+                                    int64_t* tick_ctr /*nullable*/, int mirror_index,
+                                    float* mirror_pt /*nullable*/, int64_t mirror_rows,
+                                    int64_t mirror_cols, rlpyt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class CopyDesc(ctypes.Structure):
@@ -170,6 +170,9 @@ _SIGNATURES = {
                                          c_int64, c_double, _p, _p, _p]),
     "rlpyt_clip_adam_step_dev_f32": (c_int, [_p, c_int, c_double, c_double, c_double, c_double,
                                              c_double, c_int64, c_double, _p, _p, _p, _p, _p]),
+    "rlpyt_clip_adam_step_mirror_f32": (c_int, [_p, c_int, c_double, c_double, c_double, c_double,
+                                                c_double, c_int64, c_double, _p, _p, _p, _p, c_int, _p,
+                                                c_int64, c_int64, _p]),
     "rlpyt_update_tick": (c_int, [_p, _p, c_int, c_int, _p, _p, _p, c_int64, _p, _p]),
     "rlpyt_sumtree_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_double,
                                      c_int, c_int]),

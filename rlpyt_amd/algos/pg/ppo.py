@@ -71,6 +71,14 @@ class PPO(PolicyGradientAlgo):
         batch_size = B if recurrent else T * B
         mb_size = batch_size // self.minibatches
         stats = []
+        # index mode: the loss kernel and the optimizer write their scalars straight into one table
+        # row per update (loss, pi_loss, value_loss, entropy, perplexity | gradNorm) -- no stack / cat
+        # launch per minibatch, and the backward pass is seeded with a standing 1
+        table = seed = None
+        if fused_idx and valid is None and hasattr(self.optimizer, "clip_and_step"):
+            table = torch.empty((self.epochs * self.minibatches, 6), dtype=torch.float32, device=dev)
+            seed = self._backward_seed(dev)
+        n_rows = 0
         # [T,B] fields the gather kernel can slice need contiguous storage; prev_action /
         # prev_reward are [:-1] views of [T+1,B] arrays (contiguous as [T,B] blocks).
         for _ in range(self.epochs):
@@ -99,9 +107,19 @@ class PPO(PolicyGradientAlgo):
                     self.update_counter += 1
                     continue
                 mb_obs = self.agent.gather_observation(agent_inputs.observation, idx_dev)
-                if fused_idx and valid is None:
+                if table is not None:
                     # index mode: the conv kernels and the head+loss kernel read the [T,B] batch
                     # arrays at (idx % T, idx // T) themselves -- no gather launch at all
+                    row = table[n_rows]
+                    loss, _ = self.loss(AgentInputs(mb_obs, None, None), action, return_,
+                                        advantage, None, old_prob, flat_idx=idx_dev,
+                                        unit_grad=True, scalars_out=row[:5])
+                    torch.autograd.backward(loss, grad_tensors=seed)
+                    self.optimizer.clip_and_step(self.clip_grad_norm, norm_out=row[5:])
+                    n_rows += 1
+                    self.update_counter += 1
+                    continue
+                if fused_idx and valid is None:
                     loss, scalars = self.loss(AgentInputs(mb_obs, None, None), action, return_,
                                               advantage, None, old_prob, flat_idx=idx_dev,
                                               unit_grad=True)      # loss.backward() right below
@@ -128,12 +146,22 @@ class PPO(PolicyGradientAlgo):
         if self.linear_lr_schedule:
             self.lr_scheduler.step()
             self.ratio_clip = self._ratio_clip * (self.n_itr - itr) / self.n_itr
-        host = self.diagnostics_to_host(stats)
+        if table is not None:
+            host = [[r[0], r[5], r[3], r[4]] for r in table[:n_rows].cpu().tolist()]
+        else:
+            host = self.diagnostics_to_host(stats)
         opt_info = OptInfo(*([row[k] for row in host] for k in range(4)))
         return opt_info
 
+    def _backward_seed(self, dev):
+        """A standing scalar 1 on the device: ``loss.backward()`` would fill a fresh one per minibatch."""
+        one = getattr(self, "_seed_one", None)
+        if one is None or one.device != dev:
+            one = self._seed_one = torch.ones((), dtype=torch.float32, device=dev)
+        return one
+
     def loss(self, agent_inputs, action, return_, advantage, valid, old_prob,
-             init_rnn_state=None, flat_idx=None, unit_grad=False):
+             init_rnn_state=None, flat_idx=None, unit_grad=False, scalars_out=None):
         """Fused PPO loss on a minibatch (already gathered, all in HBM).  Returns
         ``(loss, scalars)`` with scalars = [loss, pi_loss, value_loss, entropy, perplexity].
         ``flat_idx``: the loss inputs are whole ``[T,B,...]`` arrays and sample m is row
@@ -149,8 +177,9 @@ class PPO(PolicyGradientAlgo):
             return ops.ppo_head_loss(h, pi_m.weight, pi_m.bias, v_m.weight, v_m.bias, old_prob,
                                      action, advantage, return_, valid, self.ratio_clip,
                                      self.value_loss_coeff, self.entropy_loss_coeff,
-                                     flat_idx=flat_idx, trunk_bias=tb, unit_grad=unit_grad)
-        assert flat_idx is None, "index-mode loss needs the fused head+loss kernel"
+                                     flat_idx=flat_idx, trunk_bias=tb, unit_grad=unit_grad,
+                                     scalars_out=scalars_out)
+        assert flat_idx is None and scalars_out is None, "index-mode loss needs the fused head+loss kernel"
         if init_rnn_state is not None:
             init_rnn_state = buffer_method(init_rnn_state, "transpose", 0, 1)
             init_rnn_state = buffer_method(init_rnn_state, "contiguous")

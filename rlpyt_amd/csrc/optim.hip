@@ -22,6 +22,12 @@ namespace {
 struct AdamTable {
   rlpyt_adam_tensor t[RLPYT_ADAM_MAX_TENSORS];
   int n;
+  // optional transposed mirror of ONE [rows, cols] tensor (the update trunk's weight: its input
+  // gradient GEMM reads W^T, ops._LinearNoBias): tensor `mirror_k` is walked in 32 x 32 tiles and
+  // every tile is also written, through LDS, to mirror_pt[cols, rows] -- the new W^T comes out of the
+  // launch that makes the new W instead of a 7 MB transposing copy per minibatch.  mirror_k < 0: none.
+  int mirror_k, mirror_rows, mirror_cols;
+  float* mirror_pt;
 };
 
 constexpr int kOptGrid = 512, kOptBlock = 256;
@@ -89,7 +95,41 @@ __global__ __launch_bounds__(kOptBlock) void clip_adam_apply_kernel(
     const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
     p -= lr_over_bc1 * (m / denom);
   };
+  if (tab.mirror_k >= 0) {
+    // 32 x 32 tiles of the mirrored tensor: thread = (row tid >> 3, float4 tid & 7); 8 threads read /
+    // write 128 contiguous bytes of a row of W, and after the exchange of a row of W^T
+    __shared__ float tile[32][33];
+    const rlpyt_adam_tensor t = tab.t[tab.mirror_k];
+    const int R = tab.mirror_rows, C = tab.mirror_cols;
+    const int tiles_c = C >> 5, n_tiles = (R >> 5) * tiles_c;
+    const int tr = threadIdx.x >> 3, tc = threadIdx.x & 7;
+    for (int tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+      const int r0 = (tile_id / tiles_c) << 5, c0 = (tile_id % tiles_c) << 5;
+      const int64_t e = (int64_t)(r0 + tr) * C + c0 + 4 * tc;
+      const float4 g = *reinterpret_cast<const float4*>(t.g + e);
+      float4 p = *reinterpret_cast<const float4*>(t.p + e);
+      float4 m = *reinterpret_cast<const float4*>(t.m + e);
+      float4 v = *reinterpret_cast<const float4*>(t.v + e);
+      upd(g.x, p.x, m.x, v.x);
+      upd(g.y, p.y, m.y, v.y);
+      upd(g.z, p.z, m.z, v.z);
+      upd(g.w, p.w, m.w, v.w);
+      *reinterpret_cast<float4*>(t.p + e) = p;
+      *reinterpret_cast<float4*>(t.m + e) = m;
+      *reinterpret_cast<float4*>(t.v + e) = v;
+      __syncthreads();                       // (the previous tile's transposed reads are done)
+      tile[tr][4 * tc + 0] = p.x;
+      tile[tr][4 * tc + 1] = p.y;
+      tile[tr][4 * tc + 2] = p.z;
+      tile[tr][4 * tc + 3] = p.w;
+      __syncthreads();
+      const float4 q = {tile[4 * tc + 0][tr], tile[4 * tc + 1][tr], tile[4 * tc + 2][tr],
+                        tile[4 * tc + 3][tr]};
+      *reinterpret_cast<float4*>(tab.mirror_pt + (int64_t)(c0 + tr) * R + r0 + 4 * tc) = q;
+    }
+  }
   for (int k = 0; k < tab.n; ++k) {
+    if (k == tab.mirror_k) continue;
     const rlpyt_adam_tensor t = tab.t[k];
     const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) |
                        reinterpret_cast<uintptr_t>(t.m) | reinterpret_cast<uintptr_t>(t.v)) & 15) == 0;
@@ -176,6 +216,18 @@ extern "C" int rlpyt_clip_adam_step_dev_f32(const rlpyt_adam_tensor* tensors_hos
                                             void* workspace, float* grad_norm_out,
                                             const float* hyper_dev, int64_t* tick_ctr,
                                             rlpyt_stream_t stream) {
+  return rlpyt_clip_adam_step_mirror_f32(tensors_host, n_tensors, lr, beta1, beta2, eps, weight_decay,
+                                         step, max_norm, workspace, grad_norm_out, hyper_dev, tick_ctr,
+                                         -1, nullptr, 0, 0, stream);
+}
+
+extern "C" int rlpyt_clip_adam_step_mirror_f32(const rlpyt_adam_tensor* tensors_host, int n_tensors,
+                                               double lr, double beta1, double beta2, double eps,
+                                               double weight_decay, int64_t step, double max_norm,
+                                               void* workspace, float* grad_norm_out,
+                                               const float* hyper_dev, int64_t* tick_ctr,
+                                               int mirror_index, float* mirror_pt, int64_t mirror_rows,
+                                               int64_t mirror_cols, rlpyt_stream_t stream) {
   RL_CHECK_ARG(tensors_host != nullptr && workspace != nullptr, RLPYT_EINVAL,
                "rlpyt_clip_adam_step_f32: null pointer");
   RL_CHECK_ARG(n_tensors > 0 && n_tensors <= RLPYT_ADAM_MAX_TENSORS, RLPYT_ESHAPE,
@@ -185,6 +237,29 @@ extern "C" int rlpyt_clip_adam_step_dev_f32(const rlpyt_adam_tensor* tensors_hos
                (long)step);
   AdamTable tab;
   tab.n = n_tensors;
+  tab.mirror_k = -1;
+  tab.mirror_rows = tab.mirror_cols = 0;
+  tab.mirror_pt = nullptr;
+  if (mirror_index >= 0) {
+    RL_CHECK_ARG(mirror_index < n_tensors && mirror_pt != nullptr, RLPYT_EINVAL,
+                 "rlpyt_clip_adam_step_mirror_f32: mirror_index %d outside the table or null mirror",
+                 mirror_index);
+    const rlpyt_adam_tensor& t = tensors_host[mirror_index];
+    RL_CHECK_ARG(mirror_rows > 0 && mirror_cols > 0 && mirror_rows % 32 == 0 && mirror_cols % 32 == 0 &&
+                     mirror_rows * mirror_cols == t.n && mirror_rows < (1 << 30) && mirror_cols < (1 << 30),
+                 RLPYT_ESHAPE, "rlpyt_clip_adam_step_mirror_f32: the mirrored tensor must be [rows, cols] "
+                 "with both multiples of 32 and rows * cols == n (rows=%ld cols=%ld n=%ld)",
+                 (long)mirror_rows, (long)mirror_cols, (long)t.n);
+    RL_CHECK_ARG(((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) |
+                   reinterpret_cast<uintptr_t>(t.m) | reinterpret_cast<uintptr_t>(t.v) |
+                   reinterpret_cast<uintptr_t>(mirror_pt)) & 15) == 0,
+                 RLPYT_ESHAPE, "rlpyt_clip_adam_step_mirror_f32: the mirrored tensor, its gradient / "
+                 "state and the mirror must be 16-byte aligned");
+    tab.mirror_k = mirror_index;
+    tab.mirror_rows = (int)mirror_rows;
+    tab.mirror_cols = (int)mirror_cols;
+    tab.mirror_pt = mirror_pt;
+  }
   int64_t total = 0;
   for (int k = 0; k < n_tensors; ++k) {
     const rlpyt_adam_tensor& t = tensors_host[k];

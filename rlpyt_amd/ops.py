@@ -210,7 +210,7 @@ class _PpoHeadLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid,
                 ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None, trunk_bias=None,
-                unit_grad=False):
+                unit_grad=False, scalars_out=None):
         _lib.require_gpu()
         ctx.unit_grad = bool(unit_grad)
         rc_dev = None
@@ -235,7 +235,12 @@ class _PpoHeadLoss(torch.autograd.Function):
         adv = _f32(advantage).reshape(-1)
         ret = _f32(return_).reshape(-1)
         val = None if valid is None else _f32(valid).reshape(-1)
-        out = torch.empty(5, dtype=torch.float32, device=hc.device)
+        if scalars_out is None:
+            out = torch.empty(5, dtype=torch.float32, device=hc.device)
+        else:      # the caller's diagnostics row (5 consecutive floats)
+            out = scalars_out
+            assert (out.dtype == torch.float32 and out.numel() == 5 and out.is_contiguous()
+                    and out.device == hc.device)
         gh = torch.empty_like(hc)
         gparams = torch.empty(A * K + K + A + 1 + (K if tb is not None else 0),
                               dtype=torch.float32, device=hc.device)
@@ -265,12 +270,12 @@ class _PpoHeadLoss(torch.autograd.Function):
         g_tb = None if tbs is None else gp[o + K + A + 1:].reshape(tbs)
         return (gh.reshape(hs), gp[:o].reshape(wps), gp[o + K:o + K + A].reshape(bps),
                 gp[o:o + K].reshape(wvs), gp[o + K + A:o + K + A + 1].reshape(bvs)) + \
-            (None,) * 9 + (g_tb, None)
+            (None,) * 9 + (g_tb, None, None)
 
 
 def ppo_head_loss(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_, valid,
                   ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx=None,
-                  trunk_bias=None, unit_grad=False):
+                  trunk_bias=None, unit_grad=False, scalars_out=None):
     """PPO.loss (rlpyt/algos/pg/ppo.py:117-154) with the policy / value heads of
     rlpyt/models/pg/atari_ff_model.py:56-58 fused in: takes the trunk output ``h [M, K]`` and the
     head parameters, returns ``(loss, scalars)`` like ``ppo_loss``; differentiable w.r.t. ``h``
@@ -282,10 +287,12 @@ def ppo_head_loss(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_,
     pre-activation and the bias: the Linear's bias add, the ReLU, its backward and the bias
     gradient reduction never launch).
     ``unit_grad=True``: a promise that backward is seeded with exactly 1 (``loss.backward()`` on the
-    returned loss): the gradients saved by the forward kernel are handed on as they are."""
+    returned loss): the gradients saved by the forward kernel are handed on as they are.
+    ``scalars_out``: 5 consecutive f32 of the caller (a row of its diagnostics table) that receive the
+    scalars instead of a fresh tensor."""
     return _PpoHeadLoss.apply(h, w_pi, b_pi, w_v, b_v, prob_old, action, advantage, return_,
                               valid, ratio_clip, value_loss_coeff, entropy_loss_coeff, flat_idx,
-                              trunk_bias, unit_grad)
+                              trunk_bias, unit_grad, scalars_out)
 
 
 class _A2cLoss(torch.autograd.Function):
@@ -697,6 +704,54 @@ def gemm_tn(a, b):
     return c
 
 
+class TransposedMirror:
+    """``W^T`` copies of weights whose input-gradient GEMM wants them transposed (``_LinearNoBias``),
+    kept current WITHOUT a per-minibatch transposing copy: ``get(W)`` returns the cached ``W^T`` while
+    ``W`` is unchanged since it was made (storage address + in-place version counter) and re-makes it
+    otherwise; an optimizer that writes the new ``W^T`` beside the new ``W`` in its own launch
+    (``ClipAdam``, ``rlpyt_clip_adam_step_mirror_f32``) asks ``buffer_for(W)`` for the destination and
+    calls ``written(W)`` once the parameter's version has been bumped.  Any other writer of ``W``
+    (``load_state_dict``, another optimizer, DDP's initial broadcast) changes the version: the next
+    ``get`` then falls back to the copy."""
+    _entries = {}          # id(W) -> [weakref(W), W^T, (data_ptr, version) the copy describes]
+
+    @classmethod
+    def _entry(cls, w):
+        import weakref
+        e = cls._entries.get(id(w))
+        if e is not None and e[0]() is w and e[1].device == w.device:
+            return e
+        if len(cls._entries) > 64:      # dead references of models long gone
+            cls._entries = {k: v for k, v in cls._entries.items() if v[0]() is not None}
+        e = [weakref.ref(w), torch.empty((w.shape[1], w.shape[0]), dtype=w.dtype, device=w.device), None]
+        cls._entries[id(w)] = e
+        return e
+
+    @classmethod
+    def get(cls, w):
+        e = cls._entry(w)
+        key = (w.data_ptr(), w._version)
+        if e[2] != key:
+            e[1].copy_(w.detach().t())
+            e[2] = key
+        return e[1]
+
+    @classmethod
+    def buffer_for(cls, w):
+        """The ``[cols, rows]`` buffer an optimizer may fill with the transposed NEW values of ``w``,
+        or None when nobody has asked for ``w``'s transpose (nothing to keep current)."""
+        e = cls._entries.get(id(w))
+        if e is None or e[0]() is not w or e[1].device != w.device:
+            return None
+        return e[1]
+
+    @classmethod
+    def written(cls, w):
+        e = cls._entries.get(id(w))
+        if e is not None and e[0]() is w:
+            e[2] = (w.data_ptr(), w._version)
+
+
 class _LinearNoBias(torch.autograd.Function):
     """``x @ W.T`` (torch.nn.functional.linear without bias) for the update-size trunk, all three
     GEMMs of forward + backward on the bf16 matrix pipe (rlpyt/models/mlp.py:24-31 under
@@ -714,8 +769,9 @@ class _LinearNoBias(torch.autograd.Function):
         g = g.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            # g W as g (W^T)^T on the same kernel; 7 MB transposed copy
-            gx = gemm_nt(g, weight.detach().t().contiguous(), region="gemm_nt_dgrad")
+            # g W as g (W^T)^T on the same kernel; W^T from the mirror the optimizer keeps current
+            # (a 7 MB transposing copy only when somebody else changed W)
+            gx = gemm_nt(g, TransposedMirror.get(weight), region="gemm_nt_dgrad")
         if ctx.needs_input_grad[1]:
             gw = gemm_tn(g, x)
         return gx, gw

@@ -74,6 +74,13 @@ class ClipAdam(torch.optim.Adam):
         self._keep = rows
         return self._norm
 
+    @staticmethod
+    def _to_out(norm, norm_out):
+        if norm_out is None:
+            return norm
+        norm_out.copy_(norm.reshape(norm_out.shape))
+        return norm_out
+
     def captured_ready(self):
         """True once ``launch_captured_step`` may be captured: fused path, every parameter has state
         (an eager update ran) on one common step count."""
@@ -112,16 +119,17 @@ class ClipAdam(torch.optim.Adam):
         self._opt_called = True
 
     @torch.no_grad()
-    def clip_and_step(self, max_norm):
+    def clip_and_step(self, max_norm, norm_out=None):
         """``clip_grad_norm_(params, max_norm)`` + ``step()``; returns the total gradient norm
         (device scalar tensor, before clipping) like ``clip_grad_norm_``.  ``max_norm`` None or
-        <= 0: no clipping."""
+        <= 0: no clipping.  ``norm_out``: a one-element f32 device tensor (e.g. a slot of the caller's
+        diagnostics table) that receives the norm instead of the optimizer's own scalar."""
         if not self.supports_fused():
             params = [p for g in self.param_groups for p in g["params"]]
             norm = (torch.nn.utils.clip_grad_norm_(params, max_norm) if max_norm
                     else torch.zeros((), device=params[0].device))
             self.step()
-            return norm
+            return self._to_out(norm, norm_out)
         _lib.require_gpu()
         dev = self.param_groups[0]["params"][0].device
         if self._ws is None or self._ws.device != dev:
@@ -154,7 +162,7 @@ class ClipAdam(torch.optim.Adam):
             norm = (torch.nn.utils.clip_grad_norm_(params, max_norm) if max_norm
                     else torch.zeros((), device=dev))
             self.step()
-            return norm
+            return self._to_out(norm, norm_out)
         step = (steps.pop() + 1) if steps else None
         for p in group["params"]:
             if p.grad is None:
@@ -166,22 +174,40 @@ class ClipAdam(torch.optim.Adam):
             st["step"] += 1
             rows.append((p, g, st["exp_avg"], st["exp_avg_sq"]))
         if not rows:
-            return self._norm.zero_()
+            return self._to_out(self._norm.zero_(), norm_out)
         assert len(rows) <= MAX_TENSORS, f"ClipAdam: {len(rows)} tensors > {MAX_TENSORS}"
         table = (AdamTensor * len(rows))()
+        # a parameter whose transpose somebody keeps (ops.TransposedMirror: the update trunk's weight,
+        # read transposed by its input-gradient GEMM) gets its new W^T from this launch
+        from .ops import TransposedMirror
+        mirror_k, mirror_t = -1, None
         for k, (p, g, m, v) in enumerate(rows):
             table[k] = AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+            if (mirror_t is None and p.dim() == 2 and p.shape[0] % 32 == 0 and p.shape[1] % 32 == 0
+                    and ((p.data_ptr() | g.data_ptr() | m.data_ptr() | v.data_ptr()) & 15) == 0):
+                mt = TransposedMirror.buffer_for(p)
+                if mt is not None:
+                    mirror_k, mirror_t = k, mt
         b1, b2 = group["betas"]
         lr = group["lr"]
-        check(lib.rlpyt_clip_adam_step_f32(
+        norm_dst = self._norm if norm_out is None else norm_out
+        check(lib.rlpyt_clip_adam_step_mirror_f32(
             ctypes.cast(table, ctypes.c_void_p), len(rows), float(lr), float(b1), float(b2),
             float(group["eps"]), float(group["weight_decay"]), step,
             float(max_norm) if max_norm else 0., ctypes.c_void_p(self._ws.data_ptr()),
-            ctypes.c_void_p(self._norm.data_ptr()),
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "rlpyt_clip_adam_step_f32")
+            ctypes.c_void_p(norm_dst.data_ptr()), None, None, mirror_k,
+            None if mirror_t is None else ctypes.c_void_p(mirror_t.data_ptr()),
+            rows[mirror_k][0].shape[0] if mirror_t is not None else 0,
+            rows[mirror_k][0].shape[1] if mirror_t is not None else 0,
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "rlpyt_clip_adam_step_mirror_f32")
         self._keep = rows          # the launch is asynchronous: keep the gradient tensors alive
         # the kernel wrote the parameters through raw pointers: tell autograd / every cache keyed
         # on ``Tensor._version`` (ops.LstmStep's concatenated weight buffer) that they changed
         torch.autograd.graph.increment_version([r[0] for r in rows])
+        if mirror_t is not None:
+            TransposedMirror.written(rows[mirror_k][0])
+        if norm_out is not None:
+            self._opt_called = True
+            return norm_out
         self._opt_called = True    # (torch's LR schedulers check that a step preceded theirs)
         return self._norm
