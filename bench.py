@@ -901,9 +901,10 @@ def rollout_step_roofline(Bg=64, T=128, B=256):
                      "traffic": None}
     out["chain_us_per_group_step"] = round(total, 2)
     # HBM traffic from the PMC passes over scripts/step_microbench.py (scripts/rollout_pmc.sh), newest
-    # committed file.  rollout_fc's weight rows are read as 64-byte runs: for that pattern the raw
-    # FETCH_SIZE already equals the bytes (7.1 MB = W once), the guide's x2 is for wide 16 B/lane
-    # streams -- it gets the raw figure, the other two the corrected one.
+    # committed file, (2 * FETCH_SIZE + WRITE_SIZE) * 1024 for all three kernels: the calibration probe of
+    # round 6 (scripts/debug/fetch_probe.hip, profiles/r6_fetch_calibration.json) reads FETCH_SIZE at
+    # exactly half the known bytes for EVERY read pattern of the path -- 16 B / lane streams, 4 B / lane
+    # streams and the 64-byte row runs of rollout_fc's weight read alike -- and WRITE_SIZE at the bytes.
     try:
         import glob
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rollout_pmc.json")))[-1]
@@ -912,9 +913,10 @@ def rollout_step_roofline(Bg=64, T=128, B=256):
         for name in rows:
             k = pmc.get("kernels", {}).get(name)
             if k:
-                raw = k.get("hbm_bytes_raw", int((k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024))
-                out[name]["traffic"] = raw if name == "rollout_fc_kernel" else k["hbm_bytes_corrected"]
-                out[name]["traffic_source"] = os.path.relpath(path, ROOT)
+                out[name]["traffic"] = k["hbm_bytes_corrected"]
+                out[name]["traffic_over_alg"] = round(k["hbm_bytes_corrected"] / out[name]["alg_bytes"], 3)
+                out[name]["traffic_source"] = (os.path.relpath(path, ROOT) + " (counter factors: "
+                                               "profiles/r6_fetch_calibration.json)")
     except (OSError, ValueError, IndexError):
         pass
     return out

@@ -1461,8 +1461,14 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
   __shared__ __attribute__((aligned(16))) float pad[PPIX * PS_F];      // 41,600 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
-  const int64_t b = blockIdx.x / SC_PARTS;
-  const int part = (int)(blockIdx.x % SC_PARTS);
+  // XCD-aware unit map (round 6): workgroups go round-robin over the 8 XCDs in launch order, so the four
+  // parts of an environment used to sit on four XCDs and the image rows two parts share (36 rows each of
+  // 104: 38 % overlap) were fetched once per L2.  Units numbered environment-major, XCD c takes units
+  // [c n/8, (c+1) n/8): the parts of one environment share one L2.
+  int unit = blockIdx.x;
+  if ((gridDim.x & 31) == 0) unit = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t b = unit / SC_PARTS;
+  const int part = unit % SC_PARTS;
   const int64_t t = *t_dev;
   if (reward_rows != nullptr && blockIdx.x == 0) {
     for (int i = tid; i < (int)(gridDim.x / SC_PARTS); i += SC_THREADS) {

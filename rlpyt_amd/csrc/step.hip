@@ -527,8 +527,23 @@ __global__ __launch_bounds__(256) void rollout_fc_kernel(const float* __restrict
                                                          int K) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * 64 + wave * 16;
-  const int ks = blockIdx.y;
+  // XCD-aware (column block, K slice) map (round 6): workgroups go round-robin over the 8 XCDs in
+  // launch order, so with (blockIdx.x, blockIdx.y) = (column block, slice) XCD c ran column block c of
+  // EVERY slice and each XCD's L2 fetched the whole x for itself (8 x 0.88 MB: PMC traffic 1.54 x the
+  // algorithmic bytes, profiles/r5_rollout_pmc.json with the calibrated x2 of r6_fetch_calibration.json).
+  // Here the units are numbered slice-major and XCD c takes units [c n/8, (c+1) n/8): the column blocks
+  // of one slice share their x slab through one L2.
+  int cb = blockIdx.x, ks = blockIdx.y;
+  {
+    const int total = gridDim.x * gridDim.y;
+    if ((total & 7) == 0) {
+      const int L = blockIdx.x + gridDim.x * blockIdx.y;
+      const int u = (L & 7) * (total >> 3) + (L >> 3);
+      ks = u / (int)gridDim.x;
+      cb = u - ks * (int)gridDim.x;
+    }
+  }
+  const int n0 = cb * 64 + wave * 16;
   const int k0 = ks * kRfcKc;
   const int kn = min(kRfcKc, K - k0);                 // multiple of 16, >= 16
   const int m0 = blockIdx.z * 64;
