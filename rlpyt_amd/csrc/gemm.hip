@@ -22,14 +22,34 @@
 // profiles/r5_ab_presplit_weight.jsonl, r5_gemm_bench_presplit_weight.json: three 8-byte loads per
 // thread and step instead of one 16-byte load.  The kernel is bound by its vector-memory requests,
 // not by the split VALU beside the MFMAs; removed.)
-#include <stdlib.h>
-
 #include <algorithm>
-
-#include "split_bf16.h"
+#include "common.h"
 
 namespace rlpyt {
 namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma32_bf16(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo_elem, float hi_elem) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {lo_elem, hi_elem};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// (x0, x1) -> three packed bf16 pieces, hi + mid + lo == x exactly (finite, no overflow)
+__device__ __forceinline__ void split3_rn(float x0, float x1, uint32_t& hi, uint32_t& mid,
+                                          uint32_t& lo) {
+  hi = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk_bf16(r0, r1);
+  lo = cvt_pk_bf16(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
+}
 
 // Debug build (-DRLPYT_TIMING): per-wave cycle totals of the phases of the K loop
 // (scripts/debug/phase_timing.py gemm_fwd | gemm_dgrad); compiled out of the product.
@@ -53,9 +73,6 @@ __device__ float g_timing_gemm[512 * 16 * 8];
 #define RL_TOUT()
 #endif
 
-#ifndef RLPYT_GEMM_EXP_DEFAULT
-#define RLPYT_GEMM_EXP_DEFAULT 0
-#endif
 constexpr int GT = 128;                  // column-tile edge (and row-tile edge of the small variant)
 constexpr int G_THREADS = 512;
 constexpr int G_BK = 16;                 // K per barrier step
@@ -68,11 +85,7 @@ constexpr int G_ROWB = 2 * G_BK + 16;    // bytes per (piece, row) of a K-step: 
 // (4 M outputs) is one 128 x 128 tile per CU.  For TM = 256 three padded LDS stages would need
 // 166 KB, so the B operand is stored unpadded (32 B per row) with its two 16-byte K halves swapped
 // in every other group of 4 rows -- conflict-free for the 8-lane groups of ds_read_b128 as well.
-// PAIR (round 6 experiment, VERDICT r5 item 1 "K-32 steps taking whole 128-byte lines"): the rows of
-// two consecutive K-16 steps are requested TOGETHER (four register sets, a pair every second step), so
-// the two 64-byte halves of a 128-byte line of a row are asked for back to back instead of one step
-// apart; the LDS pipeline stays at K-16 granularity.  DOT2: split3_dot (split_bf16.h).
-template <int TM, bool PAIR, bool DOT2>
+template <int TM>
 __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
     int K, int tiles_m, int tiles_n) {
@@ -135,15 +148,15 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
   {                                                                                            \
     _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
       uint32_t p_[3][2];                                                                       \
-      split3<DOT2>(ra[i][0], ra[i][1], p_[0][0], p_[1][0], p_[2][0]);                          \
-      split3<DOT2>(ra[i][2], ra[i][3], p_[0][1], p_[1][1], p_[2][1]);                          \
+      split3_rn(ra[i][0], ra[i][1], p_[0][0], p_[1][0], p_[2][0]);                             \
+      split3_rn(ra[i][2], ra[i][3], p_[0][1], p_[1][1], p_[2][1]);                             \
       uint8_t* d_ = lds + (st_) * SB + sdst_a[i];                                              \
       _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
         *reinterpret_cast<uint2*>(d_ + s_ * PB_A) = uint2{p_[s_][0], p_[s_][1]};               \
     }                                                                                          \
     uint32_t q_[3][2];                                                                         \
-    split3<DOT2>(rb[0], rb[1], q_[0][0], q_[1][0], q_[2][0]);                                  \
-    split3<DOT2>(rb[2], rb[3], q_[0][1], q_[1][1], q_[2][1]);                                  \
+    split3_rn(rb[0], rb[1], q_[0][0], q_[1][0], q_[2][0]);                                     \
+    split3_rn(rb[2], rb[3], q_[0][1], q_[1][1], q_[2][1]);                                     \
     uint8_t* e_ = lds + (st_) * SB + sdst_b;                                                   \
     _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                           \
       *reinterpret_cast<uint2*>(e_ + s_ * PB_B) = uint2{q_[s_][0], q_[s_][1]};                 \
@@ -192,13 +205,20 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
   // queue to drain (~40 % of every step, measured 190-200 us for the trunk shapes).
   const int nk = K / G_BK;
   uint4 af0[2][3], bf0[NJ][3], af1[2][3], bf1[NJ][3];
+  RLPYT_G_FETCH(ra0, rb0, 0)
+  if (nk > 1) RLPYT_G_FETCH(ra1, rb1, G_BK)
+  RLPYT_G_STAGE(ra0, rb0, 0)
+  if (nk > 2) RLPYT_G_FETCH(ra0, rb0, 2 * G_BK)
+  RLPYT_G_STAGE(ra1, rb1, 1)           // (nk == 1: stale registers into a stage nobody reads)
+  if (nk > 3) RLPYT_G_FETCH(ra1, rb1, 3 * G_BK)
+  __syncthreads();
+  RLPYT_G_FRAGS(af0, bf0, 0)
   int st_next = 1, st_write = 2;     // stage of step ks + 1 / of step ks + 2
   // one step: prefetch the next fragments, MFMAs on the current ones with the split of step
-  // ks + 2 in their gaps, then FETCH_ (the request of later steps into registers just consumed)
+  // ks + 2 in their gaps, then request step ks + 4 into the registers just consumed
   constexpr int NMMA = 12 * NJ;                          // MFMAs per step
-  constexpr int NSPLIT = DOT2 ? 14 : 22;                 // VALU of one float4's split
-  constexpr int NV = (NSPLIT * (NA + 1) + NMMA - 1) / NMMA;   // split VALU per MFMA gap
-#define RLPYT_G_STEP(afc_, bfc_, afn_, bfn_, ra, rb, FETCH_)                                   \
+  constexpr int NV = (22 * (NA + 1) + NMMA - 1) / NMMA;  // split VALU per MFMA gap: 4 / 3
+#define RLPYT_G_STEP(afc_, bfc_, afn_, bfn_, ra, rb, ks_)                                      \
   {                                                                                            \
     RL_T(3)                                                                                    \
     __syncthreads();   /* stage of step ks + 1 complete; stage of step ks + 2 free */          \
@@ -216,60 +236,19 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
     }                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                         \
     RL_T(2)                                                                                    \
-    FETCH_                                                                                     \
+    if ((ks_) + 4 < nk) RLPYT_G_FETCH(ra, rb, ((ks_) + 4) * G_BK)                              \
     st_next = st_next == 2 ? 0 : st_next + 1;                                                  \
     st_write = st_write == 2 ? 0 : st_write + 1;                                               \
   }
   int ks = 0;
-  if constexpr (!PAIR) {
-    // two register sets: the rows of step s are requested two steps before they are split
-    RLPYT_G_FETCH(ra0, rb0, 0)
-    if (nk > 1) RLPYT_G_FETCH(ra1, rb1, G_BK)
-    RLPYT_G_STAGE(ra0, rb0, 0)
-    if (nk > 2) RLPYT_G_FETCH(ra0, rb0, 2 * G_BK)
-    RLPYT_G_STAGE(ra1, rb1, 1)           // (nk == 1: stale registers into a stage nobody reads)
-    if (nk > 3) RLPYT_G_FETCH(ra1, rb1, 3 * G_BK)
-    __syncthreads();
-    RLPYT_G_FRAGS(af0, bf0, 0)
-    RL_T0()
+  RL_T0()
 #pragma unroll 1
-    for (; ks + 1 < nk; ks += 2) {
-      RLPYT_G_STEP(af0, bf0, af1, bf1, ra0, rb0, if (ks + 4 < nk) RLPYT_G_FETCH(ra0, rb0, (ks + 4) * G_BK))
-      RLPYT_G_STEP(af1, bf1, af0, bf0, ra1, rb1, if (ks + 5 < nk) RLPYT_G_FETCH(ra1, rb1, (ks + 5) * G_BK))
-    }
-    if (ks < nk) RLPYT_G_STEP(af0, bf0, af1, bf1, ra0, rb0, )
-    RL_TOUT()
-  } else {
-    // four register sets: the rows of step s live in set s % 4 and are requested as PAIRS (2p, 2p+1)
-    // after the second set of pair p - 2 has been split, i.e. two to three steps before their own split
-    f32x4 ra2[NA], ra3[NA], rb2, rb3;
-#define RLPYT_G_FETCH2(raa, rba, rab, rbb, s_)                                                 \
-  {                                                                                            \
-    if ((s_) < nk) RLPYT_G_FETCH(raa, rba, (s_) * G_BK)                                        \
-    if ((s_) + 1 < nk) RLPYT_G_FETCH(rab, rbb, ((s_) + 1) * G_BK)                              \
+  for (; ks + 1 < nk; ks += 2) {
+    RLPYT_G_STEP(af0, bf0, af1, bf1, ra0, rb0, ks)
+    RLPYT_G_STEP(af1, bf1, af0, bf0, ra1, rb1, ks + 1)
   }
-    RLPYT_G_FETCH2(ra0, rb0, ra1, rb1, 0)
-    RLPYT_G_FETCH2(ra2, rb2, ra3, rb3, 2)
-    RLPYT_G_STAGE(ra0, rb0, 0)
-    RLPYT_G_STAGE(ra1, rb1, 1)           // (nk == 1: stale registers into a stage nobody reads)
-    RLPYT_G_FETCH2(ra0, rb0, ra1, rb1, 4)
-    __syncthreads();
-    RLPYT_G_FRAGS(af0, bf0, 0)
-    RL_T0()
-#pragma unroll 1
-    for (; ks + 3 < nk; ks += 4) {
-      RLPYT_G_STEP(af0, bf0, af1, bf1, ra2, rb2, )
-      RLPYT_G_STEP(af1, bf1, af0, bf0, ra3, rb3, RLPYT_G_FETCH2(ra2, rb2, ra3, rb3, ks + 6))
-      RLPYT_G_STEP(af0, bf0, af1, bf1, ra0, rb0, )
-      RLPYT_G_STEP(af1, bf1, af0, bf0, ra1, rb1, RLPYT_G_FETCH2(ra0, rb0, ra1, rb1, ks + 8))
-    }
-    // up to three steps left: their rows sit in sets 2, 3, 0 (requested above); nothing more to fetch
-    if (ks < nk) RLPYT_G_STEP(af0, bf0, af1, bf1, ra2, rb2, )
-    if (ks + 1 < nk) RLPYT_G_STEP(af1, bf1, af0, bf0, ra3, rb3, )
-    if (ks + 2 < nk) RLPYT_G_STEP(af0, bf0, af1, bf1, ra0, rb0, )
-    RL_TOUT()
-#undef RLPYT_G_FETCH2
-  }
+  if (ks < nk) RLPYT_G_STEP(af0, bf0, af1, bf1, ra0, rb0, ks)
+  RL_TOUT()
 #undef RLPYT_G_STEP
 #undef RLPYT_G_MMA
 #undef RLPYT_G_TERM
@@ -295,14 +274,6 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
 
 using namespace rlpyt;
 
-// A/B switch of the round-6 GEMM experiments (read per call): RLPYT_GEMM_EXP = bit 0 PAIR, bit 1 DOT2.
-// Shared with gemm_tn.hip.
-int rlpyt_gemm_experiment_flags() {
-  const char* e = getenv("RLPYT_GEMM_EXP");
-  return e ? atoi(e) : RLPYT_GEMM_EXP_DEFAULT;
-}
-static int gemm_experiment() { return rlpyt_gemm_experiment_flags(); }
-
 #ifdef RLPYT_TIMING
 extern "C" int rlpyt_debug_timing_read_gemm(float* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timing_gemm), (size_t)n * sizeof(float));
@@ -320,27 +291,18 @@ extern "C" int rlpyt_gemm_nt_f32(const float* a, const float* b, float* c, int64
                RLPYT_ESHAPE, "rlpyt_gemm_nt_f32: a / b must be 16-byte aligned");
   const int tiles_n = (int)ceil_div(N, GT);
   hipStream_t s = (hipStream_t)stream;
-  const int exp = gemm_experiment();
-  const bool pair = exp & 1, dot2 = exp & 2;
   // 256-row tiles when they still fill the chip twice over (the trunk's input gradient: 32 x 27)
-  const bool big = ceil_div(M, 256) * tiles_n >= 512;
-  const int tiles_m = (int)ceil_div(M, big ? 256 : GT);
-  const int grid = 8 * ((tiles_m * tiles_n + 7) / 8);     // whole rounds over the 8 XCDs
-#define RLPYT_G_LAUNCH(TM_, P_, D_)                                                              \
-  RL_LAUNCH((gemm_nt_x6_kernel<TM_, P_, D_>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, \
-            (int)N, (int)K, tiles_m, tiles_n)
-  if (big) {
-    if (pair && dot2) RLPYT_G_LAUNCH(256, true, true);
-    else if (pair) RLPYT_G_LAUNCH(256, true, false);
-    else if (dot2) RLPYT_G_LAUNCH(256, false, true);
-    else RLPYT_G_LAUNCH(256, false, false);
+  if (ceil_div(M, 256) * tiles_n >= 512) {
+    const int tiles_m = (int)ceil_div(M, 256);
+    const int grid = 8 * ((tiles_m * tiles_n + 7) / 8);     // whole rounds over the 8 XCDs
+    RL_LAUNCH((gemm_nt_x6_kernel<256>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, (int)N,
+              (int)K, tiles_m, tiles_n);
   } else {
-    if (pair && dot2) RLPYT_G_LAUNCH(128, true, true);
-    else if (pair) RLPYT_G_LAUNCH(128, true, false);
-    else if (dot2) RLPYT_G_LAUNCH(128, false, true);
-    else RLPYT_G_LAUNCH(128, false, false);
+    const int tiles_m = (int)ceil_div(M, GT);
+    const int grid = 8 * ((tiles_m * tiles_n + 7) / 8);
+    RL_LAUNCH((gemm_nt_x6_kernel<128>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, (int)N,
+              (int)K, tiles_m, tiles_n);
   }
-#undef RLPYT_G_LAUNCH
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

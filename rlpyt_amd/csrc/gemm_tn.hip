@@ -59,7 +59,6 @@ constexpr int T_PB = T_BK * T_ROWB;        // 4,608
 constexpr int T_OB = 3 * T_PB;             // 13,824 per operand
 constexpr int T_SB = 2 * T_OB;             // 27,648 per stage
 
-template <bool DOT2>
 __global__ __launch_bounds__(P_THREADS, TX_OCC) void gemm_tn_x6_kernel(const float* __restrict__ A,
                                                                const float* __restrict__ B,
                                                                float* __restrict__ C, const PpShape sh) {
@@ -115,10 +114,10 @@ __global__ __launch_bounds__(P_THREADS, TX_OCC) void gemm_tn_x6_kernel(const flo
 #define TX_STAGE(ra, rb, st_)                                                       \
   {                                                                                 \
     uint32_t p_[3][2], q_[3][2];                                                    \
-    split3<DOT2>(ra[0], ra[1], p_[0][0], p_[1][0], p_[2][0]);                       \
-    split3<DOT2>(ra[2], ra[3], p_[0][1], p_[1][1], p_[2][1]);                       \
-    split3<DOT2>(rb[0], rb[1], q_[0][0], q_[1][0], q_[2][0]);                       \
-    split3<DOT2>(rb[2], rb[3], q_[0][1], q_[1][1], q_[2][1]);                       \
+    split3_rn(ra[0], ra[1], p_[0][0], p_[1][0], p_[2][0]);                          \
+    split3_rn(ra[2], ra[3], p_[0][1], p_[1][1], p_[2][1]);                          \
+    split3_rn(rb[0], rb[1], q_[0][0], q_[1][0], q_[2][0]);                          \
+    split3_rn(rb[2], rb[3], q_[0][1], q_[1][1], q_[2][1]);                          \
     uint8_t* d_ = lds + (st_) * T_SB + sdst;                                        \
     _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                              \
       *reinterpret_cast<uint2*>(d_ + s_ * T_PB) = uint2{p_[s_][0], p_[s_][1]};      \
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(P_THREADS, TX_OCC) void gemm_tn_x6_kernel(const flo
     TX_STAGE(ra, rb, st_write)                                                      \
     _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                             \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-      __builtin_amdgcn_sched_group_barrier(0x002, DOT2 ? 3 : 4, 0);                 \
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                            \
     }                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                              \
     if ((ks_) + 4 < nk) TX_FETCH(ra, rb, (ks_) + 4)                                 \
@@ -259,7 +258,6 @@ void tn_plan(PpShape& sh) {
 
 using namespace rlpyt;
 
-int rlpyt_gemm_experiment_flags();     // gemm.hip: RLPYT_GEMM_EXP (bit 1: dot2 split)
 
 static int pp_check(const char* fn, const float* a, const float* b, const float* c, int64_t M,
                     int64_t N, int64_t K) {
@@ -301,10 +299,8 @@ extern "C" int rlpyt_gemm_tn_f32(const float* a, const float* b, float* c, int64
                "rlpyt_gemm_tn_f32: M and N must be multiples of 4 (M=%ld N=%ld)", (long)M, (long)N);
   PpShape sh = pp_shape(M, N, K, M, N);
   hipStream_t s = (hipStream_t)stream;
-  const bool dot2 = rlpyt_gemm_experiment_flags() & 2;
   if (sh.nk < 64) {            // short contraction: one unit per tile, straight into c
-    if (dot2) RL_LAUNCH(gemm_tn_x6_kernel<true>, dim3(pp_grid(sh)), dim3(P_THREADS), 0, s, a, b, c, sh);
-    else RL_LAUNCH(gemm_tn_x6_kernel<false>, dim3(pp_grid(sh)), dim3(P_THREADS), 0, s, a, b, c, sh);
+    RL_LAUNCH(gemm_tn_x6_kernel, dim3(pp_grid(sh)), dim3(P_THREADS), 0, s, a, b, c, sh);
     RL_LAUNCH_CHECK();
     return RLPYT_OK;
   }
@@ -314,8 +310,7 @@ extern "C" int rlpyt_gemm_tn_f32(const float* a, const float* b, float* c, int64
   const int n_tiles = sh.tiles_m * sh.tiles_n;
   const int units = sh.full + (n_tiles - sh.full) * sh.sub;
   float* ws = static_cast<float*>(workspace);
-  if (dot2) RL_LAUNCH(gemm_tn_x6_kernel<true>, dim3(8 * units), dim3(P_THREADS), 0, s, a, b, ws, sh);
-  else RL_LAUNCH(gemm_tn_x6_kernel<false>, dim3(8 * units), dim3(P_THREADS), 0, s, a, b, ws, sh);
+  RL_LAUNCH(gemm_tn_x6_kernel, dim3(8 * units), dim3(P_THREADS), 0, s, a, b, ws, sh);
   RL_LAUNCH_CHECK();
   const int64_t n4 = M * N / 4;
   RL_LAUNCH(gemm_reduce_slots_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, s, ws, c, sh);

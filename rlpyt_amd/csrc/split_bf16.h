@@ -30,34 +30,6 @@ __device__ __forceinline__ void split3_rn(float x0, float x1, uint32_t& hi, uint
   lo = cvt_pk_bf16(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
 }
 
-// The same split with each residual formed by ONE instruction: v_dot2c_f32_bf16 computes
-// d += a.lo * b.lo + a.hi * b.hi on packed bf16 pairs, so with b = (-1, 0) / (0, -1) it subtracts the
-// low / high bf16 of a packed pair from an f32 -- 7 VALU per two floats instead of 11 (shift / mask +
-// subtract).  The subtrahend and the difference are exactly representable, so the result is the same
-// number whenever the instruction neither rounds its exact sum twice nor flushes it
-// (tests/test_split_gpu.py compares the pieces bit for bit on the device, edge cases included).
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float sub_bf16_lo(float x, uint32_t pk) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk),
-                                         __builtin_bit_cast(bf16x2_t, 0x0000bf80u), x, false);
-}
-__device__ __forceinline__ float sub_bf16_hi(float x, uint32_t pk) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk),
-                                         __builtin_bit_cast(bf16x2_t, 0xbf800000u), x, false);
-}
-__device__ __forceinline__ void split3_dot(float x0, float x1, uint32_t& hi, uint32_t& mid,
-                                           uint32_t& lo) {
-  hi = cvt_pk_bf16(x0, x1);
-  const float r0 = sub_bf16_lo(x0, hi), r1 = sub_bf16_hi(x1, hi);
-  mid = cvt_pk_bf16(r0, r1);
-  lo = cvt_pk_bf16(sub_bf16_lo(r0, mid), sub_bf16_hi(r1, mid));
-}
-template <bool DOT2>
-__device__ __forceinline__ void split3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-  if constexpr (DOT2) split3_dot(x0, x1, hi, mid, lo);
-  else split3_rn(x0, x1, hi, mid, lo);
-}
-
 // ds_read_b64_tr_b16, the LDS transpose read of gfx950: within a group of 16 lanes, lane s supplies
 // the address of four contiguous 16-bit elements = "key s >> 2, columns 4 (s & 3) .. + 3" of a
 // 4 x 16 block, and lane i receives column i of the block, keys 0..3 (scripts/debug/tr_probe.hip

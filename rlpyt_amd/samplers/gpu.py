@@ -105,6 +105,10 @@ class GpuSampler(BaseSampler):
                 n_groups = 4
         self.n_groups = max(1, min(int(n_groups), B))
 
+    def _split_min_workers(self):
+        """Fewest env workers for which ``split_workers`` gives every pipeline group its own set."""
+        return 2 * self.n_groups
+
     # ------------------------------------------------------------------------ initialize
     def initialize(self, agent, affinity=None, seed=None, bootstrap_value=False,
                    traj_info_kwargs=None, world_size=1, rank=0, worker_process=None):
@@ -161,8 +165,8 @@ class GpuSampler(BaseSampler):
         n_w = max(self.n_workers, 1)
         # fork-shared switch "the master uploads newest frames only" (set in _ensure_device)
         self._lazy_obs = mp.get_context("fork").RawValue(ctypes.c_bool, False)
-        self.split_workers = bool(self._split_workers and self.n_workers >= 2 * self.n_groups
-                                  and self.n_groups > 1)
+        self.split_workers = bool(self._split_workers and self.n_groups > 1
+                                  and self.n_workers >= self._split_min_workers())
         self.groups = []
         runners = [[] for _ in range(n_w)]       # [worker][group]
         for g in range(self.n_groups):
@@ -323,18 +327,10 @@ class GpuSampler(BaseSampler):
                 rn.begin_batch()
         dev.begin_batch()
         tp1 = time.perf_counter()
-        native = self._native_serve()
-        tail_done = False
-        if native is not None:
-            tail_done = native.serve(T, tm)       # (with captured tail graphs: the tail too)
-        else:
-            serve_python(dev, self.sync if par else None, self.runners[0], T, tm, completed)
+        tail_done = self._serve_batch(dev, par, T, tm, completed)
         tp2 = time.perf_counter()
         if not tail_done:
-            for G in self.groups:
-                if par:
-                    self.sync.master_wait_obs(G.idx)
-                dev.tail(G)
+            self._tail_batch(dev, par)
         dev.synchronize()
         # end of batch: null the prev action / reward the next batch starts from where the
         # env finished (action_server.py:63-68); ``done`` stays set as the carry flag.
@@ -354,6 +350,21 @@ class GpuSampler(BaseSampler):
         tm["tail_s"] += tp3 - tp2
         tm["post_s"] += tp4 - tp3
         return dev.samples, completed
+
+    def _serve_batch(self, dev, par, T, tm, completed):
+        """The T time steps of a batch (``samplers/serve.py``); True when the bootstrap tail ran too."""
+        native = self._native_serve()
+        if native is not None:
+            return native.serve(T, tm)            # (with captured tail graphs: the tail too)
+        serve_python(dev, self.sync if par else None, self.runners[0], T, tm, completed)
+        return False
+
+    def _tail_batch(self, dev, par):
+        """The pass on the observation after the last step (bootstrap value, end-of-batch rows)."""
+        for G in self.groups:
+            if par:
+                self.sync.master_wait_obs(G.idx)
+            dev.tail(G)
 
     def _collect_traj_infos(self):
         """Completed-trajectory statistics of this batch from the shared table (queue for

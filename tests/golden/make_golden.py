@@ -812,6 +812,77 @@ def gen_sampler():
     save("sampler", **out)
 
 
+def gen_sampler_alt():
+    """The reference's ALTERNATING GPU samplers (rlpyt/samplers/parallel/gpu/alternating_sampler.py with
+    AlternatingActionServer / NoOverlapAlternatingActionServer, action_server.py:123-363) on CPU over
+    this repo's synthetic env under the deterministic policy of ``gen_sampler``: two worker processes
+    = one per half, reset and wait-reset collectors; every field of every batch."""
+    import sampler_cases as C
+    from rlpyt.agents.base import AgentStep, BaseAgent
+    from rlpyt.samplers.parallel.gpu.alternating_sampler import (AlternatingSampler,
+                                                                 NoOverlapAlternatingSampler)
+    from rlpyt.samplers.parallel.gpu.collectors import GpuResetCollector, GpuWaitResetCollector
+    from rlpyt.utils.collections import namedarraytuple
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from rlpyt_amd.envs.synthetic import SyntheticPong
+    AgentInfo = C.bind_agent_info(namedarraytuple)
+
+    class DetAgent(BaseAgent):
+        def __init__(self):
+            super().__init__(ModelCls=None)
+
+        def initialize(self, env_spaces, share_memory=False, global_B=1, env_ranks=None):
+            self.n = env_spaces.action.n
+            self.env_spaces, self.share_memory = env_spaces, share_memory
+
+        def to_device(self, cuda_idx=None):
+            pass
+
+        def step(self, observation, prev_action, prev_reward):
+            a, v = C.det_policy(observation, prev_action, prev_reward, self.n)
+            return AgentStep(action=a, agent_info=AgentInfo(value=v))
+
+        def value(self, observation, prev_action, prev_reward):
+            return C.det_policy(observation, prev_action, prev_reward, self.n)[1] + 1
+
+        def sample_mode(self, itr):
+            pass
+
+        train_mode = eval_mode = sample_mode
+
+        def sync_shared_memory(self):
+            pass
+
+    out = {}
+    for tag, Cls in (("alt", AlternatingSampler), ("noalt", NoOverlapAlternatingSampler)):
+        for name, mode, T, n_batches in C.CASES:
+            Coll = GpuResetCollector if mode == "reset" else GpuWaitResetCollector
+            s = Cls(EnvCls=SyntheticPong, env_kwargs=C.ENV_KWARGS, batch_T=T, batch_B=C.B,
+                    CollectorCls=Coll, max_decorrelation_steps=0)
+            s.initialize(DetAgent(), affinity=dict(workers_cpus=list(range(C.N_WORKERS)), cuda_idx=None,
+                                                   set_affinity=False, alternating=True),
+                         seed=C.SEED, bootstrap_value=True, traj_info_kwargs=dict(discount=0.9))
+            for itr in range(n_batches):
+                smp, infos = s.obtain_samples(itr)
+                k = f"{tag}_{name}{itr}_"
+                out.update({
+                    k + "obs_crc": C.obs_crc(smp.env.observation.numpy()),
+                    k + "reward": smp.env.reward.numpy().copy(),
+                    k + "prev_reward": smp.env.prev_reward.numpy().copy(),
+                    k + "done": smp.env.done.numpy().copy(),
+                    k + "game_score": smp.env.env_info.game_score.numpy().copy(),
+                    k + "traj_done": smp.env.env_info.traj_done.numpy().copy(),
+                    k + "action": smp.agent.action.numpy().copy(),
+                    k + "prev_action": smp.agent.prev_action.numpy().copy(),
+                    k + "value": smp.agent.agent_info.value.numpy().copy(),
+                    k + "bootstrap_value": smp.agent.bootstrap_value.numpy().copy(),
+                    k + "traj_fields": np.array(sorted(
+                        (ti["Length"], ti["Return"], ti["NonzeroRewards"], ti["DiscountedReturn"])
+                        for ti in infos), dtype=np.float64).reshape(-1, 4)})
+            s.shutdown()
+    save("sampler_alt", **out)
+
+
 def gen_sampler_ff():
     """The reference GpuSampler (GpuResetCollector workers + ActionServer.serve_actions,
     rlpyt/samplers/parallel/gpu/*.py) driving the reference's OWN AtariFfAgent
@@ -1290,7 +1361,7 @@ if __name__ == "__main__":
                 categorical=gen_categorical,
                 sumtree=gen_sumtree, sumtree_unique=gen_sumtree_unique, frames=gen_frames, replay=gen_replay,
                 seq_replay=gen_seq_replay, r2d1_rms=gen_r2d1_rms, catdqn=gen_catdqn,
-                models=gen_models, sampler=gen_sampler, sampler_ff=gen_sampler_ff, algos=gen_algos, algos_big=gen_algos_big,
+                models=gen_models, sampler=gen_sampler, sampler_alt=gen_sampler_alt, sampler_ff=gen_sampler_ff, algos=gen_algos, algos_big=gen_algos_big,
                 dqn_iterations=gen_dqn_iterations,
                 r2d1_iterations=gen_r2d1_iterations, agents=gen_agents,
                 runner_keys=gen_runner_keys, protocol=gen_protocol)

@@ -17,6 +17,10 @@ _PRI_REPLAY = _REPLAY + ["update_batch_priorities", "set_beta"]
 PROTOCOL = {
     # samplers (runners/minibatch_rl.py:74-96,257,329,133)
     "rlpyt.samplers.parallel.gpu.sampler.GpuSampler": ("rlpyt_amd.samplers.gpu.GpuSampler", _SAMPLER),
+    "rlpyt.samplers.parallel.gpu.alternating_sampler.AlternatingSampler":
+        ("rlpyt_amd.samplers.alternating.AlternatingSampler", _SAMPLER),
+    "rlpyt.samplers.parallel.gpu.alternating_sampler.NoOverlapAlternatingSampler":
+        ("rlpyt_amd.samplers.alternating.NoOverlapAlternatingSampler", _SAMPLER),
     # algorithms (minibatch_rl.py:88-96,259,144,78,124)
     "rlpyt.algos.pg.ppo.PPO": ("rlpyt_amd.algos.pg.ppo.PPO", _ALGO),
     "rlpyt.algos.pg.a2c.A2C": ("rlpyt_amd.algos.pg.a2c.A2C", _ALGO),
