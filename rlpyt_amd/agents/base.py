@@ -189,6 +189,75 @@ class BaseAgent:
     def toggle_alt(self):
         pass
 
+    # ---- asynchronous sampling / optimisation (rlpyt/agents/base.py:138-200: async_cpu,
+    # send_shared_memory, recv_shared_memory) -------------------------------------------------------
+    # The reference keeps a second copy of the model in OS shared memory: the optimizer process
+    # publishes into it under a lock, the sampler process copies out of it between batches.  Sampler
+    # side and optimizer side are threads of one process here and all three copies live in HBM: the
+    # optimizer's model, the SAMPLER TWIN's model (the agent object the sampler steps: this agent's
+    # settings, its own parameters, frozen during a batch) and the mailbox between them.  The copies
+    # are device-to-device launches on the calling thread's stream, ordered across threads / streams
+    # by a lock and two events.
+    def async_twin(self):
+        """The sampler-side agent of an asynchronous run (call after ``to_device``)."""
+        import copy
+        import threading
+        twin = copy.copy(self)
+        twin.model = copy.deepcopy(self.sampling_model)
+        twin.shared_model = None
+        twin._mode = None
+        twin._async_twin_reset()
+        params = [p.detach() for p in self.sampling_model.parameters()]
+        bufs = [b.detach() for b in self.sampling_model.buffers()]
+        self._mailbox = twin._mailbox = dict(
+            lock=threading.Lock(), version=0, written=None, read=None,
+            tensors=[t.clone() for t in params + bufs])
+        twin._mail_seen = 0
+        return twin
+
+    def _async_twin_reset(self):
+        """Per-instance sampling state a twin must not share with its original."""
+
+    def _mail_tensors(self):
+        m = self.sampling_model
+        return [p.detach() for p in m.parameters()] + [b.detach() for b in m.buffers()]
+
+    @torch.no_grad()
+    def send_shared_memory(self):
+        """Optimizer side: publish the current parameters (after an ``optimize_agent`` call)."""
+        box = getattr(self, "_mailbox", None)
+        if box is None:
+            return self.sync_shared_memory()
+        with box["lock"]:
+            cuda = self.device.type == "cuda"
+            if cuda and box["read"] is not None:          # the sampler's last copy-out is done first
+                torch.cuda.current_stream(self.device).wait_event(box["read"])
+            torch._foreach_copy_(box["tensors"], self._mail_tensors())
+            box["version"] += 1
+            if cuda:
+                box["written"] = torch.cuda.Event()
+                box["written"].record(torch.cuda.current_stream(self.device))
+
+    @torch.no_grad()
+    def recv_shared_memory(self):
+        """Sampler side: take over newly published parameters (between batches); True if there were."""
+        box = getattr(self, "_mailbox", None)
+        if box is None:
+            return False
+        with box["lock"]:
+            if box["version"] == getattr(self, "_mail_seen", 0):
+                return False
+            cuda = self.device.type == "cuda"
+            if cuda and box["written"] is not None:
+                torch.cuda.current_stream(self.device).wait_event(box["written"])
+            mine = self._mail_tensors()
+            torch._foreach_copy_(mine, box["tensors"])      # (bumps the parameters' version counters)
+            self._mail_seen = box["version"]
+            if cuda:
+                box["read"] = torch.cuda.Event()
+                box["read"].record(torch.cuda.current_stream(self.device))
+        return True
+
     def gather_observation(self, observation, flat_idx):
         """Minibatch rows ``idx -> (idx % T, idx // T)`` of a [T,B,...] observation batch
         (rlpyt/algos/pg/ppo.py:94-100); image agents override this to deliver the rows
@@ -246,6 +315,9 @@ class RecurrentAgentMixin:
         if cur is not None:
             for x in buffer_leaves(cur):
                 x[:, idx] = 0
+
+    def _async_twin_reset(self):
+        self._rnn_states, self._stash, self._slot = {}, None, 0
 
     def reset_where(self, mask):
         """Zero the state of the environments where ``mask`` ([B_g] bool, same device)."""

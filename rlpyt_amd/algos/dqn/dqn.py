@@ -49,7 +49,37 @@ class DQN(RlAlgorithm):
     # ------------------------------------------------------------------ set-up
     def initialize(self, agent, n_itr, batch_spec, mid_batch_reset, examples, world_size=1,
                    rank=0):
-        self.agent, self.n_itr, self.rank, self.world_size = agent, n_itr, rank, world_size
+        self._setup(agent, n_itr, batch_spec, mid_batch_reset, examples, world_size, async_=False)
+        self.optim_initialize(rank)
+
+    def async_initialize(self, agent, sampler_n_itr, batch_spec, mid_batch_reset, examples,
+                         world_size=1):
+        """Asynchronous runners only (rlpyt/algos/dqn/dqn.py:99-115): builds the replay buffer in its
+        asynchronous form (``replays/async_.py``: appends from the sampler side while the optimizer
+        side draws batches) and returns it; the optimizer comes later (``optim_initialize``).  The
+        number of updates per ``optimize_agent`` call is ``updates_per_sync`` there (the replay ratio
+        is enforced by the runner's throttle instead)."""
+        self._setup(agent, sampler_n_itr, batch_spec, mid_batch_reset, examples, world_size,
+                    async_=True)
+        self.updates_per_optimize = self.updates_per_sync
+        return self.replay_buffer
+
+    def optim_initialize(self, rank=0):
+        """Called by ``initialize`` or, in asynchronous mode, by the runner once the sampler side is up
+        (dqn.py:117-125)."""
+        self.rank = rank
+        self.optimizer = self.make_optimizer(self.agent.parameters(), self.OptimCls,
+                                             self.learning_rate, self.optim_kwargs)
+        if self.initial_optim_state_dict is not None:
+            self.optimizer.load_state_dict(self.initial_optim_state_dict)
+
+    def samples_to_buffer(self, samples):
+        """Sampler batch -> replay record (dqn.py:192-200); what a memory copier appends."""
+        return self.feed.from_samples(samples)
+
+    def _setup(self, agent, n_itr, batch_spec, mid_batch_reset, examples, world_size, async_):
+        self.agent, self.n_itr, self.world_size = agent, n_itr, world_size
+        self.rank, self.async_ = 0, bool(async_)
         self.mid_batch_reset = mid_batch_reset
         self.sampler_bs = batch_spec.size
         plan = self.plan = plan_updates(batch_spec.size, self.batch_size, self.replay_ratio,
@@ -61,10 +91,6 @@ class DQN(RlAlgorithm):
         agent.set_epsilon_itr_min_max(plan.first_learn_itr, plan.eps_last_itr)
         self.feed = self.make_feed()
         self.replay_buffer = self.make_replay(self.feed.from_examples(examples), batch_spec)
-        self.optimizer = self.make_optimizer(agent.parameters(), self.OptimCls, self.learning_rate,
-                                             self.optim_kwargs)
-        if self.initial_optim_state_dict is not None:
-            self.optimizer.load_state_dict(self.initial_optim_state_dict)
         self.beta = (BetaAnneal(self.pri_beta_init, self.pri_beta_final, plan.first_learn_itr,
                                 plan.beta_last_itr) if self.prioritized_replay else None)
 
@@ -83,8 +109,10 @@ class DQN(RlAlgorithm):
     def make_replay(self, example, batch_spec):
         Cls = self.ReplayBufferCls
         if Cls is None:
-            Cls = replay_class(frames=True, sequence=self.SEQUENCE_REPLAY,
-                               prioritized=self.prioritized_replay)
+            pick = replay_class
+            if getattr(self, "async_", False):
+                from ...replays.async_ import async_replay_class as pick
+            Cls = pick(frames=True, sequence=self.SEQUENCE_REPLAY, prioritized=self.prioritized_replay)
         else:     # the reference's injection hook (dqn.py:56,151-156)
             logger.log(f"DQN: replay buffer class supplied by the caller ({Cls.__name__}); its "
                        "constructor gets the keywords of the built-in choice.")
@@ -93,7 +121,7 @@ class DQN(RlAlgorithm):
     # ------------------------------------------------------------------ per iteration
     def ingest(self, samples):
         """New sampler batch -> replay ring."""
-        self.replay_buffer.append_samples(self.feed.from_samples(samples))
+        self.replay_buffer.append_samples(self.samples_to_buffer(samples))
 
     def optimize_agent(self, itr, samples=None, sampler_itr=None):
         itr = itr if sampler_itr is None else sampler_itr

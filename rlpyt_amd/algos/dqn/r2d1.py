@@ -63,11 +63,15 @@ class R2D1(DQN):
                       input_priority_shift=self.input_priority_shift)
         return kw
 
-    def ingest(self, samples):
+    def samples_to_buffer(self, samples):
+        """Sampler batch -> replay record, with input priorities when asked for (r2d1.py:167-179)."""
         record = self.feed.from_samples(samples)
         if self.input_priorities:      # fresh sequences enter the tree with their own TD errors
             record = Prioritised(priorities=self.input_priorities_of(samples), samples=record)
-        self.replay_buffer.append_samples(record)
+        return record
+
+    def ingest(self, samples):
+        self.replay_buffer.append_samples(self.samples_to_buffer(samples))
 
     def one_update(self, log):
         batch = self.replay_buffer.sample_batch(self.batch_B)

@@ -42,6 +42,7 @@ def _without(record, *names):
 class ReplayBuffer:
     FRAMES = SEQUENCE = PRIORITIZED = False
     async_ = False
+    TREE_CLS = None         # sum-tree class of prioritized buffers (None: ops.DeviceSumTree)
 
     def _build(self, example, size, B, discount=1, n_step_return=1, device=None,
                rnn_state_interval=0, batch_T=None, alpha=0.6, beta=0.4, default_priority=1,
@@ -73,7 +74,8 @@ class ReplayBuffer:
             self.draws = PriorityDraw(cur, alpha, beta, default_priority, input_priorities,
                                       input_priority_shift, unique=unique,
                                       stride=rnn_state_interval if self.SEQUENCE else 1,
-                                      reach=batch_T if self.SEQUENCE else 0, sequence=self.SEQUENCE)
+                                      reach=batch_T if self.SEQUENCE else 0, sequence=self.SEQUENCE,
+                                      tree_cls=self.TREE_CLS)
         else:
             self.draws = UniformDraw(cur, stride=rnn_state_interval, sequence=self.SEQUENCE)
 

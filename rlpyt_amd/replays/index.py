@@ -52,14 +52,15 @@ class PriorityDraw:
     priorities of single-step batches before inverting them and nothing for sequences."""
 
     def __init__(self, cursor, alpha, beta, default_priority, input_priorities,
-                 input_priority_shift, unique=False, stride=1, reach=0, sequence=False):
+                 input_priority_shift, unique=False, stride=1, reach=0, sequence=False,
+                 tree_cls=None):
         self.cursor, self.alpha, self.beta, self.unique = cursor, alpha, beta, bool(unique)
         self.stride, self.sequence = max(1, stride), sequence
         self.weight_eps = 0. if sequence else 1e-6
         self.input_alpha = not sequence     # fresh priorities ** alpha: single-step buffers only
         k = self.stride
         back = (math.ceil((1 + cursor.guard_back + reach) / k) if sequence else cursor.guard_back)
-        self.tree = ops.DeviceSumTree(
+        self.tree = (tree_cls or ops.DeviceSumTree)(
             T=cursor.T // k, B=cursor.B, off_backward=back,
             off_forward=math.ceil(cursor.guard_fwd / k) if sequence else cursor.guard_fwd,
             default_value=default_priority ** alpha, enable_input_priorities=input_priorities,
