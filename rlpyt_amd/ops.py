@@ -1426,6 +1426,15 @@ class DeviceSumTree:
               "rlpyt_sumtree_set_sampled")
         return leaves // self.B, leaves % self.B, pri
 
+    def leaf_values(self, leaves):
+        """Values the tree holds NOW for ``leaves`` (int64 ``t * B + b``, the last sampled set in
+        its drawn order: the call re-declares them as that set, which leaves it unchanged)."""
+        leaves = leaves.to(device=self.device, dtype=torch.int64).contiguous()
+        pri = torch.empty(leaves.numel(), dtype=torch.float64, device=self.device)
+        check(lib.rlpyt_sumtree_set_sampled(self._h, ptr(leaves), leaves.numel(), ptr(pri), stream()),
+              "rlpyt_sumtree_set_sampled")
+        return pri
+
     def update_batch_priorities(self, priorities):
         p = priorities.to(device=self.device, dtype=torch.float64).contiguous()
         check(lib.rlpyt_sumtree_update(self._h, ptr(p), p.numel(), stream()),

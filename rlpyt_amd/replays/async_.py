@@ -109,6 +109,10 @@ class AsyncSumTree(ops.DeviceSumTree):
         self._check("update_batch_priorities")
         return super().update_batch_priorities(*args, **kwargs)
 
+    def leaf_values(self, *args, **kwargs):
+        self._check("leaf_values")                 # (re-declares the sampled set: a write)
+        return super().leaf_values(*args, **kwargs)
+
 
 class AsyncReplayBufferMixin:
     """``append_samples`` / ``update_batch_priorities`` under the write lock, ``sample_batch`` under the
@@ -125,6 +129,7 @@ class AsyncReplayBufferMixin:
         tree = getattr(getattr(self, "draws", None), "tree", None)
         if isinstance(tree, AsyncSumTree):
             tree.guard = self.rw_lock
+            self.draws.guard_stale = True          # write-backs skip rows appended over meanwhile
 
     # ---- stream order --------------------------------------------------------------------------
     def _cuda(self):

@@ -60,9 +60,13 @@ class PriorityDraw:
         self.input_alpha = not sequence     # fresh priorities ** alpha: single-step buffers only
         k = self.stride
         back = (math.ceil((1 + cursor.guard_back + reach) / k) if sequence else cursor.guard_back)
+        fwd = math.ceil(cursor.guard_fwd / k) if sequence else cursor.guard_fwd
+        self.band = (back, fwd)             # guard band around the tree's cursor, in leaf rows
+        self.guard_stale = False            # asynchronous buffers: see ``update``
+        self._appended = 0                  # leaf rows advanced so far
+        self._drawn = None                  # (leaf T_idxs, B_idxs, tree cursor, _appended) of the last draw
         self.tree = (tree_cls or ops.DeviceSumTree)(
-            T=cursor.T // k, B=cursor.B, off_backward=back,
-            off_forward=math.ceil(cursor.guard_fwd / k) if sequence else cursor.guard_fwd,
+            T=cursor.T // k, B=cursor.B, off_backward=back, off_forward=fwd,
             default_value=default_priority ** alpha, enable_input_priorities=input_priorities,
             input_priority_shift=input_priority_shift, device=cursor.device)
 
@@ -76,6 +80,7 @@ class PriorityDraw:
                 priorities = priorities ** self.alpha
         k = self.stride
         if k == 1:
+            self._appended += claim.count
             self.tree.advance(claim.count, priorities=priorities)
             return
         if priorities is not None and priorities.dim() == 2:      # per-step -> per stored state
@@ -83,6 +88,7 @@ class PriorityDraw:
         leaves = t_after // k - claim.start // k
         if claim.wrapped:
             leaves += self.cursor.T // k
+        self._appended += leaves
         self.tree.advance(leaves, priorities=priorities)
 
     def draw(self, n, reach=None):
@@ -91,6 +97,8 @@ class PriorityDraw:
         else:
             u = torch.from_numpy(np.random.rand(int(n))).to(self.cursor.device, non_blocking=True)
             T_idxs, B_idxs, pri = self.tree.sample(u)
+        if self.guard_stale:
+            self._drawn = (T_idxs, B_idxs, self.tree.t, self._appended)
         if self.stride > 1:
             T_idxs = T_idxs * self.stride
         w = (1. / (pri + self.weight_eps)) ** self.beta
@@ -100,6 +108,8 @@ class PriorityDraw:
         """``draw`` from device-resident uniforms (f64 ``[n]``) with the importance exponent as a
         device scalar: no host work, capturable."""
         T_idxs, B_idxs, pri = self.tree.sample(uniforms)
+        if self.guard_stale:
+            self._drawn = (T_idxs, B_idxs, self.tree.t, self._appended)
         if self.stride > 1:
             T_idxs = T_idxs * self.stride
         w = torch.pow(1. / (pri + self.weight_eps), beta.to(pri.dtype))
@@ -107,5 +117,24 @@ class PriorityDraw:
 
     def update(self, priorities):
         """New priorities of the last drawn batch: ``** alpha`` in the caller's dtype (as numpy does
-        in the reference), then the f64 tree update."""
-        self.tree.update_batch_priorities(priorities.detach().to(self.cursor.device) ** self.alpha)
+        in the reference), then the f64 tree update.
+
+        ``guard_stale`` (set by asynchronous buffers, replays/async_.py): rows may have been appended
+        between the draw and this write-back.  The reference writes the batch's priorities regardless
+        (rlpyt/replays/non_sequence/prioritized.py:60-68 under the write lock,
+        replays/sum_tree.py:131-139) -- a leaf that meanwhile entered the guard band around the new
+        cursor becomes drawable again although its frame stack / n-step return now straddles two
+        laps, and a row rewritten meanwhile gets the old row's TD error.  Here such leaves keep the
+        value the tree holds for them now (zero inside the band, the fresh priority for rewritten
+        rows): a stated deviation that only exists where the reference's order is a race."""
+        new = priorities.detach().to(self.cursor.device) ** self.alpha
+        if self.guard_stale and self._drawn is not None and self._drawn[3] != self._appended:
+            T_leaf, B_idxs, t_draw, n_draw = self._drawn
+            n, T = self._appended - n_draw, self.tree.T
+            back, fwd = self.band
+            t_now = self.tree.t
+            rewritten = ((T_leaf - t_draw) % T) < min(n, T)
+            in_band = ((T_leaf - (t_now - back)) % T) < back + fwd
+            current = self.tree.leaf_values(T_leaf * self.tree.B + B_idxs)
+            new = torch.where(rewritten | in_band, current.to(new.dtype), new)
+        self.tree.update_batch_priorities(new)
