@@ -63,13 +63,13 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, den
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 # bf16-split kernels (DESIGN.md "fp32 contractions on the bf16 pipe"): issued bf16 MFMA flops per
 # algorithmic fp32 flop (3 exact pieces of one operand; 6 products of two 3-piece operands)
-BF16_SPLIT = {"conv1_fwd": 3, "conv1_wgrad": 3, "conv2_fwd": 6, "conv2_bwd": 6, "gemm_nt": 6,
+# (convs_fwd: conv1 as bf16x3 + conv2 as bf16x6 in one kernel: (3 x 3.891 + 6 x 1.769) / 5.660 MFLOP / image)
+BF16_SPLIT = {"convs_fwd": 3.94, "conv1_wgrad": 3, "conv2_bwd": 6, "gemm_nt": 6,
               "gemm_nt_dgrad": 6, "gemm_tn": 6}
 KERNEL_NAMES = {
-    "conv1_fwd": "conv1_fwd_kernel (gather + u8->bf16 + conv 4->16 k8 s4 + bias + ReLU; exact "
-                 "bf16x3 split of w1, f32 accumulate)",
-    "conv2_fwd": "conv2_fwd_x6_kernel (conv 16->32 k4 s2 p1 + bias + ReLU + sign mask of y2; bf16x6 "
-                 "split, f32 accumulate, dropped terms <= 2^-24, 2^-27 rms)",
+    "convs_fwd": "convs_fwd_fused_kernel (gather + u8->bf16 + conv 4->16 k8 s4 + bias + ReLU as an exact "
+                 "bf16x3 split of w1, y1 to HBM once and through LDS into conv 16->32 k4 s2 p1 + bias + ReLU "
+                 "+ sign mask of y2 as a bf16x6 split; f32 accumulate, dropped terms <= 2^-24, 2^-27 rms)",
     "conv2_bwd": "conv2_bwd_x6_kernel (dgrad + ReLU masks + weight/bias grad in one pass over the "
                  "images, conv2's ReLU mask from the forward pass's sign bits; bf16x6 split of both "
                  "operands of both contractions, f32 accumulate)",
@@ -617,7 +617,7 @@ KTIMER_NOTE = ("HIP events around each launch, on the launching stream, in 2 ite
                "workload run right after the timed region (the timed region itself carries no "
                "per-launch events: they would sit between its kernels)")
 # bench region -> kernel names as rocprofv3 prints them (profiles/r*_bench_kernel_stats.csv)
-ROCPROF_NAMES = {"conv1_fwd": ["conv1_fwd_kernel"], "conv2_fwd": ["conv2_fwd_x6_kernel"],
+ROCPROF_NAMES = {"convs_fwd": ["convs_fwd_fused_kernel"],
                  "conv2_bwd": ["conv2_bwd_x6_kernel"], "conv1_wgrad": ["conv1_wgrad_kernel"],
                  "gemm_nt": ["gemm_nt_x6_kernel<128>"], "gemm_nt_dgrad": ["gemm_nt_x6_kernel<256>"],
                  "gemm_tn": ["gemm_tn_x6_kernel", "gemm_reduce_slots_kernel"],

@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 8
+#define RLPYT_HIP_ABI_VERSION 9
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -513,6 +513,16 @@ int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat_idx /*null
  * written beside y2 -- all the backward pass needs of y2 (432 bits instead of 13.8 KB per image). */
 int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float* w2, const float* b2,
                               float* y2, uint32_t* relu_mask, rlpyt_stream_t stream);
+/* conv1 -> conv2 forward of an update minibatch in ONE pass over the images (round 6, ABI 9): the
+ * two calls above with y1 handed from conv1 to conv2 through LDS -- y1 is still written (the backward
+ * pass reads it) but never re-read: 636 MB instead of 888 MB per 8192 images.  Replaces the
+ * `conv(img)` of rlpyt/models/pg/atari_ff_model.py:50-51 under autograd at update sizes; y1, y2 and
+ * relu_mask are bit-identical to the two separate calls (same arithmetic, statement for statement).
+ * M <= the number of CUs: forwards to the two latency-tuned launches. */
+int rlpyt_atari_convs_fwd_f32(const uint8_t* obs, const int64_t* flat_idx /*nullable*/, int T,
+                              int64_t B, int64_t M, const float* w1, const float* b1,
+                              const float* w2, const float* b2, float scale, float* y1, float* y2,
+                              uint32_t* relu_mask, rlpyt_stream_t stream);
 /* Sampling-step front end in ONE launch (one environment per workgroup): the frame-stack push of
  * rlpyt_frame_push (obs[t, lo+b] rebuilt from slot / full_rows / obs[t-1] / new_frame, t = *t_dev,
  * optional reward/done row commit) followed by conv1 and conv2 of rlpyt_atari_conv{1,2}_fwd_f32 on

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class CopyDesc(ctypes.Structure):
@@ -134,6 +134,8 @@ _SIGNATURES = {
     "rlpyt_lstm_cell_f32": (c_int, [_p, c_int, _p, _p, _p, _p, _p, c_int64, c_int, _p]),
     "rlpyt_atari_conv1_fwd_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, _p, c_float, _p, _p]),
     "rlpyt_atari_conv2_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p]),
+    "rlpyt_atari_convs_fwd_f32": (c_int, [_p, _p, c_int, c_int64, c_int64, _p, _p, _p, _p, c_float, _p,
+                                          _p, _p, _p]),
     "rlpyt_atari_sample_convs_f32": (c_int, [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, _p, _p,
                                              _p, _p, _p, _p, _p, _p, c_float, _p, _p]),
     "rlpyt_atari_sample_convs_to_f32": (c_int, [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, _p, _p,

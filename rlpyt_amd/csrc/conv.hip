@@ -160,19 +160,70 @@ __device__ __forceinline__ void bytes_to_bf16(const uint4& v, uint4& lo, uint4& 
   lo = uint4{o[0], o[1], o[2], o[3]};
   hi = uint4{o[4], o[5], o[6], o[7]};
 }
-struct __attribute__((aligned(8))) U4A8 { uint32_t x, y, z, w; };   // 16 B at 8-byte alignment
 
 // ======================================================================================
 // conv1 forward: y1[m, pos, co] = relu(scale * sum_k w1[co,k] * x[m, patch(pos,k)] + b1[co])
 //   A = w1 as 3 bf16 pieces (rows co; 8 K-steps x 3 pieces x 4 VGPRs, held for the whole
-//   kernel), B = the image as bf16 [c][y][x] in LDS (66,560 B -> two workgroups per CU: one
+//   kernel), B = the image as bf16 in LDS (66,560 B -> two workgroups per CU: one
 //   converts / stages while the other contracts).
-//   K order: step st = (c, ky_hi), lane group kb = ky_lo (ky = 4 ky_hi + kb), element i = kx: the
-//   8 K-elements of a lane are 8 consecutive pixels of one image row -- one ds_read2_b64.
+//   LDS layout (round 6): [c][row pair yp = y >> 1][block xq = x >> 2][y & 1][x & 3] -- one 16-byte
+//   entry holds a 4-pixel block of TWO adjacent image rows, so the 8 K-elements of a lane are ONE
+//   16-byte-aligned ds_read_b128 whatever the position's parity (a patch starts at x = 4 ox: with plain
+//   rows the 8 pixels of odd ox sit at 8 mod 16 and need a ds_read2_b64, which a single wave per SIMD
+//   issues at a fifth of the LDS rate: 64 of them per image cost as much as the 192 MFMAs).
+//   K order: step st = (c, kyp_hi), lane group kb = (kx_hi = kb & 1, kyp_lo = kb >> 1), element
+//   i = (ky & 1, kx & 3), with ky = 2 (2 kyp_hi + kyp_lo) + (i >> 2), kx = 4 kx_hi + (i & 3).
+//   Entry of (position (oy, ox), step, kb): [c][2 oy + 2 kyp_hi + kyp_lo][ox + kx_hi]; the 16 lanes of a
+//   bank group read consecutive (or identical) entries.
 //   30 tiles of 16 positions, two at a time; 24 MFMAs per tile.
 // ======================================================================================
 constexpr int C1F_THREADS = 256;
-constexpr int F3_ROWB = W0 * 2, F3_CB = H0 * F3_ROWB, F3_XB = C0 * F3_CB;   // 160, 16,640, 66,560 B
+constexpr int F3_PRB = (W0 / 4) * 16, F3_CB = (H0 / 2) * F3_PRB, F3_XB = C0 * F3_CB;   // 320, 16,640, 66,560 B
+
+// byte offset of a position's patch origin (step 0, kb 0) in the image buffer
+__device__ __forceinline__ int c1_patch_origin(int pos) {
+  return (pos / W1) * 2 * F3_PRB + (pos % W1) * 16;
+}
+// lane part (kb) and step part of an operand address
+__device__ __forceinline__ int c1_lane_off(int kb) { return (kb >> 1) * F3_PRB + (kb & 1) * 16; }
+__device__ __forceinline__ constexpr int c1_step_off(int st) { return (st >> 1) * F3_CB + (st & 1) * 2 * F3_PRB; }
+// the three bf16 pieces of this lane's w1 operand of K-step st (w1s: w1 [16][256] as floats)
+__device__ __forceinline__ void c1_weight_pieces(const float* w1s, int n, int kb, int st, uint4 (&out)[3]) {
+  const float* wr = w1s + n * 256 + (st >> 1) * 64 + (4 * (st & 1) + 2 * (kb >> 1)) * 8 + 4 * (kb & 1);
+  float x[8], r1[8], r2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    x[i] = wr[(i >> 2) * 8 + (i & 3)];
+    r1[i] = bf16_rem(x[i]);
+    r2[i] = bf16_rem(r1[i]);
+  }
+  out[0] = uint4{pack_hi16(x[0], x[1]), pack_hi16(x[2], x[3]), pack_hi16(x[4], x[5]), pack_hi16(x[6], x[7])};
+  out[1] = uint4{pack_hi16(r1[0], r1[1]), pack_hi16(r1[2], r1[3]), pack_hi16(r1[4], r1[5]),
+                 pack_hi16(r1[6], r1[7])};
+  out[2] = uint4{pack_hi16(r2[0], r2[1]), pack_hi16(r2[2], r2[3]), pack_hi16(r2[4], r2[5]),
+                 pack_hi16(r2[6], r2[7])};
+}
+// Staging unit u (2080 per image) = 8 pixels of the two rows of a row pair: channel u / 520, pair
+// (u % 520) / 10, pixels 8 (u % 10) .. + 7 -- two 8-byte global loads (rows 2 yp and 2 yp + 1) that become
+// the two complete 16-byte entries at byte 32 u of the image buffer: a lane writes 32 contiguous bytes
+// (conflict-free ds_write_b128; 8-byte writes of one row's blocks hit 4 of the 16 slots of a bank group).
+__device__ __forceinline__ int c1_unit_src(int u) {          // byte offset of the unit's upper row in the image
+  const int c = u / 520, rem = u - c * 520, yp = rem / 10, xo = rem - yp * 10;
+  return c * HW0 + yp * 2 * W0 + xo * 8;
+}
+__device__ __forceinline__ void c1_stage_unit(uint8_t* xb, int u, const uint2& up, const uint2& dn) {
+  const uint32_t d[4] = {up.x, up.y, dn.x, dn.y};
+  uint32_t o[8];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    o[2 * jj] = pack_hi16((float)(d[jj] & 0xffu), (float)((d[jj] >> 8) & 0xffu));
+    o[2 * jj + 1] = pack_hi16((float)((d[jj] >> 16) & 0xffu), (float)(d[jj] >> 24));
+  }
+  uint4* dst = reinterpret_cast<uint4*>(xb + 32 * u);
+  dst[0] = uint4{o[0], o[1], o[4], o[5]};      // block 2 xo:     upper row | lower row
+  dst[1] = uint4{o[2], o[3], o[6], o[7]};      // block 2 xo + 1
+}
+constexpr int C1_UNITS = C0 * (H0 / 2) * (W0 / 8);   // 2080
 
 __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
     const uint8_t* __restrict__ obs, const int64_t* __restrict__ flat_idx, int T, int64_t B,
@@ -187,7 +238,7 @@ __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
   const int n = lane & 15, kb = lane >> 4;
   for (int i = tid; i < 480; i += C1F_THREADS) {
     const int pos = min(i, P1 - 1);
-    ptab[i] = (pos / W1) * 4 * F3_ROWB + (pos % W1) * 8;
+    ptab[i] = c1_patch_origin(pos);
   }
   // the 16 KB of weights pass through the (not yet used) image buffer: coalesced 16-byte loads
   for (int i = tid; i < C1 * 256 / 4; i += C1F_THREADS)
@@ -195,42 +246,28 @@ __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
   __syncthreads();
   uint4 wa[8][3];
 #pragma unroll
-  for (int st = 0; st < 8; ++st) {
-    const float* wr = reinterpret_cast<const float*>(xb) + n * 256 + (st >> 1) * 64 +
-                      (4 * (st & 1) + kb) * 8;
-    float x[8], r1[8], r2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      x[i] = wr[i];
-      r1[i] = bf16_rem(x[i]);
-      r2[i] = bf16_rem(r1[i]);
-    }
-    wa[st][0] = uint4{pack_hi16(x[0], x[1]), pack_hi16(x[2], x[3]), pack_hi16(x[4], x[5]),
-                      pack_hi16(x[6], x[7])};
-    wa[st][1] = uint4{pack_hi16(r1[0], r1[1]), pack_hi16(r1[2], r1[3]), pack_hi16(r1[4], r1[5]),
-                      pack_hi16(r1[6], r1[7])};
-    wa[st][2] = uint4{pack_hi16(r2[0], r2[1]), pack_hi16(r2[2], r2[3]), pack_hi16(r2[4], r2[5]),
-                      pack_hi16(r2[6], r2[7])};
-  }
+  for (int st = 0; st < 8; ++st) c1_weight_pieces(reinterpret_cast<const float*>(xb), n, kb, st, wa[st]);
   float bias[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias[r] = b1[4 * kb + r];
 
   // software pipeline over images: the next image is fetched into registers while this one is
   // contracted; the staging phase converts registers -> bf16 in LDS
-  constexpr int NPI = (IMG / 16 + C1F_THREADS - 1) / C1F_THREADS;   // 9 uint4 per thread
-  uint4 pimg[NPI];
+  constexpr int NPI = (C1_UNITS + C1F_THREADS - 1) / C1F_THREADS;   // 9 staging units per thread
+  uint2 pimg[NPI][2];
+  int usrc[NPI];
+#pragma unroll
+  for (int k = 0; k < NPI; ++k) usrc[k] = c1_unit_src(min(tid + k * C1F_THREADS, C1_UNITS - 1));
 #define RLPYT_F3_PREFETCH(mm_)                                                                 \
   {                                                                                            \
-    const uint4* __restrict__ src_ = reinterpret_cast<const uint4*>(                           \
-        obs + image_row(flat_idx, (mm_) / split, T, B) * IMG);                                 \
+    const uint8_t* __restrict__ src_ = obs + image_row(flat_idx, (mm_) / split, T, B) * IMG;   \
     _Pragma("unroll") for (int k = 0; k < NPI; ++k) {                                          \
-      const int i = tid + k * C1F_THREADS;                                                     \
-      if (i < IMG / 16) pimg[k] = src_[i];                                                     \
+      pimg[k][0] = *reinterpret_cast<const uint2*>(src_ + usrc[k]);                            \
+      pimg[k][1] = *reinterpret_cast<const uint2*>(src_ + usrc[k] + W0);                       \
     }                                                                                          \
   }
   if ((int64_t)blockIdx.x < M * split) RLPYT_F3_PREFETCH((int64_t)blockIdx.x)
-  const uint8_t* const xlane = xb + kb * F3_ROWB;
+  const uint8_t* const xlane = xb + c1_lane_off(kb);
 
   for (int64_t mm = blockIdx.x; mm < M * split; mm += gridDim.x) {
     const int64_t m = mm / split;
@@ -239,12 +276,7 @@ __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
 #pragma unroll
     for (int k = 0; k < NPI; ++k) {
       const int i = tid + k * C1F_THREADS;
-      if (i < IMG / 16) {
-        uint4 lo, hi;
-        bytes_to_bf16(pimg[k], lo, hi);
-        reinterpret_cast<uint4*>(xb)[2 * i] = lo;
-        reinterpret_cast<uint4*>(xb)[2 * i + 1] = hi;
-      }
+      if (i < C1_UNITS) c1_stage_unit(xb, i, pimg[k][0], pimg[k][1]);
     }
     __syncthreads();
     if (mm + gridDim.x < M * split) RLPYT_F3_PREFETCH(mm + gridDim.x)
@@ -254,17 +286,16 @@ __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
       const uint8_t* bp1 = xlane + ptab[pos1];
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       // the operands of the next step are requested before the 6 MFMAs of the current one
-      U4A8 c0 = *reinterpret_cast<const U4A8*>(bp0), c1 = *reinterpret_cast<const U4A8*>(bp1);
+      uint4 c0 = *reinterpret_cast<const uint4*>(bp0), c1 = *reinterpret_cast<const uint4*>(bp1);
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
-        U4A8 n0 = c0, n1 = c1;
+        uint4 n0 = c0, n1 = c1;
         if (st < 7) {
-          const int off = ((st + 1) >> 1) * F3_CB + ((st + 1) & 1) * 4 * F3_ROWB;
-          n0 = *reinterpret_cast<const U4A8*>(bp0 + off);
-          n1 = *reinterpret_cast<const U4A8*>(bp1 + off);
+          n0 = *reinterpret_cast<const uint4*>(bp0 + c1_step_off(st + 1));
+          n1 = *reinterpret_cast<const uint4*>(bp1 + c1_step_off(st + 1));
         }
         __builtin_amdgcn_sched_barrier(0x6);
-        const uint4 v0 = {c0.x, c0.y, c0.z, c0.w}, v1 = {c1.x, c1.y, c1.z, c1.w};
+        const uint4 v0 = c0, v1 = c1;
 #pragma unroll
         for (int s = 2; s >= 0; --s) {   // lo, mid, hi
           acc0 = mfma_bf16(wa[st][s], v0, acc0);
@@ -627,6 +658,328 @@ __global__ __launch_bounds__(C2X_THREADS) void conv2_fwd_x6_kernel(
 #undef RLPYT_C2X_BREAD
 #undef RLPYT_C2X_STAGE
 #undef RLPYT_C2X_PREFETCH
+}
+
+// ======================================================================================
+// conv1 -> conv2 forward of the UPDATE in one pass over the images (round 6): conv2 consumes y1 from
+// LDS while y1 is still written ONCE to HBM for the backward pass -- the 30 KB / image re-read of y1 by
+// conv2_fwd_x6_kernel (249 MB per minibatch of 8192) is gone: 636 MB instead of 888 MB for the pair.
+// The arithmetic is the two kernels' above, statement for statement (conv1: bf16x3 with the piece order
+// lo, mid, hi per K-step; conv2: bf16x6 with the term order a2b0, a0b2, a1b1, a1b0, a0b1, a0b0 per tap,
+// the two tap halves added own + other): y1, y2 and the sign mask are BIT-IDENTICAL to
+// conv1_fwd_kernel + conv2_fwd_x6_kernel (tests/test_conv_gpu.py).
+// One workgroup per CU, 8 waves in two ROLES (a SIMD hosts one wave of each):
+//   waves 0-3 (C1): image u8 -> bf16 in LDS (registers hold the next image), conv1 on 15 tile pairs
+//                   (4 per wave, the 16th is pair 14 again), epilogue = y1 to HBM + its three bf16
+//                   pieces into conv2's plane;
+//   waves 4-7 (C2): (tile pair tp, tap half kh): two 32-position tiles x 8 taps with the w2 pieces of
+//                   those taps in 96 VGPRs, halves exchanged through LDS, y2 + mask to HBM.
+// Two barriers per image; the matrix pipe of a SIMD is fed by the C2 wave in window A (while the C1
+// wave converts / stages the next image) and by the C1 wave in window B (while the C2 wave exchanges,
+// finishes and stores):
+//   window A:  C1 stage(image k+1) -> xb          |  C2 taps(image k) on the plane, halves -> red
+//   window B:  C1 conv1(k+1): xb -> y1, plane     |  C2 red -> y2(k), mask(k)
+// LDS: xb 66,560 + plane 49,920 + red 16,384 + tables = 136.8 KB.
+// ======================================================================================
+constexpr int CF_THREADS = 512;
+
+__global__ __launch_bounds__(CF_THREADS) void convs_fwd_fused_kernel(
+    const uint8_t* __restrict__ obs, const int64_t* __restrict__ flat_idx, int T, int64_t B,
+    const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+    const float* __restrict__ b2, float* __restrict__ y1, float* __restrict__ y2,
+    uint32_t* __restrict__ mask, int64_t M, float scale) {
+  __shared__ __attribute__((aligned(16))) uint8_t xb[F3_XB];
+  __shared__ __attribute__((aligned(16))) uint8_t pl[C2X_PL];
+  __shared__ __attribute__((aligned(16))) float red[8 * 8 * 64];     // 16 KB
+  __shared__ int ptab[480];               // position -> byte offset of its patch origin in xb
+  __shared__ int dtab[480];               // position -> byte offset of its entry in a plane piece
+  __shared__ float bs[C2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool c1_role = wave < 4;
+  // C1 lane map (16x16x32): position n, K group / output-channel group kb
+  const int n = lane & 15, kb = lane >> 4;
+  // C2 lane map (32x32x16): row / column j, channel half h; wave = (tile pair tp, tap half kh)
+  const int j = lane & 31, h = lane >> 5;
+  const int tp = (wave - 4) & 1, kh = (wave >> 1) & 1;      // (wave - 4) >> 1 for waves 4..7
+  for (int i = tid; i < 480; i += CF_THREADS) {
+    const int pos = min(i, P1 - 1);
+    ptab[i] = c1_patch_origin(pos);
+    const int Y = pos / W1 + 1, X = pos % W1 + 1;
+    dtab[i] = Y * C2X_ROWB + ((X & 1) * 10 + (X >> 1)) * 16;
+  }
+  if (tid < C2) bs[tid] = b2[tid];
+  // ---- weights through the (not yet used) image / plane buffers ----
+  for (int i = tid; i < C1 * 256 / 4; i += CF_THREADS)
+    reinterpret_cast<uint4*>(xb)[i] = reinterpret_cast<const uint4*>(w1)[i];
+  static_assert(C2 * C2X_WS * 4 <= C2X_PL, "w2 staging fits in the plane buffer");
+  {
+    f32x4 wv[C2 * 256 / 4 / CF_THREADS];
+#pragma unroll
+    for (int k = 0; k < C2 * 256 / 4 / CF_THREADS; ++k)
+      wv[k] = reinterpret_cast<const f32x4*>(w2)[tid + k * CF_THREADS];
+#pragma unroll
+    for (int k = 0; k < C2 * 256 / 4 / CF_THREADS; ++k) {
+      const int i = 4 * (tid + k * CF_THREADS);
+      float* d = reinterpret_cast<float*>(pl) + (i >> 8) * C2X_WS + (i & 255);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = wv[k][e];
+    }
+  }
+  __syncthreads();
+  uint4 wa[8][3];     // C1: the 8 K-steps of w1; C2: this wave's 8 taps of w2 -- three pieces each
+  float bias[4];
+  if (c1_role) {
+#pragma unroll
+    for (int st = 0; st < 8; ++st) c1_weight_pieces(reinterpret_cast<const float*>(xb), n, kb, st, wa[st]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = b1[4 * kb + r];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float* wr = reinterpret_cast<const float*>(pl) + j * C2X_WS + (8 * h) * 16 + 8 * kh + t;
+      uint32_t p[3][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        split3_rn(wr[(2 * i) * 16], wr[(2 * i + 1) * 16], p[0][i], p[1][i], p[2][i]);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) wa[t][s] = uint4{p[s][0], p[s][1], p[s][2], p[s][3]};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < C2X_PL / 16; i += CF_THREADS)
+    reinterpret_cast<uint4*>(pl)[i] = uint4{0u, 0u, 0u, 0u};             // borders stay zero
+
+  // ---- C1: image prefetch (registers), staging, conv1 ----
+  constexpr int NPI = (C1_UNITS + 255) / 256;        // 9 staging units per C1 thread
+  uint2 pimg[NPI][2];
+  int usrc[NPI];
+#pragma unroll
+  for (int k = 0; k < NPI; ++k) usrc[k] = c1_unit_src(min((tid & 255) + k * 256, C1_UNITS - 1));
+#define RLPYT_CF_PREFETCH(m_)                                                                  \
+  {                                                                                            \
+    const uint8_t* __restrict__ src_ = obs + image_row(flat_idx, (m_), T, B) * IMG;            \
+    _Pragma("unroll") for (int k = 0; k < NPI; ++k) {                                          \
+      pimg[k][0] = *reinterpret_cast<const uint2*>(src_ + usrc[k]);                            \
+      pimg[k][1] = *reinterpret_cast<const uint2*>(src_ + usrc[k] + W0);                       \
+    }                                                                                          \
+  }
+#define RLPYT_CF_STAGE()                                                                       \
+  _Pragma("unroll") for (int k = 0; k < NPI; ++k) {                                            \
+    const int i = tid + k * 256;                                                               \
+    if (i < C1_UNITS) c1_stage_unit(xb, i, pimg[k][0], pimg[k][1]);                            \
+  }
+  const uint8_t* const xlane = xb + c1_lane_off(kb);
+  uint8_t* const plane_lane = pl + (kb >> 1) * C2X_HB + (kb & 1) * 8;
+  // this lane's 4 tile pairs (pair 15 = pair 14 again: same values to the same places): patch origins
+  // in xb, entries in the plane, rows of y1 -- fixed for the whole kernel
+  int xo0[4], xo1[4], do0[4], do1[4], yo0[4], yo1[4];
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {
+    const int p = min(4 * pp + (wave & 3), 14);
+    const int pos0 = min(p * 32 + n, P1 - 1), pos1 = min(p * 32 + 16 + n, P1 - 1);
+    xo0[pp] = ptab[pos0]; xo1[pp] = ptab[pos1];
+    do0[pp] = dtab[pos0]; do1[pp] = dtab[pos1];
+    yo0[pp] = pos0 * C1 + 4 * kb; yo1[pp] = pos1 * C1 + 4 * kb;
+  }
+  // conv1 of image m_ as ONE stream of 32 K-steps: the operands of the next step (of the next pair at a
+  // pair's last step) are requested before the 6 MFMAs of the current one, and the epilogue of pair
+  // pp - 1 (scale, bias, ReLU, y1 store, three-piece split, plane writes) is spread in three parts behind
+  // steps 1..3 of pair pp, in the shadow of their MFMAs
+#define RLPYT_CF_RD(dst_, off_) dst_ = *reinterpret_cast<const uint4*>(xlane + (off_));
+// epilogue of a pair in six chunks of <= 12 VALU instructions, one per K-step of the NEXT pair, each
+// inside that step's MFMA region and interleaved with its MFMAs (1 MFMA : 2 VALU)
+#define RLPYT_CF_RELU(o_, pacc_, yo_, pp_)                                                     \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) o_[r] = fmaxf(pacc_[r] * scale + bias[r], 0.f); \
+  *reinterpret_cast<f32x4*>(y1img + yo_[pp_]) = o_;
+#define RLPYT_CF_SPLIT(o_, e_, q_)                                                             \
+  split3_rn(o_[2 * (e_)], o_[2 * (e_) + 1], q_[0][e_], q_[1][e_], q_[2][e_]);
+#define RLPYT_CF_PUT(q_, do_, pp_)                                                             \
+  {                                                                                            \
+    uint8_t* d_ = plane_lane + do_[pp_];                                                       \
+    _Pragma("unroll") for (int s = 0; s < 3; ++s)                                              \
+      *reinterpret_cast<uint2*>(d_ + s * C2X_SB) = uint2{q_[s][0], q_[s][1]};                  \
+  }
+#define RLPYT_CF_CHUNK(k_, pp_)                                                                \
+  if ((k_) == 0) { RLPYT_CF_RELU(o0, pacc0, yo0, pp_) }                                        \
+  if ((k_) == 1) { RLPYT_CF_RELU(o1, pacc1, yo1, pp_) }                                        \
+  if ((k_) == 2) { RLPYT_CF_SPLIT(o0, 0, q0) }                                                 \
+  if ((k_) == 3) { RLPYT_CF_SPLIT(o0, 1, q0) RLPYT_CF_PUT(q0, do0, pp_) }                      \
+  if ((k_) == 4) { RLPYT_CF_SPLIT(o1, 0, q1) }                                                 \
+  if ((k_) == 5) { RLPYT_CF_SPLIT(o1, 1, q1) RLPYT_CF_PUT(q1, do1, pp_) }
+#define RLPYT_CF_XOFF(g_) c1_step_off((g_) & 7)
+#define RLPYT_CF_CONV1(m_)                                                                     \
+  {                                                                                            \
+    float* const y1img = y1 + (m_) * Y1;                                                       \
+    /* operand registers of the 32 K-steps (g = 8 pair + step), requested TWO steps ahead */   \
+    uint4 r0[34], r1[34];                                                                       \
+    RLPYT_CF_RD(r0[0], xo0[0]) RLPYT_CF_RD(r1[0], xo1[0])                                      \
+    RLPYT_CF_RD(r0[1], xo0[0] + RLPYT_CF_XOFF(1)) RLPYT_CF_RD(r1[1], xo1[0] + RLPYT_CF_XOFF(1)) \
+    f32x4 pacc0 = {0.f, 0.f, 0.f, 0.f}, pacc1 = {0.f, 0.f, 0.f, 0.f}, o0, o1;                  \
+    uint32_t q0[3][2], q1[3][2];                                                               \
+    _Pragma("unroll") for (int pp = 0; pp < 4; ++pp) {                                         \
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};                          \
+      _Pragma("unroll") for (int st = 0; st < 8; ++st) {                                       \
+        const int g = 8 * pp + st;                                                             \
+        if (g + 2 < 32) {                                     \
+          const int pn = (g + 2) >> 3;                                                         \
+          RLPYT_CF_RD(r0[g + 2], xo0[pn] + RLPYT_CF_XOFF(g + 2))                               \
+          RLPYT_CF_RD(r1[g + 2], xo1[pn] + RLPYT_CF_XOFF(g + 2))                               \
+        }                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        const uint4 v0 = r0[g], v1 = r1[g];                                                    \
+        _Pragma("unroll") for (int s = 2; s >= 0; --s) {                                       \
+          acc0 = mfma_bf16(wa[st][s], v0, acc0);                                               \
+          acc1 = mfma_bf16(wa[st][s], v1, acc1);                                               \
+        }                                                                                      \
+        if (pp > 0 && st >= 1 && st <= 6) {                                                    \
+          RLPYT_CF_CHUNK(st - 1, pp > 0 ? pp - 1 : 0)                                          \
+          _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                   \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                 \
+          }                                                                                    \
+        }                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+      }                                                                                        \
+      pacc0 = acc0;                                                                            \
+      pacc1 = acc1;                                                                            \
+    }                                                                                          \
+    _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) { RLPYT_CF_CHUNK(k_, 3) }                 \
+  }
+
+  // ---- C2: addresses ----
+  int b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int posc = min(32 * (2 * tp + i) + j, P2 - 1);
+    b_off[i] = h * C2X_HB + (2 * (posc / W2)) * C2X_ROWB + (posc % W2) * 16;
+  }
+  // exchange blocks [destination wave (kh, tp)][tile i][64 lanes][8 rows]: 32 bytes per lane, two
+  // 16-byte accesses on either side
+  float* const red_out = red + (((1 - kh) * 2 + tp) * 2) * 512 + lane * 8;
+  const float* const red_in = red + ((kh * 2 + tp) * 2) * 512 + lane * 8;
+#define RLPYT_CF_BREAD(dst_, t_)                                                               \
+  {                                                                                            \
+    const int ky_ = 2 * kh + ((t_) >> 2), kx_ = (t_) & 3;                                      \
+    const int toff_ = ky_ * C2X_ROWB + ((kx_ & 1) * 10 + (kx_ >> 1)) * 16;                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                           \
+      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                         \
+        dst_[i_][s_] = *reinterpret_cast<const uint4*>(pl + b_off[i_] + toff_ + s_ * C2X_SB);  \
+  }
+#define RLPYT_CF_TERM(sa_, sb_)                                                                \
+  acc[0] = mfma32_bf16(wa[t][sa_], bc[0][sb_], acc[0]);                                        \
+  acc[1] = mfma32_bf16(wa[t][sa_], bc[1][sb_], acc[1]);
+
+  const int64_t m_first = blockIdx.x, m_step = gridDim.x;
+  if (m_first >= M) return;
+  // The two roles run SEPARATE loops (their register sets are disjoint apart from wa) that meet at the
+  // workgroup barrier the same number of times: three in the prologue, two per image.
+  if (c1_role) {
+    RLPYT_CF_PREFETCH(m_first)
+    __syncthreads();                      // zeroed plane, weights taken out of xb
+    RLPYT_CF_STAGE()
+    if (m_first + m_step < M) RLPYT_CF_PREFETCH(m_first + m_step)
+    __syncthreads();                      // xb holds the first image
+    RLPYT_CF_CONV1(m_first)
+    __syncthreads();                      // plane holds the first image's y1 pieces
+    RL_T0()
+    for (int64_t m = m_first; m < M; m += m_step) {
+      const bool more = m + m_step < M;
+      if (more) { RLPYT_CF_STAGE() }                                   // window A
+      RL_T(0)
+      __syncthreads();
+      RL_T(1)
+      if (more) {                                                      // window B
+        if (m + 2 * m_step < M) RLPYT_CF_PREFETCH(m + 2 * m_step)
+        RLPYT_CF_CONV1(m + m_step)
+      }
+      RL_T(2)
+      __syncthreads();
+      RL_T(3)
+    }
+    RL_TOUT()
+  } else {
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    float bsv[8];                         // b2 of this lane's 8 finished rows
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bsv[r] = bs[((8 * kh + r) & 3) + 8 * ((8 * kh + r) >> 2) + 4 * h];
+    RL_T0()
+    for (int64_t m = m_first; m < M; m += m_step) {
+      // ---------------- window A: the taps ----------------
+      f32x16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      uint4 bc[2][3], bn[2][3];
+      RLPYT_CF_BREAD(bc, 0)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (t < 7) RLPYT_CF_BREAD(bn, t + 1)
+        __builtin_amdgcn_sched_barrier(0x6);
+        RLPYT_CF_TERM(2, 0) RLPYT_CF_TERM(0, 2) RLPYT_CF_TERM(1, 1)
+        RLPYT_CF_TERM(1, 0) RLPYT_CF_TERM(0, 1) RLPYT_CF_TERM(0, 0)
+        __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int s = 0; s < 3; ++s) bc[i][s] = bn[i][s];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int r0 = 8 * (1 - kh) + 4 * q;
+          *reinterpret_cast<f32x4*>(red_out + i * 512 + 4 * q) =
+              f32x4{acc[i][r0], acc[i][r0 + 1], acc[i][r0 + 2], acc[i][r0 + 3]};
+        }
+      RL_T(0)
+      __syncthreads();
+      RL_T(1)
+      // ---------------- window B: halves meet, y2 + mask leave ----------------
+      // A lane holds position 32 pt + j of rows co = (rr & 3) + 8 (rr >> 2) + 4 h: the 32 lanes of a half
+      // store 128 contiguous bytes of one y2 row, and the ballot of (y2 > 0) IS the two sign-mask words
+      // of the row pair (low half: row co of h = 0, high half: h = 1) -- no transposition through LDS.
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int pt = 2 * tp + i;
+        const bool valid = 32 * pt + j < P2;
+        float* const yrow = y2 + m * F2 + 32 * pt + j;
+        uint32_t* const mrow = mask + m * MASK2_W + pt;
+        f32x4 other[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) other[q] = *reinterpret_cast<const f32x4*>(red_in + i * 512 + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int rr = 8 * kh + r;
+          const int co = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+          const float v = fmaxf(acc[i][rr] + other[r >> 2][r & 3] + bsv[r], 0.f);
+          if (valid) yrow[co * P2] = v;
+          const uint64_t bits = __ballot(valid && v > 0.f);
+          mrow[co * 4] = h ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+        }
+      }
+      RL_T(2)
+      __syncthreads();
+      RL_T(3)
+    }
+    RL_TOUT()
+  }
+#undef RLPYT_CF_TERM
+#undef RLPYT_CF_BREAD
+#undef RLPYT_CF_CONV1
+#undef RLPYT_CF_XOFF
+#undef RLPYT_CF_CHUNK
+#undef RLPYT_CF_PUT
+#undef RLPYT_CF_SPLIT
+#undef RLPYT_CF_RELU
+#undef RLPYT_CF_RD
+#undef RLPYT_CF_STAGE
+#undef RLPYT_CF_PREFETCH
 }
 
 // partial-gradient slot of one workgroup: dW2 [co][c][ky][kx] then db2 (conv2 backward)
@@ -1642,6 +1995,28 @@ extern "C" int rlpyt_atari_conv2_fwd_f32(const float* y1, int64_t M, const float
     RL_LAUNCH(conv2_fwd_x6_kernel, dim3(grid_for(M, 1)), dim3(C2X_THREADS), 0, s, y1, w2, b2, y2,
               relu_mask, M);
   }
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_atari_convs_fwd_f32(const uint8_t* obs, const int64_t* flat_idx, int T, int64_t B,
+                                         int64_t M, const float* w1, const float* b1, const float* w2,
+                                         const float* b2, float scale, float* y1, float* y2,
+                                         uint32_t* relu_mask, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(M >= 0 && T > 0 && B > 0, RLPYT_EINVAL, "rlpyt_atari_convs_fwd_f32: bad sizes");
+  if (M == 0) return RLPYT_OK;
+  RL_CHECK_ARG(obs && w1 && b1 && w2 && b2 && y1 && y2 && relu_mask, RLPYT_EINVAL,
+               "rlpyt_atari_convs_fwd_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(y1) && RL_ALIGNED16(w1) && RL_ALIGNED16(w2) &&
+                   RL_ALIGNED16(y2) && RL_ALIGNED16(relu_mask),
+               RLPYT_ESHAPE, "rlpyt_atari_convs_fwd_f32: obs / w1 / w2 / y1 / y2 / relu_mask must be "
+                             "16-byte aligned");
+  if (M <= grid_for(1 << 30, 1)) {   // at most one image per CU: the two latency-tuned launches
+    if (int e = rlpyt_atari_conv1_fwd_f32(obs, flat_idx, T, B, M, w1, b1, scale, y1, stream)) return e;
+    return rlpyt_atari_conv2_fwd_f32(y1, M, w2, b2, y2, relu_mask, stream);
+  }
+  RL_LAUNCH(convs_fwd_fused_kernel, dim3(grid_for(M, 1)), dim3(CF_THREADS), 0, (hipStream_t)stream,
+            obs, flat_idx, T, B, w1, b1, w2, b2, y1, y2, relu_mask, M, scale);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

@@ -537,13 +537,13 @@ class _AtariConvStack(torch.autograd.Function):
         # sign bits of y2, written by the conv2 forward kernel beside it: all that conv2's backward
         # pass needs of y2 (512 B instead of 13.8 KB per image on its load path)
         mask2 = torch.empty((M, ATARI_MASK2_WORDS), dtype=torch.int32, device=obs.device)
-        with ktimer.region("conv1_fwd", M * (33280 + 4 * 7600), M * _FL_C1):
-            check(lib.rlpyt_atari_conv1_fwd_f32(ptr(obs), ptr(idx), T, B, M, ptr(w1c), ptr(b1c),
-                                                float(scale), ptr(y1), stream()),
-                  "rlpyt_atari_conv1_fwd_f32")
-        with ktimer.region("conv2_fwd", M * (4 * (7600 + 3456) + 4 * ATARI_MASK2_WORDS), M * _FL_C2):
-            check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1), M, ptr(w2c), ptr(b2c), ptr(y2), ptr(mask2),
-                                                stream()), "rlpyt_atari_conv2_fwd_f32")
+        # conv1 -> conv2 in ONE pass over the images at update sizes (y1 goes to conv2 through LDS and to
+        # HBM once, for the backward pass); at most one image per CU: the two latency-tuned launches
+        with ktimer.region("convs_fwd", M * (33280 + 4 * (7600 + 3456) + 4 * ATARI_MASK2_WORDS),
+                           M * (_FL_C1 + _FL_C2)):
+            check(lib.rlpyt_atari_convs_fwd_f32(ptr(obs), ptr(idx), T, B, M, ptr(w1c), ptr(b1c), ptr(w2c),
+                                                ptr(b2c), float(scale), ptr(y1), ptr(y2), ptr(mask2),
+                                                stream()), "rlpyt_atari_convs_fwd_f32")
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(obs, idx, w2c, y1, mask2)
             ctx.dims = (T, B, M, float(scale))

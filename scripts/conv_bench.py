@@ -49,6 +49,9 @@ def main():
             ptr(obs), ptr(idx), T, B, M, ptr(w1), ptr(b1), 1. / 255, ptr(y1), st)), ops._FL_C1),
         "conv2_fwd": (lambda: check(lib.rlpyt_atari_conv2_fwd_f32(
             ptr(y1), M, ptr(w2), ptr(b2), ptr(y2), ptr(mask2), st)), ops._FL_C2),
+        "convs_fwd": (lambda: check(lib.rlpyt_atari_convs_fwd_f32(
+            ptr(obs), ptr(idx), T, B, M, ptr(w1), ptr(b1), ptr(w2), ptr(b2), 1. / 255, ptr(y1), ptr(y2),
+            ptr(mask2), st)), ops._FL_C1 + ops._FL_C2),
         "conv2_bwd_x6": (lambda: check(lib.rlpyt_atari_conv2_bwd_x6_f32(
             ptr(g2), ptr(mask2), ptr(y1), M, ptr(w2), ptr(dy1), ptr(ws), ptr(dw2), ptr(db2), st)),
             ops._FL_C2D + ops._FL_C2),

@@ -17,6 +17,7 @@ GEMM_ALG = 4 * (8192 * 3456 + 512 * 3456 + 8192 * 512)
 REGIONS = {
     "conv1_fwd": (["conv1_fwd_kernel"], M * (33280 + 4 * 7600)),
     "conv2_fwd": (["conv2_fwd_x6_kernel"], M * (4 * (7600 + 3456) + 512)),
+    "convs_fwd": (["convs_fwd_fused_kernel"], M * (33280 + 4 * (7600 + 3456) + 512)),
     "conv2_bwd": (["conv2_bwd_x6_kernel"], M * (4 * (3456 + 2 * 7600) + 512)),
     "conv1_wgrad": (["conv1_wgrad_kernel"], M * (33280 + 4 * 7600)),
     "gemm_nt": (["gemm_nt_x6_kernel<128>"], GEMM_ALG),

@@ -182,8 +182,8 @@ def test_iterations_match_reference_at_split_kernel_size():
     assert algo.update_counter == n_updates == 16
     torch.cuda.synchronize()
     ran = {k for k, v in _lib.variant_counts().items() if v > 0}
-    for k in ("gemm_nt_x6_kernel<128>", "gemm_tn_x6_kernel", "conv2_fwd_x6_kernel",
-              "conv1_fwd_kernel", "conv2_bwd_x6_kernel", "conv1_wgrad_kernel",
+    for k in ("gemm_nt_x6_kernel<128>", "gemm_tn_x6_kernel", "convs_fwd_fused_kernel",
+              "conv2_bwd_x6_kernel", "conv1_wgrad_kernel",
               "ppo_head_loss_kernel<8, 6, true>"):
         assert k in ran, (k, sorted(ran))
 

@@ -167,7 +167,7 @@ def test_reference_ppo_iteration_at_bench_size_matches_product(tmp_path):
     info = algo.optimize_agent(0, samples)
     torch.cuda.synchronize()
     ran = {k for k, v in _lib.variant_counts().items() if v > 0}
-    for k in ("gemm_nt_x6_kernel", "gemm_tn_x6_kernel", "conv2_fwd", "conv1_fwd_kernel",
+    for k in ("gemm_nt_x6_kernel", "gemm_tn_x6_kernel", "convs_fwd_fused_kernel",
               "conv2_bwd_x6_kernel", "conv1_wgrad_kernel", "ppo_head_loss_kernel", "scan_exact_kernel"):
         assert any(k in r for r in ran), (k, sorted(ran))
     assert algo.update_counter == 16

@@ -76,6 +76,74 @@ def test_conv_forward_kernels(ops, M):
     assert torch.equal(mask, _sign_mask(y2))      # the sign bits of the y2 the kernel itself wrote
 
 
+# 257: one workgroup with two images, 255 with one; 1100: the steady state of the two-role pipeline
+# (five images per workgroup); 300 with a minibatch gather out of a [T, B] batch
+@pytest.mark.parametrize("M,gather", [(257, False), (300, True), (1100, False), (2100, True)])
+def test_convs_forward_fused_equals_the_two_launches(ops, M, gather):
+    """``rlpyt_atari_convs_fwd_f32`` (conv1 -> conv2 in one pass, y1 through LDS; rlpyt/models/pg/
+    atari_ff_model.py:50-51 at update sizes): y1, y2 and the sign mask are BIT-identical to
+    ``rlpyt_atari_conv1_fwd_f32`` + ``rlpyt_atari_conv2_fwd_f32`` (same arithmetic statement for
+    statement), every element is written, and y1 / y2 are the float64 convolutions to f32 accuracy."""
+    from rlpyt_amd import _lib
+    from rlpyt_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(M)
+    p64 = _params(3)
+    w1, b1, w2, b2 = (t.float().cuda().contiguous() for t in p64)
+    if gather:
+        T, B = 24, 96
+        obs = torch.randint(0, 256, (T, B, 4, 104, 80), dtype=torch.uint8, generator=g)
+        idx = torch.randperm(T * B, generator=g)[:M]
+        rows = obs.view(T * B, 4, 104, 80)[(idx % T) * B + idx // T]
+        obs_d, idx_d = obs.cuda(), idx.cuda()
+        args = (ptr(obs_d), ptr(idx_d), T, B, M)
+    else:
+        rows = obs = torch.randint(0, 256, (M, 4, 104, 80), dtype=torch.uint8, generator=g)
+        obs_d = obs.cuda()
+        args = (ptr(obs_d), None, 1, M, M)
+    out = {}
+    for tag in ("two", "fused"):
+        y1 = torch.full((M, 475, 16), float("nan"), device="cuda")
+        y2 = torch.full((M, 3456), float("nan"), device="cuda")
+        mask = torch.full((M, 128), -1, dtype=torch.int32, device="cuda")
+        if tag == "two":
+            check(lib.rlpyt_atari_conv1_fwd_f32(*args, ptr(w1), ptr(b1), 1. / 255, ptr(y1), stream()), "conv1")
+            check(lib.rlpyt_atari_conv2_fwd_f32(ptr(y1), M, ptr(w2), ptr(b2), ptr(y2), ptr(mask), stream()),
+                  "conv2")
+        else:
+            check(lib.rlpyt_atari_convs_fwd_f32(*args, ptr(w1), ptr(b1), ptr(w2), ptr(b2), 1. / 255, ptr(y1),
+                                                ptr(y2), ptr(mask), stream()), "convs")
+            assert _lib.last_variant().startswith("convs_fwd_fused_kernel"), _lib.last_variant()
+        torch.cuda.synchronize()
+        out[tag] = (y1, y2, mask)
+    for a, b, what in zip(out["two"], out["fused"], ("y1", "y2", "mask")):
+        assert not torch.isnan(b.float()).any(), what
+        assert torch.equal(a, b), (what, int((a != b).sum()))
+    _a1, y1_ref, y2_ref = _ref_stack(rows, p64)
+    _close(out["fused"][0], y1_ref, what="fused y1")
+    _close(out["fused"][1], y2_ref, rel=4e-5, what="fused y2")
+    assert torch.equal(out["fused"][2], _sign_mask(out["fused"][1]))
+
+
+def test_convs_forward_fused_small_batches_take_the_two_launches(ops):
+    """At most one image per CU: the entry point forwards to the latency-tuned pair."""
+    from rlpyt_amd import _lib
+    from rlpyt_amd._lib import check, lib, ptr, stream
+    M = 5
+    obs = torch.randint(0, 256, (M, 4, 104, 80), dtype=torch.uint8).cuda()
+    w1, b1, w2, b2 = (t.float().cuda().contiguous() for t in _params(1))
+    y1, y2 = torch.empty((M, 475, 16), device="cuda"), torch.empty((M, 3456), device="cuda")
+    mask = torch.empty((M, 128), dtype=torch.int32, device="cuda")
+    _lib.variant_reset()
+    check(lib.rlpyt_atari_convs_fwd_f32(ptr(obs), None, 1, M, M, ptr(w1), ptr(b1), ptr(w2), ptr(b2), 1. / 255,
+                                        ptr(y1), ptr(y2), ptr(mask), stream()), "convs")
+    ran = {k for k, v in _lib.variant_counts().items() if v > 0}
+    assert {"conv1_fwd_kernel", "conv2_fwd_kernel<2>", "relu_mask_kernel"} <= ran, ran
+    assert not any(k.startswith("convs_fwd_fused") for k in ran)
+    _a1, y1_ref, y2_ref = _ref_stack(obs.cpu(), _params(1))
+    _close(y1, y1_ref, what="y1")
+    _close(y2, y2_ref, rel=4e-5, what="y2")
+
+
 def test_conv_identity_weights_asymmetric(ops):
     """A=I-style check with asymmetric data: w1 picks exactly one input pixel per channel, so
     the output must be that pixel / 255 -- catches transposed row/col or swapped ky/kx maps."""

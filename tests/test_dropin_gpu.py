@@ -108,7 +108,7 @@ def test_reference_minibatch_rl_trains_product_classes_on_the_gpu(tmp_path):
     assert 0. < float(flat["entropyAverage"]) <= 1.7918 and 1. <= float(flat["perplexityAverage"]) <= 6.0001
     # the product kernels did the work: rollout step graph, GAE scan, the whole update
     for name in ("sample_convs_kernel", "rollout_fc_kernel", "rollout_head_kernel", "scan_exact_kernel",
-                 "conv1_fwd_kernel", "conv2_fwd", "gemm_nt_x6_kernel", "gemm_tn_x6_kernel",
+                 "convs_fwd_fused_kernel", "gemm_nt_x6_kernel", "gemm_tn_x6_kernel",
                  "ppo_head_loss_kernel", "conv2_bwd_x6_kernel", "conv1_wgrad_kernel",
                  "clip_adam_norm_kernel", "clip_adam_apply_kernel"):
         assert any(name in k for k in ran), (name, ran)

@@ -529,6 +529,13 @@ def _conv_fwd_large():
     Cv.test_conv_identity_weights_asymmetric(_ops())
 
 
+@case("convs_fwd_fused_kernel")
+def _convs_fwd_fused():
+    import test_conv_gpu as Cv
+    Cv.test_convs_forward_fused_equals_the_two_launches(_ops(), 300, True)
+    Cv.test_convs_forward_fused_equals_the_two_launches(_ops(), 1100, False)
+
+
 @case("conv2_bwd_x6_kernel", "conv1_wgrad_kernel", "reduce_partials_kernel")
 def _conv_bwd():
     import test_conv_gpu as Cv
