@@ -16,7 +16,8 @@ from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint
 import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librlpyt_hip.so")
+# (RLPYT_HIP_LIB: another build of the same ABI, for A/B runs of two kernel versions on one box)
+LIB_PATH = os.environ.get("RLPYT_HIP_LIB") or os.path.join(_HERE, "csrc", "librlpyt_hip.so")
 ABI_VERSION = 9
 
 

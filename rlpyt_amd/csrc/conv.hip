@@ -1783,13 +1783,14 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
 // of ONE CU are 9.4 us by themselves while three quarters of the chip idle; split four ways the
 // MFMA work per CU is ~3 us.  Both weight sets are staged in LDS with row strides chosen so the
 // per-lane operand reads (stride 256 floats in the plain layout: 16..32-way bank conflicts) are
-// at most 2-way.  conv2 accumulates in the order of conv2_fwd_kernel; conv1 is an f32-MFMA chain
-// (conv1_fwd_kernel: bf16x3, same exact products, other order).
+// at most 2-way.  conv2 accumulates in the order of conv2_fwd_kernel (f32 MFMA); conv1 is
+// conv1_fwd_kernel's bf16x3 contraction, bit for bit (round 6).
 // ======================================================================================
 constexpr int SC_THREADS = 1024;
 constexpr int SC_PARTS = 4;               // workgroups per environment (3 conv2 output rows each)
 
-constexpr int WS1 = 260;                  // staged conv1 weights: [16][260] floats
+constexpr int SC_FB = 18 * F3_PRB;        // bytes per frame of a part's image rows: 18 row pairs
+constexpr int SC_WPB = 8 * 4 * 16 * 16;   // bytes per piece of the staged conv1 weights
 constexpr int WS2 = 260, WS2_KQ = 65;     // staged conv2 weights: [32][4 x 65] floats
 
 __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
@@ -1807,9 +1808,11 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
   // read (through obs_r), so the two restrict views never touch the same bytes -- with a single
   // pointer the compiler must order each row-(t-1) load after the previous row-t store
   // (load, wait, store, load, wait, ... instead of all loads in flight together)
-  __shared__ __attribute__((aligned(16))) uint8_t img[IMG];            // 33,280 B
+  // the part's 36 image rows per frame as bf16 in conv1_fwd_kernel's entry layout (two rows x four
+  // pixels per 16 bytes), and w1 as three bf16 pieces in MFMA operand order [piece][step][kb][co][8]
+  __shared__ __attribute__((aligned(16))) uint8_t xbp[C0 * SC_FB];     // 23,040 B
+  __shared__ __attribute__((aligned(16))) uint8_t w1p[3 * SC_WPB];     // 24,576 B
   __shared__ float bs[C1 + C2];                                        // biases
-  __shared__ __attribute__((aligned(16))) float w1s[C1 * WS1];         // 16,640 B
   __shared__ __attribute__((aligned(16))) float w2s[C2 * WS2];         // 33,280 B
   __shared__ __attribute__((aligned(16))) float pad[PPIX * PS_F];      // 41,600 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1861,12 +1864,34 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
       dst_stage != nullptr ? dst_stage + b * IMG : obs_w + (t * B + lo + b) * IMG);
   loads_wait();
   if (tid < C0 * LW) {
-    reinterpret_cast<u32x4*>(img)[iw] = v;
-    const int row = fw / ROW16;
+    const int row = fw / ROW16, rr = row - r0, xq = fw - row * ROW16;
     if (row >= 26 * part && row < 26 * part + 26) dst[iw] = v;
+    uint4 lo, hi;
+    bytes_to_bf16(uint4{v[0], v[1], v[2], v[3]}, lo, hi);
+    uint8_t* d = xbp + fc * SC_FB + (rr >> 1) * F3_PRB + xq * 64 + (rr & 1) * 8;
+    *reinterpret_cast<uint2*>(d) = uint2{lo.x, lo.y};
+    *reinterpret_cast<uint2*>(d + 16) = uint2{lo.z, lo.w};
+    *reinterpret_cast<uint2*>(d + 32) = uint2{hi.x, hi.y};
+    *reinterpret_cast<uint2*>(d + 48) = uint2{hi.z, hi.w};
   }
   if (tid < C1 + C2) bs[tid] = bias_in;
-  *reinterpret_cast<u32x4*>(w1s + (tid >> 6) * WS1 + (tid & 63) * 4) = a1;
+  {
+    // w1 floats 4 tid .. + 3 = (co, c, ky, kx = 4 kx_hi ..): half of the 8-element group of
+    // (step (c, ky >> 2), kb (kx_hi, (ky >> 1) & 1)), elements 4 (ky & 1) ..; split by truncation (exact)
+    const int co = tid >> 6, kk = (tid & 63) * 4, c = kk >> 6, ky = (kk >> 3) & 7, kxh = (kk >> 2) & 1;
+    const int st = 2 * c + (ky >> 2), kbw = kxh + 2 * ((ky >> 1) & 1);
+    float x[4], r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x[e] = __uint_as_float(a1[e]);
+      r1[e] = bf16_rem(x[e]);
+      r2[e] = bf16_rem(r1[e]);
+    }
+    uint8_t* d = w1p + ((st * 4 + kbw) * 16 + co) * 16 + (ky & 1) * 8;
+    *reinterpret_cast<uint2*>(d) = uint2{pack_hi16(x[0], x[1]), pack_hi16(x[2], x[3])};
+    *reinterpret_cast<uint2*>(d + SC_WPB) = uint2{pack_hi16(r1[0], r1[1]), pack_hi16(r1[2], r1[3])};
+    *reinterpret_cast<uint2*>(d + 2 * SC_WPB) = uint2{pack_hi16(r2[0], r2[1]), pack_hi16(r2[2], r2[3])};
+  }
   {
     const float* f2 = reinterpret_cast<const float*>(&a2);
     const float* f3 = reinterpret_cast<const float*>(&a3);
@@ -1881,27 +1906,24 @@ __global__ __launch_bounds__(SC_THREADS) void sample_convs_kernel(
   float wa[64];
   const int npos = (yb - ya) * W1;                                     // <= 152
   if (wave * 16 < npos) {
-    // f32 MFMA here (one tile per wave, latency-bound: splitting the weights into bf16 pieces per
-    // launch would cost more than the 64 MFMAs); k-slot = (ky_lo, kx_hi), step = (c, ky_hi,
-    // kx_lo): one dword read per 4 K-steps.  Equal to conv1_fwd_kernel up to f32 accumulation order.
-#pragma unroll
-    for (int s = 0; s < 64; ++s) {
-      const int kc = s >> 4, ky = 2 * ((s >> 2) & 3) + (kq >> 1), kx = 4 * (kq & 1) + (s & 3);
-      wa[s] = w1s[j * WS1 + kc * 64 + ky * 8 + kx];
-    }
+    // conv1_fwd_kernel's contraction: bf16x3 (the image bytes are exact in bf16, w1 in three bf16 pieces
+    // whose sum is exact), 8 K-steps x 3 v_mfma_f32_16x16x32_bf16 in its K order and piece order -- the y1
+    // of the update path BIT for bit.  (An f32-MFMA chain here -- 64 x 32 cycles per tile, ten tiles on the
+    // four SIMDs of the CU -- was 5000+ cycles of matrix pipe per launch, the longest phase of the kernel.)
     float bias[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[r] = bs[4 * kq + r];
     const int lpos = wave * 16 + j;
     const int q = ya * W1 + min(lpos, npos - 1);
-    const int a0 = (q / W1) * (4 * W0) + (q % W1) * 4 + (kq >> 1) * W0 + 4 * (kq & 1);
+    const uint8_t* bp = xbp + (2 * (q / W1 - ya)) * F3_PRB + (q % W1) * 16 + c1_lane_off(kq);
+    const uint8_t* ap = w1p + (kq * 16 + j) * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int off = (g >> 2) * HW0 + 2 * (g & 3) * W0;
-      const uint32_t w = *reinterpret_cast<const uint32_t*>(img + a0 + off);
+    for (int st = 0; st < 8; ++st) {
+      const uint4 v0 = *reinterpret_cast<const uint4*>(bp + (st >> 1) * SC_FB + (st & 1) * 2 * F3_PRB);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = mfma16(wa[4 * g + e], (float)((w >> (8 * e)) & 0xffu), acc);
+      for (int s = 2; s >= 0; --s)     // lo, mid, hi
+        acc = mfma_bf16(*reinterpret_cast<const uint4*>(ap + s * SC_WPB + st * 1024), v0, acc);
     }
     if (lpos < npos) {
       f32x4 o;
