@@ -4,10 +4,12 @@ state dicts interchange with the reference.
 
 ``Conv2dModel.features`` is the entry the DQN-family models use: raw observations in, flattened
 features out.  For the DQN geometry (4x104x80 uint8 frames, 32-64-64 channels, kernels 8/4/3,
-strides 4/2/1, paddings 0/1/1, ReLU) a no-grad forward on the device -- every sampling step, every
-target-network pass -- runs ``rlpyt_dqn_convs_fwd_f32`` (weight packing + one f32-MFMA kernel per
-layer, ``csrc/dqn_convs.hip``) instead of ~18 library launches; anything else (autograd, other
-geometries, float images, CPU) takes the ``torch.nn.Conv2d`` modules."""
+strides 4/2/1, paddings 0/1/1, ReLU) a forward of up to ``FUSED_MAX_IMAGES`` images on the device --
+every sampling step, every target-network pass, and (round 6) the online network's pass under autograd
+-- runs ``rlpyt_dqn_convs_fwd_f32`` (weight packing + one f32-MFMA kernel per layer,
+``csrc/dqn_convs.hip``) instead of ~18 library launches; under autograd the kernels' channels-last
+activations are kept for the backward pass (``ops.dqn_convs``).  Anything else (other geometries,
+float images, larger batches, CPU) takes the ``torch.nn.Conv2d`` modules."""
 import os
 
 import torch
@@ -75,8 +77,12 @@ class Conv2dModel(torch.nn.Module):
             return None
         return self._packed
 
+    # set False (or RLPYT_DQN_CONVS_GRAD=0) for the library convolutions in the forward under autograd
+    use_fused_grad_convs = os.environ.get("RLPYT_DQN_CONVS_GRAD", "1") != "0"
+
     def _fused_ok(self, observation, T_B, img_shape):
-        return (self.use_fused_nograd_convs and self._dqn_geometry and not torch.is_grad_enabled()
+        on = self.use_fused_grad_convs if torch.is_grad_enabled() else self.use_fused_nograd_convs
+        return (on and self._dqn_geometry
                 and observation.is_cuda and observation.dtype == torch.uint8
                 and tuple(img_shape) == (4, 104, 80) and 0 < T_B <= self.FUSED_MAX_IMAGES
                 and self.conv[0].weight.dtype == torch.float32 and self.conv[0].weight.is_cuda
@@ -88,6 +94,9 @@ class Conv2dModel(torch.nn.Module):
         if self._fused_ok(observation, T_B, img_shape):
             from .. import ops
             c1, c2, c3 = self.conv[0], self.conv[2], self.conv[4]
+            if torch.is_grad_enabled():          # online network of an update: own forward, kept activations
+                return ops.dqn_convs(observation.reshape(T_B, *img_shape).contiguous(), c1.weight, c1.bias,
+                                     c2.weight, c2.bias, c3.weight, c3.bias)
             packed = self._current_pack(observation.device)
             return ops.dqn_convs_fwd(observation.reshape(T_B, *img_shape).contiguous(), c1.weight, c1.bias,
                                      c2.weight, c2.bias, c3.weight, c3.bias, packed=packed)

@@ -1110,6 +1110,56 @@ def dqn_convs_fwd(obs, w1, b1, w2, b2, w3, b3, scale=1. / 255, out=None, packed=
     return out
 
 
+class _DqnConvStack(torch.autograd.Function):
+    """The DQN conv stack UNDER AUTOGRAD at update-batch sizes (the online network's pass of
+    rlpyt/algos/dqn/dqn.py:176-180 through rlpyt/models/dqn/atari_dqn_model.py:33-45): the forward is
+    the three own layer kernels of ``dqn_convs_fwd`` (uint8 in, bias + ReLU in the epilogues, no
+    conversion / bias / clamp / layout launches), whose channels-last activations y1 / y2 stay in the
+    call's workspace for the backward pass."""
+
+    @staticmethod
+    def forward(ctx, obs, w1, b1, w2, b2, w3, b3, scale):
+        _lib.require_gpu()
+        N = obs.shape[0]
+        params = tuple(x.detach().contiguous() for x in (w1, b1, w2, b2, w3, b3))
+        ws = torch.empty(int(lib.rlpyt_dqn_convs_workspace_floats(N)), dtype=torch.float32,
+                         device=obs.device)
+        out = torch.empty((N, 6912), dtype=torch.float32, device=obs.device)
+        check(lib.rlpyt_dqn_convs_fwd_f32(ptr(obs), N, *(ptr(x) for x in params), None, float(scale),
+                                          ptr(ws), ptr(out), stream()), "rlpyt_dqn_convs_fwd_f32")
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(obs, params[0], params[2], params[4], ws, out)
+            ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        obs, w1, w2, w3, ws, out = ctx.saved_tensors
+        N = obs.shape[0]
+        p0 = int(lib.rlpyt_dqn_convs_packed_floats())
+        n1 = N * 475 * 32
+        # logical NCHW views of the kernels' channels-last activations
+        y1 = ws[p0:p0 + n1].view(N, 25, 19, 32).permute(0, 3, 1, 2)
+        y2 = ws[p0 + n1:p0 + n1 + N * 108 * 64].view(N, 12, 9, 64).permute(0, 3, 1, 2)
+        y3 = out.view(N, 64, 12, 9)
+        cb = torch.ops.aten.convolution_backward
+        dz3 = (_f32(g).view(N, 64, 12, 9) * (y3 > 0)).contiguous(memory_format=torch.channels_last)
+        dy2, dw3, db3 = cb(dz3, y2, w3, [64], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, True, True])
+        dz2 = dy2 * (y2 > 0)
+        dy1, dw2, db2 = cb(dz2, y1, w2, [64], [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, True, True])
+        dz1 = dy1 * (y1 > 0)
+        x0 = obs_to_nhwc_f32(obs, scale=ctx.scale)
+        _, dw1, db1 = cb(dz1, x0, w1, [32], [4, 4], [0, 0], [1, 1], False, [0, 0], 1, [False, True, True])
+        return None, dw1, db1, dw2, db2, dw3, db3, None
+
+
+def dqn_convs(obs, w1, b1, w2, b2, w3, b3, scale=1. / 255):
+    """``dqn_convs_fwd`` differentiable w.r.t. the six conv parameters (uint8 ``[N,4,104,80]`` in,
+    ``[N, 6912]`` out in the order of ``conv(img).view(N, -1)``)."""
+    assert obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape[1:]) == (4, 104, 80)
+    return _DqnConvStack.apply(obs, w1, b1, w2, b2, w3, b3, scale)
+
+
 def mlp_q_head_ok(x, lin1, lin2):
     """Whether ``mlp_q_head`` serves ``lin2(relu(lin1(x)))``: no autograd, f32 on the device, at most
     256 rows, hidden width 256 / 512, at most 18 outputs."""

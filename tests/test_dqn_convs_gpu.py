@@ -141,7 +141,11 @@ def test_dqn_family_models_dispatch_to_the_fused_convs(lead):
             fused = m(obs, pa, pr)
         assert ran_fused()
         _lib.variant_reset()
-        grad = m(obs, pa, pr)                      # autograd: library convolutions
+        grad = m(obs, pa, pr)                      # autograd: the same kernels, activations kept
+        assert ran_fused() and grad.requires_grad
+        m.conv.use_fused_grad_convs = False
+        _lib.variant_reset()
+        grad = m(obs, pa, pr)                      # autograd through the library convolutions
         assert not ran_fused() and grad.requires_grad
         m.conv.use_fused_nograd_convs = False
         with torch.no_grad():
@@ -160,6 +164,48 @@ def test_dqn_family_models_dispatch_to_the_fused_convs(lead):
             q2, s2 = m(obs, pa, pr, None)
         np.testing.assert_allclose(q1.cpu().numpy(), q2.cpu().numpy(), rtol=2e-4, atol=2e-6)
         np.testing.assert_allclose(s1.h.cpu().numpy(), s2.h.cpu().numpy(), rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("N", [1, 32, 128, 300])
+def test_dqn_convs_under_autograd_gradients_match_the_library_path(N):
+    """``ops.dqn_convs`` (own forward kernels, channels-last activations kept, backward through the
+    library's convolution_backward on them): features and all six parameter gradients against the
+    ``torch.nn.Conv2d`` modules in float64, held to three times the f32 module path's own error."""
+    from rlpyt_amd import ops
+    convs = _stack(40 + N)
+    g = torch.Generator().manual_seed(N)
+    obs = torch.randint(0, 256, (N, 4, 104, 80), dtype=torch.uint8, generator=g)
+    cot = torch.randn(N, 6912, generator=g)
+
+    def module_path(dtype, device):
+        cs = [torch.nn.Conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding)
+              .to(device=device, dtype=dtype) for c in convs]
+        for c, src in zip(cs, convs):
+            c.load_state_dict({k: v.to(dtype) for k, v in src.state_dict().items()})
+        x = obs.to(device=device, dtype=dtype) * (1. / 255)
+        for c in cs:
+            x = torch.relu(c(x))
+        y = x.reshape(N, -1)
+        y.backward(cot.to(device=device, dtype=dtype))
+        return y.detach().cpu().double(), [p.grad.detach().cpu().double() for c in cs for p in c.parameters()]
+
+    y64, g64 = module_path(torch.float64, "cpu")
+    y32, g32 = module_path(torch.float32, "cuda")
+    dev = [torch.nn.Conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding).cuda()
+           for c in convs]
+    for c, src in zip(dev, convs):
+        c.load_state_dict(src.state_dict())
+    y = ops.dqn_convs(obs.cuda(), *[p for c in dev for p in (c.weight, c.bias)])
+    y.backward(cot.cuda())
+    torch.cuda.synchronize()
+    got = [p.grad.detach().cpu().double() for c in dev for p in c.parameters()]
+
+    def rel(a, b):
+        return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+    assert rel(y.detach().cpu().double(), y64) <= max(3 * rel(y32, y64), 3e-7)
+    for k, (a, b32, b64) in enumerate(zip(got, g32, g64)):
+        assert a.shape == b64.shape
+        assert rel(a, b64) <= max(3 * rel(b32, b64), 2e-6), (k, rel(a, b64), rel(b32, b64))
 
 
 def test_packed_weights_are_made_once_per_sampling_phase_and_never_stale_in_training():
