@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 9
+#define RLPYT_HIP_ABI_VERSION 10
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -577,6 +577,21 @@ int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const float* w1, cons
                             const float* w2, const float* b2, const float* w3, const float* b3,
                             const float* packed /*nullable*/, float scale, float* workspace, float* out,
                             rlpyt_stream_t stream);
+
+/* Backward pass of the same stack at update-batch sizes (round 6, ABI 10): autograd through
+ * `self.conv` of rlpyt/models/dqn/atari_dqn_model.py:30-37 in the online network's pass of DQN.loss
+ * (rlpyt/algos/dqn/dqn.py:176-180).  y1 [N][475][32] and y2 [N][108][64] are the channels-last
+ * activations rlpyt_dqn_convs_fwd_f32 left in its workspace (behind the packed weights), y3 = its
+ * output [N][64*108], g3 = dL/dy3 in the same layout.  ReLU masks from the activations, bias
+ * gradients = column sums; gradients OVERWRITE dw / db (torch layouts).  Weight packing + two data-
+ * gradient kernels + three weight-gradient kernels + one fixed-order reduction of their per-image-
+ * group partials (deterministic); f32 MFMA, f32 accumulate.  `workspace`:
+ * rlpyt_dqn_convs_bwd_workspace_floats(N) floats, 16-byte aligned. */
+int64_t rlpyt_dqn_convs_bwd_workspace_floats(int64_t N);
+int rlpyt_dqn_convs_bwd_f32(const uint8_t* obs, int64_t N, const float* w2, const float* w3,
+                            const float* y1, const float* y2, const float* y3, const float* g3,
+                            float scale, float* workspace, float* dw1, float* db1, float* dw2,
+                            float* db2, float* dw3, float* db3, rlpyt_stream_t stream);
 
 /* conv2 backward in one pass (dgrad + both ReLU masks + weight / bias gradients; g2 / y1 read once,
  * conv2's ReLU mask from relu_mask as written by rlpyt_atari_conv2_fwd_f32), both contractions on

@@ -1138,6 +1138,19 @@ class _DqnConvStack(torch.autograd.Function):
         N = obs.shape[0]
         p0 = int(lib.rlpyt_dqn_convs_packed_floats())
         n1 = N * 475 * 32
+        if DQN_CONVS_OWN_BWD:
+            # the own backward kernels (csrc/dqn_convs_bwd.hip): masks, bias sums and the three weight
+            # gradients from the kept channels-last activations, one call
+            g = _f32(g)
+            dws = torch.empty(int(lib.rlpyt_dqn_convs_bwd_workspace_floats(N)), dtype=torch.float32,
+                              device=obs.device)
+            grads = [torch.empty_like(w1), torch.empty(32, dtype=torch.float32, device=obs.device),
+                     torch.empty_like(w2), torch.empty(64, dtype=torch.float32, device=obs.device),
+                     torch.empty_like(w3), torch.empty(64, dtype=torch.float32, device=obs.device)]
+            check(lib.rlpyt_dqn_convs_bwd_f32(
+                ptr(obs), N, ptr(w2), ptr(w3), ptr(ws[p0:]), ptr(ws[p0 + n1:]), ptr(out), ptr(g),
+                ctx.scale, ptr(dws), *(ptr(x) for x in grads), stream()), "rlpyt_dqn_convs_bwd_f32")
+            return (None, *grads, None)
         # logical NCHW views of the kernels' channels-last activations
         y1 = ws[p0:p0 + n1].view(N, 25, 19, 32).permute(0, 3, 1, 2)
         y2 = ws[p0 + n1:p0 + n1 + N * 108 * 64].view(N, 12, 9, 64).permute(0, 3, 1, 2)
@@ -1151,6 +1164,10 @@ class _DqnConvStack(torch.autograd.Function):
         x0 = obs_to_nhwc_f32(obs, scale=ctx.scale)
         _, dw1, db1 = cb(dz1, x0, w1, [32], [4, 4], [0, 0], [1, 1], False, [0, 0], 1, [False, True, True])
         return None, dw1, db1, dw2, db2, dw3, db3, None
+
+
+# A/B switch: the conv stack's backward through the library's convolution_backward instead
+DQN_CONVS_OWN_BWD = os.environ.get("RLPYT_DQN_OWN_BWD", "1") != "0"
 
 
 def dqn_convs(obs, w1, b1, w2, b2, w3, b3, scale=1. / 255):

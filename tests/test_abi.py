@@ -85,3 +85,14 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert b"Kp >= F + A + 1 + H" in lib.rlpyt_hip_last_error()
     assert lib.rlpyt_dqn_convs_packed_floats() == 32 * 256 + 64 * 512 + 64 * 576
     assert lib.rlpyt_dqn_convs_workspace_floats(10) == 77824 + 10 * (475 * 32 + 108 * 64)
+    # backward of the same stack (ABI 10)
+    assert lib.rlpyt_dqn_convs_bwd_f32(None, 0, *([None] * 6), 1.0, *([None] * 8)) == OK
+    assert lib.rlpyt_dqn_convs_bwd_f32(None, -2, *([None] * 6), 1.0, *([None] * 8)) == -1
+    assert lib.rlpyt_dqn_convs_bwd_f32(None, 4, *([None] * 6), 1.0, *([None] * 8)) != OK
+    assert b"null pointer" in lib.rlpyt_hip_last_error()
+    assert lib.rlpyt_dqn_convs_bwd_workspace_floats(0) == 0
+    # packed transposed weights + dz2 + dz1 + one partial per image group and layer
+    n = 128
+    want = (36864 + 32768) + n * (108 * 64 + 475 * 32) + 128 * (32 * 256 + 32) + 64 * (64 * 512 + 64) \
+        + 64 * (64 * 576 + 64)
+    assert lib.rlpyt_dqn_convs_bwd_workspace_floats(n) == want

@@ -166,12 +166,82 @@ def test_dqn_family_models_dispatch_to_the_fused_convs(lead):
         np.testing.assert_allclose(s1.h.cpu().numpy(), s2.h.cpu().numpy(), rtol=2e-4, atol=2e-6)
 
 
-@pytest.mark.parametrize("N", [1, 32, 128, 300])
-def test_dqn_convs_under_autograd_gradients_match_the_library_path(N):
-    """``ops.dqn_convs`` (own forward kernels, channels-last activations kept, backward through the
-    library's convolution_backward on them): features and all six parameter gradients against the
-    ``torch.nn.Conv2d`` modules in float64, held to three times the f32 module path's own error."""
+@pytest.mark.parametrize("own_bwd", [True, False])
+@pytest.mark.parametrize("N", [1, 2, 32, 128, 257, 300])
+def test_dqn_convs_under_autograd_gradients_match_the_library_path(N, own_bwd):
+    """``ops.dqn_convs`` (own forward kernels, channels-last activations kept; backward = the own
+    kernels of csrc/dqn_convs_bwd.hip, or -- ``own_bwd=False``, the A/B switch -- the library's
+    convolution_backward on the kept activations): features and all six parameter gradients against
+    the ``torch.nn.Conv2d`` modules in float64, held to three times the f32 module path's own error.
+    N = 1 .. 300: one image per workgroup, several images per weight-gradient workgroup (N > 64 / 128),
+    ragged last group (257, 300)."""
+    from rlpyt_amd import _lib, ops
+    was = ops.DQN_CONVS_OWN_BWD
+    ops.DQN_CONVS_OWN_BWD = own_bwd
+    try:
+        _lib.variant_reset()
+        _gradient_case(ops, N)
+        ran = any("dqn_wgrad1_kernel" in k for k in _lib.variant_counts())
+        assert ran == own_bwd
+    finally:
+        ops.DQN_CONVS_OWN_BWD = was
+
+
+def test_dqn_convs_backward_is_deterministic_and_overwrites():
+    """The weight-gradient partials are summed in a fixed order: two backward passes over the same
+    batch give bit-identical gradients (also into buffers holding stale values)."""
     from rlpyt_amd import ops
+    convs = [c.cuda() for c in _stack(77)]
+    g = torch.Generator().manual_seed(5)
+    obs = torch.randint(0, 256, (130, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    cot = torch.randn(130, 6912, generator=g).cuda()
+    params = [p for c in convs for p in (c.weight, c.bias)]
+    runs = []
+    for _ in range(2):
+        for p in params:
+            p.grad = None
+        ops.dqn_convs(obs, *params).backward(cot)
+        runs.append([p.grad.clone() for p in params])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
+def test_dqn_convs_backward_dead_and_saturated_units():
+    """Biases that switch whole channels off (ReLU mask all zero: exact zero gradients through them)
+    next to channels that are always on."""
+    from rlpyt_amd import ops
+    convs = _stack(78)
+    with torch.no_grad():
+        convs[0].bias[:8] = -50.
+        convs[1].bias[5:20] = -50.
+        convs[2].bias[60:] = -50.
+        convs[2].bias[:4] = 50.
+    dev = [torch.nn.Conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding).cuda()
+           for c in convs]
+    for c, src in zip(dev, convs):
+        c.load_state_dict(src.state_dict())
+    g = torch.Generator().manual_seed(6)
+    obs = torch.randint(0, 256, (9, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    cot = torch.randn(9, 6912, generator=g).cuda()
+    ops.dqn_convs(obs, *[p for c in dev for p in (c.weight, c.bias)]).backward(cot)
+    ref = [torch.nn.Conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding).double()
+           for c in convs]
+    for c, src in zip(ref, convs):
+        c.load_state_dict({k: v.double() for k, v in src.state_dict().items()})
+    x = obs.cpu().double() * (1. / 255)
+    for c in ref:
+        x = torch.relu(c(x))
+    x.reshape(9, -1).backward(cot.cpu().double())
+    assert torch.equal(dev[0].weight.grad[:8].cpu(), torch.zeros(8, 4, 8, 8))
+    assert torch.equal(dev[1].bias.grad[5:20].cpu(), torch.zeros(15))
+    assert torch.equal(dev[2].weight.grad[60:].cpu(), torch.zeros(4, 64, 3, 3))
+    for c, r in zip(dev, ref):
+        for a, b in zip(c.parameters(), r.parameters()):
+            scale = b.grad.abs().max().item() + 1e-30
+            assert (a.grad.cpu().double() - b.grad).abs().max().item() / scale < 5e-6
+
+
+def _gradient_case(ops, N):
     convs = _stack(40 + N)
     g = torch.Generator().manual_seed(N)
     obs = torch.randint(0, 256, (N, 4, 104, 80), dtype=torch.uint8, generator=g)

@@ -570,6 +570,14 @@ def _dqn_convs():
     D.test_dqn_convs_identity_like_weights_asymmetric()
 
 
+@case("dqn_pack_bwd_weights_kernel", "dqn_dgrad3_kernel", "dqn_dgrad2_kernel", "dqn_wgrad1_kernel",
+      "dqn_wgrad23_kernel<32, 25, 19, 4, 4, 2, 8, false>",
+      "dqn_wgrad23_kernel<64, 12, 9, 3, 3, 1, 12, true>", "dqn_bwd_reduce_kernel")
+def _dqn_convs_bwd():
+    import test_dqn_convs_gpu as D
+    D.test_dqn_convs_under_autograd_gradients_match_the_library_path(32, True)
+
+
 @case("lstm_seq_step_kernel<8>", "lstm_seq_step_kernel<4>")
 def _lstm_seq():
     import test_lstm_seq_gpu as L
