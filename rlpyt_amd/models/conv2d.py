@@ -4,7 +4,8 @@ state dicts interchange with the reference.
 
 ``Conv2dModel.features`` is the entry the DQN-family models use: raw observations in, flattened
 features out.  For the DQN geometry (4x104x80 uint8 frames, 32-64-64 channels, kernels 8/4/3,
-strides 4/2/1, paddings 0/1/1, ReLU) a forward of up to ``FUSED_MAX_IMAGES`` images on the device --
+strides 4/2/1, paddings 0/1/1, ReLU) a forward of up to ``FUSED_MAX_IMAGES`` (no-grad) /
+``FUSED_MAX_IMAGES_GRAD`` (autograd) images on the device --
 every sampling step, every target-network pass, and (round 6) the online network's pass under autograd
 -- runs ``rlpyt_dqn_convs_fwd_f32`` (weight packing + one f32-MFMA kernel per layer,
 ``csrc/dqn_convs.hip``) instead of ~18 library launches; under autograd the kernels' channels-last
@@ -41,7 +42,13 @@ class Conv2dModel(torch.nn.Module):
 
     # set False (or RLPYT_DQN_CONVS=0) for the library convolutions in no-grad forwards too (A/B tests)
     use_fused_nograd_convs = os.environ.get("RLPYT_DQN_CONVS", "1") != "0"
-    FUSED_MAX_IMAGES = 1024         # beyond sampling / target-batch sizes the library kernels are the tuned ones
+    # No-grad forwards: the own kernels win at every size measured (N = 128 .. 5440: 60 / 135 us ..
+    # 1780 / 2165 us own / library, profiles/r6_dqn_convs_large_n.log) -- bounded only by the workspace
+    # (88 KB of kept activations per image).  Under autograd forward + backward are level with the
+    # library from ~2500 images on (2614 / 2620 us at 2560, 5626 / 5317 us at 5440): R2D1's 5440-image
+    # online pass stays on the library.
+    FUSED_MAX_IMAGES = int(os.environ.get("RLPYT_DQN_CONVS_MAX_N", 1 << 15))     # (env: A/B runs)
+    FUSED_MAX_IMAGES_GRAD = 2560
 
     _packed = None                  # the weights in the kernels' register order (sampling only)
 
@@ -81,10 +88,12 @@ class Conv2dModel(torch.nn.Module):
     use_fused_grad_convs = os.environ.get("RLPYT_DQN_CONVS_GRAD", "1") != "0"
 
     def _fused_ok(self, observation, T_B, img_shape):
-        on = self.use_fused_grad_convs if torch.is_grad_enabled() else self.use_fused_nograd_convs
+        grad = torch.is_grad_enabled()
+        on = self.use_fused_grad_convs if grad else self.use_fused_nograd_convs
+        limit = self.FUSED_MAX_IMAGES_GRAD if grad else self.FUSED_MAX_IMAGES
         return (on and self._dqn_geometry
                 and observation.is_cuda and observation.dtype == torch.uint8
-                and tuple(img_shape) == (4, 104, 80) and 0 < T_B <= self.FUSED_MAX_IMAGES
+                and tuple(img_shape) == (4, 104, 80) and 0 < T_B <= limit
                 and self.conv[0].weight.dtype == torch.float32 and self.conv[0].weight.is_cuda
                 and all(self.conv[i].weight.is_contiguous() for i in (0, 2, 4)))
 

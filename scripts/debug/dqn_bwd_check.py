@@ -65,17 +65,22 @@ def rel(a, b):
     return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
 
 
-for N in [int(a) for a in sys.argv[1:]] or [1, 32, 128, 300]:
-    convs = stack(40 + N)
-    g = torch.Generator().manual_seed(N)
-    obs = torch.randint(0, 256, (N, 4, 104, 80), dtype=torch.uint8, generator=g)
-    cot = torch.randn(N, 6912, generator=g)
-    g64 = module_path(convs, obs, cot, torch.float64, "cpu")
-    g32 = module_path(convs, obs, cot, torch.float32, "cuda")
-    own, t_own = own_path(convs, obs, cot, True)
-    libp, t_lib = own_path(convs, obs, cot, False)
-    names = ["dw1", "db1", "dw2", "db2", "dw3", "db3"]
-    print(f"N={N}: fwd+bwd own {t_own:.1f} us, library backward {t_lib:.1f} us")
-    for k, nm in enumerate(names):
-        print(f"  {nm}: own {rel(own[k], g64[k]):.3e}  lib-on-kept {rel(libp[k], g64[k]):.3e}  "
-              f"module-f32 {rel(g32[k], g64[k]):.3e}")
+def main():
+    for N in [int(a) for a in sys.argv[1:]] or [1, 32, 128, 300]:
+        convs = stack(40 + N)
+        g = torch.Generator().manual_seed(N)
+        obs = torch.randint(0, 256, (N, 4, 104, 80), dtype=torch.uint8, generator=g)
+        cot = torch.randn(N, 6912, generator=g)
+        g64 = module_path(convs, obs, cot, torch.float64, "cpu")
+        g32 = module_path(convs, obs, cot, torch.float32, "cuda")
+        own, t_own = own_path(convs, obs, cot, True)
+        libp, t_lib = own_path(convs, obs, cot, False)
+        names = ["dw1", "db1", "dw2", "db2", "dw3", "db3"]
+        print(f"N={N}: fwd+bwd own {t_own:.1f} us, library backward {t_lib:.1f} us")
+        for k, nm in enumerate(names):
+            print(f"  {nm}: own {rel(own[k], g64[k]):.3e}  lib-on-kept {rel(libp[k], g64[k]):.3e}  "
+                  f"module-f32 {rel(g32[k], g64[k]):.3e}")
+
+
+if __name__ == "__main__":
+    main()
