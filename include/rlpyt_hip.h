@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 10
+#define RLPYT_HIP_ABI_VERSION 11
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -556,6 +556,22 @@ int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void);
  * step; H in {256, 512}. */
 int rlpyt_lstm_seq_f32(const float* xproj, const float* w_hh, const float* h0, float* c, float* out,
                        int T, int B, int H, rlpyt_stream_t stream);
+/* The same sequence under autograd (round 6, ABI 11): the online network's training pass of
+ * rlpyt/algos/dqn/r2d1.py:286-334 through the torch.nn.LSTM of atari_r2d1_model.py:61-63.
+ * rlpyt_lstm_seq_train_f32 = rlpyt_lstm_seq_f32 that also keeps what the backward pass needs:
+ *   gates [T,B,H,4] (activated i, f, g, o of every (step, sequence, unit)) and c_all [T,B,H] (c_1..c_T).
+ * rlpyt_lstm_seq_bwd_f32 = back-propagation through time, one launch per step from T-1 to 0:
+ *   dout [T,B,H] = dL/d out (nullable), dhn [B,H] = extra gradient into h_T (nullable),
+ *   c0 [B,H] the initial cell state, w_hh_t [H,4H] = W_hh^T (made by the caller),
+ *   dc [B,H]: dL/dc_T on entry (zeros if none), dL/dc_0 on return,
+ *   dgates [T,B,4H] out: gradient w.r.t. the pre-activation gates in the module's order -- the caller
+ *   takes dx = dgates W_ih, dW_ih = dgates^T x, dW_hh = dgates^T [h0; out_1..T-1], db = column sums;
+ *   dh0 [B,H] out (nullable: one launch less).  Deterministic (fixed summation order). */
+int rlpyt_lstm_seq_train_f32(const float* xproj, const float* w_hh, const float* h0, float* c, float* out,
+                             float* gates, float* c_all, int T, int B, int H, rlpyt_stream_t stream);
+int rlpyt_lstm_seq_bwd_f32(const float* dout, const float* dhn, const float* gates, const float* c_all,
+                           const float* c0, const float* w_hh_t, float* dc, float* dgates, float* dh0,
+                           int T, int B, int H, rlpyt_stream_t stream);
 
 /* No-grad forward of the DQN-family conv stack with its default geometry -- Conv2d(4,32,8,s4) ReLU
  * Conv2d(32,64,4,s2,p1) ReLU Conv2d(64,64,3,s1,p1) ReLU, flattened: `self.conv` of

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (RLPYT_HIP_LIB: another build of the same ABI, for A/B runs of two kernel versions on one box)
 LIB_PATH = os.environ.get("RLPYT_HIP_LIB") or os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class CopyDesc(ctypes.Structure):
@@ -144,6 +144,8 @@ _SIGNATURES = {
     "rlpyt_rnn_step_inputs_f32": (c_int, [_p, c_int, c_int, _p, c_int, _p, _p, _p, _p, c_int, _p, c_int, _p,
                                           _p, c_int64, _p]),
     "rlpyt_lstm_seq_f32": (c_int, [_p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
+    "rlpyt_lstm_seq_train_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
+    "rlpyt_lstm_seq_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
     "rlpyt_dqn_convs_workspace_floats": (c_int64, [c_int64]),
     "rlpyt_dqn_convs_packed_floats": (c_int64, []),
     "rlpyt_dqn_convs_pack_f32": (c_int, [_p, _p, _p, _p, _p]),

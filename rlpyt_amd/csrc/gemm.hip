@@ -22,7 +22,10 @@
 // profiles/r5_ab_presplit_weight.jsonl, r5_gemm_bench_presplit_weight.json: three 8-byte loads per
 // thread and step instead of one 16-byte load.  The kernel is bound by its vector-memory requests,
 // not by the split VALU beside the MFMAs; removed.)
+#include <stdlib.h>
+
 #include <algorithm>
+
 #include "common.h"
 
 namespace rlpyt {
@@ -115,11 +118,16 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
     tm = xcd * R + rem / cw;
     tn = 4 * cb + rem % cw;
   } else {
+    // any other row-block count (the row ranges of a split launch, below): tiles numbered panel-major
+    // (4 column tiles x all row blocks per panel), XCD c takes the numbers [c n/8, (c+1) n/8) -- the 32
+    // workgroups an XCD runs together are 8 row blocks x 4 column tiles
     const int per_xcd = (n_tiles + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= n_tiles) return;
-    tm = tile / tiles_n;
-    tn = tile - tm * tiles_n;
+    const int li = blockIdx.x >> 3, tile = (blockIdx.x & 7) * per_xcd + li;
+    if (li >= per_xcd || tile >= n_tiles) return;
+    const int cb = tile / (4 * tiles_m), rem = tile - cb * 4 * tiles_m;
+    const int cw = min(4, tiles_n - 4 * cb);
+    tm = rem / cw;
+    tn = 4 * cb + rem % cw;
   }
 
   // staging map: float4 f = tid + 512 i = (row = f >> 2, kq = f & 3); rows clamped at the edge
@@ -269,6 +277,37 @@ __global__ __launch_bounds__(G_THREADS) void gemm_nt_x6_kernel(
     }
 }
 
+// Row blocks of 256 for the first launch of rlpyt_gemm_nt_f32's tall shapes (0: all rows as 128-row
+// tiles; ceil(M / 256): one launch, as before round 6).  Cost in rounds of one tile per CU; a round of
+// 128-row tiles is priced at 0.55 of a 256-row round (measured: scripts/gemm_bench.py --nt-split).
+// RLPYT_GEMM_NT_R256 overrides (A/B runs).
+int gemm_nt_plan(int64_t M, int tiles_n) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess &&
+            p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  const int all = (int)ceil_div(M, 256);
+  if (const char* e = getenv("RLPYT_GEMM_NT_R256")) {
+    const int r = atoi(e);
+    return r < 0 ? all : std::min(r, all);
+  }
+  int best = all;
+  double best_cost = 1e30;
+  for (int r = all; r >= 0; --r) {
+    const int64_t rest = std::max<int64_t>(0, M - (int64_t)r * 256);
+    const double cost = (double)ceil_div((int64_t)r * tiles_n, n_cu) +
+                        0.55 * (double)ceil_div(ceil_div(rest, 128) * tiles_n, n_cu);
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = r;
+    }
+  }
+  return best;
+}
+
 }  // namespace
 }  // namespace rlpyt
 
@@ -291,13 +330,24 @@ extern "C" int rlpyt_gemm_nt_f32(const float* a, const float* b, float* c, int64
                RLPYT_ESHAPE, "rlpyt_gemm_nt_f32: a / b must be 16-byte aligned");
   const int tiles_n = (int)ceil_div(N, GT);
   hipStream_t s = (hipStream_t)stream;
-  // 256-row tiles when they still fill the chip twice over (the trunk's input gradient: 32 x 27)
-  if (ceil_div(M, 256) * tiles_n >= 512) {
-    const int tiles_m = (int)ceil_div(M, 256);
-    const int grid = 8 * ((tiles_m * tiles_n + 7) / 8);     // whole rounds over the 8 XCDs
-    RL_LAUNCH((gemm_nt_x6_kernel<256>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, (int)N,
-              (int)K, tiles_m, tiles_n);
-  } else {
+  // 256-row tiles when they still fill the chip twice over (the trunk's input gradient: 32 x 27 tiles).
+  // One workgroup per CU (LDS), so the launch runs in whole rounds of n_cu tiles: 864 tiles on 256 CUs
+  // are 4 rounds, the last one 3/8 full.  The rows are therefore cut in two launches where that is
+  // shorter by the round count: the first `r256` row blocks as 256-row tiles, the rows behind them as
+  // 128-row tiles (a round of those costs ~0.55 of a 256-row round: gemm_nt_plan).
+  int r256 = 0;
+  if (ceil_div(M, 256) * tiles_n >= 512) r256 = gemm_nt_plan(M, tiles_n);
+  if (r256 > 0) {
+    const int64_t m256 = std::min<int64_t>(M, (int64_t)r256 * 256);
+    const int grid = 8 * ((r256 * tiles_n + 7) / 8);     // whole rounds over the 8 XCDs
+    RL_LAUNCH((gemm_nt_x6_kernel<256>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)m256, (int)N,
+              (int)K, r256, tiles_n);
+    RL_LAUNCH_CHECK();
+    a += m256 * K;
+    c += m256 * N;
+    M -= m256;
+  }
+  if (M > 0) {
     const int tiles_m = (int)ceil_div(M, GT);
     const int grid = 8 * ((tiles_m * tiles_n + 7) / 8);
     RL_LAUNCH((gemm_nt_x6_kernel<128>), dim3(grid), dim3(G_THREADS), 0, s, a, b, c, (int)M, (int)N,

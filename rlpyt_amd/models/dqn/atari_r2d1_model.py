@@ -118,6 +118,11 @@ class AtariR2d1Model(torch.nn.Module):
                 lstm_out, (hn, cn) = ops.lstm_sequence(self.lstm, lstm_input, *(state or (None, None)))
                 q = self.head(lstm_out.reshape(T * B, -1))
                 return restore_leading_dims(q, lead_dim, T, B), RnnState(h=hn, c=cn)
+            if ops.lstm_sequence_train_ok(self.lstm, lstm_input, None if state is None else state[0]):
+                # the online network's training pass: own forward (gates kept) + own BPTT
+                lstm_out, (hn, cn) = ops.lstm_sequence_train(self.lstm, lstm_input, *(state or (None, None)))
+                q = self.head(lstm_out.reshape(T * B, -1))
+                return restore_leading_dims(q, lead_dim, T, B), RnnState(h=hn, c=cn)
         lstm_out, (hn, cn) = self.lstm(lstm_input, state)
         q = self.head(lstm_out.reshape(T * B, -1))
         return restore_leading_dims(q, lead_dim, T, B), RnnState(h=hn, c=cn)

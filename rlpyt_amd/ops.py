@@ -956,6 +956,86 @@ def lstm_sequence(lstm, x, h0=None, c0=None):
     return out, (hn, c.unsqueeze(0))
 
 
+class _LstmSeqTrain(torch.autograd.Function):
+    """``torch.nn.LSTM`` (one layer) over ``x [T,B,I]`` UNDER AUTOGRAD on the own step kernels
+    (csrc/lstm_seq.hip): forward = input projection of all steps (one GEMM) + one launch per step that
+    keeps the activated gates and cell states; backward = one launch per step (recurrent gradient +
+    the cell's pointwise backward) + four GEMMs over all steps for dx / dW_ih / dW_hh and the bias sums.
+    The online network's training pass of R2D1 (rlpyt/algos/dqn/r2d1.py:286-334 through
+    rlpyt/models/dqn/atari_r2d1_model.py:61-63)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh):
+        _lib.require_gpu()
+        T, B, I = x.shape
+        H = w_hh.shape[1]
+        x2 = _f32(x).reshape(T * B, I)
+        w_ih_d, w_hh_d = w_ih.detach().contiguous(), w_hh.detach().contiguous()
+        xproj = torch.addmm(b_ih.detach() + b_hh.detach(), x2, w_ih_d.t())
+        h0 = _f32(h0.detach().reshape(B, H))
+        c0 = _f32(c0.detach().reshape(B, H))
+        c = c0.clone()
+        out = torch.empty((T, B, H), dtype=torch.float32, device=x.device)
+        gates = torch.empty((T, B, H, 4), dtype=torch.float32, device=x.device)
+        c_all = torch.empty((T, B, H), dtype=torch.float32, device=x.device)
+        check(lib.rlpyt_lstm_seq_train_f32(ptr(xproj), ptr(w_hh_d), ptr(h0), ptr(c), ptr(out), ptr(gates),
+                                           ptr(c_all), T, B, H, stream()), "rlpyt_lstm_seq_train_f32")
+        ctx.save_for_backward(x2, h0, c0, w_ih_d, w_hh_d, out, gates, c_all)
+        ctx.dims = (T, B, I, H)
+        hn = out[T - 1].clone()
+        return out, hn, c
+
+    @staticmethod
+    def backward(ctx, dout, dhn, dcn):
+        x2, h0, c0, w_ih, w_hh, out, gates, c_all = ctx.saved_tensors
+        T, B, I, H = ctx.dims
+        dout = None if dout is None else _f32(dout)
+        dhn = None if dhn is None else _f32(dhn)
+        dc = torch.zeros((B, H), dtype=torch.float32, device=x2.device) if dcn is None else _f32(dcn).clone()
+        dgates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=x2.device)
+        need_state = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dh0 = torch.empty((B, H), dtype=torch.float32, device=x2.device) if need_state else None
+        w_hh_t = w_hh.t().contiguous()
+        check(lib.rlpyt_lstm_seq_bwd_f32(ptr(dout), ptr(dhn), ptr(gates), ptr(c_all), ptr(c0), ptr(w_hh_t),
+                                         ptr(dc), ptr(dgates), ptr(dh0), T, B, H, stream()),
+              "rlpyt_lstm_seq_bwd_f32")
+        dg2 = dgates.view(T * B, 4 * H)
+        dx = torch.mm(dg2, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
+        dw_ih = torch.mm(dg2.t(), x2)
+        h_prev = torch.cat([h0.unsqueeze(0), out[:T - 1]], dim=0).view(T * B, H)
+        dw_hh = torch.mm(dg2.t(), h_prev)
+        db = dg2.sum(dim=0)
+        return dx, dh0, (dc if need_state else None), dw_ih, dw_hh, db, db
+
+
+def lstm_sequence_train_ok(lstm, x, h0):
+    """Whether ``lstm_sequence_train`` serves this call (``lstm_sequence_ok`` under autograd)."""
+    return (torch.is_grad_enabled() and LSTM_SEQ_TRAIN and x.is_cuda and x.dtype == torch.float32
+            and x.dim() == 3 and x.shape[0] > 0
+            and lstm.num_layers == 1 and not lstm.bidirectional and lstm.bias
+            and not lstm.batch_first and getattr(lstm, "proj_size", 0) == 0 and lstm.dropout == 0
+            and lstm.hidden_size in LSTM_SEQ_HIDDEN and lstm.weight_hh_l0.dtype == torch.float32
+            and (h0 is None or (h0.dim() == 3 and h0.shape[0] == 1 and h0.shape[1] == x.shape[1])))
+
+
+# A/B switch: the sequence under autograd through the library RNN instead
+LSTM_SEQ_TRAIN = os.environ.get("RLPYT_LSTM_SEQ_TRAIN", "1") != "0"
+
+
+def lstm_sequence_train(lstm, x, h0=None, c0=None):
+    """``lstm(x, (h0, c0))`` differentiable w.r.t. x, the initial state and the four parameters, on the
+    own kernels (``_LstmSeqTrain``).  Returns ``(out [T,B,H], (h_T [1,B,H], c_T [1,B,H]))``."""
+    T, B, _ = x.shape
+    H = lstm.hidden_size
+    if h0 is None:
+        h0 = torch.zeros((B, H), dtype=torch.float32, device=x.device)
+    if c0 is None:
+        c0 = torch.zeros((B, H), dtype=torch.float32, device=x.device)
+    out, hn, cn = _LstmSeqTrain.apply(x, h0.reshape(B, H), c0.reshape(B, H), lstm.weight_ih_l0,
+                                      lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
+    return out, (hn.unsqueeze(0), cn.unsqueeze(0))
+
+
 def update_tick(ctr, table, hyper_cur, idx_all, idx_static, tick_idx):
     """First launch of a captured minibatch update (``rlpyt_update_tick``): row ``*ctr`` of the
     per-update hyper-parameter ``table [n, cols]`` -> ``hyper_cur [cols]``; the update's index chunk

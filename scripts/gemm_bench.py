@@ -29,17 +29,22 @@ def entry(us, fl):
             "frac_of_bf16x6_ceiling": round(6 * fl / us / 1e6 / 2500, 3)}
 
 
-M, N, K = 8192, 512, 3456          # batch, trunk width, conv features
-x = torch.randn(M, K, device="cuda")
-w = torch.randn(N, K, device="cuda") * 0.02
-g = torch.randn(M, N, device="cuda")
-fl = 2 * M * N * K
-res = {"shape": {"M": M, "N": N, "K": K, "GFLOP": fl / 1e9}}
-res["fwd_nt_lockstep"] = entry(timeit(lambda: ops.gemm_nt(x, w)), fl)
-res["fwd_torch_f32"] = entry(timeit(lambda: torch.mm(x, w.t())), fl)
-wt = w.t().contiguous()
-res["dgrad_nt_lockstep_on_transposed_w"] = entry(timeit(lambda: ops.gemm_nt(g, wt)), fl)
-res["dgrad_torch_f32"] = entry(timeit(lambda: torch.mm(g, w)), fl)
-res["wgrad_tn_lockstep_split_k"] = entry(timeit(lambda: ops.gemm_tn(g, x)), fl)
-res["wgrad_torch_f32"] = entry(timeit(lambda: torch.mm(g.t(), x)), fl)
-print(json.dumps(res))
+def main():
+    M, N, K = 8192, 512, 3456          # batch, trunk width, conv features
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") * 0.02
+    g = torch.randn(M, N, device="cuda")
+    fl = 2 * M * N * K
+    res = {"shape": {"M": M, "N": N, "K": K, "GFLOP": fl / 1e9}}
+    res["fwd_nt_lockstep"] = entry(timeit(lambda: ops.gemm_nt(x, w)), fl)
+    res["fwd_torch_f32"] = entry(timeit(lambda: torch.mm(x, w.t())), fl)
+    wt = w.t().contiguous()
+    res["dgrad_nt_lockstep_on_transposed_w"] = entry(timeit(lambda: ops.gemm_nt(g, wt)), fl)
+    res["dgrad_torch_f32"] = entry(timeit(lambda: torch.mm(g, w)), fl)
+    res["wgrad_tn_lockstep_split_k"] = entry(timeit(lambda: ops.gemm_tn(g, x)), fl)
+    res["wgrad_torch_f32"] = entry(timeit(lambda: torch.mm(g.t(), x)), fl)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

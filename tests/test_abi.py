@@ -85,6 +85,14 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert b"Kp >= F + A + 1 + H" in lib.rlpyt_hip_last_error()
     assert lib.rlpyt_dqn_convs_packed_floats() == 32 * 256 + 64 * 512 + 64 * 576
     assert lib.rlpyt_dqn_convs_workspace_floats(10) == 77824 + 10 * (475 * 32 + 108 * 64)
+    # LSTM sequence under autograd (ABI 11)
+    assert lib.rlpyt_lstm_seq_train_f32(*([None] * 7), 0, 4, 512, None) == OK
+    assert lib.rlpyt_lstm_seq_train_f32(*([None] * 7), 3, 4, 512, None) != OK
+    assert lib.rlpyt_lstm_seq_train_f32(*([p] * 7), 3, 4, 100, None) != OK
+    assert lib.rlpyt_lstm_seq_bwd_f32(*([None] * 9), 0, 4, 512, None) == OK
+    assert lib.rlpyt_lstm_seq_bwd_f32(*([None] * 9), 3, 4, 512, None) != OK
+    assert b"null pointer" in lib.rlpyt_hip_last_error()
+    assert lib.rlpyt_lstm_seq_bwd_f32(*([p] * 9), 3, 4, 384, None) != OK
     # backward of the same stack (ABI 10)
     assert lib.rlpyt_dqn_convs_bwd_f32(None, 0, *([None] * 6), 1.0, *([None] * 8)) == OK
     assert lib.rlpyt_dqn_convs_bwd_f32(None, -2, *([None] * 6), 1.0, *([None] * 8)) == -1

@@ -487,6 +487,22 @@ def test_gemm_nt_bf16x6_is_f32_accurate(ops, M, N, K):
     assert ours <= 2 * theirs + scale * 2.0 ** -22, (ours, theirs)
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 3456, 512), (5001, 3456, 64), (8000, 2100, 64)])
+def test_gemm_nt_row_split_is_bit_identical(ops, M, N, K, monkeypatch):
+    """Tall shapes run as two launches (256-row tiles for the first row blocks, 128-row tiles behind
+    them: gemm_nt_plan); every output element is the same contraction in the same order whichever tile
+    holds it -- bit-identical to one launch of 256-row tiles (RLPYT_GEMM_NT_R256=-1), to all 128-row
+    tiles (0) and to an odd cut (ragged last block included)."""
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    b = torch.randn(N, K, generator=g).cuda()
+    monkeypatch.delenv("RLPYT_GEMM_NT_R256", raising=False)
+    c_plan = ops.gemm_nt(a, b)
+    for r in ("-1", "0", "7"):
+        monkeypatch.setenv("RLPYT_GEMM_NT_R256", r)
+        assert torch.equal(ops.gemm_nt(a, b), c_plan), r
+
+
 # K >= 2048: the 8-chunk split with partial tiles (K = 8192 with 108 tiles: 96 whole-chunk units +
 # 12 tiles in two K parts per XCD; K = 2080: ragged chunks of 8 / 9 steps); below: one unit per tile
 @pytest.mark.parametrize("M,N,K", [(512, 3456, 8192), (512, 3456, 1024), (132, 200, 2080),

@@ -87,3 +87,101 @@ def test_r2d1_model_dispatches_no_grad_sequences_to_the_fused_lstm():
     np.testing.assert_allclose(s1.h.cpu().numpy(), s2.h.cpu().numpy(), rtol=2e-4, atol=5e-6)
     np.testing.assert_allclose(s1.c.cpu().numpy(), s2.c.cpu().numpy(), rtol=2e-4, atol=5e-6)
     assert tuple(s1.h.shape) == (1, B, 512) and tuple(s1.c.shape) == (1, B, 512)
+
+
+# ---------------------------------------------------------------------------------------------
+# The same sequence under autograd (round 6): own forward that keeps gates / cell states + own BPTT
+# (rlpyt_lstm_seq_train_f32 / rlpyt_lstm_seq_bwd_f32) against torch.nn.LSTM in float64, beside the
+# library RNN in f32 on the same inputs.
+def _train_case(ops, H, I, T, B, with_state, use_state_outputs, seed):
+    torch.manual_seed(seed)
+    lstm = torch.nn.LSTM(I, H)
+    x = torch.randn(T, B, I)
+    state = (torch.randn(1, B, H) * 0.5, torch.randn(1, B, H) * 0.5) if with_state else None
+    w_out = torch.randn(T, B, H)
+    w_h, w_c = torch.randn(1, B, H), torch.randn(1, B, H)
+
+    def run(mod, fn, dtype, device):
+        m = torch.nn.LSTM(I, H).to(device=device, dtype=dtype)
+        m.load_state_dict({k: v.to(dtype) for k, v in lstm.state_dict().items()})
+        xs = x.to(device=device, dtype=dtype).requires_grad_(True)
+        st = None if state is None else tuple(s.to(device=device, dtype=dtype).requires_grad_(True)
+                                              for s in state)
+        out, (hn, cn) = fn(m, xs, st)
+        loss = (out * w_out.to(device=device, dtype=dtype)).sum()
+        if use_state_outputs:
+            loss = loss + (hn * w_h.to(device=device, dtype=dtype)).sum() \
+                + (cn * w_c.to(device=device, dtype=dtype)).sum()
+        loss.backward()
+        res = [out, hn, cn, xs.grad] + ([] if st is None else [s.grad for s in st]) \
+            + [p.grad for p in (m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0)]
+        return [r.detach().cpu().double() for r in res]
+
+    ref = run(None, lambda m, xs, st: m(xs, st), torch.float64, "cpu")
+    lib = run(None, lambda m, xs, st: m(xs, st), torch.float32, "cuda")
+
+    def own(m, xs, st):
+        assert ops.lstm_sequence_train_ok(m, xs, None if st is None else st[0])
+        return ops.lstm_sequence_train(m, xs, *(st or (None, None)))
+    got = run(None, own, torch.float32, "cuda")
+    names = ["out", "hn", "cn", "dx"] + (["dh0", "dc0"] if with_state else []) + ["dw_ih", "dw_hh", "db_ih", "db_hh"]
+    for nm, g, l, r in zip(names, got, lib, ref):
+        assert g.shape == r.shape, nm
+        scale = r.abs().max().item() + 1e-30
+        err, err_lib = (g - r).abs().max().item() / scale, (l - r).abs().max().item() / scale
+        # floor 1e-5: the weight gradients are ONE f32 library GEMM over all T * B rows (5440 terms per
+        # element at [85, 64]); the library RNN accumulates them step by step
+        assert err <= max(3 * err_lib, 1e-5), (nm, err, err_lib)
+
+
+@pytest.mark.parametrize("H,I", [(512, 519), (256, 37)])
+@pytest.mark.parametrize("T,B", [(1, 1), (2, 16), (7, 5), (12, 33), (85, 64)])
+@pytest.mark.parametrize("with_state,use_state_outputs", [(False, False), (True, True), (True, False)])
+def test_lstm_sequence_under_autograd_matches_torch_lstm(H, I, T, B, with_state, use_state_outputs):
+    from rlpyt_amd import ops
+    _train_case(ops, H, I, T, B, with_state, use_state_outputs, seed=T * 10 + B)
+
+
+def test_lstm_sequence_backward_is_deterministic():
+    from rlpyt_amd import ops
+    torch.manual_seed(5)
+    lstm = torch.nn.LSTM(70, 512).cuda()
+    x = torch.randn(9, 40, 70, device="cuda")
+    runs = []
+    for _ in range(2):
+        lstm.zero_grad()
+        out, _ = ops.lstm_sequence_train(lstm, x)
+        out.square().sum().backward()
+        runs.append([p.grad.clone() for p in lstm.parameters()])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
+def test_r2d1_model_dispatches_autograd_sequences_to_the_own_bptt():
+    """AtariR2d1Model under autograd, T > 1: the own forward / backward step kernels run (launch
+    counters) and the parameter gradients equal the library-RNN path's (RLPYT_LSTM_SEQ_TRAIN switch)."""
+    from rlpyt_amd import _lib, ops
+    from rlpyt_amd.models.dqn.atari_r2d1_model import AtariR2d1Model
+    torch.manual_seed(3)
+    m = AtariR2d1Model(image_shape=(4, 104, 80), output_size=6, dueling=True).cuda()
+    g = torch.Generator().manual_seed(1)
+    obs = torch.randint(0, 256, (6, 4, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    pa = torch.zeros(6, 4, 6, device="cuda")
+    pa[..., 1] = 1
+    pr = torch.randn(6, 4, generator=g).cuda()
+    grads = {}
+    for own in (True, False):
+        ops.LSTM_SEQ_TRAIN = own
+        try:
+            m.zero_grad()
+            _lib.variant_reset()
+            q, _ = m(obs, pa, pr, None)
+            q.square().sum().backward()
+            ran = any("lstm_seq_bwd_step_kernel" in k for k in _lib.variant_counts())
+            assert ran == own
+            grads[own] = [p.grad.clone() for p in m.parameters()]
+        finally:
+            ops.LSTM_SEQ_TRAIN = True
+    for a, b in zip(grads[True], grads[False]):
+        scale = b.abs().max().item() + 1e-30
+        assert (a - b).abs().max().item() / scale < 2e-4

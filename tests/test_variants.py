@@ -586,6 +586,13 @@ def _lstm_seq():
         L.test_lstm_sequence_matches_torch_lstm(H, I, 5, 70, False)
 
 
+@case("lstm_seq_bwd_step_kernel<8>", "lstm_seq_bwd_step_kernel<4>")
+def _lstm_seq_bwd():
+    import test_lstm_seq_gpu as L
+    for H, I in ((512, 519), (256, 37)):
+        L.test_lstm_sequence_under_autograd_matches_torch_lstm(H, I, 7, 5, True, True)
+
+
 @case("rnn_step_inputs_kernel")
 def _rnn_step_inputs():
     import test_dqn_gpu as D
