@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 11
+#define RLPYT_HIP_ABI_VERSION 12
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -342,6 +342,11 @@ typedef struct rlpyt_row_copy {
   int64_t nbytes;
   int32_t dt;
   int32_t reserved;
+  /* ABI 12: zero_where != NULL -> unit u = bytes [u * unit_bytes, (u + 1) * unit_bytes) of the entry is
+   * written as zeros where zero_where[u] != 0 (wait-reset collector: blank rows of finished envs,
+   * rlpyt/samplers/parallel/gpu/collectors.py:85-91) */
+  const uint8_t* zero_where;
+  int64_t unit_bytes;
 } rlpyt_row_copy;
 int rlpyt_commit_rows(const rlpyt_row_copy* table_dev, int n_entries, int64_t max_entry_bytes,
                       const int64_t* t_dev /*nullable*/, rlpyt_stream_t stream);

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (RLPYT_HIP_LIB: another build of the same ABI, for A/B runs of two kernel versions on one box)
 LIB_PATH = os.environ.get("RLPYT_HIP_LIB") or os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class CopyDesc(ctypes.Structure):

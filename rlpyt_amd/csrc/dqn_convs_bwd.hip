@@ -75,11 +75,34 @@ __global__ __launch_bounds__(256) void dqn_pack_bwd_weights_kernel(const float* 
 }
 
 // Stage a 12 x 9 x 64 gradient into the zero-bordered plane [GPH * GPW][GCS]:
-//   NCHW: dz = g[c][pos] * (y[c][pos] > 0) from the flattened conv3 output / its gradient,
-//   else:  dz[pos][c] as written by dgrad3 (already masked).
+//   NCHW: dz = g[c][pos] * (y[c][pos] > 0) from the flattened conv3 output / its gradient -- read in
+//         memory order (lanes along the positions of a channel: coalesced; the first version read four
+//         channels per lane, 432 bytes apart, and the staging was half of dgrad3's 33 us), scattered
+//         into the plane (a wave's 64 stores: 4-way bank conflicts at GCS = 68), border zeroed first;
+//   else:  dz[pos][c] as written by dgrad3 (already masked), one float4 per lane.
 template <bool NCHW, int NTHREADS>
 __device__ __forceinline__ void stage_grad_plane(float* plane, const float* __restrict__ g,
                                                  const float* __restrict__ y, int tid) {
+  if (NCHW) {
+    constexpr int NE = C2 * P2, NIT = (NE + NTHREADS - 1) / NTHREADS;
+    float gv[NIT], yv[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int f = min(tid + k * NTHREADS, NE - 1);
+      gv[k] = g[f];
+      yv[k] = y[f];
+    }
+    constexpr int NZ = GPH * GPW * GCS / 4;
+    for (int i = tid; i < NZ; i += NTHREADS) reinterpret_cast<f32x4*>(plane)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int f = tid + k * NTHREADS;
+      const int c = f / P2, pos = f - c * P2, py = pos / W2, px = pos - py * W2;
+      if (f < NE) plane[((py + 1) * GPW + px + 1) * GCS + c] = yv[k] > 0.f ? gv[k] : 0.f;
+    }
+    return;
+  }
   constexpr int Q = C2 / 4, NV = GPH * GPW * Q, NIT = (NV + NTHREADS - 1) / NTHREADS;
   f32x4 v[NIT];
   int dst[NIT];
@@ -89,16 +112,8 @@ __device__ __forceinline__ void stage_grad_plane(float* plane, const float* __re
     const int pix = f / Q, qd = f - pix * Q, py = pix / GPW, px = pix - py * GPW;
     const bool in = (py >= 1) && (py <= H2) && (px >= 1) && (px <= W2);
     const int pos = in ? (py - 1) * W2 + (px - 1) : 0;
-    if (NCHW) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float gv = g[(4 * qd + e) * P2 + pos], yv = y[(4 * qd + e) * P2 + pos];
-        v[k][e] = (in && yv > 0.f) ? gv : 0.f;
-      }
-    } else {
-      v[k] = *reinterpret_cast<const f32x4*>(g + pos * C2 + 4 * qd);
-      if (!in) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    v[k] = *reinterpret_cast<const f32x4*>(g + pos * C2 + 4 * qd);
+    if (!in) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     dst[k] = pix * GCS + 4 * qd;
   }
 #pragma unroll

@@ -9,25 +9,35 @@ namespace rlpyt {
 namespace {
 
 // Copy n_entries byte ranges: dst_e + (t + dt_e) * row_stride_e + col_off_e <- src_e[0:nbytes_e].
-// grid = (chunks, n_entries); 16-byte lanes when everything is 16-byte aligned.
+// grid = (chunks, n_entries); 16-byte lanes when everything is 16-byte aligned.  An entry with
+// zero_where writes zeros instead of the source for every unit u (unit_bytes bytes each) with
+// zero_where[u] != 0: the wait-reset collector's blank rows of finished environments
+// (rlpyt/samplers/parallel/gpu/collectors.py:85-91) without a masking launch per leaf.
 __global__ __launch_bounds__(256) void commit_rows_kernel(const rlpyt_row_copy* __restrict__ table,
                                                           const int64_t* __restrict__ t_dev) {
   const rlpyt_row_copy e = table[blockIdx.y];
   const int64_t t = (t_dev != nullptr ? *t_dev : 0) + e.dt;
   char* __restrict__ dst = static_cast<char*>(e.dst) + t * e.row_stride_bytes + e.col_off_bytes;
   const char* __restrict__ src = static_cast<const char*>(e.src);
+  const uint8_t* __restrict__ zw = e.zero_where;
+  const int64_t ub = e.unit_bytes;
   const int64_t n = e.nbytes;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
-  const bool wide = (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0);
+  const bool wide = (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) &&
+                    (zw == nullptr || (ub & 15) == 0);
   if (wide) {
     const int64_t n16 = n >> 4;
     const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
     uint4* __restrict__ d4 = reinterpret_cast<uint4*>(dst);
-    for (int64_t i = tid; i < n16; i += nthr) d4[i] = s4[i];
-    for (int64_t i = (n16 << 4) + tid; i < n; i += nthr) dst[i] = src[i];
+    for (int64_t i = tid; i < n16; i += nthr) {
+      uint4 v = s4[i];
+      if (zw != nullptr && zw[(i << 4) / ub]) v = uint4{0u, 0u, 0u, 0u};
+      d4[i] = v;
+    }
+    for (int64_t i = (n16 << 4) + tid; i < n; i += nthr) dst[i] = (zw != nullptr && zw[i / ub]) ? 0 : src[i];
   } else {
-    for (int64_t i = tid; i < n; i += nthr) dst[i] = src[i];
+    for (int64_t i = tid; i < n; i += nthr) dst[i] = (zw != nullptr && zw[i / ub]) ? 0 : src[i];
   }
 }
 

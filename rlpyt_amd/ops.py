@@ -588,7 +588,8 @@ def atari_conv_stack(obs, flat_idx, w1, b1, w2, b2, scale=1. / 255):
 # per-time-step sampler kernels (csrc/step.hip)
 # --------------------------------------------------------------------------------------
 _ROW_COPY_DTYPE = [("dst", "<u8"), ("src", "<u8"), ("row_stride", "<i8"), ("col_off", "<i8"),
-                   ("nbytes", "<i8"), ("dt", "<i4"), ("reserved", "<i4")]
+                   ("nbytes", "<i8"), ("dt", "<i4"), ("reserved", "<i4"), ("zero_where", "<u8"),
+                   ("unit_bytes", "<i8")]
 
 
 class RowCommit:
@@ -598,7 +599,9 @@ class RowCommit:
 
     ``entries``: tuples ``(dst, src, lo, dt)`` with ``dst`` a contiguous ``[T', B, ...]``
     device tensor and ``src`` a contiguous ``[hi - lo, ...]`` device tensor, or
-    ``(dst, src, None, 0)`` for a plain copy ``dst[...] = src``.  The table lives in device
+    ``(dst, src, None, 0)`` for a plain copy ``dst[...] = src``; a fifth element ``zero_where``
+    (bool / uint8 device tensor ``[hi - lo]``) makes the launch write zeros for the rows ``i`` with
+    ``zero_where[i]`` (the wait-reset collector's blank rows).  The table lives in device
     memory at a fixed address; ``set_entries`` may be called again (e.g. after hipGraph
     capture, once the sources' addresses are known)."""
 
@@ -607,7 +610,7 @@ class RowCommit:
         self._np = np
         self.n = int(n_entries)
         self.device = device
-        self.table = torch.zeros(self.n * 48, dtype=torch.uint8, device=device)
+        self.table = torch.zeros(self.n * 64, dtype=torch.uint8, device=device)
         self.max_bytes = 0
         self._keep = None
 
@@ -615,9 +618,11 @@ class RowCommit:
         np = self._np
         assert len(entries) == self.n
         host = np.zeros(self.n, dtype=_ROW_COPY_DTYPE)
-        assert host.itemsize == 48
+        assert host.itemsize == 64
         keep = []
-        for i, (dst, src, lo, dt) in enumerate(entries):
+        for i, entry in enumerate(entries):
+            dst, src, lo, dt = entry[:4]
+            zw = entry[4] if len(entry) > 4 else None
             assert dst.is_cuda and src.is_cuda and dst.is_contiguous() and src.is_contiguous()
             assert dst.dtype == src.dtype
             nbytes = src.numel() * src.element_size()
@@ -631,8 +636,13 @@ class RowCommit:
                     per_col *= d
                 row_stride, col_off = per_col * dst.shape[1], per_col * lo
                 assert lo + src.shape[0] <= dst.shape[1]
-            host[i] = (dst.data_ptr(), src.data_ptr(), row_stride, col_off, nbytes, dt, 0)
-            keep.append((dst, src))
+            zw_ptr = unit = 0
+            if zw is not None:
+                assert zw.is_cuda and zw.is_contiguous() and zw.element_size() == 1
+                assert zw.numel() == src.shape[0] and nbytes % zw.numel() == 0
+                zw_ptr, unit = zw.data_ptr(), nbytes // zw.numel()
+            host[i] = (dst.data_ptr(), src.data_ptr(), row_stride, col_off, nbytes, dt, 0, zw_ptr, unit)
+            keep.append((dst, src, zw))
             self.max_bytes = max(self.max_bytes, nbytes)
         self._keep = keep
         self.table.copy_(torch.from_numpy(host.view(np.uint8).copy()))

@@ -267,9 +267,12 @@ class DeviceBatch(TailPass):
             agent.sample_uniforms = None if G.u_all is None else (G.u_all, t)
             action, agent_info = agent.step(G.obs_stage, prev_action, prev_reward)
             agent.sample_generator = agent.sample_uniforms = None
-        if not opts.mid_batch_reset:
-            # wait-reset: finished envs record blank action / agent_info
-            # (collectors.py:85-91)
+        zw = None
+        if not opts.mid_batch_reset and capturing and G.done_stage.element_size() == 1:
+            # wait-reset: finished envs record blank action / agent_info (collectors.py:85-91) -- the
+            # row-commit launch below writes zeros for them (no masking launches per leaf)
+            zw = G.done_stage
+        elif not opts.mid_batch_reset:
             keep = ~G.done_stage
 
             def blank(x):
@@ -281,9 +284,9 @@ class DeviceBatch(TailPass):
             a_src = [x.contiguous() for x in buffer_leaves(action)]
             i_src = [x.contiguous() for x in buffer_leaves(agent_info)]
             G.post_entries = (
-                [(d, x, lo, 1) for d, x in zip(buffer_leaves(self.all_action), a_src)]
-                + [(d, x, lo, 0) for d, x in zip(buffer_leaves(s.agent.agent_info), i_src)]
-                + [(d, x, None, 0) for d, x in zip(buffer_leaves(G.action_out), a_src)])
+                [(d, x, lo, 1, zw) for d, x in zip(buffer_leaves(self.all_action), a_src)]
+                + [(d, x, lo, 0, zw) for d, x in zip(buffer_leaves(s.agent.agent_info), i_src)]
+                + [(d, x, None, 0, zw) for d, x in zip(buffer_leaves(G.action_out), a_src)])
             G.post_commit.launch(t)
         else:
             self._commit_rows(self.all_action, action, G, t + 1)

@@ -81,8 +81,8 @@ def test_r2d1_model_dispatches_no_grad_sequences_to_the_fused_lstm():
         assert not ran()
     m.use_fused_lstm_sequence = True
     _lib.variant_reset()
-    q3, _ = m(obs, pa, pr, init)                           # autograd: library RNN
-    assert not ran() and q3.requires_grad
+    q3, _ = m(obs, pa, pr, init)                           # autograd: the training variant of the kernel
+    assert ran() and q3.requires_grad
     np.testing.assert_allclose(q1.cpu().numpy(), q2.cpu().numpy(), rtol=2e-4, atol=5e-6)
     np.testing.assert_allclose(s1.h.cpu().numpy(), s2.h.cpu().numpy(), rtol=2e-4, atol=5e-6)
     np.testing.assert_allclose(s1.c.cpu().numpy(), s2.c.cpu().numpy(), rtol=2e-4, atol=5e-6)
@@ -182,6 +182,8 @@ def test_r2d1_model_dispatches_autograd_sequences_to_the_own_bptt():
             grads[own] = [p.grad.clone() for p in m.parameters()]
         finally:
             ops.LSTM_SEQ_TRAIN = True
+    top = max(b.abs().max().item() for b in grads[False])
     for a, b in zip(grads[True], grads[False]):
-        scale = b.abs().max().item() + 1e-30
+        # (the dueling head's value bias has an analytically zero gradient: rounding noise of ~1e-7)
+        scale = max(b.abs().max().item(), 1e-4 * top)
         assert (a - b).abs().max().item() / scale < 2e-4

@@ -95,6 +95,40 @@ def test_commit_rows_matches_indexing():
     assert torch.equal(out, s_act)
 
 
+def test_commit_rows_zero_where_blanks_finished_envs():
+    """Entries with ``zero_where``: rows of the flagged environments are written as zeros (the wait-reset
+    collector's blank action / agent_info, rlpyt/samplers/parallel/gpu/collectors.py:85-91), the others
+    copied -- wide (16-byte-multiple units), narrow (8-byte and 4-byte units) and odd-sized units; the
+    destination held other values before."""
+    from rlpyt_amd import ops
+    T, B, lo, Bg = 5, 9, 2, 6
+    g = torch.Generator().manual_seed(1)
+    done = torch.tensor([0, 1, 0, 0, 1, 1], dtype=torch.bool, device="cuda")
+    dsts = [torch.full((T, B, 512), 7., device="cuda"), torch.full((T + 1, B), 7, dtype=torch.int64, device="cuda"),
+            torch.full((T, B), 7., device="cuda"), torch.full((T, B, 3, 5), 7, dtype=torch.uint8, device="cuda"),
+            torch.full((Bg,), 7, dtype=torch.int64, device="cuda")]
+    srcs = [torch.randn(Bg, 512, generator=g).cuda(), torch.randint(1, 6, (Bg,), generator=g).cuda(),
+            torch.randn(Bg, generator=g).cuda(),
+            torch.randint(1, 256, (Bg, 3, 5), dtype=torch.uint8, generator=g).cuda(),
+            torch.randint(1, 6, (Bg,), generator=g).cuda()]
+    rc = ops.RowCommit(5, torch.device("cuda:0"))
+    rc.set_entries([(dsts[0], srcs[0], lo, 0, done), (dsts[1], srcs[1], lo, 1, done),
+                    (dsts[2], srcs[2], lo, 0, done), (dsts[3], srcs[3], lo, 0, done),
+                    (dsts[4], srcs[4], None, 0, done)])
+    want = [d.clone() for d in dsts]
+    t = 3
+    for k, (w, x) in enumerate(zip(want, srcs)):
+        blank = x * (~done).reshape((-1,) + (1,) * (x.dim() - 1)).to(x.dtype)
+        if k == 4:
+            w.copy_(blank)
+        else:
+            w[t + (1 if k == 1 else 0), lo:lo + Bg] = blank
+    rc.launch(torch.tensor([t], dtype=torch.int64, device="cuda"))
+    torch.cuda.synchronize()
+    for d, w in zip(dsts, want):
+        assert torch.equal(d, w)
+
+
 @pytest.mark.parametrize("n,K,A", [(256, 512, 6), (5, 64, 18), (1, 512, 2)])
 def test_categorical_head_matches_torch(n, K, A):
     """Heads + softmax within f32 tolerance (rtol 1e-5) of torch; the drawn action is exactly
