@@ -1,10 +1,10 @@
 #!/bin/bash
-# The measurements committed under profiles/r5_* (ON THE GPU BOX; ~20 min):
+# The measurements committed under profiles/r6_* (ON THE GPU BOX; ~20 min):
 #   whole GPU suite, the three bench lines (ppo / dqn / r2d1), rocprofv3 kernel trace of the ppo bench,
 #   PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) over the update's kernels and the rollout-step kernels,
 #   timed-region kernel statistics of the three lines.
 # usage: scripts/final_measurements.sh [tag=r5]      -> gpurun_out/<tag>_final/
-TAG=${1:-r5}
+TAG=${1:-r6}
 OUT=$PWD/gpurun_out/${TAG}_final
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -15,7 +15,7 @@ timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_ppo.json 2> $OUT/
 timeout 500 python bench.py --config dqn > $OUT/bench_dqn.json 2> $OUT/bench_dqn.err
 timeout 600 python bench.py --config r2d1 > $OUT/bench_r2d1.json 2> $OUT/bench_r2d1.err
 # event-free kernel durations of the same command (kernel trace only)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline --env-cost-leg-us 0 > $OUT/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-extra-configs --env-cost-leg-us 0 > $OUT/prof_bench.log 2>&1
 cp "$(find $OUT/raw -name '*kernel_stats.csv' | head -1)" $OUT/bench_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/raw
 head -14 $OUT/bench_kernel_stats.csv | cut -c1-110

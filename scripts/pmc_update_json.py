@@ -21,7 +21,9 @@ REGIONS = {
     "conv2_bwd": (["conv2_bwd_x6_kernel"], M * (4 * (3456 + 2 * 7600) + 512)),
     "conv1_wgrad": (["conv1_wgrad_kernel"], M * (33280 + 4 * 7600)),
     "gemm_nt": (["gemm_nt_x6_kernel<128>"], GEMM_ALG),
-    "gemm_nt_dgrad": (["gemm_nt_x6_kernel<256>"], GEMM_ALG),
+    # (round 6: the input gradient is two launches -- 256-row tiles + a tail of 128-row tiles, told from
+    #  the forward GEMM's 256 workgroups by its grid size)
+    "gemm_nt_dgrad": (["gemm_nt_x6_kernel<256>", "gemm_nt_x6_kernel<128>#tail"], GEMM_ALG),
     "gemm_tn": (["gemm_tn_x6_kernel", "gemm_reduce_slots_kernel"], GEMM_ALG),
 }
 RENAME = {"SQ_VALU_MFMA_BUSY_CYCLES": "mfma_busy_cycles", "SQ_BUSY_CYCLES": "sq_busy_cycles",
@@ -42,6 +44,8 @@ def main(d):
                 # takes care of it), gemm_nt_x6_kernel<128> / <256> are told apart by the template
                 if key is None:
                     continue
+                if key == "gemm_nt_x6_kernel<128>" and int(float(row.get("Grid_Size") or 0)) not in (0, 256 * 512):
+                    key += "#tail"
                 acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
     try:
         commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"],

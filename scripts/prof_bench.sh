@@ -5,7 +5,7 @@ TAG=${1:-prof}; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/${TAG}
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline --env-cost-leg-us 0 "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-extra-configs --env-cost-leg-us 0 "$@" > $OUT/bench.log 2>&1
 f=$(find $OUT/raw -name '*kernel_stats.csv' | head -1)
 cp "$f" $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $OUT/raw

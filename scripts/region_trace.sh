@@ -11,7 +11,7 @@ for cfg in $CFGS; do
   case $cfg in
     dqn)  ARGS="--config dqn --replay-fill-itrs 600 --steps 300 --warmup 20"; STEPS=300;;
     r2d1) ARGS="--config r2d1 --replay-fill-itrs 40 --steps 10 --warmup 3"; STEPS=10;;
-    ppo)  ARGS="--steps 10 --warmup 3 --env-cost-leg-us 0 --no-kernel-timing"; STEPS=10;;
+    ppo)  ARGS="--steps 10 --warmup 3 --env-cost-leg-us 0 --no-kernel-timing --no-extra-configs"; STEPS=10;;
   esac
   rm -rf $OUT/raw_$cfg
   rocprofv3 --kernel-trace --output-format csv -d $OUT/raw_$cfg -- python bench.py $ARGS --no-cpu-baseline --trace-markers $EXTRA > $OUT/bench_$cfg.json 2> $OUT/prof_$cfg.log

@@ -98,6 +98,11 @@ def test_iterations_match_reference(case):
                 # iterations at fp32 tolerance (conv / GEMM reductions reorder sums: 2e-4)
                 np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5, err_msg=f"{f} itr {itr}")
             np.testing.assert_allclose(got, ref, rtol=1e-2, atol=2e-3, err_msg=f"{f} itr {itr}")
+            # how far the diagnostics of the Adam cases drift behind the first update (VERDICT r5 weak #1;
+            # `pytest -s`, record: profiles/r6_adam_drift.txt)
+            rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
+            print(f"DRIFT {name} itr {itr} {f}: max rel {rel.max():.2e} at update {int(rel.argmax())} "
+                  f"of {rel.size} (first update {rel[0]:.2e})")
         n_updates += len(np.atleast_1d(info.loss))
         params = list(agent.parameters())
         sums, abs_sums = C.param_stats([p.cpu() for p in params])
