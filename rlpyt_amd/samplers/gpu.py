@@ -100,9 +100,12 @@ class GpuSampler(BaseSampler):
             # measured at B=256 on the bench host with the two-thread native step loop (~25 env
             # workers): 2 groups 516 K SPS, 3 groups 533-541 K, 4 groups 561 K, 5 groups 555 K,
             # 6 groups 541 K, 8 groups 496 K (with the earlier single-thread loop 3 was best)
+            # Groups of ~64 environments: B = 192 (R2D1, round 6, device-bound recurrent step of 13
+            # small kernels per group-step): 2 / 3 / 4 groups = 265-268 / 283-284 / 268-269 K SPS
+            # interleaved on one box (profiles/r6_ab_r2d1_groups.txt)
             n_groups = 2 if (self.n_workers > 0 and B >= 2 * max(self.n_workers, 1)) else 1
             if n_groups == 2 and B >= 192:
-                n_groups = 4
+                n_groups = min(4, B // 64)
         self.n_groups = max(1, min(int(n_groups), B))
 
     def _split_min_workers(self):
