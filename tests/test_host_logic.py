@@ -146,6 +146,18 @@ def test_sampler_pipeline_groups_keep_trajectories_contiguous(n_workers, n_group
     s.shutdown()
 
 
+@pytest.mark.parametrize("B,n_workers,want", [(256, 20, 4), (192, 19, 3), (512, 20, 4), (128, 16, 2),
+                                              (16, 2, 2), (16, 0, 1), (30, 20, 1)])
+def test_sampler_default_pipeline_groups(B, n_workers, want):
+    """Default layout rule (no ``n_groups`` argument): groups of ~64 environments from B = 192 on, at most
+    four; two while every worker still serves >= 2 environments; one without worker processes."""
+    from rlpyt_amd.utils.collections import AttrDict
+    s = GpuSampler(SyntheticPong, {}, batch_T=4, batch_B=B, n_workers=n_workers)
+    s.batch_spec = AttrDict(T=4, B=B)
+    s._resolve_layout(None)
+    assert s.n_groups == want
+
+
 @pytest.mark.parametrize("n_workers", [0, 2])
 def test_sampler_wait_reset_blanks_rows_after_done(n_workers):
     """GpuWaitResetCollector semantics (collectors.py:70-126): once an env is done it
