@@ -30,6 +30,8 @@
 //          27 x 21 pixels x (32 + 4) floats = 81.6 KB; y2 -> HBM as [N][108][64]
 //   conv3: the same over the 14 x 11 x (64 + 4) plane of y2 (41.9 KB); output in the flatten order of
 //          the reference's `conv(img).view(T * B, -1)`: [N][64][108].
+#include <algorithm>
+
 #include "common.h"
 
 namespace rlpyt {
@@ -93,55 +95,78 @@ __global__ __launch_bounds__(256) void dqn_pack_weights_kernel(const float* __re
 }
 
 // ---- conv1: uint8 planes -> y1 [N][475][32] ---------------------------------------------------
+// grid = min(N, kPersistImages) x D1_PARTS: workgroup (slot, part) walks the images slot, slot + slots, ...
+// with ITS weights in registers (a wave's tile / channel-tile assignment does not depend on the image); the
+// next image is requested before the MFMAs of the current one and written to LDS behind them.  At
+// sampling / update-batch sizes (N <= kPersistImages) every workgroup has one image, as before round 6;
+// at R2D1's thousands of images per pass the weight loads (36-64 KB per wave out of L2, per workgroup)
+// were most of the L2 -> CU traffic of these kernels.
+constexpr int kPersistImages = 256;
+
 __global__ __launch_bounds__(D1_THREADS) void dqn_conv1_kernel(const uint8_t* __restrict__ obs,
                                                                const float* __restrict__ packed,
                                                                const float* __restrict__ b1,
-                                                               float scale, float* __restrict__ y1) {
+                                                               float scale, float* __restrict__ y1, int64_t N) {
   __shared__ __attribute__((aligned(16))) uint8_t img[IMG];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
-  const int64_t n = blockIdx.x / D1_PARTS;
+  const int64_t slots = gridDim.x / D1_PARTS;
+  int64_t n = blockIdx.x / D1_PARTS;
   const int part = (int)(blockIdx.x % D1_PARTS);
   const int tile = part * D1_TILES + (wave >> 1), ct = wave & 1;
   // the whole image (2080 x 16 B) and this wave's weights in flight together
-  const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(obs + n * IMG);
   u32x4 v[3];
+  {
+    const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(obs + n * IMG);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) v[k] = src[min(tid + k * D1_THREADS, IMG / 16 - 1)];
+    for (int k = 0; k < 3; ++k) v[k] = src[min(tid + k * D1_THREADS, IMG / 16 - 1)];
+  }
   float wa[R1];
   const float* __restrict__ wp = packed + (int64_t)ct * R1 * 64 + lane;
 #pragma unroll
   for (int r = 0; r < R1; ++r) wa[r] = wp[r * 64];
-  f32x4 bias = *reinterpret_cast<const f32x4*>(b1 + ct * 16 + 4 * kq);
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-    if (tid + k * D1_THREADS < IMG / 16) reinterpret_cast<u32x4*>(img)[tid + k * D1_THREADS] = v[k];
-  __syncthreads();
-  if (tile >= T1) return;
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(b1 + ct * 16 + 4 * kq);
   const int lpos = tile * 16 + j, q = min(lpos, P1 - 1);
   const int oy = q / W1, ox = q - oy * W1;
   const int a0 = oy * (4 * W0) + ox * 4 + (kq >> 1) * W0 + 4 * (kq & 1);
-  // two accumulator chains (even / odd dwords): half the length of each dependent MFMA chain and of
-  // each running sum
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+  for (;;) {
 #pragma unroll
-  for (int g = 0; g < 16; g += 2) {
-    const int off = (g >> 2) * HW0 + 2 * (g & 3) * W0;
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(img + a0 + off);
-    const uint32_t wb = *reinterpret_cast<const uint32_t*>(img + a0 + off + 2 * W0);   // g + 1: ky_hi + 1
+    for (int k = 0; k < 3; ++k)
+      if (tid + k * D1_THREADS < IMG / 16) reinterpret_cast<u32x4*>(img)[tid + k * D1_THREADS] = v[k];
+    __syncthreads();
+    const int64_t nn = n + slots;
+    if (nn < N) {                                      // uniform: the next image, in flight behind the MFMAs
+      const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(obs + nn * IMG);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      acc = mfma16(wa[4 * g + e], (float)((w >> (8 * e)) & 0xffu), acc);
-      acc_b = mfma16(wa[4 * g + 4 + e], (float)((wb >> (8 * e)) & 0xffu), acc_b);
+      for (int k = 0; k < 3; ++k) v[k] = src[min(tid + k * D1_THREADS, IMG / 16 - 1)];
     }
-  }
-  acc += acc_b;
-  if (lpos < P1) {
-    f32x4 o;
+    if (tile < T1) {
+      // two accumulator chains (even / odd dwords): half the length of each dependent MFMA chain and of
+      // each running sum
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r] * scale + bias[r], 0.f);
-    *reinterpret_cast<f32x4*>(y1 + (n * P1 + q) * C1 + ct * 16 + 4 * kq) = o;
+      for (int g = 0; g < 16; g += 2) {
+        const int off = (g >> 2) * HW0 + 2 * (g & 3) * W0;
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(img + a0 + off);
+        const uint32_t wb = *reinterpret_cast<const uint32_t*>(img + a0 + off + 2 * W0);   // g + 1: ky_hi + 1
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc = mfma16(wa[4 * g + e], (float)((w >> (8 * e)) & 0xffu), acc);
+          acc_b = mfma16(wa[4 * g + 4 + e], (float)((wb >> (8 * e)) & 0xffu), acc_b);
+        }
+      }
+      acc += acc_b;
+      if (lpos < P1) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r] * scale + bias[r], 0.f);
+        *reinterpret_cast<f32x4*>(y1 + (n * P1 + q) * C1 + ct * 16 + 4 * kq) = o;
+      }
+    }
+    if (nn >= N) break;
+    n = nn;
+    __syncthreads();                                   // every wave is done reading this image
   }
 }
 
@@ -153,7 +178,7 @@ template <int CIN, int HI, int WI, int KH, int KW, int S, int R, bool NCHW_OUT>
 __global__ __launch_bounds__(D2_THREADS) void dqn_conv23_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ packed,
                                                                 const float* __restrict__ bvec,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out, int64_t N) {
   constexpr int PW = WI + 2, PH = HI + 2, CS = CIN + 4, Q = CIN / 4;
   constexpr int NV = PH * PW * Q;                          // float4 of the padded plane (pad lanes aside)
   constexpr int NIT = (NV + D2_THREADS - 1) / D2_THREADS;
@@ -162,62 +187,82 @@ __global__ __launch_bounds__(D2_THREADS) void dqn_conv23_kernel(const float* __r
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
-  const int64_t n = blockIdx.x >> 2;
+  const int64_t slots = gridDim.x >> 2;                    // persistent over the images (see conv1)
+  int64_t n = blockIdx.x >> 2;
   const int ct = (int)(blockIdx.x & 3);
-  const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(x + n * (HI * WI * CIN));
   // interior pixels from HBM / L2, border pixels zero: one pass, all loads in flight
   f32x4 v[NIT];
-  int dst[NIT];
+  int sp[NIT], dst[NIT];
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
     const int f = min(tid + k * D2_THREADS, NV - 1);
     const int pix = f / Q, qd = f - pix * Q, py = pix / PW, px = pix - py * PW;
     const bool in = (py >= 1) && (py <= HI) && (px >= 1) && (px <= WI);
-    const int sp = in ? ((py - 1) * WI + (px - 1)) * Q + qd : 0;
-    v[k] = src[sp];
-    if (!in) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    sp[k] = in ? ((py - 1) * WI + (px - 1)) * Q + qd : -1;
     dst[k] = pix * CS + 4 * qd;
+  }
+  {
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(x + n * (HI * WI * CIN));
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      v[k] = src[max(sp[k], 0)];
+      if (sp[k] < 0) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
   float wa[R];
   const float* __restrict__ wp = packed + (int64_t)ct * R * 64 + lane;
 #pragma unroll
   for (int r = 0; r < R; ++r) wa[r] = wp[r * 64];
   const f32x4 bias = *reinterpret_cast<const f32x4*>(bvec + ct * 16 + 4 * kq);
-#pragma unroll
-  for (int k = 0; k < NIT; ++k)
-    if (tid + k * D2_THREADS < NV) *reinterpret_cast<f32x4*>(plane + dst[k]) = v[k];
-  __syncthreads();
   const int lpos = wave * 16 + j, q = min(lpos, P2 - 1);
   const int oy = q / W2, ox = q - oy * W2;
   const float* base = plane + ((S * oy) * PW + S * ox) * CS + 4 * kq;
-  // two accumulator chains (even / odd channel groups): see conv1
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+  for (;;) {
 #pragma unroll
-  for (int tap = 0; tap < KH * KW; ++tap) {
-    const int ky = tap / KW, kx = tap - ky * KW;
+    for (int k = 0; k < NIT; ++k)
+      if (tid + k * D2_THREADS < NV) *reinterpret_cast<f32x4*>(plane + dst[k]) = v[k];
+    __syncthreads();
+    const int64_t nn = n + slots;
+    if (nn < N) {                                          // uniform: the next image's plane, behind the MFMAs
+      const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(x + nn * (HI * WI * CIN));
 #pragma unroll
-    for (int hc = 0; hc < CIN / 16; hc += 2) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(base + (ky * PW + kx) * CS + 16 * hc);
-      const f32x4 bw = *reinterpret_cast<const f32x4*>(base + (ky * PW + kx) * CS + 16 * hc + 16);
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {
-        acc = mfma16(wa[(tap * (CIN / 16) + hc) * 4 + sp], bv[sp], acc);
-        acc_b = mfma16(wa[(tap * (CIN / 16) + hc + 1) * 4 + sp], bw[sp], acc_b);
+      for (int k = 0; k < NIT; ++k) {
+        v[k] = src[max(sp[k], 0)];
+        if (sp[k] < 0) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-  }
-  acc += acc_b;
-  if (lpos < P2) {
-    if (NCHW_OUT) {
-      float* o = out + n * (COUT * P2) + (ct * 16 + 4 * kq) * P2 + q;
+    // two accumulator chains (even / odd channel groups): see conv1
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r * P2] = fmaxf(acc[r] + bias[r], 0.f);
-    } else {
-      f32x4 o;
+    for (int tap = 0; tap < KH * KW; ++tap) {
+      const int ky = tap / KW, kx = tap - ky * KW;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r] + bias[r], 0.f);
-      *reinterpret_cast<f32x4*>(out + (n * P2 + q) * COUT + ct * 16 + 4 * kq) = o;
+      for (int hc = 0; hc < CIN / 16; hc += 2) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(base + (ky * PW + kx) * CS + 16 * hc);
+        const f32x4 bw = *reinterpret_cast<const f32x4*>(base + (ky * PW + kx) * CS + 16 * hc + 16);
+#pragma unroll
+        for (int spi = 0; spi < 4; ++spi) {
+          acc = mfma16(wa[(tap * (CIN / 16) + hc) * 4 + spi], bv[spi], acc);
+          acc_b = mfma16(wa[(tap * (CIN / 16) + hc + 1) * 4 + spi], bw[spi], acc_b);
+        }
+      }
     }
+    acc += acc_b;
+    if (lpos < P2) {
+      if (NCHW_OUT) {
+        float* o = out + n * (COUT * P2) + (ct * 16 + 4 * kq) * P2 + q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r * P2] = fmaxf(acc[r] + bias[r], 0.f);
+      } else {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r] + bias[r], 0.f);
+        *reinterpret_cast<f32x4*>(out + (n * P2 + q) * COUT + ct * 16 + 4 * kq) = o;
+      }
+    }
+    if (nn >= N) break;
+    n = nn;
+    __syncthreads();                                       // every wave is done reading this plane
   }
 }
 
@@ -262,14 +307,15 @@ extern "C" int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const floa
     RL_LAUNCH(dqn_pack_weights_kernel, dim3((PACKED + 255) / 256), dim3(256), 0, s, w1, w2, w3, workspace);
     RL_LAUNCH_CHECK();
   }
-  RL_LAUNCH(dqn_conv1_kernel, dim3((unsigned)(N * D1_PARTS)), dim3(D1_THREADS), 0, s, obs, packed, b1,
-            scale, y1);
+  const int64_t slots = std::min<int64_t>(N, kPersistImages);      // persistent workgroups beyond that
+  RL_LAUNCH(dqn_conv1_kernel, dim3((unsigned)(slots * D1_PARTS)), dim3(D1_THREADS), 0, s, obs, packed, b1,
+            scale, y1, N);
   RL_LAUNCH_CHECK();
-  RL_LAUNCH((dqn_conv23_kernel<C1, H1, W1, 4, 4, 2, R2, false>), dim3((unsigned)(N * 4)),
-            dim3(D2_THREADS), 0, s, y1, packed + PK1, b2, y2);
+  RL_LAUNCH((dqn_conv23_kernel<C1, H1, W1, 4, 4, 2, R2, false>), dim3((unsigned)(slots * 4)),
+            dim3(D2_THREADS), 0, s, y1, packed + PK1, b2, y2, N);
   RL_LAUNCH_CHECK();
-  RL_LAUNCH((dqn_conv23_kernel<C2, H2, W2, 3, 3, 1, R3, true>), dim3((unsigned)(N * 4)),
-            dim3(D2_THREADS), 0, s, y2, packed + PK1 + PK2, b3, out);
+  RL_LAUNCH((dqn_conv23_kernel<C2, H2, W2, 3, 3, 1, R3, true>), dim3((unsigned)(slots * 4)),
+            dim3(D2_THREADS), 0, s, y2, packed + PK1 + PK2, b3, out, N);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

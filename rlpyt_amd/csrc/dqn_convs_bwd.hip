@@ -23,6 +23,8 @@
 //     accumulates in registers and writes ONE partial; dqn_bwd_reduce_kernel sums the partials in a
 //     fixed order (deterministic) and scales conv1's weight gradient by 1/255.
 // ReLU masks come from the kept activations (y > 0), bias gradients are the column sums of dz.
+#include <algorithm>
+
 #include "common.h"
 
 namespace rlpyt {
@@ -74,97 +76,122 @@ __global__ __launch_bounds__(256) void dqn_pack_bwd_weights_kernel(const float* 
   }
 }
 
-// Stage a 12 x 9 x 64 gradient into the zero-bordered plane [GPH * GPW][GCS]:
+// Staging of a 12 x 9 x 64 gradient into the zero-bordered plane [GPH * GPW][GCS], in two halves so that
+// the loads of the NEXT image can be in flight behind the MFMAs of the current one:
 //   NCHW: dz = g[c][pos] * (y[c][pos] > 0) from the flattened conv3 output / its gradient -- read in
 //         memory order (lanes along the positions of a channel: coalesced; the first version read four
 //         channels per lane, 432 bytes apart, and the staging was half of dgrad3's 33 us), scattered
-//         into the plane (a wave's 64 stores: 4-way bank conflicts at GCS = 68), border zeroed first;
+//         into the plane (a wave's 64 stores: 4-way bank conflicts at GCS = 68), border zeroed once;
 //   else:  dz[pos][c] as written by dgrad3 (already masked), one float4 per lane.
-template <bool NCHW, int NTHREADS>
-__device__ __forceinline__ void stage_grad_plane(float* plane, const float* __restrict__ g,
-                                                 const float* __restrict__ y, int tid) {
-  if (NCHW) {
-    constexpr int NE = C2 * P2, NIT = (NE + NTHREADS - 1) / NTHREADS;
-    float gv[NIT], yv[NIT];
+template <int NTHREADS>
+struct NchwStage {
+  static constexpr int NE = C2 * P2, NIT = (NE + NTHREADS - 1) / NTHREADS;
+  float gv[NIT], yv[NIT];
+  __device__ __forceinline__ void load(const float* __restrict__ g, const float* __restrict__ y, int tid) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int f = min(tid + k * NTHREADS, NE - 1);
       gv[k] = g[f];
       yv[k] = y[f];
     }
-    constexpr int NZ = GPH * GPW * GCS / 4;
-    for (int i = tid; i < NZ; i += NTHREADS) reinterpret_cast<f32x4*>(plane)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+  }
+  __device__ __forceinline__ void store(float* plane, int tid) const {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int f = tid + k * NTHREADS;
       const int c = f / P2, pos = f - c * P2, py = pos / W2, px = pos - py * W2;
       if (f < NE) plane[((py + 1) * GPW + px + 1) * GCS + c] = yv[k] > 0.f ? gv[k] : 0.f;
     }
-    return;
   }
-  constexpr int Q = C2 / 4, NV = GPH * GPW * Q, NIT = (NV + NTHREADS - 1) / NTHREADS;
+};
+template <int NTHREADS>
+struct NhwcStage {
+  static constexpr int Q = C2 / 4, NV = GPH * GPW * Q, NIT = (NV + NTHREADS - 1) / NTHREADS;
   f32x4 v[NIT];
-  int dst[NIT];
+  __device__ __forceinline__ void load(const float* __restrict__ g, int tid) {
 #pragma unroll
-  for (int k = 0; k < NIT; ++k) {
-    const int f = min(tid + k * NTHREADS, NV - 1);
-    const int pix = f / Q, qd = f - pix * Q, py = pix / GPW, px = pix - py * GPW;
-    const bool in = (py >= 1) && (py <= H2) && (px >= 1) && (px <= W2);
-    const int pos = in ? (py - 1) * W2 + (px - 1) : 0;
-    v[k] = *reinterpret_cast<const f32x4*>(g + pos * C2 + 4 * qd);
-    if (!in) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dst[k] = pix * GCS + 4 * qd;
+    for (int k = 0; k < NIT; ++k) {
+      const int f = min(tid + k * NTHREADS, NV - 1);
+      const int pix = f / Q, qd = f - pix * Q, py = pix / GPW, px = pix - py * GPW;
+      const bool in = (py >= 1) && (py <= H2) && (px >= 1) && (px <= W2);
+      const int pos = in ? (py - 1) * W2 + (px - 1) : 0;
+      v[k] = *reinterpret_cast<const f32x4*>(g + pos * C2 + 4 * qd);
+      if (!in) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
+  __device__ __forceinline__ void store(float* plane, int tid) const {
 #pragma unroll
-  for (int k = 0; k < NIT; ++k)
-    if (tid + k * NTHREADS < NV) *reinterpret_cast<f32x4*>(plane + dst[k]) = v[k];
-}
+    for (int k = 0; k < NIT; ++k) {
+      const int f = tid + k * NTHREADS;
+      const int pix = f / Q, qd = f - pix * Q;
+      if (f < NV) *reinterpret_cast<f32x4*>(plane + pix * GCS + 4 * qd) = v[k];
+    }
+  }
+};
+
+// Both data-gradient kernels are persistent over the images beyond kPersistImages (grid = min(N, 256) x 4:
+// workgroup (slot, tile | class) walks the images slot, slot + slots, ... with ITS transposed weights in
+// registers, the next image's gradient requested before the MFMAs of the current one), as the forward
+// kernels of dqn_convs.hip.
+constexpr int kPersistImages = 256;
 
 // ---- dgrad3: dz2[n][pos][ci] = (y2 > 0) * sum_{tap', co} dz3pad[pos + tap' - 1][co] w3[co][ci][8 - tap'] ----
 __global__ __launch_bounds__(DG3_THREADS) void dqn_dgrad3_kernel(const float* __restrict__ g3,
                                                                  const float* __restrict__ y3,
                                                                  const float* __restrict__ y2,
                                                                  const float* __restrict__ packed,
-                                                                 float* __restrict__ dz2) {
+                                                                 float* __restrict__ dz2, int64_t N) {
   __shared__ __attribute__((aligned(16))) float plane[GPH * GPW * GCS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
-  const int64_t n = blockIdx.x >> 2;
+  const int64_t slots = gridDim.x >> 2;
+  int64_t n = blockIdx.x >> 2;
   const int ct = (int)(blockIdx.x & 3);
+  NchwStage<DG3_THREADS> st;
+  st.load(g3 + n * (C3 * P2), y3 + n * (C3 * P2), tid);
   float wa[R3T];
   const float* __restrict__ wp = packed + (int64_t)ct * R3T * 64 + lane;
 #pragma unroll
   for (int r = 0; r < R3T; ++r) wa[r] = wp[r * 64];
-  stage_grad_plane<true, DG3_THREADS>(plane, g3 + n * (C3 * P2), y3 + n * (C3 * P2), tid);
+  for (int i = tid; i < GPH * GPW * GCS / 4; i += DG3_THREADS)      // the border stays zero
+    reinterpret_cast<f32x4*>(plane)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   const int lpos = wave * 16 + j, q = min(lpos, P2 - 1);
   const int oy = q / W2, ox = q - oy * W2;
   const float* base = plane + (oy * GPW + ox) * GCS + 4 * kq;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+  for (;;) {
+    st.store(plane, tid);
+    __syncthreads();
+    const int64_t nn = n + slots;
+    if (nn < N) st.load(g3 + nn * (C3 * P2), y3 + nn * (C3 * P2), tid);      // uniform
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int ky = tap / 3, kx = tap - ky * 3;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-    for (int hc = 0; hc < 4; hc += 2) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(base + (ky * GPW + kx) * GCS + 16 * hc);
-      const f32x4 bw = *reinterpret_cast<const f32x4*>(base + (ky * GPW + kx) * GCS + 16 * hc + 16);
+      for (int hc = 0; hc < 4; hc += 2) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(base + (ky * GPW + kx) * GCS + 16 * hc);
+        const f32x4 bw = *reinterpret_cast<const f32x4*>(base + (ky * GPW + kx) * GCS + 16 * hc + 16);
 #pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {
-        acc = mfma16(wa[(tap * 4 + hc) * 4 + sp], bv[sp], acc);
-        acc_b = mfma16(wa[(tap * 4 + hc + 1) * 4 + sp], bw[sp], acc_b);
+        for (int sp = 0; sp < 4; ++sp) {
+          acc = mfma16(wa[(tap * 4 + hc) * 4 + sp], bv[sp], acc);
+          acc_b = mfma16(wa[(tap * 4 + hc + 1) * 4 + sp], bw[sp], acc_b);
+        }
       }
     }
-  }
-  acc += acc_b;
-  if (lpos < P2) {
-    const int64_t o = (n * P2 + q) * C2 + ct * 16 + 4 * kq;
-    const f32x4 m = *reinterpret_cast<const f32x4*>(y2 + o);
-    f32x4 out;
+    acc += acc_b;
+    if (lpos < P2) {
+      const int64_t o = (n * P2 + q) * C2 + ct * 16 + 4 * kq;
+      const f32x4 m = *reinterpret_cast<const f32x4*>(y2 + o);
+      f32x4 out;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[r] = m[r] > 0.f ? acc[r] : 0.f;
-    *reinterpret_cast<f32x4*>(dz2 + o) = out;
+      for (int r = 0; r < 4; ++r) out[r] = m[r] > 0.f ? acc[r] : 0.f;
+      *reinterpret_cast<f32x4*>(dz2 + o) = out;
+    }
+    if (nn >= N) break;
+    n = nn;
+    __syncthreads();
   }
 }
 
@@ -174,50 +201,60 @@ __global__ __launch_bounds__(DG3_THREADS) void dqn_dgrad3_kernel(const float* __
 __global__ __launch_bounds__(DG2_THREADS) void dqn_dgrad2_kernel(const float* __restrict__ dz2,
                                                                  const float* __restrict__ y1,
                                                                  const float* __restrict__ packed,
-                                                                 float* __restrict__ dz1) {
+                                                                 float* __restrict__ dz1, int64_t N) {
   __shared__ __attribute__((aligned(16))) float plane[GPH * GPW * GCS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
-  const int64_t n = blockIdx.x >> 2;
+  const int64_t slots = gridDim.x >> 2;
+  int64_t n = blockIdx.x >> 2;
   const int cls = (int)(blockIdx.x & 3), py = cls >> 1, px = cls & 1;
   const int cit = wave & 1, slot = wave >> 1;
   const int nu = H1 / 2 + py, nv = W1 / 2 + px, npix = nu * nv;        // 12 | 13 rows, 9 | 10 columns
+  NhwcStage<DG2_THREADS> st;
+  st.load(dz2 + n * (P2 * C2), tid);
   float wa[R2T];
   const float* __restrict__ wp = packed + PKT3 + (int64_t)(cls * 2 + cit) * R2T * 64 + lane;
 #pragma unroll
   for (int r = 0; r < R2T; ++r) wa[r] = wp[r * 64];
-  stage_grad_plane<false, DG2_THREADS>(plane, dz2 + n * (P2 * C2), nullptr, tid);
-  __syncthreads();
-  for (int t = slot; t * 16 < npix; t += 4) {
-    const int lp = t * 16 + j, p = min(lp, npix - 1);
-    const int u = p / nv, v = p - u * nv;
-    const float* base = plane + ((u + 2 - py) * GPW + (v + 2 - px)) * GCS + 4 * kq;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+  for (;;) {
+    st.store(plane, tid);
+    __syncthreads();
+    const int64_t nn = n + slots;
+    if (nn < N) st.load(dz2 + nn * (P2 * C2), tid);                    // uniform
+    for (int t = slot; t * 16 < npix; t += 4) {
+      const int lp = t * 16 + j, p = min(lp, npix - 1);
+      const int u = p / nv, v = p - u * nv;
+      const float* base = plane + ((u + 2 - py) * GPW + (v + 2 - px)) * GCS + 4 * kq;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ab = 0; ab < 4; ++ab) {
-      const int off = -((ab >> 1) * GPW + (ab & 1)) * GCS;
+      for (int ab = 0; ab < 4; ++ab) {
+        const int off = -((ab >> 1) * GPW + (ab & 1)) * GCS;
 #pragma unroll
-      for (int hc = 0; hc < 4; hc += 2) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(base + off + 16 * hc);
-        const f32x4 bw = *reinterpret_cast<const f32x4*>(base + off + 16 * hc + 16);
+        for (int hc = 0; hc < 4; hc += 2) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(base + off + 16 * hc);
+          const f32x4 bw = *reinterpret_cast<const f32x4*>(base + off + 16 * hc + 16);
 #pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {
-          acc = mfma16(wa[(ab * 4 + hc) * 4 + sp], bv[sp], acc);
-          acc_b = mfma16(wa[(ab * 4 + hc + 1) * 4 + sp], bw[sp], acc_b);
+          for (int sp = 0; sp < 4; ++sp) {
+            acc = mfma16(wa[(ab * 4 + hc) * 4 + sp], bv[sp], acc);
+            acc_b = mfma16(wa[(ab * 4 + hc + 1) * 4 + sp], bw[sp], acc_b);
+          }
         }
       }
-    }
-    acc += acc_b;
-    if (lp < npix) {
-      const int pos = (2 * u + 1 - py) * W1 + 2 * v + 1 - px;
-      const int64_t o = (n * P1 + pos) * C1 + cit * 16 + 4 * kq;
-      const f32x4 m = *reinterpret_cast<const f32x4*>(y1 + o);
-      f32x4 out;
+      acc += acc_b;
+      if (lp < npix) {
+        const int pos = (2 * u + 1 - py) * W1 + 2 * v + 1 - px;
+        const int64_t o = (n * P1 + pos) * C1 + cit * 16 + 4 * kq;
+        const f32x4 m = *reinterpret_cast<const f32x4*>(y1 + o);
+        f32x4 out;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[r] = m[r] > 0.f ? acc[r] : 0.f;
-      *reinterpret_cast<f32x4*>(dz1 + o) = out;
+        for (int r = 0; r < 4; ++r) out[r] = m[r] > 0.f ? acc[r] : 0.f;
+        *reinterpret_cast<f32x4*>(dz1 + o) = out;
+      }
     }
+    if (nn >= N) break;
+    n = nn;
+    __syncthreads();
   }
 }
 
@@ -471,12 +508,13 @@ extern "C" int rlpyt_dqn_convs_bwd_f32(const uint8_t* obs, int64_t N, const floa
   float* part3 = workspace + off[5];
   RL_LAUNCH(dqn_pack_bwd_weights_kernel, dim3((PACKED_BWD + 255) / 256), dim3(256), 0, s, w2, w3, packed);
   RL_LAUNCH_CHECK();
-  RL_LAUNCH(dqn_dgrad3_kernel, dim3((unsigned)(N * 4)), dim3(DG3_THREADS), 0, s, g3, y3, y2, packed, dz2);
+  const int64_t slots = std::min<int64_t>(N, kPersistImages);
+  RL_LAUNCH(dqn_dgrad3_kernel, dim3((unsigned)(slots * 4)), dim3(DG3_THREADS), 0, s, g3, y3, y2, packed, dz2, N);
   RL_LAUNCH_CHECK();
   RL_LAUNCH((dqn_wgrad23_kernel<C2, H2, W2, 3, 3, 1, 12, true>), dim3((unsigned)(grp[2] * 4)), dim3(12 * 64),
             0, s, y2, g3, y3, part3, N, G[2]);
   RL_LAUNCH_CHECK();
-  RL_LAUNCH(dqn_dgrad2_kernel, dim3((unsigned)(N * 4)), dim3(DG2_THREADS), 0, s, dz2, y1, packed, dz1);
+  RL_LAUNCH(dqn_dgrad2_kernel, dim3((unsigned)(slots * 4)), dim3(DG2_THREADS), 0, s, dz2, y1, packed, dz1, N);
   RL_LAUNCH_CHECK();
   RL_LAUNCH((dqn_wgrad23_kernel<C1, H1, W1, 4, 4, 2, 8, false>), dim3((unsigned)(grp[1] * 4)), dim3(8 * 64),
             0, s, y1, dz2, nullptr, part2, N, G[1]);

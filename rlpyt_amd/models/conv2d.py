@@ -42,13 +42,12 @@ class Conv2dModel(torch.nn.Module):
 
     # set False (or RLPYT_DQN_CONVS=0) for the library convolutions in no-grad forwards too (A/B tests)
     use_fused_nograd_convs = os.environ.get("RLPYT_DQN_CONVS", "1") != "0"
-    # No-grad forwards: the own kernels win at every size measured (N = 128 .. 5440: 60 / 135 us ..
-    # 1780 / 2165 us own / library, profiles/r6_dqn_convs_large_n.log) -- bounded only by the workspace
-    # (88 KB of kept activations per image).  Under autograd forward + backward are level with the
-    # library from ~2500 images on (2614 / 2620 us at 2560, 5626 / 5317 us at 5440): R2D1's 5440-image
-    # online pass stays on the library.
+    # The own kernels win at every size measured, with and without autograd (round 6, workgroups persistent
+    # over the images beyond 256: no-grad forward 63 / 136 us at 128 images .. 1451 / 2197 us at 5440 own /
+    # library, forward + backward 230 / 414 us .. 4438 / 5339 us; profiles/r6_dqn_convs_large_n.log) --
+    # bounded only by the workspaces (88 KB of kept activations + 88 KB of gradients per image).
     FUSED_MAX_IMAGES = int(os.environ.get("RLPYT_DQN_CONVS_MAX_N", 1 << 15))     # (env: A/B runs)
-    FUSED_MAX_IMAGES_GRAD = 2560
+    FUSED_MAX_IMAGES_GRAD = int(os.environ.get("RLPYT_DQN_CONVS_MAX_N_GRAD", 1 << 15))
 
     _packed = None                  # the weights in the kernels' register order (sampling only)
 
