@@ -26,18 +26,28 @@ __global__ __launch_bounds__(256) void commit_rows_kernel(const rlpyt_row_copy* 
   const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
   const bool wide = (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) &&
                     (zw == nullptr || (ub & 15) == 0);
+  // (unit lookups in 32-bit arithmetic: a 64-bit division per lane tripled this kernel's time; entries are
+  //  far below 4 GB)
+  const uint32_t ub32 = (uint32_t)ub;
   if (wide) {
     const int64_t n16 = n >> 4;
     const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
     uint4* __restrict__ d4 = reinterpret_cast<uint4*>(dst);
-    for (int64_t i = tid; i < n16; i += nthr) {
-      uint4 v = s4[i];
-      if (zw != nullptr && zw[(i << 4) / ub]) v = uint4{0u, 0u, 0u, 0u};
-      d4[i] = v;
+    if (zw == nullptr) {
+      for (int64_t i = tid; i < n16; i += nthr) d4[i] = s4[i];
+      for (int64_t i = (n16 << 4) + tid; i < n; i += nthr) dst[i] = src[i];
+    } else {
+      for (int64_t i = tid; i < n16; i += nthr) {
+        uint4 v = s4[i];
+        if (zw[((uint32_t)i << 4) / ub32]) v = uint4{0u, 0u, 0u, 0u};
+        d4[i] = v;
+      }
+      for (int64_t i = (n16 << 4) + tid; i < n; i += nthr) dst[i] = zw[(uint32_t)i / ub32] ? 0 : src[i];
     }
-    for (int64_t i = (n16 << 4) + tid; i < n; i += nthr) dst[i] = (zw != nullptr && zw[i / ub]) ? 0 : src[i];
+  } else if (zw == nullptr) {
+    for (int64_t i = tid; i < n; i += nthr) dst[i] = src[i];
   } else {
-    for (int64_t i = tid; i < n; i += nthr) dst[i] = (zw != nullptr && zw[i / ub]) ? 0 : src[i];
+    for (int64_t i = tid; i < n; i += nthr) dst[i] = zw[(uint32_t)i / ub32] ? 0 : src[i];
   }
 }
 
@@ -113,7 +123,7 @@ extern "C" int rlpyt_commit_rows(const rlpyt_row_copy* table_dev, int n_entries,
   RL_CHECK_ARG(n_entries >= 0 && n_entries <= 64, RLPYT_EINVAL, "rlpyt_commit_rows: 0..64 entries");
   if (n_entries == 0) return RLPYT_OK;
   RL_CHECK_ARG(table_dev != nullptr, RLPYT_EINVAL, "rlpyt_commit_rows: null table");
-  const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(max_entry_bytes, 256 * 64), 1024));
+  const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(max_entry_bytes, 256 * 16), 1024));
   RL_LAUNCH(commit_rows_kernel, dim3((unsigned)chunks, (unsigned)n_entries), dim3(256), 0,
                      (hipStream_t)stream, table_dev, t_dev);
   RL_LAUNCH_CHECK();
