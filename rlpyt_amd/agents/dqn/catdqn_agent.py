@@ -34,7 +34,7 @@ class CatDqnAgent(DqnAgent):
 
     @torch.no_grad()
     def step(self, observation, prev_action, prev_reward):
-        prev_action = self.distribution.to_onehot(prev_action)
+        prev_action = self._onehot(prev_action)
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         p = self.model(obs, pa, pr)
         action = self.distribution.sample(p, generator=self.sample_generator,

@@ -89,8 +89,17 @@ class EpsilonGreedyAgentMixin:
 
 
 class DqnAgent(EpsilonGreedyAgentMixin, BaseAgent):
+    def _onehot(self, prev_action, model=None):
+        """``distribution.to_onehot(prev_action)`` (rlpyt/agents/dqn/dqn_agent.py:28) -- unless the model
+        declares that its forward never reads the previous action / reward (``uses_prev_inputs = False``,
+        the attribute the HBM sampler reads too: it then passes ``None`` for both)."""
+        model = self.model if model is None else model
+        if prev_action is None or not getattr(getattr(model, "module", model), "uses_prev_inputs", True):
+            return prev_action
+        return self.distribution.to_onehot(prev_action)
+
     def __call__(self, observation, prev_action, prev_reward):
-        prev_action = self.distribution.to_onehot(prev_action)
+        prev_action = self._onehot(prev_action)
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         return self._out(self.model(obs, pa, pr))
 
@@ -130,7 +139,7 @@ class DqnAgent(EpsilonGreedyAgentMixin, BaseAgent):
 
     @torch.no_grad()
     def step(self, observation, prev_action, prev_reward):
-        prev_action = self.distribution.to_onehot(prev_action)
+        prev_action = self._onehot(prev_action)
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         q = self.model(obs, pa, pr)
         action = self.distribution.sample(q, generator=self.sample_generator,
@@ -138,7 +147,7 @@ class DqnAgent(EpsilonGreedyAgentMixin, BaseAgent):
         return self._out(AgentStep(action=action, agent_info=AgentInfo(q=q)))
 
     def target(self, observation, prev_action, prev_reward):
-        prev_action = self.distribution.to_onehot(prev_action)
+        prev_action = self._onehot(prev_action, self.target_model)
         obs, pa, pr = self._to_model_device(observation, prev_action, prev_reward)
         return self._out(self.target_model(obs, pa, pr))
 

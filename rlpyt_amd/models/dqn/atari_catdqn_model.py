@@ -42,6 +42,8 @@ class AtariCatDqnModel(torch.nn.Module):
         """Entering sample / eval mode: the conv stack packs its weights once for that phase."""
         self.conv.refresh_step_weights()
 
+    uses_prev_inputs = False          # (see AtariDqnModel)
+
     def forward(self, observation, prev_action, prev_reward):
         """Probability masses [.., A, n_atoms] (softmax over atoms)."""
         lead_dim, T, B, img_shape = infer_leading_dims(observation, 3)

@@ -30,6 +30,11 @@ class AtariDqnModel(torch.nn.Module):
         """Entering sample / eval mode: the conv stack packs its weights once for that phase."""
         self.conv.refresh_step_weights()
 
+    # forward() never reads prev_action / prev_reward (as rlpyt/models/dqn/atari_dqn_model.py:53-64): agents
+    # then hand them over as they are instead of building a one-hot nobody reads (a fill + a scatter
+    # per forward pass: six launches per DQN update)
+    uses_prev_inputs = False
+
     def forward(self, observation, prev_action, prev_reward):
         lead_dim, T, B, img_shape = infer_leading_dims(observation, 3)
         q = self.head(self.conv.features(observation, T * B, img_shape))
