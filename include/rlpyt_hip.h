@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 12
+#define RLPYT_HIP_ABI_VERSION 13
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -553,6 +553,12 @@ int rlpyt_atari_sample_convs_to_f32(uint8_t* obs, const int64_t* t_dev, int64_t 
                                     float* y2, uint8_t* dst_stage /*nullable*/,
                                     rlpyt_stream_t stream);
 int64_t rlpyt_atari_conv_wgrad_workspace_bytes(void);
+/* Importance-sampling weights of a prioritized batch (rlpyt/replays/non_sequence/prioritized.py:52-56,
+ * sequence/prioritized.py:96-100) in one launch (round 6, ABI 13): out[i] = float(w_i / max_j w_j) with
+ * w = (1 / (priorities + eps)) ** beta in float64; beta read from device memory when beta_dev != NULL
+ * (captured update graphs), else the by-value argument.  n <= 65536. */
+int rlpyt_is_weights_f64(const double* priorities, int64_t n, double eps, const double* beta_dev /*nullable*/,
+                         double beta, float* out, rlpyt_stream_t stream);
 /* No-grad forward of a single-layer LSTM over a sequence (torch.nn.LSTM in
  * rlpyt/models/dqn/atari_r2d1_model.py:61-63 as the target / warm-up / double-DQN passes of
  * rlpyt/algos/dqn/r2d1.py:199-224 run it).  xproj [T,B,4H] = x W_ih^T + b_ih + b_hh for every step

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (RLPYT_HIP_LIB: another build of the same ABI, for A/B runs of two kernel versions on one box)
 LIB_PATH = os.environ.get("RLPYT_HIP_LIB") or os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class CopyDesc(ctypes.Structure):
@@ -143,6 +143,7 @@ _SIGNATURES = {
                                                 _p, _p, _p, _p, _p, _p, c_float, _p, _p, _p]),
     "rlpyt_rnn_step_inputs_f32": (c_int, [_p, c_int, c_int, _p, c_int, _p, _p, _p, _p, c_int, _p, c_int, _p,
                                           _p, c_int64, _p]),
+    "rlpyt_is_weights_f64": (c_int, [_p, c_int64, ctypes.c_double, _p, ctypes.c_double, _p, _p]),
     "rlpyt_lstm_seq_f32": (c_int, [_p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
     "rlpyt_lstm_seq_train_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
     "rlpyt_lstm_seq_bwd_f32": (c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),

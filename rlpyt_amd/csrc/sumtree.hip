@@ -549,3 +549,38 @@ extern "C" int rlpyt_sumtree_update(rlpyt_sumtree* t, const double* new_prioriti
   // repeated update recomputes the same unique set here, so nothing to mirror.)
   return RLPYT_OK;
 }
+
+// Importance-sampling weights of a prioritized batch (rlpyt/replays/non_sequence/prioritized.py:52-56,
+// sequence/prioritized.py:96-100): w = (1 / (p + eps)) ** beta in float64, divided by its maximum, as
+// float32 -- ONE launch instead of the seven elementwise / reduction launches of the tensor expression
+// (add, reciprocal, pow, max, divide, cast + the exponent's dtype copy).  beta from device memory (captured
+// update graphs) or by value.  One workgroup; n <= 65536.
+namespace rlpyt {
+namespace {
+__global__ __launch_bounds__(1024) void is_weights_kernel(const double* __restrict__ pri, int n, double eps,
+                                                          const double* __restrict__ beta_dev, double beta,
+                                                          float* __restrict__ out) {
+  __shared__ double red[16];
+  const double b = beta_dev != nullptr ? beta_dev[0] : beta;
+  double mx = 0.0;                                      // weights are positive
+  for (int i = threadIdx.x; i < n; i += 1024) mx = fmax(mx, pow(1.0 / (pri[i] + eps), b));
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, kWave));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int w = 1; w < 16; ++w) mx = fmax(mx, red[w]);
+  for (int i = threadIdx.x; i < n; i += 1024) out[i] = (float)(pow(1.0 / (pri[i] + eps), b) / mx);
+}
+}  // namespace
+}  // namespace rlpyt
+
+extern "C" int rlpyt_is_weights_f64(const double* priorities, int64_t n, double eps, const double* beta_dev,
+                                    double beta, float* out, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(n >= 0 && n <= 65536, RLPYT_EINVAL, "rlpyt_is_weights_f64: need 0 <= n <= 65536");
+  if (n == 0) return RLPYT_OK;
+  RL_CHECK_ARG(priorities && out, RLPYT_EINVAL, "rlpyt_is_weights_f64: null pointer");
+  RL_LAUNCH(rlpyt::is_weights_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, priorities, (int)n, eps,
+            beta_dev, beta, out);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}

@@ -810,6 +810,24 @@ def fc_small_partials(x, weight):
     return ws, lib.rlpyt_fc_small_ksplit(K)
 
 
+def is_weights(priorities, eps, beta):
+    """Importance-sampling weights ``float((1 / (p + eps)) ** beta / max)`` of a prioritized batch, float64
+    inside, one launch (``rlpyt_is_weights_f64``); ``beta``: a python float or a float64 device scalar
+    tensor (captured update graphs)."""
+    _lib.require_gpu()
+    assert priorities.dtype == torch.float64 and priorities.is_contiguous() and priorities.is_cuda
+    n = priorities.numel()
+    out = torch.empty(priorities.shape, dtype=torch.float32, device=priorities.device)
+    if isinstance(beta, torch.Tensor):
+        assert beta.dtype == torch.float64 and beta.device == priorities.device and beta.numel() == 1
+        check(lib.rlpyt_is_weights_f64(ptr(priorities), n, float(eps), ptr(beta), 0.0, ptr(out), stream()),
+              "rlpyt_is_weights_f64")
+    else:
+        check(lib.rlpyt_is_weights_f64(ptr(priorities), n, float(eps), None, float(beta), ptr(out), stream()),
+              "rlpyt_is_weights_f64")
+    return out
+
+
 def eps_greedy(q, eps, uniforms, t_dev=None):
     """Epsilon-greedy actions for Q-values ``q [n, A]`` from pre-drawn uniforms ``[T, n]`` (row
     ``t_dev[0]``, or row 0): ``u < eps ? floor(u / eps * A) : argmax`` in one launch

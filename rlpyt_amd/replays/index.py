@@ -101,8 +101,17 @@ class PriorityDraw:
             self._drawn = (T_idxs, B_idxs, self.tree.t, self._appended)
         if self.stride > 1:
             T_idxs = T_idxs * self.stride
-        w = (1. / (pri + self.weight_eps)) ** self.beta
-        return T_idxs, B_idxs, (w / w.max()).float()
+        return T_idxs, B_idxs, self._is_weights(pri, self.beta)
+
+    def _is_weights(self, pri, beta):
+        """``(1 / (p + eps)) ** beta`` over its maximum, float64 inside, as float32
+        (rlpyt/replays/non_sequence/prioritized.py:52-56) -- one launch on the device."""
+        if pri.is_cuda and pri.dtype == torch.float64:
+            return ops.is_weights(pri.contiguous(), self.weight_eps, beta)
+        if isinstance(beta, torch.Tensor):
+            beta = beta.to(pri.dtype)
+        w = torch.pow(1. / (pri + self.weight_eps), beta)
+        return (w / w.max()).float()
 
     def draw_device(self, uniforms, beta):
         """``draw`` from device-resident uniforms (f64 ``[n]``) with the importance exponent as a
@@ -112,8 +121,7 @@ class PriorityDraw:
             self._drawn = (T_idxs, B_idxs, self.tree.t, self._appended)
         if self.stride > 1:
             T_idxs = T_idxs * self.stride
-        w = torch.pow(1. / (pri + self.weight_eps), beta.to(pri.dtype))
-        return T_idxs, B_idxs, (w / w.max()).float()
+        return T_idxs, B_idxs, self._is_weights(pri, beta)
 
     def update(self, priorities):
         """New priorities of the last drawn batch: ``** alpha`` in the caller's dtype (as numpy does

@@ -721,3 +721,24 @@ def test_canary_guard_bands_catch_out_of_bounds_writes():
     finally:
         if not was_on:
             canary.disable()
+
+
+@pytest.mark.gpu
+def test_is_weights_match_the_float64_expression(ops):
+    """``rlpyt_is_weights_f64`` (one launch) against the reference's expression in numpy float64
+    (rlpyt/replays/non_sequence/prioritized.py:52-56: ``(1 / (p + eps)) ** beta``, divided by its
+    maximum, then float32): beta by value and from a device scalar; batch sizes below and above one
+    pass of the workgroup; priorities over many orders of magnitude.  float64 ``pow`` may differ from
+    libm's in the last bit, i.e. by 1e-16 -- equal after the float32 cast up to one float32 ulp."""
+    rng = np.random.RandomState(3)
+    for n, eps, beta in ((128, 1e-6, 0.4), (1, 1e-6, 1.0), (3000, 0., 0.6), (7, 1e-6, 0.0)):
+        p = np.exp(rng.uniform(-12, 6, n))
+        want = (1. / (p + eps)) ** beta
+        want = (want / want.max()).astype(np.float32)
+        pd = torch.from_numpy(p).cuda()
+        got = ops.is_weights(pd, eps, beta).cpu().numpy()
+        got_dev = ops.is_weights(pd, eps, torch.tensor([beta], dtype=torch.float64, device="cuda")).cpu().numpy()
+        assert got.dtype == np.float32 and got.shape == want.shape
+        np.testing.assert_array_equal(got, got_dev)
+        np.testing.assert_allclose(got, want, rtol=1.2e-7, atol=0)
+        assert got.max() == 1.0

@@ -738,6 +738,12 @@ def _update_tick():
         assert int(tick.item()) == c and int(ctr.item()) == cur
 
 
+@case("is_weights_kernel")
+def _is_weights():
+    import test_hip_parity as P
+    P.test_is_weights_match_the_float64_expression(_ops())
+
+
 @case("fill_f64_kernel", "write_input_pri_kernel")
 def _sumtree_input_priorities():
     import test_hip_parity as P
