@@ -86,7 +86,7 @@ class CapturedUpdates:
                                                          b["draw_cur"][self.n:]))
         a.optimizer.zero_grad(set_to_none=True)
         loss, td_abs = a.loss(batch)
-        loss.backward()
+        loss.backward(ops.unit_seed(loss.device))
         grad_norm = a.optimizer.launch_captured_step(a.clip_grad_norm, b["hyper"], b["ctr"])
         if a.prioritized_replay:
             rb.update_batch_priorities(td_abs)

@@ -148,7 +148,7 @@ class DQN(RlAlgorithm):
         batch = self.replay_buffer.sample_batch(self.batch_size)
         self.optimizer.zero_grad(set_to_none=True)
         loss, td_abs = self.loss(batch)
-        loss.backward()
+        loss.backward(ops.unit_seed(loss.device) if loss.is_cuda else None)
         grad_norm = self.clip_and_step()
         if self.prioritized_replay:
             self.replay_buffer.update_batch_priorities(td_abs)

@@ -77,7 +77,7 @@ class R2D1(DQN):
         batch = self.replay_buffer.sample_batch(self.batch_B)
         self.optimizer.zero_grad(set_to_none=True)
         loss, td_abs, priorities = self.loss(batch)
-        loss.backward()
+        loss.backward(ops.unit_seed(loss.device) if loss.is_cuda else None)
         grad_norm = self.clip_and_step()
         if self.prioritized_replay:
             self.replay_buffer.update_batch_priorities(priorities)

@@ -39,6 +39,26 @@ def _f32(x):
     return x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
 
 
+_unit_seeds = {}
+
+
+def unit_seed(device):
+    """A standing scalar 1 per device for ``loss.backward(unit_seed(dev))``: ``loss.backward()`` fills a
+    fresh one per update, and the loss Functions below recognise THIS tensor in their backward and hand
+    out their stored gradients as they are instead of multiplying them by it (one fill + one multiply per
+    update; any other incoming gradient takes the general path)."""
+    device = torch.device(device)
+    one = _unit_seeds.get(device)
+    if one is None:
+        one = _unit_seeds[device] = torch.ones((), dtype=torch.float32, device=device)
+    return one
+
+
+def _is_unit_seed(g):
+    one = _unit_seeds.get(g.device)
+    return one is not None and g.data_ptr() == one.data_ptr() and g.dim() == 0
+
+
 # --------------------------------------------------------------------------------------
 # scans
 # --------------------------------------------------------------------------------------
@@ -368,7 +388,9 @@ class _DqnLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_td):
         (gq,) = ctx.saved_tensors
-        return ((gq * g_loss).reshape(ctx.shape), None, None, None, None, None, None, None, None)
+        if not _is_unit_seed(g_loss):
+            gq = gq * g_loss
+        return (gq.reshape(ctx.shape), None, None, None, None, None, None, None, None)
 
 
 def dqn_loss(qs, target_qs, next_qs, action, return_, done_n, is_weights, disc_n, delta_clip):
@@ -408,7 +430,7 @@ class _R2d1Loss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_td, _g_pri):
         (gq,) = ctx.saved_tensors
-        return (gq * g_loss,) + (None,) * 11
+        return (gq if _is_unit_seed(g_loss) else gq * g_loss,) + (None,) * 11
 
 
 def r2d1_loss(qs, target_qs, next_qs, action, return_, done_n, valid, is_weights, disc_n,
@@ -451,7 +473,7 @@ class _CatDqnLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_kl):
         (gp,) = ctx.saved_tensors
-        return ((gp * g_loss).reshape(ctx.shape),) + (None,) * 11
+        return ((gp if _is_unit_seed(g_loss) else gp * g_loss).reshape(ctx.shape),) + (None,) * 11
 
 
 def cat_dqn_loss(ps, target_ps, next_ps, action, return_, done_n, is_weights, valid, z, v_min,

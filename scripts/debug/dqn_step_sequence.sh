@@ -18,8 +18,9 @@ end = ticks[-38]
 prev_end = None
 for r in rows[j:end]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("rlpyt::(anonymous namespace)::", "").replace("void ", "")
-    name = re.sub(r"at::native::(\(anonymous namespace\)::)?", "", name)[:90]
+    name = r["Kernel_Name"].replace("rlpyt::(anonymous namespace)::", "").replace("void ", "")
+    name = re.sub(r"at::native::(\(anonymous namespace\)::)?", "", name)
+    name = re.sub(r"\(.*", "", name)[:110]
     gap = 0 if prev_end is None else (s - prev_end) / 1e3
     print(f"{gap:8.1f} gap {(e - s) / 1e3:7.1f} us  {name}")
     prev_end = e
