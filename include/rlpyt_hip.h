@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 13
+#define RLPYT_HIP_ABI_VERSION 14
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -604,6 +604,13 @@ int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const float* w1, cons
                             const float* w2, const float* b2, const float* w3, const float* b3,
                             const float* packed /*nullable*/, float scale, float* workspace, float* out,
                             rlpyt_stream_t stream);
+
+/* conv1 of that stack alone -- Conv2d(4, 32, 8, stride 4) + bias + ReLU on uint8 frames [N,4,104,80], y1
+ * [N][475][32] channels-last -- as an exact bf16x3 contraction (the frames are exact in bf16, w1 split into
+ * three bf16 pieces whose sum is exact; f32 accumulate): round 6, ABI 14.  rlpyt_dqn_convs_fwd_f32 runs its
+ * first layer through it whenever w1 is given in the torch layout [32,4,8,8]. */
+int rlpyt_dqn_conv1_f32(const uint8_t* obs, int64_t N, const float* w1, const float* b1, float scale,
+                        float* y1, rlpyt_stream_t stream);
 
 /* Backward pass of the same stack at update-batch sizes (round 6, ABI 10): autograd through
  * `self.conv` of rlpyt/models/dqn/atari_dqn_model.py:30-37 in the online network's pass of DQN.loss

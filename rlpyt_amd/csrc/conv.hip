@@ -323,6 +323,106 @@ __global__ __launch_bounds__(C1F_THREADS) void conv1_fwd_kernel(
 #undef RLPYT_F3_PREFETCH
 }
 
+// The DQN family's conv1 -- Conv2d(4, 32, 8, stride 4) on the same 4 x 104 x 80 frames: conv1_fwd_kernel's
+// geometry with 32 output channels (rlpyt/models/dqn/atari_dqn_model.py:30-37) -- on the same exact
+// bf16x3 contraction (round 6; csrc/dqn_convs.hip ran it on the f32 MFMA at 1/5 of this matrix-pipe
+// rate: 12.8 us of MFMA issue per image and CU against 2.4 us here).  No gather (the images of a pass are
+// contiguous), output [N][475][32] channels-last as dqn_conv23_kernel reads it.  A wave owns one 16-channel
+// tile (its w1 pieces in 96 VGPRs for the whole kernel) and every second pair of position tiles; a
+// workgroup walks images (x `split` parts for small batches), the next image is fetched into registers
+// behind the MFMAs; two workgroups per CU (2 x 68 KB of LDS): one stages while the other contracts.
+__global__ __launch_bounds__(C1F_THREADS) void dqn_conv1_x3_kernel(
+    const uint8_t* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
+    float* __restrict__ y1, int64_t M, float scale, int split) {
+  constexpr int CO = 32;
+  __shared__ __attribute__((aligned(16))) uint8_t xb[F3_XB];
+  __shared__ int ptab[480];               // position -> byte offset of its patch origin
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kb = lane >> 4;
+  const int ct = wave & 1, slot = wave >> 1;          // channel tile, pair slot (2 per workgroup)
+  for (int i = tid; i < 480; i += C1F_THREADS) {
+    const int pos = min(i, P1 - 1);
+    ptab[i] = c1_patch_origin(pos);
+  }
+  // the 32 KB of weights pass through the (not yet used) image buffer: coalesced 16-byte loads
+  for (int i = tid; i < CO * 256 / 4; i += C1F_THREADS)
+    reinterpret_cast<uint4*>(xb)[i] = reinterpret_cast<const uint4*>(w1)[i];
+  __syncthreads();
+  uint4 wa[8][3];
+#pragma unroll
+  for (int st = 0; st < 8; ++st)
+    c1_weight_pieces(reinterpret_cast<const float*>(xb), ct * 16 + n, kb, st, wa[st]);
+  float bias[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = b1[ct * 16 + 4 * kb + r];
+
+  constexpr int NPI = (C1_UNITS + C1F_THREADS - 1) / C1F_THREADS;   // 9 staging units per thread
+  uint2 pimg[NPI][2];
+  int usrc[NPI];
+#pragma unroll
+  for (int k = 0; k < NPI; ++k) usrc[k] = c1_unit_src(min(tid + k * C1F_THREADS, C1_UNITS - 1));
+#define RLPYT_D3_PREFETCH(mm_)                                                                 \
+  {                                                                                            \
+    const uint8_t* __restrict__ src_ = obs + ((mm_) / split) * IMG;                            \
+    _Pragma("unroll") for (int k = 0; k < NPI; ++k) {                                          \
+      pimg[k][0] = *reinterpret_cast<const uint2*>(src_ + usrc[k]);                            \
+      pimg[k][1] = *reinterpret_cast<const uint2*>(src_ + usrc[k] + W0);                       \
+    }                                                                                          \
+  }
+  if ((int64_t)blockIdx.x < M * split) RLPYT_D3_PREFETCH((int64_t)blockIdx.x)
+  const uint8_t* const xlane = xb + c1_lane_off(kb);
+
+  for (int64_t mm = blockIdx.x; mm < M * split; mm += gridDim.x) {
+    const int64_t m = mm / split;
+    const int part = (int)(mm - m * split);
+    __syncthreads();  // the previous image's (or the weights') readers are done
+#pragma unroll
+    for (int k = 0; k < NPI; ++k) {
+      const int i = tid + k * C1F_THREADS;
+      if (i < C1_UNITS) c1_stage_unit(xb, i, pimg[k][0], pimg[k][1]);
+    }
+    __syncthreads();
+    if (mm + gridDim.x < M * split) RLPYT_D3_PREFETCH(mm + gridDim.x)
+    for (int p = part * 2 + slot; p < 15; p += split * 2) {
+      const int pos0 = p * 32 + n, pos1 = pos0 + 16;
+      const uint8_t* bp0 = xlane + ptab[pos0];
+      const uint8_t* bp1 = xlane + ptab[pos1];
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      uint4 c0 = *reinterpret_cast<const uint4*>(bp0), c1 = *reinterpret_cast<const uint4*>(bp1);
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        uint4 n0 = c0, n1 = c1;
+        if (st < 7) {
+          n0 = *reinterpret_cast<const uint4*>(bp0 + c1_step_off(st + 1));
+          n1 = *reinterpret_cast<const uint4*>(bp1 + c1_step_off(st + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0x6);
+        const uint4 v0 = c0, v1 = c1;
+#pragma unroll
+        for (int s2 = 2; s2 >= 0; --s2) {   // lo, mid, hi
+          acc0 = mfma_bf16(wa[st][s2], v0, acc0);
+          acc1 = mfma_bf16(wa[st][s2], v1, acc1);
+        }
+        __builtin_amdgcn_sched_barrier(0x6);
+        c0 = n0;
+        c1 = n1;
+      }
+      // unconditional stores (see conv1_fwd_kernel): a lane past position 474 repeats position 474's
+      float* out = y1 + m * (int64_t)(P1 * CO) + ct * 16 + 4 * kb;
+      f32x4 o0, o1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o0[r] = fmaxf(acc0[r] * scale + bias[r], 0.f);
+        o1[r] = fmaxf(acc1[r] * scale + bias[r], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(out + min(pos0, P1 - 1) * CO) = o0;
+      *reinterpret_cast<f32x4*>(out + min(pos1, P1 - 1) * CO) = o1;
+    }
+  }
+#undef RLPYT_D3_PREFETCH
+}
+
 // Stage one image's y1 [475,16] into the zero-bordered plane pad[(iy+1)*PW + ix+1][PS].
 template <int PS>
 __device__ __forceinline__ void stage_y1_padded(float* pad, const float* __restrict__ y1img, int tid,
@@ -1995,6 +2095,22 @@ extern "C" int rlpyt_atari_conv1_fwd_f32(const uint8_t* obs, const int64_t* flat
   const int split = (M * 2 <= cus) ? 4 : (M <= cus ? 2 : 1);  // M <= 128: 4, M <= 256: 2
   RL_LAUNCH(conv1_fwd_kernel, dim3(grid_for(M * split, 2)), dim3(C1F_THREADS), 0,   // 2 x 67 KB of LDS per CU
                      (hipStream_t)stream, obs, flat_idx, T, B, w1, b1, y1, M, scale, split);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+// conv1 of the DQN-family stack on the bf16x3 contraction (called by rlpyt_dqn_convs_fwd_f32, csrc/dqn_convs.hip)
+extern "C" int rlpyt_dqn_conv1_f32(const uint8_t* obs, int64_t N, const float* w1, const float* b1,
+                                   float scale, float* y1, rlpyt_stream_t stream) {
+  RL_CHECK_ARG(N >= 0, RLPYT_EINVAL, "rlpyt_dqn_conv1_f32: bad sizes");
+  if (N == 0) return RLPYT_OK;
+  RL_CHECK_ARG(obs && w1 && b1 && y1, RLPYT_EINVAL, "rlpyt_dqn_conv1_f32: null pointer");
+  RL_CHECK_ARG(RL_ALIGNED16(obs) && RL_ALIGNED16(y1) && RL_ALIGNED16(w1), RLPYT_ESHAPE,
+               "rlpyt_dqn_conv1_f32: obs / y1 / w1 must be 16-byte aligned");
+  const int cus = grid_for(1 << 30, 1);
+  const int split = (N * 2 <= cus) ? 4 : (N <= cus ? 2 : 1);  // N <= 128: 4, N <= 256: 2
+  RL_LAUNCH(dqn_conv1_x3_kernel, dim3(grid_for(N * split, 2)), dim3(C1F_THREADS), 0, (hipStream_t)stream,
+            obs, w1, b1, y1, N, scale, split);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

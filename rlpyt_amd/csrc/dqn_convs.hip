@@ -30,6 +30,8 @@
 //          27 x 21 pixels x (32 + 4) floats = 81.6 KB; y2 -> HBM as [N][108][64]
 //   conv3: the same over the 14 x 11 x (64 + 4) plane of y2 (41.9 KB); output in the flatten order of
 //          the reference's `conv(img).view(T * B, -1)`: [N][64][108].
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -308,9 +310,19 @@ extern "C" int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const floa
     RL_LAUNCH_CHECK();
   }
   const int64_t slots = std::min<int64_t>(N, kPersistImages);      // persistent workgroups beyond that
-  RL_LAUNCH(dqn_conv1_kernel, dim3((unsigned)(slots * D1_PARTS)), dim3(D1_THREADS), 0, s, obs, packed, b1,
-            scale, y1, N);
-  RL_LAUNCH_CHECK();
+  // conv1 on the exact bf16x3 contraction (csrc/conv.hip) whenever the weights are at hand in the torch
+  // layout; RLPYT_DQN_CONV1_X3=0: the f32-MFMA kernel (A/B runs)
+  static const bool conv1_x3 = [] {
+    const char* e = getenv("RLPYT_DQN_CONV1_X3");
+    return !(e && e[0] == '0');
+  }();
+  if (conv1_x3 && w1 != nullptr && RL_ALIGNED16(w1)) {
+    if (int rc = rlpyt_dqn_conv1_f32(obs, N, w1, b1, scale, y1, stream)) return rc;
+  } else {
+    RL_LAUNCH(dqn_conv1_kernel, dim3((unsigned)(slots * D1_PARTS)), dim3(D1_THREADS), 0, s, obs, packed, b1,
+              scale, y1, N);
+    RL_LAUNCH_CHECK();
+  }
   RL_LAUNCH((dqn_conv23_kernel<C1, H1, W1, 4, 4, 2, R2, false>), dim3((unsigned)(slots * 4)),
             dim3(D2_THREADS), 0, s, y1, packed + PK1, b2, y2, N);
   RL_LAUNCH_CHECK();

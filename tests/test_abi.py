@@ -85,6 +85,9 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert b"Kp >= F + A + 1 + H" in lib.rlpyt_hip_last_error()
     assert lib.rlpyt_dqn_convs_packed_floats() == 32 * 256 + 64 * 512 + 64 * 576
     assert lib.rlpyt_dqn_convs_workspace_floats(10) == 77824 + 10 * (475 * 32 + 108 * 64)
+    # conv1 of the DQN stack on the bf16 pipe (ABI 14)
+    assert lib.rlpyt_dqn_conv1_f32(None, 0, None, None, 1.0, None, None) == OK
+    assert lib.rlpyt_dqn_conv1_f32(None, 3, None, None, 1.0, None, None) != OK
     # importance-sampling weights (ABI 13)
     assert lib.rlpyt_is_weights_f64(None, 0, 1e-6, None, 0.4, None, None) == OK
     assert lib.rlpyt_is_weights_f64(None, 5, 1e-6, None, 0.4, None, None) != OK

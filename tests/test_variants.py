@@ -561,7 +561,27 @@ def _gemm_tn_x6():
     Cv.test_gemm_tn_bf16x6_is_f32_accurate(_ops(), 132, 200, 2080)    # ragged K chunks + partials
 
 
-@case("dqn_pack_weights_kernel", "dqn_conv1_kernel",
+@case("dqn_conv1_kernel")
+def _dqn_conv1_f32_mfma():
+    """The f32-MFMA conv1 (callers that hand over packed weights only): same features as the bf16x3 one."""
+    import test_dqn_convs_gpu as D
+    from rlpyt_amd._lib import check, lib, ptr, stream
+    ops = _ops()
+    convs = [c.cuda() for c in D._stack(11)]
+    args = [p for c in convs for p in (c.weight.detach(), c.bias.detach())]
+    g = torch.Generator().manual_seed(12)
+    obs = torch.randint(0, 256, (7, 4, 104, 80), dtype=torch.uint8, generator=g).cuda()
+    want = ops.dqn_convs_fwd(obs, *args)
+    packed = ops.dqn_convs_pack(args[0], args[2], args[4])
+    ws = torch.empty(int(lib.rlpyt_dqn_convs_workspace_floats(7)), dtype=torch.float32, device="cuda")
+    out = torch.empty((7, 6912), dtype=torch.float32, device="cuda")
+    check(lib.rlpyt_dqn_convs_fwd_f32(ptr(obs), 7, None, ptr(args[1]), None, ptr(args[3]), None, ptr(args[5]),
+                                      ptr(packed), 1. / 255, ptr(ws), ptr(out), stream()), "fwd")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-6)
+
+
+@case("dqn_pack_weights_kernel", "dqn_conv1_x3_kernel",
       "dqn_conv23_kernel<32, 25, 19, 4, 4, 2, 128, false>",
       "dqn_conv23_kernel<64, 12, 9, 3, 3, 1, 144, true>")
 def _dqn_convs():
