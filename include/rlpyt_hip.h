@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 14
+#define RLPYT_HIP_ABI_VERSION 15
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -611,6 +611,16 @@ int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const float* w1, cons
  * first layer through it whenever w1 is given in the torch layout [32,4,8,8]. */
 int rlpyt_dqn_conv1_f32(const uint8_t* obs, int64_t N, const float* w1, const float* b1, float scale,
                         float* y1, rlpyt_stream_t stream);
+
+/* conv2 + conv3 of that stack on the bf16 matrix pipe ("bf16x6": both operands as three bf16 pieces, six
+ * products of order <= 2, f32 accumulate; round 6, ABI 15): rlpyt_dqn_convs_x6_pack turns w2 [64,32,4,4] /
+ * w3 [64,64,3,3] into operand-order pieces (rlpyt_dqn_convs_x6_packed_bytes() bytes), rlpyt_dqn_conv23_x6_f32
+ * maps y1 [N][475][32] -> y2 [N][108][64] -> out [N][6912].  rlpyt_dqn_convs_pack_f32 / _fwd_f32 use them:
+ * the packed buffer of rlpyt_dqn_convs_packed_floats() floats carries the pieces behind the f32 copies. */
+int64_t rlpyt_dqn_convs_x6_packed_bytes(void);
+int rlpyt_dqn_convs_x6_pack(const float* w2, const float* w3, void* packed, rlpyt_stream_t stream);
+int rlpyt_dqn_conv23_x6_f32(const float* y1, int64_t N, const void* packed, const float* b2, const float* b3,
+                            float* y2, float* out, rlpyt_stream_t stream);
 
 /* Backward pass of the same stack at update-batch sizes (round 6, ABI 10): autograd through
  * `self.conv` of rlpyt/models/dqn/atari_dqn_model.py:30-37 in the online network's pass of DQN.loss

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (RLPYT_HIP_LIB: another build of the same ABI, for A/B runs of two kernel versions on one box)
 LIB_PATH = os.environ.get("RLPYT_HIP_LIB") or os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class CopyDesc(ctypes.Structure):
@@ -151,6 +151,9 @@ _SIGNATURES = {
     "rlpyt_dqn_convs_packed_floats": (c_int64, []),
     "rlpyt_dqn_convs_pack_f32": (c_int, [_p, _p, _p, _p, _p]),
     "rlpyt_dqn_convs_fwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, _p, _p, c_float, _p, _p, _p]),
+    "rlpyt_dqn_convs_x6_packed_bytes": (c_int64, []),
+    "rlpyt_dqn_convs_x6_pack": (c_int, [_p, _p, _p, _p]),
+    "rlpyt_dqn_conv23_x6_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, _p]),
     "rlpyt_dqn_conv1_f32": (c_int, [_p, c_int64, _p, _p, c_float, _p, _p]),
     "rlpyt_dqn_convs_bwd_workspace_floats": (c_int64, [c_int64]),
     "rlpyt_dqn_convs_bwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, _p, c_float, _p, _p, _p, _p, _p, _p,

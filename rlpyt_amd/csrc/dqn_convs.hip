@@ -273,11 +273,21 @@ __global__ __launch_bounds__(D2_THREADS) void dqn_conv23_kernel(const float* __r
 
 using namespace rlpyt;
 
-extern "C" int64_t rlpyt_dqn_convs_workspace_floats(int64_t N) {
-  return (int64_t)PACKED + N * (int64_t)(P1 * C1 + P2 * C2);
+// Packed weights = [f32 register-order copies of the three layers (PACKED floats)] [bf16 pieces of w2 / w3 in
+// operand order for the bf16x6 kernels of csrc/dqn_convs_x6.hip]; workspace = packed | y1 | y2.
+static int64_t packed_total_floats() { return (int64_t)PACKED + rlpyt_dqn_convs_x6_packed_bytes() / 4; }
+
+// RLPYT_DQN_CONV1_X3 / RLPYT_DQN_CONV23_X6 = 0: the f32-MFMA kernels of this file (A/B runs)
+static bool env_on(const char* name) {
+  const char* e = getenv(name);
+  return !(e && e[0] == '0');
 }
 
-extern "C" int64_t rlpyt_dqn_convs_packed_floats(void) { return (int64_t)PACKED; }
+extern "C" int64_t rlpyt_dqn_convs_workspace_floats(int64_t N) {
+  return packed_total_floats() + N * (int64_t)(P1 * C1 + P2 * C2);
+}
+
+extern "C" int64_t rlpyt_dqn_convs_packed_floats(void) { return packed_total_floats(); }
 
 extern "C" int rlpyt_dqn_convs_pack_f32(const float* w1, const float* w2, const float* w3, float* packed,
                                         rlpyt_stream_t stream) {
@@ -286,7 +296,7 @@ extern "C" int rlpyt_dqn_convs_pack_f32(const float* w1, const float* w2, const 
   RL_LAUNCH(dqn_pack_weights_kernel, dim3((PACKED + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1, w2,
             w3, packed);
   RL_LAUNCH_CHECK();
-  return RLPYT_OK;
+  return rlpyt_dqn_convs_x6_pack(w2, w3, packed + PACKED, stream);
 }
 
 extern "C" int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const float* w1, const float* b1,
@@ -302,27 +312,31 @@ extern "C" int rlpyt_dqn_convs_fwd_f32(const uint8_t* obs, int64_t N, const floa
                RLPYT_ESHAPE, "rlpyt_dqn_convs_fwd_f32: obs / biases / workspace / out must be 16-byte aligned");
   RL_CHECK_ARG(N <= (1 << 20), RLPYT_ESHAPE, "rlpyt_dqn_convs_fwd_f32: N too large");
   hipStream_t s = (hipStream_t)stream;
+  // (read per call: tests and A/B scripts flip them inside one process)
+  const bool conv1_x3 = env_on("RLPYT_DQN_CONV1_X3"), conv23_x6 = env_on("RLPYT_DQN_CONV23_X6");
+  const bool c1x3 = conv1_x3 && w1 != nullptr && RL_ALIGNED16(w1);
   const float* packed = packed_in != nullptr ? packed_in : workspace;
-  float* y1 = workspace + PACKED;
+  float* y1 = workspace + packed_total_floats();
   float* y2 = y1 + N * (int64_t)(P1 * C1);
   if (packed_in == nullptr) {
-    RL_LAUNCH(dqn_pack_weights_kernel, dim3((PACKED + 255) / 256), dim3(256), 0, s, w1, w2, w3, workspace);
-    RL_LAUNCH_CHECK();
+    // only the parts the chosen kernels read
+    if (!c1x3 || !conv23_x6) {
+      RL_LAUNCH(dqn_pack_weights_kernel, dim3((PACKED + 255) / 256), dim3(256), 0, s, w1, w2, w3, workspace);
+      RL_LAUNCH_CHECK();
+    }
+    if (conv23_x6)
+      if (int rc = rlpyt_dqn_convs_x6_pack(w2, w3, workspace + PACKED, stream)) return rc;
   }
   const int64_t slots = std::min<int64_t>(N, kPersistImages);      // persistent workgroups beyond that
-  // conv1 on the exact bf16x3 contraction (csrc/conv.hip) whenever the weights are at hand in the torch
-  // layout; RLPYT_DQN_CONV1_X3=0: the f32-MFMA kernel (A/B runs)
-  static const bool conv1_x3 = [] {
-    const char* e = getenv("RLPYT_DQN_CONV1_X3");
-    return !(e && e[0] == '0');
-  }();
-  if (conv1_x3 && w1 != nullptr && RL_ALIGNED16(w1)) {
+  // conv1 on the exact bf16x3 contraction (csrc/conv.hip) whenever the weights are at hand in the torch layout
+  if (c1x3) {
     if (int rc = rlpyt_dqn_conv1_f32(obs, N, w1, b1, scale, y1, stream)) return rc;
   } else {
     RL_LAUNCH(dqn_conv1_kernel, dim3((unsigned)(slots * D1_PARTS)), dim3(D1_THREADS), 0, s, obs, packed, b1,
               scale, y1, N);
     RL_LAUNCH_CHECK();
   }
+  if (conv23_x6) return rlpyt_dqn_conv23_x6_f32(y1, N, packed + PACKED, b2, b3, y2, out, stream);
   RL_LAUNCH((dqn_conv23_kernel<C1, H1, W1, 4, 4, 2, R2, false>), dim3((unsigned)(slots * 4)),
             dim3(D2_THREADS), 0, s, y1, packed + PK1, b2, y2, N);
   RL_LAUNCH_CHECK();

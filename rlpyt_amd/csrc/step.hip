@@ -123,6 +123,8 @@ extern "C" int rlpyt_commit_rows(const rlpyt_row_copy* table_dev, int n_entries,
   RL_CHECK_ARG(n_entries >= 0 && n_entries <= 64, RLPYT_EINVAL, "rlpyt_commit_rows: 0..64 entries");
   if (n_entries == 0) return RLPYT_OK;
   RL_CHECK_ARG(table_dev != nullptr, RLPYT_EINVAL, "rlpyt_commit_rows: null table");
+  RL_CHECK_ARG(max_entry_bytes >= 0 && max_entry_bytes < (1LL << 31), RLPYT_ESHAPE,
+               "rlpyt_commit_rows: entries must be smaller than 2 GB");
   const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(max_entry_bytes, 256 * 16), 1024));
   RL_LAUNCH(commit_rows_kernel, dim3((unsigned)chunks, (unsigned)n_entries), dim3(256), 0,
                      (hipStream_t)stream, table_dev, t_dev);

@@ -83,8 +83,14 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert lib.rlpyt_q_head_f32(p, 8, p, p, p, 4, 384, 6, p, None) != OK
     assert lib.rlpyt_rnn_step_inputs_f32(p, 512, 1, p, 6, p, None, p, p, 512, p, 1000, p, p, 4, None) != OK
     assert b"Kp >= F + A + 1 + H" in lib.rlpyt_hip_last_error()
-    assert lib.rlpyt_dqn_convs_packed_floats() == 32 * 256 + 64 * 512 + 64 * 576
-    assert lib.rlpyt_dqn_convs_workspace_floats(10) == 77824 + 10 * (475 * 32 + 108 * 64)
+    # f32 register-order copies + the bf16 pieces of w2 / w3 (3 pieces x 2 bytes per weight)
+    x6 = lib.rlpyt_dqn_convs_x6_packed_bytes()
+    assert x6 == (64 * 512 + 64 * 576) * 6
+    assert lib.rlpyt_dqn_convs_packed_floats() == 32 * 256 + 64 * 512 + 64 * 576 + x6 // 4
+    assert lib.rlpyt_dqn_convs_workspace_floats(10) == 77824 + x6 // 4 + 10 * (475 * 32 + 108 * 64)
+    assert lib.rlpyt_dqn_conv23_x6_f32(None, 0, None, None, None, None, None, None) == OK
+    assert lib.rlpyt_dqn_conv23_x6_f32(None, 2, None, None, None, None, None, None) != OK
+    assert lib.rlpyt_dqn_convs_x6_pack(None, None, None, None) != OK
     # conv1 of the DQN stack on the bf16 pipe (ABI 14)
     assert lib.rlpyt_dqn_conv1_f32(None, 0, None, None, 1.0, None, None) == OK
     assert lib.rlpyt_dqn_conv1_f32(None, 3, None, None, 1.0, None, None) != OK

@@ -215,5 +215,5 @@ def test_async_rl_dqn_end_to_end():
     assert float(last["CumReplayRatio"]) <= algo.replay_ratio * 1.25
     ran = {k for k, v in _lib.variant_counts().items() if v > 0}
     for name in ("dqn_loss_kernel", "frames_gather_kernel", "replay_step_fields_kernel", "find_kernel",
-                 "clip_adam_apply_kernel", "dqn_conv1_kernel"):
+                 "clip_adam_apply_kernel", "dqn_conv1"):
         assert any(name in k for k in ran), (name, sorted(ran))
