@@ -54,6 +54,13 @@ import time
 
 import torch
 
+
+def resolve_opt_info(info):
+    """Wait for an optimize_agent call's diagnostics (rlpyt_amd/utils/deferred.py)."""
+    from rlpyt_amd.utils.deferred import resolve
+    return resolve(info)
+
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -264,7 +271,8 @@ def main():
     if args.frozen_env:
         env_kwargs["frozen"] = True
     leg_steps = args.env_cost_leg_steps if (args.env_cost_leg_us > 0 and args.env_cost_us == 0) else 0
-    n_itr_total = (args.warmup + args.steps + (0 if args.no_kernel_timing else 2)
+    n_itr_total = (args.warmup + args.steps + max(1, min(args.steps, 5))
+                   + (0 if args.no_kernel_timing else 2)
                    + (1 + leg_steps if leg_steps else 0) + (2 if world > 1 else 0))
     # worker processes and their CPUs the reference's way: one worker per entry of
     # affinity["workers_cpus"] (rlpyt/samplers/parallel/base.py:157-172); rank r takes the r-th
@@ -341,13 +349,35 @@ def main():
         agent.train_mode(itr)
         opt_info = algo.optimize_agent(itr, samples)
     sync()
-    elapsed = elapsed_local = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0
     trace_marker(args)
+    # ---- phase-timing leg: where an iteration's time goes.  In the timed region optimize_agent hands
+    # back diagnostics whose copy to the host is still in flight (utils/deferred.py) and nothing reads
+    # them, so the host is already inside the next sampling phase while the last minibatches run -- a host
+    # clock around the sampler then includes that wait.  Here every iteration reads its diagnostics at
+    # once (as a runner that stores them per iteration does) and the clocks measure the sampler alone.
+    ph_steps = max(1, min(args.steps, 5))
+    for k in sampler.timing:
+        sampler.timing[k] = 0.
+    wt0 = None if wt is None else wt.copy()
+    sync()
+    tp = time.perf_counter()
+    t_sample = 0.
+    for k in range(ph_steps):
+        itr = args.warmup + args.steps + k
+        ts = time.perf_counter()
+        agent.sample_mode(itr)
+        samples, _infos = sampler.obtain_samples(itr)
+        t_sample += time.perf_counter() - ts
+        agent.train_mode(itr)
+        resolve_opt_info(algo.optimize_agent(itr, samples))
+    sync()
+    ph_elapsed = time.perf_counter() - tp
     timing = dict(sampler.timing)         # (the env-cost leg below keeps adding to sampler.timing)
     worker_ms = None
     if wt0 is not None:
         # per env worker and time step: ms waiting for the master's actions / ms stepping envs
-        d = (wt - wt0) / (args.steps * T) * 1e-6
+        d = (wt - wt0) / (ph_steps * T) * 1e-6
         dd = wt - wt0
         worker_ms = {"wait_mean": float(d[:, 0].mean()), "wait_max": float(d[:, 0].max()),
                      "step_mean": float(d[:, 1].mean()), "step_max": float(d[:, 1].max()),
@@ -371,7 +401,7 @@ def main():
         ktimer.reset()
         ktimer.enable(True)
         for k in range(2):
-            one_step(args.warmup + args.steps + k)
+            one_step(args.warmup + args.steps + ph_steps + k)
         sync()
         ktimer.enable(False)
         ksum = ktimer.summary()
@@ -379,12 +409,12 @@ def main():
     leg = None
     if leg_steps:
         cost_ref.value = float(args.env_cost_leg_us)
-        one_step(args.warmup + args.steps + 2)           # untimed: workers pick up the new cost
+        one_step(args.warmup + args.steps + ph_steps + 2)           # untimed: workers pick up the new cost
         sync()
         tl = time.perf_counter()
         ts_leg = 0.
         for k in range(leg_steps):
-            itr = args.warmup + args.steps + 3 + k
+            itr = args.warmup + args.steps + ph_steps + 3 + k
             t1 = time.perf_counter()
             agent.sample_mode(itr)
             samples, _infos = sampler.obtain_samples(itr)
@@ -438,9 +468,9 @@ def main():
             cpu_block=[block[0], block[-1]],
             # where this rank's iteration goes: a curve that bends with rollout_ms is host-bound (CPUs
             # per rank), one that bends with allreduce_exposed_ms is xGMI-bound
-            rollout_ms=t_sample / args.steps * 1e3,
-            update_ms=(elapsed_local - t_sample) / args.steps * 1e3,
-            ms_per_time_step=t_sample / args.steps / T * 1e3,
+            rollout_ms=t_sample / ph_steps * 1e3,
+            update_ms=(ph_elapsed - t_sample) / ph_steps * 1e3,
+            ms_per_time_step=t_sample / ph_steps / T * 1e3,
             update_ms_ddp_sync=upd_ms.get("sync"), update_ms_no_sync=upd_ms.get("no_sync"),
             allreduce_exposed_ms=(upd_ms["sync"] - upd_ms["no_sync"]) if upd_ms else None))
         multi = dict(dist_world_size=dist.get_world_size(), backend=dist.get_backend(),
@@ -493,7 +523,11 @@ def main():
                        "env_step_cost_us": args.env_cost_us, "host_cores": ncpu,
                        "host_cpu_quota": cpus,
                        "parallelism": f"dp{world}"},
-            "sampling_frac_of_step": t_sample / (elapsed if elapsed > 0 else 1.),
+            "sampling_frac_of_step": t_sample / (ph_elapsed if ph_elapsed > 0 else 1.),
+            "phase_timing": f"sampling_frac_of_step and the sampler object: {ph_steps} iterations after "
+                            "the timed region with the diagnostics read back inside optimize_agent "
+                            f"({ph_elapsed / ph_steps * 1e3:.2f} ms per iteration there); in the timed "
+                            "region their copy to the host is left in flight (utils/deferred.py)",
             # how the SAME launch rule lays out 2 / 4 / 8 ranks under this box's CPU quota: the
             # rollout needs ~B env steps of host CPU per time step and rank, so the first scaling
             # curve on a quota-limited box is a curve of host CPUs per rank
@@ -502,12 +536,12 @@ def main():
                                            "serve_threads_spin": bool(cpus / n >= 6)}
                                   for n in (1, 2, 4, 8)},
             "sampler": {"pipeline_groups": sampler.n_groups, "hip_graph": not args.no_graph,
-                        "ms_per_time_step": t_sample / args.steps / T * 1e3,
-                        "master_wait_env_ms": timing["wait_env_s"] / args.steps / T * 1e3,
-                        "master_issue_ms": timing["device_issue_s"] / args.steps / T * 1e3,
+                        "ms_per_time_step": t_sample / ph_steps / T * 1e3,
+                        "master_wait_env_ms": timing["wait_env_s"] / ph_steps / T * 1e3,
+                        "master_issue_ms": timing["device_issue_s"] / ph_steps / T * 1e3,
                         "master_wait_device_ms":
-                            timing["device_wait_s"] / args.steps / T * 1e3,
-                        "per_batch_ms": {k[:-2]: timing[k] / args.steps * 1e3
+                            timing["device_wait_s"] / ph_steps / T * 1e3,
+                        "per_batch_ms": {k[:-2]: timing[k] / ph_steps * 1e3
                                          for k in ("pre_s", "loop_s", "tail_s", "post_s")},
                         "worker_ms_per_time_step": worker_ms},
             "last_loss": opt_info.loss[-1] if opt_info.loss else None,
@@ -1242,7 +1276,7 @@ def replay_config_main(args):
     examples = sampler.initialize(agent, seed=1, bootstrap_value=False)
     torch.cuda.set_device(0)
     agent.to_device(0)
-    n_itr = fill + warmup + steps
+    n_itr = fill + warmup + steps + 200
     algo.initialize(agent=agent, n_itr=n_itr, batch_spec=sampler.batch_spec,
                     mid_batch_reset=sampler.mid_batch_reset, examples=examples)
     rb = algo.replay_buffer
@@ -1278,7 +1312,25 @@ def replay_config_main(args):
     elapsed = time.perf_counter() - t0
     trace_marker(args)
     updates = algo.update_counter - u0
-    sampler_obj = sampler_stats(sampler, dict(sampler.timing), wt, wt0, steps, T, t_sample,
+    # ---- phase-timing leg (see main()): iterations whose diagnostics are read back at once, so that the
+    # host clock around the sampler does not include the wait for the previous iteration's updates
+    ph_steps = max(1, min(steps, 200 if args.config == "dqn" else 5))
+    for k in sampler.timing:
+        sampler.timing[k] = 0.
+    wt0 = None if wt is None else wt.copy()
+    tp = time.perf_counter()
+    t_sample = 0.
+    for k in range(ph_steps):
+        itr = fill + warmup + steps + k
+        ts = time.perf_counter()
+        agent.sample_mode(itr)
+        samples, _ = sampler.obtain_samples(itr)
+        t_sample += time.perf_counter() - ts
+        agent.train_mode(itr)
+        resolve_opt_info(algo.optimize_agent(itr, samples))
+    torch.cuda.synchronize()
+    ph_elapsed = time.perf_counter() - tp
+    sampler_obj = sampler_stats(sampler, dict(sampler.timing), wt, wt0, ph_steps, T, t_sample,
                                 not args.no_graph)
     sampler.shutdown()
 
@@ -1361,7 +1413,11 @@ def replay_config_main(args):
                    "updates_per_iteration": algo.updates_per_optimize,
                    "batch_size": int(algo.batch_size)},
         "updates_per_s": updates / elapsed, "updates": updates,
-        "sampling_frac_of_step": t_sample / elapsed,
+        "sampling_frac_of_step": t_sample / ph_elapsed,
+        "phase_timing": f"sampling_frac_of_step and the sampler object: {ph_steps} iterations after the "
+                        "timed region with the diagnostics read back inside optimize_agent "
+                        f"({ph_elapsed / ph_steps * 1e3:.3f} ms per iteration there); in the timed region "
+                        "their copy to the host is left in flight (utils/deferred.py)",
         "sampler": sampler_obj,
         "roofline": dict(kernel=replay[key].get("kernel", key),
                          **{k: v for k, v in replay[key].items() if k != "kernel"},

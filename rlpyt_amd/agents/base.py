@@ -13,6 +13,7 @@ import torch
 from ..models.utils import strip_ddp_state_dict
 from ..utils import logger
 from ..utils.collections import namedarraytuple
+from ..utils.deferred import LEAN_HOST
 
 AgentInputs = namedarraytuple("AgentInputs", ["observation", "prev_action", "prev_reward"])
 AgentStep = namedarraytuple("AgentStep", ["action", "agent_info"])
@@ -31,6 +32,8 @@ class BaseAgent:
         self.model = self.shared_model = self.distribution = None
         self.device = torch.device("cpu")
         self._mode = None
+        self._mode_itr = None
+        self._mode_repeat = False
         self.sample_generator = None   # torch.Generator for action draws (None: default)
         # (uniform table [T', B], device row index) for agents whose sampling forward can draw
         # from pre-generated uniforms (keeps RNG state out of captured hipGraphs)
@@ -150,6 +153,7 @@ class BaseAgent:
 
     def load_state_dict(self, state_dict):
         self.model.load_state_dict(state_dict)
+        self._mode_itr = None                  # (derived weight buffers are stale: see ``_enter``)
 
     # The three modes differ in: the module's train flag, whether fused-step weight buffers need a
     # refresh (any mode the sampler steps the agent in), and what subclasses hook on (epsilon,
@@ -158,10 +162,38 @@ class BaseAgent:
 
     def _enter(self, mode, itr):
         training, steps_envs = self._MODES[mode]
-        self.model.train(training)
-        self._mode = mode
-        if steps_envs:
+        # The runner AND the sampler both announce a sampling phase (``agent.sample_mode(itr)`` in
+        # rlpyt/runners/minibatch_rl.py:237 and rlpyt/samplers/parallel/gpu/sampler.py:33): the second
+        # call of a pair finds the agent already in that mode for that iteration and has nothing to
+        # redo -- on config #3 the repeat cost a weight-packing launch, two epsilon uploads and a walk
+        # over the module tree per iteration.  Anything that writes parameters in between (a state-dict
+        # load, the asynchronous mailbox) clears ``_mode_itr``.
+        repeat = LEAN_HOST and mode == self._mode and itr is not None and itr == self._mode_itr
+        self._mode_repeat = repeat
+        self._set_training(training)
+        self._mode, self._mode_itr = mode, itr
+        if steps_envs and not repeat:
             self._refresh_step_weights()
+
+    def _set_training(self, training):
+        """``model.train(training)`` without the per-call walk over the module tree (``Module.train``
+        goes through ``named_children`` / ``__setattr__`` of every submodule: ~50 us for the DQN
+        model, three times per iteration): the flag is written into the cached module list, and only
+        when it differs."""
+        model = self.model
+        if not LEAN_HOST:
+            model.train(training)
+            return
+        if model.training == training and getattr(self, "_train_flag_of", None) is model:
+            return
+        mods = getattr(self, "_train_mods", None)
+        if mods is None or self._train_flag_of is not model:
+            mods = self._train_mods = list(model.modules())
+            self._train_flag_of = model
+            model.train(training)              # the first time through the module's own method
+            return
+        for m in mods:
+            m.training = training
 
     def train_mode(self, itr):
         self._enter("train", itr)
@@ -205,7 +237,7 @@ class BaseAgent:
         twin = copy.copy(self)
         twin.model = copy.deepcopy(self.sampling_model)
         twin.shared_model = None
-        twin._mode = None
+        twin._mode = twin._mode_itr = None
         twin._async_twin_reset()
         params = [p.detach() for p in self.sampling_model.parameters()]
         bufs = [b.detach() for b in self.sampling_model.buffers()]
@@ -252,6 +284,7 @@ class BaseAgent:
                 torch.cuda.current_stream(self.device).wait_event(box["written"])
             mine = self._mail_tensors()
             torch._foreach_copy_(mine, box["tensors"])      # (bumps the parameters' version counters)
+            self._mode_itr = None                           # (see ``_enter``: derived buffers are stale)
             self._mail_seen = box["version"]
             if cuda:
                 box["read"] = torch.cuda.Event()

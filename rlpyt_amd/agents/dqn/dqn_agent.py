@@ -82,6 +82,8 @@ class EpsilonGreedyAgentMixin:
 
     def _enter(self, mode, itr):
         super()._enter(mode, itr)
+        if self._mode_repeat:          # the sampler's echo of the runner's call: epsilon is set already
+            return
         if mode == "sample":
             self.distribution.set_epsilon(self.eps.sampling(itr))
         elif mode == "eval":

@@ -19,6 +19,7 @@ from collections import namedtuple
 import torch
 
 from ...utils.collections import namedarraytuple
+from ...utils.deferred import PendingOptInfo
 
 UpdatePlan = namedtuple("UpdatePlan", ["updates_per_itr", "first_learn_itr", "eps_last_itr",
                                        "beta_last_itr"])
@@ -81,30 +82,41 @@ Prioritised = namedarraytuple("PrioritiesSamplesToBuffer", ["priorities", "sampl
 
 class UpdateLog:
     """Accumulates one row of scalar diagnostics and any number of vector diagnostics per update,
-    all as device tensors; ``to_opt_info`` moves them to the host once."""
+    all as device tensors; ``to_opt_info`` starts ONE device -> host copy of them and returns an
+    ``OptInfo`` that waits for it on first access (``utils/deferred.py``)."""
 
     def __init__(self, OptInfo, scalar_fields):
         self.OptInfo, self.scalar_fields = OptInfo, tuple(scalar_fields)
-        self.rows, self.vectors = [], {f: [] for f in OptInfo._fields if f not in scalar_fields}
+        self.blocks, self.vectors = [], {f: [] for f in OptInfo._fields if f not in scalar_fields}
 
     def add(self, scalars, **vectors):
-        self.rows.append(torch.stack([s.detach().float() for s in scalars]))
+        self.blocks.append(torch.stack([s.detach().float() for s in scalars]).unsqueeze(0))
         for name, v in vectors.items():
             self.vectors[name].append(v.reshape(-1))
 
     def add_rows(self, rows, **vectors):
         """Several updates at once: ``rows [k, n_scalars]`` and ``[k, m]`` vector diagnostics, all
         device tensors (the rings a captured update graph writes; cloned: the rings are reused)."""
-        self.rows.extend(rows.detach().float().clone().unbind(0))
+        self.blocks.append(rows.detach().float().clone())
         for name, v in vectors.items():
             self.vectors[name].append(v.detach().clone().reshape(-1))
 
     def to_opt_info(self):
-        out = {f: [] for f in self.OptInfo._fields}
-        if self.rows:
-            host = torch.stack(self.rows).cpu().tolist()
-            for k, f in enumerate(self.scalar_fields):
-                out[f] = [r[k] for r in host]
-            for f, chunks in self.vectors.items():
-                out[f] = torch.cat(chunks).cpu().tolist()
-        return self.OptInfo(*(out[f] for f in self.OptInfo._fields))
+        fields = self.OptInfo._fields
+        if not self.blocks:
+            return self.OptInfo(*([] for _ in fields))
+        one = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts)    # noqa: E731
+        names = [f for f, chunks in self.vectors.items() if chunks]
+        tensors = [one(self.blocks)] + [one(self.vectors[f]) for f in names]
+        OptInfo, scalar_fields = self.OptInfo, self.scalar_fields
+
+        def build(host):
+            out = {f: [] for f in fields}
+            table = host[0].tolist()
+            for k, f in enumerate(scalar_fields):
+                out[f] = [r[k] for r in table]
+            for f, h in zip(names, host[1:]):
+                out[f] = h.tolist()
+            return OptInfo(*(out[f] for f in fields))
+
+        return PendingOptInfo(OptInfo, tensors, build)

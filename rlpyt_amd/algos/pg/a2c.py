@@ -3,6 +3,7 @@ returns from the fused scan, loss + gradients from the fused A2C kernel."""
 import torch
 
 from ... import ops
+from ...utils.deferred import PendingOptInfo
 from ...utils.buffer import buffer_method
 from ...agents.base import AgentInputs
 from ...utils.quick_args import save__init__args
@@ -37,10 +38,10 @@ class A2C(PolicyGradientAlgo):
         loss, scalars = self.loss(samples)
         loss.backward()
         grad_norm = self.clip_and_step()
-        host = torch.stack([scalars[0], grad_norm.to(scalars.dtype), scalars[3],
-                            scalars[4]]).cpu().tolist()
+        row = torch.stack([scalars[0], grad_norm.to(scalars.dtype), scalars[3], scalars[4]])
         self.update_counter += 1
-        return OptInfo(loss=host[0], gradNorm=host[1], entropy=host[2], perplexity=host[3])
+        # (read back when a field is first looked at: utils/deferred.py)
+        return PendingOptInfo(OptInfo, [row], lambda host: OptInfo(*host[0].tolist()))
 
     def loss(self, samples):
         mv = self.on_device

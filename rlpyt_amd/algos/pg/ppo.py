@@ -16,6 +16,7 @@ import torch
 
 from ... import ops
 from ...agents.base import AgentInputs
+from ...utils.deferred import PendingOptInfo
 from ...utils.buffer import buffer_func, buffer_method
 from ...utils.collections import namedarraytuple
 from ...utils.misc import iterate_mb_idxs
@@ -146,12 +147,22 @@ class PPO(PolicyGradientAlgo):
         if self.linear_lr_schedule:
             self.lr_scheduler.step()
             self.ratio_clip = self._ratio_clip * (self.n_itr - itr) / self.n_itr
+        # ONE read-back of the diagnostics per call, and not a blocking one: the returned object waits
+        # for the copy when a field is first read (utils/deferred.py) -- a runner that stores
+        # diagnostics every iteration sees no difference, one that reads them when it logs lets the
+        # host start on the next sampling phase while the last minibatches run
         if table is not None:
-            host = [[r[0], r[5], r[3], r[4]] for r in table[:n_rows].cpu().tolist()]
+            rows, cols = table[:n_rows], (0, 5, 3, 4)
+        elif stats:
+            rows, cols = torch.stack(stats), (0, 1, 2, 3)
         else:
-            host = self.diagnostics_to_host(stats)
-        opt_info = OptInfo(*([row[k] for row in host] for k in range(4)))
-        return opt_info
+            return OptInfo(*([] for _ in range(4)))
+
+        def build(host):
+            data = host[0].tolist()
+            return OptInfo(*([r[c] for r in data] for c in cols))
+
+        return PendingOptInfo(OptInfo, [rows], build)
 
     def _backward_seed(self, dev):
         """A standing scalar 1 on the device: ``loss.backward()`` would fill a fresh one per minibatch."""

@@ -32,6 +32,7 @@ class EpsilonGreedy(DiscreteMixin, Distribution):
         super().__init__(**kwargs)
         self._epsilon = epsilon
         self._buf = self._scalar_buf = None
+        self._uploaded = None           # what the device buffers hold (float, or a host tensor)
         self._env_slice = None
 
     epsilon = property(lambda self: self._epsilon)
@@ -47,21 +48,38 @@ class EpsilonGreedy(DiscreteMixin, Distribution):
         self._scalar_buf = torch.zeros(1, dtype=torch.float32, device=device)
         self._buf = (torch.zeros(int(n_envs), dtype=torch.float32, device=device)
                      if n_envs else None)
+        self._uploaded = None
         self._refresh()
 
     def select_envs(self, lo=None, hi=None):
         self._env_slice = None if lo is None else (int(lo), int(hi))
 
     def _refresh(self):
+        """Bring the device buffers up to date.  A scalar epsilon goes out as ``fill_`` launches: a
+        host -> device copy from pageable memory makes the caller wait for everything queued on the
+        stream before it (``sample_mode`` runs while the previous iteration's updates are still in
+        flight), a fill does not.  Unchanged values are not written again."""
         if self._scalar_buf is None:
             return
-        e = torch.as_tensor(self._epsilon, dtype=torch.float32).reshape(-1)
-        self._scalar_buf.copy_(e[:1])
+        eps = self._epsilon
+        if not isinstance(eps, torch.Tensor) or eps.numel() == 1:
+            value = float(eps)
+            if self._uploaded != value:
+                self._scalar_buf.fill_(value)
+                if self._buf is not None:
+                    self._buf.fill_(value)
+                self._uploaded = value
+            return
+        e = eps.detach().to(dtype=torch.float32, device="cpu").reshape(-1)
+        if self._buf is not None and e.numel() != self._buf.numel():
+            raise ValueError(f"vector epsilon has {e.numel()} entries for {self._buf.numel()} "
+                             "environments")
+        if isinstance(self._uploaded, torch.Tensor) and torch.equal(self._uploaded, e):
+            return
+        self._scalar_buf.fill_(float(e[0]))
         if self._buf is not None:
-            if e.numel() not in (1, self._buf.numel()):
-                raise ValueError(f"vector epsilon has {e.numel()} entries for {self._buf.numel()} "
-                                 "environments")
-            self._buf.copy_(e.expand(self._buf.numel()))
+            self._buf.copy_(e)
+        self._uploaded = e.clone()
 
     def _eps_for(self, n):
         """Epsilon operand for a batch of ``n`` environments."""

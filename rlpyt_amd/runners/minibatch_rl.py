@@ -27,6 +27,7 @@ from collections import deque, namedtuple
 import torch
 
 from ..utils import logger
+from ..utils.deferred import PendingOptInfo
 from ..utils.seed import make_seed, set_seed
 
 Schedule = namedtuple("Schedule", ["n_itr", "log_every", "itr_batch"])
@@ -56,6 +57,7 @@ class RunLog:
     def __init__(self, opt_fields, traj_window=None, prefix="Diagnostics/"):
         self.prefix = prefix
         self.opt = {name: [] for name in opt_fields}
+        self.waiting = []               # PendingOptInfo objects not read yet (utils/deferred.py)
         self.window = None if traj_window is None else deque(maxlen=int(traj_window))
         self.trajs = self.new_trajs = 0
         self.eval_seconds = 0.
@@ -71,12 +73,27 @@ class RunLog:
         self.new_trajs += n
         if self.window is not None:
             self.window.extend(traj_infos)
+        if isinstance(opt_info, PendingOptInfo):      # its device -> host copy is in flight: read at
+            self.waiting.append(opt_info)             # the period's end, not once per iteration
+            if len(self.waiting) > 64:                # (bounded: pinned staging of the oldest goes back)
+                self._settle(self.waiting.pop(0))
+        else:
+            self._settle(opt_info)
+
+    def _settle(self, opt_info):
         for name, bucket in self.opt.items():
             got = getattr(opt_info, name, [])
             bucket += got if isinstance(got, list) else [got]
 
+    def settle(self):
+        """Bring the buckets up to date with every iteration absorbed so far."""
+        for info in self.waiting:
+            self._settle(info)
+        self.waiting.clear()
+
     def drop_period(self):
         """Forget the period's accumulations without printing (non-logging ranks)."""
+        self.waiting.clear()
         for bucket in self.opt.values():
             bucket.clear()
         self.new_trajs = 0
@@ -109,6 +126,7 @@ class RunLog:
         if shown:
             for key in (k for k in shown[0] if not k.startswith("_")):
                 logger.record_tabular_misc_stat(key, [t[key] for t in shown])
+        self.settle()
         for name, bucket in self.opt.items():
             logger.record_tabular_misc_stat(name, bucket)
         logger.dump_tabular(with_prefix=False)

@@ -15,7 +15,7 @@ for rep in 1 2; do
       case $cfg in
         dqn)  A="--config dqn --replay-fill-itrs 3000";;
         r2d1) A="--config r2d1 --replay-fill-itrs 60 --steps 15";;
-        ppo)  A="--steps 12 --warmup 4 --env-cost-leg-us 0 --no-kernel-timing";;
+        ppo)  A="--steps 12 --warmup 4 --env-cost-leg-us 0 --no-kernel-timing --no-extra-configs";;
       esac
       env $VAR=$v timeout 300 python bench.py $A --no-cpu-baseline 2> $OUT/${cfg}_${v}_${rep}.err | python -c "
 import json,sys

@@ -800,3 +800,70 @@ def test_conv_pack_guard_follows_weight_versions():
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     m.load_state_dict(sd)                           # copy_ bumps the version counters
     assert m._current_pack(dev) is None
+
+
+def test_pending_opt_info_reads_like_the_namedtuple():
+    """``utils/deferred.PendingOptInfo``: what ``optimize_agent`` returns while the diagnostics' copy
+    to the host is in flight has to serve every way a runner reads an ``OptInfo`` -- field attributes
+    and ``getattr(opt_info, k, [])`` (rlpyt/runners/minibatch_rl.py:139-142), ``_fields``, iteration."""
+    from collections import namedtuple
+    from rlpyt_amd.algos.dqn.replay_algo import UpdateLog
+    from rlpyt_amd.utils.deferred import PendingOptInfo, resolve
+    Info = namedtuple("OptInfo", ["loss", "gradNorm", "tdAbsErr"])
+    log = UpdateLog(Info, ("loss", "gradNorm"))
+    assert log.to_opt_info() == Info([], [], [])
+    log.add((torch.tensor(1.5), torch.tensor(2.5)), tdAbsErr=torch.tensor([1., 2.]))
+    log.add_rows(torch.tensor([[3., 4.], [5., 6.]]), tdAbsErr=torch.tensor([[7.], [8.]]))
+    info = log.to_opt_info()
+    assert isinstance(info, PendingOptInfo) and info._fields == Info._fields
+    assert getattr(info, "nope", []) == []
+    assert info.loss == [1.5, 3., 5.] and info.gradNorm == [2.5, 4., 6.]
+    assert info.tdAbsErr == [1., 2., 7., 8.]
+    assert list(info) == [info.loss, info.gradNorm, info.tdAbsErr] and len(info) == 3
+    assert resolve(info) == Info(info.loss, info.gradNorm, info.tdAbsErr)
+    assert info._asdict() == resolve(info)._asdict() and resolve(resolve(info)) is resolve(info)
+    # the product runner's log reads pending infos when it emits, not when it absorbs
+    from rlpyt_amd.runners.minibatch_rl import RunLog
+    rl = RunLog(Info._fields)
+    log2 = UpdateLog(Info, ("loss", "gradNorm"))
+    log2.add((torch.tensor(9.), torch.tensor(10.)), tdAbsErr=torch.tensor([11.]))
+    rl.absorb([], log2.to_opt_info())
+    rl.absorb([], Info([1.], [2.], [3.]))
+    assert rl.opt["loss"] == [1.] and len(rl.waiting) == 1
+    rl.settle()
+    assert rl.opt["loss"] == [1., 9.] and rl.opt["tdAbsErr"] == [3., 11.] and not rl.waiting
+
+
+def test_repeated_mode_call_of_one_iteration_is_a_no_op():
+    """Runner and sampler both call ``agent.sample_mode(itr)`` (minibatch_rl.py:237, gpu/sampler.py:33):
+    the echo must not redo the per-phase work, a new iteration / another mode / a state-dict load must."""
+    from rlpyt_amd.agents.dqn.dqn_agent import AtariDqnAgent
+    from rlpyt_amd.envs.synthetic import SyntheticPong
+    env = SyntheticPong()
+    a = AtariDqnAgent(model_kwargs=dict(fc_sizes=16), eps_itr_max=10)
+    a.initialize(env.spaces)
+    calls = {"refresh": 0, "eps": 0}
+    a._refresh_step_weights = lambda: calls.__setitem__("refresh", calls["refresh"] + 1)
+    set_eps = a.distribution.set_epsilon
+    a.distribution.set_epsilon = lambda e: (calls.__setitem__("eps", calls["eps"] + 1), set_eps(e))
+    a.sample_mode(3)
+    assert calls == {"refresh": 1, "eps": 1} and not a.model.training
+    assert all(not m.training for m in a.model.modules())
+    a.sample_mode(3)
+    assert calls == {"refresh": 1, "eps": 1}
+    a.sample_mode(4)
+    assert calls == {"refresh": 2, "eps": 2}
+    a.train_mode(4)
+    assert all(m.training for m in a.model.modules()) and calls["refresh"] == 2
+    a.sample_mode(4)                              # back from training: the weights changed
+    assert calls == {"refresh": 3, "eps": 3} and all(not m.training for m in a.model.modules())
+    a.load_state_dict(a.model.state_dict())
+    a.sample_mode(4)
+    assert calls["refresh"] == 4
+    a.eval_mode(4)
+    a.eval_mode(4)
+    assert calls["refresh"] == 5
+    # a flag somebody set through the module's own method is still brought back
+    a.model.train()
+    a.eval_mode(5)
+    assert all(not m.training for m in a.model.modules())
