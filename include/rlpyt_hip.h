@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 15
+#define RLPYT_HIP_ABI_VERSION 16
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -443,6 +443,17 @@ int rlpyt_rnn_step_inputs_f32(const float* feat, int F, int relu, const int64_t*
  * b_hidden) + b_out.  K in {256, 512}, A <= 18. */
 int rlpyt_q_head_f32(const float* partial, int ksplit, const float* b_hidden, const float* w_out,
                      const float* b_out, int64_t n, int K, int A, float* q, rlpyt_stream_t stream);
+/* The same head inside an update (round 6, ABI 16; autograd through `self.head` in the online network's pass of
+ * DQN.loss, rlpyt/algos/dqn/dqn.py:226-230): rlpyt_q_head_train_f32 also keeps the hidden activations
+ * h [n,K] (h_out nullable = rlpyt_q_head_f32); rlpyt_q_head_bwd_f32 turns dq [n,A] into dw_out [A,K] = dq^T h,
+ * db_out [A], dh [n,K] = (dq w_out) * (h > 0) -- the gradient at the hidden layer's pre-activation -- and
+ * db_hidden [K] = its column sums, in one launch (n <= 256, K % 64 == 0, A <= 18; fixed summation order).
+ * The hidden layer's weight / input gradients (dh^T x, dh W_hidden) are GEMMs of the caller. */
+int rlpyt_q_head_train_f32(const float* partial, int ksplit, const float* b_hidden, const float* w_out,
+                           const float* b_out, int64_t n, int K, int A, float* q, float* h_out /*nullable*/,
+                           rlpyt_stream_t stream);
+int rlpyt_q_head_bwd_f32(const float* dq, const float* h, const float* w_out, int64_t n, int K, int A,
+                         float* dw_out, float* db_out, float* dh, float* db_hidden, rlpyt_stream_t stream);
 
 /* One LSTM cell step for the per-time-step sampling forward of the recurrent agents
  * (torch.nn.LSTM with T = 1 as used by rlpyt/models/dqn/atari_r2d1_model.py:61-63 and

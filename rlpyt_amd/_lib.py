@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (RLPYT_HIP_LIB: another build of the same ABI, for A/B runs of two kernel versions on one box)
 LIB_PATH = os.environ.get("RLPYT_HIP_LIB") or os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class CopyDesc(ctypes.Structure):
@@ -159,6 +159,8 @@ _SIGNATURES = {
     "rlpyt_dqn_convs_bwd_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, _p, c_float, _p, _p, _p, _p, _p, _p,
                                         _p, _p]),
     "rlpyt_q_head_f32": (c_int, [_p, c_int, _p, _p, _p, c_int64, c_int, c_int, _p, _p]),
+    "rlpyt_q_head_train_f32": (c_int, [_p, c_int, _p, _p, _p, c_int64, c_int, c_int, _p, _p, _p]),
+    "rlpyt_q_head_bwd_f32": (c_int, [_p, _p, _p, c_int64, c_int, c_int, _p, _p, _p, _p, _p]),
     "rlpyt_rollout_fc_ksplit": (c_int, [c_int]),
     "rlpyt_rollout_fc_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "rlpyt_rollout_fc_f32": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p]),

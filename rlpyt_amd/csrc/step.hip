@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256) void q_head_kernel(const float* __restrict__ p
                                                      const float* __restrict__ b_hidden,
                                                      const float* __restrict__ w_out,
                                                      const float* __restrict__ b_out, int64_t n, int A,
-                                                     float* __restrict__ q) {
+                                                     float* __restrict__ q, float* __restrict__ h_out) {
   constexpr int K = 256 * KW;
   constexpr int AMAX = 18;                             // the full Atari action set
   __shared__ float red[4][AMAX];
@@ -758,6 +758,7 @@ __global__ __launch_bounds__(256) void q_head_kernel(const float* __restrict__ p
   for (int i = 0; i < KW; ++i) {
     const int k = kb + 64 * i;
     hv[i] = fmaxf(hv[i] + b_hidden[k], 0.f);
+    if (h_out != nullptr) h_out[row * K + k] = hv[i];   // (kept for the backward pass: rlpyt_q_head_train_f32)
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) acc[a] = fmaf(hv[i], w_out[(int64_t)min(a, A - 1) * K + k], acc[a]);
   }
@@ -771,22 +772,106 @@ __global__ __launch_bounds__(256) void q_head_kernel(const float* __restrict__ p
   const int a = threadIdx.x;
   if (a < A) q[row * A + a] = (((red[0][a] + red[1][a]) + red[2][a]) + red[3][a]) + b_out[a];
 }
+
+// Backward of that head up to the hidden layer's pre-activation (round 6): from dq [n, A] and the kept
+// hidden activations h [n, K]
+//   dw_out [A, K] = dq^T h,  db_out [A] = column sums of dq,
+//   dh [n, K] = (dq w_out) * (h > 0)   (= the gradient at the hidden layer's pre-activation),
+//   db_hidden [K] = column sums of dh
+// -- what autograd runs as fill + fill + multiply + two GEMMs of < 6 us + a column-sum reduction + the ReLU's
+// threshold kernel + another reduction (8 launches, ~45 us inside a captured DQN update).  A workgroup owns
+// 64 hidden units (one per lane), its four waves take every fourth row and meet in LDS in wave order:
+// deterministic.  The hidden layer's own weight / input gradients (dh^T x, dh W) stay GEMMs of the caller.
+constexpr int kQbAmax = 18, kQbRows = 256;
+__global__ __launch_bounds__(256) void q_head_bwd_kernel(const float* __restrict__ dq,
+                                                         const float* __restrict__ h,
+                                                         const float* __restrict__ w_out, int n, int K,
+                                                         int A, float* __restrict__ dw_out,
+                                                         float* __restrict__ db_out, float* __restrict__ dh,
+                                                         float* __restrict__ db_hidden) {
+  __shared__ float sdq[kQbRows * kQbAmax];
+  __shared__ float red[3][64][kQbAmax + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  for (int i = tid; i < n * A; i += 256) sdq[i] = dq[i];
+  float w2[kQbAmax], dw[kQbAmax];
+#pragma unroll
+  for (int a = 0; a < kQbAmax; ++a) {
+    w2[a] = a < A ? w_out[(int64_t)a * K + k] : 0.f;
+    dw[a] = 0.f;
+  }
+  float db = 0.f;
+  __syncthreads();
+  for (int m = wave; m < n; m += 4) {
+    const float hv = h[(int64_t)m * K + k];
+    const float* __restrict__ d = sdq + m * A;
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < kQbAmax; ++a)
+      if (a < A) {
+        const float g = d[a];
+        s = fmaf(g, w2[a], s);
+        dw[a] = fmaf(g, hv, dw[a]);
+      }
+    const float g1 = hv > 0.f ? s : 0.f;
+    dh[(int64_t)m * K + k] = g1;
+    db += g1;
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int a = 0; a < kQbAmax; ++a) red[wave - 1][lane][a] = dw[a];
+    red[wave - 1][lane][kQbAmax] = db;
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int a = 0; a < kQbAmax; ++a)
+      if (a < A)
+        dw_out[(int64_t)a * K + k] = ((dw[a] + red[0][lane][a]) + red[1][lane][a]) + red[2][lane][a];
+    db_hidden[k] = ((db + red[0][lane][kQbAmax]) + red[1][lane][kQbAmax]) + red[2][lane][kQbAmax];
+  } else if (blockIdx.x == 0 && wave == 1 && lane < A) {
+    float s = 0.f;
+    for (int m = 0; m < n; ++m) s += sdq[m * A + lane];
+    db_out[lane] = s;
+  }
+}
 }  // namespace
 }  // namespace rlpyt
 
 extern "C" int rlpyt_q_head_f32(const float* partial, int ksplit, const float* b_hidden,
                                 const float* w_out, const float* b_out, int64_t n, int K, int A, float* q,
                                 rlpyt_stream_t stream) {
+  return rlpyt_q_head_train_f32(partial, ksplit, b_hidden, w_out, b_out, n, K, A, q, nullptr, stream);
+}
+
+// ... and the variant that also keeps the hidden activations h [n, K] for rlpyt_q_head_bwd_f32
+extern "C" int rlpyt_q_head_train_f32(const float* partial, int ksplit, const float* b_hidden,
+                                      const float* w_out, const float* b_out, int64_t n, int K, int A,
+                                      float* q, float* h_out, rlpyt_stream_t stream) {
   RL_CHECK_ARG(partial && b_hidden && w_out && b_out && q, RLPYT_EINVAL, "rlpyt_q_head_f32: null pointer");
   RL_CHECK_ARG(n > 0 && ksplit > 0 && A > 0 && A <= 18 && (K == 512 || K == 256), RLPYT_ESHAPE,
                "rlpyt_q_head_f32: need n > 0, 0 < A <= 18, K in {256, 512} (K=%d A=%d)", K, A);
   hipStream_t s = (hipStream_t)stream;
   if (K == 512)
     RL_LAUNCH((rlpyt::q_head_kernel<2>), dim3((unsigned)n), dim3(256), 0, s, partial, ksplit, b_hidden,
-              w_out, b_out, n, A, q);
+              w_out, b_out, n, A, q, h_out);
   else
     RL_LAUNCH((rlpyt::q_head_kernel<1>), dim3((unsigned)n), dim3(256), 0, s, partial, ksplit, b_hidden,
-              w_out, b_out, n, A, q);
+              w_out, b_out, n, A, q, h_out);
+  RL_LAUNCH_CHECK();
+  return RLPYT_OK;
+}
+
+extern "C" int rlpyt_q_head_bwd_f32(const float* dq, const float* h, const float* w_out, int64_t n, int K,
+                                    int A, float* dw_out, float* db_out, float* dh, float* db_hidden,
+                                    rlpyt_stream_t stream) {
+  RL_CHECK_ARG(dq && h && w_out && dw_out && db_out && dh && db_hidden, RLPYT_EINVAL,
+               "rlpyt_q_head_bwd_f32: null pointer");
+  RL_CHECK_ARG(n > 0 && n <= rlpyt::kQbRows && A > 0 && A <= rlpyt::kQbAmax && K > 0 && K % 64 == 0,
+               RLPYT_ESHAPE, "rlpyt_q_head_bwd_f32: need 0 < n <= 256, 0 < A <= 18, K %% 64 == 0 (n=%d K=%d A=%d)",
+               (int)n, K, A);
+  RL_LAUNCH(rlpyt::q_head_bwd_kernel, dim3((unsigned)(K / 64)), dim3(256), 0, (hipStream_t)stream, dq, h,
+            w_out, (int)n, K, A, dw_out, db_out, dh, db_hidden);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
 }

@@ -21,9 +21,20 @@ class MlpModel(torch.nn.Module):
 
     # set False (or RLPYT_Q_HEAD=0) for the library GEMMs in no-grad forwards too (A/B tests)
     use_fused_q_head = os.environ.get("RLPYT_Q_HEAD", "1") != "0"
+    # ... and RLPYT_Q_HEAD_TRAIN=0 for autograd through the library GEMMs in the pass under autograd
+    use_fused_q_head_train = os.environ.get("RLPYT_Q_HEAD_TRAIN", "1") != "0"
 
     def forward(self, input):
         m = self.model
+        if (self.use_fused_q_head_train and len(m) == 3 and torch.is_grad_enabled()
+                and isinstance(input, torch.Tensor) and input.is_cuda and input.dim() == 2
+                and isinstance(m[1], torch.nn.ReLU) and isinstance(m[0], torch.nn.Linear)
+                and isinstance(m[2], torch.nn.Linear)):
+            # the same head in the online network's pass of an update: own forward that keeps the hidden
+            # activations, own backward for everything but the hidden layer's two GEMMs
+            from .. import ops
+            if ops.mlp_q_head_train_ok(input, m[0], m[2]):
+                return ops.mlp_q_head_train(input, m[0], m[2])
         if (self.use_fused_q_head and len(m) == 3 and not torch.is_grad_enabled()
                 and isinstance(input, torch.Tensor) and input.is_cuda and input.dim() == 2
                 and isinstance(m[1], torch.nn.ReLU) and isinstance(m[0], torch.nn.Linear)

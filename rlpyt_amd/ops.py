@@ -1329,6 +1329,54 @@ def mlp_q_head(x, lin1, lin2):
     return q
 
 
+class _MlpQHeadTrain(torch.autograd.Function):
+    """``lin2(relu(lin1(x)))`` under autograd on the own kernels: forward = split-K hidden layer +
+    ``rlpyt_q_head_train_f32`` (keeps h); backward = ``rlpyt_q_head_bwd_f32`` (output layer's gradients, the
+    ReLU mask, the hidden bias gradient: one launch for what autograd issues as eight) + two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        n, K, A = x.shape[0], w1.shape[0], w2.shape[0]
+        partial, ksplit = fc_small_partials(x, w1)
+        q = torch.empty((n, A), dtype=torch.float32, device=x.device)
+        h = torch.empty((n, K), dtype=torch.float32, device=x.device)
+        check(lib.rlpyt_q_head_train_f32(ptr(partial), ksplit, ptr(b1), ptr(w2), ptr(b2), n, K, A, ptr(q),
+                                         ptr(h), stream()), "rlpyt_q_head_train_f32")
+        ctx.save_for_backward(x, w1, w2, h)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        x, w1, w2, h = ctx.saved_tensors
+        n, K, A = x.shape[0], w1.shape[0], w2.shape[0]
+        dq = _f32(dq)
+        dev = x.device
+        dw2 = torch.empty((A, K), dtype=torch.float32, device=dev)
+        db2 = torch.empty(A, dtype=torch.float32, device=dev)
+        dh = torch.empty((n, K), dtype=torch.float32, device=dev)
+        db1 = torch.empty(K, dtype=torch.float32, device=dev)
+        check(lib.rlpyt_q_head_bwd_f32(ptr(dq), ptr(h), ptr(w2), n, K, A, ptr(dw2), ptr(db2), ptr(dh),
+                                       ptr(db1), stream()), "rlpyt_q_head_bwd_f32")
+        dx = dh @ w1 if ctx.needs_input_grad[0] else None
+        dw1 = dh.t() @ x
+        return dx, dw1, db1, dw2, db2
+
+
+def mlp_q_head_train_ok(x, lin1, lin2):
+    """Whether ``mlp_q_head_train`` serves ``lin2(relu(lin1(x)))`` under autograd (the online network's head
+    in a DQN update): what ``mlp_q_head_ok`` asks for, contiguous parameters, hidden width a multiple of 64."""
+    return (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+            and 0 < x.shape[0] <= 256 and lin1.out_features in (256, 512) and lin1.in_features % 16 == 0
+            and 0 < lin2.out_features <= 18 and lin1.bias is not None and lin2.bias is not None
+            and lin1.weight.dtype == torch.float32 and lin1.weight.is_cuda
+            and lin1.weight.is_contiguous() and lin2.weight.is_contiguous())
+
+
+def mlp_q_head_train(x, lin1, lin2):
+    _lib.require_gpu()
+    return _MlpQHeadTrain.apply(x.contiguous(), lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+
+
 def categorical_head(h, w_pi, b_pi, w_v=None, b_v=None, uniforms=None, u_row=None):
     """Policy / value heads + softmax (+ inverse-CDF action sampling when ``uniforms`` is
     given) in one kernel -- the no-grad sampling forward of

@@ -81,6 +81,12 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert b"H must be 256 or 512" in lib.rlpyt_hip_last_error()
     assert lib.rlpyt_q_head_f32(p, 8, p, p, p, 4, 512, 19, p, None) != OK
     assert lib.rlpyt_q_head_f32(p, 8, p, p, p, 4, 384, 6, p, None) != OK
+    # the head inside an update (ABI 16)
+    assert lib.rlpyt_q_head_train_f32(p, 8, p, p, p, 4, 384, 6, p, p, None) != OK
+    assert lib.rlpyt_q_head_bwd_f32(None, p, p, 4, 512, 6, p, p, p, p, None) != OK
+    assert lib.rlpyt_q_head_bwd_f32(p, p, p, 257, 512, 6, p, p, p, p, None) != OK
+    assert lib.rlpyt_q_head_bwd_f32(p, p, p, 4, 500, 6, p, p, p, p, None) != OK
+    assert lib.rlpyt_q_head_bwd_f32(p, p, p, 4, 512, 19, p, p, p, p, None) != OK
     assert lib.rlpyt_rnn_step_inputs_f32(p, 512, 1, p, 6, p, None, p, p, 512, p, 1000, p, p, 4, None) != OK
     assert b"Kp >= F + A + 1 + H" in lib.rlpyt_hip_last_error()
     # f32 register-order copies + the bf16 pieces of w2 / w3 (3 pieces x 2 bytes per weight)

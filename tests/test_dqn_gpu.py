@@ -567,9 +567,11 @@ def test_mlp_q_head_matches_torch(n, K_in, hidden, A):
     ref64 = m.double()(x.double())
     m = m.float()
     _lib.variant_reset()
-    lib = m(x)                                           # autograd: library GEMMs
+    m.use_fused_q_head_train = False
+    lib = m(x)                                           # autograd with the switch off: library GEMMs
     assert lib.requires_grad
     assert not any("q_head_kernel" in k and v > 0 for k, v in _lib.variant_counts().items())
+    del m.use_fused_q_head_train
     with torch.no_grad():
         got = m(x)
     assert any("q_head_kernel" in k and v > 0 for k, v in _lib.variant_counts().items())
@@ -577,3 +579,43 @@ def test_mlp_q_head_matches_torch(n, K_in, hidden, A):
     err = (got.double() - ref64).abs().max().item() / scale
     err_lib = (lib.detach().double() - ref64).abs().max().item() / scale
     assert got.shape == (n, A) and err <= max(3 * err_lib, 3e-7), (err, err_lib)
+
+
+@pytest.mark.parametrize("n,K_in,hidden,A", [(128, 6912, 512, 6), (32, 64, 256, 18), (7, 48, 256, 1)])
+def test_mlp_q_head_under_autograd_matches_torch(n, K_in, hidden, A):
+    """The same head in the online network's pass of an update (``ops.mlp_q_head_train``: own forward that
+    keeps the hidden activations, ``rlpyt_q_head_bwd_f32`` for the output layer's gradients + ReLU mask +
+    hidden bias gradient): Q-values and all five gradients against the modules in float64, held to the f32
+    module path's own error (rlpyt/models/mlp.py:24-31 under rlpyt/algos/dqn/dqn.py:226-265)."""
+    from rlpyt_amd import _lib
+    from rlpyt_amd.models.mlp import MlpModel
+    torch.manual_seed(n + A)
+    m = MlpModel(K_in, hidden, output_size=A).cuda()
+    with torch.no_grad():
+        m.model[0].bias.add_(0.3)                        # (some units on, some off)
+    x = torch.randn(n, K_in, device="cuda")
+    g = torch.randn(n, A, device="cuda")
+
+    def run(model, xin, gin):
+        xin = xin.clone().requires_grad_(True)
+        model.zero_grad(set_to_none=True)
+        q = model(xin)
+        q.backward(gin)
+        return [q.detach(), xin.grad] + [p.grad for p in model.parameters()]
+
+    ref64 = run(m.double(), x.double(), g.double())
+    m = m.float()
+    m.use_fused_q_head_train = False
+    lib = run(m, x, g)
+    del m.use_fused_q_head_train
+    _lib.variant_reset()
+    got = run(m, x, g)
+    ran = {k for k, v in _lib.variant_counts().items() if v > 0}
+    assert any("q_head_bwd_kernel" in k for k in ran) and any("q_head_kernel" in k for k in ran), ran
+    for name, a, b, r in zip(("q", "dx", "dw1", "db1", "dw2", "db2"), got, lib, ref64):
+        scale = r.abs().max().item() + 1e-30
+        err = (a.double() - r).abs().max().item() / scale
+        err_lib = (b.double() - r).abs().max().item() / scale
+        assert a.shape == r.shape and err <= max(3 * err_lib, 1e-6), (name, err, err_lib)
+    again = run(m, x, g)                                  # fixed summation order
+    assert all(torch.equal(a, b) for a, b in zip(got, again))

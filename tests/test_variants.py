@@ -643,6 +643,13 @@ def _q_head_256():
     D.test_mlp_q_head_matches_torch(5, 64, 256, 3)
 
 
+@case("q_head_bwd_kernel")
+def _q_head_bwd():
+    import test_dqn_gpu as D
+    D.test_mlp_q_head_under_autograd_matches_torch(128, 6912, 512, 6)
+    D.test_mlp_q_head_under_autograd_matches_torch(7, 48, 256, 1)
+
+
 @case("replay_step_fields_kernel")
 def _replay_step_fields():
     """One-launch field gather of a single-step replay batch vs the row-by-row gathers + selects it
