@@ -780,20 +780,29 @@ __global__ __launch_bounds__(256) void q_head_kernel(const float* __restrict__ p
 //   db_hidden [K] = column sums of dh
 // -- what autograd runs as fill + fill + multiply + two GEMMs of < 6 us + a column-sum reduction + the ReLU's
 // threshold kernel + another reduction (8 launches, ~45 us inside a captured DQN update).  A workgroup owns
-// 64 hidden units (one per lane), its four waves take every fourth row and meet in LDS in wave order:
-// deterministic.  The hidden layer's own weight / input gradients (dh^T x, dh W) stay GEMMs of the caller.
-constexpr int kQbAmax = 18, kQbRows = 256;
-__global__ __launch_bounds__(256) void q_head_bwd_kernel(const float* __restrict__ dq,
-                                                         const float* __restrict__ h,
-                                                         const float* __restrict__ w_out, int n, int K,
-                                                         int A, float* __restrict__ dw_out,
-                                                         float* __restrict__ db_out, float* __restrict__ dh,
-                                                         float* __restrict__ db_hidden) {
+// 64 hidden units (one per lane), its sixteen waves take every sixteenth row (their h values requested up
+// front) and meet in LDS in wave order: deterministic (8 us; a four-wave version with the loads inside
+// the row loop took 21).  The hidden layer's own weight / input gradients (dh^T x, dh W) stay GEMMs of the caller.
+constexpr int kQbAmax = 18, kQbRows = 256, kQbWaves = 16, kQbRpw = kQbRows / kQbWaves;
+__global__ __launch_bounds__(kQbWaves * 64) void q_head_bwd_kernel(const float* __restrict__ dq,
+                                                                  const float* __restrict__ h,
+                                                                  const float* __restrict__ w_out, int n,
+                                                                  int K, int A, float* __restrict__ dw_out,
+                                                                  float* __restrict__ db_out,
+                                                                  float* __restrict__ dh,
+                                                                  float* __restrict__ db_hidden) {
   __shared__ float sdq[kQbRows * kQbAmax];
-  __shared__ float red[3][64][kQbAmax + 1];
+  __shared__ float red[kQbWaves][kQbAmax + 1][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = blockIdx.x * 64 + lane;
-  for (int i = tid; i < n * A; i += 256) sdq[i] = dq[i];
+  // this wave's rows wave, wave + 16, ...: their hidden activations requested up front (one round trip)
+  float hv[kQbRpw];
+#pragma unroll
+  for (int i = 0; i < kQbRpw; ++i) {
+    const int m = wave + kQbWaves * i;
+    hv[i] = m < n ? h[(int64_t)m * K + k] : 0.f;
+  }
+  for (int i = tid; i < n * A; i += kQbWaves * 64) sdq[i] = dq[i];
   float w2[kQbAmax], dw[kQbAmax];
 #pragma unroll
   for (int a = 0; a < kQbAmax; ++a) {
@@ -802,37 +811,41 @@ __global__ __launch_bounds__(256) void q_head_bwd_kernel(const float* __restrict
   }
   float db = 0.f;
   __syncthreads();
-  for (int m = wave; m < n; m += 4) {
-    const float hv = h[(int64_t)m * K + k];
-    const float* __restrict__ d = sdq + m * A;
-    float s = 0.f;
 #pragma unroll
-    for (int a = 0; a < kQbAmax; ++a)
-      if (a < A) {
-        const float g = d[a];
-        s = fmaf(g, w2[a], s);
-        dw[a] = fmaf(g, hv, dw[a]);
-      }
-    const float g1 = hv > 0.f ? s : 0.f;
-    dh[(int64_t)m * K + k] = g1;
-    db += g1;
-  }
-  if (wave > 0) {
+  for (int i = 0; i < kQbRpw; ++i) {
+    const int m = wave + kQbWaves * i;
+    if (m < n) {                                               // (uniform per wave)
+      const float* __restrict__ d = sdq + m * A;
+      float s = 0.f;
 #pragma unroll
-    for (int a = 0; a < kQbAmax; ++a) red[wave - 1][lane][a] = dw[a];
-    red[wave - 1][lane][kQbAmax] = db;
+      for (int a = 0; a < kQbAmax; ++a)
+        if (a < A) {
+          const float g = d[a];
+          s = fmaf(g, w2[a], s);
+          dw[a] = fmaf(g, hv[i], dw[a]);
+        }
+      const float g1 = hv[i] > 0.f ? s : 0.f;
+      dh[(int64_t)m * K + k] = g1;
+      db += g1;
+    }
   }
+#pragma unroll
+  for (int a = 0; a < kQbAmax; ++a) red[wave][a][lane] = dw[a];
+  red[wave][kQbAmax][lane] = db;
   __syncthreads();
-  if (wave == 0) {
+  // the 16 wave partials of every (output | hidden bias, column) summed in wave order
+  for (int it = tid; it < (A + 1) * 64; it += kQbWaves * 64) {
+    const int a = it >> 6, c = it & 63, slot = a < A ? a : kQbAmax;
+    float s = red[0][slot][c];
 #pragma unroll
-    for (int a = 0; a < kQbAmax; ++a)
-      if (a < A)
-        dw_out[(int64_t)a * K + k] = ((dw[a] + red[0][lane][a]) + red[1][lane][a]) + red[2][lane][a];
-    db_hidden[k] = ((db + red[0][lane][kQbAmax]) + red[1][lane][kQbAmax]) + red[2][lane][kQbAmax];
-  } else if (blockIdx.x == 0 && wave == 1 && lane < A) {
+    for (int w = 1; w < kQbWaves; ++w) s += red[w][slot][c];
+    if (a < A) dw_out[(int64_t)a * K + blockIdx.x * 64 + c] = s;
+    else db_hidden[blockIdx.x * 64 + c] = s;
+  }
+  if (blockIdx.x == 0 && tid < A) {                            // (after the barrier: sdq is complete)
     float s = 0.f;
-    for (int m = 0; m < n; ++m) s += sdq[m * A + lane];
-    db_out[lane] = s;
+    for (int m = 0; m < n; ++m) s += sdq[m * A + tid];
+    db_out[tid] = s;
   }
 }
 }  // namespace
@@ -870,7 +883,7 @@ extern "C" int rlpyt_q_head_bwd_f32(const float* dq, const float* h, const float
   RL_CHECK_ARG(n > 0 && n <= rlpyt::kQbRows && A > 0 && A <= rlpyt::kQbAmax && K > 0 && K % 64 == 0,
                RLPYT_ESHAPE, "rlpyt_q_head_bwd_f32: need 0 < n <= 256, 0 < A <= 18, K %% 64 == 0 (n=%d K=%d A=%d)",
                (int)n, K, A);
-  RL_LAUNCH(rlpyt::q_head_bwd_kernel, dim3((unsigned)(K / 64)), dim3(256), 0, (hipStream_t)stream, dq, h,
+  RL_LAUNCH(rlpyt::q_head_bwd_kernel, dim3((unsigned)(K / 64)), dim3(rlpyt::kQbWaves * 64), 0, (hipStream_t)stream, dq, h,
             w_out, (int)n, K, A, dw_out, db_out, dh, db_hidden);
   RL_LAUNCH_CHECK();
   return RLPYT_OK;
