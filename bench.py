@@ -1244,7 +1244,9 @@ def replay_config_main(args):
         # sampling-only iterations before the timed region: by default until the 62 500-row ring
         # has WRAPPED (the timed sampling / updates then run on a full ring: every leaf of the
         # 1M-leaf tree live, frame windows crossing the wrap point)
-        workers = args.workers if args.workers > 0 else 2
+        # (16 envs on 4 worker processes: 1486 / 1560 updates/s against 1404 / 1474 on 2, 1421 / 1515 on 8,
+        #  1458 / 1516 on 16 -- interleaved on one box, profiles/r6_dqn_workers_sweep.jsonl)
+        workers = args.workers if args.workers > 0 else 4
         fill = int(1e6) // B // T + 400 if args.replay_fill_itrs < 0 else args.replay_fill_itrs
         steps = args.steps if args.steps is not None else 300
         warmup = args.warmup if args.warmup is not None else 20
