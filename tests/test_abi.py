@@ -91,7 +91,7 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert b"Kp >= F + A + 1 + H" in lib.rlpyt_hip_last_error()
     # f32 register-order copies + the bf16 pieces of w2 / w3 (3 pieces x 2 bytes per weight)
     x6 = lib.rlpyt_dqn_convs_x6_packed_bytes()
-    assert x6 == (64 * 512 + 64 * 576) * 6
+    assert x6 == (64 * 512 + 64 * 576) * 6 * 2          # 16 x 16 tile order | 32 x 32 tile order
     assert lib.rlpyt_dqn_convs_packed_floats() == 32 * 256 + 64 * 512 + 64 * 576 + x6 // 4
     assert lib.rlpyt_dqn_convs_workspace_floats(10) == 77824 + x6 // 4 + 10 * (475 * 32 + 108 * 64)
     assert lib.rlpyt_dqn_conv23_x6_f32(None, 0, None, None, None, None, None, None) == OK

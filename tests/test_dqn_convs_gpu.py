@@ -296,7 +296,7 @@ def test_packed_weights_are_made_once_per_sampling_phase_and_never_stale_in_trai
         #  an f32-MFMA kernel is switched on)
         c = _lib.variant_counts()
         return max(sum(v for k, v in c.items() if "dqn_pack_weights_kernel" in k),
-                   sum(v for k, v in c.items() if "dqn_x6_pack_kernel" in k))
+                   sum(v for k, v in c.items() if "dqn_x6_pack_kernel" in k or "dqn_t32_pack_kernel" in k))
 
     with torch.no_grad():
         m.train()
@@ -338,7 +338,7 @@ def test_packed_weights_are_dropped_when_parameters_change_in_eval_mode():
         #  an f32-MFMA kernel is switched on)
         c = _lib.variant_counts()
         return max(sum(v for k, v in c.items() if "dqn_pack_weights_kernel" in k),
-                   sum(v for k, v in c.items() if "dqn_x6_pack_kernel" in k))
+                   sum(v for k, v in c.items() if "dqn_x6_pack_kernel" in k or "dqn_t32_pack_kernel" in k))
 
     with torch.no_grad():
         m.eval()

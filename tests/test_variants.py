@@ -581,12 +581,27 @@ def _dqn_conv1_f32_mfma():
     np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-6)
 
 
-@case("dqn_conv1_x3_kernel", "dqn_x6_pack_kernel",
-      "dqn_conv23_x6_kernel<32, 25, 19, 4, 4, 2, false>", "dqn_conv23_x6_kernel<64, 12, 9, 3, 3, 1, true>")
+@case("dqn_conv1_x3_kernel", "dqn_t32_pack_kernel",
+      "dqn_conv23_t32_kernel<32, 25, 19, 4, 4, 2, 3, false>", "dqn_conv23_t32_kernel<64, 12, 9, 3, 3, 1, 6, true>")
 def _dqn_convs():
     import test_dqn_convs_gpu as D
     D.test_dqn_convs_match_torch_conv2d(3)
+    D.test_dqn_convs_match_torch_conv2d(300)
     D.test_dqn_convs_identity_like_weights_asymmetric()
+
+
+@case("dqn_x6_pack_kernel", "dqn_conv23_x6_kernel<32, 25, 19, 4, 4, 2, false>",
+      "dqn_conv23_x6_kernel<64, 12, 9, 3, 3, 1, true>")
+def _dqn_convs_x6_16x16_tiles():
+    """conv2 / conv3 on 16 x 16 tiles (RLPYT_DQN_CONV23_T32=0, the A/B switch): same tests."""
+    import test_dqn_convs_gpu as D
+    os.environ["RLPYT_DQN_CONV23_T32"] = "0"
+    try:
+        D.test_dqn_convs_match_torch_conv2d(3)
+        D.test_dqn_convs_match_torch_conv2d(300)
+        D.test_dqn_convs_identity_like_weights_asymmetric()
+    finally:
+        del os.environ["RLPYT_DQN_CONV23_T32"]
 
 
 @case("dqn_pack_weights_kernel", "dqn_conv23_kernel<32, 25, 19, 4, 4, 2, 128, false>",
