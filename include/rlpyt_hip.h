@@ -40,7 +40,7 @@ typedef void* rlpyt_stream_t; /* hipStream_t */
 const char* rlpyt_hip_last_error(void);
 /* ABI version of this header (3); bumped when a signature, an entry point or a workspace layout
  * changes, so that a stale .so fails the binding's version check instead of an attribute lookup. */
-#define RLPYT_HIP_ABI_VERSION 16
+#define RLPYT_HIP_ABI_VERSION 17
 int rlpyt_hip_abi_version(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0. */
 int rlpyt_hip_device_info(char* name, int cap);
@@ -678,6 +678,27 @@ int rlpyt_replay_step_fields(const int64_t* action, const float* reward, const u
                              float* out_return, uint8_t* out_done, uint8_t* out_done_n,
                              int64_t* tgt_prev_action, float* tgt_prev_reward,
                              rlpyt_stream_t stream);
+
+/* Replay append in one launch (ABI 17) -- BaseNStepReturnBuffer.append_samples' slice assignments
+ * (rlpyt/replays/n_step.py:60-83: samples[idxs] = ...) and FrameBufferMixin.append_samples
+ * (rlpyt/replays/frame.py:39-59) for T new time steps at ring row `start` of a [ring_T, B] ring,
+ * T <= ring_T, rows wrapping at ring_T:
+ *   field f:  ring_f[(start + t) % ring_T] = src_f[t]         (row_bytes = B * item bytes each);
+ *   frames (nullable together with obs): frames u8 [ring_T + C - 1, B, frame_bytes], obs u8
+ *     [T, B, C, frame_bytes]:  frames[C - 1 + (start + t) % ring_T, b] = obs[t, b, C - 1];
+ *     start == 0: frames[f, b] = obs[0, b, f] for f < C - 1 (history of row 0);
+ *     else if (start + T) % ring_T <= start (the lap closed): frames[j] = frames[ring_T + j] for
+ *     j < C - 1, read AFTER the newest-frame writes (`<=`: DESIGN section 3's stated deviation
+ *     from the strict `<` of frame.py:57 when an append of exactly ring_T rows lands on its start).
+ * `fields` is a HOST array.  Pure byte moves, one writer per destination byte: bit-exact. */
+typedef struct rlpyt_append_field {
+  void* ring;
+  const void* src;
+  int64_t row_bytes;
+} rlpyt_append_field;
+int rlpyt_replay_append(const rlpyt_append_field* fields, int n_fields, const uint8_t* obs,
+                        uint8_t* frames, int64_t frame_bytes, int C, int64_t T, int64_t B,
+                        int64_t start, int64_t ring_T, rlpyt_stream_t stream);
 
 /* NStepFrameBuffer.extract_observation -- rlpyt/replays/non_sequence/frame.py:14-30.
  * frames u8 [T+C-1, B, H*W]; done u8 [T,B]; obs[i,c,:] = frames[t_i+c, b_i, :], then for

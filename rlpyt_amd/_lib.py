@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must precede the CDLL load; see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (RLPYT_HIP_LIB: another build of the same ABI, for A/B runs of two kernel versions on one box)
 LIB_PATH = os.environ.get("RLPYT_HIP_LIB") or os.path.join(_HERE, "csrc", "librlpyt_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class CopyDesc(ctypes.Structure):
@@ -35,6 +35,11 @@ class StepGroup(ctypes.Structure):
                 ("obs_host", c_void_p), ("row_bytes", c_int64), ("t_host", c_void_p),
                 ("graph_exec", c_void_p),
                 ("stream", c_void_p), ("event", c_void_p), ("tail_graph_exec", c_void_p)]
+
+
+class AppendField(ctypes.Structure):
+    """Mirror of ``rlpyt_append_field`` (include/rlpyt_hip.h)."""
+    _fields_ = [("ring", c_void_p), ("src", c_void_p), ("row_bytes", c_int64)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -172,6 +177,7 @@ _SIGNATURES = {
                                             _p, _p]),
     "rlpyt_gather_rows": (c_int, [_p, _p, _p, _p, c_int, c_int64, c_int64, c_int64, _p]),
     "rlpyt_replay_step_fields": (c_int, [_p] * 7 + [c_int64, c_int, c_int64, c_int] + [_p] * 9),
+    "rlpyt_replay_append": (c_int, [_p, c_int, _p, _p, c_int64, c_int] + [c_int64] * 4 + [_p]),
     "rlpyt_frames_gather": (c_int, [_p, _p, _p, _p, _p, c_int64, c_int, c_int64, c_int, c_int64,
                                     _p]),
     "rlpyt_frames_gather_seq": (c_int, [_p, _p, _p, _p, _p, c_int64, c_int, c_int, c_int64,

@@ -1494,6 +1494,70 @@ def replay_step_fields(action, reward, done, return_, done_n, t_idx, b_idx, n_st
     return pa, pr, a, r, d, dn, tpa, tpr
 
 
+class ReplayAppender:
+    """``T`` new time steps into a replay ring in one launch (``rlpyt_replay_append``:
+    rlpyt/replays/n_step.py:60-83 and rlpyt/replays/frame.py:39-59).
+
+    ``rings``: the stored fields ``[ring_T, B, ...]`` (contiguous device tensors); ``frames`` (uint8
+    ``[ring_T + C - 1, B, *img]``): the unique-frame store, written from a ``[T, B, C, *img]``
+    observation with its history / mirror rows.  The field table (ring pointers, row sizes) is
+    built once; a call fills in the source pointers."""
+
+    def __init__(self, rings, ring_T, B, frames=None, n_frames=1):
+        _lib.require_gpu()
+        self.rings, self.ring_T, self.B = list(rings), int(ring_T), int(B)
+        self.table = (_lib.AppendField * max(1, len(self.rings)))()
+        for k, ring in enumerate(self.rings):
+            assert ring.shape[0] == self.ring_T and ring.shape[1] == self.B
+            self.table[k].ring = ptr(ring).value
+            self.table[k].row_bytes = _row_bytes(ring, 1)
+        self._row_elems = [_row_bytes(ring, 1) // ring.element_size() for ring in self.rings]
+        self.frames, self.C, self.frame_bytes = frames, 1, 0
+        if frames is not None:
+            self.C = int(n_frames)
+            assert frames.dtype == torch.uint8 and frames.shape[1] == self.B
+            assert frames.shape[0] == self.ring_T + self.C - 1
+            self.frame_bytes = _row_bytes(frames, 2)
+        self._frames_ptr = ptr(frames)
+        self._tail = (self.frame_bytes, self.C)
+
+    @staticmethod
+    def _ready(new, like):
+        """``new`` as a contiguous device tensor of the ring's dtype (what a slice assignment would
+        convert it to)."""
+        if not isinstance(new, torch.Tensor):
+            new = torch.as_tensor(new)
+        if new.device != like.device or new.dtype != like.dtype:
+            new = new.to(device=like.device, dtype=like.dtype, non_blocking=True)
+        return new if new.is_contiguous() else new.contiguous()
+
+    def __call__(self, news, start, observation=None):
+        keep = []                         # converted leaves stay alive until the launch is enqueued
+        T = None
+        table = self.table
+        for k, (ring, new) in enumerate(zip(self.rings, news)):
+            if not (new.__class__ is torch.Tensor and new.dtype is ring.dtype and new.is_cuda
+                    and new.is_contiguous()):
+                new = self._ready(new, ring)
+                keep.append(new)
+            T = new.shape[0] if T is None else T
+            assert new.numel() == T * self._row_elems[k], \
+                f"replay append: field {k}: {tuple(new.shape)} into ring {tuple(ring.shape)}"
+            table[k].src = new.data_ptr()
+        obs_ptr = None
+        if self.frames is not None:
+            if not (observation.__class__ is torch.Tensor and observation.dtype is torch.uint8
+                    and observation.is_cuda and observation.is_contiguous()):
+                observation = self._ready(observation, self.frames)
+            T = observation.shape[0] if T is None else T
+            assert tuple(observation.shape[:3]) == (T, self.B, self.C) and \
+                observation.shape[3:] == self.frames.shape[2:]
+            obs_ptr = ctypes.c_void_p(observation.data_ptr())
+        check(lib.rlpyt_replay_append(self.table, len(self.rings), obs_ptr, self._frames_ptr,
+                                      self.frame_bytes, self.C, int(T), self.B, int(start),
+                                      self.ring_T, stream()), "rlpyt_replay_append")
+
+
 def frames_gather(frames, done, t_idx, b_idx, n_frames, out=None):
     """NStepFrameBuffer.extract_observation (replays/non_sequence/frame.py:14-30).
 

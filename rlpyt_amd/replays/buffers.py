@@ -15,14 +15,19 @@ target inputs (``rlpyt_frames_gather[_pair|_seq]``), the small-field gathers
 (``rlpyt_gather_rows`` / ``rlpyt_gather_sequences``) and the importance weights are kernels; the
 only host -> device traffic per batch is its ``n`` float64 uniforms (``np.random.rand``, so that a
 seeded run draws the reference's stream)."""
+import os
+
 import torch
 
 from .. import ops
 from ..agents.base import AgentInputs
-from ..utils.buffer import buffer_func, get_leading_dims
+from ..utils.buffer import buffer_func, buffer_leaves, buffer_pairs, get_leading_dims
 from ..utils.collections import namedarraytuple
 from .index import PriorityDraw, UniformDraw
 from .store import FieldRing, FrameStore, RingCursor, RnnStateStore, as_index
+
+# (RLPYT_REPLAY_APPEND=0: the slice assignments of replays/store.py on the device too, for A/B runs)
+ONE_LAUNCH_APPEND = os.environ.get("RLPYT_REPLAY_APPEND", "1") != "0"
 
 StepBatch = namedarraytuple("SamplesFromReplay", ["agent_inputs", "action", "return_", "done",
                                                   "done_n", "target_inputs"])
@@ -43,6 +48,7 @@ class ReplayBuffer:
     FRAMES = SEQUENCE = PRIORITIZED = False
     async_ = False
     TREE_CLS = None         # sum-tree class of prioritized buffers (None: ops.DeviceSumTree)
+    _appender = None        # ops.ReplayAppender over this buffer's rings, built at the first append
 
     def _build(self, example, size, B, discount=1, n_step_return=1, device=None,
                rnn_state_interval=0, batch_T=None, alpha=0.6, beta=0.4, default_priority=1,
@@ -63,6 +69,7 @@ class ReplayBuffer:
         cur = self.cursor = RingCursor(size, B, guard_back=n_step_return, guard_fwd=1, device=dev)
         self.T, self.size = cur.T, cur.T * B
         self.fields = FieldRing(stored, cur, discount, n_step_return)
+        self._flat_record = all(isinstance(x, torch.Tensor) for x in self.fields.data)
         self.frame_store = FrameStore(example.observation, cur) if self.FRAMES else None
         if self.frame_store is not None:
             cur.guard_fwd = max(cur.guard_fwd, self.frame_store.guard_fwd)
@@ -99,17 +106,41 @@ class ReplayBuffer:
         priorities = None
         if hasattr(samples, "priorities"):
             priorities, samples = samples.priorities, samples.samples
-        T, B = get_leading_dims(samples, n_dim=2)
+        news = None
+        if self._flat_record:       # every stored field is one array: no walk over the record
+            news = [getattr(samples, f) for f in self._stored_fields]
+            T, B = news[0].shape[:2]
+        else:
+            T, B = get_leading_dims(samples, n_dim=2)
         assert B == self.B
         claim = self.cursor.claim(T)
-        stored = type(self.fields.data)(*(getattr(samples, f) for f in self._stored_fields))
-        self.fields.write(stored, claim)
-        if self.frame_store is not None:
-            self.frame_store.write(samples.observation, claim)
+        if self.device.type == "cuda" and T <= self.T and ONE_LAUNCH_APPEND:
+            if news is None:
+                stored = type(self.fields.data)(*(getattr(samples, f) for f in self._stored_fields))
+                news = [new for _, new in buffer_pairs(self.fields.data, stored)]
+            self._append_one_launch(news, samples, claim)
+        else:       # host tensors (tests/test_host_logic.py) or an append longer than a lap
+            stored = type(self.fields.data)(*(getattr(samples, f) for f in self._stored_fields))
+            self.fields.write(stored, claim)
+            if self.frame_store is not None:
+                self.frame_store.write(samples.observation, claim)
         if self.rnn_store is not None:
             self.rnn_store.write(samples.prev_rnn_state, claim)
         self.draws.on_append(claim, self.cursor.t, priorities)
         return T, claim.rows
+
+    def _append_one_launch(self, news, samples, claim):
+        """Fields (``news``: one array per ring leaf) + newest frames + history / mirror rows of an
+        append as ONE kernel (``rlpyt_replay_append``) instead of a slice assignment per leaf, then
+        the n-step refresh."""
+        fs = self.frame_store
+        if self._appender is None:
+            self._appender = ops.ReplayAppender(
+                buffer_leaves(self.fields.data), self.T, self.B,
+                frames=None if fs is None else fs.frames, n_frames=1 if fs is None else fs.C)
+        self._appender(news, claim.start, None if fs is None else samples.observation)
+        if self.fields.n_step > 1:
+            self.fields._refresh_returns(claim)
 
     def sample_batch(self, batch_B, batch_T=None):
         if self.SEQUENCE:

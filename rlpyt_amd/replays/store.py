@@ -77,8 +77,7 @@ class FieldRing:
 
     def write(self, samples, claim):
         dev = self.cursor.device
-        self.data[claim.rows] = type(samples)(
-            *(None if leaf is None else on_device(leaf, dev) for leaf in samples))
+        self.data[claim.rows] = buffer_func(samples, on_device, dev)
         if self.n_step > 1:
             self._refresh_returns(claim)
 

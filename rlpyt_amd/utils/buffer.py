@@ -106,6 +106,13 @@ def buffer_func(buf, func, *args, **kwargs):
     return _map(lambda x: func(x, *args, **kwargs), buf)
 
 
+def buffer_pairs(buf, other):
+    """``(leaf, matching leaf of other)`` for every non-None leaf of ``buf`` (same structure)."""
+    out = []
+    _map(lambda a, b: out.append((a, b)), buf, other)
+    return out
+
+
 def get_leading_dims(buf, n_dim=1):
     """Leading dims of the first leaf; asserts all leaves agree."""
     leaves = []

@@ -81,6 +81,15 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert b"H must be 256 or 512" in lib.rlpyt_hip_last_error()
     assert lib.rlpyt_q_head_f32(p, 8, p, p, p, 4, 512, 19, p, None) != OK
     assert lib.rlpyt_q_head_f32(p, 8, p, p, p, 4, 384, 6, p, None) != OK
+    # replay append in one launch (ABI 17)
+    fld = (_lib.AppendField * 1)()
+    assert lib.rlpyt_replay_append(None, 0, None, None, 0, 1, 0, 4, 0, 10, None) == OK      # T = 0
+    assert lib.rlpyt_replay_append(None, 1, None, None, 0, 1, 2, 4, 0, 10, None) != OK
+    assert b"null field table" in lib.rlpyt_hip_last_error()
+    assert lib.rlpyt_replay_append(fld, 1, None, None, 0, 1, 2, 4, 0, 10, None) != OK       # null ring
+    assert lib.rlpyt_replay_append(None, 0, None, None, 0, 1, 11, 4, 0, 10, None) != OK     # > one lap
+    assert b"at most one lap" in lib.rlpyt_hip_last_error()
+    assert lib.rlpyt_replay_append(None, 0, p, None, 8, 4, 2, 4, 0, 10, None) != OK         # obs w/o frames
     # the head inside an update (ABI 16)
     assert lib.rlpyt_q_head_train_f32(p, 8, p, p, p, 4, 384, 6, p, p, None) != OK
     assert lib.rlpyt_q_head_bwd_f32(None, p, p, 4, 512, 6, p, p, p, p, None) != OK

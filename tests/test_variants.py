@@ -665,6 +665,13 @@ def _q_head_bwd():
     D.test_mlp_q_head_under_autograd_matches_torch(7, 48, 256, 1)
 
 
+@case("replay_append_kernel")
+def _replay_append():
+    import test_replay_append_gpu as A
+    for shape in ((4, 104, 80, 16, False), (4, 3, 2, 2, True), (3, 7, 5, 3, False)):
+        A.test_one_launch_append_equals_the_slice_assignments(shape)
+
+
 @case("replay_step_fields_kernel")
 def _replay_step_fields():
     """One-launch field gather of a single-step replay batch vs the row-by-row gathers + selects it
