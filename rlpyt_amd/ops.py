@@ -790,9 +790,18 @@ class _LinearNoBias(torch.autograd.Function):
     autograd): forward ``gemm_nt(x, W)``, input gradient ``gemm_nt(g, W^T copy)``, weight gradient
     ``gemm_tn(g, x)``.  No vendor GEMM."""
 
+    # gemm_nt runs one 128 x 128 tile per CU and has no K split: below ~200 tiles (R2D1's trunk FC at
+    # 2 560 - 5 440 rows: 80 - 172 tiles x 216 K steps) the chip is part empty for the whole contraction
+    # and the library's smaller tiles are as fast or faster (300 vs 286 - 319 us); both gradient GEMMs
+    # have thousands of tiles / eight K chunks at those sizes and stay on the own kernels
+    MIN_FORWARD_TILES = 200
+
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        tiles = -(-x.shape[0] // 128) * -(-weight.shape[0] // 128)
+        if tiles < _LinearNoBias.MIN_FORWARD_TILES:
+            return torch.nn.functional.linear(x, weight.detach())
         return gemm_nt(x, weight.detach())
 
     @staticmethod
@@ -1358,7 +1367,7 @@ class _MlpQHeadTrain(torch.autograd.Function):
         check(lib.rlpyt_q_head_bwd_f32(ptr(dq), ptr(h), ptr(w2), n, K, A, ptr(dw2), ptr(db2), ptr(dh),
                                        ptr(db1), stream()), "rlpyt_q_head_bwd_f32")
         dx = dh @ w1 if ctx.needs_input_grad[0] else None
-        dw1 = dh.t() @ x
+        dw1 = dh.t() @ x      # (gemm_tn here measured neutral: profiles/r6_ab_q_head_wgrad_tn.jsonl)
         return dx, dw1, db1, dw2, db2
 
 

@@ -115,7 +115,7 @@ def test_ppo_minibatch_at_bench_size_product_vs_miopen_vs_f64():
     os.environ["RLPYT_TRUNK_FUSION"] = "0"
     try:
         model.use_fused_conv = False
-        model.use_split_gemm = False
+        model.use_split_gemm = model.conv.head.use_split_gemm = False
         algo_u = PPO(ratio_clip=CLIP, value_loss_coeff=VC, entropy_loss_coeff=EC,
                      fused_head_loss=False)
         algo_u.agent = agent
@@ -134,6 +134,7 @@ def test_ppo_minibatch_at_bench_size_product_vs_miopen_vs_f64():
         os.environ.pop("RLPYT_TRUNK_FUSION", None)
         model.use_fused_conv = True
         model.use_split_gemm = AtariFfModel.use_split_gemm
+        del model.conv.head.use_split_gemm
 
     # ---- (3) float64 -------------------------------------------------------------------------
     import copy

@@ -554,6 +554,41 @@ def test_linear_nobias_autograd(ops):
     _close(w.grad, w64.grad, rel=3e-6, what="linear_nobias dw")
 
 
+@pytest.mark.parametrize("rows", [2560, 1088])
+def test_mlp_model_update_size_rows_on_the_split_gemms(ops, rows):
+    """MlpModel at update-size row counts (R2D1's trunk FC 6912 -> 512 at 2 560 - 5 440 rows,
+    rlpyt/models/mlp.py:24-31 as the head of rlpyt/models/conv2d.py:88-118): Linear layers on
+    gemm_nt / gemm_tn under autograd and without, against the same modules in float64; the library
+    path (RLPYT_MLP_GEMM=0 / fewer rows) held to the same bound beside it."""
+    from rlpyt_amd import _lib
+    from rlpyt_amd.models.mlp import MlpModel
+    torch.manual_seed(5)
+    mlp = MlpModel(6912, [512]).cuda()
+    ref = MlpModel(6912, [512]).double().cuda()
+    ref.load_state_dict({k: v.double() for k, v in mlp.state_dict().items()})
+    g = torch.Generator().manual_seed(8)
+    x64 = torch.randn(rows, 6912, generator=g, dtype=torch.float64).cuda().requires_grad_(True)
+    gy = torch.randn(rows, 512, generator=g, dtype=torch.float64).cuda()
+    y64 = ref.model(x64)
+    (y64 * gy).sum().backward()
+    x = x64.detach().float().requires_grad_(True)
+    _lib.variant_reset()
+    y = mlp(x)
+    (y * gy.float()).sum().backward()
+    counts = _lib.variant_counts()
+    assert any(k.startswith("gemm_nt_x6_kernel") for k in counts) and "gemm_tn_x6_kernel" in counts, counts
+    # (forward: 80 / 36 tiles of 128 x 128 -> the library's GEMM, ops._LinearNoBias.MIN_FORWARD_TILES)
+    lin, lin64 = mlp.model[0], ref.model[0]
+    for what, a, d in (("y", y, y64), ("dx", x.grad, x64.grad), ("dW", lin.weight.grad, lin64.weight.grad),
+                       ("db", lin.bias.grad, lin64.bias.grad)):
+        _close(a, d, rel=5e-6, what=f"MlpModel wide {what}")
+    with torch.no_grad():
+        lib_y = mlp.model(x.detach())                     # the library's f32 path
+    err_own = (y.detach().double() - y64).abs().max().item()
+    err_lib = (lib_y.double() - y64).abs().max().item()
+    assert err_own <= 2 * err_lib + 1e-6, (err_own, err_lib)
+
+
 def _check_conv2_bwd_tail(y1, y2, g2, w2, dy1, n):
     """dy1 of the LAST n images against a float64 evaluation of conv2's backward-data pass."""
     M = y1.shape[0]
