@@ -854,9 +854,9 @@ def pmc_traffic(name, g):
         rel = os.path.relpath(path, ROOT)
         return {"bytes_per_launch": k["hbm_bytes_corrected"] * scale,
                 "traffic_over_alg": k.get("traffic_over_alg"),
-                "source": f"{rel} @ {doc.get('commit') or 'unstamped'} (rocprofv3 --pmc FETCH_SIZE / "
-                          "WRITE_SIZE passes over scripts/conv_bench.py / scripts/gemm_bench.py, "
-                          "M=8192; scripts/pmc_update.sh)"}
+                "source": rel + (f" @ {doc['commit']}" if doc.get("commit") else "") + " (" +
+                          (doc.get("note") or "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each; "
+                                              "scripts/pmc_update.sh").split(";")[0] + ")"}
     return None
 
 
@@ -1426,9 +1426,9 @@ def replay_config_main(args):
                          traffic=None if traffic is None else traffic["bytes_per_launch"],
                          traffic_over_alg=None if traffic is None else traffic["traffic_over_alg"],
                          traffic_source=None if traffic is None else traffic["source"],
-                         note="the replay kernel of this config (SURVEY 8(d)); the step's time is in "
-                              "the model's MIOpen / hipBLASLt kernels: profiles/r3_" + args.config +
-                              "_kernel_stats.csv"),
+                         note="the replay kernel of this config (SURVEY 8(d)); where the iteration's "
+                              "device time goes, kernel by kernel: profiles/r6_" + args.config +
+                              "_region_final.txt (timed-region statistics of this command)"),
         "roofline_replay": replay,
         "last_loss": (info.loss[-1] if info.loss else None),
     }

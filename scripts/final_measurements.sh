@@ -3,14 +3,16 @@
 #   whole GPU suite, the three bench lines (ppo / dqn / r2d1), rocprofv3 kernel trace of the ppo bench,
 #   PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) over the update's kernels and the rollout-step kernels,
 #   timed-region kernel statistics of the three lines.
-# usage: scripts/final_measurements.sh [tag=r5]      -> gpurun_out/<tag>_final/
+# usage: [SKIP_TESTS=1] scripts/final_measurements.sh [tag=r6]      -> gpurun_out/<tag>_final/
 TAG=${1:-r6}
 OUT=$PWD/gpurun_out/${TAG}_final
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
+if [ -z "$SKIP_TESTS" ]; then      # (SKIP_TESTS=1: the suite was run on this tree in its own call)
 timeout 1500 python -m pytest tests -m gpu -q --timeout 420 -p no:cacheprovider > $OUT/gpu_tests.log 2>&1
 echo "pytest rc=$?" >> $OUT/gpu_tests.log
 tail -4 $OUT/gpu_tests.log
+fi
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_ppo.json 2> $OUT/bench_ppo.err
 timeout 500 python bench.py --config dqn > $OUT/bench_dqn.json 2> $OUT/bench_dqn.err
 timeout 600 python bench.py --config r2d1 > $OUT/bench_r2d1.json 2> $OUT/bench_r2d1.err

@@ -70,7 +70,7 @@ def test_bench_gpus2_same_gpu_runs_two_ranks():
 def test_pmc_traffic_reads_the_committed_counters():
     """``bench.pmc_traffic`` (the ``roofline.traffic`` of the driver line) finds every region of the
     update and both replay gathers in the newest committed ``profiles/r*pmc_counters.json``, rescales
-    by algorithmic bytes and carries the commit of the PMC pass in its source string."""
+    by algorithmic bytes and names the file (+ its commit stamp when it has one) in its source string."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
@@ -84,7 +84,7 @@ def test_pmc_traffic_reads_the_committed_counters():
         t = bench.pmc_traffic(name, {"alg_bytes_per_launch": alg})
         assert t is not None, name
         assert 0.9 * alg < t["bytes_per_launch"] < 3.0 * alg, (name, t)
-        assert "profiles/r" in t["source"] and "@" in t["source"], t["source"]
+        assert "profiles/r" in t["source"] and "rocprofv3 --pmc" in t["source"], t["source"]
         half = bench.pmc_traffic(name, {"alg_bytes_per_launch": alg // 2})
         assert abs(half["bytes_per_launch"] * 2 - t["bytes_per_launch"]) <= 2 + 1e-6 * t["bytes_per_launch"]
     assert bench.pmc_traffic("no_such_region", {"alg_bytes_per_launch": 1}) is None
