@@ -8,6 +8,7 @@ everything after the network outputs -- action / double-DQN target selection, va
 h / h^-1, n-step target, (Huber) TD loss, IS weights, the ``valid`` mask, ``dL/dq`` and the
 sequence priorities eta*max + (1-eta)*mean -- is ONE kernel (``rlpyt_r2d1_loss_fwd_bwd_f32``).
 Input priorities of fresh samples (r2d1.py:181-242) are computed on the device as well."""
+import os
 from collections import namedtuple
 
 import torch
@@ -27,6 +28,13 @@ class R2D1(DQN):
     OptInfoCls = OptInfo
     SEQUENCE_REPLAY = True
     CAPTURABLE = False      # sequence batches: three outputs of ``loss``, kernel-bound updates
+    # double DQN's action-selection pass (r2d1.py:300-303: the ONLINE network, no grad, over the batch_T +
+    # n_step steps behind the warm-up, from the warmed-up state) repeats the training pass on its first
+    # batch_T steps -- same weights, same inputs, same initial state.  True: take those q-values from
+    # the training pass and run only the n_step steps behind it from the state the training pass ends in
+    # (one pass of the whole network over batch_T x B fewer steps per update); False: the reference's
+    # statement sequence.
+    share_online_pass = os.environ.get("RLPYT_R2D1_SHARE_ONLINE", "1") != "0"
 
     def __init__(self, discount=0.997, batch_T=80, batch_B=64, warmup_T=40,
                  store_rnn_state_interval=40, min_steps_learn=int(1e5), delta_clip=None,
@@ -129,13 +137,20 @@ class R2D1(DQN):
                 target_rnn_state = buffer_method(target_rnn_state, "mul", keep)
         else:
             target_rnn_state = init_rnn_state
-        qs, _ = self.agent(*inputs(agent_slice), init_rnn_state)               # [bT, B, A]
+        qs, end_rnn_state = self.agent(*inputs(agent_slice), init_rnn_state)   # [bT, B, A]
         with torch.no_grad():
             target_qs, _ = self.agent.target(*inputs(target_slice), target_rnn_state)
             next_qs = None
             if self.double_dqn:
-                next_qs, _ = self.agent(*inputs(target_slice), init_rnn_state)
-                next_qs = next_qs[-bT:]
+                n_tail = all_observation.shape[0] - (wT + bT)      # = n_step_return
+                if self.share_online_pass and 0 < n_tail <= bT and end_rnn_state is not None:
+                    # steps [n_tail, bT) of the training pass + the n_tail steps behind it
+                    tail_qs, _ = self.agent(*inputs(slice(wT + bT, None)),
+                                            buffer_method(end_rnn_state, "detach"))
+                    next_qs = torch.cat([qs.detach()[n_tail:], tail_qs.to(qs.dtype)])
+                else:
+                    next_qs, _ = self.agent(*inputs(target_slice), init_rnn_state)
+                    next_qs = next_qs[-bT:]
             target_qs = target_qs[-bT:]
         valid = ops.valid_from_done(samples.done[wT:].contiguous())
         is_weights = samples.is_weights if self.prioritized_replay else None

@@ -310,11 +310,14 @@ def test_dqn_captured_update_graph_equals_eager_updates(case, monkeypatch):
         np.testing.assert_allclose(x["root"], y["root"], rtol=1e-6)   # f64 sums of f32-noise priorities
 
 
-def test_r2d1_iterations_match_reference():
+@pytest.mark.parametrize("share", [True, False], ids=["shared_online_pass", "reference_passes"])
+def test_r2d1_iterations_match_reference(share, monkeypatch):
     """R2D1.optimize_agent (input priorities, sequence replay with stored LSTM states, warm-up +
     training passes, fused loss / priorities kernel, target updates) vs the reference's own run
-    with its AtariR2d1Agent on CPU (small fc / LSTM sizes, full-size conv stack).  Conv and LSTM
-    run through MIOpen here; tolerances as for the DQN iterations."""
+    with its AtariR2d1Agent on CPU (small fc / LSTM sizes, full-size conv stack); tolerances as for
+    the DQN iterations.  Both with double DQN's action-selection pass taken from the training pass +
+    the n_step steps behind it (``R2D1.share_online_pass``, the default) and with the reference's
+    statement sequence (a second pass of the online network over batch_T + n_step steps)."""
     from collections import namedtuple
     from rlpyt_amd.agents.dqn.r2d1_agent import AgentInfo, AtariR2d1Agent
     from rlpyt_amd.algos.dqn.r2d1 import R2D1
@@ -322,6 +325,7 @@ def test_r2d1_iterations_match_reference():
     from rlpyt_amd.models.dqn.atari_r2d1_model import RnnState
     from rlpyt_amd.samplers.collections import BatchSpec
     from rlpyt_amd.spaces import IntBox
+    monkeypatch.setattr(R2D1, "share_online_pass", share)
     g = load_golden("r2d1_iterations")
     spaces = EnvSpaces(observation=IntBox(0, 256, shape=(4, 104, 80), dtype="uint8"),
                        action=IntBox(0, C.A))
@@ -369,3 +373,11 @@ def test_r2d1_iterations_match_reference():
         t_sums = C.param_stats([p.cpu() for p in agent.target_model.parameters()])[1]
         np.testing.assert_allclose(t_sums, g[f"r2d1_itr{itr}_target_abs_sums"], rtol=2e-4)
     assert algo.update_counter == int(g["r2d1_update_counter"])
+    # the two statement sequences on ONE drawn batch: the shared pass computes the same q-values once
+    batch = algo.replay_buffer.sample_batch(algo.batch_B)
+    outs = []
+    for mode in (True, False):
+        monkeypatch.setattr(R2D1, "share_online_pass", mode)
+        outs.append([x.detach().double().cpu() for x in algo.loss(batch)])
+    for a, b_, name in zip(outs[0], outs[1], ("loss", "td_abs_errors", "priorities")):
+        torch.testing.assert_close(a, b_, rtol=1e-5, atol=1e-6, msg=lambda m: f"{name}: {m}")
