@@ -338,18 +338,24 @@ def main():
     wt0 = None if wt is None else wt.copy()
     sync()
     trace_marker(args)
+    cg0 = cgroup_cpu_stat()
     t0 = time.perf_counter()
     t_sample = 0.
+    itr_starts, episodes_done = [], []
     for k in range(args.steps):
         itr = args.warmup + k
         ts = time.perf_counter()
+        itr_starts.append(ts)
         agent.sample_mode(itr)
         samples, _infos = sampler.obtain_samples(itr)
         t_sample += time.perf_counter() - ts
+        episodes_done.append(len(_infos))
         agent.train_mode(itr)
         opt_info = algo.optimize_agent(itr, samples)
     sync()
     elapsed = time.perf_counter() - t0
+    host_quota = cgroup_cpu_delta(cg0, cgroup_cpu_stat(), elapsed, itr_starts + [t0 + elapsed])
+    host_quota["episodes_completed"] = episodes_done[:64]
     trace_marker(args)
     # ---- phase-timing leg: where an iteration's time goes.  In the timed region optimize_agent hands
     # back diagnostics whose copy to the host is still in flight (utils/deferred.py) and nothing reads
@@ -523,6 +529,7 @@ def main():
                        "env_step_cost_us": args.env_cost_us, "host_cores": ncpu,
                        "host_cpu_quota": cpus,
                        "parallelism": f"dp{world}"},
+            "host_quota_in_timed_region": host_quota,
             "sampling_frac_of_step": t_sample / (ph_elapsed if ph_elapsed > 0 else 1.),
             "phase_timing": f"sampling_frac_of_step and the sampler object: {ph_steps} iterations after "
                             "the timed region with the diagnostics read back inside optimize_agent "
@@ -835,6 +842,37 @@ def dry_run(args, rank, world, local_rank, cpus, workers, block):
                           "dry_run": True, "value": None, "n_gpus": n, "backend": backend,
                           "rccl_version": _rccl_version(), "host_cpu_quota": cpus,
                           "ranks": ranks}), flush=True)
+
+
+def cgroup_cpu_stat():
+    """cpu.stat of this process's cgroup (v2), or None."""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            t = f.read().split()
+        return {t[i]: int(t[i + 1]) for i in range(0, len(t) - 1, 2)}
+    except (OSError, ValueError):
+        return None
+
+
+def cgroup_cpu_delta(a, b, elapsed_s, marks):
+    """What the box's CPU quota did to the timed region: CPU-seconds used, enforcement periods, periods in
+    which the cgroup was THROTTLED (all of its threads -- env workers, the serve loop, the launching thread --
+    frozen until the period ends) and the longest / median host-side iteration, so that a line whose value is
+    low because the host was frozen for part of it can be told from one that is slow."""
+    raw = [y - x for x, y in zip(marks[:-1], marks[1:])]
+    gaps = sorted(raw)
+    out = {"iteration_ms_median": round(gaps[len(gaps) // 2] * 1e3, 3) if gaps else None,
+           "iteration_ms_max": round(gaps[-1] * 1e3, 3) if gaps else None,
+           "iteration_ms": [round(g * 1e3, 1) for g in raw[:64]]}
+    if a is None or b is None:
+        out["cpu_stat"] = None
+        return out
+    d = {k: b[k] - a.get(k, 0) for k in b}
+    out.update(cpu_seconds_used=round(d.get("usage_usec", 0) / 1e6, 3),
+               cpus_busy_mean=round(d.get("usage_usec", 0) / 1e6 / elapsed_s, 2) if elapsed_s > 0 else None,
+               periods=d.get("nr_periods"), throttled_periods=d.get("nr_throttled"),
+               throttled_usec_sum_over_cpus=d.get("throttled_usec"))
+    return out
 
 
 def pmc_traffic(name, g):
