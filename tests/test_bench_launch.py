@@ -90,6 +90,28 @@ def test_pmc_traffic_reads_the_committed_counters():
     assert bench.pmc_traffic("no_such_region", {"alg_bytes_per_launch": 1}) is None
 
 
+def test_cgroup_cpu_delta_reports_throttling_and_iteration_spread():
+    """``bench.cgroup_cpu_delta`` (the line's ``host_quota_in_timed_region``): CPU-seconds, enforcement and
+    throttled periods between two ``cpu.stat`` readings, median / longest host-side iteration; without a
+    cgroup-v2 ``cpu.stat`` the iteration times are still there."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = dict(usage_usec=1_000_000, nr_periods=10, nr_throttled=1, throttled_usec=5_000)
+    b = dict(usage_usec=9_000_000, nr_periods=17, nr_throttled=3, throttled_usec=45_000)
+    marks = [0.0, 0.030, 0.070, 0.100, 0.160]
+    d = bench.cgroup_cpu_delta(a, b, 0.8, marks)
+    assert d["cpu_seconds_used"] == 8.0 and d["cpus_busy_mean"] == 10.0
+    assert d["periods"] == 7 and d["throttled_periods"] == 2 and d["throttled_usec_sum_over_cpus"] == 40_000
+    assert d["iteration_ms"] == [30.0, 40.0, 30.0, 60.0]
+    assert d["iteration_ms_max"] == 60.0 and d["iteration_ms_median"] == 40.0
+    d0 = bench.cgroup_cpu_delta(None, b, 0.8, marks)
+    assert d0["cpu_stat"] is None and d0["iteration_ms_max"] == 60.0
+    st = bench.cgroup_cpu_stat()
+    assert st is None or "usage_usec" in st
+
+
 def test_trace_region_cuts_a_kernel_trace_to_the_marked_region(tmp_path):
     """scripts/trace_region.py: dispatches between the two ``erfinv`` markers of ``bench.py
     --trace-markers``, per-kernel statistics and the device-busy share (union of the intervals)."""
