@@ -70,3 +70,21 @@ print("rollout kernels (per phase):")
 for k, (c, t) in sorted(per_kernel.items(), key=lambda x: -x[1][1])[:16]:
     print(f"  {k:60s} {c / n_roll:7.1f} x {t / c / 1e3:6.1f} us = {t / n_roll / 1e6:.3f} ms")
 print("rollout kernel time by queue:", {q: round(t / n_roll / 1e6, 3) for q, t in queues.items()})
+
+# idle gaps inside the update phases: where the device waits for the host (kernel before -> kernel after)
+gaps = defaultdict(lambda: [0, 0])
+tot_gap = 0
+for (ws, we) in wins[:-1]:
+    ks = [(s, e, n) for s, e, n, q in rows if s >= ws and e <= we]
+    end, prev = ks[0][1], ks[0][2]
+    for s, e, n in ks[1:]:
+        if s > end:
+            key = (prev.split("(")[0][-38:], n.split("(")[0][-38:])
+            gaps[key][0] += 1; gaps[key][1] += s - end
+            tot_gap += s - end
+        if e > end:
+            end, prev = e, n
+n_upd = len(wins) - 1
+print(f"update: idle {tot_gap / n_upd / 1e6:.3f} ms per phase; largest gap classes (per phase):")
+for (a, b), (c, t) in sorted(gaps.items(), key=lambda x: -x[1][1])[:14]:
+    print(f"  {a:38s} -> {b:38s} {c / n_upd:6.1f} x {t / c / 1e3:7.1f} us = {t / n_upd / 1e6:.3f} ms")
