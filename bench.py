@@ -341,7 +341,7 @@ def main():
     cg0 = cgroup_cpu_stat()
     t0 = time.perf_counter()
     t_sample = 0.
-    itr_starts, episodes_done = [], []
+    itr_starts, episodes_done, sampling_s = [], [], []
     for k in range(args.steps):
         itr = args.warmup + k
         ts = time.perf_counter()
@@ -349,6 +349,7 @@ def main():
         agent.sample_mode(itr)
         samples, _infos = sampler.obtain_samples(itr)
         t_sample += time.perf_counter() - ts
+        sampling_s.append(time.perf_counter() - ts)
         episodes_done.append(len(_infos))
         agent.train_mode(itr)
         opt_info = algo.optimize_agent(itr, samples)
@@ -356,6 +357,8 @@ def main():
     elapsed = time.perf_counter() - t0
     host_quota = cgroup_cpu_delta(cg0, cgroup_cpu_stat(), elapsed, itr_starts + [t0 + elapsed])
     host_quota["episodes_completed"] = episodes_done[:64]
+    # (host clock around obtain_samples: includes the wait for the previous iteration's updates the host ran ahead of)
+    host_quota["obtain_samples_ms"] = [round(x * 1e3, 1) for x in sampling_s[:64]]
     trace_marker(args)
     # ---- phase-timing leg: where an iteration's time goes.  In the timed region optimize_agent hands
     # back diagnostics whose copy to the host is still in flight (utils/deferred.py) and nothing reads
