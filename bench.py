@@ -612,7 +612,7 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_configs(args, timeout_s=600):
+def extra_configs(args, timeout_s=300):
     """BASELINE configs #3 (DQN) and #5 (R2D1) under the same clock as the headline (VERDICT r5 item
     6): each is a child ``python bench.py --config <c>`` run AFTER the PPO measurement is over (its
     sampler shut down, nothing of it timed any more), with that config's own default steps / warmup
